@@ -1,0 +1,151 @@
+"""CPU suite: the NumPy oracle replayed against the committed reference fixtures.
+
+The fixtures in tests/golden/ are outputs of the imported reference (tools/gen_golden.py);
+this is what pins the oracle wherever /root/reference is absent."""
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden_names, load_golden
+from oracle import integrators as orc
+from oracle import models as mdl
+
+
+@pytest.mark.parametrize("name", golden_names("euclid"))
+def test_euclid_leapfrog(name):
+    g = load_golden(name)
+    n, d = g["q0"].shape
+    target = mdl.target_from_id(g["target"], g["target_params"], d)
+    mk = int(g["metric_kind"])
+    metric = None if mk == mdl.METRIC_IDENTITY else g["metric"]
+    system = orc.EuclidSystem(target, mk, metric)
+    h = float(g["step_size"])
+    for k, s in enumerate(g["checkpoints"]):
+        for c in range(n):
+            q, p = orc.leapfrog_steps(system, g["q0"][c], g["p0"][c], g["dir"][c] * h, int(s))
+            assert_close(q, g["q_out"][k, c], 1e-13 * max(1, s), f"{name} q@{s}")
+            assert_close(p, g["p_out"][k, c], 1e-13 * max(1, s), f"{name} p@{s}")
+            assert_close(system.h(q, p), g["h_out"][k, c], 1e-12, f"{name} h@{s}")
+        qb, pb = orc.leapfrog_steps_batch(system, g["q0"], g["p0"], g["dir"] * h, int(s))
+        assert_close(qb, g["q_out"][k], 1e-12 * max(1, s), f"{name} batch q@{s}")
+        assert_close(pb, g["p_out"][k], 1e-12 * max(1, s), f"{name} batch p@{s}")
+
+
+def _riemann_system(g, counters=None):
+    n, d = g["q0"].shape
+    target = mdl.target_from_id(g["target"], g["target_params"], d)
+    mid = int(g["rmetric"])
+    if mid == mdl.RMETRIC_SOFTABS:
+        return orc.RiemannianSystem(target, None, float(g["rmetric_params"][0]), counters)
+    return orc.RiemannianSystem(target, mdl.rmetric_from_id(mid, g["rmetric_params"], d), None,
+                                counters)
+
+
+def _riemann_kwargs(g):
+    norm = orc.NORMS[int(g["norm"])]
+    return dict(
+        fp_solver=orc.FP_SOLVERS[int(g["fp_solver"])], rev_norm=norm,
+        fp_kwargs=dict(norm=norm, convergence_tol=float(g["fp_conv_tol"]),
+                       divergence_tol=float(g["fp_div_tol"]), max_iters=int(g["fp_max_iters"])),
+    )
+
+
+RIEMANN = [n for n in golden_names() if n.startswith(("riemann", "softabs"))]
+
+
+@pytest.mark.parametrize("name", RIEMANN)
+def test_implicit_leapfrog(name):
+    g = load_golden(name)
+    if g["q0"].shape[1] > 64:
+        cps = [(0, int(g["checkpoints"][0]))]  # keep the CPU suite fast: first checkpoint only
+    else:
+        cps = list(enumerate(int(s) for s in g["checkpoints"]))
+    counters = orc.Counters()
+    system = _riemann_system(g, counters)
+    kw = _riemann_kwargs(g)
+    h = float(g["step_size"])
+    tol = 1e-9 if name.startswith("softabs") else 2e-11
+    n = g["q0"].shape[0]
+    s_max = int(g["checkpoints"].max())
+    with np.errstate(all="ignore"):
+        for c in range(n):
+            for k, s in cps:
+                q, p, st, nd = orc.implicit_leapfrog_steps(
+                    system, g["q0"][c], g["p0"][c], g["dir"][c] * h, s, **kw)
+                assert_close(q, g["q_out"][k, c], tol, f"{name} q@{s} chain {c}")
+                assert_close(p, g["p_out"][k, c], tol, f"{name} p@{s} chain {c}")
+                if s == s_max:
+                    assert st == g["status"][c]
+                    assert nd == g["n_done"][c]
+    if len(cps) == len(g["checkpoints"]):
+        counters.clear()
+        with np.errstate(all="ignore"):
+            for c in range(n):
+                orc.implicit_leapfrog_steps(system, g["q0"][c], g["p0"][c], g["dir"][c] * h,
+                                            s_max, **kw)
+        assert counters.get("fp_iters", 0) == int(g["count_fp_iters"])
+
+
+@pytest.mark.parametrize("name", golden_names("constrained"))
+def test_constrained_leapfrog(name):
+    g = load_golden(name)
+    n, d = g["q0"].shape
+    target = mdl.target_from_id(g["target"], g["target_params"], d)
+    constraint = mdl.constr_from_id(g["constr"], g["constr_params"])
+    mk = int(g["metric_kind"])
+    metric = None if mk == mdl.METRIC_IDENTITY else g["metric"]
+    system = orc.ConstrainedSystem(target, constraint, mk, metric)
+    h = float(g["step_size"])
+    s_max = int(g["checkpoints"].max())
+    for c in range(n):
+        for k, s in enumerate(int(s) for s in g["checkpoints"]):
+            q, p, st, nd = orc.constrained_leapfrog_steps(
+                system, g["q0"][c], g["p0"][c], g["dir"][c] * h, s, n_inner_step=int(g["n_inner"]))
+            assert_close(q, g["q_out"][k, c], 1e-10, f"{name} q@{s} chain {c}")
+            assert_close(p, g["p_out"][k, c], 1e-10, f"{name} p@{s} chain {c}")
+            if s == s_max:
+                assert st == g["status"][c]
+                assert nd == g["n_done"][c]
+
+
+# ---- the reference's own solver known-answer tests (tests/test_solvers.py:36, 65-121) ----------------
+@pytest.mark.parametrize("solver", [orc.solve_fixed_point_direct, orc.solve_fixed_point_steffensen])
+@pytest.mark.parametrize("norm", [orc.maximum_norm, orc.euclidean_norm])
+@pytest.mark.parametrize("tol", [1e-6, 1e-8, 1e-10])
+def test_fixed_point_known_answers(solver, norm, tol):
+    x = solver(np.cos, np.array([1.0]), convergence_tol=tol, norm=norm)
+    assert abs(x[0] - 0.7390851332151607) < 10 * tol  # tests/test_solvers.py:36
+    x = solver(lambda y: 0.5 * (y + 2.0 / y), np.array([1.0]), convergence_tol=tol, norm=norm)
+    assert abs(x[0] - 2.0**0.5) < 10 * tol  # Babylonian square root
+
+
+@pytest.mark.parametrize("solver", [orc.solve_fixed_point_direct, orc.solve_fixed_point_steffensen])
+def test_fixed_point_failures(solver):
+    # the reference's divergent problems (tests/test_solvers.py:47-55, 83-92): only the class of
+    # the failure is pinned there; the direct solver must report divergence
+    # (with float input Steffensen's extrapolation lands exactly on the fixed point 0 of the
+    # doubling map - checked against the imported reference - so only direct sees it diverge)
+    funcs = [lambda x: 1 + x**2]
+    if solver is orc.solve_fixed_point_direct:
+        funcs.append(lambda x: 2 * x)
+    for func in funcs:
+        with np.errstate(all="ignore"), pytest.raises(orc.ConvergenceError) as e:
+            solver(func, np.arange(3, dtype=np.float64), max_iters=10000)
+        assert e.value.status == orc.ST_DIVERGED
+    with pytest.raises(orc.ConvergenceError) as e:
+        solver(np.cos, np.array([1.0]), max_iters=1)
+    assert e.value.status == orc.ST_MAX_ITERS
+
+    def bad(x):
+        raise ValueError("boom")
+
+    with pytest.raises(orc.ConvergenceError) as e:
+        solver(bad, np.array([1.0]))
+    assert e.value.status == orc.ST_SOLVER_LINALG
+
+    def bad2(x):
+        raise orc.LinAlgError("boom")
+
+    with pytest.raises(orc.ConvergenceError) as e:
+        solver(bad2, np.array([1.0]))
+    assert e.value.status == orc.ST_SOLVER_LINALG

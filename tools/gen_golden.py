@@ -1,0 +1,384 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the IMPORTED reference (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--out tests/golden]
+
+The reference (``/root/reference/src``) is imported here and ONLY here; it never travels.
+For every case the same closed-form model (``oracle/models.py``) is pushed through
+  (1) the reference's own System + Integrator classes, one chain at a time, and
+  (2) the NumPy restatement in ``oracle/integrators.py``,
+the two are asserted equal (this is what pins the oracle), and the reference's inputs and
+outputs are written as a small fixture: model parameters, (q0, p0, dir, step_size), the state
+after each checkpointed number of steps, Hamiltonian values, per-chain status / completed
+steps and the reference's call counters.  Fixtures are data only - no reference source.
+"""
+
+from __future__ import annotations
+
+import argparse
+import collections
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/src")
+
+import mici  # noqa: E402  (the reference)
+from mici import errors as merr  # noqa: E402
+from mici.states import ChainState  # noqa: E402
+
+from oracle import integrators as orc  # noqa: E402
+from oracle import models as mdl  # noqa: E402
+
+SEED = 3046987125  # reference tests/test_integrators.py:8
+
+
+def status_of(exc):
+    msg = str(exc)
+    if isinstance(exc, merr.NonReversibleStepError):
+        return orc.ST_NON_REVERSIBLE
+    if isinstance(exc, merr.ConvergenceError):
+        if "diverged" in msg:
+            return orc.ST_DIVERGED
+        if "did not converge" in msg:
+            return orc.ST_MAX_ITERS
+        return orc.ST_SOLVER_LINALG
+    if isinstance(exc, merr.LinAlgError):
+        return orc.ST_LINALG
+    raise exc
+
+
+def safe_h(system, state):
+    try:
+        with np.errstate(all="ignore"):
+            return system.h(state)
+    except (merr.LinAlgError, ValueError):
+        return np.nan
+
+
+def run_reference(integrator, system, q0, p0, dirs, checkpoints):
+    """Step every chain with the reference; freeze a chain at its last good state on failure."""
+    n, d = q0.shape
+    n_max = max(checkpoints)
+    q_out = np.zeros((len(checkpoints), n, d))
+    p_out = np.zeros((len(checkpoints), n, d))
+    h_out = np.zeros((len(checkpoints), n))
+    h0 = np.zeros(n)
+    status = np.zeros(n, dtype=np.int32)
+    n_done = np.zeros(n, dtype=np.int32)
+    counts = collections.Counter()
+    for c in range(n):
+        cc = collections.Counter()
+        state = ChainState(pos=q0[c].copy(), mom=p0[c].copy(), dir=int(dirs[c]), _call_counts=cc)
+        h0[c] = safe_h(system, state)
+        cc.clear()
+        for s in range(1, n_max + 1):
+            if status[c] == 0:
+                try:
+                    state = integrator.step(state)
+                    n_done[c] = s
+                except (merr.IntegratorError, merr.LinAlgError) as e:
+                    status[c] = status_of(e)
+            if s in checkpoints:
+                k = checkpoints.index(s)
+                q_out[k, c], p_out[k, c] = state.pos, state.mom
+                h_out[k, c] = safe_h(system, state.copy())
+        for key, val in cc.items():
+            key = key[0] if isinstance(key, tuple) else key
+            counts[str(key).split(".")[-1]] += val
+    return dict(q_out=q_out, p_out=p_out, h0=h0, h_out=h_out, status=status, n_done=n_done), counts
+
+
+def check_close(name, a, b, rtol, atol=0.0):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), f"{name}: NaN pattern differs"
+    a, b = np.nan_to_num(a, nan=0.0), np.nan_to_num(b, nan=0.0)
+    err = np.max(np.abs(a - b) / (atol + rtol * np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+    if not err <= 1.0:
+        raise AssertionError(f"{name}: oracle differs from reference (scaled err {err:.3g})")
+
+
+# ---------------------------------------------------------------------------------------------
+def euclid_case(name, target, metric_kind, metric, q0, p0, dirs, h, checkpoints):
+    if metric_kind == mdl.METRIC_IDENTITY:
+        ref_metric = None
+    else:
+        ref_metric = np.array(metric)
+    system = mici.systems.EuclideanMetricSystem(
+        neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad, metric=ref_metric
+    )
+    integrator = mici.integrators.LeapfrogIntegrator(system, h)
+    ref, counts = run_reference(integrator, system, q0, p0, dirs, checkpoints)
+    osys = orc.EuclidSystem(target, metric_kind, metric)
+    for k, s in enumerate(checkpoints):
+        for c in range(q0.shape[0]):
+            q, p = orc.leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, s)
+            check_close(f"{name} q@{s}", q, ref["q_out"][k, c], 1e-13 * max(1, s))
+            check_close(f"{name} p@{s}", p, ref["p_out"][k, c], 1e-13 * max(1, s))
+            check_close(f"{name} h@{s}", np.array(osys.h(q, p)), ref["h_out"][k, c], 1e-12)
+        qb, pb = orc.leapfrog_steps_batch(osys, q0, p0, dirs * h, s)
+        check_close(f"{name} batch q@{s}", qb, ref["q_out"][k], 1e-12 * max(1, s))
+        check_close(f"{name} batch p@{s}", pb, ref["p_out"][k], 1e-12 * max(1, s))
+    return dict(
+        kind="euclid", target=target.tid, target_params=target.params(), metric_kind=metric_kind,
+        metric=np.zeros(0) if metric is None else np.asarray(metric), q0=q0, p0=p0, dir=dirs,
+        step_size=h, checkpoints=np.array(checkpoints), **ref,
+    ), counts
+
+
+def riemann_case(name, target, rmetric, softabs_coeff, q0, p0, dirs, h, checkpoints,
+                 fp_solver=0, norm=0, fp_kwargs=None):
+    fp_kwargs = fp_kwargs or {}
+    if softabs_coeff is None:
+        system = mici.systems.DenseRiemannianMetricSystem(
+            neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+            metric_func=rmetric.metric_func, vjp_metric_func=rmetric.vjp_metric_func,
+        )
+    else:
+        system = mici.systems.SoftAbsRiemannianMetricSystem(
+            neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+            hess_neg_log_dens=target.hess, mtp_neg_log_dens=target.mtp,
+            softabs_coeff=softabs_coeff,
+        )
+    ref_solvers = {0: mici.solvers.solve_fixed_point_direct,
+                   1: mici.solvers.solve_fixed_point_steffensen}
+    ref_norms = {0: mici.solvers.maximum_norm, 1: mici.solvers.euclidean_norm}
+    ref_kwargs = dict(fp_kwargs)
+    ref_kwargs["norm"] = ref_norms[norm]
+    iters = collections.Counter()
+
+    def counting_solver(func, x0, **kw):
+        def f(x):
+            iters["fp_iters"] += 1
+            return func(x)
+        iters["fp_solves"] += 1
+        return ref_solvers[fp_solver](f, x0, **kw)
+
+    integrator = mici.integrators.ImplicitLeapfrogIntegrator(
+        system, h, fixed_point_solver=counting_solver, fixed_point_solver_kwargs=ref_kwargs,
+        reverse_check_norm=ref_norms[norm],
+    )
+    ref, counts = run_reference(integrator, system, q0, p0, dirs, checkpoints)
+    counts.update(iters)
+    # oracle cross-check
+    ocount = orc.Counters()
+    osys = orc.RiemannianSystem(target, rmetric, softabs_coeff, ocount)
+    okw = dict(fp_solver=orc.FP_SOLVERS[fp_solver], rev_norm=orc.NORMS[norm],
+               fp_kwargs=dict(fp_kwargs, norm=orc.NORMS[norm]))
+    n_max = max(checkpoints)
+    for c in range(q0.shape[0]):
+        for k, s in enumerate(checkpoints):
+            q, p, st, nd = orc.implicit_leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, s, **okw)
+            tol = 2e-11 if softabs_coeff is None else 1e-9
+            check_close(f"{name} q@{s} chain {c}", q, ref["q_out"][k, c], tol)
+            check_close(f"{name} p@{s} chain {c}", p, ref["p_out"][k, c], tol)
+            if s == n_max:
+                assert st == ref["status"][c], (name, c, st, ref["status"][c])
+                assert nd == ref["n_done"][c], (name, c, nd, ref["n_done"][c])
+    # iteration counts must agree exactly when summed over the max-checkpoint run
+    ocount.clear()
+    for c in range(q0.shape[0]):
+        orc.implicit_leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, n_max, **okw)
+    assert ocount.get("fp_iters", 0) == counts["fp_iters"], (name, dict(ocount), dict(counts))
+    n_fact = counts.get("metric", 0)
+    # (the reference run has the initial metric cached by the h0 evaluation: one per chain)
+    assert ocount.get("metric", 0) == n_fact + q0.shape[0], (name, dict(ocount), dict(counts))
+    return dict(
+        kind="riemann", target=target.tid, target_params=target.params(),
+        rmetric=(mdl.RMETRIC_SOFTABS if softabs_coeff is not None else rmetric.mid),
+        rmetric_params=(np.array([softabs_coeff]) if softabs_coeff is not None
+                        else rmetric.params()),
+        q0=q0, p0=p0, dir=dirs, step_size=h, checkpoints=np.array(checkpoints),
+        fp_solver=fp_solver, norm=norm,
+        fp_conv_tol=fp_kwargs.get("convergence_tol", 1e-9),
+        fp_div_tol=fp_kwargs.get("divergence_tol", 1e10),
+        fp_max_iters=fp_kwargs.get("max_iters", 100),
+        **ref,
+    ), counts
+
+
+def constrained_case(name, target, constraint, metric_kind, metric, q0, p0, dirs, h,
+                     checkpoints, n_inner=1):
+    ref_metric = None if metric_kind == mdl.METRIC_IDENTITY else np.array(metric)
+    system = mici.systems.DenseConstrainedEuclideanMetricSystem(
+        neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+        constr=constraint.constr, jacob_constr=constraint.jacob_constr, metric=ref_metric,
+    )
+    integrator = mici.integrators.ConstrainedLeapfrogIntegrator(system, h, n_inner_step=n_inner)
+    ref, counts = run_reference(integrator, system, q0, p0, dirs, checkpoints)
+    osys = orc.ConstrainedSystem(target, constraint, metric_kind, metric)
+    n_max = max(checkpoints)
+    for c in range(q0.shape[0]):
+        for k, s in enumerate(checkpoints):
+            q, p, st, nd = orc.constrained_leapfrog_steps(
+                osys, q0[c], p0[c], dirs[c] * h, s, n_inner_step=n_inner)
+            check_close(f"{name} q@{s} chain {c}", q, ref["q_out"][k, c], 1e-10)
+            check_close(f"{name} p@{s} chain {c}", p, ref["p_out"][k, c], 1e-10)
+            if s == n_max:
+                assert st == ref["status"][c], (name, c, st, ref["status"][c])
+                assert nd == ref["n_done"][c], (name, c, nd, ref["n_done"][c])
+    return dict(
+        kind="constrained", target=target.tid, target_params=target.params(),
+        constr=constraint.cid, constr_params=constraint.params(), metric_kind=metric_kind,
+        metric=np.zeros(0) if metric is None else np.asarray(metric), q0=q0, p0=p0, dir=dirs,
+        step_size=h, checkpoints=np.array(checkpoints), n_inner=n_inner, **ref,
+    ), counts
+
+
+def project_momentum(osys, q, p):
+    out = np.empty_like(p)
+    for c in range(q.shape[0]):
+        out[c] = osys.project_onto_cotangent_space(p[c].copy(), osys.constraint.jacob_constr(q[c]))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    rng = np.random.default_rng(SEED)
+    cases = {}
+
+    def dirs_for(n):
+        d = np.ones(n, dtype=np.int8)
+        d[1::3] = -1
+        return d
+
+    # ---- explicit leapfrog, Euclidean metric (BASELINE configs c1 / c2) -------------------------
+    def add_euclid(name, target, mk, metric, n, h, cps):
+        d = target.dim
+        q0 = rng.standard_normal((n, d))
+        z = rng.standard_normal((n, d))
+        osys = orc.EuclidSystem(target, mk, metric)
+        p0 = np.stack([osys.msqrt(zz) for zz in z])
+        cases[name] = lambda: euclid_case(name, target, mk, metric, q0, p0, dirs_for(n), h, cps)
+
+    add_euclid("euclid_c1_iso_d32", mdl.GaussIso(32), mdl.METRIC_IDENTITY, None, 4, 0.1, [1, 5, 20])
+    prec128 = np.exp(-0.2 * rng.standard_normal(128))
+    add_euclid("euclid_c2_diag_d128", mdl.GaussDiag(prec128), mdl.METRIC_IDENTITY, None, 8, 0.05,
+               [1, 5, 100])
+    add_euclid("euclid_c2_diag_diagmetric_d128", mdl.GaussDiag(prec128), mdl.METRIC_DIAG,
+               np.exp(0.1 * rng.standard_normal(128)), 8, 0.05, [1, 5, 100])
+    P128 = mdl.make_spd(128, rng)
+    add_euclid("euclid_c2_dense_d128", mdl.GaussDense(P128), mdl.METRIC_IDENTITY, None, 8, 0.05,
+               [1, 5, 20, 100])
+    add_euclid("euclid_c2_dense_densemetric_d128", mdl.GaussDense(P128), mdl.METRIC_DENSE, P128,
+               8, 0.05, [1, 5, 100])
+    P20 = mdl.make_spd(20, rng)
+    add_euclid("euclid_dense_d20_ragged", mdl.GaussDense(P20), mdl.METRIC_DENSE,
+               mdl.make_spd(20, rng), 5, 0.1, [1, 7])
+    for size in (1, 2, 5):  # the reference's own test sizes (tests/test_integrators.py:20-22)
+        eigval = np.exp(0.1 * rng.standard_normal(size))
+        eigvec = np.linalg.qr(rng.standard_normal((size, size)))[0]
+        dense = (eigvec * eigval) @ eigvec.T
+        add_euclid(f"euclid_quartic_dense_d{size}", mdl.Poly(size, 0.0, 1.0), mdl.METRIC_DENSE,
+                   dense, 5, 0.05, [1, 5, 20])
+        add_euclid(f"euclid_quadratic_diag_d{size}", mdl.Poly(size, 1.0, 0.0), mdl.METRIC_DIAG,
+                   eigval, 5, 0.25, [1, 5, 20])
+    add_euclid("euclid_banana_d16", mdl.Banana(16), mdl.METRIC_IDENTITY, None, 4, 0.02, [1, 10])
+
+    # ---- implicit leapfrog, dense Riemannian metric (c3a, c4) -----------------------------------------
+    def add_riemann(name, target, rmetric, coeff, n, h, cps, qscale=1.0, **kw):
+        d = target.dim
+        q0 = qscale * rng.standard_normal((n, d))
+        z = rng.standard_normal((n, d))
+        osys = orc.RiemannianSystem(target, rmetric, coeff)
+        p0 = np.stack([osys.sample_momentum(orc._State(q0[c], None), z[c]) for c in range(n)])
+        cases[name] = lambda: riemann_case(name, target, rmetric, coeff, q0, p0, dirs_for(n), h,
+                                           cps, **kw)
+
+    B64 = mdl.make_spd(64, rng)
+    add_riemann("riemann_c3_rank1_banana_d64", mdl.Banana(64), mdl.Rank1Metric(B64), None, 6,
+                0.02, [1, 5, 20])
+    add_riemann("riemann_rank1_poly_d64", mdl.Poly(64, 1.0, 1.0 / 3.0), mdl.Rank1Metric(B64),
+                None, 4, 0.05, [1, 10])
+    B8 = mdl.make_spd(8, rng)
+    add_riemann("riemann_rank1_poly_d8", mdl.Poly(8, 1.0, 1.0 / 3.0), mdl.Rank1Metric(B8), None,
+                6, 0.1, [1, 5, 20])
+    add_riemann("riemann_rank1_poly_d8_l2_steffensen", mdl.Poly(8, 1.0, 1.0 / 3.0),
+                mdl.Rank1Metric(B8), None, 6, 0.1, [1, 5], fp_solver=1, norm=1)
+    for size in (1, 2, 5):  # dense twin of tests/test_integrators.py:492-516
+        add_riemann(f"riemann_diagquad_poly_d{size}", mdl.Poly(size, 1.0, 1.0 / 3.0),
+                    mdl.DiagQuadMetric(size), None, 5, 0.1, [1, 5, 20])
+    B256 = mdl.make_spd(256, rng)
+    add_riemann("riemann_c4_rank1_banana_d256", mdl.Banana(256), mdl.Rank1Metric(B256), None, 2,
+                0.01, [1, 3])
+    # failure paths: large steps / tiny iteration budgets
+    add_riemann("riemann_fail_bigstep_d8", mdl.Poly(8, 1.0, 1.0 / 3.0), mdl.Rank1Metric(B8), None,
+                8, 1.5, [1, 4], qscale=2.0)
+    add_riemann("riemann_fail_maxiters_d8", mdl.Poly(8, 1.0, 1.0 / 3.0), mdl.Rank1Metric(B8), None,
+                6, 0.3, [1, 3], fp_kwargs=dict(max_iters=3))
+    add_riemann("riemann_fail_diagquad_d5", mdl.Poly(5, 1.0, 1.0 / 3.0), mdl.DiagQuadMetric(5), None,
+                8, 1.2, [1, 4], qscale=2.0)
+
+    add_riemann("riemann_fail_mixed_rank1_d8", mdl.Poly(8, 1.0, 1.0 / 3.0), mdl.Rank1Metric(B8),
+                None, 12, 0.6, [1, 3, 6], qscale=2.0)
+    add_riemann("riemann_fail_mixed_diagquad_d5", mdl.Poly(5, 1.0, 1.0 / 3.0),
+                mdl.DiagQuadMetric(5), None, 12, 0.3, [1, 3, 6], qscale=2.0)
+
+    def add_nonfinite():
+        name = "riemann_fail_nonfinite_d8"
+        q0 = rng.standard_normal((4, 8))
+        p0 = rng.standard_normal((4, 8))
+        q0[1, :] = 1e200      # metric overflows -> "Array is not finite" outside a solver
+        q0[2, 3] = np.nan     # NaN position -> same
+        cases[name] = lambda: riemann_case(name, mdl.Poly(8, 1.0, 1.0 / 3.0), mdl.Rank1Metric(B8),
+                                           None, q0, p0, dirs_for(4), 0.1, [1, 3])
+    add_nonfinite()
+
+    # ---- SoftAbs (c3b) ------------------------------------------------------------------------------
+    add_riemann("softabs_c3_funnel_d64", mdl.Funnel(np.linspace(0.5, 2.0, 63)), None, 1.0, 3,
+                0.02, [1, 4])
+    add_riemann("softabs_funnel_d8", mdl.Funnel(np.linspace(0.5, 2.0, 7)), None, 1.0, 6,
+                0.05, [1, 5, 20])
+    add_riemann("softabs_poly_d5", mdl.Poly(5, 1.0, 1.0 / 3.0), None, 1.0, 5, 0.1, [1, 5, 20])
+
+    # ---- constrained leapfrog (c5 + the reference's own constrained test systems) ------------------
+    def add_constrained(name, target, constraint, mk, metric, q0, h, cps, n_inner=1):
+        n, d = q0.shape
+        z = rng.standard_normal((n, d))
+        osys = orc.ConstrainedSystem(target, constraint, mk, metric)
+        p0 = project_momentum(osys, q0, np.stack([osys.msqrt(zz) for zz in z]))
+        cases[name] = lambda: constrained_case(name, target, constraint, mk, metric, q0, p0,
+                                               dirs_for(n), h, cps, n_inner)
+
+    add_constrained("constrained_c5_torus", mdl.Torus(), mdl.TorusConstr(), mdl.METRIC_IDENTITY,
+                    None, mdl.torus_init(16, rng), 0.1, [1, 5, 20, 100])
+    add_constrained("constrained_torus_inner2", mdl.Torus(), mdl.TorusConstr(),
+                    mdl.METRIC_IDENTITY, None, mdl.torus_init(6, rng), 0.2, [1, 10], n_inner=2)
+    add_constrained("constrained_torus_fail_bigstep", mdl.Torus(), mdl.TorusConstr(),
+                    mdl.METRIC_IDENTITY, None, mdl.torus_init(16, rng), 1.2, [1, 5])
+    for size in (2, 5):  # tests/test_integrators.py:519-565
+        eigval = np.exp(0.1 * rng.standard_normal(size))
+        eigvec = np.linalg.qr(rng.standard_normal((size, size)))[0]
+        dense = (eigvec * eigval) @ eigvec.T
+        theta = rng.uniform(size=5) * 2 * np.pi
+        qc = np.concatenate([np.cos(theta)[:, None], np.sin(theta)[:, None],
+                             rng.standard_normal((5, size - 2))], 1)
+        add_constrained(f"constrained_circle_dense_d{size}", mdl.Poly(size, 0.0, 0.5),
+                        mdl.CircleConstr(), mdl.METRIC_DENSE, dense, qc, 0.1, [1, 5, 20])
+        add_constrained(f"constrained_circle_diag_d{size}", mdl.Poly(size, 0.0, 0.5),
+                        mdl.CircleConstr(), mdl.METRIC_DIAG, eigval, qc.copy(), 0.1, [1, 5, 20])
+        ql = np.concatenate([np.zeros((5, 1)), rng.standard_normal((5, size - 1))], 1)
+        add_constrained(f"constrained_linear_dense_d{size}", mdl.Poly(size, 1.0, 0.0),
+                        mdl.FirstCoordConstr(), mdl.METRIC_DENSE, dense, ql, 0.1, [1, 5, 20])
+
+    all_counts = {}
+    for name, fn in cases.items():
+        if args.only and args.only not in name:
+            continue
+        data, counts = fn()
+        np.savez_compressed(os.path.join(args.out, name + ".npz"),
+                            **{f"count_{k}": v for k, v in counts.items()}, **data)
+        all_counts[name] = dict(counts)
+        print(f"{name}: ok  status={data['status'].tolist()} n_done={data['n_done'].tolist()} "
+              f"counts={dict(counts)}")
+
+
+if __name__ == "__main__":
+    main()
