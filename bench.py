@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""bench.py - leapfrog-steps/sec (all chains) of the MI355X integrator hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2iv|c3|c5] [--traj-len L]
+
+Contract (driver): W untimed warm-up passes, then EXACTLY K timed passes bracketed by a barrier +
+device synchronise on both sides; the maximum over ranks is the job time; rank 0 prints ONE JSON
+line.  A "step" of the bench is one pass of the hot path over one batch of synthetic input: one
+call of the C-ABI entry point integrating a trajectory of L leapfrog steps for every chain of the
+rank's shard (L = the trajectory length SURVEY.md section 8d quotes for the config).  `value` is
+leapfrog steps (Integrator.step equivalents) per second summed over all chains and ranks, with the
+inputs resident in HBM when the timed region starts; failed chains count only completed steps.
+
+Default (N=1) workload = BASELINE.json configs[1] (c2): EuclideanMetricSystem, dense-precision
+Gaussian target, D=128, 4096 chains per GPU, identity metric, explicit leapfrog h=0.05, L=1000.
+Multi-GPU: chains are sharded (weak scaling: 4096 chains per GPU), no collective during
+integration, one RCCL all-gather of positions per trajectory (= trace collection).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_MFMA_PEAK_TF = 78.6   # MI355X dense FP64 matrix peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+
+
+def make_workload(config, n_chains, rng):
+    """Synthetic inputs of SURVEY.md section 8d.  Returns dict with the device system, integrator
+    factory args, initial state, the oracle twin and the algorithmic work per chain-step."""
+    from mici_amd import integrators, models, systems
+    from oracle import integrators as orc
+    from oracle import models as omdl
+
+    if config in ("c2", "c2i", "c2iv"):
+        dim, h, traj = 128, 0.05, 1000
+        if config == "c2i":
+            target, otarget = models.GaussIso(dim), omdl.GaussIso(dim)
+            metric = None
+            flops = 8.0 * dim
+            name = "c2(i) iso-Gaussian"
+        else:
+            P = omdl.make_spd(dim, rng)
+            target, otarget = models.GaussDense(P), omdl.GaussDense(P)
+            metric = P if config == "c2iv" else None
+            flops = 2.0 * dim * dim * (2 if config == "c2iv" else 1) + 8.0 * dim
+            name = "c2(iv) dense-Gaussian + dense metric" if config == "c2iv" else \
+                "c2(iii) dense-precision Gaussian"
+        system = systems.EuclideanMetricSystem(target, metric=metric)
+        mk = 0 if metric is None else 2
+        osys = orc.EuclidSystem(otarget, mk, metric)
+        integ = integrators.LeapfrogIntegrator(system, h)
+        q0 = rng.standard_normal((n_chains, dim))
+        z = rng.standard_normal((n_chains, dim))
+        p0 = z if metric is None else z @ np.linalg.cholesky(metric).T
+        return dict(name=f"{name}, EuclideanMetricSystem + LeapfrogIntegrator", dim=dim, h=h,
+                    traj=traj, integ=integ, system=system, osys=osys, q0=q0, p0=p0,
+                    bytes_per_chain_step=32.0 * dim, flops_per_chain_step=flops,
+                    bound="hbm" if config == "c2i" else "mfma", kind="euclid")
+    raise SystemExit(f"unknown --config {config}")
+
+
+def cpu_baseline(w, budget_s=20.0):
+    """The NumPy oracle (vectorised over chains, BLAS threads as configured) timed on a bounded
+    sample of the same workload on this box's host cores."""
+    from oracle import integrators as orc
+
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    n, steps = w["q0"].shape[0], 20
+    t0 = time.perf_counter()
+    orc.leapfrog_steps_batch(w["osys"], w["q0"], w["p0"], w["h"], steps)
+    dt = time.perf_counter() - t0
+    # scale the sample to ~budget_s of CPU work, capped at the real trajectory length
+    steps2 = int(min(w["traj"], max(steps, steps * budget_s / max(dt, 1e-6))))
+    t0 = time.perf_counter()
+    orc.leapfrog_steps_batch(w["osys"], w["q0"], w["p0"], w["h"], steps2)
+    dt = time.perf_counter() - t0
+    value = n * steps2 / dt
+    # reference-style figure: one chain at a time on one core
+    t0 = time.perf_counter()
+    n1 = 0
+    while time.perf_counter() - t0 < 2.0:
+        orc.leapfrog_steps(w["osys"], w["q0"][n1 % n], w["p0"][n1 % n], w["h"], 100)
+        n1 += 1
+    single = n1 * 100 / (time.perf_counter() - t0)
+    return dict(value=value, unit="leapfrog-steps/s", cores=int(cores), kind="port",
+                sample=f"oracle.leapfrog_steps_batch (NumPy, vectorised over chains): {n} chains x "
+                       f"{steps2} steps of the same workload in {dt:.1f} s",
+                single_chain_1core=single)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2")
+    ap.add_argument("--chains-per-gpu", type=int, default=None)
+    ap.add_argument("--traj-len", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    dist = None
+    if world > 1:
+        import torch  # plumbing only: rendezvous, barrier, max-over-ranks (CPU tensors over gloo)
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    from mici_amd import _ffi
+    from mici_amd.runtime import Context, DeviceBatch
+
+    ctx = Context(local_rank)
+    n_local = args.chains_per_gpu or 4096
+    rng = np.random.default_rng(1234 + rank)
+    w = make_workload(args.config, n_local, rng)
+    traj = args.traj_len or w["traj"]
+    integ = w["integ"]
+
+    batch = DeviceBatch(ctx, n_local, w["dim"])
+    dirs = np.ones(n_local, dtype=np.int8)
+
+    # optional RCCL communicator for the per-trajectory trace gather
+    comm = None
+    gather_mode = "none"
+    pos_all = None
+    if world > 1:
+        import ctypes as C
+        import torch
+
+        gather_mode = os.environ.get("MICI_AMD_BENCH_GATHER", "rccl")
+        if gather_mode == "rccl":
+            try:
+                idbuf = torch.zeros(_ffi.MM_COMM_ID_BYTES, dtype=torch.uint8)
+                if rank == 0:
+                    raw = (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)()
+                    _ffi.check(ctx._lib.mm_comm_unique_id(raw), None, "mm_comm_unique_id")
+                    idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+                dist.broadcast(idbuf, src=0)
+                raw = (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)(*idbuf.tolist())
+                h = C.c_void_p()
+                _ffi.check(ctx._lib.mm_comm_create(ctx.handle, world, rank, raw, C.byref(h)),
+                           ctx.handle, "mm_comm_create")
+                comm = h
+                pos_all = np.empty((world * n_local, w["dim"]))
+            except Exception as e:  # keep the scaling run alive, but say so in the JSON line
+                print(f"[bench] RCCL gather unavailable ({e}); falling back to host gather",
+                      file=sys.stderr)
+                gather_mode = "gloo-host"
+
+    def one_pass():
+        integ.step_device(batch, traj, ctx)
+        if world > 1:
+            if comm is not None:
+                _ffi.check(ctx._lib.mm_comm_allgather_pos(
+                    comm, batch.handle, pos_all.ctypes.data_as(_ffi.c_double_p)), ctx.handle,
+                    "mm_comm_allgather_pos")
+            elif gather_mode == "gloo-host":
+                import torch
+                q, _, _ = batch.download()
+                out = [torch.empty_like(torch.from_numpy(q)) for _ in range(world)]
+                dist.all_gather(out, torch.from_numpy(q))
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    batch.upload(w["q0"], w["p0"], dirs)
+    for _ in range(args.warmup):
+        one_pass()
+    batch.upload(w["q0"], w["p0"], dirs)  # timed region starts from the same resident state
+
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for k in range(args.steps):
+        ctx.record(0)
+        integ.step_device(batch, traj, ctx)
+        ctx.record(1)
+        if world > 1:
+            # trace collection once per trajectory
+            if comm is not None:
+                _ffi.check(ctx._lib.mm_comm_allgather_pos(
+                    comm, batch.handle, pos_all.ctypes.data_as(_ffi.c_double_p)), ctx.handle,
+                    "mm_comm_allgather_pos")
+            elif gather_mode == "gloo-host":
+                import torch
+                q, _, _ = batch.download()
+                out = [torch.empty_like(torch.from_numpy(q)) for _ in range(world)]
+                dist.all_gather(out, torch.from_numpy(q))
+        kernel_ms += ctx.elapsed_ms(0, 1)  # HIP events on the stream the kernel runs on
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    status, n_done = (np.zeros(n_local, np.int32), np.full(n_local, traj, np.int32))
+    if w["kind"] != "euclid":
+        status, n_done = batch.download_status()
+    done_local = float(n_local) * traj * args.steps if w["kind"] == "euclid" else None
+    total_steps = done_local
+    if dist is not None:
+        import torch
+        t = torch.tensor([done_local], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_steps = float(t.item())
+
+    if rank == 0:
+        value = total_steps / elapsed
+        launch_s = kernel_ms / 1e3 / args.steps
+        chain_steps_per_launch = n_local * traj
+        if w["bound"] == "mfma":
+            achieved = w["flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
+            roof = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                        frac=achieved / FP64_MFMA_PEAK_TF, traffic=None)
+        else:
+            achieved = w["bytes_per_chain_step"] * chain_steps_per_launch / launch_s / 1e9
+            roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None)
+        roof["kernel_ms_per_launch"] = kernel_ms / args.steps
+        out = {
+            "metric": "leapfrog-steps/sec (all chains)",
+            "value": value,
+            "unit": "leapfrog-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{w['name']}, D={w['dim']}, {n_local} chains/GPU x {world} GPU, "
+                            f"h={w['h']}, one pass = a trajectory of {traj} leapfrog steps per chain",
+                "baseline_config": "BASELINE.json configs[1]" if args.config == "c2" else args.config,
+                "chains_per_gpu": n_local, "dim": w["dim"], "traj_len": traj,
+                "parallelism": f"chains sharded x{world}, trace gather: {gather_mode}",
+            },
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out), flush=True)
+
+    if comm is not None:
+        ctx._lib.mm_comm_destroy(comm)
+    batch.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

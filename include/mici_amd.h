@@ -1,0 +1,220 @@
+/* mici_amd.h - C ABI of libmici_amd.so: the MI355X (gfx950) symplectic-integrator hot path.
+ *
+ * The reference (matt-graham/mici) is pure Python and has no FFI; the interface this library sits
+ * behind is the duck-type `Integrator.step(state) -> state` / `System.h / dh_dmom / sample_momentum`
+ * consumed by mici.transitions / mici.adapters / mici.samplers.  Each entry point below cites the
+ * reference symbol (file:line under /root/reference/src/mici) whose arithmetic it replaces, batched
+ * over N independent chains.  Plain pointers and sizes only; no callbacks; all numerics fp64.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative mm_rc; mm_last_error() describes the failure.
+ *  - host pointers are borrowed for the duration of the call only.
+ *  - a mm_ctx owns one HIP stream on one device; launches are asynchronous on that stream, the
+ *    download / scalar-returning calls synchronise it.  A ctx is not thread safe; distinct ctxs are
+ *    independent (one host thread or process per GPU).
+ *  - chain state is row-major pos[N][D], mom[N][D] (fp64) and dir[N] (int8, +1/-1): the batched form
+ *    of the reference ChainState(pos, mom, dir) (states.py:160-305).
+ *  - per-chain failures do not fail the call: status[N] carries the mm_status of the first failed
+ *    step and n_done[N] the number of completed steps; a failed chain is frozen at its last good
+ *    (pos, mom) exactly as mici.transitions leaves it (transitions.py:292-295).
+ */
+#ifndef MICI_AMD_H
+#define MICI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_ABI_VERSION 1
+
+typedef struct mm_ctx mm_ctx;
+typedef struct mm_model mm_model;
+typedef struct mm_state mm_state;
+typedef struct mm_comm mm_comm;
+
+typedef enum mm_rc {
+  MM_OK = 0,
+  MM_ERR_INVALID = -1,     /* bad argument                                  */
+  MM_ERR_HIP = -2,         /* HIP runtime error (message in mm_last_error)  */
+  MM_ERR_UNSUPPORTED = -3, /* model / size combination has no device kernel */
+  MM_ERR_NOMEM = -4,
+  MM_ERR_RCCL = -5
+} mm_rc;
+
+/* Built-in synthetic models (closed forms: SURVEY.md section 8d / Appendix A).  The reference takes
+ * arbitrary Python callables (systems.py:107,119,788,792,1332,1358,1888,1920); a device kernel needs
+ * device-side derivatives, so targets / metrics / constraints are an enum with packed fp64 params. */
+typedef enum mm_target {
+  MM_TARGET_GAUSS_ISO = 0,   /* l = |q|^2/2                                       params: -        */
+  MM_TARGET_GAUSS_DIAG = 1,  /* l = sum prec_i q_i^2 / 2                          params: prec[D]  */
+  MM_TARGET_GAUSS_DENSE = 2, /* l = q^T P q / 2                                   params: P[D*D]   */
+  MM_TARGET_POLY = 3,        /* l = a sum q^2/2 + b sum q^4/4                     params: a, b     */
+  MM_TARGET_BANANA = 4,      /* l = sum (1-q_i)^2/20 + sum (q_{i+1}-q_i^2)^2      params: -        */
+  MM_TARGET_FUNNEL = 5,      /* scaled funnel, q=(v,x): v^2/18 + n v/2 + e^-v sum w x^2 / 2  params: w[D-1] */
+  MM_TARGET_TORUS = 6        /* README torus density, D=3                         params: R, r, alpha */
+} mm_target;
+
+typedef enum mm_metric_kind { /* fixed (Euclidean) metric, systems.py:327-345 */
+  MM_METRIC_IDENTITY = 0,
+  MM_METRIC_DIAG = 1,  /* metric[D]   (matrices.py:771-792)  */
+  MM_METRIC_DENSE = 2  /* metric[D*D] (matrices.py:1191-1216) */
+} mm_metric_kind;
+
+typedef enum mm_rmetric { /* position-dependent metric of a RiemannianMetricSystem */
+  MM_RMETRIC_NONE = 0,
+  MM_RMETRIC_RANK1 = 1,    /* M(q) = B + q q^T / D, params B[D*D]; DenseRiemannianMetricSystem     */
+  MM_RMETRIC_DIAGQUAD = 2, /* M(q) = diag(1 + q^2) held dense;     DenseRiemannianMetricSystem     */
+  MM_RMETRIC_SOFTABS = 3   /* SoftAbs of the target Hessian, params coeff; SoftAbsRiemannianMetricSystem */
+} mm_rmetric;
+
+typedef enum mm_constr { /* holonomic constraint, C = 1 */
+  MM_CONSTR_NONE = 0,
+  MM_CONSTR_TORUS = 1,  /* (sqrt(x^2+y^2)-R)^2 + z^2 - r^2, params R, r */
+  MM_CONSTR_FIRST = 2,  /* q_0                                          */
+  MM_CONSTR_CIRCLE = 3  /* q_0^2 + q_1^2 - 1                            */
+} mm_constr;
+
+/* Per-chain status: which reference exception the failed step would have raised (errors.py:6-35). */
+typedef enum mm_status {
+  MM_ST_OK = 0,
+  MM_ST_DIVERGED = 1,       /* ConvergenceError: solver diverged            (solvers.py:80-84, 446-451) */
+  MM_ST_MAX_ITERS = 2,      /* ConvergenceError: max_iters exhausted        (solvers.py:93-94, 465-469) */
+  MM_ST_SOLVER_LINALG = 3,  /* ConvergenceError: LinAlg/ValueError in solver (solvers.py:89-92, 461-464) */
+  MM_ST_NON_REVERSIBLE = 4, /* NonReversibleStepError    (integrators.py:510-515, 523-528, 974-979) */
+  MM_ST_LINALG = 5          /* LinAlgError outside a solver (matrices.py:211-215, 1170-1172)        */
+} mm_status;
+
+typedef enum mm_norm { MM_NORM_LINF = 0, MM_NORM_L2 = 1 } mm_norm;           /* solvers.py:20-27 */
+typedef enum mm_fp_solver { MM_FP_DIRECT = 0, MM_FP_STEFFENSEN = 1 } mm_fp_solver; /* solvers.py:47-154 */
+typedef enum mm_proj_solver { MM_PROJ_NEWTON = 0 } mm_proj_solver;         /* solvers.py:346-469 */
+
+typedef struct mm_model_desc {
+  int32_t dim;
+  int32_t target;
+  const double* target_params;
+  size_t n_target_params;
+  int32_t metric_kind; /* fixed metric (Euclidean / constrained systems) */
+  const double* metric;
+  size_t n_metric;
+  int32_t rmetric; /* position-dependent metric (Riemannian systems) */
+  const double* rmetric_params;
+  size_t n_rmetric_params;
+  int32_t constr;
+  const double* constr_params;
+  size_t n_constr_params;
+} mm_model_desc;
+
+/* ImplicitLeapfrogIntegrator ctor defaults (integrators.py:438-446) + solve_fixed_point_* kwargs
+ * (solvers.py:47-54). */
+typedef struct mm_fp_opts {
+  double conv_tol;   /* 1e-9  */
+  double div_tol;    /* 1e10  */
+  int32_t max_iters; /* 100   */
+  int32_t norm;      /* MM_NORM_LINF */
+  int32_t solver;    /* MM_FP_DIRECT */
+  int32_t rev_norm;  /* MM_NORM_LINF */
+  double rev_tol;    /* 2e-8  */
+} mm_fp_opts;
+
+/* ConstrainedLeapfrogIntegrator ctor defaults (integrators.py:855-864) + Newton kwargs
+ * (solvers.py:346-357). */
+typedef struct mm_proj_opts {
+  double constr_tol; /* 1e-9 */
+  double pos_tol;    /* 1e-8 */
+  double div_tol;    /* 1e10 */
+  int32_t max_iters; /* 50   */
+  int32_t norm;      /* MM_NORM_LINF */
+  int32_t solver;    /* MM_PROJ_NEWTON */
+  int32_t rev_norm;  /* MM_NORM_LINF */
+  double rev_tol;    /* 2e-8 */
+  int32_t n_inner;   /* 1    */
+  int32_t reserved;
+} mm_proj_opts;
+
+/* Work counters summed over chains (the reference's ChainState._call_counts, states.py:204-212;
+ * they are the n_M / n_B denominators of SURVEY.md section 8d). */
+typedef struct mm_counters {
+  int64_t n_grad;         /* grad_neg_log_dens evaluations              */
+  int64_t n_metric;       /* metric constructions (factorisations)      */
+  int64_t n_inverse;      /* explicit inverses                          */
+  int64_t n_fp_evals;     /* fixed-point function evaluations           */
+  int64_t n_fp_solves;    /* fixed-point solves                         */
+  int64_t n_newton_iters; /* projection-solver iterations               */
+  int64_t n_constr;       /* constraint + Jacobian evaluations          */
+  int64_t reserved;
+} mm_counters;
+
+/* ---- library / context ------------------------------------------------------------------------- */
+int mm_abi_version(void);
+int mm_device_count(int* count);
+int mm_ctx_create(int device, mm_ctx** out);
+int mm_ctx_destroy(mm_ctx* ctx);
+int mm_ctx_sync(mm_ctx* ctx);
+/* ctx may be NULL: returns the last error of a failed mm_ctx_create / argument check on this thread */
+const char* mm_last_error(const mm_ctx* ctx);
+/* HIP-event timing on the ctx stream (bench.py's kernel timing): record slot 0..15, then query. */
+int mm_ctx_record(mm_ctx* ctx, int slot);
+int mm_ctx_elapsed_ms(mm_ctx* ctx, int slot_begin, int slot_end, double* ms);
+
+/* ---- model ------------------------------------------------------------------------------------------ */
+int mm_model_create(mm_ctx* ctx, const mm_model_desc* desc, mm_model** out);
+int mm_model_destroy(mm_model* model);
+
+/* ---- chain state: batched ChainState(pos, mom, dir) (states.py:160-305) ---------------------------- */
+int mm_state_alloc(mm_ctx* ctx, int64_t n_chains, int32_t dim, mm_state** out);
+int mm_state_free(mm_state* state);
+int mm_state_upload(mm_state* state, const double* pos, const double* mom, const int8_t* dir);
+int mm_state_download(mm_state* state, double* pos, double* mom, int8_t* dir);
+/* status[N] / n_done[N] of the last implicit / constrained call on this state */
+int mm_state_download_status(mm_state* state, int32_t* status, int32_t* n_done);
+/* raw device pointers (zero-copy interop / RCCL): any of the outputs may be NULL */
+int mm_state_device_ptrs(mm_state* state, double** pos, double** mom, int8_t** dir);
+
+/* ---- the hot path ------------------------------------------------------------------------------------ */
+/* LeapfrogIntegrator.step x n_steps on an EuclideanMetricSystem (integrators.py:63-80, 170-173;
+ * systems.py:143-152, 352-363): p -= t/2 grad(q); q += t M^-1 p; p -= t/2 grad(q), t = dir*step_size,
+ * with the end-of-step gradient reused by the next step (state cache, states.py:136-153). */
+int mm_leapfrog_euclid(mm_ctx* ctx, const mm_model* model, mm_state* state, double step_size,
+                       int32_t n_steps);
+
+/* ImplicitLeapfrogIntegrator.step x n_steps on a Dense / SoftAbs RiemannianMetricSystem
+ * (integrators.py:493-544; solvers.py:47-154; systems.py:1360-1402; matrices.py:1161-1188, 1631-1685).
+ * opts == NULL selects the reference defaults. counters may be NULL. */
+int mm_implicit_leapfrog(mm_ctx* ctx, const mm_model* model, mm_state* state, double step_size,
+                         int32_t n_steps, const mm_fp_opts* opts, mm_counters* counters);
+
+/* ConstrainedLeapfrogIntegrator.step x n_steps on a DenseConstrainedEuclideanMetricSystem
+ * (integrators.py:929-984; solvers.py:429-469; systems.py:786-873, 1010-1022). */
+int mm_constrained_leapfrog(mm_ctx* ctx, const mm_model* model, mm_state* state, double step_size,
+                            int32_t n_steps, const mm_proj_opts* opts, mm_counters* counters);
+
+/* ---- what mici.transitions needs around the path ---------------------------------------------------- */
+/* System.h(state) per chain (systems.py:187-196, 348-350, 1375-1379, 850-853); NaN where the
+ * reference would raise LinAlgError. h is a host array of N doubles. */
+int mm_hamiltonian(mm_ctx* ctx, const mm_model* model, mm_state* state, double* h);
+/* System.dh_dmom(state) = M^-1 p per chain (systems.py:352-354, 1398-1399); out is host [N][D]. */
+int mm_dh_dmom(mm_ctx* ctx, const mm_model* model, mm_state* state, double* out);
+/* System.sample_momentum with the standard-normal draw z supplied by the host RNG:
+ * mom = M^{1/2} z (systems.py:365-366, 1401-1402), then projected onto the cotangent space for a
+ * constrained system (systems.py:614-616). z is host [N][D]. */
+int mm_sample_momentum(mm_ctx* ctx, const mm_model* model, mm_state* state, const double* z);
+
+/* ---- multi-GPU: chains are sharded, no collective inside integration; one RCCL all-gather over
+ * xGMI per trace collection (the role of the reference's process pool + memmaps,
+ * samplers.py:668-772, 104-138). ------------------------------------------------------------------- */
+#define MM_COMM_ID_BYTES 128
+int mm_comm_unique_id(uint8_t id[MM_COMM_ID_BYTES]); /* rank 0 creates, host side distributes */
+int mm_comm_create(mm_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t id[MM_COMM_ID_BYTES],
+                   mm_comm** out);
+int mm_comm_destroy(mm_comm* comm);
+/* Gather every rank's pos shard ([n_local][D], equal n_local on all ranks) into host buffer
+ * pos_all[n_ranks*n_local][D] on every rank (rank-major = global chain order). */
+int mm_comm_allgather_pos(mm_comm* comm, mm_state* state, double* pos_all);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICI_AMD_H */

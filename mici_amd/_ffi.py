@@ -1,0 +1,148 @@
+"""ctypes binding of libmici_amd.so (include/mici_amd.h).  There is no fallback: if the shared
+library is missing or a call fails, a DeviceError is raised."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .errors import DeviceError
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmici_amd.so")
+
+MM_COMM_ID_BYTES = 128
+ABI_VERSION = 1
+
+c_double_p = C.POINTER(C.c_double)
+c_int8_p = C.POINTER(C.c_int8)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32),
+        ("target", C.c_int32),
+        ("target_params", c_double_p),
+        ("n_target_params", C.c_size_t),
+        ("metric_kind", C.c_int32),
+        ("metric", c_double_p),
+        ("n_metric", C.c_size_t),
+        ("rmetric", C.c_int32),
+        ("rmetric_params", c_double_p),
+        ("n_rmetric_params", C.c_size_t),
+        ("constr", C.c_int32),
+        ("constr_params", c_double_p),
+        ("n_constr_params", C.c_size_t),
+    ]
+
+
+class FpOpts(C.Structure):
+    _fields_ = [
+        ("conv_tol", C.c_double),
+        ("div_tol", C.c_double),
+        ("max_iters", C.c_int32),
+        ("norm", C.c_int32),
+        ("solver", C.c_int32),
+        ("rev_norm", C.c_int32),
+        ("rev_tol", C.c_double),
+    ]
+
+
+class ProjOpts(C.Structure):
+    _fields_ = [
+        ("constr_tol", C.c_double),
+        ("pos_tol", C.c_double),
+        ("div_tol", C.c_double),
+        ("max_iters", C.c_int32),
+        ("norm", C.c_int32),
+        ("solver", C.c_int32),
+        ("rev_norm", C.c_int32),
+        ("rev_tol", C.c_double),
+        ("n_inner", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "n_grad", "n_metric", "n_inverse", "n_fp_evals", "n_fp_solves", "n_newton_iters",
+        "n_constr", "reserved")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
+# every symbol include/mici_amd.h declares: name -> (restype, argtypes)
+_VP = C.c_void_p
+SIGNATURES = {
+    "mm_abi_version": (C.c_int, []),
+    "mm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mm_ctx_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
+    "mm_ctx_destroy": (C.c_int, [_VP]),
+    "mm_ctx_sync": (C.c_int, [_VP]),
+    "mm_last_error": (C.c_char_p, [_VP]),
+    "mm_ctx_record": (C.c_int, [_VP, C.c_int]),
+    "mm_ctx_elapsed_ms": (C.c_int, [_VP, C.c_int, C.c_int, c_double_p]),
+    "mm_model_create": (C.c_int, [_VP, C.POINTER(ModelDesc), C.POINTER(_VP)]),
+    "mm_model_destroy": (C.c_int, [_VP]),
+    "mm_state_alloc": (C.c_int, [_VP, C.c_int64, C.c_int32, C.POINTER(_VP)]),
+    "mm_state_free": (C.c_int, [_VP]),
+    "mm_state_upload": (C.c_int, [_VP, c_double_p, c_double_p, c_int8_p]),
+    "mm_state_download": (C.c_int, [_VP, c_double_p, c_double_p, c_int8_p]),
+    "mm_state_download_status": (C.c_int, [_VP, c_int32_p, c_int32_p]),
+    "mm_state_device_ptrs": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
+    "mm_leapfrog_euclid": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int32]),
+    "mm_implicit_leapfrog": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int32,
+                                       C.POINTER(FpOpts), C.POINTER(Counters)]),
+    "mm_constrained_leapfrog": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int32,
+                                          C.POINTER(ProjOpts), C.POINTER(Counters)]),
+    "mm_hamiltonian": (C.c_int, [_VP, _VP, _VP, c_double_p]),
+    "mm_dh_dmom": (C.c_int, [_VP, _VP, _VP, c_double_p]),
+    "mm_sample_momentum": (C.c_int, [_VP, _VP, _VP, c_double_p]),
+    "mm_comm_unique_id": (C.c_int, [c_uint8_p]),
+    "mm_comm_create": (C.c_int, [_VP, C.c_int32, C.c_int32, c_uint8_p, C.POINTER(_VP)]),
+    "mm_comm_destroy": (C.c_int, [_VP]),
+    "mm_comm_allgather_pos": (C.c_int, [_VP, _VP, c_double_p]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load libmici_amd.so and bind every declared symbol (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise DeviceError(
+            f"{_LIB_PATH} is missing: build it with `python -m mici_amd.build` "
+            "(hipcc, --offload-arch=gfx950). mici_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        raise DeviceError(f"cannot load {_LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DeviceError(f"{_LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mm_abi_version() != ABI_VERSION:
+        raise DeviceError("libmici_amd.so ABI version mismatch; rebuild with mici_amd.build")
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None, what=""):
+    if rc == 0:
+        return
+    msg = load().mm_last_error(ctx)
+    msg = msg.decode("utf-8", "replace") if msg else ""
+    raise DeviceError(f"{what or 'libmici_amd call'} failed (rc={rc}): {msg}")

@@ -1,0 +1,86 @@
+"""Build libmici_amd.so for gfx950 with hipcc (in-tree; cross-compiles without a GPU).
+
+    python -m mici_amd.build [--force] [--jobs N]
+
+Each csrc/*.hip is compiled to an object (in parallel), then linked into mici_amd/lib/libmici_amd.so.
+Objects are rebuilt only when a source or header is newer."""
+
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_build")
+LIB = os.path.join(HERE, "lib", "libmici_amd.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
+         "-Wno-unused-function", "-ffp-contract=on"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need ROCm to build libmici_amd.so)")
+    return exe
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build(force=False, jobs=None, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(
+        os.path.join(HERE, "..", "include", "*.h"))
+    hdr_time = _newest(headers)
+    cc = hipcc()
+    todo = []
+    objs = []
+    for src in sources:
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
+                os.path.getmtime(src), hdr_time):
+            todo.append((src, obj))
+
+    def compile_one(pair):
+        src, obj = pair
+        cmd = [cc, *FLAGS, "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return src, r.returncode, r.stdout + r.stderr
+
+    if todo:
+        with cf.ThreadPoolExecutor(max_workers=jobs or min(8, len(todo))) as ex:
+            for src, rc, log in ex.map(compile_one, todo):
+                if verbose:
+                    print(f"[mici_amd.build] hipcc {os.path.basename(src)} -> rc={rc}")
+                if rc != 0:
+                    raise RuntimeError(f"hipcc failed on {src}:\n{log}")
+                if verbose and log.strip():
+                    print(log)
+    if todo or force or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
+        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB, "-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+        if verbose:
+            print(f"[mici_amd.build] linked {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    a = ap.parse_args()
+    build(force=a.force, jobs=a.jobs)
+    sys.exit(0)

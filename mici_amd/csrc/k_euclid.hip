@@ -1,0 +1,288 @@
+// Explicit leapfrog on Euclidean-metric systems, batched over chains (gfx950 / CDNA4).
+//
+// Replaces, per chain and per step (reference /root/reference/src/mici):
+//   LeapfrogIntegrator._step          integrators.py:170-173   A(t/2) B(t) A(t/2)
+//   System.h1_flow                    systems.py:143-152       p -= dt * grad_neg_log_dens(q)
+//   EuclideanMetricSystem.h2_flow     systems.py:362-363       q += dt * M^-1 p
+//   EuclideanMetricSystem.dh2_dmom    systems.py:352-354       identity / diag^-1 / explicit-inverse mat-vec
+// The gradient evaluated at the end of step k is carried in registers into step k+1, which is what
+// the reference's state cache does (states.py:136-153).
+//
+// Two kernels:
+//   leapfrog_elem_kernel  - separable targets x identity/diagonal metric: one lane per (chain, dim)
+//                           element pair, n_steps fused, HBM-bound at n_steps = 1 (32*D B/chain-step).
+//   leapfrog_mfma_kernel  - dense-precision Gaussian target and/or dense metric: 16 chains per
+//                           workgroup, the [16 x D] x [D x D] products on v_mfma_f64_16x16x4_f64
+//                           with the D x D operand register-resident (one 16-column slab per wave)
+//                           and the chain tile exchanged through LDS once per product.
+#include "mm_internal.h"
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+enum { T_ISO = MM_TARGET_GAUSS_ISO, T_DIAG = MM_TARGET_GAUSS_DIAG, T_DENSE = MM_TARGET_GAUSS_DENSE,
+       T_POLY = MM_TARGET_POLY };
+enum { M_ID = MM_METRIC_IDENTITY, M_DIAG = MM_METRIC_DIAG, M_DENSE = MM_METRIC_DENSE };
+
+template <int TARGET>
+__device__ __forceinline__ double elem_grad(double q, double tp0, double tp1) {
+  if constexpr (TARGET == T_ISO) return q;
+  if constexpr (TARGET == T_DIAG) return tp0 * q;           // tp0 = prec[dim]
+  if constexpr (TARGET == T_POLY) return tp0 * q + tp1 * (q * q * q);  // a q + b q^3
+  return 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Separable targets: each lane owns VEC consecutive dims of one chain.
+template <int TARGET, int METRIC, int VEC>
+__global__ __launch_bounds__(256) void leapfrog_elem_kernel(
+    double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
+    int64_t n_chains, int dim, double step_size, int n_steps, const double* __restrict__ tparams,
+    const double* __restrict__ minv_diag) {
+  const int vec_per_chain = dim / VEC;
+  const int64_t total = n_chains * vec_per_chain;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t chain = idx / vec_per_chain;
+    const int d0 = (int)(idx - chain * vec_per_chain) * VEC;
+    const double t = (double)dir[chain] * step_size;
+    const double ht = 0.5 * t;
+    double q[VEC], p[VEC], g[VEC], tp0[VEC], tp1[VEC], mi[VEC];
+    const int64_t off = chain * dim + d0;
+    if constexpr (VEC == 2) {
+      const double2 qv = *reinterpret_cast<const double2*>(pos + off);
+      const double2 pv = *reinterpret_cast<const double2*>(mom + off);
+      q[0] = qv.x; q[1] = qv.y; p[0] = pv.x; p[1] = pv.y;
+    } else {
+      q[0] = pos[off]; p[0] = mom[off];
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if constexpr (TARGET == T_DIAG) { tp0[v] = tparams[d0 + v]; tp1[v] = 0.0; }
+      else if constexpr (TARGET == T_POLY) { tp0[v] = tparams[0]; tp1[v] = tparams[1]; }
+      else { tp0[v] = 0.0; tp1[v] = 0.0; }
+      mi[v] = (METRIC == M_DIAG) ? minv_diag[d0 + v] : 1.0;
+      g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
+    }
+    for (int s = 0; s < n_steps; ++s) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        p[v] -= ht * g[v];
+        if constexpr (METRIC == M_DIAG) q[v] += t * (mi[v] * p[v]);
+        else q[v] += t * p[v];
+        g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
+        p[v] -= ht * g[v];
+      }
+    }
+    if constexpr (VEC == 2) {
+      *reinterpret_cast<double2*>(pos + off) = make_double2(q[0], q[1]);
+      *reinterpret_cast<double2*>(mom + off) = make_double2(p[0], p[1]);
+    } else {
+      pos[off] = q[0]; mom[off] = p[0];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dense target and/or dense metric on FP64 MFMA.
+//
+// Workgroup = DP/16 waves, 16 chains.  Wave w owns output columns [16w, 16w+16).
+//   C/D layout of v_mfma_f64_16x16x4_f64: lane l, reg r -> row (chain) = (l>>4) + 4r, col = l&15.
+//   A operand (chain tile):  lane l supplies X[chain = l&15][k],  k = (l>>4)*(DP/4) + kk
+//   B operand (matrix slab): lane l supplies W[col0 + (l&15)][k], same k          (kk = MFMA index)
+// so MFMA kk accumulates the 4 k-values {kq*(DP/4)+kk : kq=0..3}; over kk = 0..DP/4-1 every k is
+// covered once.  With this k-permutation a lane's A fragments are DP/4 consecutive doubles of one
+// LDS row -> ds_read_b128.  LDS rows are padded by 2 doubles (one b128 access width) so the 16 rows
+// read by a lane group fall in distinct 16-byte bank slots.
+template <int DP>
+struct MfmaCfg {
+  static constexpr int NW = DP / 16;      // waves per workgroup
+  static constexpr int KK = DP / 4;       // MFMAs per product per wave
+  static constexpr int LDW = DP + 2;      // LDS row stride in doubles
+  static constexpr int TILE = 16 * LDW;   // doubles per LDS chain tile
+};
+
+template <int DP>
+__device__ __forceinline__ void load_slab(double (&frag)[DP / 4], const double* __restrict__ w,
+                                          int dim, int col, int kq) {
+#pragma unroll
+  for (int kk = 0; kk < DP / 4; ++kk) {
+    const int k = kq * (DP / 4) + kk;
+    frag[kk] = (col < dim && k < dim) ? w[(int64_t)col * dim + k] : 0.0;
+  }
+}
+
+template <int DP>
+__device__ __forceinline__ double4_t tile_times_slab(const double* __restrict__ tile,
+                                                     const double (&frag)[DP / 4], int lane) {
+  // A fragments: row (lane&15), doubles [(lane>>4)*KK, +KK)
+  const double* row = tile + (lane & 15) * MfmaCfg<DP>::LDW + (lane >> 4) * (DP / 4);
+  double4_t acc0 = {0.0, 0.0, 0.0, 0.0};
+  double4_t acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < DP / 4; kk += 2) {
+    const double2 a = *reinterpret_cast<const double2*>(row + kk);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, frag[kk], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, frag[kk + 1], acc1, 0, 0, 0);
+  }
+  return acc0 + acc1;
+}
+
+template <int DP, int TARGET, int METRIC>
+__global__ __launch_bounds__(DP * 4) void leapfrog_mfma_kernel(
+    double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
+    int64_t n_chains, int dim, double step_size, int n_steps, const double* __restrict__ tparams,
+    const double* __restrict__ minv) {
+  using Cfg = MfmaCfg<DP>;
+  __shared__ __attribute__((aligned(16))) double lds[(METRIC == M_DENSE ? 4 : 2) * Cfg::TILE];
+  double* qbuf = lds;                    // two q tiles (double buffered)
+  double* pbuf = lds + 2 * Cfg::TILE;    // two p tiles (dense metric only)
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int col = wave * 16 + (lane & 15);  // my column in the C layout
+  const int kq = lane >> 4;
+  const int64_t chain0 = (int64_t)blockIdx.x * 16;
+
+  // register-resident matrix slabs (B operands)
+  double pfrag[TARGET == T_DENSE ? DP / 4 : 1];
+  double mfrag[METRIC == M_DENSE ? DP / 4 : 1];
+  if constexpr (TARGET == T_DENSE) load_slab<DP>(pfrag, tparams, dim, col, kq);
+  if constexpr (METRIC == M_DENSE) load_slab<DP>(mfrag, minv, dim, col, kq);
+
+  double tp0 = 0.0, tp1 = 0.0, mi = 1.0;
+  if constexpr (TARGET == T_DIAG) tp0 = (col < dim) ? tparams[col] : 0.0;
+  if constexpr (TARGET == T_POLY) { tp0 = tparams[0]; tp1 = tparams[1]; }
+  if constexpr (METRIC == M_DIAG) mi = (col < dim) ? minv[col] : 0.0;
+
+  // chain state in the C layout: q[r], p[r] <-> chain (lane>>4)+4r, column col
+  double q[4], p[4], g[4], t[4], ht[4];
+  bool live[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t chain = chain0 + (lane >> 4) + 4 * r;
+    live[r] = chain < n_chains && col < dim;
+    q[r] = live[r] ? pos[chain * dim + col] : 0.0;
+    p[r] = live[r] ? mom[chain * dim + col] : 0.0;
+    t[r] = (chain < n_chains) ? (double)dir[chain] * step_size : 0.0;
+    ht[r] = 0.5 * t[r];
+  }
+
+  auto publish = [&](double* tile, const double (&x)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[((lane >> 4) + 4 * r) * Cfg::LDW + col] = x[r];
+  };
+  auto gradient = [&](int s) {
+    if constexpr (TARGET == T_DENSE) {
+      double* tile = qbuf + (s & 1) * Cfg::TILE;
+      publish(tile, q);
+      __syncthreads();
+      const double4_t acc = tile_times_slab<DP>(tile, pfrag, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g[r] = acc[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g[r] = elem_grad<TARGET>(q[r], tp0, tp1);
+    }
+  };
+
+  gradient(1);  // g(q0); uses buffer 1 so that step 0 starts on buffer 0
+  for (int s = 0; s < n_steps; ++s) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] -= ht[r] * g[r];
+    if constexpr (METRIC == M_DENSE) {
+      double* tile = pbuf + (s & 1) * Cfg::TILE;
+      publish(tile, p);
+      __syncthreads();
+      const double4_t v = tile_times_slab<DP>(tile, mfrag, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q[r] += t[r] * v[r];
+    } else if constexpr (METRIC == M_DIAG) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q[r] += t[r] * (mi * p[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q[r] += t[r] * p[r];
+    }
+    gradient(s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] -= ht[r] * g[r];
+  }
+
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (live[r]) {
+      const int64_t chain = chain0 + (lane >> 4) + 4 * r;
+      pos[chain * dim + col] = q[r];
+      mom[chain * dim + col] = p[r];
+    }
+  }
+}
+
+template <int TARGET, int METRIC>
+int launch_elem(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
+  const int dim = s->dim;
+  const bool vec2 = (dim % 2 == 0);
+  const int64_t total = s->n * (vec2 ? dim / 2 : dim);
+  int64_t blocks = (total + 255) / 256;
+  const int64_t cap = (int64_t)ctx->n_cu * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  if (vec2)
+    hipLaunchKernelGGL((leapfrog_elem_kernel<TARGET, METRIC, 2>), dim3((unsigned)blocks), dim3(256),
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->n, dim, h, n_steps,
+                       m->d_target_params, m->d_metric_inv);
+  else
+    hipLaunchKernelGGL((leapfrog_elem_kernel<TARGET, METRIC, 1>), dim3((unsigned)blocks), dim3(256),
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->n, dim, h, n_steps,
+                       m->d_target_params, m->d_metric_inv);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
+template <int DP, int TARGET, int METRIC>
+int launch_mfma_dp(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
+  const unsigned blocks = (unsigned)((s->n + 15) / 16);
+  hipLaunchKernelGGL((leapfrog_mfma_kernel<DP, TARGET, METRIC>), dim3(blocks), dim3(DP * 4), 0,
+                     ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->n, s->dim, h, n_steps,
+                     m->d_target_params, m->d_metric_inv);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
+template <int TARGET, int METRIC>
+int launch_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
+  const int dim = s->dim;
+  if (dim <= 16) return launch_mfma_dp<16, TARGET, METRIC>(ctx, m, s, h, n_steps);
+  if (dim <= 32) return launch_mfma_dp<32, TARGET, METRIC>(ctx, m, s, h, n_steps);
+  if (dim <= 64) return launch_mfma_dp<64, TARGET, METRIC>(ctx, m, s, h, n_steps);
+  if (dim <= 128) return launch_mfma_dp<128, TARGET, METRIC>(ctx, m, s, h, n_steps);
+  mm_set_error(ctx, "mm_leapfrog_euclid: dense target/metric kernels support dim <= 128");
+  return MM_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+int mm_launch_leapfrog_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
+  const int T = m->target, M = m->metric_kind;
+#define MM_CASE_ELEM(TT, MM_) \
+  if (T == TT && M == MM_) return launch_elem<TT, MM_>(ctx, m, s, h, n_steps);
+#define MM_CASE_MFMA(TT, MM_) \
+  if (T == TT && M == MM_) return launch_mfma<TT, MM_>(ctx, m, s, h, n_steps);
+  MM_CASE_ELEM(T_ISO, M_ID)
+  MM_CASE_ELEM(T_ISO, M_DIAG)
+  MM_CASE_ELEM(T_DIAG, M_ID)
+  MM_CASE_ELEM(T_DIAG, M_DIAG)
+  MM_CASE_ELEM(T_POLY, M_ID)
+  MM_CASE_ELEM(T_POLY, M_DIAG)
+  MM_CASE_MFMA(T_DENSE, M_ID)
+  MM_CASE_MFMA(T_DENSE, M_DIAG)
+  MM_CASE_MFMA(T_DENSE, M_DENSE)
+  MM_CASE_MFMA(T_ISO, M_DENSE)
+  MM_CASE_MFMA(T_DIAG, M_DENSE)
+  MM_CASE_MFMA(T_POLY, M_DENSE)
+#undef MM_CASE_ELEM
+#undef MM_CASE_MFMA
+  return -100;  // not a separable / dense-Gaussian target: caller falls through to the generic kernel
+}

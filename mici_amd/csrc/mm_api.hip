@@ -1,0 +1,602 @@
+// C ABI of libmici_amd.so (see include/mici_amd.h).  Host-side plumbing only: contexts, device
+// buffers, model parameter staging (including the one-off host factorisation of a fixed dense
+// metric), argument checks, kernel dispatch and the RCCL trace gather.
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <vector>
+
+#include "mm_internal.h"
+
+// launchers living in other translation units
+int mm_launch_leapfrog_generic(mm_ctx*, const mm_model*, mm_state*, double, int);
+int mm_launch_euclid_hamiltonian(mm_ctx*, const mm_model*, mm_state*, double*);
+int mm_launch_euclid_dh_dmom(mm_ctx*, const mm_model*, mm_state*, double*);
+int mm_launch_euclid_sample_momentum(mm_ctx*, const mm_model*, mm_state*, const double*);
+int mm_launch_riemann_aux(mm_ctx*, const mm_model*, mm_state*, int op, double* d_out,
+                          const double* d_z);
+int mm_launch_constrained_project_momentum(mm_ctx*, const mm_model*, mm_state*);
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+void mm_set_error(const mm_ctx* ctx, const std::string& msg) {
+  g_last_error = msg;
+  if (ctx) const_cast<mm_ctx*>(ctx)->last_error = msg;
+}
+
+extern "C" {
+
+int mm_abi_version(void) { return MM_ABI_VERSION; }
+
+const char* mm_last_error(const mm_ctx* ctx) {
+  return ctx ? ctx->last_error.c_str() : g_last_error.c_str();
+}
+
+int mm_device_count(int* count) {
+  MM_REQUIRE(nullptr, count != nullptr, "mm_device_count: count is NULL");
+  MM_HIP_CHECK(nullptr, hipGetDeviceCount(count));
+  return MM_OK;
+}
+
+int mm_ctx_create(int device, mm_ctx** out) {
+  MM_REQUIRE(nullptr, out != nullptr, "mm_ctx_create: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  MM_HIP_CHECK(nullptr, hipGetDeviceCount(&count));
+  MM_REQUIRE(nullptr, device >= 0 && device < count, "mm_ctx_create: no such device");
+  MM_HIP_CHECK(nullptr, hipSetDevice(device));
+  hipDeviceProp_t prop;
+  MM_HIP_CHECK(nullptr, hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    mm_set_error(nullptr, std::string("mm_ctx_create: device is ") + prop.gcnArchName +
+                              ", this library is built for gfx950 (MI355X) only");
+    return MM_ERR_UNSUPPORTED;
+  }
+  mm_ctx* ctx = new mm_ctx();
+  ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    mm_set_error(nullptr, "mm_ctx_create: hipStreamCreate failed");
+    return MM_ERR_HIP;
+  }
+  for (auto& e : ctx->events) {
+    if (hipEventCreate(&e) != hipSuccess) {
+      mm_set_error(nullptr, "mm_ctx_create: hipEventCreate failed");
+      return MM_ERR_HIP;
+    }
+  }
+  if (hipMalloc(&ctx->d_counters, sizeof(mm_counters)) != hipSuccess) {
+    mm_set_error(nullptr, "mm_ctx_create: hipMalloc failed");
+    return MM_ERR_NOMEM;
+  }
+  *out = ctx;
+  return MM_OK;
+}
+
+int mm_ctx_destroy(mm_ctx* ctx) {
+  if (!ctx) return MM_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& e : ctx->events) (void)hipEventDestroy(e);
+  (void)hipFree(ctx->d_counters);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return MM_OK;
+}
+
+int mm_ctx_sync(mm_ctx* ctx) {
+  MM_REQUIRE(nullptr, ctx != nullptr, "mm_ctx_sync: ctx is NULL");
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return MM_OK;
+}
+
+int mm_ctx_record(mm_ctx* ctx, int slot) {
+  MM_REQUIRE(nullptr, ctx != nullptr, "mm_ctx_record: ctx is NULL");
+  MM_REQUIRE(ctx, slot >= 0 && slot < 16, "mm_ctx_record: slot out of range");
+  MM_HIP_CHECK(ctx, hipEventRecord(ctx->events[slot], ctx->stream));
+  return MM_OK;
+}
+
+int mm_ctx_elapsed_ms(mm_ctx* ctx, int a, int b, double* ms) {
+  MM_REQUIRE(nullptr, ctx != nullptr, "mm_ctx_elapsed_ms: ctx is NULL");
+  MM_REQUIRE(ctx, a >= 0 && a < 16 && b >= 0 && b < 16 && ms, "mm_ctx_elapsed_ms: bad argument");
+  MM_HIP_CHECK(ctx, hipEventSynchronize(ctx->events[b]));
+  float f = 0.f;
+  MM_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->events[a], ctx->events[b]));
+  *ms = f;
+  return MM_OK;
+}
+
+// ---- model --------------------------------------------------------------------------------------------
+static int upload(mm_ctx* ctx, const double* src, size_t n, double** dst) {
+  *dst = nullptr;
+  if (n == 0) return MM_OK;
+  if (hipMalloc(dst, n * sizeof(double)) != hipSuccess) {
+    mm_set_error(ctx, "hipMalloc failed while staging model parameters");
+    return MM_ERR_NOMEM;
+  }
+  MM_HIP_CHECK(ctx, hipMemcpy(*dst, src, n * sizeof(double), hipMemcpyHostToDevice));
+  return MM_OK;
+}
+
+// One-off host factorisation of a FIXED dense metric (matrices.py:1161-1188): lower Cholesky factor
+// and the explicit inverse L^-T L^-1 the reference multiplies momenta by (matrices.py:222-223).
+static bool host_chol_inverse(const double* a, int n, std::vector<double>& l, std::vector<double>& inv) {
+  l.assign((size_t)n * n, 0.0);
+  for (int j = 0; j < n; ++j) {
+    double d = a[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= l[(size_t)j * n + k] * l[(size_t)j * n + k];
+    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    const double ljj = std::sqrt(d);
+    l[(size_t)j * n + j] = ljj;
+    for (int i = j + 1; i < n; ++i) {
+      double s = a[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) s -= l[(size_t)i * n + k] * l[(size_t)j * n + k];
+      l[(size_t)i * n + j] = s / ljj;
+    }
+  }
+  // W = L^-1 (lower), column by column
+  std::vector<double> w((size_t)n * n, 0.0);
+  for (int c = 0; c < n; ++c) {
+    for (int i = c; i < n; ++i) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) s -= l[(size_t)i * n + k] * w[(size_t)k * n + c];
+      w[(size_t)i * n + c] = s / l[(size_t)i * n + i];
+    }
+  }
+  inv.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = 0.0;
+      for (int k = i; k < n; ++k) s += w[(size_t)k * n + i] * w[(size_t)k * n + j];
+      inv[(size_t)i * n + j] = inv[(size_t)j * n + i] = s;
+    }
+  return true;
+}
+
+int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
+  MM_REQUIRE(nullptr, ctx != nullptr, "mm_model_create: ctx is NULL");
+  MM_REQUIRE(ctx, d != nullptr && out != nullptr, "mm_model_create: NULL argument");
+  *out = nullptr;
+  const int D = d->dim;
+  MM_REQUIRE(ctx, D >= 1, "mm_model_create: dim must be >= 1");
+  size_t need_t = 0;
+  switch (d->target) {
+    case MM_TARGET_GAUSS_ISO: case MM_TARGET_BANANA: need_t = 0; break;
+    case MM_TARGET_GAUSS_DIAG: need_t = D; break;
+    case MM_TARGET_GAUSS_DENSE: need_t = (size_t)D * D; break;
+    case MM_TARGET_POLY: need_t = 2; break;
+    case MM_TARGET_FUNNEL: need_t = D - 1; MM_REQUIRE(ctx, D >= 2, "funnel target needs dim >= 2"); break;
+    case MM_TARGET_TORUS: need_t = 3; MM_REQUIRE(ctx, D == 3, "torus target needs dim == 3"); break;
+    default: MM_REQUIRE(ctx, false, "mm_model_create: unknown target id");
+  }
+  MM_REQUIRE(ctx, d->n_target_params == need_t && (need_t == 0 || d->target_params),
+             "mm_model_create: wrong number of target params");
+  size_t need_m = d->metric_kind == MM_METRIC_IDENTITY ? 0
+                  : d->metric_kind == MM_METRIC_DIAG   ? (size_t)D
+                  : d->metric_kind == MM_METRIC_DENSE  ? (size_t)D * D
+                                                       : (size_t)-1;
+  MM_REQUIRE(ctx, need_m != (size_t)-1, "mm_model_create: unknown metric kind");
+  MM_REQUIRE(ctx, d->n_metric == need_m && (need_m == 0 || d->metric),
+             "mm_model_create: wrong number of metric entries");
+  size_t need_r = d->rmetric == MM_RMETRIC_NONE       ? 0
+                  : d->rmetric == MM_RMETRIC_RANK1    ? (size_t)D * D
+                  : d->rmetric == MM_RMETRIC_DIAGQUAD ? 0
+                  : d->rmetric == MM_RMETRIC_SOFTABS  ? 1
+                                                      : (size_t)-1;
+  MM_REQUIRE(ctx, need_r != (size_t)-1, "mm_model_create: unknown Riemannian metric id");
+  MM_REQUIRE(ctx, d->n_rmetric_params == need_r && (need_r == 0 || d->rmetric_params),
+             "mm_model_create: wrong number of Riemannian metric params");
+  MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE || d->metric_kind == MM_METRIC_IDENTITY,
+             "mm_model_create: a Riemannian system has no fixed metric");
+  size_t need_c = d->constr == MM_CONSTR_NONE     ? 0
+                  : d->constr == MM_CONSTR_TORUS  ? 2
+                  : d->constr == MM_CONSTR_FIRST  ? 0
+                  : d->constr == MM_CONSTR_CIRCLE ? 0
+                                                  : (size_t)-1;
+  MM_REQUIRE(ctx, need_c != (size_t)-1, "mm_model_create: unknown constraint id");
+  MM_REQUIRE(ctx, d->n_constr_params == need_c && (need_c == 0 || d->constr_params),
+             "mm_model_create: wrong number of constraint params");
+  MM_REQUIRE(ctx, d->constr != MM_CONSTR_TORUS || D == 3, "torus constraint needs dim == 3");
+  MM_REQUIRE(ctx, d->constr != MM_CONSTR_CIRCLE || D >= 2, "circle constraint needs dim >= 2");
+  MM_REQUIRE(ctx, d->constr == MM_CONSTR_NONE || d->rmetric == MM_RMETRIC_NONE,
+             "mm_model_create: constrained Riemannian systems are not part of the path");
+  if (d->rmetric == MM_RMETRIC_SOFTABS) {
+    MM_REQUIRE(ctx, d->rmetric_params[0] > 0.0, "softabs_coeff must be positive");  // matrices.py:1652-1654
+    MM_REQUIRE(ctx, d->target == MM_TARGET_FUNNEL || d->target == MM_TARGET_POLY,
+               "SoftAbs metric needs a target with device Hessian/MTP (funnel, poly)");
+  }
+
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  mm_model* m = new mm_model();
+  m->ctx = ctx;
+  m->dim = D;
+  m->target = d->target;
+  m->metric_kind = d->metric_kind;
+  m->rmetric = d->rmetric;
+  m->constr = d->constr;
+  m->n_target_params = need_t;
+  m->n_rmetric_params = need_r;
+  m->n_constr_params = need_c;
+  for (size_t i = 0; i < need_t && i < 4; ++i) m->h_target_params[i] = d->target_params[i];
+  for (size_t i = 0; i < need_r && i < 4; ++i) m->h_rmetric_params[i] = d->rmetric_params[i];
+  for (size_t i = 0; i < need_c && i < 4; ++i) m->h_constr_params[i] = d->constr_params[i];
+  int rc = upload(ctx, d->target_params, need_t, &m->d_target_params);
+  if (rc == MM_OK) rc = upload(ctx, d->rmetric_params, need_r, &m->d_rmetric_params);
+  if (rc == MM_OK) rc = upload(ctx, d->constr_params, need_c, &m->d_constr_params);
+  if (rc == MM_OK) rc = upload(ctx, d->metric, need_m, &m->d_metric);
+  if (rc == MM_OK && d->metric_kind == MM_METRIC_DIAG) {
+    std::vector<double> inv(D), sq(D);
+    for (int i = 0; i < D; ++i) {
+      if (!(d->metric[i] > 0.0) || !std::isfinite(d->metric[i])) {
+        mm_set_error(ctx, "mm_model_create: diagonal metric must be positive and finite");
+        rc = MM_ERR_INVALID;
+        break;
+      }
+      inv[i] = 1.0 / d->metric[i];
+      sq[i] = std::sqrt(d->metric[i]);
+    }
+    if (rc == MM_OK) rc = upload(ctx, inv.data(), D, &m->d_metric_inv);
+    if (rc == MM_OK) rc = upload(ctx, sq.data(), D, &m->d_metric_chol);
+  }
+  if (rc == MM_OK && d->metric_kind == MM_METRIC_DENSE) {
+    std::vector<double> l, inv;
+    if (!host_chol_inverse(d->metric, D, l, inv)) {
+      mm_set_error(ctx, "mm_model_create: Cholesky factorisation failed.");  // matrices.py:1170-1172
+      rc = MM_ERR_INVALID;
+    }
+    if (rc == MM_OK) rc = upload(ctx, inv.data(), (size_t)D * D, &m->d_metric_inv);
+    if (rc == MM_OK) rc = upload(ctx, l.data(), (size_t)D * D, &m->d_metric_chol);
+  }
+  if (rc != MM_OK) {
+    mm_model_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return MM_OK;
+}
+
+int mm_model_destroy(mm_model* m) {
+  if (!m) return MM_OK;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipFree(m->d_target_params);
+  (void)hipFree(m->d_metric);
+  (void)hipFree(m->d_metric_inv);
+  (void)hipFree(m->d_metric_chol);
+  (void)hipFree(m->d_rmetric_params);
+  (void)hipFree(m->d_constr_params);
+  delete m;
+  return MM_OK;
+}
+
+// ---- state ---------------------------------------------------------------------------------------------
+int mm_state_alloc(mm_ctx* ctx, int64_t n, int32_t dim, mm_state** out) {
+  MM_REQUIRE(nullptr, ctx != nullptr, "mm_state_alloc: ctx is NULL");
+  MM_REQUIRE(ctx, out != nullptr, "mm_state_alloc: out is NULL");
+  *out = nullptr;
+  MM_REQUIRE(ctx, n >= 0 && dim >= 1, "mm_state_alloc: need n_chains >= 0 and dim >= 1");
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  mm_state* s = new mm_state();
+  s->ctx = ctx;
+  s->n = n;
+  s->dim = dim;
+  const size_t nd = (size_t)(n > 0 ? n : 1) * dim, n1 = (size_t)(n > 0 ? n : 1);
+  s->scratch_elems = nd;
+  bool ok = hipMalloc(&s->d_pos, nd * sizeof(double)) == hipSuccess &&
+            hipMalloc(&s->d_mom, nd * sizeof(double)) == hipSuccess &&
+            hipMalloc(&s->d_scratch, nd * sizeof(double)) == hipSuccess &&
+            hipMalloc(&s->d_dir, n1) == hipSuccess &&
+            hipMalloc(&s->d_status, n1 * sizeof(int32_t)) == hipSuccess &&
+            hipMalloc(&s->d_n_done, n1 * sizeof(int32_t)) == hipSuccess;
+  if (!ok) {
+    mm_state_free(s);
+    mm_set_error(ctx, "mm_state_alloc: hipMalloc failed");
+    return MM_ERR_NOMEM;
+  }
+  (void)hipMemsetAsync(s->d_status, 0, n1 * sizeof(int32_t), ctx->stream);
+  (void)hipMemsetAsync(s->d_n_done, 0, n1 * sizeof(int32_t), ctx->stream);
+  (void)hipMemsetAsync(s->d_dir, 1, n1, ctx->stream);
+  *out = s;
+  return MM_OK;
+}
+
+int mm_state_free(mm_state* s) {
+  if (!s) return MM_OK;
+  (void)hipSetDevice(s->ctx->device);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  (void)hipFree(s->d_pos);
+  (void)hipFree(s->d_mom);
+  (void)hipFree(s->d_dir);
+  (void)hipFree(s->d_status);
+  (void)hipFree(s->d_n_done);
+  (void)hipFree(s->d_scratch);
+  (void)hipFree(s->d_work);
+  delete s;
+  return MM_OK;
+}
+
+int mm_state_upload(mm_state* s, const double* pos, const double* mom, const int8_t* dir) {
+  MM_REQUIRE(nullptr, s != nullptr, "mm_state_upload: state is NULL");
+  mm_ctx* ctx = s->ctx;
+  if (s->n == 0) return MM_OK;
+  const size_t nd = (size_t)s->n * s->dim;
+  if (pos) MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_pos, pos, nd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (mom) MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_mom, mom, nd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (dir) {
+    for (int64_t i = 0; i < s->n; ++i)
+      MM_REQUIRE(ctx, dir[i] == 1 || dir[i] == -1, "mm_state_upload: dir entries must be +1 or -1");
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_dir, dir, (size_t)s->n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // host buffers are only borrowed
+  return MM_OK;
+}
+
+int mm_state_download(mm_state* s, double* pos, double* mom, int8_t* dir) {
+  MM_REQUIRE(nullptr, s != nullptr, "mm_state_download: state is NULL");
+  mm_ctx* ctx = s->ctx;
+  if (s->n == 0) return MM_OK;
+  const size_t nd = (size_t)s->n * s->dim;
+  if (pos) MM_HIP_CHECK(ctx, hipMemcpyAsync(pos, s->d_pos, nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (mom) MM_HIP_CHECK(ctx, hipMemcpyAsync(mom, s->d_mom, nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (dir) MM_HIP_CHECK(ctx, hipMemcpyAsync(dir, s->d_dir, (size_t)s->n, hipMemcpyDeviceToHost, ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return MM_OK;
+}
+
+int mm_state_download_status(mm_state* s, int32_t* status, int32_t* n_done) {
+  MM_REQUIRE(nullptr, s != nullptr, "mm_state_download_status: state is NULL");
+  mm_ctx* ctx = s->ctx;
+  if (s->n == 0) return MM_OK;
+  if (status) MM_HIP_CHECK(ctx, hipMemcpyAsync(status, s->d_status, (size_t)s->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (n_done) MM_HIP_CHECK(ctx, hipMemcpyAsync(n_done, s->d_n_done, (size_t)s->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return MM_OK;
+}
+
+int mm_state_device_ptrs(mm_state* s, double** pos, double** mom, int8_t** dir) {
+  MM_REQUIRE(nullptr, s != nullptr, "mm_state_device_ptrs: state is NULL");
+  if (pos) *pos = s->d_pos;
+  if (mom) *mom = s->d_mom;
+  if (dir) *dir = s->d_dir;
+  return MM_OK;
+}
+
+// ---- hot path dispatch ----------------------------------------------------------------------------------
+static int check_pair(mm_ctx* ctx, const mm_model* m, mm_state* s, const char* who) {
+  MM_REQUIRE(nullptr, ctx != nullptr, std::string(who) + ": ctx is NULL");
+  MM_REQUIRE(ctx, m != nullptr && s != nullptr, std::string(who) + ": NULL model/state");
+  MM_REQUIRE(ctx, m->ctx == ctx && s->ctx == ctx, std::string(who) + ": model/state belong to another ctx");
+  MM_REQUIRE(ctx, m->dim == s->dim, std::string(who) + ": model dim != state dim");
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return MM_OK;
+}
+
+int mm_leapfrog_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int32_t n_steps) {
+  int rc = check_pair(ctx, m, s, "mm_leapfrog_euclid");
+  if (rc != MM_OK) return rc;
+  MM_REQUIRE(ctx, m->rmetric == MM_RMETRIC_NONE && m->constr == MM_CONSTR_NONE,
+             "mm_leapfrog_euclid: model is not a plain EuclideanMetricSystem");
+  MM_REQUIRE(ctx, n_steps >= 0, "mm_leapfrog_euclid: n_steps < 0");
+  if (s->n == 0 || n_steps == 0) return MM_OK;
+  rc = mm_launch_leapfrog_euclid(ctx, m, s, h, n_steps);
+  if (rc == -100 || (rc == MM_ERR_UNSUPPORTED && m->dim > 128))
+    rc = mm_launch_leapfrog_generic(ctx, m, s, h, n_steps);
+  return rc;
+}
+
+static int finish_counters(mm_ctx* ctx, mm_counters* counters) {
+  if (!counters) return MM_OK;
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(counters, ctx->d_counters, sizeof(mm_counters), hipMemcpyDeviceToHost, ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return MM_OK;
+}
+
+int mm_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int32_t n_steps,
+                         const mm_fp_opts* opts, mm_counters* counters) {
+  int rc = check_pair(ctx, m, s, "mm_implicit_leapfrog");
+  if (rc != MM_OK) return rc;
+  MM_REQUIRE(ctx, m->rmetric != MM_RMETRIC_NONE, "mm_implicit_leapfrog: model has no Riemannian metric");
+  MM_REQUIRE(ctx, n_steps >= 0, "mm_implicit_leapfrog: n_steps < 0");
+  mm_fp_opts o = {1e-9, 1e10, 100, MM_NORM_LINF, MM_FP_DIRECT, MM_NORM_LINF, 2e-8};
+  if (opts) o = *opts;
+  MM_REQUIRE(ctx, o.max_iters >= 0 && (o.norm == 0 || o.norm == 1) && (o.rev_norm == 0 || o.rev_norm == 1) &&
+                      (o.solver == MM_FP_DIRECT || o.solver == MM_FP_STEFFENSEN),
+             "mm_implicit_leapfrog: bad solver options");
+  MM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(mm_counters), ctx->stream));
+  if (s->n > 0) {
+    rc = mm_launch_implicit_leapfrog(ctx, m, s, h, n_steps, o, ctx->d_counters);
+    if (rc != MM_OK) return rc;
+  }
+  return finish_counters(ctx, counters);
+}
+
+int mm_constrained_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int32_t n_steps,
+                            const mm_proj_opts* opts, mm_counters* counters) {
+  int rc = check_pair(ctx, m, s, "mm_constrained_leapfrog");
+  if (rc != MM_OK) return rc;
+  MM_REQUIRE(ctx, m->constr != MM_CONSTR_NONE, "mm_constrained_leapfrog: model has no constraint");
+  MM_REQUIRE(ctx, n_steps >= 0, "mm_constrained_leapfrog: n_steps < 0");
+  mm_proj_opts o = {1e-9, 1e-8, 1e10, 50, MM_NORM_LINF, MM_PROJ_NEWTON, MM_NORM_LINF, 2e-8, 1, 0};
+  if (opts) o = *opts;
+  MM_REQUIRE(ctx, o.max_iters >= 0 && o.n_inner >= 1 && (o.norm == 0 || o.norm == 1) &&
+                      (o.rev_norm == 0 || o.rev_norm == 1) && o.solver == MM_PROJ_NEWTON,
+             "mm_constrained_leapfrog: bad solver options");
+  MM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(mm_counters), ctx->stream));
+  if (s->n > 0) {
+    rc = mm_launch_constrained_leapfrog(ctx, m, s, h, n_steps, o, ctx->d_counters);
+    if (rc != MM_OK) return rc;
+  }
+  return finish_counters(ctx, counters);
+}
+
+int mm_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* h) {
+  int rc = check_pair(ctx, m, s, "mm_hamiltonian");
+  if (rc != MM_OK) return rc;
+  MM_REQUIRE(ctx, h != nullptr, "mm_hamiltonian: h is NULL");
+  if (s->n == 0) return MM_OK;
+  rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 0, s->d_scratch, nullptr)
+                                       : mm_launch_euclid_hamiltonian(ctx, m, s, s->d_scratch);
+  if (rc != MM_OK) return rc;
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(h, s->d_scratch, (size_t)s->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return MM_OK;
+}
+
+int mm_dh_dmom(mm_ctx* ctx, const mm_model* m, mm_state* s, double* out) {
+  int rc = check_pair(ctx, m, s, "mm_dh_dmom");
+  if (rc != MM_OK) return rc;
+  MM_REQUIRE(ctx, out != nullptr, "mm_dh_dmom: out is NULL");
+  if (s->n == 0) return MM_OK;
+  rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 1, s->d_scratch, nullptr)
+                                       : mm_launch_euclid_dh_dmom(ctx, m, s, s->d_scratch);
+  if (rc != MM_OK) return rc;
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(out, s->d_scratch, (size_t)s->n * s->dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return MM_OK;
+}
+
+int mm_sample_momentum(mm_ctx* ctx, const mm_model* m, mm_state* s, const double* z) {
+  int rc = check_pair(ctx, m, s, "mm_sample_momentum");
+  if (rc != MM_OK) return rc;
+  MM_REQUIRE(ctx, z != nullptr, "mm_sample_momentum: z is NULL");
+  if (s->n == 0) return MM_OK;
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_scratch, z, (size_t)s->n * s->dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 2, nullptr, s->d_scratch)
+                                       : mm_launch_euclid_sample_momentum(ctx, m, s, s->d_scratch);
+  if (rc != MM_OK) return rc;
+  if (m->constr != MM_CONSTR_NONE) {
+    rc = mm_launch_constrained_project_momentum(ctx, m, s);  // systems.py:614-616
+    if (rc != MM_OK) return rc;
+  }
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return MM_OK;
+}
+
+// ---- RCCL trace gather (librccl is opened lazily: single-GPU users never load it) ---------------------
+typedef struct { char internal[MM_COMM_ID_BYTES]; } mm_nccl_id;  // ncclUniqueId is 128 opaque bytes
+typedef void* mm_nccl_comm;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(mm_nccl_id*) = nullptr;
+  int (*CommInitRank)(mm_nccl_comm*, int, mm_nccl_id, int) = nullptr;
+  int (*CommDestroy)(mm_nccl_comm) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, mm_nccl_comm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
+
+static int rccl_load(const mm_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.lib) return MM_OK;
+  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) {
+    mm_set_error(ctx, std::string("cannot load librccl: ") + dlerror());
+    return MM_ERR_RCCL;
+  }
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+  g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) {
+    mm_set_error(ctx, "librccl is missing a required ncclXxx symbol");
+    return MM_ERR_RCCL;
+  }
+  g_rccl.lib = lib;
+  return MM_OK;
+}
+
+static int rccl_fail(const mm_ctx* ctx, const char* what, int code) {
+  mm_set_error(ctx, std::string(what) + ": " +
+                        (g_rccl.GetErrorString ? g_rccl.GetErrorString(code) : "RCCL error"));
+  return MM_ERR_RCCL;
+}
+
+struct mm_comm {
+  mm_ctx* ctx = nullptr;
+  mm_nccl_comm comm = nullptr;
+  int n_ranks = 1, rank = 0;
+  double* d_gather = nullptr;
+  size_t gather_elems = 0;
+};
+
+int mm_comm_unique_id(uint8_t id[MM_COMM_ID_BYTES]) {
+  MM_REQUIRE(nullptr, id != nullptr, "mm_comm_unique_id: id is NULL");
+  int rc = rccl_load(nullptr);
+  if (rc != MM_OK) return rc;
+  mm_nccl_id uid;
+  const int e = g_rccl.GetUniqueId(&uid);
+  if (e != 0) return rccl_fail(nullptr, "ncclGetUniqueId", e);
+  std::memcpy(id, uid.internal, MM_COMM_ID_BYTES);
+  return MM_OK;
+}
+
+int mm_comm_create(mm_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t id[MM_COMM_ID_BYTES],
+                   mm_comm** out) {
+  MM_REQUIRE(nullptr, ctx != nullptr, "mm_comm_create: ctx is NULL");
+  MM_REQUIRE(ctx, out != nullptr && id != nullptr, "mm_comm_create: NULL argument");
+  *out = nullptr;
+  MM_REQUIRE(ctx, n_ranks >= 1 && rank >= 0 && rank < n_ranks, "mm_comm_create: bad rank / n_ranks");
+  int rc = rccl_load(ctx);
+  if (rc != MM_OK) return rc;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  mm_nccl_id uid;
+  std::memcpy(uid.internal, id, MM_COMM_ID_BYTES);
+  mm_comm* c = new mm_comm();
+  c->ctx = ctx;
+  c->n_ranks = n_ranks;
+  c->rank = rank;
+  const int e = g_rccl.CommInitRank(&c->comm, n_ranks, uid, rank);
+  if (e != 0) {
+    delete c;
+    return rccl_fail(ctx, "ncclCommInitRank", e);
+  }
+  *out = c;
+  return MM_OK;
+}
+
+int mm_comm_destroy(mm_comm* c) {
+  if (!c) return MM_OK;
+  (void)hipSetDevice(c->ctx->device);
+  (void)hipStreamSynchronize(c->ctx->stream);
+  if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+  (void)hipFree(c->d_gather);
+  delete c;
+  return MM_OK;
+}
+
+int mm_comm_allgather_pos(mm_comm* c, mm_state* s, double* pos_all) {
+  MM_REQUIRE(nullptr, c != nullptr, "mm_comm_allgather_pos: comm is NULL");
+  mm_ctx* ctx = c->ctx;
+  MM_REQUIRE(ctx, s != nullptr && pos_all != nullptr && s->ctx == ctx, "mm_comm_allgather_pos: bad argument");
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t local = (size_t)s->n * s->dim, total = local * c->n_ranks;
+  if (local == 0) return MM_OK;
+  if (c->gather_elems < total) {
+    (void)hipFree(c->d_gather);
+    c->d_gather = nullptr;
+    c->gather_elems = 0;
+    if (hipMalloc(&c->d_gather, total * sizeof(double)) != hipSuccess) {
+      mm_set_error(ctx, "mm_comm_allgather_pos: hipMalloc failed");
+      return MM_ERR_NOMEM;
+    }
+    c->gather_elems = total;
+  }
+  const int kNcclFloat64 = 8;  // ncclDataType_t::ncclFloat64 / ncclDouble
+  const int e = g_rccl.AllGather(s->d_pos, c->d_gather, local, kNcclFloat64, c->comm, ctx->stream);
+  if (e != 0) return rccl_fail(ctx, "ncclAllGather", e);
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(pos_all, c->d_gather, total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return MM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// Device-side helpers shared by the wave-per-chain kernels: wavefront reductions and the built-in
+// targets / constraints evaluated cooperatively by one 64-lane wave with the position vector in LDS.
+// Closed forms: SURVEY.md section 8d / Appendix A (NumPy twins in oracle/models.py).
+#pragma once
+
+#include "mm_internal.h"
+
+namespace mmdev {
+
+// Order LDS traffic between the lanes of ONE wave (the wave executes DS instructions in order; this
+// only stops the compiler from moving loads/stores across the exchange point).
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// max that propagates NaN (np.abs(x).max() semantics, solvers.py:25-27)
+__device__ __forceinline__ double nanmax(double a, double b) {
+  return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = nanmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__device__ __forceinline__ double wave_bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+// norm over the first `dim` entries held one-per-lane-slot: elements i = lane, lane+64, ...
+// kind 0: max |x| (maximum_norm, solvers.py:25-27); kind 1: sqrt(sum x^2) (euclidean_norm, :20-22)
+__device__ __forceinline__ double wave_norm_accum(double acc, double x, int kind) {
+  return kind == MM_NORM_LINF ? nanmax(acc, fabs(x)) : acc + x * x;
+}
+__device__ __forceinline__ double wave_norm_finish(double acc, int kind) {
+  return kind == MM_NORM_LINF ? wave_max(acc) : sqrt(wave_sum(acc));
+}
+
+// ---- targets ------------------------------------------------------------------------------------------
+struct TargetAux {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+};
+
+// Wave-collective: reductions a target needs before its per-element gradient can be formed.
+__device__ __forceinline__ TargetAux target_prepare(int target, const double* q, int dim,
+                                                    const double* __restrict__ tp, int lane) {
+  TargetAux a;
+  if (target == MM_TARGET_FUNNEL) {
+    double s = 0.0;
+    for (int i = 1 + lane; i < dim; i += 64) s += tp[i - 1] * q[i] * q[i];
+    a.s0 = wave_sum(s);   // S = sum w x^2
+    a.s1 = exp(-q[0]);    // e = exp(-v)
+  }
+  return a;
+}
+
+// grad_neg_log_dens element i.  For MM_TARGET_GAUSS_DENSE the row dot product reads P from global.
+__device__ __forceinline__ double target_grad_elem(int target, const TargetAux& a, const double* q,
+                                                   int i, int dim, const double* __restrict__ tp) {
+  switch (target) {
+    case MM_TARGET_GAUSS_ISO:
+      return q[i];
+    case MM_TARGET_GAUSS_DIAG:
+      return tp[i] * q[i];
+    case MM_TARGET_GAUSS_DENSE: {
+      double s = 0.0;
+      const double* row = tp + (int64_t)i * dim;
+      for (int j = 0; j < dim; ++j) s += row[j] * q[j];
+      return s;
+    }
+    case MM_TARGET_POLY:
+      return tp[0] * q[i] + tp[1] * (q[i] * q[i] * q[i]);
+    case MM_TARGET_BANANA: {
+      double g = -(1.0 - q[i]) / 10.0;
+      if (i > 0) g += 2.0 * (q[i] - q[i - 1] * q[i - 1]);
+      if (i < dim - 1) g -= 4.0 * q[i] * (q[i + 1] - q[i] * q[i]);
+      return g;
+    }
+    case MM_TARGET_FUNNEL: {
+      if (i == 0) return q[0] / 9.0 + 0.5 * (dim - 1) - 0.5 * a.s1 * a.s0;
+      return a.s1 * tp[i - 1] * q[i];
+    }
+    case MM_TARGET_TORUS: {
+      const double R = tp[0], r = tp[1], al = tp[2];
+      const double x = q[0], y = q[1], z = q[2];
+      const double rho2 = x * x + y * y, rho = sqrt(rho2);
+      const double theta = atan2(y, x), phi = atan2(z, rho - R);
+      const double s4 = sin(4.0 * theta), c4 = cos(4.0 * theta), sp = sin(phi), cp = cos(phi);
+      const double d1 = 1.0 + r * cp / R, d2 = 1.0 + al * s4 * cp;
+      const double dl_dphi = -(r / R) * sp / d1 + al * s4 * sp / d2;
+      const double dl_dth = -4.0 * al * c4 * cp / d2;
+      const double s2 = (rho - R) * (rho - R) + z * z;
+      const double dphi_drho = -z / s2, dphi_dz = (rho - R) / s2;
+      if (i == 0) return dl_dth * (-y / rho2) + dl_dphi * dphi_drho * (x / rho);
+      if (i == 1) return dl_dth * (x / rho2) + dl_dphi * dphi_drho * (y / rho);
+      return dl_dphi * dphi_dz;
+    }
+    default:
+      return 0.0;
+  }
+}
+
+// neg_log_dens = wave_sum over i of this per-element term.
+__device__ __forceinline__ double target_nld_elem(int target, const TargetAux& a, const double* q,
+                                                  int i, int dim, const double* __restrict__ tp) {
+  switch (target) {
+    case MM_TARGET_GAUSS_ISO:
+      return 0.5 * q[i] * q[i];
+    case MM_TARGET_GAUSS_DIAG:
+      return 0.5 * tp[i] * q[i] * q[i];
+    case MM_TARGET_GAUSS_DENSE:
+      return 0.5 * q[i] * target_grad_elem(target, a, q, i, dim, tp);
+    case MM_TARGET_POLY: {
+      const double q2 = q[i] * q[i];
+      return 0.5 * tp[0] * q2 + 0.25 * tp[1] * q2 * q2;
+    }
+    case MM_TARGET_BANANA: {
+      double v = (1.0 - q[i]) * (1.0 - q[i]) / 20.0;
+      if (i < dim - 1) {
+        const double r = q[i + 1] - q[i] * q[i];
+        v += r * r;
+      }
+      return v;
+    }
+    case MM_TARGET_FUNNEL:
+      return i == 0 ? q[0] * q[0] / 18.0 + 0.5 * (dim - 1) * q[0] + 0.5 * a.s1 * a.s0 : 0.0;
+    case MM_TARGET_TORUS: {
+      if (i != 0) return 0.0;
+      const double R = tp[0], r = tp[1], al = tp[2];
+      const double rho = sqrt(q[0] * q[0] + q[1] * q[1]);
+      const double theta = atan2(q[1], q[0]), phi = atan2(q[2], rho - R);
+      return log1p(r * cos(phi) / R) - log1p(sin(4.0 * theta) * cos(phi) * al);
+    }
+    default:
+      return 0.0;
+  }
+}
+
+}  // namespace mmdev

@@ -1,0 +1,87 @@
+// Internal definitions shared by the C-ABI translation unit and the HIP kernels (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/mici_amd.h"
+
+struct mm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t events[16] = {};
+  int n_cu = 0;
+  std::string last_error;
+  mm_counters* d_counters = nullptr;  // device scratch for work counters
+};
+
+struct mm_model {
+  mm_ctx* ctx = nullptr;
+  int dim = 0;
+  int target = 0;
+  int metric_kind = 0;
+  int rmetric = 0;
+  int constr = 0;
+  // device copies (nullptr when absent)
+  double* d_target_params = nullptr;
+  size_t n_target_params = 0;
+  double* d_metric = nullptr;       // as given: diag[D] or dense[D*D]
+  double* d_metric_inv = nullptr;   // diag: 1/diag [D]; dense: explicit inverse [D*D]
+  double* d_metric_chol = nullptr;  // diag: sqrt(diag) [D]; dense: lower Cholesky factor [D*D]
+  double* d_rmetric_params = nullptr;
+  size_t n_rmetric_params = 0;
+  double* d_constr_params = nullptr;
+  size_t n_constr_params = 0;
+  double h_target_params[4] = {0, 0, 0, 0};  // first few params host-side (scalars)
+  double h_rmetric_params[4] = {0, 0, 0, 0};
+  double h_constr_params[4] = {0, 0, 0, 0};
+};
+
+struct mm_state {
+  mm_ctx* ctx = nullptr;
+  int64_t n = 0;
+  int dim = 0;
+  double* d_pos = nullptr;
+  double* d_mom = nullptr;
+  int8_t* d_dir = nullptr;
+  int32_t* d_status = nullptr;
+  int32_t* d_n_done = nullptr;
+  double* d_scratch = nullptr;  // [N] or [N*D] doubles for h / dh_dmom / z
+  size_t scratch_elems = 0;
+  void* d_work = nullptr;  // per-chain workspace of the large-D implicit path
+  size_t work_bytes = 0;
+};
+
+// ---- error plumbing -------------------------------------------------------------------------------
+void mm_set_error(const mm_ctx* ctx, const std::string& msg);
+
+#define MM_HIP_CHECK(ctx, expr)                                                              \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      mm_set_error((ctx), std::string(#expr) + ": " + hipGetErrorString(_e));                \
+      return MM_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+#define MM_REQUIRE(ctx, cond, msg)       \
+  do {                                   \
+    if (!(cond)) {                       \
+      mm_set_error((ctx), (msg));        \
+      return MM_ERR_INVALID;             \
+    }                                    \
+  } while (0)
+
+// ---- kernel launchers (defined in the .hip files) -----------------------------------------------------
+int mm_launch_leapfrog_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double step_size,
+                              int n_steps);
+int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double step_size,
+                                int n_steps, const mm_fp_opts& opts, mm_counters* d_counters);
+int mm_launch_constrained_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double step_size,
+                                   int n_steps, const mm_proj_opts& opts, mm_counters* d_counters);
+int mm_launch_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_h);
+int mm_launch_dh_dmom(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_out);
+int mm_launch_sample_momentum(mm_ctx* ctx, const mm_model* m, mm_state* s, const double* d_z);

@@ -1,0 +1,213 @@
+"""Symplectic integrators with the reference's ``Integrator`` surface (mici/integrators.py) whose
+``step`` runs on the MI355X through libmici_amd.so.
+
+Each class offers
+  * ``step(state) -> new state``  - exactly the reference contract (integrators.py:63-80): the input
+    state is not modified, ``AdaptationError`` if ``step_size is None``, and the reference's
+    exception classes (``ConvergenceError``, ``NonReversibleStepError``, ``LinAlgError``) are raised
+    for the corresponding per-chain device status, so mici.transitions / adapters / samplers drive
+    it unchanged (verified by duck-typing: ``system``, ``step_size`` read/write, ``step``);
+  * ``step_batch(pos, mom, dir, n_steps) -> (pos, mom, status, n_done)`` - N chains, host arrays;
+  * ``step_device(batch, n_steps)`` - chains already resident in HBM (``DeviceBatch``), no copies.
+There is no CPU path: a missing library or device raises ``DeviceError``."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi, solvers
+from .errors import AdaptationError, raise_for_status
+from .runtime import DeviceBatch, default_context
+
+
+class Integrator:
+    """Base class (reference integrators.py:30-89)."""
+
+    _needs = None  # system kind required
+
+    def __init__(self, system, step_size=None):
+        if self._needs is not None and getattr(system, "_kind", None) != self._needs:
+            raise ValueError(f"{type(self).__name__} needs a {self._needs} system, got "
+                             f"{type(system).__name__}")
+        self.system = system
+        self.step_size = step_size
+        self._one = {}  # cached single-chain DeviceBatch per context
+        self.last_counters = None
+
+    # pickling / deepcopy: device handles are dropped and lazily re-created; every copy has its own
+    # step_size (adapters mutate it per chain, adapters.py:373) - SURVEY.md H9
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_one"] = {}
+        return d
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = object.__new__(type(self))
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == "_one" else (v if k == "system" else copy.deepcopy(v, memo))
+        return new
+
+    def _check_step_size(self):
+        if self.step_size is None:
+            raise AdaptationError(
+                "Integrator `step_size` is `None`. This value should only be used if a step size "
+                "adapter is being used to set the step size.")
+
+    # ---- device entry point, implemented by subclasses ------------------------------------------
+    def _launch(self, ctx, model, batch, n_steps):
+        raise NotImplementedError
+
+    def step_device(self, batch, n_steps=1, ctx=None):
+        """Advance a device-resident batch by ``n_steps`` (asynchronous on the context stream)."""
+        self._check_step_size()
+        ctx = ctx or batch.ctx
+        self._launch(ctx, self.system.device_model(ctx), batch, int(n_steps))
+
+    def step_batch(self, pos, mom, dir=1, n_steps=1, ctx=None):  # noqa: A002
+        """N chains from host arrays; returns ``(pos, mom, status[N], n_done[N])``.  A failed chain is
+        frozen at its last successfully completed step (transitions.py:292-295)."""
+        self._check_step_size()
+        ctx = ctx or default_context()
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        if pos.ndim != 2:
+            raise ValueError("pos must be [N, D]")
+        batch = DeviceBatch(ctx, pos.shape[0], pos.shape[1])
+        try:
+            batch.upload(pos, mom, dir)
+            self.step_device(batch, n_steps, ctx)
+            q, p, _ = batch.download()
+            status, n_done = self._status(batch, n_steps)
+        finally:
+            batch.close()
+        return q, p, status, n_done
+
+    def _status(self, batch, n_steps):
+        return (np.zeros(batch.n_chains, dtype=np.int32),
+                np.full(batch.n_chains, n_steps, dtype=np.int32))
+
+    def step(self, state):
+        """Single-chain step with the reference's semantics (integrators.py:63-80)."""
+        self._check_step_size()
+        ctx = default_context()
+        pos = np.ascontiguousarray(state.pos, dtype=np.float64)
+        batch = self._one.get(id(ctx))
+        if batch is None or batch.handle is None or batch.dim != pos.shape[0]:
+            batch = self._one[id(ctx)] = DeviceBatch(ctx, 1, pos.shape[0])
+        batch.upload(pos[None], np.asarray(state.mom, dtype=np.float64)[None], [int(state.dir)])
+        self.step_device(batch, 1, ctx)
+        status, _ = self._status(batch, 1)
+        raise_for_status(status[0])
+        q, p, _ = batch.download()
+        new = state.copy()
+        new.pos = q[0]
+        new.mom = p[0]
+        return new
+
+
+class LeapfrogIntegrator(Integrator):
+    r"""Explicit leapfrog :math:`\Phi_1(t/2)\circ\Phi_2(t)\circ\Phi_1(t/2)` on an
+    ``EuclideanMetricSystem`` (reference integrators.py:134-173)."""
+
+    _needs = "euclid"
+
+    def _launch(self, ctx, model, batch, n_steps):
+        _ffi.check(ctx._lib.mm_leapfrog_euclid(ctx.handle, model.handle, batch.handle,
+                                               float(self.step_size), n_steps),
+                   ctx.handle, "mm_leapfrog_euclid")
+
+
+class ImplicitLeapfrogIntegrator(Integrator):
+    """Implicit (generalised) leapfrog on a Riemannian-metric system with fixed-point solves and
+    reversibility checks (reference integrators.py:381-544).  NB as in the reference every
+    sub-map uses the full ``step_size`` (SURVEY.md hazard H1)."""
+
+    _needs = "riemann"
+
+    def __init__(self, system, step_size=None, reverse_check_tol=2e-8,
+                 reverse_check_norm=solvers.maximum_norm,
+                 fixed_point_solver=solvers.solve_fixed_point_direct,
+                 fixed_point_solver_kwargs=None):
+        super().__init__(system, step_size)
+        self.reverse_check_tol = reverse_check_tol
+        self.reverse_check_norm = reverse_check_norm
+        self.fixed_point_solver = fixed_point_solver
+        self.fixed_point_solver_kwargs = dict(fixed_point_solver_kwargs or {})
+
+    def _opts(self):
+        kw = dict(solvers.FIXED_POINT_DEFAULTS)
+        unknown = set(self.fixed_point_solver_kwargs) - set(kw)
+        if unknown:
+            raise ValueError(f"unknown fixed_point_solver_kwargs: {sorted(unknown)}")
+        kw.update(self.fixed_point_solver_kwargs)
+        o = _ffi.FpOpts()
+        o.conv_tol = kw["convergence_tol"]
+        o.div_tol = kw["divergence_tol"]
+        o.max_iters = int(kw["max_iters"])
+        o.norm = solvers.norm_code(kw["norm"])
+        o.solver = solvers.fp_solver_code(self.fixed_point_solver)
+        o.rev_norm = solvers.norm_code(self.reverse_check_norm)
+        o.rev_tol = self.reverse_check_tol
+        return o
+
+    def _launch(self, ctx, model, batch, n_steps):
+        opts = self._opts()
+        counters = _ffi.Counters()
+        _ffi.check(ctx._lib.mm_implicit_leapfrog(ctx.handle, model.handle, batch.handle,
+                                                 float(self.step_size), n_steps, C.byref(opts),
+                                                 C.byref(counters)),
+                   ctx.handle, "mm_implicit_leapfrog")
+        self.last_counters = counters.as_dict()
+
+    def _status(self, batch, n_steps):
+        return batch.download_status()
+
+
+class ConstrainedLeapfrogIntegrator(Integrator):
+    """Constrained leapfrog with Newton projection onto the manifold and reversibility check
+    (reference integrators.py:684-984)."""
+
+    _needs = "constrained"
+
+    def __init__(self, system, step_size=None, n_inner_step=1, reverse_check_tol=2e-8,
+                 reverse_check_norm=solvers.maximum_norm,
+                 projection_solver=solvers.solve_projection_onto_manifold_newton,
+                 projection_solver_kwargs=None):
+        super().__init__(system, step_size)
+        self.n_inner_step = n_inner_step
+        self.reverse_check_tol = reverse_check_tol
+        self.reverse_check_norm = reverse_check_norm
+        self.projection_solver = projection_solver
+        self.projection_solver_kwargs = dict(projection_solver_kwargs or {})
+
+    def _opts(self):
+        kw = dict(solvers.PROJECTION_DEFAULTS)
+        unknown = set(self.projection_solver_kwargs) - set(kw)
+        if unknown:
+            raise ValueError(f"unknown projection_solver_kwargs: {sorted(unknown)}")
+        kw.update(self.projection_solver_kwargs)
+        o = _ffi.ProjOpts()
+        o.constr_tol = kw["constraint_tol"]
+        o.pos_tol = kw["position_tol"]
+        o.div_tol = kw["divergence_tol"]
+        o.max_iters = int(kw["max_iters"])
+        o.norm = solvers.norm_code(kw["norm"])
+        o.solver = solvers.proj_solver_code(self.projection_solver)
+        o.rev_norm = solvers.norm_code(self.reverse_check_norm)
+        o.rev_tol = self.reverse_check_tol
+        o.n_inner = int(self.n_inner_step)
+        return o
+
+    def _launch(self, ctx, model, batch, n_steps):
+        opts = self._opts()
+        counters = _ffi.Counters()
+        _ffi.check(ctx._lib.mm_constrained_leapfrog(ctx.handle, model.handle, batch.handle,
+                                                    float(self.step_size), n_steps, C.byref(opts),
+                                                    C.byref(counters)),
+                   ctx.handle, "mm_constrained_leapfrog")
+        self.last_counters = counters.as_dict()
+
+    def _status(self, batch, n_steps):
+        return batch.download_status()

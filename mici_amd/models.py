@@ -1,0 +1,180 @@
+"""Built-in synthetic models: host-side *descriptors* only (ids + packed fp64 parameters).
+
+The reference takes arbitrary Python callables for ``neg_log_dens`` / ``metric_func`` / ``constr``
+(systems.py:107,119,788,792,1332,1358); a HIP kernel needs device-side closed forms, so the targets,
+position-dependent metrics and constraints of SURVEY.md section 8d are an enum implemented in
+``csrc/mm_device.h`` and selected by the ids below (``include/mici_amd.h``).  No arithmetic on chain
+state happens in this module."""
+
+from __future__ import annotations
+
+import numpy as np
+
+TARGET_GAUSS_ISO, TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_POLY = 0, 1, 2, 3
+TARGET_BANANA, TARGET_FUNNEL, TARGET_TORUS = 4, 5, 6
+METRIC_IDENTITY, METRIC_DIAG, METRIC_DENSE = 0, 1, 2
+RMETRIC_NONE, RMETRIC_RANK1, RMETRIC_DIAGQUAD, RMETRIC_SOFTABS = 0, 1, 2, 3
+CONSTR_NONE, CONSTR_TORUS, CONSTR_FIRST, CONSTR_CIRCLE = 0, 1, 2, 3
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Target:
+    """Descriptor of a built-in target density (negative log density + device derivatives)."""
+
+    def __init__(self, tid, dim, params=()):
+        self.tid = int(tid)
+        self.dim = int(dim)
+        self.params = _f64(params).ravel()
+
+    def __repr__(self):
+        return f"{type(self).__name__}(dim={self.dim})"
+
+
+class GaussIso(Target):
+    """l(q) = |q|^2 / 2."""
+
+    def __init__(self, dim):
+        super().__init__(TARGET_GAUSS_ISO, dim)
+
+
+class GaussDiag(Target):
+    """l(q) = sum_i prec_i q_i^2 / 2."""
+
+    def __init__(self, prec):
+        prec = _f64(prec)
+        if prec.ndim != 1:
+            raise ValueError("prec must be 1D")
+        super().__init__(TARGET_GAUSS_DIAG, prec.shape[0], prec)
+
+
+class GaussDense(Target):
+    """l(q) = q^T P q / 2 with a dense symmetric precision P."""
+
+    def __init__(self, prec):
+        prec = _f64(prec)
+        if prec.ndim != 2 or prec.shape[0] != prec.shape[1]:
+            raise ValueError("prec must be a square 2D array")
+        super().__init__(TARGET_GAUSS_DENSE, prec.shape[0], prec)
+
+
+class Poly(Target):
+    """l(q) = a sum(q^2)/2 + b sum(q^4)/4."""
+
+    def __init__(self, dim, a, b):
+        super().__init__(TARGET_POLY, dim, [a, b])
+
+
+class Banana(Target):
+    """l(q) = sum (1-q_i)^2/20 + sum (q_{i+1} - q_i^2)^2."""
+
+    def __init__(self, dim):
+        super().__init__(TARGET_BANANA, dim)
+
+
+class Funnel(Target):
+    """Scaled funnel over q = (v, x): v^2/18 + n v/2 + exp(-v) sum(w x^2)/2, w distinct."""
+
+    def __init__(self, w):
+        w = _f64(w)
+        super().__init__(TARGET_FUNNEL, w.shape[0] + 1, w)
+
+
+class Torus(Target):
+    """Density on the README torus (reference README.md:315-337); dim 3."""
+
+    def __init__(self, R=1.0, r=0.5, alpha=0.9):
+        super().__init__(TARGET_TORUS, 3, [R, r, alpha])
+
+
+class RiemannianMetric:
+    def __init__(self, mid, dim, params=()):
+        self.mid = int(mid)
+        self.dim = int(dim)
+        self.params = _f64(params).ravel()
+
+
+class Rank1Metric(RiemannianMetric):
+    """M(q) = B + q q^T / D."""
+
+    def __init__(self, base):
+        base = _f64(base)
+        if base.ndim != 2 or base.shape[0] != base.shape[1]:
+            raise ValueError("base must be a square 2D array")
+        super().__init__(RMETRIC_RANK1, base.shape[0], base)
+
+
+class DiagQuadMetric(RiemannianMetric):
+    """M(q) = diag(1 + q^2), held as a dense matrix."""
+
+    def __init__(self, dim):
+        super().__init__(RMETRIC_DIAGQUAD, dim)
+
+
+class Constraint:
+    def __init__(self, cid, params=()):
+        self.cid = int(cid)
+        self.params = _f64(params).ravel()
+
+
+class TorusConstr(Constraint):
+    """c(q) = (sqrt(x^2+y^2) - R)^2 + z^2 - r^2."""
+
+    def __init__(self, R=1.0, r=0.5):
+        super().__init__(CONSTR_TORUS, [R, r])
+
+
+class FirstCoordConstr(Constraint):
+    """c(q) = q_0."""
+
+    def __init__(self):
+        super().__init__(CONSTR_FIRST)
+
+
+class CircleConstr(Constraint):
+    """c(q) = q_0^2 + q_1^2 - 1."""
+
+    def __init__(self):
+        super().__init__(CONSTR_CIRCLE)
+
+
+def target_from_id(tid, params, dim):
+    tid = int(tid)
+    params = _f64(params)
+    if tid == TARGET_GAUSS_ISO:
+        return GaussIso(dim)
+    if tid == TARGET_GAUSS_DIAG:
+        return GaussDiag(params)
+    if tid == TARGET_GAUSS_DENSE:
+        return GaussDense(params.reshape(dim, dim))
+    if tid == TARGET_POLY:
+        return Poly(dim, params[0], params[1])
+    if tid == TARGET_BANANA:
+        return Banana(dim)
+    if tid == TARGET_FUNNEL:
+        return Funnel(params)
+    if tid == TARGET_TORUS:
+        return Torus(*params)
+    raise ValueError(f"unknown target id {tid}")
+
+
+def rmetric_from_id(mid, params, dim):
+    mid = int(mid)
+    if mid == RMETRIC_RANK1:
+        return Rank1Metric(_f64(params).reshape(dim, dim))
+    if mid == RMETRIC_DIAGQUAD:
+        return DiagQuadMetric(dim)
+    raise ValueError(f"unknown Riemannian metric id {mid}")
+
+
+def constr_from_id(cid, params):
+    cid = int(cid)
+    if cid == CONSTR_TORUS:
+        return TorusConstr(*params)
+    if cid == CONSTR_FIRST:
+        return FirstCoordConstr()
+    if cid == CONSTR_CIRCLE:
+        return CircleConstr()
+    raise ValueError(f"unknown constraint id {cid}")

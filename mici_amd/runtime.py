@@ -1,0 +1,187 @@
+"""Thin Python owners of the C-ABI handles: Context (device + stream), DeviceModel, DeviceBatch.
+
+Host arrays are NumPy-owned and only borrowed for the duration of a call; device buffers are owned
+by the handles and released in ``close()`` / ``__del__`` (ownership)."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import _ffi
+from .errors import DeviceError
+
+
+def _dptr(a):
+    return a.ctypes.data_as(_ffi.c_double_p)
+
+
+class Context:
+    """One HIP stream on one device.  Not thread safe; distinct contexts are independent."""
+
+    def __init__(self, device=None):
+        self._lib = _ffi.load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        count = C.c_int(0)
+        _ffi.check(self._lib.mm_device_count(C.byref(count)), None, "mm_device_count")
+        if count.value == 0:
+            raise DeviceError("no HIP device visible; mici_amd needs an MI355X (no CPU fallback)")
+        device = device % count.value
+        h = C.c_void_p()
+        _ffi.check(self._lib.mm_ctx_create(device, C.byref(h)), None, "mm_ctx_create")
+        self.handle = h
+        self.device = device
+
+    def sync(self):
+        _ffi.check(self._lib.mm_ctx_sync(self.handle), self.handle, "mm_ctx_sync")
+
+    def record(self, slot):
+        _ffi.check(self._lib.mm_ctx_record(self.handle, slot), self.handle, "mm_ctx_record")
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_double(0.0)
+        _ffi.check(self._lib.mm_ctx_elapsed_ms(self.handle, a, b, C.byref(ms)), self.handle,
+                   "mm_ctx_elapsed_ms")
+        return ms.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.mm_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = {}
+_default_lock = threading.Lock()
+
+
+def default_context(device=None):
+    """Process-wide context per device (created lazily)."""
+    key = device if device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+    with _default_lock:
+        ctx = _default.get(key)
+        if ctx is None or ctx.handle is None:
+            ctx = _default[key] = Context(key)
+        return ctx
+
+
+class DeviceModel:
+    """Device copy of a built-in model (target + fixed metric + Riemannian metric + constraint)."""
+
+    def __init__(self, ctx, dim, target, metric_kind=0, metric=None, rmetric=0, rmetric_params=None,
+                 constr=0, constr_params=None):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self._keep = []
+
+        def arr(a):
+            a = np.ascontiguousarray(np.zeros(0) if a is None else a, dtype=np.float64).ravel()
+            self._keep.append(a)
+            return (_dptr(a) if a.size else None), a.size
+
+        d = _ffi.ModelDesc()
+        d.dim = dim
+        d.target = target.tid
+        d.target_params, d.n_target_params = arr(target.params)
+        d.metric_kind = metric_kind
+        d.metric, d.n_metric = arr(metric)
+        d.rmetric = rmetric
+        d.rmetric_params, d.n_rmetric_params = arr(rmetric_params)
+        d.constr = constr
+        d.constr_params, d.n_constr_params = arr(constr_params)
+        h = C.c_void_p()
+        _ffi.check(self._lib.mm_model_create(ctx.handle, C.byref(d), C.byref(h)), ctx.handle,
+                   "mm_model_create")
+        self.handle = h
+        self.dim = dim
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            self._lib.mm_model_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBatch:
+    """N chains resident in HBM: pos[N,D], mom[N,D] (fp64, row-major), dir[N] (int8)."""
+
+    def __init__(self, ctx, n_chains, dim):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        h = C.c_void_p()
+        _ffi.check(self._lib.mm_state_alloc(ctx.handle, int(n_chains), int(dim), C.byref(h)),
+                   ctx.handle, "mm_state_alloc")
+        self.handle = h
+        self.n_chains = int(n_chains)
+        self.dim = int(dim)
+
+    @staticmethod
+    def _mat(a, n, d, name):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != (n, d):
+            raise ValueError(f"{name} must have shape ({n}, {d}), got {a.shape}")
+        return a
+
+    def upload(self, pos=None, mom=None, dir=None):  # noqa: A002
+        pos = self._mat(pos, self.n_chains, self.dim, "pos")
+        mom = self._mat(mom, self.n_chains, self.dim, "mom")
+        if dir is not None:
+            dir = np.ascontiguousarray(np.broadcast_to(np.asarray(dir), (self.n_chains,)),  # noqa: A001
+                                       dtype=np.int8)
+            if not np.all(np.abs(dir) == 1):
+                raise ValueError("dir entries must be +1 or -1")
+        _ffi.check(self._lib.mm_state_upload(
+            self.handle, None if pos is None else _dptr(pos), None if mom is None else _dptr(mom),
+            None if dir is None else dir.ctypes.data_as(_ffi.c_int8_p)), self.ctx.handle,
+            "mm_state_upload")
+
+    def download(self):
+        pos = np.empty((self.n_chains, self.dim))
+        mom = np.empty((self.n_chains, self.dim))
+        dir_ = np.empty(self.n_chains, dtype=np.int8)
+        _ffi.check(self._lib.mm_state_download(self.handle, _dptr(pos), _dptr(mom),
+                                               dir_.ctypes.data_as(_ffi.c_int8_p)),
+                   self.ctx.handle, "mm_state_download")
+        return pos, mom, dir_
+
+    def download_status(self):
+        status = np.zeros(self.n_chains, dtype=np.int32)
+        n_done = np.zeros(self.n_chains, dtype=np.int32)
+        _ffi.check(self._lib.mm_state_download_status(
+            self.handle, status.ctypes.data_as(_ffi.c_int32_p),
+            n_done.ctypes.data_as(_ffi.c_int32_p)), self.ctx.handle, "mm_state_download_status")
+        return status, n_done
+
+    def device_ptrs(self):
+        p, m, d = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _ffi.check(self._lib.mm_state_device_ptrs(self.handle, C.byref(p), C.byref(m), C.byref(d)),
+                   self.ctx.handle, "mm_state_device_ptrs")
+        return p.value, m.value, d.value
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            self._lib.mm_state_free(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,210 @@
+"""Hamiltonian systems: the reference's ``System`` surface (mici/systems.py) over device models.
+
+Constructor argument names follow the reference (``neg_log_dens``, ``metric``, ``metric_func``,
+``constr``, ``softabs_coeff`` ...), but where the reference takes Python callables these classes take
+the built-in descriptors of :mod:`mici_amd.models` - derivatives are closed forms on the device, so
+``grad_neg_log_dens`` / ``vjp_metric_func`` / ``jacob_constr`` / ``backend`` must be left ``None``.
+
+Methods used by mici.transitions / samplers (``h``, ``dh_dmom``, ``sample_momentum``;
+transitions.py:141-195, 281-301, 434-473) accept a single ``ChainState`` (mici's or ours) or, via
+the ``*_batch`` variants, arrays of shape [N, D]."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi, models
+from .runtime import DeviceBatch, DeviceModel, default_context
+
+
+class System:
+    """Base: owns the model description; device handles are created lazily per context."""
+
+    _kind = "euclid"
+
+    def __init__(self, neg_log_dens, grad_neg_log_dens=None, backend=None):
+        if not isinstance(neg_log_dens, models.Target):
+            raise TypeError(
+                "neg_log_dens must be a built-in mici_amd.models.Target descriptor: the device "
+                "integrators need device-side closed-form derivatives (SURVEY.md H4)")
+        if grad_neg_log_dens is not None or backend is not None:
+            raise ValueError("derivatives are supplied by the device model; leave "
+                             "grad_neg_log_dens / backend as None")
+        self.target = neg_log_dens
+        self.dim = neg_log_dens.dim
+        self._device = {}
+
+    # ---- description -> device model --------------------------------------------------------
+    def _model_args(self):
+        return {}
+
+    def device_model(self, ctx=None):
+        ctx = ctx or default_context()
+        m = self._device.get(id(ctx))
+        if m is None or m.handle is None:
+            m = self._device[id(ctx)] = DeviceModel(ctx, self.dim, self.target, **self._model_args())
+        return m
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_device"] = {}  # device handles are re-created lazily after unpickling
+        return d
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = object.__new__(type(self))
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == "_device" else copy.deepcopy(v, memo)
+        return new
+
+    # ---- batched quantities ---------------------------------------------------------------------
+    def _batch(self, pos, mom, ctx=None):
+        ctx = ctx or default_context()
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        if pos.ndim != 2 or pos.shape[1] != self.dim:
+            raise ValueError(f"pos must have shape [N, {self.dim}]")
+        batch = DeviceBatch(ctx, pos.shape[0], self.dim)
+        batch.upload(pos, mom, None)
+        return ctx, batch
+
+    def h_batch(self, pos, mom, ctx=None):
+        """``System.h`` for N chains -> [N] (NaN where the reference would raise LinAlgError)."""
+        ctx, batch = self._batch(pos, mom, ctx)
+        out = np.empty(batch.n_chains)
+        _ffi.check(ctx._lib.mm_hamiltonian(ctx.handle, self.device_model(ctx).handle, batch.handle,
+                                           out.ctypes.data_as(_ffi.c_double_p)), ctx.handle,
+                   "mm_hamiltonian")
+        batch.close()
+        return out
+
+    def dh_dmom_batch(self, pos, mom, ctx=None):
+        ctx, batch = self._batch(pos, mom, ctx)
+        out = np.empty((batch.n_chains, self.dim))
+        _ffi.check(ctx._lib.mm_dh_dmom(ctx.handle, self.device_model(ctx).handle, batch.handle,
+                                       out.ctypes.data_as(_ffi.c_double_p)), ctx.handle,
+                   "mm_dh_dmom")
+        batch.close()
+        return out
+
+    def sample_momentum_batch(self, pos, z, ctx=None):
+        """mom = M^{1/2} z (then cotangent projection for constrained systems); z ~ N(0, I) is
+        drawn by the caller's NumPy Generator."""
+        ctx, batch = self._batch(pos, np.zeros_like(np.asarray(pos, dtype=np.float64)), ctx)
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        if z.shape != (batch.n_chains, self.dim):
+            raise ValueError("z must have the shape of pos")
+        _ffi.check(ctx._lib.mm_sample_momentum(ctx.handle, self.device_model(ctx).handle,
+                                               batch.handle, z.ctypes.data_as(_ffi.c_double_p)),
+                   ctx.handle, "mm_sample_momentum")
+        _, mom, _ = batch.download()
+        batch.close()
+        return mom
+
+    # ---- single-state surface used by mici.transitions ----------------------------------------------
+    def h(self, state):
+        val = self.h_batch(np.asarray(state.pos)[None], np.asarray(state.mom)[None])[0]
+        if np.isnan(val) and np.all(np.isfinite(state.pos)) and np.all(np.isfinite(state.mom)):
+            from .errors import LinAlgError
+            raise LinAlgError("Cholesky factorisation failed.")
+        return float(val)
+
+    def dh_dmom(self, state):
+        return self.dh_dmom_batch(np.asarray(state.pos)[None], np.asarray(state.mom)[None])[0]
+
+    def dh2_dmom(self, state):
+        return self.dh_dmom(state)
+
+    def sample_momentum(self, state, rng):
+        z = rng.standard_normal(np.asarray(state.pos).shape)
+        return self.sample_momentum_batch(np.asarray(state.pos)[None], z[None])[0]
+
+
+class EuclideanMetricSystem(System):
+    """Fixed-metric system, h2 = p^T M^-1 p / 2 (reference systems.py:264-366)."""
+
+    _kind = "euclid"
+
+    def __init__(self, neg_log_dens, *, metric=None, grad_neg_log_dens=None, backend=None):
+        super().__init__(neg_log_dens, grad_neg_log_dens, backend)
+        if metric is None:
+            self.metric_kind, self.metric = models.METRIC_IDENTITY, None
+        else:
+            metric = np.asarray(metric, dtype=np.float64)
+            if metric.ndim == 1:
+                self.metric_kind = models.METRIC_DIAG
+            elif metric.ndim == 2:
+                self.metric_kind = models.METRIC_DENSE
+            else:
+                raise ValueError("If NumPy ndarray value is used for `metric` must be either 1D "
+                                 "(diagonal matrix) or 2D (dense positive definite matrix).")
+            if metric.shape[0] != self.dim or metric.shape[-1] != self.dim:
+                raise ValueError("metric shape does not match the target dimension")
+            self.metric = metric
+
+    def _model_args(self):
+        return dict(metric_kind=self.metric_kind, metric=self.metric)
+
+
+class DenseRiemannianMetricSystem(System):
+    """Position-dependent dense metric M(q) (reference systems.py:1690-1734, 1187-1402)."""
+
+    _kind = "riemann"
+
+    def __init__(self, neg_log_dens, metric_func, *, vjp_metric_func=None, grad_neg_log_dens=None,
+                 backend=None):
+        super().__init__(neg_log_dens, grad_neg_log_dens, backend)
+        if not isinstance(metric_func, models.RiemannianMetric):
+            raise TypeError("metric_func must be a built-in mici_amd.models.RiemannianMetric")
+        if vjp_metric_func is not None:
+            raise ValueError("vjp_metric_func is supplied by the device model; leave it None")
+        if metric_func.dim != self.dim:
+            raise ValueError("metric_func dimension does not match the target dimension")
+        self.rmetric = metric_func
+
+    def _model_args(self):
+        return dict(rmetric=self.rmetric.mid, rmetric_params=self.rmetric.params)
+
+
+class SoftAbsRiemannianMetricSystem(System):
+    """SoftAbs-regularised Hessian metric (reference systems.py:1737-1920)."""
+
+    _kind = "riemann"
+
+    def __init__(self, neg_log_dens, *, grad_neg_log_dens=None, hess_neg_log_dens=None,
+                 mtp_neg_log_dens=None, softabs_coeff=1.0, backend=None):
+        super().__init__(neg_log_dens, grad_neg_log_dens, backend)
+        if hess_neg_log_dens is not None or mtp_neg_log_dens is not None:
+            raise ValueError("Hessian / MTP are supplied by the device model; leave them None")
+        if softabs_coeff <= 0:
+            raise ValueError("softabs_coeff must be positive.")
+        self.softabs_coeff = float(softabs_coeff)
+
+    def _model_args(self):
+        return dict(rmetric=models.RMETRIC_SOFTABS, rmetric_params=[self.softabs_coeff])
+
+
+class DenseConstrainedEuclideanMetricSystem(EuclideanMetricSystem):
+    """Euclidean-metric system on the manifold {q : constr(q) = 0}, density w.r.t. the Hausdorff
+    measure (reference systems.py:876-1031, 619-873; ``dens_wrt_hausdorff=True``)."""
+
+    _kind = "constrained"
+
+    def __init__(self, neg_log_dens, constr, *, metric=None, dens_wrt_hausdorff=True,
+                 grad_neg_log_dens=None, jacob_constr=None, mhp_constr=None, backend=None):
+        super().__init__(neg_log_dens, metric=metric, grad_neg_log_dens=grad_neg_log_dens,
+                         backend=backend)
+        if not isinstance(constr, models.Constraint):
+            raise TypeError("constr must be a built-in mici_amd.models.Constraint")
+        if jacob_constr is not None or mhp_constr is not None:
+            raise ValueError("constraint derivatives are supplied by the device model")
+        if not dens_wrt_hausdorff:
+            raise NotImplementedError(
+                "dens_wrt_hausdorff=False (Gram log-det term) is outside the accelerated path")
+        self.constraint = constr
+
+    def _model_args(self):
+        args = super()._model_args()
+        args.update(constr=self.constraint.cid, constr_params=self.constraint.params)
+        return args
