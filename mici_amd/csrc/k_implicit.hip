@@ -1,0 +1,680 @@
+// Implicit (generalised) leapfrog on dense-metric Riemannian systems, one 64-lane wave per chain,
+// D <= 64 (gfx950 / CDNA4).
+//
+// Replaces, per chain and per step (reference /root/reference/src/mici):
+//   ImplicitLeapfrogIntegrator._step / _step_a / _step_b_fwd / _step_b_adj / _step_c_fwd / _step_c_adj
+//                                        integrators.py:493-544  (all six sub-maps use the FULL t: H1)
+//   solve_fixed_point_direct / _steffensen solvers.py:47-94, 97-154 (+ maximum/euclidean norm :20-27)
+//   RiemannianMetricSystem.dh1_dpos / dh2_dpos / dh2_dmom / h / sample_momentum  systems.py:1375-1402
+//   DensePositiveDefiniteMatrix: factorisation, explicit inverse, log|det|, grad_log_abs_det,
+//       grad_quadratic_form_inv            matrices.py:1161-1188, 1175-1181, 982-984
+//
+// Data layout.  The D x D metric of a chain is held ENTIRELY IN REGISTERS of its wave, distributed
+// 2-D block-cyclically: lane (ti, tj) = (lane>>3, lane&7) owns the TS x TS entries
+// {(ti + 8a, tj + 8b)}, TS = ceil(D/8) <= 8 (128 VGPRs at D = 64).  With this layout
+//   * one step of the symmetric sweep operator (Gauss-Jordan on an SPD matrix, which keeps the matrix
+//     symmetric so "column k" and "row k" are the same vector) is a rank-1 update in which every lane
+//     does TS*TS independent v_fma_f64 from 2*TS operands -> VALU bound, no triangular structure, no
+//     sqrt, no back-substitution; 64 sweeps give -M^-1 and the pivots give log det M;
+//   * M^-1 v is a TS x TS register mat-vec plus a 3-stage xor-shuffle reduction over the 8 lanes of a
+//     row group.
+// The published pivot column and all D-vectors move through a few hundred bytes of per-wave LDS;
+// the shared base matrix of the rank-one metric sits in LDS once per workgroup.  Each wave iterates
+// its own fixed-point solves, so data-dependent iteration counts and failures need no masking: a
+// failed chain's wave simply stops (status / n_done, chain frozen at its last good state).
+#include "mm_device.h"
+
+namespace {
+
+using namespace mmdev;
+
+constexpr int kWaves = 4;  // chains per workgroup
+
+struct ImplicitArgs {
+  double* pos;
+  double* mom;
+  const int8_t* dir;
+  int32_t* status;
+  int32_t* n_done;
+  int64_t n_chains;
+  int dim;
+  double step_size;
+  int n_steps;
+  int target;
+  const double* tparams;
+  const double* rparams;
+  mm_fp_opts opts;
+  mm_counters* counters;
+  // aux ops
+  double* out;
+  const double* z;
+};
+
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
+// Per-wave LDS scratch (doubles): 5 vectors of 64.
+struct WaveLds {
+  double* col;  // published sweep column (permuted order)
+  double* vin;  // mat-vec input  (permuted order)
+  double* vout; // mat-vec output (permuted order)
+  double* nat;  // natural-order vector for target derivatives
+  double* aux;  // natural-order spare (z for sample_momentum)
+};
+
+template <int TS>
+struct Geo {
+  static constexpr int DP = 8 * TS;                    // padded dimension
+  static constexpr int TSTRIDE = TS * TS + 2;          // per-lane stride of the shared base matrix
+  // position of flat element i in a permuted LDS vector: group (i & 7) holds TS consecutive values
+  __device__ static __forceinline__ int pos(int i) { return (i & 7) * TS + (i >> 3); }
+};
+
+// ---- symmetric sweep: T <- M^-1, returns false if a pivot is not > 0 (== Cholesky would fail) ------
+template <int TS, bool LOGDET, bool CHOLVEC>
+__device__ __forceinline__ bool sweep_inverse(double (&T)[TS][TS], int dim, int lane,
+                                              const WaveLds& w, double* logdet, double* chol_y) {
+  const int ti = lane >> 3, tj = lane & 7;
+  bool ok = true;
+  double ld = 0.0, y = 0.0;
+#pragma unroll
+  for (int kb = 0; kb < TS; ++kb) {
+    for (int kt = 0; kt < 8; ++kt) {
+      const int k = kb * 8 + kt;
+      if (k >= dim) break;
+      // owners of column k publish it (rows ti + 8a live at [a][kb] of lanes with tj == kt)
+      if (tj == kt) {
+#pragma unroll
+        for (int a = 0; a < TS; ++a) w.col[ti * TS + a] = T[a][kb];
+      }
+      wave_sync();
+      const double piv = w.col[kt * TS + kb];
+      ok = ok && (piv > 0.0);
+      const double d = fast_rcp(piv);
+      if constexpr (LOGDET) ld += log(piv);
+      if constexpr (CHOLVEC) {
+        // y += L[:, k] z_k with L[i, k] = a_ik / sqrt(a_kk) for i >= k (Cholesky column from the sweep)
+        const double rs = 1.0 / sqrt(piv);
+        const double zk = w.aux[k];
+        if (lane >= k && lane < dim) y += (w.col[Geo<TS>::pos(lane)] * rs) * zk;
+      }
+      double ar[TS], ac[TS];
+#pragma unroll
+      for (int a = 0; a < TS; ++a) {
+        ar[a] = w.col[ti * TS + a];
+        ac[a] = w.col[tj * TS + a];
+      }
+      // special entries that make one uniform FMA do the whole sweep step:
+      //   col factor  c_k   = a_kk - 1,   row multiplier m_k = 1 - d,   m_i = a_i d otherwise
+#pragma unroll
+      for (int a = 0; a < TS; ++a) ar[a] *= d;
+      if (ti == kt) ar[kb] = 1.0 - d;
+      if (tj == kt) ac[kb] = piv - 1.0;
+#pragma unroll
+      for (int a = 0; a < TS; ++a)
+#pragma unroll
+        for (int b = 0; b < TS; ++b) T[a][b] = __builtin_fma(-ar[a], ac[b], T[a][b]);
+      if (ti == kt && tj == kt) T[kb][kb] -= 2.0;
+      wave_sync();
+    }
+  }
+  // T now holds -M^-1 on the leading dim x dim block (padding rows/cols untouched)
+#pragma unroll
+  for (int a = 0; a < TS; ++a)
+#pragma unroll
+    for (int b = 0; b < TS; ++b) T[a][b] = -T[a][b];
+  if constexpr (LOGDET) *logdet = ld;
+  if constexpr (CHOLVEC) *chol_y = y;
+  // every lane saw the same pivots, so `ok` is wave-uniform
+  return ok;
+}
+
+// ---- y = T x with x, y "flat" (element i on lane i) ----------------------------------------------------
+template <int TS>
+__device__ __forceinline__ double matvec_flat(const double (&T)[TS][TS], double x, int lane,
+                                              const WaveLds& w) {
+  const int ti = lane >> 3, tj = lane & 7;
+  if (lane < Geo<TS>::DP) w.vin[Geo<TS>::pos(lane)] = x;
+  wave_sync();
+  double xc[TS], part[TS];
+#pragma unroll
+  for (int b = 0; b < TS; ++b) xc[b] = w.vin[tj * TS + b];
+#pragma unroll
+  for (int a = 0; a < TS; ++a) {
+    double s = 0.0;
+#pragma unroll
+    for (int b = 0; b < TS; ++b) s = __builtin_fma(T[a][b], xc[b], s);
+    part[a] = s;
+  }
+#pragma unroll
+  for (int a = 0; a < TS; ++a) {
+    part[a] += __shfl_xor(part[a], 1, 64);
+    part[a] += __shfl_xor(part[a], 2, 64);
+    part[a] += __shfl_xor(part[a], 4, 64);
+  }
+  if (tj == 0) {
+#pragma unroll
+    for (int a = 0; a < TS; ++a) w.vout[ti * TS + a] = part[a];
+  }
+  wave_sync();
+  const double y = (lane < Geo<TS>::DP) ? w.vout[Geo<TS>::pos(lane)] : 0.0;
+  wave_sync();
+  return y;
+}
+
+// diagonal of T in flat form
+template <int TS>
+__device__ __forceinline__ double diag_flat(const double (&T)[TS][TS], int lane, const WaveLds& w) {
+  const int ti = lane >> 3, tj = lane & 7;
+  if (ti == tj) {
+#pragma unroll
+    for (int a = 0; a < TS; ++a) w.vout[ti * TS + a] = T[a][a];
+  }
+  wave_sync();
+  const double y = (lane < Geo<TS>::DP) ? w.vout[Geo<TS>::pos(lane)] : 0.0;
+  wave_sync();
+  return y;
+}
+
+// ---- metric_func(q) into the register tiles (padding: identity) ---------------------------------------
+// returns false if an entry is not finite ("Array is not finite.", matrices.py:211-215)
+template <int TS, int RMETRIC>
+__device__ __forceinline__ bool build_metric(double (&T)[TS][TS], double q, int dim, int lane,
+                                             const WaveLds& w, const double* base_lds) {
+  const int ti = lane >> 3, tj = lane & 7;
+  if (lane < Geo<TS>::DP) w.vin[Geo<TS>::pos(lane)] = q;
+  wave_sync();
+  double qr[TS], qc[TS];
+#pragma unroll
+  for (int a = 0; a < TS; ++a) {
+    qr[a] = w.vin[ti * TS + a];
+    qc[a] = w.vin[tj * TS + a];
+  }
+  // Padded rows / columns: q is 0 there and the staged base matrix is 0, so the closed form gives 0
+  // off the diagonal; the diagonal of the padding is set to 1 afterwards (identity block).
+  bool finite = true;
+  const double inv_d = 1.0 / (double)dim;
+#pragma unroll
+  for (int a = 0; a < TS; ++a)
+#pragma unroll
+    for (int b = 0; b < TS; ++b) {
+      double v;
+      if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+        v = base_lds[lane * Geo<TS>::TSTRIDE + a * TS + b] + (qr[a] * qc[b]) * inv_d;
+      } else {  // MM_RMETRIC_DIAGQUAD: only diagonal lanes / diagonal tile entries are non-zero
+        v = 0.0;
+      }
+      T[a][b] = v;
+    }
+  if (ti == tj) {
+#pragma unroll
+    for (int a = 0; a < TS; ++a) {
+      if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) T[a][a] = __builtin_fma(qr[a], qr[a], 1.0);
+      if (ti + 8 * a >= dim) T[a][a] = 1.0;
+    }
+  }
+  // "Array is not finite." (matrices.py:211-215): x * 0 is NaN exactly for inf / NaN entries
+  double chk = 0.0;
+#pragma unroll
+  for (int a = 0; a < TS; ++a)
+#pragma unroll
+    for (int b = 0; b < TS; ++b) chk = __builtin_fma(T[a][b], 0.0, chk);
+  finite = (chk == 0.0);
+  wave_sync();
+  return __all(finite);
+}
+
+// 0.5 * vjp_metric(V) for the symmetric explicit matrix V held in tiles (general-VJP path):
+//   rank-one metric: (V + V^T) q / (2D) = V q / D ;  diag-quad metric: q_i V_ii
+template <int TS, int RMETRIC>
+__device__ __forceinline__ double half_vjp_tiles(const double (&V)[TS][TS], double q, int dim,
+                                                 int lane, const WaveLds& w) {
+  if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+    return matvec_flat<TS>(V, q, lane, w) / (double)dim;
+  } else {
+    return q * diag_flat<TS>(V, lane, w);
+  }
+}
+
+// 0.5 * vjp_metric(-u u^T)  (dh2_dpos, systems.py:1392-1396 with matrices.py:1179-1181)
+template <int RMETRIC>
+__device__ __forceinline__ double half_vjp_neg_outer(double u, double q, int dim, int lane) {
+  if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+    const double uq = wave_sum(lane < dim ? u * q : 0.0);
+    return -(u * uq) / (double)dim;
+  } else {
+    return -q * (u * u);
+  }
+}
+
+__device__ __forceinline__ double flat_norm(double x, int dim, int lane, int kind) {
+  const double acc = wave_norm_accum(0.0, lane < dim ? x : 0.0, kind);
+  return wave_norm_finish(acc, kind);
+}
+
+// Fixed-point solvers as a resumable state machine (solvers.py:47-94 direct, :97-154 Steffensen):
+// the caller evaluates f at the requested point and feeds the value back.  This keeps ONE call site
+// for the expensive function evaluation (metric construction) in the kernel.
+struct FpState {
+  double x0, x1;
+  int iter, stage;
+};
+enum { FP_CONT = 0, FP_DONE = 1, FP_FAIL = 2 };
+
+__device__ __forceinline__ FpState fp_begin(double x_init) { return FpState{x_init, 0.0, 0, 0}; }
+
+// fx = f(point last requested).  FP_CONT: evaluate f at *out next; FP_DONE: *out is the solution;
+// FP_FAIL: *status says why (diverged / max_iters).
+__device__ __forceinline__ int fp_feed(FpState& s, double fx, const mm_fp_opts& o, int dim, int lane,
+                                       double* out, int* status) {
+  double x;
+  if (o.solver == MM_FP_DIRECT) {
+    x = fx;
+  } else {
+    if (s.stage == 0) {
+      s.x1 = fx;
+      s.stage = 1;
+      *out = fx;
+      return FP_CONT;
+    }
+    double denom = fx - 2.0 * s.x1 + s.x0;
+    if (fabs(denom) == 0.0) denom = 2.220446049250313e-16;  // np.finfo(float64).eps
+    x = s.x0 - (s.x1 - s.x0) * (s.x1 - s.x0) / denom;
+    s.stage = 0;
+  }
+  const double err = flat_norm(x - s.x0, dim, lane, o.norm);
+  if (err > o.div_tol || err != err) {
+    *status = MM_ST_DIVERGED;
+    return FP_FAIL;
+  }
+  *out = x;
+  if (err < o.conv_tol) return FP_DONE;
+  s.x0 = x;
+  if (++s.iter >= o.max_iters) {
+    *status = MM_ST_MAX_ITERS;
+    return FP_FAIL;
+  }
+  return FP_CONT;
+}
+
+template <int TS>
+__device__ __forceinline__ double grad_flat(int target, double q, int dim, int lane,
+                                            const WaveLds& w, const double* tparams) {
+  if (lane < 64) w.nat[lane] = (lane < dim) ? q : 0.0;
+  wave_sync();
+  const TargetAux aux = target_prepare(target, w.nat, dim, tparams, lane);
+  const double g = (lane < dim) ? target_grad_elem(target, aux, w.nat, lane, dim, tparams) : 0.0;
+  wave_sync();
+  return g;
+}
+
+template <int TS, int RMETRIC>
+__device__ __forceinline__ void stage_base(double* base_lds, const double* rparams, int dim) {
+  if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+    // base_lds[lane][a][b] = B[ti + 8a][tj + 8b], lane stride padded by 16 B against bank conflicts
+    for (int idx = threadIdx.x; idx < 64 * TS * TS; idx += blockDim.x) {
+      const int l = idx / (TS * TS), r = idx - l * (TS * TS), a = r / TS, b = r - a * TS;
+      const int i = (l >> 3) + 8 * a, j = (l & 7) + 8 * b;
+      base_lds[l * Geo<TS>::TSTRIDE + r] = (i < dim && j < dim) ? rparams[(int64_t)i * dim + j] : 0.0;
+    }
+  }
+  __syncthreads();
+}
+
+// momentum-space fixed point  x = base + sgn_t * dh2_dpos(q, x)  with the metric fixed (B / B-check)
+template <int TS, int RMETRIC>
+__device__ __forceinline__ int momentum_solve(const double (&T)[TS][TS], double base, double tt,
+                                              double q, const mm_fp_opts& o, int dim, int lane,
+                                              const WaveLds& w, double* result, long long* n_evals) {
+  FpState st = fp_begin(base);
+  double pt = base;
+  int status = MM_ST_OK;
+  for (;;) {
+    const double u = matvec_flat<TS>(T, pt, lane, w);
+    const double fx = base - tt * half_vjp_neg_outer<RMETRIC>(u, q, dim, lane);
+    *n_evals += 1;
+    const int act = fp_feed(st, fx, o, dim, lane, &pt, &status);
+    if (act == FP_DONE) break;
+    if (act == FP_FAIL) return status;
+  }
+  *result = pt;
+  return MM_ST_OK;
+}
+
+enum { MODE_INIT = 0, MODE_CFIRST = 1, MODE_CHK = 2, MODE_ADJ = 3, MODE_BADJ = 4 };
+
+template <int TS, int RMETRIC>
+__global__ __launch_bounds__(64 * kWaves) void implicit_leapfrog_kernel(ImplicitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* base_lds = lds;
+  const int base_elems = (RMETRIC == MM_RMETRIC_RANK1) ? 64 * Geo<TS>::TSTRIDE : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* wl = lds + base_elems + wave * 5 * 64;
+  const WaveLds w{wl, wl + 64, wl + 128, wl + 192, wl + 256};
+  stage_base<TS, RMETRIC>(base_lds, A.rparams, A.dim);
+
+  const int64_t chain = (int64_t)blockIdx.x * kWaves + wave;
+  if (chain >= A.n_chains) return;  // no block-level barrier below this point
+  const int dim = A.dim;
+  const mm_fp_opts o = A.opts;
+  const bool act = lane < dim;
+  double q = act ? A.pos[chain * dim + lane] : 0.0;
+  double p = act ? A.mom[chain * dim + lane] : 0.0;
+  const double t = (double)A.dir[chain] * A.step_size;
+
+  long long n_evals = 0, n_solves = 0, n_metric = 0, n_grad = 0;
+  int status = MM_ST_OK, done = 0;
+  double T[TS][TS];
+
+  // One loop, one metric-construction site.  `mode` says why the metric at `xq` is being built:
+  //   INIT   cold start at the initial position (LinAlgError outside a solver on failure)
+  //   CFIRST first evaluation shared by the C reversibility check and the C-adjoint solve
+  //   CHK    later iterations of the reversibility-check solve   (integrators.py:521-528)
+  //   ADJ    later iterations of the C-adjoint solve             (integrators.py:530-536)
+  //   BADJ   metric at the new position for B-adjoint + final A  (integrators.py:504-515, 544)
+  int mode = MODE_INIT;
+  double xq = q;
+  double g = 0.0, pw = 0.0, qw = 0.0, q_init = 0.0, ptA = 0.0;
+  FpState sC = fp_begin(0.0), sA = fp_begin(0.0);
+  int actA = FP_CONT, stA = MM_ST_OK;
+
+  while (A.n_steps > 0) {
+    bool okm = build_metric<TS, RMETRIC>(T, xq, dim, lane, w, base_lds);
+    okm = sweep_inverse<TS, false, false>(T, dim, lane, w, nullptr, nullptr) && okm;
+    n_metric += (mode == MODE_CFIRST) ? 2 : 1;  // the reference builds the shared one twice
+    if (!okm) {
+      status = (mode == MODE_INIT || mode == MODE_BADJ) ? MM_ST_LINALG : MM_ST_SOLVER_LINALG;
+      break;
+    }
+    if (mode == MODE_INIT || mode == MODE_BADJ) {
+      if (mode == MODE_BADJ) {
+        // ---- B adj: p -= t dh2_dpos(q', p) then reversibility check     integrators.py:504-515
+        const double p_init = pw;
+        const double u = matvec_flat<TS>(T, pw, lane, w);
+        pw = pw - t * half_vjp_neg_outer<RMETRIC>(u, qw, dim, lane);
+        double p_back;
+        ++n_solves;
+        status = momentum_solve<TS, RMETRIC>(T, pw, -t, qw, o, dim, lane, w, &p_back, &n_evals);
+        if (status != MM_ST_OK) break;
+        if (flat_norm(p_back - p_init, dim, lane, o.rev_norm) > o.rev_tol) {
+          status = MM_ST_NON_REVERSIBLE;
+          break;
+        }
+        // ---- A: p -= t dh1_dpos(q')                                      integrators.py:544
+        g = grad_flat<TS>(A.target, qw, dim, lane, w, A.tparams);
+        ++n_grad;
+        pw = pw - t * (g + half_vjp_tiles<TS, RMETRIC>(T, qw, dim, lane, w));
+        q = qw;
+        p = pw;
+        if (++done == A.n_steps) break;
+      } else {
+        g = grad_flat<TS>(A.target, q, dim, lane, w, A.tparams);
+        ++n_grad;
+      }
+      // ---- A: p -= t dh1_dpos(q), dh1 = grad + 0.5 vjp(M^-1)            integrators.py:493-494
+      pw = p - t * (g + half_vjp_tiles<TS, RMETRIC>(T, q, dim, lane, w));
+      // ---- B fwd: solve p' = p - t dh2_dpos(q, p')                        integrators.py:496-502
+      ++n_solves;
+      status = momentum_solve<TS, RMETRIC>(T, pw, t, q, o, dim, lane, w, &pw, &n_evals);
+      if (status != MM_ST_OK) break;
+      // ---- C fwd: q += t M(q)^-1 p                                        integrators.py:517-519
+      q_init = q;
+      qw = q + t * matvec_flat<TS>(T, pw, lane, w);
+      xq = qw;
+      mode = MODE_CFIRST;
+      continue;
+    }
+    // position-space solves: f(x) = qw -/+ t M(x)^-1 p with M(xq)^-1 now in the tiles
+    const double u = matvec_flat<TS>(T, pw, lane, w);
+    bool chk_done = false, adj_done = false;
+    double q_back = 0.0;
+    if (mode == MODE_CFIRST) {
+      n_solves += 2;
+      n_evals += 2;
+      sC = fp_begin(qw);
+      sA = fp_begin(qw);
+      double ptC;
+      int stC = MM_ST_OK;
+      const int actC = fp_feed(sC, qw - t * u, o, dim, lane, &ptC, &stC);
+      actA = fp_feed(sA, qw + t * u, o, dim, lane, &ptA, &stA);
+      if (actC == FP_FAIL) {
+        status = stC;
+        break;
+      }
+      if (actC == FP_DONE) {
+        chk_done = true;
+        q_back = ptC;
+      } else {
+        xq = ptC;
+        mode = MODE_CHK;
+        continue;
+      }
+    } else if (mode == MODE_CHK) {
+      ++n_evals;
+      double pt;
+      int st = MM_ST_OK;
+      const int a = fp_feed(sC, qw - t * u, o, dim, lane, &pt, &st);
+      if (a == FP_FAIL) {
+        status = st;
+        break;
+      }
+      if (a == FP_CONT) {
+        xq = pt;
+        continue;
+      }
+      chk_done = true;
+      q_back = pt;
+    } else {  // MODE_ADJ
+      ++n_evals;
+      double pt;
+      int st = MM_ST_OK;
+      const int a = fp_feed(sA, qw + t * u, o, dim, lane, &pt, &st);
+      if (a == FP_FAIL) {
+        status = st;
+        break;
+      }
+      if (a == FP_CONT) {
+        xq = pt;
+        continue;
+      }
+      adj_done = true;
+      ptA = pt;
+    }
+    if (chk_done) {
+      if (flat_norm(q_back - q_init, dim, lane, o.rev_norm) > o.rev_tol) {
+        status = MM_ST_NON_REVERSIBLE;  // integrators.py:523-528
+        break;
+      }
+      // the C-adjoint solve resumes from its (already fed) first evaluation
+      if (actA == FP_FAIL) {
+        status = stA;
+        break;
+      }
+      if (actA == FP_DONE) {
+        adj_done = true;
+      } else {
+        xq = ptA;
+        mode = MODE_ADJ;
+        continue;
+      }
+    }
+    if (adj_done) {
+      qw = ptA;  // state.pos = solution; metric cache dropped -> rebuilt for B adj
+      xq = qw;
+      mode = MODE_BADJ;
+    }
+  }
+  // a failed step leaves q, p at the last completed step (they are only overwritten on success)
+  if (act) {
+    A.pos[chain * dim + lane] = q;
+    A.mom[chain * dim + lane] = p;
+  }
+  if (lane == 0) {
+    A.status[chain] = status;
+    A.n_done[chain] = done;
+    if (A.counters) {
+      atomicAdd((unsigned long long*)&A.counters->n_grad, (unsigned long long)n_grad);
+      atomicAdd((unsigned long long*)&A.counters->n_metric, (unsigned long long)n_metric);
+      atomicAdd((unsigned long long*)&A.counters->n_inverse, (unsigned long long)n_metric);
+      atomicAdd((unsigned long long*)&A.counters->n_fp_evals, (unsigned long long)n_evals);
+      atomicAdd((unsigned long long*)&A.counters->n_fp_solves, (unsigned long long)n_solves);
+    }
+  }
+}
+
+// ---- System-level quantities for Riemannian systems: op 0 = h, 1 = dh_dmom, 2 = sample_momentum ------
+template <int TS, int RMETRIC, int OP>
+__global__ __launch_bounds__(64 * kWaves) void riemann_aux_kernel(ImplicitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* base_lds = lds;
+  const int base_elems = (RMETRIC == MM_RMETRIC_RANK1) ? 64 * Geo<TS>::TSTRIDE : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* wl = lds + base_elems + wave * 5 * 64;
+  const WaveLds w{wl, wl + 64, wl + 128, wl + 192, wl + 256};
+  stage_base<TS, RMETRIC>(base_lds, A.rparams, A.dim);
+  const int64_t chain = (int64_t)blockIdx.x * kWaves + wave;
+  if (chain >= A.n_chains) return;
+  const int dim = A.dim;
+  const bool act = lane < dim;
+  const double q = act ? A.pos[chain * dim + lane] : 0.0;
+  const double p = act ? A.mom[chain * dim + lane] : 0.0;
+  double T[TS][TS];
+  bool ok = build_metric<TS, RMETRIC>(T, q, dim, lane, w, base_lds);
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  if constexpr (OP == 0) {
+    double logdet;
+    ok = sweep_inverse<TS, true, false>(T, dim, lane, w, &logdet, nullptr) && ok;
+    const double u = matvec_flat<TS>(T, p, lane, w);
+    w.nat[lane] = act ? q : 0.0;
+    wave_sync();
+    const TargetAux aux = target_prepare(A.target, w.nat, dim, A.tparams, lane);
+    double e = act ? target_nld_elem(A.target, aux, w.nat, lane, dim, A.tparams) + 0.5 * p * u : 0.0;
+    e = wave_sum(e) + 0.5 * logdet;
+    if (lane == 0) A.out[chain] = ok ? e : nan;
+  } else if constexpr (OP == 1) {
+    ok = sweep_inverse<TS, false, false>(T, dim, lane, w, nullptr, nullptr) && ok;
+    const double u = matvec_flat<TS>(T, p, lane, w);
+    if (act) A.out[chain * dim + lane] = ok ? u : nan;
+  } else {
+    w.aux[lane] = act ? A.z[chain * dim + lane] : 0.0;
+    wave_sync();
+    double y;
+    ok = sweep_inverse<TS, false, true>(T, dim, lane, w, nullptr, &y) && ok;
+    if (act) A.mom[chain * dim + lane] = ok ? y : nan;
+  }
+}
+
+template <int TS, int RMETRIC>
+size_t lds_bytes() {
+  const size_t base = (RMETRIC == MM_RMETRIC_RANK1) ? 64 * Geo<TS>::TSTRIDE : 0;
+  return (base + kWaves * 5 * 64) * sizeof(double);
+}
+
+template <int TS, int RMETRIC>
+int launch_step(mm_ctx* ctx, const ImplicitArgs& a, int64_t n) {
+  const unsigned blocks = (unsigned)((n + kWaves - 1) / kWaves);
+  const size_t lds = lds_bytes<TS, RMETRIC>();
+  hipLaunchKernelGGL((implicit_leapfrog_kernel<TS, RMETRIC>), dim3(blocks), dim3(64 * kWaves), lds,
+                     ctx->stream, a);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
+template <int TS, int RMETRIC>
+int launch_aux(mm_ctx* ctx, const ImplicitArgs& a, int64_t n, int op) {
+  const unsigned blocks = (unsigned)((n + kWaves - 1) / kWaves);
+  const size_t lds = lds_bytes<TS, RMETRIC>();
+  if (op == 0)
+    hipLaunchKernelGGL((riemann_aux_kernel<TS, RMETRIC, 0>), dim3(blocks), dim3(64 * kWaves), lds, ctx->stream, a);
+  else if (op == 1)
+    hipLaunchKernelGGL((riemann_aux_kernel<TS, RMETRIC, 1>), dim3(blocks), dim3(64 * kWaves), lds, ctx->stream, a);
+  else
+    hipLaunchKernelGGL((riemann_aux_kernel<TS, RMETRIC, 2>), dim3(blocks), dim3(64 * kWaves), lds, ctx->stream, a);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
+template <class Fn>
+int dispatch(mm_ctx* ctx, const mm_model* m, Fn&& fn) {
+  const int ts = (m->dim + 7) / 8;
+#define MM_TS_CASE(TSV)                                                              \
+  if (ts <= TSV) {                                                                   \
+    if (m->rmetric == MM_RMETRIC_RANK1) return fn.template operator()<TSV, MM_RMETRIC_RANK1>(); \
+    return fn.template operator()<TSV, MM_RMETRIC_DIAGQUAD>();                       \
+  }
+  MM_TS_CASE(1)
+  MM_TS_CASE(2)
+  MM_TS_CASE(4)
+  MM_TS_CASE(8)
+#undef MM_TS_CASE
+  mm_set_error(ctx, "dense-Riemannian wave-per-chain kernels support dim <= 64");
+  return MM_ERR_UNSUPPORTED;
+}
+
+ImplicitArgs make_args(const mm_model* m, mm_state* s) {
+  ImplicitArgs a{};
+  a.pos = s->d_pos;
+  a.mom = s->d_mom;
+  a.dir = s->d_dir;
+  a.status = s->d_status;
+  a.n_done = s->d_n_done;
+  a.n_chains = s->n;
+  a.dim = s->dim;
+  a.target = m->target;
+  a.tparams = m->d_target_params;
+  a.rparams = m->d_rmetric_params;
+  return a;
+}
+
+struct StepFn {
+  mm_ctx* ctx;
+  ImplicitArgs a;
+  int64_t n;
+  template <int TS, int RM>
+  int operator()() { return launch_step<TS, RM>(ctx, a, n); }
+};
+struct AuxFn {
+  mm_ctx* ctx;
+  ImplicitArgs a;
+  int64_t n;
+  int op;
+  template <int TS, int RM>
+  int operator()() { return launch_aux<TS, RM>(ctx, a, n, op); }
+};
+
+}  // namespace
+
+int mm_launch_softabs_leapfrog(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
+                               mm_counters*);
+int mm_launch_softabs_aux(mm_ctx*, const mm_model*, mm_state*, int, double*, const double*);
+int mm_launch_implicit_large(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
+                             mm_counters*);
+int mm_launch_riemann_aux_large(mm_ctx*, const mm_model*, mm_state*, int, double*, const double*);
+
+int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                                const mm_fp_opts& opts, mm_counters* d_counters) {
+  if (m->rmetric == MM_RMETRIC_SOFTABS)
+    return mm_launch_softabs_leapfrog(ctx, m, s, h, n_steps, opts, d_counters);
+  if (m->dim > 64) return mm_launch_implicit_large(ctx, m, s, h, n_steps, opts, d_counters);
+  ImplicitArgs a = make_args(m, s);
+  a.step_size = h;
+  a.n_steps = n_steps;
+  a.opts = opts;
+  a.counters = d_counters;
+  return dispatch(ctx, m, StepFn{ctx, a, s->n});
+}
+
+int mm_launch_riemann_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* d_out,
+                          const double* d_z) {
+  if (m->rmetric == MM_RMETRIC_SOFTABS) return mm_launch_softabs_aux(ctx, m, s, op, d_out, d_z);
+  if (m->dim > 64) return mm_launch_riemann_aux_large(ctx, m, s, op, d_out, d_z);
+  ImplicitArgs a = make_args(m, s);
+  a.out = d_out;
+  a.z = d_z;
+  return dispatch(ctx, m, AuxFn{ctx, a, s->n, op});
+}

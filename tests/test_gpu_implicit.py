@@ -1,0 +1,169 @@
+"""GPU parity: implicit leapfrog on dense-Riemannian systems vs reference fixtures and the oracle.
+
+Tolerance: the solves stop at 1e-9 and the factorisation differs from LAPACK
+only in rounding, so with identical iteration counts positions/momenta agree to <= 1e-10 * max(1,|x|);
+status codes, completed-step counts and fixed-point evaluation counts must match exactly."""
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden_names, load_golden
+from oracle import integrators as orc
+from oracle import models as omdl
+
+from mici_amd import integrators, models, solvers, systems
+from mici_amd.errors import ConvergenceError, LinAlgError, NonReversibleStepError
+from mici_amd.states import ChainState
+
+pytestmark = pytest.mark.gpu
+
+DENSE = [n for n in golden_names("riemann")]
+SOLVER = {0: solvers.solve_fixed_point_direct, 1: solvers.solve_fixed_point_steffensen}
+NORM = {0: solvers.maximum_norm, 1: solvers.euclidean_norm}
+
+
+def build(g):
+    n, d = g["q0"].shape
+    target = models.target_from_id(g["target"], g["target_params"], d)
+    mid = int(g["rmetric"])
+    if mid == models.RMETRIC_SOFTABS:
+        system = systems.SoftAbsRiemannianMetricSystem(target, softabs_coeff=float(g["rmetric_params"][0]))
+    else:
+        system = systems.DenseRiemannianMetricSystem(
+            target, models.rmetric_from_id(mid, g["rmetric_params"], d))
+    integ = integrators.ImplicitLeapfrogIntegrator(
+        system, float(g["step_size"]), reverse_check_norm=NORM[int(g["norm"])],
+        fixed_point_solver=SOLVER[int(g["fp_solver"])],
+        fixed_point_solver_kwargs=dict(convergence_tol=float(g["fp_conv_tol"]),
+                                       divergence_tol=float(g["fp_div_tol"]),
+                                       max_iters=int(g["fp_max_iters"]), norm=NORM[int(g["norm"])]))
+    return system, integ
+
+
+@pytest.mark.parametrize("name", DENSE)
+def test_implicit_leapfrog_matches_reference_fixture(name):
+    g = load_golden(name)
+    system, integ = build(g)
+    n = g["q0"].shape[0]
+    s_max = int(g["checkpoints"].max())
+    for k, s in enumerate(int(s) for s in g["checkpoints"]):
+        q, p, status, n_done = integ.step_batch(g["q0"], g["p0"], g["dir"], n_steps=s)
+        assert_close(q, g["q_out"][k], 1e-10, f"{name} q@{s}")
+        assert_close(p, g["p_out"][k], 1e-10, f"{name} p@{s}")
+        if s == s_max:
+            assert np.array_equal(status, g["status"]), (status, g["status"])
+            assert np.array_equal(n_done, g["n_done"]), (n_done, g["n_done"])
+            c = integ.last_counters
+            assert c["n_fp_evals"] == int(g["count_fp_iters"])
+            # the reference run had the initial metric cached by its h0 evaluation (one per chain that
+            # got as far as building it)
+            assert c["n_metric"] >= int(g.get("count_metric", 0))
+        good = g["status"] == 0 if s == s_max else np.ones(n, bool)
+        finite = np.isfinite(g["h_out"][k])
+        h = system.h_batch(q, p)
+        sel = finite & np.isfinite(q).all(1)
+        assert_close(h[sel], g["h_out"][k][sel], 1e-9, f"{name} h@{s}")
+
+
+def test_single_state_step_raises_reference_exceptions():
+    g = load_golden("riemann_fail_mixed_diagquad_d5")
+    system, integ = build(g)
+    expect = {1: ConvergenceError, 2: ConvergenceError, 3: ConvergenceError,
+              4: NonReversibleStepError, 5: LinAlgError}
+    seen = set()
+    for c in range(g["q0"].shape[0]):
+        state = ChainState(pos=g["q0"][c].copy(), mom=g["p0"][c].copy(), dir=int(g["dir"][c]))
+        init = state.copy()
+        n_ok = 0
+        try:
+            for _ in range(int(g["checkpoints"].max())):
+                state = integ.step(state)
+                n_ok += 1
+            assert g["status"][c] == 0
+        except tuple(set(expect.values())) as e:
+            assert isinstance(e, expect[int(g["status"][c])])
+            seen.add(int(g["status"][c]))
+        assert n_ok == g["n_done"][c]
+        k = len(g["checkpoints"]) - 1
+        assert_close(state.pos, g["q_out"][k, c], 1e-10, "stepwise q")
+        assert np.array_equal(init.pos, g["q0"][c])
+    assert seen, "fixture should contain failing chains"
+    g = load_golden("riemann_fail_nonfinite_d8")
+    system, integ = build(g)
+    with pytest.raises(LinAlgError):  # metric overflow outside any solver (matrices.py:211-215)
+        integ.step(ChainState(pos=g["q0"][1].copy(), mom=g["p0"][1].copy(), dir=1))
+
+
+@pytest.mark.parametrize("dim,n,target_kind,metric_kind,h,steps", [
+    (64, 1024, "banana", "rank1", 0.02, 4),    # BASELINE config c3(a) at full size
+    (64, 64, "poly", "rank1", 0.05, 6),
+    (37, 21, "banana", "rank1", 0.02, 5),      # ragged: D not a multiple of 8
+    (13, 9, "poly", "diagquad", 0.1, 10),
+    (3, 5, "poly", "rank1", 0.1, 10),
+])
+def test_implicit_leapfrog_matches_oracle_and_is_reversible(dim, n, target_kind, metric_kind, h, steps):
+    rng = np.random.default_rng(99)
+    ot = {"banana": lambda: omdl.Banana(dim), "poly": lambda: omdl.Poly(dim, 1.0, 1.0 / 3.0)}[target_kind]()
+    om = {"rank1": lambda: omdl.Rank1Metric(omdl.make_spd(dim, rng)),
+          "diagquad": lambda: omdl.DiagQuadMetric(dim)}[metric_kind]()
+    counters = orc.Counters()
+    osys = orc.RiemannianSystem(ot, om, None, counters)
+    system = systems.DenseRiemannianMetricSystem(
+        models.target_from_id(ot.tid, ot.params(), dim), models.rmetric_from_id(om.mid, om.params(), dim))
+    integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+    q0 = rng.standard_normal((n, dim))
+    z = rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, z)
+    dirs = np.where(rng.uniform(size=n) < 0.5, -1, 1).astype(np.int8)
+    q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=steps)
+    dev_counts = dict(integ.last_counters)
+    assert np.all(status == 0) and np.all(n_done == steps)
+    sample = np.unique(np.concatenate([np.arange(min(n, 4)), [n - 1], rng.integers(0, n, 3)]))
+    for c in sample:
+        st = orc._State(q0[c], None)
+        assert_close(p0[c], osys.sample_momentum(st, z[c]), 1e-12, "sample_momentum")
+        qo, po, so, no = orc.implicit_leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, steps)
+        assert so == 0 and no == steps
+        assert_close(q[c], qo, 1e-10, f"q chain {c}")
+        assert_close(p[c], po, 1e-10, f"p chain {c}")
+    if len(sample) == n:  # whole batch run through the oracle: work counters must agree exactly
+        counters.clear()
+        for c in range(n):
+            orc.implicit_leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, steps)
+        assert dev_counts["n_fp_evals"] == counters["fp_iters"]
+        assert dev_counts["n_metric"] == counters["metric"]
+        assert dev_counts["n_grad"] == counters["grad"]
+    # reversibility at full size: flip direction and integrate back (tests/test_integrators.py:75-91)
+    qb, pb, sb, _ = integ.step_batch(q, p, -dirs, n_steps=steps)
+    assert np.all(sb == 0)
+    assert_close(qb, q0, 1e-6, "reversed q")
+    assert_close(pb, p0, 1e-6, "reversed p")
+    # dh_dmom and the Hamiltonian against the oracle on the sample
+    v = system.dh_dmom_batch(q, p)
+    hd = system.h_batch(q, p)
+    for c in sample:
+        st = orc._State(q[c], p[c])
+        assert_close(v[c], osys.dh2_dmom(st), 1e-10, "dh_dmom")
+        assert_close(hd[c], osys.h(st), 1e-10, "h")
+
+
+@pytest.mark.parametrize("size", [1, 2, 5])
+def test_energy_conservation_like_reference_property_test(size):
+    """tests/test_integrators.py:93-108 replayed with the reference's own seeded initial states
+    (:8, 43-48) on the dense twin of its DiagonalRiemannian test system (step 0.1, h_diff_tol 1e-3,
+    :492-508)."""
+    rng = np.random.default_rng(3046987125)
+    states = rng.standard_normal((5, 2, size))
+    q, p = np.ascontiguousarray(states[:, 0]), np.ascontiguousarray(states[:, 1])
+    system = systems.DenseRiemannianMetricSystem(models.Poly(size, 1.0, 1.0 / 3.0),
+                                                 models.DiagQuadMetric(size))
+    integ = integrators.ImplicitLeapfrogIntegrator(system, 0.1)
+    hs = [system.h_batch(q, p)]
+    alive = np.ones(5, bool)
+    for _ in range(200):
+        q, p, st, nd = integ.step_batch(q, p, 1, n_steps=1)
+        alive &= st == 0
+        hs.append(system.h_batch(q, p))
+    hs = np.array(hs)[:, alive]  # the reference returns early (passes) on an IntegratorError
+    diff = hs[:100].mean(0) - hs[100:].mean(0)
+    assert np.all(np.abs(diff) < 1e-3)
