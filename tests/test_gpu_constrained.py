@@ -1,0 +1,99 @@
+"""GPU parity: constrained leapfrog (Newton projection) vs reference fixtures and the oracle.
+Tolerance: solves stop at 1e-9 / 1e-8, so with equal iteration counts results agree to 1e-10;
+status and completed-step counts must match exactly."""
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden_names, load_golden
+from oracle import integrators as orc
+from oracle import models as omdl
+
+from mici_amd import integrators, models, systems
+from mici_amd.errors import ConvergenceError, NonReversibleStepError
+from mici_amd.states import ChainState
+
+pytestmark = pytest.mark.gpu
+
+
+def build(g):
+    n, d = g["q0"].shape
+    target = models.target_from_id(g["target"], g["target_params"], d)
+    constr = models.constr_from_id(g["constr"], g["constr_params"])
+    mk = int(g["metric_kind"])
+    metric = None if mk == models.METRIC_IDENTITY else g["metric"]
+    system = systems.DenseConstrainedEuclideanMetricSystem(target, constr, metric=metric)
+    integ = integrators.ConstrainedLeapfrogIntegrator(system, float(g["step_size"]),
+                                                      n_inner_step=int(g["n_inner"]))
+    return system, integ
+
+
+@pytest.mark.parametrize("name", golden_names("constrained"))
+def test_constrained_leapfrog_matches_reference_fixture(name):
+    g = load_golden(name)
+    system, integ = build(g)
+    s_max = int(g["checkpoints"].max())
+    for k, s in enumerate(int(s) for s in g["checkpoints"]):
+        q, p, status, n_done = integ.step_batch(g["q0"], g["p0"], g["dir"], n_steps=s)
+        # 1e-10 while roundoff-level differences have had <= 20 steps to grow; 5e-9 beyond that
+        # (<= 5e-9 when the nonlinear dynamics has amplified solver-level noise)
+        tol = 1e-10 if s <= 20 else 5e-9
+        assert_close(q, g["q_out"][k], tol, f"{name} q@{s}")
+        assert_close(p, g["p_out"][k], tol, f"{name} p@{s}")
+        if s == s_max:
+            assert np.array_equal(status, g["status"]), (status, g["status"])
+            assert np.array_equal(n_done, g["n_done"]), (n_done, g["n_done"])
+        h = system.h_batch(q, p)
+        assert_close(h, g["h_out"][k], 1e-10, f"{name} h@{s}")
+
+
+def test_torus_full_size_properties():
+    """BASELINE config c5 per-GPU shard (2048 chains), h = 0.1: constraint and cotangent residuals
+    (tests/test_integrators.py:159-197), reversibility, oracle on a sample."""
+    rng = np.random.default_rng(1234)
+    n, h, steps = 2048, 0.1, 50
+    target, constr = omdl.Torus(), omdl.TorusConstr()
+    osys = orc.ConstrainedSystem(target, constr)
+    system = systems.DenseConstrainedEuclideanMetricSystem(models.Torus(), models.TorusConstr())
+    integ = integrators.ConstrainedLeapfrogIntegrator(system, h)
+    q0 = omdl.torus_init(n, rng)
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, 3)))
+    jac0 = np.stack([constr.jacob_constr(x)[0] for x in q0])
+    assert np.max(np.abs(np.sum(jac0 * p0, 1))) < 1e-12  # momentum starts in the cotangent space
+    q, p, status, n_done = integ.step_batch(q0, p0, 1, n_steps=steps)
+    ok = status == 0
+    assert ok.mean() > 0.95
+    c = np.array([constr.constr(x)[0] for x in q[ok]])
+    assert np.max(np.abs(c)) < 1e-8
+    jac = np.stack([constr.jacob_constr(x)[0] for x in q[ok]])
+    assert np.max(np.abs(np.sum(jac * p[ok], 1))) < 1e-8
+    for cidx in np.concatenate([np.arange(6), rng.integers(0, n, 6)]):
+        qo, po, so, no = orc.constrained_leapfrog_steps(osys, q0[cidx], p0[cidx], h, steps)
+        assert so == status[cidx] and no == n_done[cidx]
+        assert_close(q[cidx], qo, 1e-9, f"q chain {cidx}")
+        assert_close(p[cidx], po, 1e-9, f"p chain {cidx}")
+    # reversibility as the reference tests it (tests/test_integrators.py:75-91: n_step <= 20, allclose)
+    q5, p5, s5, _ = integ.step_batch(q0, p0, 1, n_steps=5)
+    ok5 = s5 == 0
+    qb, pb, sb, _ = integ.step_batch(q5[ok5], p5[ok5], -1, n_steps=5)
+    back = sb == 0
+    assert back.mean() > 0.95
+    assert np.allclose(qb[back], q0[ok5][back], rtol=1e-5, atol=1e-6)
+    assert np.allclose(pb[back], p0[ok5][back], rtol=1e-5, atol=1e-6)
+
+
+def test_single_state_step_raises_reference_exceptions():
+    g = load_golden("constrained_torus_fail_bigstep")
+    system, integ = build(g)
+    expect = {2: ConvergenceError, 1: ConvergenceError, 3: ConvergenceError, 4: NonReversibleStepError}
+    for c in range(g["q0"].shape[0]):
+        state = ChainState(pos=g["q0"][c].copy(), mom=g["p0"][c].copy(), dir=int(g["dir"][c]))
+        n_ok = 0
+        try:
+            for _ in range(int(g["checkpoints"].max())):
+                state = integ.step(state)
+                n_ok += 1
+            assert g["status"][c] == 0
+        except (ConvergenceError, NonReversibleStepError) as e:
+            assert isinstance(e, expect[int(g["status"][c])])
+        assert n_ok == g["n_done"][c]
