@@ -1,0 +1,281 @@
+// The implicit-leapfrog step as a backend-independent state machine.
+//
+// A "team" (one wave for D <= 64, one workgroup for larger D) owns a chain.  D-vectors are "flat": one
+// element per team thread (threads >= D idle).  The backend BK supplies the linear algebra on the
+// chain's metric, which it keeps on-chip in whatever layout suits it:
+//   bool   build_and_invert(double x)   metric_func(x) -> explicit M(x)^-1 kept by the backend;
+//                                        false = not finite / not positive definite
+//   double matvec(double v)             M^-1 v
+//   double half_vjp_inv(double q)       0.5 * vjp_metric(q)(M^-1)     (the general-VJP path)
+//   double half_vjp_neg_outer(u, q)     0.5 * vjp_metric(q)(-u u^T)
+//   double norm(double x, int kind)     team-uniform max|x| or sqrt(sum x^2)  (solvers.py:20-27)
+//   double grad(double q)               grad_neg_log_dens
+// All control flow below is team-uniform (it depends only on norms / pivots every thread agrees on),
+// so a team iterates its own solves and stops on failure without any masking.
+//
+// Reference sequence (integrators.py:493-544; every sub-map uses the full time step):
+//   A(t)  B(t)  C(t) + check  C*(t)  B*(t) + check  A(t)
+#pragma once
+
+#include "mm_device.h"
+
+namespace mmimp {
+
+struct ImplicitArgs {
+  double* pos;
+  double* mom;
+  const int8_t* dir;
+  int32_t* status;
+  int32_t* n_done;
+  int64_t n_chains;
+  int dim;
+  double step_size;
+  int n_steps;
+  int target;
+  const double* tparams;
+  const double* rparams;
+  mm_fp_opts opts;
+  mm_counters* counters;
+  // aux ops
+  double* out;
+  const double* z;
+};
+
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+
+// Fixed-point solvers as a resumable state machine (solvers.py:47-94 direct, :97-154 Steffensen):
+// the caller evaluates f at the requested point and feeds the value back, so the kernel has ONE
+// call site for the expensive function evaluation (metric construction).
+struct FpState {
+  double x0, x1;
+  int iter, stage;
+};
+enum { FP_CONT = 0, FP_DONE = 1, FP_FAIL = 2 };
+
+__device__ __forceinline__ FpState fp_begin(double x_init) { return FpState{x_init, 0.0, 0, 0}; }
+
+// fx = f(point last requested).  FP_CONT: evaluate f at *out next; FP_DONE: *out is the solution;
+// FP_FAIL: *status says why (diverged / max_iters).
+template <class BK>
+__device__ __forceinline__ int fp_feed(BK& bk, FpState& s, double fx, const mm_fp_opts& o,
+                                       double* out, int* status) {
+  double x;
+  if (o.solver == MM_FP_DIRECT) {
+    x = fx;
+  } else {
+    if (s.stage == 0) {
+      s.x1 = fx;
+      s.stage = 1;
+      *out = fx;
+      return FP_CONT;
+    }
+    double denom = fx - 2.0 * s.x1 + s.x0;
+    if (fabs(denom) == 0.0) denom = 2.220446049250313e-16;  // np.finfo(float64).eps
+    x = s.x0 - (s.x1 - s.x0) * (s.x1 - s.x0) / denom;
+    s.stage = 0;
+  }
+  const double err = bk.norm(x - s.x0, o.norm);
+  if (err > o.div_tol || err != err) {
+    *status = MM_ST_DIVERGED;
+    return FP_FAIL;
+  }
+  *out = x;
+  if (err < o.conv_tol) return FP_DONE;
+  s.x0 = x;
+  if (++s.iter >= o.max_iters) {
+    *status = MM_ST_MAX_ITERS;
+    return FP_FAIL;
+  }
+  return FP_CONT;
+}
+
+// momentum-space fixed point  x = base - tt * dh2_dpos(q, x)  with the metric fixed (B and B-check)
+template <class BK>
+__device__ __forceinline__ int momentum_solve(BK& bk, double base, double tt, double q,
+                                              const mm_fp_opts& o, double* result,
+                                              long long* n_evals) {
+  FpState st = fp_begin(base);
+  double pt = base;
+  int status = MM_ST_OK;
+  for (;;) {
+    const double u = bk.matvec(pt);
+    const double fx = base - tt * bk.half_vjp_neg_outer(u, q);
+    *n_evals += 1;
+    const int act = fp_feed(bk, st, fx, o, &pt, &status);
+    if (act == FP_DONE) break;
+    if (act == FP_FAIL) return status;
+  }
+  *result = pt;
+  return MM_ST_OK;
+}
+
+struct ChainResult {
+  int status, done;
+  long long n_evals, n_solves, n_metric, n_grad;
+};
+
+enum { MODE_INIT = 0, MODE_CFIRST = 1, MODE_CHK = 2, MODE_ADJ = 3, MODE_BADJ = 4 };
+
+// Advance one chain by up to n_steps; q, p are updated in place only by completed steps.
+template <class BK>
+__device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double& q, double& p, double t,
+                                                               int n_steps, const mm_fp_opts& o) {
+  ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0};
+  // One loop, one metric-construction site.  `mode` says why the metric at `xq` is being built:
+  //   INIT   cold start at the initial position (LinAlgError outside a solver on failure)
+  //   CFIRST first evaluation shared by the C reversibility check and the C-adjoint solve (both start
+  //          at the same point, so one factorisation serves both; the reference builds it twice and
+  //          it is counted twice for comparability)
+  //   CHK    later iterations of the reversibility-check solve   (integrators.py:521-528)
+  //   ADJ    later iterations of the C-adjoint solve             (integrators.py:530-536)
+  //   BADJ   metric at the new position for B-adjoint + final A  (integrators.py:504-515, 544)
+  int mode = MODE_INIT;
+  double xq = q;
+  double g = 0.0, pw = 0.0, qw = 0.0, q_init = 0.0, ptA = 0.0;
+  FpState sC = fp_begin(0.0), sA = fp_begin(0.0);
+  int actA = FP_CONT, stA = MM_ST_OK;
+
+  while (n_steps > 0) {
+    const bool okm = bk.build_and_invert(xq);
+    r.n_metric += (mode == MODE_CFIRST) ? 2 : 1;
+    if (!okm) {
+      r.status = (mode == MODE_INIT || mode == MODE_BADJ) ? MM_ST_LINALG : MM_ST_SOLVER_LINALG;
+      break;
+    }
+    if (mode == MODE_INIT || mode == MODE_BADJ) {
+      if (mode == MODE_BADJ) {
+        // ---- B adj: p -= t dh2_dpos(q', p) then reversibility check     integrators.py:504-515
+        const double p_init = pw;
+        const double u = bk.matvec(pw);
+        pw = pw - t * bk.half_vjp_neg_outer(u, qw);
+        double p_back;
+        ++r.n_solves;
+        r.status = momentum_solve(bk, pw, -t, qw, o, &p_back, &r.n_evals);
+        if (r.status != MM_ST_OK) break;
+        if (bk.norm(p_back - p_init, o.rev_norm) > o.rev_tol) {
+          r.status = MM_ST_NON_REVERSIBLE;
+          break;
+        }
+        // ---- A: p -= t dh1_dpos(q')                                      integrators.py:544
+        g = bk.grad(qw);
+        ++r.n_grad;
+        pw = pw - t * (g + bk.half_vjp_inv(qw));
+        q = qw;
+        p = pw;
+        if (++r.done == n_steps) break;
+      } else {
+        g = bk.grad(q);
+        ++r.n_grad;
+      }
+      // ---- A: p -= t dh1_dpos(q), dh1 = grad + 0.5 vjp(M^-1)            integrators.py:493-494
+      pw = p - t * (g + bk.half_vjp_inv(q));
+      // ---- B fwd: solve p' = p - t dh2_dpos(q, p')                        integrators.py:496-502
+      ++r.n_solves;
+      r.status = momentum_solve(bk, pw, t, q, o, &pw, &r.n_evals);
+      if (r.status != MM_ST_OK) break;
+      // ---- C fwd: q += t M(q)^-1 p                                        integrators.py:517-519
+      q_init = q;
+      qw = q + t * bk.matvec(pw);
+      xq = qw;
+      mode = MODE_CFIRST;
+      continue;
+    }
+    // position-space solves: f(x) = qw -/+ t M(x)^-1 p with M(xq)^-1 now held by the backend
+    const double u = bk.matvec(pw);
+    bool chk_done = false, adj_done = false;
+    double q_back = 0.0;
+    if (mode == MODE_CFIRST) {
+      r.n_solves += 2;
+      r.n_evals += 2;
+      sC = fp_begin(qw);
+      sA = fp_begin(qw);
+      double ptC;
+      int stC = MM_ST_OK;
+      const int actC = fp_feed(bk, sC, qw - t * u, o, &ptC, &stC);
+      actA = fp_feed(bk, sA, qw + t * u, o, &ptA, &stA);
+      if (actC == FP_FAIL) {
+        r.status = stC;
+        break;
+      }
+      if (actC == FP_DONE) {
+        chk_done = true;
+        q_back = ptC;
+      } else {
+        xq = ptC;
+        mode = MODE_CHK;
+        continue;
+      }
+    } else if (mode == MODE_CHK) {
+      ++r.n_evals;
+      double pt;
+      int st = MM_ST_OK;
+      const int a = fp_feed(bk, sC, qw - t * u, o, &pt, &st);
+      if (a == FP_FAIL) {
+        r.status = st;
+        break;
+      }
+      if (a == FP_CONT) {
+        xq = pt;
+        continue;
+      }
+      chk_done = true;
+      q_back = pt;
+    } else {  // MODE_ADJ
+      ++r.n_evals;
+      double pt;
+      int st = MM_ST_OK;
+      const int a = fp_feed(bk, sA, qw + t * u, o, &pt, &st);
+      if (a == FP_FAIL) {
+        r.status = st;
+        break;
+      }
+      if (a == FP_CONT) {
+        xq = pt;
+        continue;
+      }
+      adj_done = true;
+      ptA = pt;
+    }
+    if (chk_done) {
+      if (bk.norm(q_back - q_init, o.rev_norm) > o.rev_tol) {
+        r.status = MM_ST_NON_REVERSIBLE;  // integrators.py:523-528
+        break;
+      }
+      // the C-adjoint solve resumes from its (already fed) first evaluation
+      if (actA == FP_FAIL) {
+        r.status = stA;
+        break;
+      }
+      if (actA == FP_DONE) {
+        adj_done = true;
+      } else {
+        xq = ptA;
+        mode = MODE_ADJ;
+        continue;
+      }
+    }
+    if (adj_done) {
+      qw = ptA;  // state.pos = solution; the metric cache is dropped -> rebuilt for B adj
+      xq = qw;
+      mode = MODE_BADJ;
+    }
+  }
+  return r;
+}
+
+__device__ __forceinline__ void add_counters(mm_counters* c, const ChainResult& r) {
+  if (!c) return;
+  atomicAdd((unsigned long long*)&c->n_grad, (unsigned long long)r.n_grad);
+  atomicAdd((unsigned long long*)&c->n_metric, (unsigned long long)r.n_metric);
+  atomicAdd((unsigned long long*)&c->n_inverse, (unsigned long long)r.n_metric);
+  atomicAdd((unsigned long long*)&c->n_fp_evals, (unsigned long long)r.n_evals);
+  atomicAdd((unsigned long long*)&c->n_fp_solves, (unsigned long long)r.n_solves);
+}
+
+}  // namespace mmimp

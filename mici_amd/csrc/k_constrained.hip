@@ -73,7 +73,8 @@ __device__ __forceinline__ Vec<D> minv_apply(const ConArgs& A, const Vec<D>& x) 
 template <int D>
 __device__ __forceinline__ double constr_value(const ConArgs& A, const Vec<D>& q) {
   if (A.constr == MM_CONSTR_TORUS) {
-    const double rho = sqrt(q.v[0] * q.v[0] + q.v[1] * q.v[1]);
+    constexpr int I1 = D > 1 ? 1 : 0;
+    const double rho = sqrt(q.v[0] * q.v[0] + q.v[I1] * q.v[I1]);
     const double dr = rho - A.cp0;
     return dr * dr + q.v[D > 2 ? 2 : 0] * q.v[D > 2 ? 2 : 0] - A.cp1 * A.cp1;
   }
@@ -87,7 +88,8 @@ __device__ __forceinline__ Vec<D> constr_jacob(const ConArgs& A, const Vec<D>& q
 #pragma unroll
   for (int i = 0; i < D; ++i) j.v[i] = 0.0;
   if (A.constr == MM_CONSTR_TORUS) {
-    const double rho = sqrt(q.v[0] * q.v[0] + q.v[1] * q.v[1]);
+    constexpr int I1 = D > 1 ? 1 : 0;
+    const double rho = sqrt(q.v[0] * q.v[0] + q.v[I1] * q.v[I1]);
     const double f = 2.0 * (rho - A.cp0) / rho;
     j.v[0] = f * q.v[0];
     if constexpr (D > 1) j.v[1] = f * q.v[1];

@@ -22,41 +22,14 @@
 // the shared base matrix of the rank-one metric sits in LDS once per workgroup.  Each wave iterates
 // its own fixed-point solves, so data-dependent iteration counts and failures need no masking: a
 // failed chain's wave simply stops (status / n_done, chain frozen at its last good state).
-#include "mm_device.h"
+#include "implicit_core.h"
 
 namespace {
 
 using namespace mmdev;
+using namespace mmimp;
 
 constexpr int kWaves = 4;  // chains per workgroup
-
-struct ImplicitArgs {
-  double* pos;
-  double* mom;
-  const int8_t* dir;
-  int32_t* status;
-  int32_t* n_done;
-  int64_t n_chains;
-  int dim;
-  double step_size;
-  int n_steps;
-  int target;
-  const double* tparams;
-  const double* rparams;
-  mm_fp_opts opts;
-  mm_counters* counters;
-  // aux ops
-  double* out;
-  const double* z;
-};
-
-__device__ __forceinline__ double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = __builtin_fma(-x, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-x, r, 1.0);
-  return __builtin_fma(r, e, r);
-}
 
 // Per-wave LDS scratch (doubles): 5 vectors of 64.
 struct WaveLds {
@@ -257,51 +230,6 @@ __device__ __forceinline__ double flat_norm(double x, int dim, int lane, int kin
   return wave_norm_finish(acc, kind);
 }
 
-// Fixed-point solvers as a resumable state machine (solvers.py:47-94 direct, :97-154 Steffensen):
-// the caller evaluates f at the requested point and feeds the value back.  This keeps ONE call site
-// for the expensive function evaluation (metric construction) in the kernel.
-struct FpState {
-  double x0, x1;
-  int iter, stage;
-};
-enum { FP_CONT = 0, FP_DONE = 1, FP_FAIL = 2 };
-
-__device__ __forceinline__ FpState fp_begin(double x_init) { return FpState{x_init, 0.0, 0, 0}; }
-
-// fx = f(point last requested).  FP_CONT: evaluate f at *out next; FP_DONE: *out is the solution;
-// FP_FAIL: *status says why (diverged / max_iters).
-__device__ __forceinline__ int fp_feed(FpState& s, double fx, const mm_fp_opts& o, int dim, int lane,
-                                       double* out, int* status) {
-  double x;
-  if (o.solver == MM_FP_DIRECT) {
-    x = fx;
-  } else {
-    if (s.stage == 0) {
-      s.x1 = fx;
-      s.stage = 1;
-      *out = fx;
-      return FP_CONT;
-    }
-    double denom = fx - 2.0 * s.x1 + s.x0;
-    if (fabs(denom) == 0.0) denom = 2.220446049250313e-16;  // np.finfo(float64).eps
-    x = s.x0 - (s.x1 - s.x0) * (s.x1 - s.x0) / denom;
-    s.stage = 0;
-  }
-  const double err = flat_norm(x - s.x0, dim, lane, o.norm);
-  if (err > o.div_tol || err != err) {
-    *status = MM_ST_DIVERGED;
-    return FP_FAIL;
-  }
-  *out = x;
-  if (err < o.conv_tol) return FP_DONE;
-  s.x0 = x;
-  if (++s.iter >= o.max_iters) {
-    *status = MM_ST_MAX_ITERS;
-    return FP_FAIL;
-  }
-  return FP_CONT;
-}
-
 template <int TS>
 __device__ __forceinline__ double grad_flat(int target, double q, int dim, int lane,
                                             const WaveLds& w, const double* tparams) {
@@ -326,27 +254,32 @@ __device__ __forceinline__ void stage_base(double* base_lds, const double* rpara
   __syncthreads();
 }
 
-// momentum-space fixed point  x = base + sgn_t * dh2_dpos(q, x)  with the metric fixed (B / B-check)
+// Backend of implicit_core.h for one wave per chain.
 template <int TS, int RMETRIC>
-__device__ __forceinline__ int momentum_solve(const double (&T)[TS][TS], double base, double tt,
-                                              double q, const mm_fp_opts& o, int dim, int lane,
-                                              const WaveLds& w, double* result, long long* n_evals) {
-  FpState st = fp_begin(base);
-  double pt = base;
-  int status = MM_ST_OK;
-  for (;;) {
-    const double u = matvec_flat<TS>(T, pt, lane, w);
-    const double fx = base - tt * half_vjp_neg_outer<RMETRIC>(u, q, dim, lane);
-    *n_evals += 1;
-    const int act = fp_feed(st, fx, o, dim, lane, &pt, &status);
-    if (act == FP_DONE) break;
-    if (act == FP_FAIL) return status;
-  }
-  *result = pt;
-  return MM_ST_OK;
-}
+struct WaveBackend {
+  double T[TS][TS];
+  int dim, lane, target;
+  WaveLds w;
+  const double* base_lds;
+  const double* tparams;
 
-enum { MODE_INIT = 0, MODE_CFIRST = 1, MODE_CHK = 2, MODE_ADJ = 3, MODE_BADJ = 4 };
+  __device__ __forceinline__ bool build_and_invert(double x) {
+    bool ok = build_metric<TS, RMETRIC>(T, x, dim, lane, w, base_lds);
+    ok = sweep_inverse<TS, false, false>(T, dim, lane, w, nullptr, nullptr) && ok;
+    return ok;
+  }
+  __device__ __forceinline__ double matvec(double v) { return matvec_flat<TS>(T, v, lane, w); }
+  __device__ __forceinline__ double half_vjp_inv(double q) {
+    return half_vjp_tiles<TS, RMETRIC>(T, q, dim, lane, w);
+  }
+  __device__ __forceinline__ double half_vjp_neg_outer(double u, double q) {
+    return ::half_vjp_neg_outer<RMETRIC>(u, q, dim, lane);
+  }
+  __device__ __forceinline__ double norm(double x, int kind) { return flat_norm(x, dim, lane, kind); }
+  __device__ __forceinline__ double grad(double q) {
+    return grad_flat<TS>(target, q, dim, lane, w, tparams);
+  }
+};
 
 template <int TS, int RMETRIC>
 __global__ __launch_bounds__(64 * kWaves) void implicit_leapfrog_kernel(ImplicitArgs A) {
@@ -355,175 +288,34 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_leapfrog_kernel(Implicit
   const int base_elems = (RMETRIC == MM_RMETRIC_RANK1) ? 64 * Geo<TS>::TSTRIDE : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* wl = lds + base_elems + wave * 5 * 64;
-  const WaveLds w{wl, wl + 64, wl + 128, wl + 192, wl + 256};
   stage_base<TS, RMETRIC>(base_lds, A.rparams, A.dim);
 
   const int64_t chain = (int64_t)blockIdx.x * kWaves + wave;
   if (chain >= A.n_chains) return;  // no block-level barrier below this point
   const int dim = A.dim;
-  const mm_fp_opts o = A.opts;
   const bool act = lane < dim;
   double q = act ? A.pos[chain * dim + lane] : 0.0;
   double p = act ? A.mom[chain * dim + lane] : 0.0;
   const double t = (double)A.dir[chain] * A.step_size;
 
-  long long n_evals = 0, n_solves = 0, n_metric = 0, n_grad = 0;
-  int status = MM_ST_OK, done = 0;
-  double T[TS][TS];
+  WaveBackend<TS, RMETRIC> bk;
+  bk.dim = dim;
+  bk.lane = lane;
+  bk.target = A.target;
+  bk.w = WaveLds{wl, wl + 64, wl + 128, wl + 192, wl + 256};
+  bk.base_lds = base_lds;
+  bk.tparams = A.tparams;
+  const ChainResult r = implicit_leapfrog_chain(bk, q, p, t, A.n_steps, A.opts);
 
-  // One loop, one metric-construction site.  `mode` says why the metric at `xq` is being built:
-  //   INIT   cold start at the initial position (LinAlgError outside a solver on failure)
-  //   CFIRST first evaluation shared by the C reversibility check and the C-adjoint solve
-  //   CHK    later iterations of the reversibility-check solve   (integrators.py:521-528)
-  //   ADJ    later iterations of the C-adjoint solve             (integrators.py:530-536)
-  //   BADJ   metric at the new position for B-adjoint + final A  (integrators.py:504-515, 544)
-  int mode = MODE_INIT;
-  double xq = q;
-  double g = 0.0, pw = 0.0, qw = 0.0, q_init = 0.0, ptA = 0.0;
-  FpState sC = fp_begin(0.0), sA = fp_begin(0.0);
-  int actA = FP_CONT, stA = MM_ST_OK;
-
-  while (A.n_steps > 0) {
-    bool okm = build_metric<TS, RMETRIC>(T, xq, dim, lane, w, base_lds);
-    okm = sweep_inverse<TS, false, false>(T, dim, lane, w, nullptr, nullptr) && okm;
-    n_metric += (mode == MODE_CFIRST) ? 2 : 1;  // the reference builds the shared one twice
-    if (!okm) {
-      status = (mode == MODE_INIT || mode == MODE_BADJ) ? MM_ST_LINALG : MM_ST_SOLVER_LINALG;
-      break;
-    }
-    if (mode == MODE_INIT || mode == MODE_BADJ) {
-      if (mode == MODE_BADJ) {
-        // ---- B adj: p -= t dh2_dpos(q', p) then reversibility check     integrators.py:504-515
-        const double p_init = pw;
-        const double u = matvec_flat<TS>(T, pw, lane, w);
-        pw = pw - t * half_vjp_neg_outer<RMETRIC>(u, qw, dim, lane);
-        double p_back;
-        ++n_solves;
-        status = momentum_solve<TS, RMETRIC>(T, pw, -t, qw, o, dim, lane, w, &p_back, &n_evals);
-        if (status != MM_ST_OK) break;
-        if (flat_norm(p_back - p_init, dim, lane, o.rev_norm) > o.rev_tol) {
-          status = MM_ST_NON_REVERSIBLE;
-          break;
-        }
-        // ---- A: p -= t dh1_dpos(q')                                      integrators.py:544
-        g = grad_flat<TS>(A.target, qw, dim, lane, w, A.tparams);
-        ++n_grad;
-        pw = pw - t * (g + half_vjp_tiles<TS, RMETRIC>(T, qw, dim, lane, w));
-        q = qw;
-        p = pw;
-        if (++done == A.n_steps) break;
-      } else {
-        g = grad_flat<TS>(A.target, q, dim, lane, w, A.tparams);
-        ++n_grad;
-      }
-      // ---- A: p -= t dh1_dpos(q), dh1 = grad + 0.5 vjp(M^-1)            integrators.py:493-494
-      pw = p - t * (g + half_vjp_tiles<TS, RMETRIC>(T, q, dim, lane, w));
-      // ---- B fwd: solve p' = p - t dh2_dpos(q, p')                        integrators.py:496-502
-      ++n_solves;
-      status = momentum_solve<TS, RMETRIC>(T, pw, t, q, o, dim, lane, w, &pw, &n_evals);
-      if (status != MM_ST_OK) break;
-      // ---- C fwd: q += t M(q)^-1 p                                        integrators.py:517-519
-      q_init = q;
-      qw = q + t * matvec_flat<TS>(T, pw, lane, w);
-      xq = qw;
-      mode = MODE_CFIRST;
-      continue;
-    }
-    // position-space solves: f(x) = qw -/+ t M(x)^-1 p with M(xq)^-1 now in the tiles
-    const double u = matvec_flat<TS>(T, pw, lane, w);
-    bool chk_done = false, adj_done = false;
-    double q_back = 0.0;
-    if (mode == MODE_CFIRST) {
-      n_solves += 2;
-      n_evals += 2;
-      sC = fp_begin(qw);
-      sA = fp_begin(qw);
-      double ptC;
-      int stC = MM_ST_OK;
-      const int actC = fp_feed(sC, qw - t * u, o, dim, lane, &ptC, &stC);
-      actA = fp_feed(sA, qw + t * u, o, dim, lane, &ptA, &stA);
-      if (actC == FP_FAIL) {
-        status = stC;
-        break;
-      }
-      if (actC == FP_DONE) {
-        chk_done = true;
-        q_back = ptC;
-      } else {
-        xq = ptC;
-        mode = MODE_CHK;
-        continue;
-      }
-    } else if (mode == MODE_CHK) {
-      ++n_evals;
-      double pt;
-      int st = MM_ST_OK;
-      const int a = fp_feed(sC, qw - t * u, o, dim, lane, &pt, &st);
-      if (a == FP_FAIL) {
-        status = st;
-        break;
-      }
-      if (a == FP_CONT) {
-        xq = pt;
-        continue;
-      }
-      chk_done = true;
-      q_back = pt;
-    } else {  // MODE_ADJ
-      ++n_evals;
-      double pt;
-      int st = MM_ST_OK;
-      const int a = fp_feed(sA, qw + t * u, o, dim, lane, &pt, &st);
-      if (a == FP_FAIL) {
-        status = st;
-        break;
-      }
-      if (a == FP_CONT) {
-        xq = pt;
-        continue;
-      }
-      adj_done = true;
-      ptA = pt;
-    }
-    if (chk_done) {
-      if (flat_norm(q_back - q_init, dim, lane, o.rev_norm) > o.rev_tol) {
-        status = MM_ST_NON_REVERSIBLE;  // integrators.py:523-528
-        break;
-      }
-      // the C-adjoint solve resumes from its (already fed) first evaluation
-      if (actA == FP_FAIL) {
-        status = stA;
-        break;
-      }
-      if (actA == FP_DONE) {
-        adj_done = true;
-      } else {
-        xq = ptA;
-        mode = MODE_ADJ;
-        continue;
-      }
-    }
-    if (adj_done) {
-      qw = ptA;  // state.pos = solution; metric cache dropped -> rebuilt for B adj
-      xq = qw;
-      mode = MODE_BADJ;
-    }
-  }
   // a failed step leaves q, p at the last completed step (they are only overwritten on success)
   if (act) {
     A.pos[chain * dim + lane] = q;
     A.mom[chain * dim + lane] = p;
   }
   if (lane == 0) {
-    A.status[chain] = status;
-    A.n_done[chain] = done;
-    if (A.counters) {
-      atomicAdd((unsigned long long*)&A.counters->n_grad, (unsigned long long)n_grad);
-      atomicAdd((unsigned long long*)&A.counters->n_metric, (unsigned long long)n_metric);
-      atomicAdd((unsigned long long*)&A.counters->n_inverse, (unsigned long long)n_metric);
-      atomicAdd((unsigned long long*)&A.counters->n_fp_evals, (unsigned long long)n_evals);
-      atomicAdd((unsigned long long*)&A.counters->n_fp_solves, (unsigned long long)n_solves);
-    }
+    A.status[chain] = r.status;
+    A.n_done[chain] = r.done;
+    add_counters(A.counters, r);
   }
 }
 

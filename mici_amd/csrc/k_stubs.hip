@@ -8,11 +8,3 @@ int mm_launch_softabs_aux(mm_ctx* ctx, const mm_model*, mm_state*, int, double*,
   mm_set_error(ctx, "SoftAbs kernel not built yet");
   return MM_ERR_UNSUPPORTED;
 }
-int mm_launch_implicit_large(mm_ctx* ctx, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*) {
-  mm_set_error(ctx, "dense-Riemannian kernels for dim > 64 not built yet");
-  return MM_ERR_UNSUPPORTED;
-}
-int mm_launch_riemann_aux_large(mm_ctx* ctx, const mm_model*, mm_state*, int, double*, const double*) {
-  mm_set_error(ctx, "dense-Riemannian kernels for dim > 64 not built yet");
-  return MM_ERR_UNSUPPORTED;
-}
