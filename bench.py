@@ -67,6 +67,29 @@ def make_workload(config, n_chains, rng):
                     traj=traj, integ=integ, system=system, osys=osys, q0=q0, p0=p0,
                     bytes_per_chain_step=32.0 * dim, flops_per_chain_step=flops,
                     bound="hbm" if config == "c2i" else "mfma", kind="euclid")
+    if config in ("c3", "c4"):
+        dim, h, traj = (64, 0.02, 100) if config == "c3" else (256, 0.01, 50)
+        base = omdl.make_spd(dim, rng)
+        system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(base))
+        osys = orc.RiemannianSystem(omdl.Banana(dim), omdl.Rank1Metric(base))
+        integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+        q0 = rng.standard_normal((n_chains, dim))
+        p0 = system.sample_momentum_batch(q0, rng.standard_normal((n_chains, dim)))
+        return dict(name=f"{config}(a) DenseRiemannianMetricSystem (rank-one-update dense metric, banana "
+                         "target) + ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
+                    system=system, osys=osys, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
+                    flops_per_chain_step=None, bound="mfma", kind="riemann")
+    if config == "c5":
+        dim, h, traj = 3, 0.1, 1000
+        system = systems.DenseConstrainedEuclideanMetricSystem(models.Torus(), models.TorusConstr())
+        osys = orc.ConstrainedSystem(omdl.Torus(), omdl.TorusConstr())
+        integ = integrators.ConstrainedLeapfrogIntegrator(system, h)
+        q0 = omdl.torus_init(n_chains, rng)
+        p0 = system.sample_momentum_batch(q0, rng.standard_normal((n_chains, dim)))
+        return dict(name="c5 DenseConstrainedEuclideanMetricSystem (README torus) + "
+                         "ConstrainedLeapfrogIntegrator (Newton)", dim=dim, h=h, traj=traj, integ=integ,
+                    system=system, osys=osys, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
+                    flops_per_chain_step=1500.0, bound="hbm", kind="constrained")
     raise SystemExit(f"unknown --config {config}")
 
 
@@ -80,6 +103,20 @@ def cpu_baseline(w, budget_s=20.0):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count() or 1
+    if w["kind"] != "euclid":
+        # per-chain NumPy oracle (how the reference itself runs: one chain at a time, one core)
+        fn = orc.implicit_leapfrog_steps if w["kind"] == "riemann" else orc.constrained_leapfrog_steps
+        steps = {"riemann": 5, "constrained": 50}[w["kind"]]
+        done, n1 = 0, 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s and n1 < w["q0"].shape[0]:
+            _, _, _, nd = fn(w["osys"], w["q0"][n1], w["p0"][n1], w["h"], steps)
+            done += nd
+            n1 += 1
+        dt = time.perf_counter() - t0
+        return dict(value=done / dt, unit="leapfrog-steps/s", cores=1, kind="port",
+                    sample=f"oracle per-chain NumPy: {n1} chains x {steps} steps of the same workload "
+                           f"in {dt:.1f} s (1 thread; BLAS single-threaded at these sizes)")
     n, steps = w["q0"].shape[0], 20
     t0 = time.perf_counter()
     orc.leapfrog_steps_batch(w["osys"], w["q0"], w["p0"], w["h"], steps)
@@ -131,7 +168,7 @@ def main():
     from mici_amd.runtime import Context, DeviceBatch
 
     ctx = Context(local_rank)
-    n_local = args.chains_per_gpu or 4096
+    n_local = args.chains_per_gpu or {"c3": 1024, "c4": 1024, "c5": 2048}.get(args.config, 4096)
     rng = np.random.default_rng(1234 + rank)
     w = make_workload(args.config, n_local, rng)
     traj = args.traj_len or w["traj"]
@@ -194,6 +231,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kernel_ms = 0.0
+    done_acc, counters_acc = 0.0, {}
     for k in range(args.steps):
         ctx.record(0)
         integ.step_device(batch, traj, ctx)
@@ -210,6 +248,11 @@ def main():
                 out = [torch.empty_like(torch.from_numpy(q)) for _ in range(world)]
                 dist.all_gather(out, torch.from_numpy(q))
         kernel_ms += ctx.elapsed_ms(0, 1)  # HIP events on the stream the kernel runs on
+        if w["kind"] != "euclid":
+            _, nd = batch.download_status()  # the sampler needs this per trajectory anyway
+            done_acc += float(nd.sum())
+            for key, val in (integ.last_counters or {}).items():
+                counters_acc[key] = counters_acc.get(key, 0) + val
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -218,10 +261,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    status, n_done = (np.zeros(n_local, np.int32), np.full(n_local, traj, np.int32))
-    if w["kind"] != "euclid":
-        status, n_done = batch.download_status()
-    done_local = float(n_local) * traj * args.steps if w["kind"] == "euclid" else None
+    done_local = float(n_local) * traj * args.steps if w["kind"] == "euclid" else done_acc
     total_steps = done_local
     if dist is not None:
         import torch
@@ -233,6 +273,16 @@ def main():
         value = total_steps / elapsed
         launch_s = kernel_ms / 1e3 / args.steps
         chain_steps_per_launch = n_local * traj
+        if w["kind"] == "riemann":
+            # algorithmic flops of SURVEY.md section 8d from the device work counters:
+            #   n_M D^3/3 (factorisations) + n_inv 2D^3/3 (one explicit inverse per completed step)
+            #   + (2 n_M + 3 n_B) D^2 (solves / mat-vecs / outer products), n_B = momentum-solve evals
+            d = float(w["dim"])
+            n_m = counters_acc.get("n_metric", 0)
+            n_b = max(counters_acc.get("n_fp_evals", 0) - n_m, 0)
+            flops_total = n_m * d**3 / 3 + done_local * 2 * d**3 / 3 + (2 * n_m + 3 * n_b) * d * d
+            w["flops_per_chain_step"] = flops_total / max(done_local, 1.0)
+            chain_steps_per_launch = done_local / args.steps
         if w["bound"] == "mfma":
             achieved = w["flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
             roof = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
@@ -241,7 +291,18 @@ def main():
             achieved = w["bytes_per_chain_step"] * chain_steps_per_launch / launch_s / 1e9
             roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=None)
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
+        # (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); null when not profiled
+        pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm.json")
+        if args.config == "c2" and n_local == 4096 and traj == 1000 and os.path.exists(pmc):
+            with open(pmc) as fh:
+                roof["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/r01_c2_pmc_hbm.json (rocprofv3 --pmc, corrected)"
         roof["kernel_ms_per_launch"] = kernel_ms / args.steps
+        roof["algorithmic_flops_per_chain_step"] = w["flops_per_chain_step"]
+        roof["algorithmic_bytes_per_chain_step"] = w["bytes_per_chain_step"]
+        if counters_acc:
+            roof["work_counters"] = counters_acc
         out = {
             "metric": "leapfrog-steps/sec (all chains)",
             "value": value,
@@ -258,7 +319,9 @@ def main():
             "config": {
                 "workload": f"{w['name']}, D={w['dim']}, {n_local} chains/GPU x {world} GPU, "
                             f"h={w['h']}, one pass = a trajectory of {traj} leapfrog steps per chain",
-                "baseline_config": "BASELINE.json configs[1]" if args.config == "c2" else args.config,
+                "baseline_config": {"c2": "BASELINE.json configs[1]", "c3": "BASELINE.json configs[2]",
+                                    "c4": "BASELINE.json configs[3] (per-GPU shard)",
+                                    "c5": "BASELINE.json configs[4] (per-GPU shard)"}.get(args.config, args.config),
                 "chains_per_gpu": n_local, "dim": w["dim"], "traj_len": traj,
                 "parallelism": f"chains sharded x{world}, trace gather: {gather_mode}",
             },
