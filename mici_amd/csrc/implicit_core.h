@@ -51,44 +51,43 @@ __device__ __forceinline__ double fast_rcp(double x) {
 
 // Fixed-point solvers as a resumable state machine (solvers.py:47-94 direct, :97-154 Steffensen):
 // the caller evaluates f at the requested point and feeds the value back, so the kernel has ONE
-// call site for the expensive function evaluation (metric construction).
-struct FpState {
-  double x0, x1;
+// call site for the expensive function evaluation (metric construction).  The iterate storage
+// (x0, x1) is passed by reference so that a backend can keep it outside the register file.
+struct FpCtl {
   int iter, stage;
 };
 enum { FP_CONT = 0, FP_DONE = 1, FP_FAIL = 2 };
 
-__device__ __forceinline__ FpState fp_begin(double x_init) { return FpState{x_init, 0.0, 0, 0}; }
-
 // fx = f(point last requested).  FP_CONT: evaluate f at *out next; FP_DONE: *out is the solution;
 // FP_FAIL: *status says why (diverged / max_iters).
 template <class BK>
-__device__ __forceinline__ int fp_feed(BK& bk, FpState& s, double fx, const mm_fp_opts& o,
-                                       double* out, int* status) {
+__device__ __forceinline__ int fp_feed(BK& bk, FpCtl& c, double& x0, double& x1, double fx,
+                                       const mm_fp_opts& o, double* out, int* status) {
   double x;
   if (o.solver == MM_FP_DIRECT) {
     x = fx;
   } else {
-    if (s.stage == 0) {
-      s.x1 = fx;
-      s.stage = 1;
+    if (c.stage == 0) {
+      x1 = fx;
+      c.stage = 1;
       *out = fx;
       return FP_CONT;
     }
-    double denom = fx - 2.0 * s.x1 + s.x0;
+    const double a0 = x0, a1 = x1;
+    double denom = fx - 2.0 * a1 + a0;
     if (fabs(denom) == 0.0) denom = 2.220446049250313e-16;  // np.finfo(float64).eps
-    x = s.x0 - (s.x1 - s.x0) * (s.x1 - s.x0) / denom;
-    s.stage = 0;
+    x = a0 - (a1 - a0) * (a1 - a0) / denom;
+    c.stage = 0;
   }
-  const double err = bk.norm(x - s.x0, o.norm);
+  const double err = bk.norm(x - x0, o.norm);
   if (err > o.div_tol || err != err) {
     *status = MM_ST_DIVERGED;
     return FP_FAIL;
   }
   *out = x;
   if (err < o.conv_tol) return FP_DONE;
-  s.x0 = x;
-  if (++s.iter >= o.max_iters) {
+  x0 = x;
+  if (++c.iter >= o.max_iters) {
     *status = MM_ST_MAX_ITERS;
     return FP_FAIL;
   }
@@ -100,14 +99,14 @@ template <class BK>
 __device__ __forceinline__ int momentum_solve(BK& bk, double base, double tt, double q,
                                               const mm_fp_opts& o, double* result,
                                               long long* n_evals) {
-  FpState st = fp_begin(base);
-  double pt = base;
+  FpCtl c{0, 0};
+  double x0 = base, x1 = 0.0, pt = base;
   int status = MM_ST_OK;
   for (;;) {
     const double u = bk.matvec(pt);
     const double fx = base - tt * bk.half_vjp_neg_outer(u, q);
     *n_evals += 1;
-    const int act = fp_feed(bk, st, fx, o, &pt, &status);
+    const int act = fp_feed(bk, c, x0, x1, fx, o, &pt, &status);
     if (act == FP_DONE) break;
     if (act == FP_FAIL) return status;
   }
@@ -122,12 +121,21 @@ struct ChainResult {
 
 enum { MODE_INIT = 0, MODE_CFIRST = 1, MODE_CHK = 2, MODE_ADJ = 3, MODE_BADJ = 4 };
 
-// Advance one chain by up to n_steps; q, p are updated in place only by completed steps.
+// Per-thread flat state that is live across the whole step; the backend decides where it lives
+// (registers for the wave backend, LDS for the register-starved block backend): double& BK::slot(i).
+enum {
+  SL_Q = 0, SL_P, SL_G, SL_QINIT, SL_PTA, SL_AX0, SL_AX1,  // state, cached gradient, parked C* solve
+  SL_XQ, SL_PW, SL_QW, SL_SX0, SL_SX1, SL_GNEW,            // working point / momentum / position, active solve
+  SL_COUNT
+};
+
+// Advance one chain by up to n_steps.  On entry slot(SL_Q), slot(SL_P) hold the state; they are
+// overwritten only by completed steps (a failed chain stays at its last good state).
 template <class BK>
-__device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double& q, double& p, double t,
-                                                               int n_steps, const mm_fp_opts& o) {
+__device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t, int n_steps,
+                                                               const mm_fp_opts& o) {
   ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0};
-  // One loop, one metric-construction site.  `mode` says why the metric at `xq` is being built:
+  // One loop, one metric-construction site.  `mode` says why the metric at slot(SL_XQ) is being built:
   //   INIT   cold start at the initial position (LinAlgError outside a solver on failure)
   //   CFIRST first evaluation shared by the C reversibility check and the C-adjoint solve (both start
   //          at the same point, so one factorisation serves both; the reference builds it twice and
@@ -136,13 +144,18 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double& q
   //   ADJ    later iterations of the C-adjoint solve             (integrators.py:530-536)
   //   BADJ   metric at the new position for B-adjoint + final A  (integrators.py:504-515, 544)
   int mode = MODE_INIT;
-  double xq = q;
-  double g = 0.0, pw = 0.0, qw = 0.0, q_init = 0.0, ptA = 0.0;
-  FpState sC = fp_begin(0.0), sA = fp_begin(0.0);
-  int actA = FP_CONT, stA = MM_ST_OK;
+  bk.slot(SL_XQ) = bk.slot(SL_Q);
+  FpCtl cS{0, 0};  // control of the solve currently iterating (CHK, then ADJ); iterates in SL_SX0/1
+  int actA = FP_CONT, stA = MM_ST_OK, iterA = 0, stageA = 0;
 
   while (n_steps > 0) {
-    const bool okm = bk.build_and_invert(xq);
+    // Scalar-heavy work goes HERE, where the metric registers are dead (the build below overwrites
+    // every tile): the gradient at the point whose metric is about to be built for A / B-adj + A.
+    if (mode == MODE_INIT || mode == MODE_BADJ) {
+      bk.slot(SL_GNEW) = bk.grad(bk.slot(SL_XQ));
+      ++r.n_grad;
+    }
+    const bool okm = bk.build_and_invert(bk.slot(SL_XQ));
     r.n_metric += (mode == MODE_CFIRST) ? 2 : 1;
     if (!okm) {
       r.status = (mode == MODE_INIT || mode == MODE_BADJ) ? MM_ST_LINALG : MM_ST_SOLVER_LINALG;
@@ -151,54 +164,67 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double& q
     if (mode == MODE_INIT || mode == MODE_BADJ) {
       if (mode == MODE_BADJ) {
         // ---- B adj: p -= t dh2_dpos(q', p) then reversibility check     integrators.py:504-515
-        const double p_init = pw;
-        const double u = bk.matvec(pw);
-        pw = pw - t * bk.half_vjp_neg_outer(u, qw);
+        const double qw = bk.slot(SL_QW);
+        const double p_init = bk.slot(SL_PW);
+        const double u = bk.matvec(p_init);
+        double pw = p_init - t * bk.half_vjp_neg_outer(u, qw);
         double p_back;
         ++r.n_solves;
         r.status = momentum_solve(bk, pw, -t, qw, o, &p_back, &r.n_evals);
         if (r.status != MM_ST_OK) break;
-        if (bk.norm(p_back - p_init, o.rev_norm) > o.rev_tol) {
+        if (bk.norm(p_back - bk.slot(SL_PW), o.rev_norm) > o.rev_tol) {
           r.status = MM_ST_NON_REVERSIBLE;
           break;
         }
         // ---- A: p -= t dh1_dpos(q')                                      integrators.py:544
-        g = bk.grad(qw);
-        ++r.n_grad;
+        const double g = bk.slot(SL_GNEW);
         pw = pw - t * (g + bk.half_vjp_inv(qw));
-        q = qw;
-        p = pw;
+        bk.slot(SL_G) = g;
+        bk.slot(SL_Q) = qw;
+        bk.slot(SL_P) = pw;
         if (++r.done == n_steps) break;
       } else {
-        g = bk.grad(q);
-        ++r.n_grad;
+        bk.slot(SL_G) = bk.slot(SL_GNEW);
       }
       // ---- A: p -= t dh1_dpos(q), dh1 = grad + 0.5 vjp(M^-1)            integrators.py:493-494
-      pw = p - t * (g + bk.half_vjp_inv(q));
+      const double q = bk.slot(SL_Q);
+      double pw = bk.slot(SL_P) - t * (bk.slot(SL_G) + bk.half_vjp_inv(q));
       // ---- B fwd: solve p' = p - t dh2_dpos(q, p')                        integrators.py:496-502
       ++r.n_solves;
       r.status = momentum_solve(bk, pw, t, q, o, &pw, &r.n_evals);
       if (r.status != MM_ST_OK) break;
       // ---- C fwd: q += t M(q)^-1 p                                        integrators.py:517-519
-      q_init = q;
-      qw = q + t * bk.matvec(pw);
-      xq = qw;
+      bk.slot(SL_QINIT) = q;
+      const double qw = q + t * bk.matvec(pw);
+      bk.slot(SL_PW) = pw;
+      bk.slot(SL_QW) = qw;
+      bk.slot(SL_XQ) = qw;
       mode = MODE_CFIRST;
       continue;
     }
     // position-space solves: f(x) = qw -/+ t M(x)^-1 p with M(xq)^-1 now held by the backend
-    const double u = bk.matvec(pw);
+    const double u = bk.matvec(bk.slot(SL_PW));
+    const double qw = bk.slot(SL_QW);
     bool chk_done = false, adj_done = false;
     double q_back = 0.0;
     if (mode == MODE_CFIRST) {
       r.n_solves += 2;
       r.n_evals += 2;
-      sC = fp_begin(qw);
-      sA = fp_begin(qw);
+      {
+        // first evaluation of the C-adjoint solve; its state stays parked in slots until CHK is done
+        FpCtl cA{0, 0};
+        bk.slot(SL_AX0) = qw;
+        double ptA;
+        actA = fp_feed(bk, cA, bk.slot(SL_AX0), bk.slot(SL_AX1), qw + t * u, o, &ptA, &stA);
+        bk.slot(SL_PTA) = ptA;
+        iterA = cA.iter;
+        stageA = cA.stage;
+      }
+      cS = FpCtl{0, 0};
+      bk.slot(SL_SX0) = qw;
       double ptC;
       int stC = MM_ST_OK;
-      const int actC = fp_feed(bk, sC, qw - t * u, o, &ptC, &stC);
-      actA = fp_feed(bk, sA, qw + t * u, o, &ptA, &stA);
+      const int actC = fp_feed(bk, cS, bk.slot(SL_SX0), bk.slot(SL_SX1), qw - t * u, o, &ptC, &stC);
       if (actC == FP_FAIL) {
         r.status = stC;
         break;
@@ -207,43 +233,34 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double& q
         chk_done = true;
         q_back = ptC;
       } else {
-        xq = ptC;
+        bk.slot(SL_XQ) = ptC;
         mode = MODE_CHK;
         continue;
       }
-    } else if (mode == MODE_CHK) {
+    } else {  // MODE_CHK or MODE_ADJ: one more evaluation of the active solve
       ++r.n_evals;
       double pt;
       int st = MM_ST_OK;
-      const int a = fp_feed(bk, sC, qw - t * u, o, &pt, &st);
+      const double fx = (mode == MODE_CHK) ? qw - t * u : qw + t * u;
+      const int a = fp_feed(bk, cS, bk.slot(SL_SX0), bk.slot(SL_SX1), fx, o, &pt, &st);
       if (a == FP_FAIL) {
         r.status = st;
         break;
       }
       if (a == FP_CONT) {
-        xq = pt;
+        bk.slot(SL_XQ) = pt;
         continue;
       }
-      chk_done = true;
-      q_back = pt;
-    } else {  // MODE_ADJ
-      ++r.n_evals;
-      double pt;
-      int st = MM_ST_OK;
-      const int a = fp_feed(bk, sA, qw + t * u, o, &pt, &st);
-      if (a == FP_FAIL) {
-        r.status = st;
-        break;
+      if (mode == MODE_CHK) {
+        chk_done = true;
+        q_back = pt;
+      } else {
+        adj_done = true;
+        bk.slot(SL_PTA) = pt;
       }
-      if (a == FP_CONT) {
-        xq = pt;
-        continue;
-      }
-      adj_done = true;
-      ptA = pt;
     }
     if (chk_done) {
-      if (bk.norm(q_back - q_init, o.rev_norm) > o.rev_tol) {
+      if (bk.norm(q_back - bk.slot(SL_QINIT), o.rev_norm) > o.rev_tol) {
         r.status = MM_ST_NON_REVERSIBLE;  // integrators.py:523-528
         break;
       }
@@ -255,14 +272,18 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double& q
       if (actA == FP_DONE) {
         adj_done = true;
       } else {
-        xq = ptA;
+        cS = FpCtl{iterA, stageA};
+        bk.slot(SL_SX0) = bk.slot(SL_AX0);
+        bk.slot(SL_SX1) = bk.slot(SL_AX1);
+        bk.slot(SL_XQ) = bk.slot(SL_PTA);
         mode = MODE_ADJ;
         continue;
       }
     }
     if (adj_done) {
-      qw = ptA;  // state.pos = solution; the metric cache is dropped -> rebuilt for B adj
-      xq = qw;
+      const double q2 = bk.slot(SL_PTA);  // state.pos = solution; metric cache dropped -> rebuilt for B adj
+      bk.slot(SL_QW) = q2;
+      bk.slot(SL_XQ) = q2;
       mode = MODE_BADJ;
     }
   }

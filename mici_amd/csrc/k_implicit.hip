@@ -30,6 +30,7 @@ using namespace mmdev;
 using namespace mmimp;
 
 constexpr int kWaves = 4;  // chains per workgroup
+constexpr int kWaveLdsDoubles = 5 * 64 + mmimp::SL_COUNT * 64;  // per-wave scratch vectors + step state
 
 // Per-wave LDS scratch (doubles): 5 vectors of 64.
 struct WaveLds {
@@ -57,9 +58,9 @@ __device__ __forceinline__ bool sweep_inverse(double (&T)[TS][TS], int dim, int 
   double ld = 0.0, y = 0.0;
 #pragma unroll
   for (int kb = 0; kb < TS; ++kb) {
+#pragma unroll 1
     for (int kt = 0; kt < 8; ++kt) {
-      const int k = kb * 8 + kt;
-      if (k >= dim) break;
+      const int k = kb * 8 + kt;  // padded columns (k >= dim) are identity: sweeping them is a no-op
       // owners of column k publish it (rows ti + 8a live at [a][kb] of lanes with tj == kt)
       if (tj == kt) {
 #pragma unroll
@@ -235,8 +236,8 @@ __device__ __forceinline__ double grad_flat(int target, double q, int dim, int l
                                             const WaveLds& w, const double* tparams) {
   if (lane < 64) w.nat[lane] = (lane < dim) ? q : 0.0;
   wave_sync();
-  const TargetAux aux = target_prepare(target, w.nat, dim, tparams, lane);
-  const double g = (lane < dim) ? target_grad_elem(target, aux, w.nat, lane, dim, tparams) : 0.0;
+  const TargetAux aux = target_prepare<false>(target, w.nat, dim, tparams, lane);
+  const double g = (lane < dim) ? target_grad_elem<false>(target, aux, w.nat, lane, dim, tparams) : 0.0;
   wave_sync();
   return g;
 }
@@ -260,6 +261,9 @@ struct WaveBackend {
   double T[TS][TS];
   int dim, lane, target;
   WaveLds w;
+  double* stash;  // [SL_COUNT][64] flat state of the step, in LDS to keep VGPRs for the tiles
+
+  __device__ __forceinline__ double& slot(int i) { return stash[i * 64 + lane]; }
   const double* base_lds;
   const double* tparams;
 
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_leapfrog_kernel(Implicit
   double* base_lds = lds;
   const int base_elems = (RMETRIC == MM_RMETRIC_RANK1) ? 64 * Geo<TS>::TSTRIDE : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* wl = lds + base_elems + wave * 5 * 64;
+  double* wl = lds + base_elems + wave * kWaveLdsDoubles;
   stage_base<TS, RMETRIC>(base_lds, A.rparams, A.dim);
 
   const int64_t chain = (int64_t)blockIdx.x * kWaves + wave;
@@ -303,9 +307,14 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_leapfrog_kernel(Implicit
   bk.lane = lane;
   bk.target = A.target;
   bk.w = WaveLds{wl, wl + 64, wl + 128, wl + 192, wl + 256};
+  bk.stash = wl + 320;
   bk.base_lds = base_lds;
   bk.tparams = A.tparams;
-  const ChainResult r = implicit_leapfrog_chain(bk, q, p, t, A.n_steps, A.opts);
+  bk.slot(SL_Q) = q;
+  bk.slot(SL_P) = p;
+  const ChainResult r = implicit_leapfrog_chain(bk, t, A.n_steps, A.opts);
+  q = bk.slot(SL_Q);
+  p = bk.slot(SL_P);
 
   // a failed step leaves q, p at the last completed step (they are only overwritten on success)
   if (act) {
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(64 * kWaves) void riemann_aux_kernel(ImplicitArgs A
   double* base_lds = lds;
   const int base_elems = (RMETRIC == MM_RMETRIC_RANK1) ? 64 * Geo<TS>::TSTRIDE : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* wl = lds + base_elems + wave * 5 * 64;
+  double* wl = lds + base_elems + wave * kWaveLdsDoubles;
   const WaveLds w{wl, wl + 64, wl + 128, wl + 192, wl + 256};
   stage_base<TS, RMETRIC>(base_lds, A.rparams, A.dim);
   const int64_t chain = (int64_t)blockIdx.x * kWaves + wave;
@@ -344,8 +353,8 @@ __global__ __launch_bounds__(64 * kWaves) void riemann_aux_kernel(ImplicitArgs A
     const double u = matvec_flat<TS>(T, p, lane, w);
     w.nat[lane] = act ? q : 0.0;
     wave_sync();
-    const TargetAux aux = target_prepare(A.target, w.nat, dim, A.tparams, lane);
-    double e = act ? target_nld_elem(A.target, aux, w.nat, lane, dim, A.tparams) + 0.5 * p * u : 0.0;
+    const TargetAux aux = target_prepare<false>(A.target, w.nat, dim, A.tparams, lane);
+    double e = act ? target_nld_elem<false>(A.target, aux, w.nat, lane, dim, A.tparams) + 0.5 * p * u : 0.0;
     e = wave_sum(e) + 0.5 * logdet;
     if (lane == 0) A.out[chain] = ok ? e : nan;
   } else if constexpr (OP == 1) {
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(64 * kWaves) void riemann_aux_kernel(ImplicitArgs A
 template <int TS, int RMETRIC>
 size_t lds_bytes() {
   const size_t base = (RMETRIC == MM_RMETRIC_RANK1) ? 64 * Geo<TS>::TSTRIDE : 0;
-  return (base + kWaves * 5 * 64) * sizeof(double);
+  return (base + kWaves * kWaveLdsDoubles) * sizeof(double);
 }
 
 template <int TS, int RMETRIC>

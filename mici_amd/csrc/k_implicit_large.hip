@@ -1,17 +1,17 @@
-// Implicit leapfrog on dense-metric Riemannian systems for 64 < D <= 279 (BASELINE config c4:
-// D = 256): one 512-thread workgroup (a whole CU) per chain.  gfx950 / CDNA4.
+// Implicit leapfrog on dense-metric Riemannian systems for 64 < D <= 264 (BASELINE config c4:
+// D = 256): one 1024-thread workgroup (a whole CU) per chain.  gfx950 / CDNA4.
 //
 // Same reference arithmetic as k_implicit.hip (the step itself is implicit_core.h); what changes is
 // where the D x D metric lives.  512 KB of fp64 does not fit one CU's LDS (160 KB), but the symmetric
 // half (D(D+1)/2 * 8 B = 263 KB at D = 256) fits its 512 KB register file:
-//   * threads form the lower triangle of a 31 x 31 grid (496 of the 512 threads); thread (ti >= tj)
-//     owns the 9 x 9 block-cyclic tile {(ti + 31 a, tj + 31 b)} = 162 VGPRs.  31 * 9 = 279 >= 256, and
-//     a prime grid keeps the 2 x 8 waves under the 256-VGPR/wave budget (2 waves per SIMD).
+//   * the 1024 threads (16 waves, 4 per SIMD, 128 VGPRs each) form the lower triangle of a 44 x 44
+//     grid (990 tile owners); thread (ti >= tj) owns the 6 x 6 block-cyclic tile
+//     {(ti + 44 a, tj + 44 b)} = 72 VGPRs.  44 * 6 = 264 >= 256.
 //   * the symmetric sweep operator keeps the matrix symmetric, so the mirrored tiles are never needed:
-//     step k publishes column k (from the tiles of grid column k%31 and, transposed, of grid row k%31)
-//     into LDS; every thread then applies T[a][b] -= m[a] * c[b] (81 v_fma_f64) from 18 LDS operands.
-//   * M^-1 v: each tile contributes to 9 "row" and (off-diagonal tiles) 9 "column" partial sums, laid
-//     out in LDS so that every output element has exactly 31 private slots -> deterministic reduction.
+//     step k publishes column k (from the tiles of grid column k%44 and, transposed, of grid row k%44)
+//     into LDS; every thread then applies at(a, b) -= m[a] * c[b] (36 v_fma_f64) from 12 LDS operands.
+//   * M^-1 v: each tile contributes to 6 "row" and (off-diagonal tiles) 6 "column" partial sums, laid
+//     out in LDS so that every output element has exactly 44 private slots -> deterministic reduction.
 // Throughput is one chain per CU, 256 chains in flight per GPU.
 #include "implicit_core.h"
 
@@ -23,13 +23,21 @@ using namespace mmimp;
 constexpr int PG = 31;             // process-grid side
 constexpr int TS = 9;              // tile side
 constexpr int DP = PG * TS;        // 279: padded dimension
-constexpr int NT = 512;            // threads per workgroup
+constexpr int NT = 512;            // threads per workgroup (8 waves, 2 per SIMD -> 256 VGPRs each)
 constexpr int NTILE = PG * (PG + 1) / 2;  // 496 tile-owning threads
 constexpr int GS = 10;             // doubles reserved per grid group in a permuted LDS vector
 constexpr int PV = PG * GS;        // permuted vector length
 constexpr int SLOTS = 33;          // 31 partial-sum slots per output element (+2 pad vs bank conflicts)
 
 __device__ __forceinline__ int ppos(int i) { return (i % PG) * GS + i / PG; }
+
+// Launder a lane-varying index so that address arithmetic derived from it is recomputed where it is
+// used instead of being hoisted out of the step loop into long-lived VGPRs (the register file is full
+// of metric tiles; a few integer ops per use are free).
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 
 struct BlockLds {
   double* col0;
@@ -39,8 +47,10 @@ struct BlockLds {
   double* nat;   // natural order [DP + pad]
   double* aux;   // natural order [DP + pad]
   double* red;   // [16]
+  double* stash; // [SL_COUNT][288] per-thread flat state of the step (keeps it out of VGPRs)
+  double* trow;  // [TS][NT] the last tile row of every thread (register relief, see BlockBackend::at)
 };
-constexpr int kLdsDoubles = 3 * PV + PG * TS * SLOTS + 2 * 288 + 16;
+constexpr int kLdsDoubles = 3 * PV + PG * TS * SLOTS + 2 * 288 + 16 + SL_COUNT * 288 + TS * NT;
 
 __device__ __forceinline__ double block_reduce(double v, int kind_max, double* red) {
   // kind_max: 0 sum, 1 NaN-propagating max.  Uniform result; two barriers.
@@ -57,12 +67,22 @@ __device__ __forceinline__ double block_reduce(double v, int kind_max, double* r
 
 template <int RMETRIC>
 struct BlockBackend {
-  double T[TS][TS];
+  // Tile storage: rows 0..TS-2 in registers (144 VGPRs), row TS-1 in LDS.  The compiler could not
+  // keep all 81 doubles plus the sweep operands inside the 256-VGPR budget of a wave here and spilled
+  // tile entries to scratch (L2-bound: measured 8x slowdown of the sweep); parking one row in LDS by
+  // hand removes the spills at the price of 18 LDS accesses per sweep step.
+  double Treg[TS - 1][TS];
+  __device__ __forceinline__ double& at(int a, int b) {
+    return a < TS - 1 ? Treg[a][b] : w.trow[b * NT + tid];
+  }
   int dim, tid, ti, tj, target;
   bool tile;  // this thread owns a tile
   BlockLds w;
-  const double* base;  // global (L2-resident) base matrix of the rank-one metric
+  const double* base;  // global (L2-resident) base matrix of the rank-one metric, zero-padded DP x DP
   const double* tparams;
+
+  // flat state only exists for tid < DP; the other threads share one dummy cell per slot
+  __device__ __forceinline__ double& slot(int i) { return w.stash[i * 288 + (tid < DP ? tid : 287)]; }
 
   __device__ __forceinline__ double norm(double x, int kind) {
     const double a = tid < dim ? x : 0.0;
@@ -75,47 +95,40 @@ struct BlockBackend {
     if (tid < DP) w.vin[ppos(tid)] = (tid < dim) ? x : 0.0;
     __syncthreads();
     double chk = 0.0;
-    if (tile) {
-      double qr[TS], qc[TS], vr[TS], vc[TS];
-      int ir[TS], jc[TS];
+    const int ti = opaque(this->ti), tj = opaque(this->tj);
+    {  // every thread builds a tile (threads >= 496 duplicate tile (30,30)): the tiles are then fully
+       // re-defined here, i.e. dead before this point, which frees their registers for scalar work
+      // `base` is the rank-one metric's base matrix zero-padded to DP x DP on the host, and x is 0 on the
+      // padding, so the closed form is exactly 0 on padded entries; the padded diagonal is set to 1 below.
+      double qc[TS];
 #pragma unroll
-      for (int a = 0; a < TS; ++a) {
-        qr[a] = w.vin[ti * GS + a];
-        qc[a] = w.vin[tj * GS + a];
-        const int i = ti + PG * a, j = tj + PG * a;
-        vr[a] = i < dim ? 1.0 : 0.0;
-        vc[a] = j < dim ? 1.0 : 0.0;
-        ir[a] = i < dim ? i : dim - 1;
-        jc[a] = j < dim ? j : dim - 1;
-      }
+      for (int b = 0; b < TS; ++b) qc[b] = w.vin[tj * GS + b];
       const double inv_d = 1.0 / (double)dim;
 #pragma unroll
       for (int a = 0; a < TS; ++a) {
-        // one tile row at a time: keeps only 9 loads (and their addresses) in flight
-        const double* brow = base + (int64_t)ir[a] * dim;
+        // one tile row at a time: 9 loads with immediate offsets from one row pointer
+        const double qa = w.vin[ti * GS + a] * inv_d;
+        if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+          const double* brow = base + (int64_t)(ti + PG * a) * DP + tj;
 #pragma unroll
-        for (int b = 0; b < TS; ++b) {
-          double v;
-          if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-            v = (vr[a] * vc[b]) * (brow[jc[b]] + (qr[a] * qc[b]) * inv_d);
-          } else {
-            v = 0.0;
-          }
-          T[a][b] = v;
+          for (int b = 0; b < TS; ++b) at(a, b) = __builtin_fma(qa, qc[b], brow[PG * b]);
+        } else {
+#pragma unroll
+          for (int b = 0; b < TS; ++b) at(a, b) = 0.0;
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (ti == tj) {
 #pragma unroll
         for (int a = 0; a < TS; ++a) {
-          if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) T[a][a] = __builtin_fma(qr[a], qr[a], 1.0);
-          if (ti + PG * a >= dim) T[a][a] = 1.0;
+          if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) at(a, a) = __builtin_fma(qc[a], qc[a], 1.0);
+          if (ti + PG * a >= dim) at(a, a) = 1.0;
         }
       }
 #pragma unroll
       for (int a = 0; a < TS; ++a)
 #pragma unroll
-        for (int b = 0; b < TS; ++b) chk = __builtin_fma(T[a][b], 0.0, chk);
+        for (int b = 0; b < TS; ++b) chk = __builtin_fma(at(a, b), 0.0, chk);
     }
     // NaN in chk <=> some entry is inf/NaN ("Array is not finite.", matrices.py:211-215)
     const double bad = block_reduce(chk == 0.0 ? 0.0 : 1.0, 0, w.red);
@@ -129,17 +142,18 @@ struct BlockBackend {
     double ld = 0.0, y = 0.0;
 #pragma unroll
     for (int kb = 0; kb < TS; ++kb) {
+#pragma unroll 1
       for (int kt = 0; kt < PG; ++kt) {
         const int k = kb * PG + kt;
-        if (k >= dim) break;
+        const int ti = opaque(this->ti), tj = opaque(this->tj);
         double* col = (k & 1) ? w.col1 : w.col0;
         if (tile) {
           if (tj == kt) {  // grid column kt: rows ti + 31 a
 #pragma unroll
-            for (int a = 0; a < TS; ++a) col[ti * GS + a] = T[a][kb];
+            for (int a = 0; a < TS; ++a) col[ti * GS + a] = at(a, kb);
           } else if (ti == kt) {  // grid row kt (tj < kt): entries (k, tj + 31 b) = column k by symmetry
 #pragma unroll
-            for (int b = 0; b < TS; ++b) col[tj * GS + b] = T[kb][b];
+            for (int b = 0; b < TS; ++b) col[tj * GS + b] = at(kb, b);
           }
         }
         __syncthreads();
@@ -151,30 +165,29 @@ struct BlockBackend {
           const double rs = 1.0 / sqrt(piv);
           if (tid >= k && tid < dim) y += (col[ppos(tid)] * rs) * w.aux[k];
         }
-        if (tile) {
-          double ar[TS], ac[TS];
+        {
+          double ac[TS];
+#pragma unroll
+          for (int b = 0; b < TS; ++b) ac[b] = col[tj * GS + b];
+          if (tj == kt) ac[kb] = piv - 1.0;
+          // one tile row at a time: only one row multiplier is live (register budget: 256 / wave)
 #pragma unroll
           for (int a = 0; a < TS; ++a) {
-            ar[a] = col[ti * GS + a] * d;
-            ac[a] = col[tj * GS + a];
+            double m = col[ti * GS + a] * d;
+            if (a == kb && ti == kt) m = 1.0 - d;
+#pragma unroll
+            for (int b = 0; b < TS; ++b) at(a, b) = __builtin_fma(-m, ac[b], at(a, b));
+            __builtin_amdgcn_sched_barrier(0);
           }
-          if (ti == kt) ar[kb] = 1.0 - d;
-          if (tj == kt) ac[kb] = piv - 1.0;
-#pragma unroll
-          for (int a = 0; a < TS; ++a)
-#pragma unroll
-            for (int b = 0; b < TS; ++b) T[a][b] = __builtin_fma(-ar[a], ac[b], T[a][b]);
-          if (ti == kt && tj == kt) T[kb][kb] -= 2.0;
+          if (ti == kt && tj == kt) at(kb, kb) -= 2.0;
         }
         // the next step publishes into the other buffer; the barrier of that step orders reuse
       }
     }
-    if (tile) {
 #pragma unroll
-      for (int a = 0; a < TS; ++a)
+    for (int a = 0; a < TS; ++a)
 #pragma unroll
-        for (int b = 0; b < TS; ++b) T[a][b] = -T[a][b];
-    }
+      for (int b = 0; b < TS; ++b) at(a, b) = -at(a, b);
     __syncthreads();
     if constexpr (LOGDET) *logdet = ld;
     if constexpr (CHOLVEC) *chol_y = y;
@@ -188,32 +201,31 @@ struct BlockBackend {
   }
 
   __device__ __forceinline__ double matvec(double v) {
+    const int tid = opaque(this->tid), ti = opaque(this->ti), tj = opaque(this->tj);
     if (tid < DP) w.vin[ppos(tid)] = (tid < dim) ? v : 0.0;
     __syncthreads();
-    if (tile) {
+    {
       double xr[TS], xc[TS];
 #pragma unroll
       for (int a = 0; a < TS; ++a) {
         xr[a] = w.vin[ti * GS + a];
         xc[a] = w.vin[tj * GS + a];
       }
-      // row partials: y[ti + 31 a] += sum_b T[a][b] x[tj + 31 b]  -> slot tj of group ti
+      // row partials: y[ti + 31 a] += sum_b at(a, b) x[tj + 31 b]  -> slot tj of group ti
 #pragma unroll
       for (int a = 0; a < TS; ++a) {
         double s = 0.0;
 #pragma unroll
-        for (int b = 0; b < TS; ++b) s = __builtin_fma(T[a][b], xc[b], s);
-        w.part[(ti * TS + a) * SLOTS + tj] = s;
+        for (int b = 0; b < TS; ++b) s = __builtin_fma(at(a, b), xc[b], s);
+        if (tile) w.part[(ti * TS + a) * SLOTS + tj] = s;
       }
-      // column partials of off-diagonal tiles (the mirrored tile): y[tj + 31 b] += sum_a T[a][b] x[ti + 31 a]
-      if (ti != tj) {
+      // column partials of off-diagonal tiles (the mirrored tile): y[tj + 31 b] += sum_a at(a, b) x[ti + 31 a]
 #pragma unroll
-        for (int b = 0; b < TS; ++b) {
-          double s = 0.0;
+      for (int b = 0; b < TS; ++b) {
+        double s = 0.0;
 #pragma unroll
-          for (int a = 0; a < TS; ++a) s = __builtin_fma(T[a][b], xr[a], s);
-          w.part[(tj * TS + b) * SLOTS + ti] = s;
-        }
+        for (int a = 0; a < TS; ++a) s = __builtin_fma(at(a, b), xr[a], s);
+        if (tile && ti != tj) w.part[(tj * TS + b) * SLOTS + ti] = s;
       }
     }
     __syncthreads();
@@ -230,7 +242,7 @@ struct BlockBackend {
   __device__ __forceinline__ double diag() {
     if (tile && ti == tj) {
 #pragma unroll
-      for (int a = 0; a < TS; ++a) w.vin[ti * GS + a] = T[a][a];
+      for (int a = 0; a < TS; ++a) w.vin[ti * GS + a] = at(a, a);
     }
     __syncthreads();
     const double y = (tid < dim) ? w.vin[ppos(tid)] : 0.0;
@@ -255,8 +267,8 @@ struct BlockBackend {
   __device__ __forceinline__ double grad(double q) {
     if (tid < 288) w.nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
-    const TargetAux aux = target_prepare(target, w.nat, dim, tparams, threadIdx.x & 63);
-    const double g = (tid < dim) ? target_grad_elem(target, aux, w.nat, tid, dim, tparams) : 0.0;
+    const TargetAux aux = target_prepare<false>(target, w.nat, dim, tparams, threadIdx.x & 63);
+    const double g = (tid < dim) ? target_grad_elem<false>(target, aux, w.nat, tid, dim, tparams) : 0.0;
     __syncthreads();
     return g;
   }
@@ -264,8 +276,8 @@ struct BlockBackend {
   __device__ __forceinline__ double neg_log_dens_elem(double q) {
     if (tid < 288) w.nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
-    const TargetAux aux = target_prepare(target, w.nat, dim, tparams, threadIdx.x & 63);
-    const double e = (tid < dim) ? target_nld_elem(target, aux, w.nat, tid, dim, tparams) : 0.0;
+    const TargetAux aux = target_prepare<false>(target, w.nat, dim, tparams, threadIdx.x & 63);
+    const double e = (tid < dim) ? target_nld_elem<false>(target, aux, w.nat, tid, dim, tparams) : 0.0;
     __syncthreads();
     return e;
   }
@@ -282,8 +294,8 @@ __device__ __forceinline__ void init_backend(BlockBackend<RMETRIC>& bk, const Im
   int ti = (int)((sqrtf(8.0f * (float)tid + 1.0f) - 1.0f) * 0.5f);
   while (ti * (ti + 1) / 2 > tid) --ti;
   while ((ti + 1) * (ti + 2) / 2 <= tid) ++ti;
-  bk.ti = ti;
-  bk.tj = tid - ti * (ti + 1) / 2;
+  bk.ti = bk.tile ? ti : PG - 1;
+  bk.tj = bk.tile ? tid - ti * (ti + 1) / 2 : PG - 1;
   bk.w.col0 = lds;
   bk.w.col1 = lds + PV;
   bk.w.vin = lds + 2 * PV;
@@ -291,6 +303,8 @@ __device__ __forceinline__ void init_backend(BlockBackend<RMETRIC>& bk, const Im
   bk.w.nat = bk.w.part + PG * TS * SLOTS;
   bk.w.aux = bk.w.nat + 288;
   bk.w.red = bk.w.aux + 288;
+  bk.w.stash = bk.w.red + 16;
+  bk.w.trow = bk.w.stash + SL_COUNT * 288;
   bk.base = A.rparams;
   bk.tparams = A.tparams;
 }
@@ -306,7 +320,11 @@ __global__ __launch_bounds__(NT, 2) void implicit_large_kernel(ImplicitArgs A) {
   double q = act ? A.pos[chain * dim + tid] : 0.0;
   double p = act ? A.mom[chain * dim + tid] : 0.0;
   const double t = (double)A.dir[chain] * A.step_size;
-  const ChainResult r = implicit_leapfrog_chain(bk, q, p, t, A.n_steps, A.opts);
+  bk.slot(SL_Q) = q;
+  bk.slot(SL_P) = p;
+  const ChainResult r = implicit_leapfrog_chain(bk, t, A.n_steps, A.opts);
+  q = bk.slot(SL_Q);
+  p = bk.slot(SL_P);
   if (act) {
     A.pos[chain * dim + tid] = q;
     A.mom[chain * dim + tid] = p;
@@ -361,7 +379,7 @@ ImplicitArgs make_args(const mm_model* m, mm_state* s) {
   a.dim = s->dim;
   a.target = m->target;
   a.tparams = m->d_target_params;
-  a.rparams = m->d_rmetric_params;
+  a.rparams = m->d_rmetric_padded;  // zero-padded to 279 x 279 for the rank-one metric
   return a;
 }
 

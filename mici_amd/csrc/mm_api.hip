@@ -207,6 +207,11 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
   MM_REQUIRE(ctx, d->constr != MM_CONSTR_CIRCLE || D >= 2, "circle constraint needs dim >= 2");
   MM_REQUIRE(ctx, d->constr == MM_CONSTR_NONE || d->rmetric == MM_RMETRIC_NONE,
              "mm_model_create: constrained Riemannian systems are not part of the path");
+  MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE || d->target != MM_TARGET_TORUS,
+             "mm_model_create: the torus target is only defined for constrained systems");
+  MM_REQUIRE(ctx, d->target != MM_TARGET_FUNNEL || d->rmetric == MM_RMETRIC_NONE ||
+                      d->rmetric == MM_RMETRIC_SOFTABS,
+             "mm_model_create: the funnel target pairs with a fixed metric or the SoftAbs metric");
   if (d->rmetric == MM_RMETRIC_SOFTABS) {
     MM_REQUIRE(ctx, d->rmetric_params[0] > 0.0, "softabs_coeff must be positive");  // matrices.py:1652-1654
     MM_REQUIRE(ctx, d->target == MM_TARGET_FUNNEL || d->target == MM_TARGET_POLY,
@@ -230,6 +235,14 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
   int rc = upload(ctx, d->target_params, need_t, &m->d_target_params);
   if (rc == MM_OK) rc = upload(ctx, d->rmetric_params, need_r, &m->d_rmetric_params);
   if (rc == MM_OK) rc = upload(ctx, d->constr_params, need_c, &m->d_constr_params);
+  if (rc == MM_OK && d->rmetric == MM_RMETRIC_RANK1 && D > 64 && D <= 279) {
+    // workgroup-per-chain kernels read the base matrix through a fixed 279-wide zero-padded image
+    const int DP = 279;
+    std::vector<double> pad((size_t)DP * DP, 0.0);
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < D; ++j) pad[(size_t)i * DP + j] = d->rmetric_params[(size_t)i * D + j];
+    rc = upload(ctx, pad.data(), pad.size(), &m->d_rmetric_padded);
+  }
   if (rc == MM_OK) rc = upload(ctx, d->metric, need_m, &m->d_metric);
   if (rc == MM_OK && d->metric_kind == MM_METRIC_DIAG) {
     std::vector<double> inv(D), sq(D);
@@ -270,6 +283,7 @@ int mm_model_destroy(mm_model* m) {
   (void)hipFree(m->d_metric_inv);
   (void)hipFree(m->d_metric_chol);
   (void)hipFree(m->d_rmetric_params);
+  (void)hipFree(m->d_rmetric_padded);
   (void)hipFree(m->d_constr_params);
   delete m;
   return MM_OK;

@@ -49,9 +49,14 @@ struct TargetAux {
 };
 
 // Wave-collective: reductions a target needs before its per-element gradient can be formed.
+// TRIG = false compiles the transcendental targets (torus, funnel) out: the constant tables of
+// exp / atan2 / sin / cos get hoisted into long-lived VGPRs, which the register-resident-metric
+// kernels cannot spare (measured: 18 VGPRs for exp alone).
+template <bool TRIG = true>
 __device__ __forceinline__ TargetAux target_prepare(int target, const double* q, int dim,
                                                     const double* __restrict__ tp, int lane) {
   TargetAux a;
+  if constexpr (!TRIG) return a;
   if (target == MM_TARGET_FUNNEL) {
     double s = 0.0;
     for (int i = 1 + lane; i < dim; i += 64) s += tp[i - 1] * q[i] * q[i];
@@ -62,8 +67,14 @@ __device__ __forceinline__ TargetAux target_prepare(int target, const double* q,
 }
 
 // grad_neg_log_dens element i.  For MM_TARGET_GAUSS_DENSE the row dot product reads P from global.
+// TRIG = false compiles the torus target out: its atan2/sin/cos/log1p expansions need ~80 VGPRs,
+// which the register-resident-metric kernels (Riemannian systems, never on a torus) cannot spare.
+template <bool TRIG = true>
 __device__ __forceinline__ double target_grad_elem(int target, const TargetAux& a, const double* q,
                                                    int i, int dim, const double* __restrict__ tp) {
+  if constexpr (!TRIG) {
+    if (target == MM_TARGET_TORUS || target == MM_TARGET_FUNNEL) return 0.0;
+  }
   switch (target) {
     case MM_TARGET_GAUSS_ISO:
       return q[i];
@@ -83,11 +94,11 @@ __device__ __forceinline__ double target_grad_elem(int target, const TargetAux& 
       if (i < dim - 1) g -= 4.0 * q[i] * (q[i + 1] - q[i] * q[i]);
       return g;
     }
-    case MM_TARGET_FUNNEL: {
+    case MM_TARGET_FUNNEL: if constexpr (TRIG) {
       if (i == 0) return q[0] / 9.0 + 0.5 * (dim - 1) - 0.5 * a.s1 * a.s0;
       return a.s1 * tp[i - 1] * q[i];
-    }
-    case MM_TARGET_TORUS: {
+    } else { return 0.0; }
+    case MM_TARGET_TORUS: if constexpr (TRIG) {
       const double R = tp[0], r = tp[1], al = tp[2];
       const double x = q[0], y = q[1], z = q[2];
       const double rho2 = x * x + y * y, rho = sqrt(rho2);
@@ -101,22 +112,26 @@ __device__ __forceinline__ double target_grad_elem(int target, const TargetAux& 
       if (i == 0) return dl_dth * (-y / rho2) + dl_dphi * dphi_drho * (x / rho);
       if (i == 1) return dl_dth * (x / rho2) + dl_dphi * dphi_drho * (y / rho);
       return dl_dphi * dphi_dz;
-    }
+    } else { return 0.0; }
     default:
       return 0.0;
   }
 }
 
 // neg_log_dens = wave_sum over i of this per-element term.
+template <bool TRIG = true>
 __device__ __forceinline__ double target_nld_elem(int target, const TargetAux& a, const double* q,
                                                   int i, int dim, const double* __restrict__ tp) {
+  if constexpr (!TRIG) {
+    if (target == MM_TARGET_TORUS || target == MM_TARGET_FUNNEL) return 0.0;
+  }
   switch (target) {
     case MM_TARGET_GAUSS_ISO:
       return 0.5 * q[i] * q[i];
     case MM_TARGET_GAUSS_DIAG:
       return 0.5 * tp[i] * q[i] * q[i];
     case MM_TARGET_GAUSS_DENSE:
-      return 0.5 * q[i] * target_grad_elem(target, a, q, i, dim, tp);
+      return 0.5 * q[i] * target_grad_elem<TRIG>(target, a, q, i, dim, tp);
     case MM_TARGET_POLY: {
       const double q2 = q[i] * q[i];
       return 0.5 * tp[0] * q2 + 0.25 * tp[1] * q2 * q2;
@@ -131,13 +146,13 @@ __device__ __forceinline__ double target_nld_elem(int target, const TargetAux& a
     }
     case MM_TARGET_FUNNEL:
       return i == 0 ? q[0] * q[0] / 18.0 + 0.5 * (dim - 1) * q[0] + 0.5 * a.s1 * a.s0 : 0.0;
-    case MM_TARGET_TORUS: {
+    case MM_TARGET_TORUS: if constexpr (TRIG) {
       if (i != 0) return 0.0;
       const double R = tp[0], r = tp[1], al = tp[2];
       const double rho = sqrt(q[0] * q[0] + q[1] * q[1]);
       const double theta = atan2(q[1], q[0]), phi = atan2(q[2], rho - R);
       return log1p(r * cos(phi) / R) - log1p(sin(4.0 * theta) * cos(phi) * al);
-    }
+    } else { return 0.0; }
     default:
       return 0.0;
   }

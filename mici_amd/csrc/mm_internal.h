@@ -32,6 +32,7 @@ struct mm_model {
   double* d_metric_inv = nullptr;   // diag: 1/diag [D]; dense: explicit inverse [D*D]
   double* d_metric_chol = nullptr;  // diag: sqrt(diag) [D]; dense: lower Cholesky factor [D*D]
   double* d_rmetric_params = nullptr;
+  double* d_rmetric_padded = nullptr;  // rank-one base matrix zero-padded to 279 x 279 (dim > 64)
   size_t n_rmetric_params = 0;
   double* d_constr_params = nullptr;
   size_t n_constr_params = 0;
