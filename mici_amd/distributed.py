@@ -1,0 +1,119 @@
+"""Multi-GPU: shard independent chains across ranks, gather traces once per collection.
+
+The reference's only parallelism is data-parallel over chains: one chain per worker process, work
+handed out through queues and traces collected through per-chain ``.npy`` memmaps
+(reference samplers.py:546-565, 668-772, 104-138).  Here each rank (one process per GPU) owns a
+contiguous shard of the chains; there is no communication during integration; trace collection is
+one all-gather of the shard positions - RCCL over xGMI on device buffers (``RcclTraceGather``) or,
+for host arrays / CPU tests, any ``torch.distributed`` group (``gather_host``).
+
+Shards are padded to equal length (the collective needs equal counts); padding rows are dropped
+again after the gather."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+
+def shard_bounds(n_chains, world_size):
+    """Contiguous balanced shards: returns [(start, stop)] * world_size covering range(n_chains)."""
+    base, extra = divmod(int(n_chains), int(world_size))
+    bounds, start = [], 0
+    for r in range(world_size):
+        stop = start + base + (1 if r < extra else 0)
+        bounds.append((start, stop))
+        start = stop
+    return bounds
+
+
+def padded_shard_len(n_chains, world_size):
+    return -(-int(n_chains) // int(world_size))
+
+
+def take_shard(array, rank, world_size, pad=True):
+    """Rows of ``array`` owned by ``rank``; padded (by repeating the last owned row, or zeros for
+    an empty shard) to the common length so that every rank runs the same batch shape."""
+    array = np.asarray(array)
+    n = array.shape[0]
+    start, stop = shard_bounds(n, world_size)[rank]
+    shard = array[start:stop]
+    if pad:
+        want = padded_shard_len(n, world_size)
+        if shard.shape[0] < want:
+            fill = shard[-1:] if shard.shape[0] else np.zeros((1,) + array.shape[1:], array.dtype)
+            shard = np.concatenate([shard] + [fill] * (want - shard.shape[0]), axis=0)
+    return np.ascontiguousarray(shard)
+
+
+def unpad_gathered(gathered, n_chains, world_size):
+    """Drop the padding rows of a rank-major gather of padded shards -> global chain order."""
+    want = padded_shard_len(n_chains, world_size)
+    gathered = np.asarray(gathered)
+    parts = []
+    for r, (start, stop) in enumerate(shard_bounds(n_chains, world_size)):
+        parts.append(gathered[r * want: r * want + (stop - start)])
+    return np.concatenate(parts, axis=0)
+
+
+def gather_host(local, n_chains, group=None):
+    """All-gather padded host shards through torch.distributed (any backend; gloo in the CPU
+    tests) and return the un-padded global array on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    t = torch.from_numpy(np.ascontiguousarray(local))
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return unpad_gathered(np.concatenate([o.numpy() for o in out], axis=0), n_chains, world)
+
+
+def exchange_unique_id(ctx, group=None):
+    """Rank 0 creates the RCCL unique id; it is broadcast as 128 bytes over the host group."""
+    import torch
+    import torch.distributed as dist
+
+    buf = torch.zeros(_ffi.MM_COMM_ID_BYTES, dtype=torch.uint8)
+    if dist.get_rank(group) == 0:
+        raw = (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)()
+        _ffi.check(ctx._lib.mm_comm_unique_id(raw), None, "mm_comm_unique_id")
+        buf = torch.tensor(list(raw), dtype=torch.uint8)
+    dist.broadcast(buf, src=0, group=group)
+    return (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)(*buf.tolist())
+
+
+class RcclTraceGather:
+    """One RCCL communicator per rank; ``gather(batch)`` all-gathers the device-resident position
+    shards over xGMI and returns the global [world * n_local, D] array on the host."""
+
+    def __init__(self, ctx, rank, world_size, unique_id):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world_size)
+        h = C.c_void_p()
+        _ffi.check(ctx._lib.mm_comm_create(ctx.handle, self.world, self.rank, unique_id, C.byref(h)),
+                   ctx.handle, "mm_comm_create")
+        self.handle = h
+        self._out = None
+
+    def gather(self, batch):
+        shape = (self.world * batch.n_chains, batch.dim)
+        if self._out is None or self._out.shape != shape:
+            self._out = np.empty(shape)
+        _ffi.check(self.ctx._lib.mm_comm_allgather_pos(
+            self.handle, batch.handle, self._out.ctypes.data_as(_ffi.c_double_p)),
+            self.ctx.handle, "mm_comm_allgather_pos")
+        return self._out
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            self.ctx._lib.mm_comm_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
