@@ -79,6 +79,18 @@ def make_workload(config, n_chains, rng):
                          "target) + ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
                     system=system, osys=osys, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
                     flops_per_chain_step=None, bound="mfma", kind="riemann")
+    if config == "c3b":
+        dim, h, traj = 64, 0.02, 100
+        wts = np.linspace(0.5, 2.0, dim - 1)
+        system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(wts), softabs_coeff=1.0)
+        osys = orc.RiemannianSystem(omdl.Funnel(wts), None, 1.0)
+        integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+        q0 = rng.standard_normal((n_chains, dim))
+        p0 = system.sample_momentum_batch(q0, rng.standard_normal((n_chains, dim)))
+        return dict(name="c3(b) SoftAbsRiemannianMetricSystem (scaled funnel) + "
+                         "ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
+                    system=system, osys=osys, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
+                    flops_per_chain_step=None, bound="mfma", kind="softabs")
     if config == "c5":
         dim, h, traj = 3, 0.1, 1000
         system = systems.DenseConstrainedEuclideanMetricSystem(models.Torus(), models.TorusConstr())
@@ -105,8 +117,8 @@ def cpu_baseline(w, budget_s=20.0):
         cores = os.cpu_count() or 1
     if w["kind"] != "euclid":
         # per-chain NumPy oracle (how the reference itself runs: one chain at a time, one core)
-        fn = orc.implicit_leapfrog_steps if w["kind"] == "riemann" else orc.constrained_leapfrog_steps
-        steps = {"riemann": 5, "constrained": 50}[w["kind"]]
+        fn = orc.constrained_leapfrog_steps if w["kind"] == "constrained" else orc.implicit_leapfrog_steps
+        steps = {"riemann": 5, "softabs": 3, "constrained": 50}[w["kind"]]
         done, n1 = 0, 0
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < budget_s and n1 < w["q0"].shape[0]:
@@ -168,7 +180,7 @@ def main():
     from mici_amd.runtime import Context, DeviceBatch
 
     ctx = Context(local_rank)
-    n_local = args.chains_per_gpu or {"c3": 1024, "c4": 1024, "c5": 2048}.get(args.config, 4096)
+    n_local = args.chains_per_gpu or {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048}.get(args.config, 4096)
     rng = np.random.default_rng(1234 + rank)
     w = make_workload(args.config, n_local, rng)
     traj = args.traj_len or w["traj"]
@@ -273,6 +285,15 @@ def main():
         value = total_steps / elapsed
         launch_s = kernel_ms / 1e3 / args.steps
         chain_steps_per_launch = n_local * traj
+        if w["kind"] == "softabs":
+            # algorithmic flops: n_eig * 9 D^3 (symmetric eigendecomposition
+            # with vectors) + 4 D^3 per momentum-solve evaluation (grad_quadratic_form_inv's two GEMMs)
+            d = float(w["dim"])
+            n_m = counters_acc.get("n_metric", 0)
+            n_b = max(counters_acc.get("n_fp_evals", 0) - n_m, 0)
+            flops_total = n_m * 9 * d**3 + n_b * 4 * d**3
+            w["flops_per_chain_step"] = flops_total / max(done_local, 1.0)
+            chain_steps_per_launch = done_local / args.steps
         if w["kind"] == "riemann":
             # algorithmic flops of SURVEY.md section 8d from the device work counters:
             #   n_M D^3/3 (factorisations) + n_inv 2D^3/3 (one explicit inverse per completed step)
@@ -319,7 +340,8 @@ def main():
             "config": {
                 "workload": f"{w['name']}, D={w['dim']}, {n_local} chains/GPU x {world} GPU, "
                             f"h={w['h']}, one pass = a trajectory of {traj} leapfrog steps per chain",
-                "baseline_config": {"c2": "BASELINE.json configs[1]", "c3": "BASELINE.json configs[2]",
+                "baseline_config": {"c2": "BASELINE.json configs[1]", "c3": "BASELINE.json configs[2] (Cholesky path)",
+                                    "c3b": "BASELINE.json configs[2] (SoftAbs path)",
                                     "c4": "BASELINE.json configs[3] (per-GPU shard)",
                                     "c5": "BASELINE.json configs[4] (per-GPU shard)"}.get(args.config, args.config),
                 "chains_per_gpu": n_local, "dim": w["dim"], "traj_len": traj,

@@ -5,9 +5,9 @@
 // chain's metric, which it keeps on-chip in whatever layout suits it:
 //   bool   build_and_invert(double x)   metric_func(x) -> explicit M(x)^-1 kept by the backend;
 //                                        false = not finite / not positive definite
-//   double matvec(double v)             M^-1 v
-//   double half_vjp_inv(double q)       0.5 * vjp_metric(q)(M^-1)     (the general-VJP path)
-//   double half_vjp_neg_outer(u, q)     0.5 * vjp_metric(q)(-u u^T)
+//   double matvec(double v)             M^-1 v                          (dh2_dmom)
+//   double half_vjp_inv(double q)       0.5 * vjp_metric(q)(grad_log_abs_det)   (dh1_dpos - grad)
+//   double dh2_dpos(double p, double q) 0.5 * vjp_metric(q)(grad_quadratic_form_inv(p))
 //   double norm(double x, int kind)     team-uniform max|x| or sqrt(sum x^2)  (solvers.py:20-27)
 //   double grad(double q)               grad_neg_log_dens
 // All control flow below is team-uniform (it depends only on norms / pivots every thread agrees on),
@@ -103,8 +103,7 @@ __device__ __forceinline__ int momentum_solve(BK& bk, double base, double tt, do
   double x0 = base, x1 = 0.0, pt = base;
   int status = MM_ST_OK;
   for (;;) {
-    const double u = bk.matvec(pt);
-    const double fx = base - tt * bk.half_vjp_neg_outer(u, q);
+    const double fx = base - tt * bk.dh2_dpos(pt, q);
     *n_evals += 1;
     const int act = fp_feed(bk, c, x0, x1, fx, o, &pt, &status);
     if (act == FP_DONE) break;
@@ -166,8 +165,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         // ---- B adj: p -= t dh2_dpos(q', p) then reversibility check     integrators.py:504-515
         const double qw = bk.slot(SL_QW);
         const double p_init = bk.slot(SL_PW);
-        const double u = bk.matvec(p_init);
-        double pw = p_init - t * bk.half_vjp_neg_outer(u, qw);
+        double pw = p_init - t * bk.dh2_dpos(p_init, qw);
         double p_back;
         ++r.n_solves;
         r.status = momentum_solve(bk, pw, -t, qw, o, &p_back, &r.n_evals);

@@ -276,8 +276,10 @@ struct WaveBackend {
   __device__ __forceinline__ double half_vjp_inv(double q) {
     return half_vjp_tiles<TS, RMETRIC>(T, q, dim, lane, w);
   }
-  __device__ __forceinline__ double half_vjp_neg_outer(double u, double q) {
-    return ::half_vjp_neg_outer<RMETRIC>(u, q, dim, lane);
+  // dense metric: grad_quadratic_form_inv(p) = -(M^-1 p)(M^-1 p)^T   (matrices.py:1179-1181)
+  __device__ __forceinline__ double dh2_dpos(double p, double q) {
+    const double u = matvec_flat<TS>(T, p, lane, w);
+    return half_vjp_neg_outer<RMETRIC>(u, q, dim, lane);
   }
   __device__ __forceinline__ double norm(double x, int kind) { return flat_norm(x, dim, lane, kind); }
   __device__ __forceinline__ double grad(double q) {

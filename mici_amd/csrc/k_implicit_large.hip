@@ -255,7 +255,9 @@ struct BlockBackend {
     else return q * diag();
   }
 
-  __device__ __forceinline__ double half_vjp_neg_outer(double u, double q) {
+  // dense metric: grad_quadratic_form_inv(p) = -(M^-1 p)(M^-1 p)^T   (matrices.py:1179-1181)
+  __device__ __forceinline__ double dh2_dpos(double p, double q) {
+    const double u = matvec(p);
     if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
       const double uq = block_reduce(tid < dim ? u * q : 0.0, 0, w.red);
       return -(u * uq) / (double)dim;

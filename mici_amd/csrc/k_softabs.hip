@@ -1,0 +1,481 @@
+// Implicit leapfrog on SoftAbsRiemannianMetricSystem (D <= 64): one 256-thread workgroup per chain,
+// the Hessian / eigenvectors / work matrices in LDS.  gfx950 / CDNA4.
+//
+// Replaces, per chain and per step (reference /root/reference/src/mici):
+//   SoftAbsRiemannianMetricSystem (metric = SoftAbs-regularised Hessian, vjp = matrix-Tressian
+//       product)                                                  systems.py:1737-1920
+//   SoftAbsRegularizedPositiveDefiniteMatrix: eigh, softabs, grad_softabs, grad_log_abs_det,
+//       grad_quadratic_form_inv                                   matrices.py:1631-1685
+//   EigendecomposedSymmetric / PositiveDefiniteMatrix: V diag(.) V^T products, inverse, sqrt,
+//       "Eigenvalues must all be positive."                       matrices.py:1529-1628
+//   the integrator step itself is implicit_core.h (integrators.py:493-544, solvers.py:47-154)
+//
+// eigh = parallel cyclic two-sided Jacobi: each round rotates D/2 disjoint (p,q) pairs
+// (round-robin schedule), columns of H and V then rows of H; sweeps repeat until
+// off(H)^2 <= 1e-30 diag(H)^2 (quadratic convergence, 7-9 sweeps at D = 64).  The result is used only
+// through V f(lambda) V^T products, which do not depend on eigenvalue order or eigenvector signs.
+// The matrix-Tressian products of the built-in targets need only the diagonal and the first row of
+// their matrix argument, so V diag(g) V^T and A J A^T are never formed in full; the latter still needs
+// the D^3 product B = A J (A = V diag(e)), done as an LDS-tiled FMA GEMM.
+#include "implicit_core.h"
+
+namespace {
+
+using namespace mmdev;
+using namespace mmimp;
+
+constexpr int NT = 256;
+constexpr int LD = 65;            // LDS leading dimension of the 64 x 64 matrices
+constexpr int MAT = 64 * LD;
+constexpr int kMaxSweeps = 30;
+
+struct SaLds {
+  double* H;    // Hessian -> (after eigh) J matrix / scratch
+  double* V;    // eigenvectors (columns)
+  double* W;    // A = V diag(e), then B = A J
+  double* lam;  // unregularised eigenvalues
+  double* lamt; // softabs eigenvalues
+  double* gsa;  // grad_softabs(lam)
+  double* v1;   // vectors
+  double* v2;
+  double* nat;
+  double* rc;   // rotation cos [32]
+  double* rs;   // rotation sin [32]
+  int* rp;      // pair p [32]
+  int* rq;      // pair q [32]
+  double* red;  // [8]
+  double* stash;  // [SL_COUNT][65]
+};
+constexpr int kLdsDoubles = 3 * MAT + 6 * 64 + 4 * 32 + 8 + SL_COUNT * 65;
+
+__device__ __forceinline__ double block_reduce4(double v, int kind_max, double* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = kind_max ? wave_max(v) : wave_sum(v);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double r = red[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) r = kind_max ? nanmax(r, red[w]) : r + red[w];
+  __syncthreads();
+  return r;
+}
+
+struct SoftAbsBackend {
+  int dim, tid, target;
+  double coeff;
+  SaLds w;
+  const double* tparams;
+
+  // flat state exists for tid < 64; the other threads share a dummy cell (index 64) per slot
+  __device__ __forceinline__ double& slot(int i) { return w.stash[i * 65 + (tid < 64 ? tid : 64)]; }
+
+  __device__ __forceinline__ double norm(double x, int kind) {
+    const double a = tid < dim ? x : 0.0;
+    if (kind == MM_NORM_LINF) return block_reduce4(fabs(a), 1, w.red);
+    return sqrt(block_reduce4(a * a, 0, w.red));
+  }
+
+  // ---- hess_neg_log_dens(q) into w.H (systems.py:1870-1888); q flat --------------------------------
+  __device__ __forceinline__ void build_hessian(double q) {
+    if (tid < 64) w.nat[tid] = (tid < dim) ? q : 0.0;
+    __syncthreads();
+    const double* x = w.nat;
+    double e = 0.0, s = 0.0;
+    if (target == MM_TARGET_FUNNEL) {
+      e = exp(-x[0]);
+      double acc = 0.0;
+      for (int i = 1 + (threadIdx.x & 63); i < dim; i += 64) acc += tparams[i - 1] * x[i] * x[i];
+      s = wave_sum(acc);  // every wave computes the same S = sum w x^2
+    }
+    for (int idx = tid; idx < dim * dim; idx += NT) {
+      const int i = idx / dim, j = idx - i * dim;
+      double h = 0.0;
+      if (target == MM_TARGET_POLY) {
+        if (i == j) h = tparams[0] + 3.0 * tparams[1] * x[i] * x[i];
+      } else {  // funnel: arrowhead
+        if (i == 0 && j == 0) h = 1.0 / 9.0 + 0.5 * e * s;
+        else if (i == 0) h = -e * tparams[j - 1] * x[j];
+        else if (j == 0) h = -e * tparams[i - 1] * x[i];
+        else if (i == j) h = e * tparams[i - 1];
+      }
+      w.H[i * LD + j] = h;
+      w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+  }
+
+  // ---- eigh(H) by parallel cyclic Jacobi: w.lam = eigenvalues, w.V = eigenvectors ----------------------
+  __device__ __forceinline__ bool eigh() {
+    const int n2 = dim + (dim & 1);
+    const int half = n2 >> 1;
+    bool converged = false;
+    for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
+      double off = 0.0, dg = 0.0;
+      for (int idx = tid; idx < dim * dim; idx += NT) {
+        const int i = idx / dim, j = idx - i * dim;
+        const double h = w.H[i * LD + j];
+        if (i == j) dg += h * h; else off += h * h;
+      }
+      off = block_reduce4(off, 0, w.red);
+      dg = block_reduce4(dg, 0, w.red);
+      if (!(off == off) || !(dg == dg) || fabs(off) > 1.7e308 || fabs(dg) > 1.7e308) return false;
+      if (off <= 1e-30 * dg) {
+        converged = true;
+        break;
+      }
+      for (int r = 0; r < n2 - 1; ++r) {
+        if (tid < half) {
+          int a, b;
+          if (tid == 0) { a = n2 - 1; b = r; }
+          else { a = (r + tid) % (n2 - 1); b = (r - tid + (n2 - 1)) % (n2 - 1); }
+          const int p = a < b ? a : b, q = a < b ? b : a;
+          double c = 1.0, s = 0.0;
+          if (q < dim) {
+            const double hpq = w.H[p * LD + q];
+            if (hpq != 0.0) {
+              const double tau = (w.H[q * LD + q] - w.H[p * LD + p]) / (2.0 * hpq);
+              const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+              c = 1.0 / sqrt(1.0 + t * t);
+              s = t * c;
+            }
+          }
+          w.rp[tid] = p; w.rq[tid] = q; w.rc[tid] = c; w.rs[tid] = s;
+        }
+        __syncthreads();
+        // column rotations of H and V: (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q) for every row
+        for (int idx = tid; idx < half * dim; idx += NT) {
+          const int g = idx / dim, i = idx - g * dim;
+          const int p = w.rp[g], q = w.rq[g];
+          if (q < dim) {
+            const double c = w.rc[g], s = w.rs[g];
+            const double hp = w.H[i * LD + p], hq = w.H[i * LD + q];
+            w.H[i * LD + p] = c * hp - s * hq;
+            w.H[i * LD + q] = s * hp + c * hq;
+            const double vp = w.V[i * LD + p], vq = w.V[i * LD + q];
+            w.V[i * LD + p] = c * vp - s * vq;
+            w.V[i * LD + q] = s * vp + c * vq;
+          }
+        }
+        __syncthreads();
+        // row rotations of H
+        for (int idx = tid; idx < half * dim; idx += NT) {
+          const int g = idx / dim, j = idx - g * dim;
+          const int p = w.rp[g], q = w.rq[g];
+          if (q < dim) {
+            const double c = w.rc[g], s = w.rs[g];
+            const double hp = w.H[p * LD + j], hq = w.H[q * LD + j];
+            w.H[p * LD + j] = c * hp - s * hq;
+            w.H[q * LD + j] = s * hp + c * hq;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (tid < 64) w.lam[tid] = (tid < dim) ? w.H[tid * LD + tid] : 1.0;
+    __syncthreads();
+    return converged;
+  }
+
+  // softabs(x) = x / tanh(coeff x); grad_softabs (matrices.py:1662-1669)
+  __device__ __forceinline__ bool regularise() {
+    double bad = 0.0;
+    if (tid < 64) {
+      double lt = 1.0, gs = 0.0;
+      if (tid < dim) {
+        const double x = w.lam[tid], ax = coeff * x;
+        const double th = tanh(ax), sh = sinh(ax);
+        lt = x / th;
+        gs = 1.0 / th - ax / (sh * sh);
+        if (!(lt > 0.0)) bad = 1.0;  // "Eigenvalues must all be positive." (NaN included)
+      }
+      w.lamt[tid] = lt;
+      w.gsa[tid] = gs;
+    }
+    return block_reduce4(bad, 0, w.red) == 0.0;
+  }
+
+  __device__ __forceinline__ bool build_and_invert(double x) {
+    build_hessian(x);
+    if (!eigh()) return false;
+    return regularise();
+  }
+
+  // V^T v (flat in, flat out): thread k < dim sums column k
+  __device__ __forceinline__ double vt_times(double v) {
+    if (tid < 64) w.v1[tid] = (tid < dim) ? v : 0.0;
+    __syncthreads();
+    double s = 0.0;
+    if (tid < dim)
+      for (int i = 0; i < dim; ++i) s = __builtin_fma(w.V[i * LD + tid], w.v1[i], s);
+    __syncthreads();
+    return s;
+  }
+  // V v
+  __device__ __forceinline__ double v_times(double v) {
+    if (tid < 64) w.v2[tid] = (tid < dim) ? v : 0.0;
+    __syncthreads();
+    double s = 0.0;
+    if (tid < dim)
+      for (int k = 0; k < dim; ++k) s = __builtin_fma(w.V[tid * LD + k], w.v2[k], s);
+    __syncthreads();
+    return s;
+  }
+
+  // M^-1 v = V diag(1/lamt) V^T v   (matrices.py:1568-1575, 1623-1624)
+  __device__ __forceinline__ double matvec(double v) {
+    const double c = vt_times(v);
+    return v_times(tid < dim ? (1.0 / w.lamt[tid]) * c : 0.0);
+  }
+
+  // mtp_neg_log_dens(q)(m) given only what the built-in Tressians touch: m_ii (md) and the symmetric
+  // first row m_0i (m0), flat.  systems.py:1890-1920; closed forms SURVEY.md Appendix A.
+  __device__ __forceinline__ double mtp(double q, double md, double m0) {
+    if (target == MM_TARGET_POLY) return 6.0 * tparams[1] * q * md;
+    // funnel: q = (v, x)
+    if (tid < 64) {
+      w.v1[tid] = (tid < dim) ? q : 0.0;
+      w.v2[tid] = (tid < dim) ? md : 0.0;
+      w.nat[tid] = (tid < dim) ? m0 : 0.0;
+    }
+    __syncthreads();
+    const double ev = exp(-w.v1[0]);
+    const double mvv = w.v2[0];
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (tid >= 1 && tid < dim) {
+      const double wi = tparams[tid - 1], xi = w.v1[tid];
+      a1 = wi * xi * xi;                    // S
+      a2 = 2.0 * w.nat[tid] * wi * xi;      // (m_vi + m_iv) w_i x_i
+      a3 = w.v2[tid] * wi;                  // m_ii w_i
+    }
+    const double S = block_reduce4(a1, 0, w.red);
+    const double s2 = block_reduce4(a2, 0, w.red);
+    const double s3 = block_reduce4(a3, 0, w.red);
+    double out = 0.0;
+    if (tid == 0) out = -0.5 * ev * S * mvv + ev * s2 - ev * s3;
+    else if (tid < dim) {
+      const double wk = tparams[tid - 1];
+      out = ev * wk * w.v1[tid] * mvv - ev * wk * (2.0 * w.nat[tid]);
+    }
+    __syncthreads();
+    return out;
+  }
+
+  // 0.5 * mtp(grad_log_abs_det), grad_log_abs_det = V diag(grad_softabs(lam)/lamt) V^T  (:1671-1674)
+  __device__ __forceinline__ double half_vjp_inv(double q) {
+    double md = 0.0, m0 = 0.0;
+    if (tid < dim) {
+      for (int k = 0; k < dim; ++k) {
+        const double g = w.gsa[k] / w.lamt[k];
+        const double vik = w.V[tid * LD + k];
+        md = __builtin_fma(vik * vik, g, md);
+        m0 = __builtin_fma(w.V[k] * vik, g, m0);  // V[0][k] V[i][k] g_k
+      }
+    }
+    return 0.5 * mtp(q, md, m0);
+  }
+
+  // 0.5 * mtp(grad_quadratic_form_inv(p)),  -(V (e e^T o J) V^T) = -A J A^T, A = V diag(e),
+  // e = V^T p / lamt, J_kl = (lamt_k - lamt_l)/(lam_k - lam_l), J_kk = grad_softabs(lam_k)  (:1676-1685)
+  __device__ __forceinline__ double dh2_dpos(double p, double q) {
+    const double c = vt_times(p);
+    if (tid < 64) w.v1[tid] = (tid < dim) ? c / w.lamt[tid] : 0.0;  // e
+    __syncthreads();
+    // J into w.H, A into w.W
+    for (int idx = tid; idx < dim * dim; idx += NT) {
+      const int k = idx / dim, l = idx - k * dim;
+      double num = w.lamt[k] - w.lamt[l], den = w.lam[k] - w.lam[l];
+      if (k == l) { num += w.gsa[k]; den = 1.0; }
+      w.H[k * LD + l] = num / den;                 // 0/0 -> NaN for degenerate spectra, as the reference
+      w.W[k * LD + l] = w.V[k * LD + l] * w.v1[l]; // A[i=k][k=l]
+    }
+    __syncthreads();
+    // md_i = sum_kl A_ik J_kl A_il ; m0_i = sum_kl A_0k J_kl A_il : thread i accumulates over l of
+    // (sum_k A_ik J_kl) A_il.  Work split: 4 threads per row i (each a quarter of the l range).
+    double md = 0.0, m0 = 0.0;
+    {
+      const int i = tid >> 2, part = tid & 3;
+      if (i < dim) {
+        for (int l = part; l < dim; l += 4) {
+          double bi = 0.0, b0 = 0.0;
+          for (int k = 0; k < dim; ++k) {
+            const double jkl = w.H[k * LD + l];
+            bi = __builtin_fma(w.W[i * LD + k], jkl, bi);
+            b0 = __builtin_fma(w.W[k], jkl, b0);  // A[0][k]
+          }
+          const double ail = w.W[i * LD + l];
+          md = __builtin_fma(bi, ail, md);
+          m0 = __builtin_fma(b0, ail, m0);
+        }
+      }
+      md += __shfl_xor(md, 1, 64); md += __shfl_xor(md, 2, 64);
+      m0 += __shfl_xor(m0, 1, 64); m0 += __shfl_xor(m0, 2, 64);
+      __syncthreads();
+      if (part == 0 && i < 64) { w.v2[i] = -md; w.nat[i] = -m0; }
+      __syncthreads();
+    }
+    const double mdf = (tid < dim) ? w.v2[tid] : 0.0;
+    const double m0f = (tid < dim) ? w.nat[tid] : 0.0;
+    __syncthreads();
+    return 0.5 * mtp(q, mdf, m0f);
+  }
+
+  __device__ __forceinline__ double grad(double q) {
+    if (tid < 64) w.nat[tid] = (tid < dim) ? q : 0.0;
+    __syncthreads();
+    const TargetAux aux = target_prepare<true>(target, w.nat, dim, tparams, threadIdx.x & 63);
+    const double g = (tid < dim) ? target_grad_elem<true>(target, aux, w.nat, tid, dim, tparams) : 0.0;
+    __syncthreads();
+    return g;
+  }
+  __device__ __forceinline__ double nld_elem(double q) {
+    if (tid < 64) w.nat[tid] = (tid < dim) ? q : 0.0;
+    __syncthreads();
+    const TargetAux aux = target_prepare<true>(target, w.nat, dim, tparams, threadIdx.x & 63);
+    const double e = (tid < dim) ? target_nld_elem<true>(target, aux, w.nat, tid, dim, tparams) : 0.0;
+    __syncthreads();
+    return e;
+  }
+};
+
+__device__ __forceinline__ void init_backend(SoftAbsBackend& bk, const ImplicitArgs& A, double* lds) {
+  bk.dim = A.dim;
+  bk.tid = threadIdx.x;
+  bk.target = A.target;
+  bk.coeff = A.z[0];  // softabs coefficient (device copy of the model's rmetric_params)
+  bk.tparams = A.tparams;
+  double* p = lds;
+  bk.w.H = p; p += MAT;
+  bk.w.V = p; p += MAT;
+  bk.w.W = p; p += MAT;
+  bk.w.lam = p; p += 64;
+  bk.w.lamt = p; p += 64;
+  bk.w.gsa = p; p += 64;
+  bk.w.v1 = p; p += 64;
+  bk.w.v2 = p; p += 64;
+  bk.w.nat = p; p += 64;
+  bk.w.rc = p; p += 32;
+  bk.w.rs = p; p += 32;
+  bk.w.rp = reinterpret_cast<int*>(p); p += 32;
+  bk.w.rq = reinterpret_cast<int*>(p); p += 32;
+  bk.w.red = p; p += 8;
+  bk.w.stash = p;
+}
+
+struct SaArgs {
+  ImplicitArgs a;
+  const double* coeff;  // device pointer to softabs_coeff
+  int op;
+};
+
+__global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  ImplicitArgs A = S.a;
+  A.z = S.coeff;
+  const int64_t chain = blockIdx.x;
+  SoftAbsBackend bk;
+  init_backend(bk, A, lds);
+  const int dim = A.dim, tid = threadIdx.x;
+  const bool act = tid < dim;
+  const double q = act ? A.pos[chain * dim + tid] : 0.0;
+  const double p = act ? A.mom[chain * dim + tid] : 0.0;
+  const double t = (double)A.dir[chain] * A.step_size;
+  bk.slot(SL_Q) = q;
+  bk.slot(SL_P) = p;
+  __syncthreads();
+  const ChainResult r = implicit_leapfrog_chain(bk, t, A.n_steps, A.opts);
+  if (act) {
+    A.pos[chain * dim + tid] = bk.slot(SL_Q);
+    A.mom[chain * dim + tid] = bk.slot(SL_P);
+  }
+  if (tid == 0) {
+    A.status[chain] = r.status;
+    A.n_done[chain] = r.done;
+    add_counters(A.counters, r);
+  }
+}
+
+// op 0: h = l + 0.5 logdet + 0.5 p^T M^-1 p ; 1: dh_dmom ; 2: sample_momentum = V diag(sqrt(lamt)) V^T z
+__global__ __launch_bounds__(NT) void softabs_aux_kernel(SaArgs S, double* out, const double* z) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  ImplicitArgs A = S.a;
+  A.z = S.coeff;
+  const int64_t chain = blockIdx.x;
+  SoftAbsBackend bk;
+  init_backend(bk, A, lds);
+  const int dim = A.dim, tid = threadIdx.x;
+  const bool act = tid < dim;
+  const double q = act ? A.pos[chain * dim + tid] : 0.0;
+  const double p = act ? A.mom[chain * dim + tid] : 0.0;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  const bool ok = bk.build_and_invert(q);
+  if (S.op == 0) {
+    const double u = bk.matvec(p);
+    double e = bk.nld_elem(q) + (act ? 0.5 * p * u + 0.5 * log(fabs(bk.w.lamt[tid])) : 0.0);
+    e = block_reduce4(e, 0, bk.w.red);
+    if (tid == 0) out[chain] = ok ? e : nan;
+  } else if (S.op == 1) {
+    const double u = bk.matvec(p);
+    if (act) out[chain * dim + tid] = ok ? u : nan;
+  } else {
+    const double zz = act ? z[chain * dim + tid] : 0.0;
+    const double c = bk.vt_times(zz);
+    const double y = bk.v_times(act ? sqrt(bk.w.lamt[tid]) * c : 0.0);
+    if (act) A.mom[chain * dim + tid] = ok ? y : nan;
+  }
+}
+
+SaArgs make_args(const mm_model* m, mm_state* s) {
+  SaArgs S{};
+  S.a.pos = s->d_pos;
+  S.a.mom = s->d_mom;
+  S.a.dir = s->d_dir;
+  S.a.status = s->d_status;
+  S.a.n_done = s->d_n_done;
+  S.a.n_chains = s->n;
+  S.a.dim = s->dim;
+  S.a.target = m->target;
+  S.a.tparams = m->d_target_params;
+  S.coeff = m->d_rmetric_params;
+  return S;
+}
+
+int check_dim(mm_ctx* ctx, const mm_model* m) {
+  if (m->dim > 64) {
+    mm_set_error(ctx, "SoftAbs kernels support dim <= 64 (LDS-resident eigendecomposition)");
+    return MM_ERR_UNSUPPORTED;
+  }
+  return MM_OK;
+}
+
+}  // namespace
+
+int mm_launch_softabs_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                               const mm_fp_opts& opts, mm_counters* d_counters) {
+  int rc = check_dim(ctx, m);
+  if (rc != MM_OK) return rc;
+  SaArgs S = make_args(m, s);
+  S.a.step_size = h;
+  S.a.n_steps = n_steps;
+  S.a.opts = opts;
+  S.a.counters = d_counters;
+  const size_t lds = kLdsDoubles * sizeof(double);
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(softabs_leapfrog_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(softabs_leapfrog_kernel, dim3((unsigned)s->n), dim3(NT), lds, ctx->stream, S);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
+int mm_launch_softabs_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* d_out,
+                          const double* d_z) {
+  int rc = check_dim(ctx, m);
+  if (rc != MM_OK) return rc;
+  SaArgs S = make_args(m, s);
+  S.op = op;
+  const size_t lds = kLdsDoubles * sizeof(double);
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(softabs_aux_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(softabs_aux_kernel, dim3((unsigned)s->n), dim3(NT), lds, ctx->stream, S, d_out, d_z);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}

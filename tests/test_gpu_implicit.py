@@ -17,7 +17,7 @@ from mici_amd.states import ChainState
 
 pytestmark = pytest.mark.gpu
 
-DENSE = [n for n in golden_names("riemann")]
+DENSE = [n for n in golden_names("riemann")] + [n for n in golden_names("softabs")]
 SOLVER = {0: solvers.solve_fixed_point_direct, 1: solvers.solve_fixed_point_steffensen}
 NORM = {0: solvers.maximum_norm, 1: solvers.euclidean_norm}
 
@@ -46,10 +46,13 @@ def test_implicit_leapfrog_matches_reference_fixture(name):
     system, integ = build(g)
     n = g["q0"].shape[0]
     s_max = int(g["checkpoints"].max())
+    # SoftAbs: Jacobi eigh vs LAPACK differs at 1e-13 and the divided differences of
+    # grad_quadratic_form_inv amplify that; the oracle itself is pinned to the reference at 1e-9 there
+    tol = 2e-9 if name.startswith("softabs") else 1e-10
     for k, s in enumerate(int(s) for s in g["checkpoints"]):
         q, p, status, n_done = integ.step_batch(g["q0"], g["p0"], g["dir"], n_steps=s)
-        assert_close(q, g["q_out"][k], 1e-10, f"{name} q@{s}")
-        assert_close(p, g["p_out"][k], 1e-10, f"{name} p@{s}")
+        assert_close(q, g["q_out"][k], tol, f"{name} q@{s}")
+        assert_close(p, g["p_out"][k], tol, f"{name} p@{s}")
         if s == s_max:
             assert np.array_equal(status, g["status"]), (status, g["status"])
             assert np.array_equal(n_done, g["n_done"]), (n_done, g["n_done"])
@@ -62,7 +65,7 @@ def test_implicit_leapfrog_matches_reference_fixture(name):
         finite = np.isfinite(g["h_out"][k])
         h = system.h_batch(q, p)
         sel = finite & np.isfinite(q).all(1)
-        assert_close(h[sel], g["h_out"][k][sel], 1e-9, f"{name} h@{s}")
+        assert_close(h[sel], g["h_out"][k][sel], 10 * tol, f"{name} h@{s}")
 
 
 def test_single_state_step_raises_reference_exceptions():
@@ -167,3 +170,30 @@ def test_energy_conservation_like_reference_property_test(size):
     hs = np.array(hs)[:, alive]  # the reference returns early (passes) on an IntegratorError
     diff = hs[:100].mean(0) - hs[100:].mean(0)
     assert np.all(np.abs(diff) < 1e-3)
+
+
+def test_softabs_full_size_matches_oracle():
+    """BASELINE config c3(b): SoftAbsRiemannianMetricSystem, scaled funnel D=64, h=0.02."""
+    rng = np.random.default_rng(7)
+    dim, n, h, steps = 64, 64, 0.02, 3
+    w = np.linspace(0.5, 2.0, dim - 1)
+    osys = orc.RiemannianSystem(omdl.Funnel(w), None, 1.0)
+    system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(w), softabs_coeff=1.0)
+    integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+    q0 = rng.standard_normal((n, dim))
+    z = rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, z)
+    q, p, status, n_done = integ.step_batch(q0, p0, 1, n_steps=steps)
+    assert np.all(status == 0) and np.all(n_done == steps)
+    for c in (0, 1, n - 1):
+        st = orc._State(q0[c], None)
+        assert_close(p0[c], osys.sample_momentum(st, z[c]), 1e-11, "sample_momentum")
+        qo, po, so, no = orc.implicit_leapfrog_steps(osys, q0[c], p0[c], h, steps)
+        assert so == 0
+        assert_close(q[c], qo, 2e-9, f"q chain {c}")
+        assert_close(p[c], po, 2e-9, f"p chain {c}")
+        st = orc._State(q[c], p[c])
+        assert_close(system.h_batch(q[c:c + 1], p[c:c + 1])[0], osys.h(st), 1e-9, "h")
+    qb, pb, sb, _ = integ.step_batch(q, p, -1, n_steps=steps)
+    assert np.all(sb == 0)
+    assert_close(qb, q0, 1e-6, "reversed q")
