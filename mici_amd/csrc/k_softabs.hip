@@ -87,8 +87,9 @@ struct SoftAbsBackend {
       for (int i = 1 + (threadIdx.x & 63); i < dim; i += 64) acc += tparams[i - 1] * x[i] * x[i];
       s = wave_sum(acc);  // every wave computes the same S = sum w x^2
     }
-    for (int idx = tid; idx < dim * dim; idx += NT) {
-      const int i = idx / dim, j = idx - i * dim;
+    for (int i = tid >> 6; i < dim; i += NT / 64) {
+      const int j = tid & 63;
+      if (j >= dim) continue;
       double h = 0.0;
       if (target == MM_TARGET_POLY) {
         if (i == j) h = tparams[0] + 3.0 * tparams[1] * x[i] * x[i];
@@ -111,10 +112,13 @@ struct SoftAbsBackend {
     bool converged = false;
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
       double off = 0.0, dg = 0.0;
-      for (int idx = tid; idx < dim * dim; idx += NT) {
-        const int i = idx / dim, j = idx - i * dim;
-        const double h = w.H[i * LD + j];
-        if (i == j) dg += h * h; else off += h * h;
+      {
+        const int j = tid & 63;  // column; rows strided by 4 (no integer division in the hot loops)
+        if (j < dim)
+          for (int i = tid >> 6; i < dim; i += NT / 64) {
+            const double h = w.H[i * LD + j];
+            if (i == j) dg += h * h; else off += h * h;
+          }
       }
       off = block_reduce4(off, 0, w.red);
       dg = block_reduce4(dg, 0, w.red);
@@ -127,7 +131,10 @@ struct SoftAbsBackend {
         if (tid < half) {
           int a, b;
           if (tid == 0) { a = n2 - 1; b = r; }
-          else { a = (r + tid) % (n2 - 1); b = (r - tid + (n2 - 1)) % (n2 - 1); }
+          else {
+            a = r + tid; if (a >= n2 - 1) a -= n2 - 1;
+            b = r - tid; if (b < 0) b += n2 - 1;
+          }
           const int p = a < b ? a : b, q = a < b ? b : a;
           double c = 1.0, s = 0.0;
           if (q < dim) {
@@ -143,10 +150,10 @@ struct SoftAbsBackend {
         }
         __syncthreads();
         // column rotations of H and V: (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q) for every row
-        for (int idx = tid; idx < half * dim; idx += NT) {
-          const int g = idx / dim, i = idx - g * dim;
+        for (int g = tid >> 6; g < half; g += NT / 64) {  // pair g is wave-uniform
+          const int i = tid & 63;
           const int p = w.rp[g], q = w.rq[g];
-          if (q < dim) {
+          if (q < dim && i < dim) {
             const double c = w.rc[g], s = w.rs[g];
             const double hp = w.H[i * LD + p], hq = w.H[i * LD + q];
             w.H[i * LD + p] = c * hp - s * hq;
@@ -158,10 +165,10 @@ struct SoftAbsBackend {
         }
         __syncthreads();
         // row rotations of H
-        for (int idx = tid; idx < half * dim; idx += NT) {
-          const int g = idx / dim, j = idx - g * dim;
+        for (int g = tid >> 6; g < half; g += NT / 64) {
+          const int j = tid & 63;
           const int p = w.rp[g], q = w.rq[g];
-          if (q < dim) {
+          if (q < dim && j < dim) {
             const double c = w.rc[g], s = w.rs[g];
             const double hp = w.H[p * LD + j], hq = w.H[q * LD + j];
             w.H[p * LD + j] = c * hp - s * hq;
@@ -281,8 +288,9 @@ struct SoftAbsBackend {
     if (tid < 64) w.v1[tid] = (tid < dim) ? c / w.lamt[tid] : 0.0;  // e
     __syncthreads();
     // J into w.H, A into w.W
-    for (int idx = tid; idx < dim * dim; idx += NT) {
-      const int k = idx / dim, l = idx - k * dim;
+    for (int k = tid >> 6; k < dim; k += NT / 64) {
+      const int l = tid & 63;
+      if (l >= dim) continue;
       double num = w.lamt[k] - w.lamt[l], den = w.lam[k] - w.lam[l];
       if (k == l) { num += w.gsa[k]; den = 1.0; }
       w.H[k * LD + l] = num / den;                 // 0/0 -> NaN for degenerate spectra, as the reference
