@@ -217,18 +217,30 @@ def main():
                       file=sys.stderr)
                 gather_mode = "gloo-host"
 
+    want_host = 1 if rank == 0 else 0  # only the trace-writing rank needs the gathered array on the host
+
+    def collect_traces():
+        """Trace collection, once per trajectory: RCCL all-gather over xGMI on the communicator's own
+        stream (overlapped with the next trajectory), pinned host copy on rank 0 only."""
+        if comm is not None:
+            _ffi.check(ctx._lib.mm_comm_allgather_pos_async(comm, batch.handle, want_host),
+                       ctx.handle, "mm_comm_allgather_pos_async")
+        elif gather_mode == "gloo-host":
+            import torch
+            q, _, _ = batch.download()
+            out = [torch.empty_like(torch.from_numpy(q)) for _ in range(world)]
+            dist.all_gather(out, torch.from_numpy(q))
+
+    def finish_traces():
+        if comm is not None:
+            _ffi.check(ctx._lib.mm_comm_wait(
+                comm, pos_all.ctypes.data_as(_ffi.c_double_p) if want_host else None),
+                ctx.handle, "mm_comm_wait")
+
     def one_pass():
         integ.step_device(batch, traj, ctx)
         if world > 1:
-            if comm is not None:
-                _ffi.check(ctx._lib.mm_comm_allgather_pos(
-                    comm, batch.handle, pos_all.ctypes.data_as(_ffi.c_double_p)), ctx.handle,
-                    "mm_comm_allgather_pos")
-            elif gather_mode == "gloo-host":
-                import torch
-                q, _, _ = batch.download()
-                out = [torch.empty_like(torch.from_numpy(q)) for _ in range(world)]
-                dist.all_gather(out, torch.from_numpy(q))
+            collect_traces()
 
     def barrier():
         ctx.sync()
@@ -238,6 +250,8 @@ def main():
     batch.upload(w["q0"], w["p0"], dirs)
     for _ in range(args.warmup):
         one_pass()
+    if world > 1:
+        finish_traces()
     batch.upload(w["q0"], w["p0"], dirs)  # timed region starts from the same resident state
 
     barrier()
@@ -249,22 +263,15 @@ def main():
         integ.step_device(batch, traj, ctx)
         ctx.record(1)
         if world > 1:
-            # trace collection once per trajectory
-            if comm is not None:
-                _ffi.check(ctx._lib.mm_comm_allgather_pos(
-                    comm, batch.handle, pos_all.ctypes.data_as(_ffi.c_double_p)), ctx.handle,
-                    "mm_comm_allgather_pos")
-            elif gather_mode == "gloo-host":
-                import torch
-                q, _, _ = batch.download()
-                out = [torch.empty_like(torch.from_numpy(q)) for _ in range(world)]
-                dist.all_gather(out, torch.from_numpy(q))
+            collect_traces()  # trace collection once per trajectory
         kernel_ms += ctx.elapsed_ms(0, 1)  # HIP events on the stream the kernel runs on
         if w["kind"] != "euclid":
             _, nd = batch.download_status()  # the sampler needs this per trajectory anyway
             done_acc += float(nd.sum())
             for key, val in (integ.last_counters or {}).items():
                 counters_acc[key] = counters_acc.get(key, 0) + val
+    if world > 1:
+        finish_traces()  # the last gather must have landed inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:

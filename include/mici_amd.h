@@ -213,6 +213,13 @@ int mm_comm_destroy(mm_comm* comm);
 /* Gather every rank's pos shard ([n_local][D], equal n_local on all ranks) into host buffer
  * pos_all[n_ranks*n_local][D] on every rank (rank-major = global chain order). */
 int mm_comm_allgather_pos(mm_comm* comm, mm_state* state, double* pos_all);
+/* Overlapped form: snapshot the shard (device-to-device) on the ctx stream, then all-gather it on the
+ * communicator's own HIP stream - and, if want_host != 0, copy the gathered [n_ranks*n_local][D] array
+ * to a pinned host buffer - while the ctx stream goes on integrating the next trajectory.
+ * mm_comm_wait blocks until the last enqueued gather has landed; pos_all may be NULL (device-side
+ * gather only, e.g. on ranks that do not write traces). */
+int mm_comm_allgather_pos_async(mm_comm* comm, mm_state* state, int want_host);
+int mm_comm_wait(mm_comm* comm, double* pos_all);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,8 @@ SIGNATURES = {
     "mm_comm_create": (C.c_int, [_VP, C.c_int32, C.c_int32, c_uint8_p, C.POINTER(_VP)]),
     "mm_comm_destroy": (C.c_int, [_VP]),
     "mm_comm_allgather_pos": (C.c_int, [_VP, _VP, c_double_p]),
+    "mm_comm_allgather_pos_async": (C.c_int, [_VP, _VP, C.c_int]),
+    "mm_comm_wait": (C.c_int, [_VP, c_double_p]),
 }
 
 _lib = None

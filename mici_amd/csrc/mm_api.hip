@@ -541,6 +541,15 @@ struct mm_comm {
   int n_ranks = 1, rank = 0;
   double* d_gather = nullptr;
   size_t gather_elems = 0;
+  // overlapped gather: own stream, snapshot of the shard, pinned host landing buffer
+  hipStream_t stream = nullptr;
+  hipEvent_t snap_ready = nullptr, gather_done = nullptr;
+  double* d_snap = nullptr;
+  size_t snap_elems = 0;
+  double* h_pinned = nullptr;
+  size_t pinned_elems = 0;
+  size_t last_total = 0;
+  bool last_host = false, pending = false;
 };
 
 int mm_comm_unique_id(uint8_t id[MM_COMM_ID_BYTES]) {
@@ -574,6 +583,13 @@ int mm_comm_create(mm_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t id[
     delete c;
     return rccl_fail(ctx, "ncclCommInitRank", e);
   }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->snap_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->gather_done, hipEventDisableTiming) != hipSuccess) {
+    mm_set_error(ctx, "mm_comm_create: stream / event creation failed");
+    mm_comm_destroy(c);
+    return MM_ERR_HIP;
+  }
   *out = c;
   return MM_OK;
 }
@@ -582,8 +598,14 @@ int mm_comm_destroy(mm_comm* c) {
   if (!c) return MM_OK;
   (void)hipSetDevice(c->ctx->device);
   (void)hipStreamSynchronize(c->ctx->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)g_rccl.CommDestroy(c->comm);
   (void)hipFree(c->d_gather);
+  (void)hipFree(c->d_snap);
+  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->snap_ready) (void)hipEventDestroy(c->snap_ready);
+  if (c->gather_done) (void)hipEventDestroy(c->gather_done);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return MM_OK;
 }
@@ -610,6 +632,68 @@ int mm_comm_allgather_pos(mm_comm* c, mm_state* s, double* pos_all) {
   if (e != 0) return rccl_fail(ctx, "ncclAllGather", e);
   MM_HIP_CHECK(ctx, hipMemcpyAsync(pos_all, c->d_gather, total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return MM_OK;
+}
+
+int mm_comm_allgather_pos_async(mm_comm* c, mm_state* s, int want_host) {
+  MM_REQUIRE(nullptr, c != nullptr, "mm_comm_allgather_pos_async: comm is NULL");
+  mm_ctx* ctx = c->ctx;
+  MM_REQUIRE(ctx, s != nullptr && s->ctx == ctx, "mm_comm_allgather_pos_async: bad argument");
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t local = (size_t)s->n * s->dim, total = local * c->n_ranks;
+  if (local == 0) return MM_OK;
+  if (c->snap_elems < local || c->gather_elems < total) {
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_snap);
+    (void)hipFree(c->d_gather);
+    c->d_snap = c->d_gather = nullptr;
+    c->snap_elems = c->gather_elems = 0;
+    if (hipMalloc(&c->d_snap, local * sizeof(double)) != hipSuccess ||
+        hipMalloc(&c->d_gather, total * sizeof(double)) != hipSuccess) {
+      mm_set_error(ctx, "mm_comm_allgather_pos_async: hipMalloc failed");
+      return MM_ERR_NOMEM;
+    }
+    c->snap_elems = local;
+    c->gather_elems = total;
+  }
+  if (want_host && c->pinned_elems < total) {
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(c->stream));
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    c->h_pinned = nullptr;
+    c->pinned_elems = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), total * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+      mm_set_error(ctx, "mm_comm_allgather_pos_async: hipHostMalloc failed");
+      return MM_ERR_NOMEM;
+    }
+    c->pinned_elems = total;
+  }
+  // the previous gather must have finished reading the snapshot before it is overwritten
+  if (c->pending) MM_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, c->gather_done, 0));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(c->d_snap, s->d_pos, local * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  MM_HIP_CHECK(ctx, hipEventRecord(c->snap_ready, ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamWaitEvent(c->stream, c->snap_ready, 0));
+  const int kNcclFloat64 = 8;
+  const int e = g_rccl.AllGather(c->d_snap, c->d_gather, local, kNcclFloat64, c->comm, c->stream);
+  if (e != 0) return rccl_fail(ctx, "ncclAllGather", e);
+  MM_HIP_CHECK(ctx, hipEventRecord(c->gather_done, c->stream));
+  if (want_host)
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(c->h_pinned, c->d_gather, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  c->last_total = total;
+  c->last_host = want_host != 0;
+  c->pending = true;
+  return MM_OK;
+}
+
+int mm_comm_wait(mm_comm* c, double* pos_all) {
+  MM_REQUIRE(nullptr, c != nullptr, "mm_comm_wait: comm is NULL");
+  mm_ctx* ctx = c->ctx;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(c->stream));
+  if (pos_all) {
+    MM_REQUIRE(ctx, c->pending && c->last_host, "mm_comm_wait: no host gather is pending");
+    std::memcpy(pos_all, c->h_pinned, c->last_total * sizeof(double));
+  }
+  c->pending = false;
   return MM_OK;
 }
 

@@ -107,6 +107,26 @@ class RcclTraceGather:
             self.ctx.handle, "mm_comm_allgather_pos")
         return self._out
 
+    def gather_async(self, batch, want_host=True):
+        """Snapshot the shard and start the all-gather (+ optional copy to pinned host memory) on the
+        communicator's own stream; the context stream is free to integrate the next trajectory."""
+        self._shape = (self.world * batch.n_chains, batch.dim)
+        _ffi.check(self.ctx._lib.mm_comm_allgather_pos_async(self.handle, batch.handle,
+                                                             1 if want_host else 0),
+                   self.ctx.handle, "mm_comm_allgather_pos_async")
+
+    def wait(self, want_host=True):
+        """Block until the last ``gather_async`` has landed; returns the host array if requested."""
+        out = None
+        if want_host:
+            if self._out is None or self._out.shape != self._shape:
+                self._out = np.empty(self._shape)
+            out = self._out
+        _ffi.check(self.ctx._lib.mm_comm_wait(
+            self.handle, None if out is None else out.ctypes.data_as(_ffi.c_double_p)),
+            self.ctx.handle, "mm_comm_wait")
+        return out
+
     def close(self):
         if getattr(self, "handle", None) and self.ctx.handle:
             self.ctx._lib.mm_comm_destroy(self.handle)

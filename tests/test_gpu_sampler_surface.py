@@ -95,5 +95,11 @@ def test_rccl_trace_gather_single_rank():
     gather = distributed.RcclTraceGather(ctx, 0, 1, raw)
     out = gather.gather(batch)
     assert np.array_equal(out, q)
+    # overlapped form: the snapshot is taken before the state moves on
+    gather.gather_async(batch, want_host=True)
+    batch.upload(q + 1.0, None, None)
+    assert np.array_equal(gather.wait(want_host=True), q)
+    gather.gather_async(batch, want_host=False)
+    gather.wait(want_host=False)
     gather.close()
     batch.close()
