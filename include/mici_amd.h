@@ -89,7 +89,11 @@ typedef enum mm_status {
 
 typedef enum mm_norm { MM_NORM_LINF = 0, MM_NORM_L2 = 1 } mm_norm;           /* solvers.py:20-27 */
 typedef enum mm_fp_solver { MM_FP_DIRECT = 0, MM_FP_STEFFENSEN = 1 } mm_fp_solver; /* solvers.py:47-154 */
-typedef enum mm_proj_solver { MM_PROJ_NEWTON = 0 } mm_proj_solver;         /* solvers.py:346-469 */
+typedef enum mm_proj_solver {      /* solvers.py:195-343, 346-469, 472-614 */
+  MM_PROJ_NEWTON = 0,
+  MM_PROJ_QUASI_NEWTON = 1,
+  MM_PROJ_NEWTON_LINE_SEARCH = 2
+} mm_proj_solver;
 
 typedef struct mm_model_desc {
   int32_t dim;
@@ -131,7 +135,7 @@ typedef struct mm_proj_opts {
   int32_t rev_norm;  /* MM_NORM_LINF */
   double rev_tol;    /* 2e-8 */
   int32_t n_inner;   /* 1    */
-  int32_t reserved;
+  int32_t max_line_search_iters; /* 10 (line-search solver only, solvers.py:482) */
 } mm_proj_opts;
 
 /* Work counters summed over chains (the reference's ChainState._call_counts, states.py:204-212;

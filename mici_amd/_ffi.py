@@ -60,7 +60,7 @@ class ProjOpts(C.Structure):
         ("rev_norm", C.c_int32),
         ("rev_tol", C.c_double),
         ("n_inner", C.c_int32),
-        ("reserved", C.c_int32),
+        ("max_line_search_iters", C.c_int32),
     ]
 
 

@@ -176,6 +176,109 @@ __device__ __forceinline__ int newton_project(const ConArgs& A, Vec<D>& q, Vec<D
   return MM_ST_MAX_ITERS;
 }
 
+// solve_projection_onto_manifold_quasi_newton (solvers.py:303-343): Gram matrix J_prev (|t| M^-1) J_prev^T
+// Cholesky-factored once before the loop (failure = LinAlgError OUTSIDE the solver), only constr in it.
+template <int D>
+__device__ __forceinline__ int quasi_newton_project(const ConArgs& A, Vec<D>& q, Vec<D>& p,
+                                                    const Vec<D>& jac_prev, double t, Vec<D>* jac_out,
+                                                    long long* n_iters) {
+  const mm_proj_opts& o = A.opts;
+  const double abs_t = fabs(t);
+  const Vec<D> mjp = minv_apply<D>(A, jac_prev);
+  const double gram = abs_t * dot<D>(jac_prev, mjp);
+  if (!(gram > 0.0) || !finite(gram)) return MM_ST_LINALG;
+  const double l = sqrt(gram);
+  const double inv = (1.0 / l) / l;
+  Vec<D> mu;
+#pragma unroll
+  for (int i = 0; i < D; ++i) mu.v[i] = 0.0;
+  for (int it = 0; it < o.max_iters; ++it) {
+    *n_iters += 1;
+    const double c = constr_value<D>(A, q);
+    const double err = fabs(c);
+    const double dmu = inv * c;
+    Vec<D> dpos;
+#pragma unroll
+    for (int i = 0; i < D; ++i) dpos.v[i] = abs_t * (mjp.v[i] * dmu);
+    if (err > o.div_tol || err != err) return MM_ST_DIVERGED;
+    if (err < o.constr_tol && vnorm<D>(dpos, o.norm) < o.pos_tol) {
+      const double sgn = (t > 0.0) ? 1.0 : ((t < 0.0) ? -1.0 : 0.0);
+#pragma unroll
+      for (int i = 0; i < D; ++i) p.v[i] -= sgn * mu.v[i];
+      *jac_out = constr_jacob<D>(A, q);
+      return MM_ST_OK;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      mu.v[i] += jac_prev.v[i] * dmu;
+      q.v[i] -= dpos.v[i];
+    }
+  }
+  return MM_ST_MAX_ITERS;
+}
+
+// solve_projection_onto_manifold_newton_with_line_search (solvers.py:561-614)
+template <int D>
+__device__ __forceinline__ int line_search_project(const ConArgs& A, Vec<D>& q, Vec<D>& p,
+                                                   const Vec<D>& jac_prev, double t, Vec<D>* jac_out,
+                                                   long long* n_iters) {
+  const mm_proj_opts& o = A.opts;
+  const double abs_t = fabs(t);
+  const Vec<D> mjp = minv_apply<D>(A, jac_prev);
+  Vec<D> mu, dpos;
+#pragma unroll
+  for (int i = 0; i < D; ++i) { mu.v[i] = 0.0; dpos.v[i] = 0.0; }
+  double step = 0.0;
+  for (int it = 0; it < o.max_iters; ++it) {
+    *n_iters += 1;
+    const Vec<D> jac = constr_jacob<D>(A, q);
+    const double c = constr_value<D>(A, q);
+    const double err = fabs(c);
+    if (it > 0 && (err > o.div_tol || err != err)) return MM_ST_DIVERGED;
+    bool small_step = (it == 0);
+    if (!small_step) {
+      Vec<D> sd;
+#pragma unroll
+      for (int i = 0; i < D; ++i) sd.v[i] = step * dpos.v[i];
+      small_step = vnorm<D>(sd, o.norm) < o.pos_tol;
+    }
+    if (err < o.constr_tol && small_step) {
+      const double sgn = (t > 0.0) ? 1.0 : ((t < 0.0) ? -1.0 : 0.0);
+#pragma unroll
+      for (int i = 0; i < D; ++i) p.v[i] -= sgn * mu.v[i];
+      *jac_out = jac;
+      return MM_ST_OK;
+    }
+    const double a = dot<D>(jac, mjp) * abs_t;
+    if (!finite(a)) return MM_ST_SOLVER_LINALG;
+    const double dmu = c / a;
+#pragma unroll
+    for (int i = 0; i < D; ++i) dpos.v[i] = -(abs_t * (mjp.v[i] * dmu));
+    const Vec<D> q_curr = q;
+    step = 1.0;
+    for (int ls = 0; ls < o.max_line_search_iters; ++ls) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) q.v[i] = q_curr.v[i] + step * dpos.v[i];
+      const double new_err = fabs(constr_value<D>(A, q));
+      if (new_err < err) break;
+      step *= 0.5;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) mu.v[i] += step * (jac_prev.v[i] * dmu);
+  }
+  return MM_ST_MAX_ITERS;
+}
+
+template <int D>
+__device__ __forceinline__ int project(const ConArgs& A, Vec<D>& q, Vec<D>& p, const Vec<D>& jac_prev,
+                                       double t, Vec<D>* jac_out, long long* n_iters) {
+  if (A.opts.solver == MM_PROJ_QUASI_NEWTON)
+    return quasi_newton_project<D>(A, q, p, jac_prev, t, jac_out, n_iters);
+  if (A.opts.solver == MM_PROJ_NEWTON_LINE_SEARCH)
+    return line_search_project<D>(A, q, p, jac_prev, t, jac_out, n_iters);
+  return newton_project<D>(A, q, p, jac_prev, t, jac_out, n_iters);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void constrained_leapfrog_kernel(ConArgs A) {
   const int64_t chain = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -209,7 +312,7 @@ __global__ __launch_bounds__(256) void constrained_leapfrog_kernel(ConArgs A) {
 #pragma unroll
       for (int i = 0; i < D; ++i) qs.v[i] += t_in * v.v[i];  // h2_flow, systems.py:362-363
       Vec<D> j_new;
-      status = newton_project<D>(A, qs, ps, j_prev, t_in, &j_new, &n_newton);
+      status = project<D>(A, qs, ps, j_prev, t_in, &j_new, &n_newton);
       if (status != MM_ST_OK) break;
       if (in == n_inner - 1) {  // pre-evaluated dh1_dpos, integrators.py:956-969
         gs = target_grad<D>(A, qs);
@@ -221,7 +324,7 @@ __global__ __launch_bounds__(256) void constrained_leapfrog_kernel(ConArgs A) {
       const Vec<D> vb = minv_apply<D>(A, pb);
 #pragma unroll
       for (int i = 0; i < D; ++i) qb.v[i] -= t_in * vb.v[i];
-      status = newton_project<D>(A, qb, pb, j_new, -t_in, &j_tmp, &n_newton);
+      status = project<D>(A, qb, pb, j_new, -t_in, &j_tmp, &n_newton);
       if (status != MM_ST_OK) break;
       Vec<D> diff;
 #pragma unroll

@@ -15,6 +15,8 @@
 //                           workgroup, the [16 x D] x [D x D] products on v_mfma_f64_16x16x4_f64
 //                           with the D x D operand register-resident (one 16-column slab per wave)
 //                           and the chain tile exchanged through LDS once per product.
+#include <cstdlib>
+
 #include "mm_internal.h"
 
 namespace {
@@ -95,12 +97,12 @@ __global__ __launch_bounds__(256) void leapfrog_elem_kernel(
 // covered once.  With this k-permutation a lane's A fragments are DP/4 consecutive doubles of one
 // LDS row -> ds_read_b128.  LDS rows are padded by 2 doubles (one b128 access width) so the 16 rows
 // read by a lane group fall in distinct 16-byte bank slots.
-template <int DP>
+template <int DP, int CT>
 struct MfmaCfg {
-  static constexpr int NW = DP / 16;      // waves per workgroup
-  static constexpr int KK = DP / 4;       // MFMAs per product per wave
-  static constexpr int LDW = DP + 2;      // LDS row stride in doubles
-  static constexpr int TILE = 16 * LDW;   // doubles per LDS chain tile
+  static constexpr int NW = DP / (16 * CT);  // waves per workgroup (each owns CT 16-column tiles)
+  static constexpr int KK = DP / 4;          // MFMAs per product per 16-column tile
+  static constexpr int LDW = DP + 2;         // LDS row stride in doubles
+  static constexpr int TILE = 16 * LDW;      // doubles per LDS chain tile
 };
 
 template <int DP>
@@ -113,111 +115,150 @@ __device__ __forceinline__ void load_slab(double (&frag)[DP / 4], const double* 
   }
 }
 
-template <int DP>
-__device__ __forceinline__ double4_t tile_times_slab(const double* __restrict__ tile,
-                                                     const double (&frag)[DP / 4], int lane) {
-  // A fragments: row (lane&15), doubles [(lane>>4)*KK, +KK)
-  const double* row = tile + (lane & 15) * MfmaCfg<DP>::LDW + (lane >> 4) * (DP / 4);
-  double4_t acc0 = {0.0, 0.0, 0.0, 0.0};
-  double4_t acc1 = {0.0, 0.0, 0.0, 0.0};
+// acc[c] = tile x slab c for the CT column tiles of this wave; each A fragment is read from LDS once
+template <int DP, int CT>
+__device__ __forceinline__ void tile_times_slabs(const double* __restrict__ tile,
+                                                 const double (&frag)[CT][DP / 4], int lane,
+                                                 double4_t (&out)[CT]) {
+  const double* row = tile + (lane & 15) * (DP + 2) + (lane >> 4) * (DP / 4);
+  double4_t acc0[CT], acc1[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    acc0[c] = double4_t{0.0, 0.0, 0.0, 0.0};
+    acc1[c] = double4_t{0.0, 0.0, 0.0, 0.0};
+  }
 #pragma unroll
   for (int kk = 0; kk < DP / 4; kk += 2) {
     const double2 a = *reinterpret_cast<const double2*>(row + kk);
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, frag[kk], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, frag[kk + 1], acc1, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      acc0[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, frag[c][kk], acc0[c], 0, 0, 0);
+      acc1[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, frag[c][kk + 1], acc1[c], 0, 0, 0);
+    }
   }
-  return acc0 + acc1;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) out[c] = acc0[c] + acc1[c];
 }
 
-template <int DP, int TARGET, int METRIC>
-__global__ __launch_bounds__(DP * 4) void leapfrog_mfma_kernel(
+template <int DP, int CT, int TARGET, int METRIC>
+__global__ __launch_bounds__(DP * 4 / CT) void leapfrog_mfma_kernel(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
     int64_t n_chains, int dim, double step_size, int n_steps, const double* __restrict__ tparams,
     const double* __restrict__ minv) {
-  using Cfg = MfmaCfg<DP>;
+  using Cfg = MfmaCfg<DP, CT>;
   __shared__ __attribute__((aligned(16))) double lds[(METRIC == M_DENSE ? 4 : 2) * Cfg::TILE];
   double* qbuf = lds;                    // two q tiles (double buffered)
   double* pbuf = lds + 2 * Cfg::TILE;    // two p tiles (dense metric only)
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int col = wave * 16 + (lane & 15);  // my column in the C layout
   const int kq = lane >> 4;
   const int64_t chain0 = (int64_t)blockIdx.x * 16;
+  int col[CT];  // my columns in the C layout
+#pragma unroll
+  for (int c = 0; c < CT; ++c) col[c] = (wave * CT + c) * 16 + (lane & 15);
 
   // register-resident matrix slabs (B operands)
-  double pfrag[TARGET == T_DENSE ? DP / 4 : 1];
-  double mfrag[METRIC == M_DENSE ? DP / 4 : 1];
-  if constexpr (TARGET == T_DENSE) load_slab<DP>(pfrag, tparams, dim, col, kq);
-  if constexpr (METRIC == M_DENSE) load_slab<DP>(mfrag, minv, dim, col, kq);
+  double pfrag[TARGET == T_DENSE ? CT : 1][TARGET == T_DENSE ? DP / 4 : 1];
+  double mfrag[METRIC == M_DENSE ? CT : 1][METRIC == M_DENSE ? DP / 4 : 1];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    if constexpr (TARGET == T_DENSE) load_slab<DP>(pfrag[c], tparams, dim, col[c], kq);
+    if constexpr (METRIC == M_DENSE) load_slab<DP>(mfrag[c], minv, dim, col[c], kq);
+  }
 
-  double tp0 = 0.0, tp1 = 0.0, mi = 1.0;
-  if constexpr (TARGET == T_DIAG) tp0 = (col < dim) ? tparams[col] : 0.0;
-  if constexpr (TARGET == T_POLY) { tp0 = tparams[0]; tp1 = tparams[1]; }
-  if constexpr (METRIC == M_DIAG) mi = (col < dim) ? minv[col] : 0.0;
+  double tp0[CT], tp1[CT], mi[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    tp0[c] = 0.0; tp1[c] = 0.0; mi[c] = 1.0;
+    if constexpr (TARGET == T_DIAG) tp0[c] = (col[c] < dim) ? tparams[col[c]] : 0.0;
+    if constexpr (TARGET == T_POLY) { tp0[c] = tparams[0]; tp1[c] = tparams[1]; }
+    if constexpr (METRIC == M_DIAG) mi[c] = (col[c] < dim) ? minv[col[c]] : 0.0;
+  }
 
-  // chain state in the C layout: q[r], p[r] <-> chain (lane>>4)+4r, column col
-  double q[4], p[4], g[4], t[4], ht[4];
-  bool live[4];
+  // chain state in the C layout: q[c][r], p[c][r] <-> chain (lane>>4)+4r, column col[c]
+  double q[CT][4], p[CT][4], g[CT][4], t[4], ht[4];
+  bool live[CT][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t chain = chain0 + (lane >> 4) + 4 * r;
-    live[r] = chain < n_chains && col < dim;
-    q[r] = live[r] ? pos[chain * dim + col] : 0.0;
-    p[r] = live[r] ? mom[chain * dim + col] : 0.0;
     t[r] = (chain < n_chains) ? (double)dir[chain] * step_size : 0.0;
     ht[r] = 0.5 * t[r];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      live[c][r] = chain < n_chains && col[c] < dim;
+      q[c][r] = live[c][r] ? pos[chain * dim + col[c]] : 0.0;
+      p[c][r] = live[c][r] ? mom[chain * dim + col[c]] : 0.0;
+    }
   }
 
-  auto publish = [&](double* tile, const double (&x)[4]) {
+  auto publish = [&](double* tile, const double (&x)[CT][4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tile[((lane >> 4) + 4 * r) * Cfg::LDW + col] = x[r];
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[((lane >> 4) + 4 * r) * Cfg::LDW + col[c]] = x[c][r];
   };
   auto gradient = [&](int s) {
     if constexpr (TARGET == T_DENSE) {
       double* tile = qbuf + (s & 1) * Cfg::TILE;
       publish(tile, q);
       __syncthreads();
-      const double4_t acc = tile_times_slab<DP>(tile, pfrag, lane);
+      double4_t acc[CT];
+      tile_times_slabs<DP, CT>(tile, pfrag, lane, acc);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) g[r] = acc[r];
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[c][r] = acc[c][r];
     } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) g[r] = elem_grad<TARGET>(q[r], tp0, tp1);
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[c][r] = elem_grad<TARGET>(q[c][r], tp0[c], tp1[c]);
     }
   };
 
   gradient(1);  // g(q0); uses buffer 1 so that step 0 starts on buffer 0
   for (int s = 0; s < n_steps; ++s) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[r] -= ht[r] * g[r];
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[c][r] -= ht[r] * g[c][r];
     if constexpr (METRIC == M_DENSE) {
       double* tile = pbuf + (s & 1) * Cfg::TILE;
       publish(tile, p);
       __syncthreads();
-      const double4_t v = tile_times_slab<DP>(tile, mfrag, lane);
+      double4_t v[CT];
+      tile_times_slabs<DP, CT>(tile, mfrag, lane, v);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) q[r] += t[r] * v[r];
-    } else if constexpr (METRIC == M_DIAG) {
+      for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) q[r] += t[r] * (mi * p[r]);
+        for (int r = 0; r < 4; ++r) q[c][r] += t[r] * v[c][r];
     } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) q[r] += t[r] * p[r];
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (METRIC == M_DIAG) q[c][r] += t[r] * (mi[c] * p[c][r]);
+          else q[c][r] += t[r] * p[c][r];
+        }
     }
     gradient(s);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[r] -= ht[r] * g[r];
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[c][r] -= ht[r] * g[c][r];
   }
 
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (live[r]) {
-      const int64_t chain = chain0 + (lane >> 4) + 4 * r;
-      pos[chain * dim + col] = q[r];
-      mom[chain * dim + col] = p[r];
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (live[c][r]) {
+        const int64_t chain = chain0 + (lane >> 4) + 4 * r;
+        pos[chain * dim + col[c]] = q[c][r];
+        mom[chain * dim + col[c]] = p[c][r];
+      }
     }
-  }
 }
 
 template <int TARGET, int METRIC>
@@ -241,23 +282,36 @@ int launch_elem(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_ste
   return MM_OK;
 }
 
-template <int DP, int TARGET, int METRIC>
+template <int DP, int CT, int TARGET, int METRIC>
 int launch_mfma_dp(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
   const unsigned blocks = (unsigned)((s->n + 15) / 16);
-  hipLaunchKernelGGL((leapfrog_mfma_kernel<DP, TARGET, METRIC>), dim3(blocks), dim3(DP * 4), 0,
-                     ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->n, s->dim, h, n_steps,
-                     m->d_target_params, m->d_metric_inv);
+  hipLaunchKernelGGL((leapfrog_mfma_kernel<DP, CT, TARGET, METRIC>), dim3(blocks),
+                     dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->n, s->dim, h,
+                     n_steps, m->d_target_params, m->d_metric_inv);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
+}
+
+// columns per wave: 16 (CT = 1, two waves per SIMD at D = 128) or 32 (CT = 2, one wave per SIMD, each
+// A fragment read once for two column tiles, half the waves at the per-product barrier)
+int mfma_ct() {
+  static const int ct = [] {
+    const char* e = getenv("MICI_AMD_MFMA_CT");
+    return (e && e[0] == '2') ? 2 : 1;  // measured equal on c2(iii), CT = 1 faster with a dense metric
+  }();
+  return ct;
 }
 
 template <int TARGET, int METRIC>
 int launch_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
   const int dim = s->dim;
-  if (dim <= 16) return launch_mfma_dp<16, TARGET, METRIC>(ctx, m, s, h, n_steps);
-  if (dim <= 32) return launch_mfma_dp<32, TARGET, METRIC>(ctx, m, s, h, n_steps);
-  if (dim <= 64) return launch_mfma_dp<64, TARGET, METRIC>(ctx, m, s, h, n_steps);
-  if (dim <= 128) return launch_mfma_dp<128, TARGET, METRIC>(ctx, m, s, h, n_steps);
+  if (dim <= 16) return launch_mfma_dp<16, 1, TARGET, METRIC>(ctx, m, s, h, n_steps);
+  if (dim <= 32) return launch_mfma_dp<32, 1, TARGET, METRIC>(ctx, m, s, h, n_steps);
+  if (dim <= 64) return launch_mfma_dp<64, 1, TARGET, METRIC>(ctx, m, s, h, n_steps);
+  if (dim <= 128) {
+    if (mfma_ct() == 2) return launch_mfma_dp<128, 2, TARGET, METRIC>(ctx, m, s, h, n_steps);
+    return launch_mfma_dp<128, 1, TARGET, METRIC>(ctx, m, s, h, n_steps);
+  }
   mm_set_error(ctx, "mm_leapfrog_euclid: dense target/metric kernels support dim <= 128");
   return MM_ERR_UNSUPPORTED;
 }

@@ -436,10 +436,11 @@ int mm_constrained_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
   if (rc != MM_OK) return rc;
   MM_REQUIRE(ctx, m->constr != MM_CONSTR_NONE, "mm_constrained_leapfrog: model has no constraint");
   MM_REQUIRE(ctx, n_steps >= 0, "mm_constrained_leapfrog: n_steps < 0");
-  mm_proj_opts o = {1e-9, 1e-8, 1e10, 50, MM_NORM_LINF, MM_PROJ_NEWTON, MM_NORM_LINF, 2e-8, 1, 0};
+  mm_proj_opts o = {1e-9, 1e-8, 1e10, 50, MM_NORM_LINF, MM_PROJ_NEWTON, MM_NORM_LINF, 2e-8, 1, 10};
   if (opts) o = *opts;
   MM_REQUIRE(ctx, o.max_iters >= 0 && o.n_inner >= 1 && (o.norm == 0 || o.norm == 1) &&
-                      (o.rev_norm == 0 || o.rev_norm == 1) && o.solver == MM_PROJ_NEWTON,
+                      (o.rev_norm == 0 || o.rev_norm == 1) && o.solver >= MM_PROJ_NEWTON &&
+                      o.solver <= MM_PROJ_NEWTON_LINE_SEARCH && o.max_line_search_iters >= 0,
              "mm_constrained_leapfrog: bad solver options");
   MM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(mm_counters), ctx->stream));
   if (s->n > 0) {

@@ -188,6 +188,9 @@ class ConstrainedLeapfrogIntegrator(Integrator):
         if unknown:
             raise ValueError(f"unknown projection_solver_kwargs: {sorted(unknown)}")
         kw.update(self.projection_solver_kwargs)
+        if ("max_line_search_iters" in self.projection_solver_kwargs
+                and solvers.proj_solver_code(self.projection_solver) != 2):
+            raise ValueError("max_line_search_iters only applies to the line-search solver")
         o = _ffi.ProjOpts()
         o.constr_tol = kw["constraint_tol"]
         o.pos_tol = kw["position_tol"]
@@ -198,6 +201,7 @@ class ConstrainedLeapfrogIntegrator(Integrator):
         o.rev_norm = solvers.norm_code(self.reverse_check_norm)
         o.rev_tol = self.reverse_check_tol
         o.n_inner = int(self.n_inner_step)
+        o.max_line_search_iters = int(kw["max_line_search_iters"])
         return o
 
     def _launch(self, ctx, model, batch, n_steps):

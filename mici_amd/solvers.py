@@ -30,8 +30,13 @@ solve_projection_onto_manifold_newton = _Selector(                            # 
 
 FIXED_POINT_DEFAULTS = dict(convergence_tol=1e-9, divergence_tol=1e10, max_iters=100,
                             norm=maximum_norm)
+solve_projection_onto_manifold_quasi_newton = _Selector(                      # solvers.py:195-343
+    "solve_projection_onto_manifold_quasi_newton", 1)
+solve_projection_onto_manifold_newton_with_line_search = _Selector(           # solvers.py:472-614
+    "solve_projection_onto_manifold_newton_with_line_search", 2)
+
 PROJECTION_DEFAULTS = dict(constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10,
-                           max_iters=50, norm=maximum_norm)
+                           max_iters=50, norm=maximum_norm, max_line_search_iters=10)
 
 
 def norm_code(norm):
@@ -56,6 +61,10 @@ def fp_solver_code(solver):
 
 def proj_solver_code(solver):
     name = solver.name if isinstance(solver, _Selector) else getattr(solver, "__name__", None)
-    if name == "solve_projection_onto_manifold_newton":
-        return 0
-    raise ValueError("projection_solver must be solve_projection_onto_manifold_newton")
+    codes = {"solve_projection_onto_manifold_newton": 0,
+             "solve_projection_onto_manifold_quasi_newton": 1,
+             "solve_projection_onto_manifold_newton_with_line_search": 2}
+    if name in codes:
+        return codes[name]
+    raise ValueError("projection_solver must be one of the three solve_projection_onto_manifold_* "
+                     "selectors")

@@ -557,12 +557,96 @@ def solve_projection_newton(
                            ST_MAX_ITERS, i)
 
 
+def solve_projection_quasi_newton(
+    system, q, p, q_prev, jac_prev, t, constraint_tol=1e-9, position_tol=1e-8,
+    divergence_tol=1e10, max_iters=50, norm=maximum_norm,
+):
+    """solve_projection_onto_manifold_quasi_newton (solvers.py:303-343): the Gram matrix
+    J_prev (|t| M^-1) J_prev^T is Cholesky-factored ONCE, outside the try block (a failure there is a
+    LinAlgError outside the solver); only constr is re-evaluated in the loop."""
+    mu = np.zeros_like(q)
+    abs_t = abs(t)
+    gram = DensePD(jac_prev @ (abs_t * system.minv_mat(jac_prev.T)))
+    inv_gram = gram.inv
+    error = np.nan
+    i = -1
+    try:
+        for i in range(max_iters):
+            system.counters.bump("newton_iters")
+            c = system.constr(q)
+            error = norm(c)
+            delta_mu = jac_prev.T @ (inv_gram @ c)
+            delta_pos = abs_t * system.minv(delta_mu)
+            if error > divergence_tol or np.isnan(error):
+                raise ConvergenceError(f"Quasi-Newton solver diverged on iteration {i}.",
+                                       ST_DIVERGED, i)
+            if error < constraint_tol and norm(delta_pos) < position_tol:
+                p = p - np.sign(t) * mu
+                return q, p, system.jacob(q)
+            mu = mu + delta_mu
+            q = q - delta_pos
+    except (ValueError, LinAlgError) as e:
+        raise ConvergenceError(f"{type(e)} at iteration {i} of quasi-Newton solver ({e}).",
+                               ST_SOLVER_LINALG, i) from e
+    raise ConvergenceError(f"Quasi-Newton solver did not converge with {max_iters} iterations.",
+                           ST_MAX_ITERS, i)
+
+
+def solve_projection_newton_line_search(
+    system, q, p, q_prev, jac_prev, t, constraint_tol=1e-9, position_tol=1e-8,
+    divergence_tol=1e10, max_iters=50, max_line_search_iters=10, norm=maximum_norm,
+):
+    """solve_projection_onto_manifold_newton_with_line_search (solvers.py:561-614)."""
+    mu = np.zeros_like(q)
+    abs_t = abs(t)
+    delta_pos, step_size = None, None
+    error = np.nan
+    for i in range(max_iters):
+        try:
+            system.counters.bump("newton_iters")
+            jac = system.jacob(q)
+            c = system.constr(q)
+            error = norm(c)
+            if i > 0 and (error > divergence_tol or np.isnan(error)):
+                raise ConvergenceError(f"Newton solver diverged at iteration {i}.", ST_DIVERGED, i)
+            if error < constraint_tol and (i == 0 or norm(step_size * delta_pos) < position_tol):
+                p = p - np.sign(t) * mu
+                return q, p, jac
+            a = _chk_finite(jac @ (abs_t * system.minv_mat(jac_prev.T)))
+            lu, piv = sla.lu_factor(a, check_finite=False)
+            delta_mu = jac_prev.T @ sla.lu_solve((lu, piv), c, check_finite=False)
+            delta_pos = -(abs_t * system.minv(delta_mu))
+            pos_curr = q.copy()
+            step_size = 1.0
+            for _ in range(max_line_search_iters):
+                q = pos_curr + step_size * delta_pos
+                new_error = norm(system.constr(q))
+                if new_error < error:
+                    break
+                step_size *= 0.5
+            mu = mu + step_size * delta_mu
+        except (ValueError, LinAlgError) as e:
+            raise ConvergenceError(f"{type(e)} at iteration {i} of Newton solver ({e}).",
+                                   ST_SOLVER_LINALG, i) from e
+    raise ConvergenceError(f"Newton solver did not converge in {max_iters} iterations.",
+                           ST_MAX_ITERS, i)
+
+
+def _newton3(*a, **k):
+    q, p = solve_projection_newton(*a, **k)
+    return q, p, None
+
+
+PROJ_SOLVERS = {0: _newton3, 1: solve_projection_quasi_newton, 2: solve_projection_newton_line_search}
+
+
 def constrained_leapfrog_step(system, q, p, dt, n_inner_step=1, rev_tol=2e-8,
-                              rev_norm=maximum_norm, proj_kwargs=None, grad_jac=None):
+                              rev_norm=maximum_norm, proj_kwargs=None, grad_jac=None, proj_solver=0):
     """One ConstrainedLeapfrogIntegrator._step (integrators.py:929-984).  ``grad_jac`` carries
     the cached (gradient, Jacobian) at q from the previous step.  Returns
     (q, p, (grad, jac)) or raises."""
     proj_kwargs = proj_kwargs or {}
+    solve = PROJ_SOLVERS[proj_solver]
     if grad_jac is None:
         grad_jac = (system.grad(q), system.jacob(q))
     g, jac = grad_jac
@@ -575,16 +659,14 @@ def constrained_leapfrog_step(system, q, p, dt, n_inner_step=1, rev_tol=2e-8,
     for i in range(n_inner_step):
         q_prev, jac_prev = q, jac
         q_new = q + t_in * system.minv(p)  # h2_flow, systems.py:362-363
-        q_new, p = solve_projection_newton(system, q_new, p, q_prev, jac_prev, t_in,
-                                           **proj_kwargs)
+        q_new, p, _ = solve(system, q_new, p, q_prev, jac_prev, t_in, **proj_kwargs)
         jac_new = system.jacob(q_new)
         if i == n_inner_step - 1:
             g = system.grad(q_new)  # pre-evaluated dh1_dpos, :956-969
         p = system.project_onto_cotangent_space(p, jac_new)
         # reversibility check (:971-979)
         q_back = q_new + (-t_in) * system.minv(p)
-        q_back, _ = solve_projection_newton(system, q_back, p.copy(), q_new, jac_new, -t_in,
-                                            **proj_kwargs)
+        q_back, _, _ = solve(system, q_back, p.copy(), q_new, jac_new, -t_in, **proj_kwargs)
         if rev_norm(q_back - q_prev) > rev_tol:
             raise NonReversibleStepError("Non-reversible step (positions).")
         q, jac = q_new, jac_new

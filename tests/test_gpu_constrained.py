@@ -9,7 +9,7 @@ from conftest import assert_close, golden_names, load_golden
 from oracle import integrators as orc
 from oracle import models as omdl
 
-from mici_amd import integrators, models, systems
+from mici_amd import integrators, models, solvers, systems
 from mici_amd.errors import ConvergenceError, NonReversibleStepError
 from mici_amd.states import ChainState
 
@@ -23,8 +23,12 @@ def build(g):
     mk = int(g["metric_kind"])
     metric = None if mk == models.METRIC_IDENTITY else g["metric"]
     system = systems.DenseConstrainedEuclideanMetricSystem(target, constr, metric=metric)
+    proj = {0: solvers.solve_projection_onto_manifold_newton,
+            1: solvers.solve_projection_onto_manifold_quasi_newton,
+            2: solvers.solve_projection_onto_manifold_newton_with_line_search}[int(g.get("proj_solver", 0))]
     integ = integrators.ConstrainedLeapfrogIntegrator(system, float(g["step_size"]),
-                                                      n_inner_step=int(g["n_inner"]))
+                                                      n_inner_step=int(g["n_inner"]),
+                                                      projection_solver=proj)
     return system, integ
 
 

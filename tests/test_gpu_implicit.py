@@ -197,3 +197,56 @@ def test_softabs_full_size_matches_oracle():
     qb, pb, sb, _ = integ.step_batch(q, p, -1, n_steps=steps)
     assert np.all(sb == 0)
     assert_close(qb, q0, 1e-6, "reversed q")
+
+
+@pytest.mark.parametrize("dim,n,steps", [(65, 3, 2), (100, 2, 2), (279, 1, 1)])
+def test_large_kernel_boundaries_match_oracle(dim, n, steps):
+    """Workgroup-per-chain kernel at its smallest (65), a ragged (100) and its largest (279) dim."""
+    rng = np.random.default_rng(dim)
+    om = omdl.Rank1Metric(omdl.make_spd(dim, rng))
+    ot = omdl.Banana(dim)
+    osys = orc.RiemannianSystem(ot, om, None)
+    system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(om.base))
+    integ = integrators.ImplicitLeapfrogIntegrator(system, 0.01)
+    q0 = rng.standard_normal((n, dim))
+    z = rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, z)
+    q, p, status, n_done = integ.step_batch(q0, p0, 1, n_steps=steps)
+    assert np.all(status == 0)
+    for c in range(n):
+        assert_close(p0[c], osys.sample_momentum(orc._State(q0[c], None), z[c]), 1e-11, "sample_momentum")
+        qo, po, so, no = orc.implicit_leapfrog_steps(osys, q0[c], p0[c], 0.01, steps)
+        assert so == 0
+        assert_close(q[c], qo, 1e-10, f"q chain {c}")
+        assert_close(p[c], po, 1e-10, f"p chain {c}")
+        st = orc._State(q[c], p[c])
+        assert_close(system.h_batch(q[c:c + 1], p[c:c + 1])[0], osys.h(st), 1e-10, "h")
+
+
+def test_unsupported_sizes_fail_loudly():
+    from mici_amd.errors import DeviceError
+    rng = np.random.default_rng(0)
+    big = 280
+    system = systems.DenseRiemannianMetricSystem(models.Banana(big), models.Rank1Metric(np.eye(big)))
+    with pytest.raises(DeviceError):
+        integrators.ImplicitLeapfrogIntegrator(system, 0.01).step_batch(
+            rng.standard_normal((1, big)), rng.standard_normal((1, big)), 1, 1)
+    system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(np.linspace(0.5, 2, 64)))
+    with pytest.raises(DeviceError):
+        integrators.ImplicitLeapfrogIntegrator(system, 0.01).step_batch(
+            rng.standard_normal((1, 65)), rng.standard_normal((1, 65)), 1, 1)
+    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(9, 1.0, 0.0), models.CircleConstr())
+    with pytest.raises(DeviceError):
+        integrators.ConstrainedLeapfrogIntegrator(system, 0.1).step_batch(
+            rng.standard_normal((1, 9)), rng.standard_normal((1, 9)), 1, 1)
+
+
+def test_empty_batches():
+    system = systems.DenseRiemannianMetricSystem(models.Poly(4, 1.0, 0.0), models.DiagQuadMetric(4))
+    q, p, st, nd = integrators.ImplicitLeapfrogIntegrator(system, 0.1).step_batch(
+        np.zeros((0, 4)), np.zeros((0, 4)), 1, 3)
+    assert q.shape == (0, 4) and st.shape == (0,)
+    system = systems.DenseConstrainedEuclideanMetricSystem(models.Torus(), models.TorusConstr())
+    q, p, st, nd = integrators.ConstrainedLeapfrogIntegrator(system, 0.1).step_batch(
+        np.zeros((0, 3)), np.zeros((0, 3)), 1, 3)
+    assert q.shape == (0, 3)

@@ -100,7 +100,8 @@ def test_constrained_leapfrog(name):
     for c in range(n):
         for k, s in enumerate(int(s) for s in g["checkpoints"]):
             q, p, st, nd = orc.constrained_leapfrog_steps(
-                system, g["q0"][c], g["p0"][c], g["dir"][c] * h, s, n_inner_step=int(g["n_inner"]))
+                system, g["q0"][c], g["p0"][c], g["dir"][c] * h, s, n_inner_step=int(g["n_inner"]),
+                proj_solver=int(g.get("proj_solver", 0)))
             assert_close(q, g["q_out"][k, c], 1e-10, f"{name} q@{s} chain {c}")
             assert_close(p, g["p_out"][k, c], 1e-10, f"{name} p@{s} chain {c}")
             if s == s_max:

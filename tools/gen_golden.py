@@ -201,20 +201,24 @@ def riemann_case(name, target, rmetric, softabs_coeff, q0, p0, dirs, h, checkpoi
 
 
 def constrained_case(name, target, constraint, metric_kind, metric, q0, p0, dirs, h,
-                     checkpoints, n_inner=1):
+                     checkpoints, n_inner=1, proj_solver=0):
     ref_metric = None if metric_kind == mdl.METRIC_IDENTITY else np.array(metric)
     system = mici.systems.DenseConstrainedEuclideanMetricSystem(
         neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
         constr=constraint.constr, jacob_constr=constraint.jacob_constr, metric=ref_metric,
     )
-    integrator = mici.integrators.ConstrainedLeapfrogIntegrator(system, h, n_inner_step=n_inner)
+    ref_proj = {0: mici.solvers.solve_projection_onto_manifold_newton,
+                1: mici.solvers.solve_projection_onto_manifold_quasi_newton,
+                2: mici.solvers.solve_projection_onto_manifold_newton_with_line_search}[proj_solver]
+    integrator = mici.integrators.ConstrainedLeapfrogIntegrator(
+        system, h, n_inner_step=n_inner, projection_solver=ref_proj)
     ref, counts = run_reference(integrator, system, q0, p0, dirs, checkpoints)
     osys = orc.ConstrainedSystem(target, constraint, metric_kind, metric)
     n_max = max(checkpoints)
     for c in range(q0.shape[0]):
         for k, s in enumerate(checkpoints):
             q, p, st, nd = orc.constrained_leapfrog_steps(
-                osys, q0[c], p0[c], dirs[c] * h, s, n_inner_step=n_inner)
+                osys, q0[c], p0[c], dirs[c] * h, s, n_inner_step=n_inner, proj_solver=proj_solver)
             check_close(f"{name} q@{s} chain {c}", q, ref["q_out"][k, c], 1e-10)
             check_close(f"{name} p@{s} chain {c}", p, ref["p_out"][k, c], 1e-10)
             if s == n_max:
@@ -224,7 +228,8 @@ def constrained_case(name, target, constraint, metric_kind, metric, q0, p0, dirs
         kind="constrained", target=target.tid, target_params=target.params(),
         constr=constraint.cid, constr_params=constraint.params(), metric_kind=metric_kind,
         metric=np.zeros(0) if metric is None else np.asarray(metric), q0=q0, p0=p0, dir=dirs,
-        step_size=h, checkpoints=np.array(checkpoints), n_inner=n_inner, **ref,
+        step_size=h, checkpoints=np.array(checkpoints), n_inner=n_inner, proj_solver=proj_solver,
+        **ref,
     ), counts
 
 
@@ -339,13 +344,13 @@ def main():
     add_riemann("softabs_poly_d5", mdl.Poly(5, 1.0, 1.0 / 3.0), None, 1.0, 5, 0.1, [1, 5, 20])
 
     # ---- constrained leapfrog (c5 + the reference's own constrained test systems) ------------------
-    def add_constrained(name, target, constraint, mk, metric, q0, h, cps, n_inner=1):
+    def add_constrained(name, target, constraint, mk, metric, q0, h, cps, n_inner=1, proj_solver=0):
         n, d = q0.shape
         z = rng.standard_normal((n, d))
         osys = orc.ConstrainedSystem(target, constraint, mk, metric)
         p0 = project_momentum(osys, q0, np.stack([osys.msqrt(zz) for zz in z]))
         cases[name] = lambda: constrained_case(name, target, constraint, mk, metric, q0, p0,
-                                               dirs_for(n), h, cps, n_inner)
+                                               dirs_for(n), h, cps, n_inner, proj_solver)
 
     add_constrained("constrained_c5_torus", mdl.Torus(), mdl.TorusConstr(), mdl.METRIC_IDENTITY,
                     None, mdl.torus_init(16, rng), 0.1, [1, 5, 20, 100])
@@ -367,6 +372,24 @@ def main():
         ql = np.concatenate([np.zeros((5, 1)), rng.standard_normal((5, size - 1))], 1)
         add_constrained(f"constrained_linear_dense_d{size}", mdl.Poly(size, 1.0, 0.0),
                         mdl.FirstCoordConstr(), mdl.METRIC_DENSE, dense, ql, 0.1, [1, 5, 20])
+
+    # ---- the other two projection solvers (added last: earlier fixtures keep their random streams) ----
+    for ps, tag in ((1, "quasi"), (2, "linesearch")):
+        add_constrained(f"constrained_torus_{tag}", mdl.Torus(), mdl.TorusConstr(),
+                        mdl.METRIC_IDENTITY, None, mdl.torus_init(12, rng), 0.1, [1, 5, 20],
+                        proj_solver=ps)
+        add_constrained(f"constrained_torus_{tag}_fail_bigstep", mdl.Torus(), mdl.TorusConstr(),
+                        mdl.METRIC_IDENTITY, None, mdl.torus_init(12, rng), 1.0, [1, 4],
+                        proj_solver=ps)
+        eigval = np.exp(0.1 * rng.standard_normal(5))
+        eigvec = np.linalg.qr(rng.standard_normal((5, 5)))[0]
+        dense = (eigvec * eigval) @ eigvec.T
+        theta = rng.uniform(size=5) * 2 * np.pi
+        qc = np.concatenate([np.cos(theta)[:, None], np.sin(theta)[:, None],
+                             rng.standard_normal((5, 3))], 1)
+        add_constrained(f"constrained_circle_dense_d5_{tag}", mdl.Poly(5, 0.0, 0.5),
+                        mdl.CircleConstr(), mdl.METRIC_DENSE, dense, qc, 0.1, [1, 5, 20],
+                        proj_solver=ps)
 
     all_counts = {}
     for name, fn in cases.items():
