@@ -5,6 +5,7 @@
 // chain's metric, which it keeps on-chip in whatever layout suits it:
 //   bool   build_and_invert(double x)   metric_func(x) -> explicit M(x)^-1 kept by the backend;
 //                                        false = not finite / not positive definite
+//   bool   build_and_solve(x, rhs, &u)  metric_func(x) used for the single solve u = M(x)^-1 rhs
 //   double matvec(double v)             M^-1 v                          (dh2_dmom)
 //   double half_vjp_inv(double q)       0.5 * vjp_metric(q)(grad_log_abs_det)   (dh1_dpos - grad)
 //   double dh2_dpos(double p, double q) 0.5 * vjp_metric(q)(grad_quadratic_form_inv(p))
@@ -154,7 +155,12 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       bk.slot(SL_GNEW) = bk.grad(bk.slot(SL_XQ));
       ++r.n_grad;
     }
-    const bool okm = bk.build_and_invert(bk.slot(SL_XQ));
+    // INIT / BADJ need the explicit inverse (applied ~12 times: momentum solves, both A half-steps, the
+    // general-VJP path); the position-space iterations use their metric for a single solve.
+    double u_pos = 0.0;
+    const bool okm = (mode == MODE_INIT || mode == MODE_BADJ)
+                         ? bk.build_and_invert(bk.slot(SL_XQ))
+                         : bk.build_and_solve(bk.slot(SL_XQ), bk.slot(SL_PW), &u_pos);
     r.n_metric += (mode == MODE_CFIRST) ? 2 : 1;
     if (!okm) {
       r.status = (mode == MODE_INIT || mode == MODE_BADJ) ? MM_ST_LINALG : MM_ST_SOLVER_LINALG;
@@ -201,7 +207,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       continue;
     }
     // position-space solves: f(x) = qw -/+ t M(x)^-1 p with M(xq)^-1 now held by the backend
-    const double u = bk.matvec(bk.slot(SL_PW));
+    const double u = u_pos;
     const double qw = bk.slot(SL_QW);
     bool chk_done = false, adj_done = false;
     double q_back = 0.0;

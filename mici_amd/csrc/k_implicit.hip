@@ -30,7 +30,7 @@ using namespace mmdev;
 using namespace mmimp;
 
 constexpr int kWaves = 4;  // chains per workgroup
-constexpr int kWaveLdsDoubles = 5 * 64 + mmimp::SL_COUNT * 64;  // per-wave scratch vectors + step state
+constexpr int kWaveLdsDoubles = 5 * 64 + mmimp::SL_COUNT * 64 + 8 * 64;  // scratch vectors + step state + column block
 
 // Per-wave LDS scratch (doubles): 5 vectors of 64.
 struct WaveLds {
@@ -108,6 +108,76 @@ __device__ __forceinline__ bool sweep_inverse(double (&T)[TS][TS], int dim, int 
   return ok;
 }
 
+// ---- solve M u = rhs WITHOUT forming the inverse: LDL^T elimination + substitutions -------------------
+// The position-space fixed-point iterations (C reversibility check, C adjoint: ~9 of the ~10 metric
+// constructions per step) use each metric for exactly one solve.  Symmetric elimination needs only the
+// shrinking trailing window: in block kb a lane updates its (TS-kb)^2 entries with a, b >= kb, i.e.
+// sum_kb 8 (TS-kb)^2 = 1632 FMAs at D = 64 instead of the 4096 of a full sweep.
+//   forward substitution rides along (the published column IS the column of L, read flat);
+//   the rows of U = D L^T stay frozen in the tiles (row multipliers of eliminated rows are zeroed) and
+//   are re-published 8 columns at a time for a column-oriented back substitution.
+// T is destroyed.  Returns false if a pivot is not > 0.
+template <int TS>
+__device__ __forceinline__ bool eliminate_solve(double (&T)[TS][TS], double rhs, int lane,
+                                                const WaveLds& w, double* blk, double* u_out) {
+  const int ti = lane >> 3, tj = lane & 7;
+  bool ok = true;
+  double y = rhs;    // flat: element `lane`
+  double invd = 1.0; // 1 / pivot of row `lane`
+#pragma unroll
+  for (int kb = 0; kb < TS; ++kb) {
+#pragma unroll 1
+    for (int kt = 0; kt < 8; ++kt) {
+      const int k = kb * 8 + kt;
+      if (tj == kt) {
+#pragma unroll
+        for (int a = kb; a < TS; ++a) w.col[ti * TS + a] = T[a][kb];
+      }
+      wave_sync();
+      const double piv = w.col[kt * TS + kb];
+      ok = ok & (piv > 0.0);
+      const double d = fast_rcp(piv);
+      // forward substitution with column k of L (flat): y_i -= (a_ik / piv) y_k for i > k
+      const double yk = wave_bcast(y, k);
+      const double ci = (lane < Geo<TS>::DP) ? w.col[Geo<TS>::pos(lane)] : 0.0;
+      if (lane > k) y = __builtin_fma(-(ci * d), yk, y);
+      if (lane == k) invd = d;
+      // rank-1 update of the trailing window; rows <= k of the current block row are frozen (U rows)
+      double ar[TS], ac[TS];
+#pragma unroll
+      for (int a = kb; a < TS; ++a) {
+        ar[a] = w.col[ti * TS + a] * d;
+        ac[a] = w.col[tj * TS + a];
+      }
+      if (ti <= kt) ar[kb] = 0.0;
+#pragma unroll
+      for (int a = kb; a < TS; ++a)
+#pragma unroll
+        for (int b = kb; b < TS; ++b) T[a][b] = __builtin_fma(-ar[a], ac[b], T[a][b]);
+      wave_sync();
+    }
+  }
+  // back substitution: z = D^-1 y, then for k = DP-1 .. 0: u_k = z_k, z_i -= (U_ik / d_i) u_k for i < k
+  double z = y * invd;
+#pragma unroll
+  for (int kb = TS - 1; kb >= 0; --kb) {
+    // publish the 8 columns of block kb (frozen rows above the diagonal): blk[kt][pos(i)] = entry (i, kb*8+kt)
+#pragma unroll
+    for (int a = 0; a <= kb; ++a) blk[tj * 64 + ti * TS + a] = T[a][kb];
+    wave_sync();
+#pragma unroll 1
+    for (int kt = 7; kt >= 0; --kt) {
+      const int k = kb * 8 + kt;
+      const double uk = wave_bcast(z, k);
+      const double uik = (lane < k) ? blk[kt * 64 + Geo<TS>::pos(lane)] : 0.0;
+      z = __builtin_fma(-(uik * invd), uk, z);
+    }
+    wave_sync();
+  }
+  *u_out = z;
+  return ok;
+}
+
 // ---- y = T x with x, y "flat" (element i on lane i) ----------------------------------------------------
 template <int TS>
 __device__ __forceinline__ double matvec_flat(const double (&T)[TS][TS], double x, int lane,
@@ -126,11 +196,7 @@ __device__ __forceinline__ double matvec_flat(const double (&T)[TS][TS], double 
     part[a] = s;
   }
 #pragma unroll
-  for (int a = 0; a < TS; ++a) {
-    part[a] += __shfl_xor(part[a], 1, 64);
-    part[a] += __shfl_xor(part[a], 2, 64);
-    part[a] += __shfl_xor(part[a], 4, 64);
-  }
+  for (int a = 0; a < TS; ++a) part[a] = group8_sum(part[a]);  // over the 8 lanes of a row group (DPP)
   if (tj == 0) {
 #pragma unroll
     for (int a = 0; a < TS; ++a) w.vout[ti * TS + a] = part[a];
@@ -262,6 +328,7 @@ struct WaveBackend {
   int dim, lane, target;
   WaveLds w;
   double* stash;  // [SL_COUNT][64] flat state of the step, in LDS to keep VGPRs for the tiles
+  double* blk;    // [8][64] one block of re-published columns for the back substitution
 
   __device__ __forceinline__ double& slot(int i) { return stash[i * 64 + lane]; }
   const double* base_lds;
@@ -270,6 +337,13 @@ struct WaveBackend {
   __device__ __forceinline__ bool build_and_invert(double x) {
     bool ok = build_metric<TS, RMETRIC>(T, x, dim, lane, w, base_lds);
     ok = sweep_inverse<TS, false, false>(T, dim, lane, w, nullptr, nullptr) && ok;
+    return ok;
+  }
+  // metric at x used for ONE solve u = M(x)^-1 rhs (position-space fixed-point iterations)
+  __device__ __forceinline__ bool build_and_solve(double x, double rhs, double* u) {
+    bool ok = build_metric<TS, RMETRIC>(T, x, dim, lane, w, base_lds);
+    ok = eliminate_solve<TS>(T, rhs, lane, w, blk, u) && ok;
+    if (lane >= dim) *u = 0.0;
     return ok;
   }
   __device__ __forceinline__ double matvec(double v) { return matvec_flat<TS>(T, v, lane, w); }
@@ -310,6 +384,7 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_leapfrog_kernel(Implicit
   bk.target = A.target;
   bk.w = WaveLds{wl, wl + 64, wl + 128, wl + 192, wl + 256};
   bk.stash = wl + 320;
+  bk.blk = wl + 320 + SL_COUNT * 64;
   bk.base_lds = base_lds;
   bk.tparams = A.tparams;
   bk.slot(SL_Q) = q;
@@ -370,6 +445,49 @@ __global__ __launch_bounds__(64 * kWaves) void riemann_aux_kernel(ImplicitArgs A
     ok = sweep_inverse<TS, false, true>(T, dim, lane, w, nullptr, &y) && ok;
     if (act) A.mom[chain * dim + lane] = ok ? y : nan;
   }
+}
+
+// ---- developer micro-benchmark (not part of the ABI header): R repetitions of one primitive per wave
+template <int TS>
+__global__ __launch_bounds__(64 * kWaves) void debug_primitive_kernel(ImplicitArgs A, int variant,
+                                                                      int repeats, double* sink) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* base_lds = lds;
+  const int base_elems = 64 * Geo<TS>::TSTRIDE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* wl = lds + base_elems + wave * kWaveLdsDoubles;
+  const WaveLds w{wl, wl + 64, wl + 128, wl + 192, wl + 256};
+  double* blk = wl + 320 + SL_COUNT * 64;
+  stage_base<TS, MM_RMETRIC_RANK1>(base_lds, A.rparams, A.dim);
+  const int64_t chain = (int64_t)blockIdx.x * kWaves + wave;
+  if (chain >= A.n_chains) return;
+  const int dim = A.dim;
+  double q = lane < dim ? A.pos[chain * dim + lane] : 0.0;
+  double p = lane < dim ? A.mom[chain * dim + lane] : 0.0;
+  double T[TS][TS];
+  double acc = 0.0;
+  build_metric<TS, MM_RMETRIC_RANK1>(T, q, dim, lane, w, base_lds);
+  if (variant == 2) sweep_inverse<TS, false, false>(T, dim, lane, w, nullptr, nullptr);
+  for (int r = 0; r < repeats; ++r) {
+    if (variant == 0) {
+      build_metric<TS, MM_RMETRIC_RANK1>(T, q, dim, lane, w, base_lds);
+      sweep_inverse<TS, false, false>(T, dim, lane, w, nullptr, nullptr);
+      acc += T[0][0];
+    } else if (variant == 1) {
+      build_metric<TS, MM_RMETRIC_RANK1>(T, q, dim, lane, w, base_lds);
+      double u;
+      eliminate_solve<TS>(T, p, lane, w, blk, &u);
+      acc += u;
+    } else if (variant == 2) {
+      p = matvec_flat<TS>(T, p, lane, w) * 0.5 + 0.1;
+      acc += p;
+    } else {
+      build_metric<TS, MM_RMETRIC_RANK1>(T, q, dim, lane, w, base_lds);
+      acc += T[0][0];
+    }
+    q += 1e-9 * acc;
+  }
+  if (lane == 0) sink[chain] = acc;
 }
 
 template <int TS, int RMETRIC>
@@ -480,4 +598,29 @@ int mm_launch_riemann_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, d
   a.out = d_out;
   a.z = d_z;
   return dispatch(ctx, m, AuxFn{ctx, a, s->n, op});
+}
+
+// developer hook (tools/ubench_primitives.py): time `repeats` repetitions of one primitive per chain
+extern "C" int mm_debug_primitive_bench(mm_ctx* ctx, const mm_model* m, mm_state* s, int variant,
+                                        int repeats, double* ms) {
+  if (!ctx || !m || !s || m->dim > 64 || m->dim <= 32 || m->rmetric != MM_RMETRIC_RANK1) return MM_ERR_INVALID;
+  ImplicitArgs a = make_args(m, s);
+  const unsigned blocks = (unsigned)((s->n + kWaves - 1) / kWaves);
+  const size_t lds = lds_bytes<8, MM_RMETRIC_RANK1>();
+  hipEvent_t e0, e1;
+  MM_HIP_CHECK(ctx, hipEventCreate(&e0));
+  MM_HIP_CHECK(ctx, hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    MM_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL((debug_primitive_kernel<8>), dim3(blocks), dim3(64 * kWaves), lds, ctx->stream, a,
+                       variant, repeats, s->d_scratch);
+    MM_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+    MM_HIP_CHECK(ctx, hipEventSynchronize(e1));
+  }
+  float f = 0.f;
+  MM_HIP_CHECK(ctx, hipEventElapsedTime(&f, e0, e1));
+  *ms = f;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return MM_OK;
 }

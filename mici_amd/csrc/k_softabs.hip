@@ -229,6 +229,12 @@ struct SoftAbsBackend {
   }
 
   // M^-1 v = V diag(1/lamt) V^T v   (matrices.py:1568-1575, 1623-1624)
+  __device__ __forceinline__ bool build_and_solve(double x, double rhs, double* u) {
+    const bool ok = build_and_invert(x);
+    *u = matvec(rhs);
+    return ok;
+  }
+
   __device__ __forceinline__ double matvec(double v) {
     const double c = vt_times(v);
     return v_times(tid < dim ? (1.0 / w.lamt[tid]) * c : 0.0);

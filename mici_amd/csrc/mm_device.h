@@ -15,10 +15,41 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// Cross-lane data movement on the VALU (DPP) instead of ds_bpermute: a bpermute is an LDS-crossbar
+// round trip (~100+ cycles) that a lone wave cannot hide, and a 6-stage butterfly chains six of them;
+// DPP moves cost one VALU slot each.  quad_perm / row_mirror / row_half_mirror act inside rows of 16.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // lane i <-> 7 - i inside each 8-lane half row
+constexpr int kDppMirror = 0x140;     // lane i <-> 15 - i inside each 16-lane row
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane must be wave-uniform
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// sum over the 8 lanes sharing lane>>3 (result in all 8)
+__device__ __forceinline__ double group8_sum(double v) {
+  v += dpp_move<kDppXor1>(v);
+  v += dpp_move<kDppXor2>(v);
+  v += dpp_move<kDppHalfMirror>(v);
   return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  v = group8_sum(v);
+  v += dpp_move<kDppMirror>(v);  // every lane of a 16-lane row now holds the row sum
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 // max that propagates NaN (np.abs(x).max() semantics, solvers.py:25-27)
@@ -27,12 +58,16 @@ __device__ __forceinline__ double nanmax(double a, double b) {
 }
 
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = nanmax(v, __shfl_xor(v, off, 64));
-  return v;
+  v = nanmax(v, dpp_move<kDppXor1>(v));
+  v = nanmax(v, dpp_move<kDppXor2>(v));
+  v = nanmax(v, dpp_move<kDppHalfMirror>(v));
+  v = nanmax(v, dpp_move<kDppMirror>(v));
+  return nanmax(nanmax(readlane_f64(v, 0), readlane_f64(v, 16)),
+                nanmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
-__device__ __forceinline__ double wave_bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+// broadcast from a wave-uniform source lane (v_readlane, no LDS crossbar)
+__device__ __forceinline__ double wave_bcast(double v, int src_lane) { return readlane_f64(v, src_lane); }
 
 // norm over the first `dim` entries held one-per-lane-slot: elements i = lane, lane+64, ...
 // kind 0: max |x| (maximum_norm, solvers.py:25-27); kind 1: sqrt(sum x^2) (euclidean_norm, :20-22)

@@ -1,0 +1,33 @@
+"""Developer micro-benchmark: cycles per primitive of the wave-per-chain Riemannian kernel
+(build+sweep inverse, build+LDL^T solve, mat-vec, build only), one wave per chain."""
+import ctypes as C
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from mici_amd import models, systems  # noqa: E402
+from mici_amd.runtime import DeviceBatch, default_context  # noqa: E402
+from oracle import models as omdl  # noqa: E402
+
+ctx = default_context()
+lib = ctx._lib
+lib.mm_debug_primitive_bench.restype = C.c_int
+lib.mm_debug_primitive_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                         C.POINTER(C.c_double)]
+rng = np.random.default_rng(0)
+dim = 64
+system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(omdl.make_spd(dim, rng)))
+model = system.device_model(ctx)
+for n in (1024, 2048, 4096):
+    batch = DeviceBatch(ctx, n, dim)
+    batch.upload(rng.standard_normal((n, dim)), rng.standard_normal((n, dim)), 1)
+    for variant, name in ((0, "build + sweep inverse"), (1, "build + LDL^T solve"), (2, "mat-vec"),
+                          (3, "build only")):
+        reps = 200 if variant == 2 else 20
+        ms = C.c_double(0)
+        rc = lib.mm_debug_primitive_bench(ctx.handle, model.handle, batch.handle, variant, reps, C.byref(ms))
+        assert rc == 0, rc
+        us = ms.value * 1e3 / reps
+        print(f"N={n:5d} {name:24s}: {us:8.2f} us per call per wave-slot  (~{us * 2250:9.0f} cycles @2.25GHz)")
+    batch.close()
