@@ -581,7 +581,11 @@ int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, dou
                                 const mm_fp_opts& opts, mm_counters* d_counters) {
   if (m->rmetric == MM_RMETRIC_SOFTABS)
     return mm_launch_softabs_leapfrog(ctx, m, s, h, n_steps, opts, d_counters);
-  if (m->dim > 64) return mm_launch_implicit_large(ctx, m, s, h, n_steps, opts, d_counters);
+  // D <= 64: one wave per chain; above that a team of waves shares the chain's metric
+  // (k_implicit_large.hip).  MICI_AMD_TEAM=15|22 routes 32 < D <= 64 to a team kernel (A/B measurements).
+  static const bool force_team = getenv("MICI_AMD_TEAM") != nullptr;
+  if (m->dim > 64 || (m->dim > 32 && force_team))
+    return mm_launch_implicit_large(ctx, m, s, h, n_steps, opts, d_counters);
   ImplicitArgs a = make_args(m, s);
   a.step_size = h;
   a.n_steps = n_steps;

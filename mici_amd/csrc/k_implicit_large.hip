@@ -1,18 +1,19 @@
-// Implicit leapfrog on dense-metric Riemannian systems for 64 < D <= 264 (BASELINE config c4:
-// D = 256): one 1024-thread workgroup (a whole CU) per chain.  gfx950 / CDNA4.
+// Implicit leapfrog on dense-metric Riemannian systems with the metric held in the REGISTERS of a team
+// of waves: one workgroup per chain, 32 < D <= 279 (BASELINE configs c3: D = 64, c4: D = 256).
+// gfx950 / CDNA4.
 //
 // Same reference arithmetic as k_implicit.hip (the step itself is implicit_core.h); what changes is
-// where the D x D metric lives.  512 KB of fp64 does not fit one CU's LDS (160 KB), but the symmetric
-// half (D(D+1)/2 * 8 B = 263 KB at D = 256) fits its 512 KB register file:
-//   * the 1024 threads (16 waves, 4 per SIMD, 128 VGPRs each) form the lower triangle of a 44 x 44
-//     grid (990 tile owners); thread (ti >= tj) owns the 6 x 6 block-cyclic tile
-//     {(ti + 44 a, tj + 44 b)} = 72 VGPRs.  44 * 6 = 264 >= 256.
+// where the D x D metric lives.  Only the symmetric half is stored:
+//   * the threads form the lower triangle of a PG x PG grid; thread (ti >= tj) owns the TS x TS
+//     block-cyclic tile {(ti + PG a, tj + PG b)}.  PG * TS >= D.
 //   * the symmetric sweep operator keeps the matrix symmetric, so the mirrored tiles are never needed:
-//     step k publishes column k (from the tiles of grid column k%44 and, transposed, of grid row k%44)
-//     into LDS; every thread then applies at(a, b) -= m[a] * c[b] (36 v_fma_f64) from 12 LDS operands.
-//   * M^-1 v: each tile contributes to 6 "row" and (off-diagonal tiles) 6 "column" partial sums, laid
-//     out in LDS so that every output element has exactly 44 private slots -> deterministic reduction.
-// Throughput is one chain per CU, 256 chains in flight per GPU.
+//     step k publishes column k (from the tiles of grid column k % PG and, transposed, of grid row
+//     k % PG) into LDS; every thread then applies at(a, b) -= m[a] * c[b] (TS^2 v_fma_f64) from 2 TS
+//     LDS operands.
+//   * M^-1 v: each tile contributes to TS "row" and (off-diagonal tiles) TS "column" partial sums, laid
+//     out in LDS so that every output element has exactly PG private slots -> deterministic reduction.
+// Two geometries are instantiated (TeamCfg below): 31 x 31 grid of 9 x 9 tiles on 512 threads for
+// D <= 279 (one chain per CU half), and 15 x 15 grid of 5 x 5 tiles on 128 threads for D <= 75.
 #include "implicit_core.h"
 
 namespace {
@@ -20,16 +21,36 @@ namespace {
 using namespace mmdev;
 using namespace mmimp;
 
-constexpr int PG = 31;             // process-grid side
-constexpr int TS = 9;              // tile side
-constexpr int DP = PG * TS;        // 279: padded dimension
-constexpr int NT = 512;            // threads per workgroup (8 waves, 2 per SIMD -> 256 VGPRs each)
-constexpr int NTILE = PG * (PG + 1) / 2;  // 496 tile-owning threads
-constexpr int GS = 10;             // doubles reserved per grid group in a permuted LDS vector
-constexpr int PV = PG * GS;        // permuted vector length
-constexpr int SLOTS = 33;          // 31 partial-sum slots per output element (+2 pad vs bank conflicts)
-
-__device__ __forceinline__ int ppos(int i) { return (i % PG) * GS + i / PG; }
+// Geometry of a team: PG x PG thread grid (lower triangle owns tiles), TS x TS block-cyclic tiles.
+//   TeamCfg<31, 9, 512, true>  64 < D <= 279: a whole CU per chain, last tile row parked in LDS
+//   TeamCfg<15, 5, 128, false> 32 < D <= 75 : two waves per chain (25 doubles of metric per thread), eight
+//                              chains per CU, so that BASELINE c3 (1024 chains) puts two waves on every
+//                              SIMD - a lone wave issues FP64 VALU at only ~half rate on gfx950 (measured)
+template <int PG_, int TS_, int NT_, bool PARK_, int MINW_, int NB_>
+struct TeamCfg {
+  static constexpr int NB = NB_;                    // pivot columns per block of the blocked sweep
+  static constexpr int MINW = MINW_;                // waves per SIMD the register allocation targets
+  static constexpr int PG = PG_;                    // process-grid side
+  static constexpr int TS = TS_;                    // tile side
+  static constexpr int DP = PG_ * TS_;              // padded dimension
+  static constexpr int NT = NT_;                    // threads per workgroup
+  static constexpr int NTILE = PG_ * (PG_ + 1) / 2; // tile-owning threads
+  static constexpr int GS = TS_ + (TS_ & 1);        // doubles per grid group in a permuted LDS vector (even)
+  static constexpr int PV = PG_ * GS;               // permuted vector length
+  static constexpr int SLOTS = PG_ + 2;             // partial-sum slots per output element (+2 pad)
+  static constexpr int VL = ((DP + 7) / 8) * 8 + 8; // natural-order vector length (>= DP + 1)
+  static constexpr bool PARK = PARK_;               // park the last tile row in LDS (register relief)
+  static constexpr int TREG = PARK_ ? TS_ - 1 : TS_;
+  // mat-vec partial sums [PG][TS][SLOTS]; the blocked sweep's panel buffers [2][2][NB][PV] alias them
+  static constexpr int PART = PG_ * TS_ * SLOTS > 4 * NB_ * PV ? PG_ * TS_ * SLOTS : 4 * NB_ * PV;
+  static constexpr int LDS_DOUBLES =
+      3 * PV + PART + 2 * VL + 16 + mmimp::SL_COUNT * VL + (PARK_ ? TS_ * NT_ : 0);
+  static_assert(NTILE <= NT_, "not enough threads for the tile triangle");
+  __device__ static __forceinline__ int ppos(int i) { return (i % PG_) * GS + i / PG_; }
+};
+using CfgLarge = TeamCfg<31, 9, 512, true, 2, 4>;
+using CfgSmall = TeamCfg<15, 5, 128, false, 3, 1>;
+using CfgMid = TeamCfg<22, 3, 256, false, 4, 1>;
 
 // Launder a lane-varying index so that address arithmetic derived from it is recomputed where it is
 // used instead of being hoisted out of the step loop into long-lived VGPRs (the register file is full
@@ -47,11 +68,11 @@ struct BlockLds {
   double* nat;   // natural order [DP + pad]
   double* aux;   // natural order [DP + pad]
   double* red;   // [16]
-  double* stash; // [SL_COUNT][288] per-thread flat state of the step (keeps it out of VGPRs)
+  double* stash; // [SL_COUNT][VL] per-thread flat state of the step (keeps it out of VGPRs)
   double* trow;  // [TS][NT] the last tile row of every thread (register relief, see BlockBackend::at)
 };
-constexpr int kLdsDoubles = 3 * PV + PG * TS * SLOTS + 2 * 288 + 16 + SL_COUNT * 288 + TS * NT;
 
+template <class C>
 __device__ __forceinline__ double block_reduce(double v, int kind_max, double* red) {
   // kind_max: 0 sum, 1 NaN-propagating max.  Uniform result; two barriers.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -60,20 +81,26 @@ __device__ __forceinline__ double block_reduce(double v, int kind_max, double* r
   __syncthreads();
   double r = red[0];
 #pragma unroll
-  for (int w = 1; w < NT / 64; ++w) r = kind_max ? nanmax(r, red[w]) : r + red[w];
+  for (int w = 1; w < C::NT / 64; ++w) r = kind_max ? nanmax(r, red[w]) : r + red[w];
   __syncthreads();
   return r;
 }
 
-template <int RMETRIC>
+template <class C, int RMETRIC>
 struct BlockBackend {
+  static constexpr int PG = C::PG, TS = C::TS, DP = C::DP, NT = C::NT, GS = C::GS, SLOTS = C::SLOTS, VL = C::VL;
+  __device__ static __forceinline__ int ppos(int i) { return C::ppos(i); }
   // Tile storage: rows 0..TS-2 in registers (144 VGPRs), row TS-1 in LDS.  The compiler could not
   // keep all 81 doubles plus the sweep operands inside the 256-VGPR budget of a wave here and spilled
   // tile entries to scratch (L2-bound: measured 8x slowdown of the sweep); parking one row in LDS by
   // hand removes the spills at the price of 18 LDS accesses per sweep step.
-  double Treg[TS - 1][TS];
+  double Treg[C::TREG][TS];
   __device__ __forceinline__ double& at(int a, int b) {
-    return a < TS - 1 ? Treg[a][b] : w.trow[b * NT + tid];
+    if constexpr (C::PARK) {
+      return a < TS - 1 ? Treg[a][b] : w.trow[b * NT + tid];
+    } else {
+      return Treg[a][b];
+    }
   }
   int dim, tid, ti, tj, target;
   bool tile;  // this thread owns a tile
@@ -82,12 +109,12 @@ struct BlockBackend {
   const double* tparams;
 
   // flat state only exists for tid < DP; the other threads share one dummy cell per slot
-  __device__ __forceinline__ double& slot(int i) { return w.stash[i * 288 + (tid < DP ? tid : 287)]; }
+  __device__ __forceinline__ double& slot(int i) { return w.stash[i * VL + (tid < DP ? tid : VL - 1)]; }
 
   __device__ __forceinline__ double norm(double x, int kind) {
     const double a = tid < dim ? x : 0.0;
-    if (kind == MM_NORM_LINF) return block_reduce(fabs(a), 1, w.red);
-    return sqrt(block_reduce(a * a, 0, w.red));
+    if (kind == MM_NORM_LINF) return block_reduce<C>(fabs(a), 1, w.red);
+    return sqrt(block_reduce<C>(a * a, 0, w.red));
   }
 
   // metric_func(x) into the tiles; returns false if any entry is not finite
@@ -116,7 +143,7 @@ struct BlockBackend {
 #pragma unroll
           for (int b = 0; b < TS; ++b) at(a, b) = 0.0;
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (C::PARK) __builtin_amdgcn_sched_barrier(0);
       }
       if (ti == tj) {
 #pragma unroll
@@ -131,7 +158,7 @@ struct BlockBackend {
         for (int b = 0; b < TS; ++b) chk = __builtin_fma(at(a, b), 0.0, chk);
     }
     // NaN in chk <=> some entry is inf/NaN ("Array is not finite.", matrices.py:211-215)
-    const double bad = block_reduce(chk == 0.0 ? 0.0 : 1.0, 0, w.red);
+    const double bad = block_reduce<C>(chk == 0.0 ? 0.0 : 1.0, 0, w.red);
     return bad == 0.0;
   }
 
@@ -147,13 +174,26 @@ struct BlockBackend {
         const int k = kb * PG + kt;
         const int ti = opaque(this->ti), tj = opaque(this->tj);
         double* col = (k & 1) ? w.col1 : w.col0;
-        if (tile) {
-          if (tj == kt) {  // grid column kt: rows ti + 31 a
+        // publish column k: grid column kt holds rows ti + PG a of it; grid row kt (tj < kt) holds, by
+        // symmetry, entries (k, tj + PG b)
+        // (the small geometry uses one store sequence with selected operands: with two branches the
+        // compiler spilt its tile to scratch to merge them; the large one is the other way round)
+        if constexpr (C::PARK) {
+          if (tile) {
+            if (tj == kt) {
 #pragma unroll
-            for (int a = 0; a < TS; ++a) col[ti * GS + a] = at(a, kb);
-          } else if (ti == kt) {  // grid row kt (tj < kt): entries (k, tj + 31 b) = column k by symmetry
+              for (int a = 0; a < TS; ++a) col[ti * GS + a] = at(a, kb);
+            } else if (ti == kt) {
 #pragma unroll
-            for (int b = 0; b < TS; ++b) col[tj * GS + b] = at(kb, b);
+              for (int b = 0; b < TS; ++b) col[tj * GS + b] = at(kb, b);
+            }
+          }
+        } else {
+          const bool pc = (tj == kt), pr = (ti == kt);
+          if (tile && (pc || pr)) {
+            double* dst = col + (pc ? ti : tj) * GS;
+#pragma unroll
+            for (int a = 0; a < TS; ++a) dst[a] = pc ? at(a, kb) : at(kb, a);
           }
         }
         __syncthreads();
@@ -171,13 +211,17 @@ struct BlockBackend {
           for (int b = 0; b < TS; ++b) ac[b] = col[tj * GS + b];
           if (tj == kt) ac[kb] = piv - 1.0;
           // one tile row at a time: only one row multiplier is live (register budget: 256 / wave)
+          // (PARK: rows are kept apart by scheduling barriers so that the register-starved large geometry
+          // does not hoist all row multipliers; the next row's multiplier is prefetched by hand instead)
+          double mnext = col[ti * GS];
 #pragma unroll
           for (int a = 0; a < TS; ++a) {
-            double m = col[ti * GS + a] * d;
+            double m = mnext * d;
+            if (a + 1 < TS) mnext = col[ti * GS + a + 1];
             if (a == kb && ti == kt) m = 1.0 - d;
 #pragma unroll
             for (int b = 0; b < TS; ++b) at(a, b) = __builtin_fma(-m, ac[b], at(a, b));
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (C::PARK) __builtin_amdgcn_sched_barrier(0);
           }
           if (ti == kt && tj == kt) at(kb, kb) -= 2.0;
         }
@@ -194,9 +238,157 @@ struct BlockBackend {
     return ok;
   }
 
+
+  // ---- blocked symmetric sweep -------------------------------------------------------------------
+  // Sweeping the NBK columns K = {kb PG + kt0 + s} at once (P = A_KK, Q = A_:K):
+  //     A_RR -= Q_R P^-1 Q_R^T,   A_RK = Q_R P^-1,   A_KK = -P^-1
+  // is, for ALL entries uniformly, the rank-NBK update  A -= W X^T  with
+  //     W_i = Q_i P^-1 (i not in K),  W_K = I - P^-1;     X_j = Q_j (j not in K),  X_K = P - I,
+  // followed by  A_KK -= 2 I  (the scalar sweep above is the NBK = 1 case).  One block costs two
+  // barriers instead of NBK: (1) publish the panel Q; (2) threads tid < DP turn "their" row of Q
+  // into a row of W (every thread inverts the tiny P redundantly from broadcast LDS reads - that also
+  // gives every thread the pivots for the positive-definiteness check and logdet); (3) NBK
+  // back-to-back rank-one tile updates with no synchronisation in between, so their LDS operand
+  // loads pipeline.  Panel/W buffers are double-buffered by block parity and alias the mat-vec's
+  // partial-sum area (idle during a sweep).
+  template <int NBK, bool LOGDET>
+  __device__ __forceinline__ void block_step(int kb, int kt0, int par, bool& ok, double& ld) {
+    constexpr int PV = C::PV;
+    const int ti = opaque(this->ti), tj = opaque(this->tj), tid = opaque(this->tid);
+    double* Qp = w.part + par * (2 * C::NB * PV);
+    double* Wp = Qp + C::NB * PV;
+    // (1) publish: grid column kt0+s holds rows ti + PG a of column s; grid row kt0+s holds (tj < ti),
+    // by symmetry, its rows tj + PG b
+    if (tile) {
+      const int sc = tj - kt0, sr = ti - kt0;
+      if (sc >= 0 && sc < NBK) {
+#pragma unroll
+        for (int a = 0; a < TS; ++a) Qp[sc * PV + ti * GS + a] = at(a, kb);
+      }
+      if (sr >= 0 && sr < NBK && tj != ti) {
+#pragma unroll
+        for (int b = 0; b < TS; ++b) Qp[sr * PV + tj * GS + b] = at(kb, b);
+      }
+    }
+    __syncthreads();
+    // (2) P^-1 by Gauss-Jordan in registers (uniform across the workgroup)
+    {
+      double Pm[NBK][NBK];
+#pragma unroll
+      for (int s = 0; s < NBK; ++s)
+#pragma unroll
+        for (int t = 0; t < NBK; ++t) {
+          // a block hanging over the end of the grid row (PG % NBK != 0) sees identity columns there
+          const bool in = (kt0 + s < PG) && (kt0 + t < PG);
+          Pm[s][t] = in ? Qp[t * PV + (kt0 + (in ? s : 0)) * GS + kb] : (s == t ? 1.0 : 0.0);
+        }
+#pragma unroll
+      for (int k = 0; k < NBK; ++k) {
+        const double piv = Pm[k][k];
+        ok = ok && (piv > 0.0);
+        if constexpr (LOGDET) ld += log(piv);
+        const double d = fast_rcp(piv);
+        double rk[NBK];
+#pragma unroll
+        for (int t = 0; t < NBK; ++t) rk[t] = Pm[k][t] * d;
+#pragma unroll
+        for (int s = 0; s < NBK; ++s) {
+          if (s == k) continue;
+          const double f = Pm[s][k];
+#pragma unroll
+          for (int t = 0; t < NBK; ++t)
+            if (t != k) Pm[s][t] = __builtin_fma(-f, rk[t], Pm[s][t]);
+          Pm[s][k] = -f * d;
+        }
+#pragma unroll
+        for (int t = 0; t < NBK; ++t) Pm[k][t] = rk[t];
+        Pm[k][k] = d;
+      }
+      // Pm = P^-1 (plain Gauss-Jordan with the pivot row scaled: no sign convention needed here)
+      if (tid < DP) {
+        const int g = tid % PG, a = tid / PG, pp = g * GS + a;
+        double qi[NBK];
+#pragma unroll
+        for (int t = 0; t < NBK; ++t) qi[t] = (kt0 + t < PG) ? Qp[t * PV + pp] : 0.0;
+        const int r = g - kt0;
+        const bool in_k = (a == kb) && r >= 0 && r < NBK;
+#pragma unroll
+        for (int s = 0; s < NBK; ++s) {
+          double wv = 0.0;
+#pragma unroll
+          for (int t = 0; t < NBK; ++t) wv = __builtin_fma(qi[t], Pm[t][s], wv);
+          if (in_k) {
+            double y = 0.0;
+#pragma unroll
+            for (int t = 0; t < NBK; ++t) y = (r == t) ? Pm[t][s] : y;
+            wv = ((r == s) ? 1.0 : 0.0) - y;
+          }
+          Wp[s * PV + pp] = wv;
+        }
+      }
+    }
+    __syncthreads();
+    // (3) rank-NBK update of every tile
+#pragma unroll
+    for (int s = 0; s < NBK; ++s) {
+      if (kt0 + s >= PG) break;  // uniform: only the overhanging tail of the last block
+      double ac[TS];
+#pragma unroll
+      for (int b = 0; b < TS; ++b) ac[b] = Qp[s * PV + tj * GS + b];
+      if (tj == kt0 + s) ac[kb] -= 1.0;
+      double mnext = Wp[s * PV + ti * GS];
+#pragma unroll
+      for (int a = 0; a < TS; ++a) {
+        const double m = mnext;
+        if (a + 1 < TS) mnext = Wp[s * PV + ti * GS + a + 1];
+#pragma unroll
+        for (int b = 0; b < TS; ++b) at(a, b) = __builtin_fma(-m, ac[b], at(a, b));
+        if constexpr (C::PARK) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (ti == tj && ti >= kt0 && ti < kt0 + NBK) at(kb, kb) -= 2.0;
+  }
+
+  template <bool LOGDET>
+  __device__ __forceinline__ bool sweep_blocked(double* logdet) {
+    constexpr int NB = C::NB;
+    bool ok = true;
+    double ld = 0.0;
+    int par = 0;
+#pragma unroll
+    for (int kb = 0; kb < TS; ++kb) {
+#pragma unroll 1
+      for (int kt0 = 0; kt0 < PG; kt0 += NB) {
+        block_step<NB, LOGDET>(kb, kt0, par, ok, ld);
+        par ^= 1;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < TS; ++a)
+#pragma unroll
+      for (int b = 0; b < TS; ++b) at(a, b) = -at(a, b);
+    __syncthreads();
+    if constexpr (LOGDET) *logdet = ld;
+    return ok;
+  }
+
+  // blocked where it pays (measured: +11% on c4; the small geometries are instruction-issue bound and the
+  // redundant P^-1 of a block costs them more than the saved barriers)
+  template <bool LOGDET>
+  __device__ __forceinline__ bool invert(double* logdet) {
+    if constexpr (C::NB > 1) return sweep_blocked<LOGDET>(logdet);
+    else return sweep<LOGDET, false>(logdet, nullptr);
+  }
+
   __device__ __forceinline__ bool build_and_invert(double x) {
     bool ok = build(x);
-    ok = sweep<false, false>(nullptr, nullptr) && ok;
+    ok = invert<false>(nullptr) && ok;
+    return ok;
+  }
+
+  __device__ __forceinline__ bool build_and_solve(double x, double rhs, double* u) {
+    const bool ok = build_and_invert(x);
+    *u = matvec(rhs);
     return ok;
   }
 
@@ -259,7 +451,7 @@ struct BlockBackend {
   __device__ __forceinline__ double dh2_dpos(double p, double q) {
     const double u = matvec(p);
     if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-      const double uq = block_reduce(tid < dim ? u * q : 0.0, 0, w.red);
+      const double uq = block_reduce<C>(tid < dim ? u * q : 0.0, 0, w.red);
       return -(u * uq) / (double)dim;
     } else {
       return -q * (u * u);
@@ -267,7 +459,7 @@ struct BlockBackend {
   }
 
   __device__ __forceinline__ double grad(double q) {
-    if (tid < 288) w.nat[tid] = (tid < dim) ? q : 0.0;
+    if (tid < VL) w.nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
     const TargetAux aux = target_prepare<false>(target, w.nat, dim, tparams, threadIdx.x & 63);
     const double g = (tid < dim) ? target_grad_elem<false>(target, aux, w.nat, tid, dim, tparams) : 0.0;
@@ -276,7 +468,7 @@ struct BlockBackend {
   }
 
   __device__ __forceinline__ double neg_log_dens_elem(double q) {
-    if (tid < 288) w.nat[tid] = (tid < dim) ? q : 0.0;
+    if (tid < VL) w.nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
     const TargetAux aux = target_prepare<false>(target, w.nat, dim, tparams, threadIdx.x & 63);
     const double e = (tid < dim) ? target_nld_elem<false>(target, aux, w.nat, tid, dim, tparams) : 0.0;
@@ -285,9 +477,10 @@ struct BlockBackend {
   }
 };
 
-template <int RMETRIC>
-__device__ __forceinline__ void init_backend(BlockBackend<RMETRIC>& bk, const ImplicitArgs& A,
+template <class C, int RMETRIC>
+__device__ __forceinline__ void init_backend(BlockBackend<C, RMETRIC>& bk, const ImplicitArgs& A,
                                              double* lds) {
+  constexpr int PG = C::PG, TS = C::TS, PV = C::PV, SLOTS = C::SLOTS, VL = C::VL, NTILE = C::NTILE;
   const int tid = threadIdx.x;
   bk.dim = A.dim;
   bk.tid = tid;
@@ -302,21 +495,21 @@ __device__ __forceinline__ void init_backend(BlockBackend<RMETRIC>& bk, const Im
   bk.w.col1 = lds + PV;
   bk.w.vin = lds + 2 * PV;
   bk.w.part = lds + 3 * PV;
-  bk.w.nat = bk.w.part + PG * TS * SLOTS;
-  bk.w.aux = bk.w.nat + 288;
-  bk.w.red = bk.w.aux + 288;
+  bk.w.nat = bk.w.part + C::PART;
+  bk.w.aux = bk.w.nat + VL;
+  bk.w.red = bk.w.aux + VL;
   bk.w.stash = bk.w.red + 16;
-  bk.w.trow = bk.w.stash + SL_COUNT * 288;
+  bk.w.trow = bk.w.stash + SL_COUNT * VL;
   bk.base = A.rparams;
   bk.tparams = A.tparams;
 }
 
-template <int RMETRIC>
-__global__ __launch_bounds__(NT, 2) void implicit_large_kernel(ImplicitArgs A) {
+template <class C, int RMETRIC>
+__global__ __launch_bounds__(C::NT, C::MINW) void implicit_team_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int64_t chain = blockIdx.x;
-  BlockBackend<RMETRIC> bk;
-  init_backend(bk, A, lds);
+  BlockBackend<C, RMETRIC> bk;
+  init_backend<C, RMETRIC>(bk, A, lds);
   const int dim = A.dim, tid = threadIdx.x;
   const bool act = tid < dim;
   double q = act ? A.pos[chain * dim + tid] : 0.0;
@@ -338,12 +531,12 @@ __global__ __launch_bounds__(NT, 2) void implicit_large_kernel(ImplicitArgs A) {
   }
 }
 
-template <int RMETRIC, int OP>
-__global__ __launch_bounds__(NT, 2) void riemann_aux_large_kernel(ImplicitArgs A) {
+template <class C, int RMETRIC, int OP>
+__global__ __launch_bounds__(C::NT, C::MINW) void riemann_aux_team_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int64_t chain = blockIdx.x;
-  BlockBackend<RMETRIC> bk;
-  init_backend(bk, A, lds);
+  BlockBackend<C, RMETRIC> bk;
+  init_backend<C, RMETRIC>(bk, A, lds);
   const int dim = A.dim, tid = threadIdx.x;
   const bool act = tid < dim;
   const double q = act ? A.pos[chain * dim + tid] : 0.0;
@@ -352,17 +545,17 @@ __global__ __launch_bounds__(NT, 2) void riemann_aux_large_kernel(ImplicitArgs A
   bool ok = bk.build(q);
   if constexpr (OP == 0) {
     double logdet;
-    ok = bk.template sweep<true, false>(&logdet, nullptr) && ok;
+    ok = bk.template invert<true>(&logdet) && ok;
     const double u = bk.matvec(p);
     const double e = bk.neg_log_dens_elem(q) + (act ? 0.5 * p * u : 0.0);
-    const double h = block_reduce(e, 0, bk.w.red) + 0.5 * logdet;
+    const double h = block_reduce<C>(e, 0, bk.w.red) + 0.5 * logdet;
     if (tid == 0) A.out[chain] = ok ? h : nan;
   } else if constexpr (OP == 1) {
-    ok = bk.template sweep<false, false>(nullptr, nullptr) && ok;
+    ok = bk.template invert<false>(nullptr) && ok;
     const double u = bk.matvec(p);
     if (act) A.out[chain * dim + tid] = ok ? u : nan;
   } else {
-    if (tid < 288) bk.w.aux[tid] = act ? A.z[chain * dim + tid] : 0.0;
+    if (tid < C::VL) bk.w.aux[tid] = act ? A.z[chain * dim + tid] : 0.0;
     __syncthreads();
     double y;
     ok = bk.template sweep<false, true>(nullptr, &y) && ok;
@@ -381,53 +574,91 @@ ImplicitArgs make_args(const mm_model* m, mm_state* s) {
   a.dim = s->dim;
   a.target = m->target;
   a.tparams = m->d_target_params;
-  a.rparams = m->d_rmetric_padded;  // zero-padded to 279 x 279 for the rank-one metric
+  a.rparams = m->d_rmetric_padded;  // rank-one base matrix zero-padded to C::DP x C::DP
   return a;
 }
 
-template <class K>
+template <class C, class K>
 int launch(mm_ctx* ctx, K kernel, const ImplicitArgs& a) {
-  const size_t lds = kLdsDoubles * sizeof(double);
+  const size_t lds = C::LDS_DOUBLES * sizeof(double);
   MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)a.n_chains), dim3(NT), lds, ctx->stream, a);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)a.n_chains), dim3(C::NT), lds, ctx->stream, a);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }
 
+template <class C>
+int launch_step(mm_ctx* ctx, const mm_model* m, const ImplicitArgs& a) {
+  if (m->rmetric == MM_RMETRIC_RANK1) return launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_RANK1>, a);
+  return launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_DIAGQUAD>, a);
+}
+
+template <class C>
+int launch_aux(mm_ctx* ctx, const mm_model* m, const ImplicitArgs& a, int op) {
+  const bool r1 = m->rmetric == MM_RMETRIC_RANK1;
+  if (op == 0)
+    return r1 ? launch<C>(ctx, riemann_aux_team_kernel<C, MM_RMETRIC_RANK1, 0>, a)
+              : launch<C>(ctx, riemann_aux_team_kernel<C, MM_RMETRIC_DIAGQUAD, 0>, a);
+  if (op == 1)
+    return r1 ? launch<C>(ctx, riemann_aux_team_kernel<C, MM_RMETRIC_RANK1, 1>, a)
+              : launch<C>(ctx, riemann_aux_team_kernel<C, MM_RMETRIC_DIAGQUAD, 1>, a);
+  return r1 ? launch<C>(ctx, riemann_aux_team_kernel<C, MM_RMETRIC_RANK1, 2>, a)
+            : launch<C>(ctx, riemann_aux_team_kernel<C, MM_RMETRIC_DIAGQUAD, 2>, a);
+}
+
+bool check_team_model(mm_ctx* ctx, const mm_model* m) {
+  if (m->dim > CfgLarge::DP) {
+    mm_set_error(ctx, "dense-Riemannian kernels support dim <= 279 (register-resident metric)");
+    return false;
+  }
+  const int want = mm_team_padded_dim(m->dim);
+  if (m->rmetric == MM_RMETRIC_RANK1 && (m->d_rmetric_padded == nullptr || m->rmetric_pad_dim != want)) {
+    mm_set_error(ctx, "internal: rank-one base matrix was not padded for the team kernels");
+    return false;
+  }
+  return true;
+}
+
 }  // namespace
+
+namespace {
+// 0: CfgMid, 1: CfgSmall, 2: CfgLarge.  MICI_AMD_TEAM=22 selects the 4-wave geometry where it applies
+// (D <= 66); it and the 2-wave one lose to the wave-per-chain kernel at D <= 64 (tools/sweep_chains.sh).
+int team_variant(int dim) {
+  static const bool want_mid = [] {
+    const char* e = getenv("MICI_AMD_TEAM");
+    return e && atoi(e) == 22;
+  }();
+  if (dim <= CfgMid::DP && want_mid) return 0;
+  return dim <= CfgSmall::DP ? 1 : 2;
+}
+}  // namespace
+
+// leading dimension of the zero-padded base matrix the team kernels read (mm_model_create pads to it)
+int mm_team_padded_dim(int dim) {
+  const int v = team_variant(dim);
+  return v == 0 ? CfgMid::DP : v == 1 ? CfgSmall::DP : CfgLarge::DP;
+}
 
 int mm_launch_implicit_large(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
                              const mm_fp_opts& opts, mm_counters* d_counters) {
-  if (m->dim > DP) {
-    mm_set_error(ctx, "dense-Riemannian kernels support dim <= 279 (register-resident metric)");
-    return MM_ERR_UNSUPPORTED;
-  }
+  if (!check_team_model(ctx, m)) return MM_ERR_UNSUPPORTED;
   ImplicitArgs a = make_args(m, s);
   a.step_size = h;
   a.n_steps = n_steps;
   a.opts = opts;
   a.counters = d_counters;
-  if (m->rmetric == MM_RMETRIC_RANK1) return launch(ctx, implicit_large_kernel<MM_RMETRIC_RANK1>, a);
-  return launch(ctx, implicit_large_kernel<MM_RMETRIC_DIAGQUAD>, a);
+  const int v = team_variant(m->dim);
+  return v == 0 ? launch_step<CfgMid>(ctx, m, a) : v == 1 ? launch_step<CfgSmall>(ctx, m, a) : launch_step<CfgLarge>(ctx, m, a);
 }
 
 int mm_launch_riemann_aux_large(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* d_out,
                                 const double* d_z) {
-  if (m->dim > DP) {
-    mm_set_error(ctx, "dense-Riemannian kernels support dim <= 279 (register-resident metric)");
-    return MM_ERR_UNSUPPORTED;
-  }
+  if (!check_team_model(ctx, m)) return MM_ERR_UNSUPPORTED;
   ImplicitArgs a = make_args(m, s);
   a.out = d_out;
   a.z = d_z;
-  const bool r1 = m->rmetric == MM_RMETRIC_RANK1;
-  if (op == 0)
-    return r1 ? launch(ctx, riemann_aux_large_kernel<MM_RMETRIC_RANK1, 0>, a)
-              : launch(ctx, riemann_aux_large_kernel<MM_RMETRIC_DIAGQUAD, 0>, a);
-  if (op == 1)
-    return r1 ? launch(ctx, riemann_aux_large_kernel<MM_RMETRIC_RANK1, 1>, a)
-              : launch(ctx, riemann_aux_large_kernel<MM_RMETRIC_DIAGQUAD, 1>, a);
-  return r1 ? launch(ctx, riemann_aux_large_kernel<MM_RMETRIC_RANK1, 2>, a)
-            : launch(ctx, riemann_aux_large_kernel<MM_RMETRIC_DIAGQUAD, 2>, a);
+  const int v = team_variant(m->dim);
+  return v == 0 ? launch_aux<CfgMid>(ctx, m, a, op) : v == 1 ? launch_aux<CfgSmall>(ctx, m, a, op) : launch_aux<CfgLarge>(ctx, m, a, op);
 }

@@ -235,9 +235,10 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
   int rc = upload(ctx, d->target_params, need_t, &m->d_target_params);
   if (rc == MM_OK) rc = upload(ctx, d->rmetric_params, need_r, &m->d_rmetric_params);
   if (rc == MM_OK) rc = upload(ctx, d->constr_params, need_c, &m->d_constr_params);
-  if (rc == MM_OK && d->rmetric == MM_RMETRIC_RANK1 && D > 64 && D <= 279) {
-    // workgroup-per-chain kernels read the base matrix through a fixed 279-wide zero-padded image
-    const int DP = 279;
+  if (rc == MM_OK && d->rmetric == MM_RMETRIC_RANK1 && D > 32 && D <= 279) {
+    // team-per-chain kernels read the base matrix through a zero-padded image of their tile geometry
+    const int DP = mm_team_padded_dim(D);
+    m->rmetric_pad_dim = DP;
     std::vector<double> pad((size_t)DP * DP, 0.0);
     for (int i = 0; i < D; ++i)
       for (int j = 0; j < D; ++j) pad[(size_t)i * DP + j] = d->rmetric_params[(size_t)i * D + j];

@@ -32,7 +32,8 @@ struct mm_model {
   double* d_metric_inv = nullptr;   // diag: 1/diag [D]; dense: explicit inverse [D*D]
   double* d_metric_chol = nullptr;  // diag: sqrt(diag) [D]; dense: lower Cholesky factor [D*D]
   double* d_rmetric_params = nullptr;
-  double* d_rmetric_padded = nullptr;  // rank-one base matrix zero-padded to 279 x 279 (dim > 64)
+  double* d_rmetric_padded = nullptr;  // rank-one base matrix zero-padded for the team kernels (dim > 32)
+  int rmetric_pad_dim = 0;             // its leading dimension (mm_team_padded_dim)
   size_t n_rmetric_params = 0;
   double* d_constr_params = nullptr;
   size_t n_constr_params = 0;
@@ -86,3 +87,4 @@ int mm_launch_constrained_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, 
 int mm_launch_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_h);
 int mm_launch_dh_dmom(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_out);
 int mm_launch_sample_momentum(mm_ctx* ctx, const mm_model* m, mm_state* s, const double* d_z);
+int mm_team_padded_dim(int dim);  // k_implicit_large.hip: leading dimension of the padded rank-one base matrix
