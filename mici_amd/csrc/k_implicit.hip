@@ -23,6 +23,7 @@
 // its own fixed-point solves, so data-dependent iteration counts and failures need no masking: a
 // failed chain's wave simply stops (status / n_done, chain frozen at its last good state).
 #include "implicit_core.h"
+#include <cstring>
 
 namespace {
 
@@ -576,16 +577,24 @@ int mm_launch_softabs_aux(mm_ctx*, const mm_model*, mm_state*, int, double*, con
 int mm_launch_implicit_large(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
                              mm_counters*);
 int mm_launch_riemann_aux_large(mm_ctx*, const mm_model*, mm_state*, int, double*, const double*);
+int mm_launch_implicit_mfma(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
 
 int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
                                 const mm_fp_opts& opts, mm_counters* d_counters) {
   if (m->rmetric == MM_RMETRIC_SOFTABS)
     return mm_launch_softabs_leapfrog(ctx, m, s, h, n_steps, opts, d_counters);
-  // D <= 64: one wave per chain; above that a team of waves shares the chain's metric
-  // (k_implicit_large.hip).  MICI_AMD_TEAM=15|22 routes 32 < D <= 64 to a team kernel (A/B measurements).
-  static const bool force_team = getenv("MICI_AMD_TEAM") != nullptr;
-  if (m->dim > 64 || (m->dim > 32 && force_team))
+  // D <= 32: one wave per chain, rank-1 sweep on the VALU (this file).  32 < D <= 64: one wave per chain,
+  // blocked sweep on the matrix cores (k_implicit_mfma.hip).  D > 64: a team of waves shares the chain's
+  // metric (k_implicit_large.hip).  MICI_AMD_IMPLICIT_KERNEL=wave|team overrides the 32 < D <= 64 choice
+  // (A/B measurements, tools/sweep_chains.sh).
+  static const int force = [] {
+    const char* e = getenv("MICI_AMD_IMPLICIT_KERNEL");
+    if (!e) return 0;
+    return strcmp(e, "wave") == 0 ? 1 : strcmp(e, "team") == 0 ? 2 : 0;
+  }();
+  if (m->dim > 64 || (m->dim > 32 && force == 2))
     return mm_launch_implicit_large(ctx, m, s, h, n_steps, opts, d_counters);
+  if (m->dim > 32 && force == 0) return mm_launch_implicit_mfma(ctx, m, s, h, n_steps, opts, d_counters);
   ImplicitArgs a = make_args(m, s);
   a.step_size = h;
   a.n_steps = n_steps;

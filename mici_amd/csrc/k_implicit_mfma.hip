@@ -1,0 +1,416 @@
+// Implicit leapfrog on dense-metric Riemannian systems, 32 < D <= 64, one wave per chain, with the
+// metric inverted by a BLOCKED symmetric sweep whose rank-4 updates run on the FP64 matrix cores
+// (v_mfma_f64_16x16x4_f64).  gfx950 / CDNA4.
+//
+// Why: at BASELINE c3 (1024 chains, D = 64) there is exactly one chain per SIMD.  A lone wave issues
+// about one VALU instruction per 6 cycles (tools/ubench_latency.hip), so the per-column cost of the
+// rank-1 sweep of k_implicit.hip (~105 instructions, 64 of them v_fma_f64) is an instruction-issue
+// bound, not a flop bound.  One v_mfma_f64_16x16x4 is ONE issue slot for 1024 fused multiply-adds,
+// so a rank-4 update of the whole matrix is 10 instructions instead of 256.
+//
+// Layout.  D is padded to 64 = 4 x 4 tiles of 16 x 16; only the 10 tiles on or below the diagonal are
+// stored, each in the MFMA accumulator layout: lane l = 16 g + j, register r holds entry
+// (16 I + 4 r + g, 16 J + j) of tile (I, J).  Consequently the four consecutive matrix rows
+// K = 16 I0 + 4 r0 + {0,1,2,3} are, for every tile of tile-row I0, exactly register r0 of all 64 lanes
+// -- which is precisely the B-operand layout (lane (k = g, n = j)) of the instruction.
+//
+// Blocked sweep (same algebra as BlockBackend::block_step in k_implicit_large.hip), per block K:
+//   (1) publish the panel Q = A[K, :] (4 x 64) to LDS as Qt[c][g]: tile-row I0 directly, the part right
+//       of the diagonal from the transposed tiles (I, I0), I > I0, by symmetry;
+//   (2) every lane inverts the 4 x 4 pivot block P redundantly (closed form through 2 x 2 Schur
+//       complements: two reciprocals instead of four), then lane c turns column c of the panel into
+//       column c of  W = P^-1 (Q - E),  E = identity on the K columns (this one modification yields both
+//       W_K = I - P^-1 and X_K = P - I of the uniform rank-4 form  A -= W^T X,  X = Q - E);
+//   (3) ten MFMAs: tile (I, J) += (-W)[:, tile I]^T  X[:, tile J];  then A_KK -= 2 I.
+// After 16 blocks the tiles hold -M^-1.
+//
+// Reference arithmetic replaced: DensePositiveDefiniteMatrix factorisation + explicit inverse
+// (matrices.py:1161-1188) inside ImplicitLeapfrogIntegrator._step (integrators.py:493-544); the step
+// logic itself is implicit_core.h (shared with the other backends).
+#include "implicit_core.h"
+
+namespace {
+
+using namespace mmdev;
+using namespace mmimp;
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWaves = 4;      // chains per workgroup
+constexpr int kTiles = 10;     // lower-triangular 16 x 16 tiles of a 64 x 64 matrix
+constexpr int kPartStride = 17;
+// per-wave LDS (doubles): Qt[64][4], Wt[64][4], nat[64], vperm[64], aux[64], part[64][17], mpart[3][64],
+// stash[SL_COUNT][64]
+constexpr int kMfmaWaveDoubles = 256 + 256 + 64 + 64 + 64 + 64 * kPartStride + 192 + SL_COUNT * 64;
+constexpr int kBaseDoubles = kTiles * 4 * 64;  // staged base matrix of the rank-one metric
+
+__host__ __device__ constexpr int tix(int I, int J) { return I * (I + 1) / 2 + J; }
+
+struct MLds {
+  double* qt;     // [64][4] panel, column-major in the block index
+  double* wt;     // [64][4] -W
+  double* nat;    // [64] natural-order vector
+  double* vperm;  // [4][4][4] = [I][g][r] copy of a vector for row operands
+  double* aux;    // [64]
+  double* part;   // [64][17] direct partial sums of the mat-vec
+  double* mpart;  // [3][4][16] mirrored partial sums
+  double* stash;  // [SL_COUNT][64]
+};
+
+template <int RMETRIC>
+struct MfmaBackend {
+  d4 acc[kTiles];
+  int dim, lane, target;
+  MLds w;
+  const double* base_lds;
+  const double* tparams;
+
+  __device__ __forceinline__ double& slot(int i) { return w.stash[i * 64 + lane]; }
+
+  // ---- metric_func(x) into the tiles; false if an entry is not finite ----------------------------
+  __device__ __forceinline__ bool build(double x) {
+    const int g = lane >> 4, j = lane & 15;
+    const double xm = (lane < dim) ? x : 0.0;
+    w.nat[lane] = xm;
+    w.vperm[(((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = xm;
+    wave_sync();
+    const double inv_d = 1.0 / (double)dim;
+    double qc[4];
+    d4 qr[4];
+#pragma unroll
+    for (int X = 0; X < 4; ++X) {
+      qc[X] = w.nat[16 * X + j];
+      qr[X] = *reinterpret_cast<const d4*>(w.vperm + ((X * 4 + g) << 2));
+    }
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J) {
+        const int t = tix(I, J);
+        if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+          const d2 b01 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 0) * 64 + lane) * 2);
+          const d2 b23 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 1) * 64 + lane) * 2);
+          const double qs = qc[J] * inv_d;
+          acc[t][0] = __builtin_fma(qr[I][0], qs, b01[0]);
+          acc[t][1] = __builtin_fma(qr[I][1], qs, b01[1]);
+          acc[t][2] = __builtin_fma(qr[I][2], qs, b23[0]);
+          acc[t][3] = __builtin_fma(qr[I][3], qs, b23[1]);
+        } else {
+          acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+      }
+    // diagonal entries: (16 I + 4 r + g, same) <-> tile (I, I), register r, lanes with j == 4 r + g
+    double chk = 0.0;
+#pragma unroll
+    for (int I = 0; I < 4; ++I) {
+      const int t = tix(I, I);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool on_diag = (j == 4 * r + g);
+        if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
+          const double qi = qr[I][r];
+          if (on_diag) acc[t][r] = __builtin_fma(qi, qi, 1.0);
+        }
+        if (on_diag && 16 * I + 4 * r + g >= dim) acc[t][r] = 1.0;  // identity on the padding
+        // "Array is not finite." (matrices.py:211-215).  Both built-in metrics have their largest
+        // entries on the diagonal (B_ii + q_i^2 / D with B_ii > 0; 1 + q_i^2), so a non-finite entry
+        // anywhere implies a non-finite diagonal-tile entry.
+        chk = __builtin_fma(acc[t][r], 0.0, chk);
+      }
+    }
+    wave_sync();
+    return __all(chk == 0.0);
+  }
+
+  // ---- one block of the sweep (I0, R0 compile-time after unrolling) ----------------------------------
+  __device__ __forceinline__ void block_step(const int I0, const int R0, bool& ok) {
+    const int g = lane >> 4, j = lane & 15;
+    const int k0 = 16 * I0 + 4 * R0;
+    // (1) publish rows K of the matrix as Qt[c][s] = A[k0 + s][c]
+#pragma unroll
+    for (int J = 0; J <= I0; ++J) w.qt[((16 * J + j) << 2) + g] = acc[tix(I0, J)][R0];
+    if ((j >> 2) == R0) {
+#pragma unroll
+      for (int I = I0 + 1; I < 4; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.qt[((16 * I + 4 * r + g) << 2) + (j & 3)] = acc[tix(I, I0)][r];
+    }
+    wave_sync();
+    // (2) P^-1 (uniform) and this lane's column of W
+    d4 wv;
+    {
+      const d4 c0 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 0) << 2));
+      const d4 c1 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 1) << 2));
+      const d4 c2 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 2) << 2));
+      const d4 c3 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 3) << 2));
+      // P = [A B; B^T C] with 2 x 2 blocks (P symmetric; use the lower triangle)
+      const double a = c0[0], b = c0[1], e = c1[1];                   // A = [a b; b e]
+      const double b00 = c0[2], b01 = c0[3], b10 = c1[2], b11 = c1[3];  // B = P[0:2, 2:4] (c_s is column s of P)
+      const double h = c2[2], i2 = c2[3], jj = c3[3];                 // C = [h i2; i2 jj]
+      const double det_a = __builtin_fma(a, e, -b * b);
+      const double ida = fast_rcp(det_a);
+      const double ia00 = e * ida, ia01 = -b * ida, ia11 = a * ida;  // A^-1
+      // T = A^-1 B
+      const double t00 = __builtin_fma(ia00, b00, ia01 * b10), t01 = __builtin_fma(ia00, b01, ia01 * b11);
+      const double t10 = __builtin_fma(ia01, b00, ia11 * b10), t11 = __builtin_fma(ia01, b01, ia11 * b11);
+      // S = C - B^T T
+      const double s00 = h - __builtin_fma(b00, t00, b10 * t10);
+      const double s01 = i2 - __builtin_fma(b00, t01, b10 * t11);
+      const double s11 = jj - __builtin_fma(b01, t01, b11 * t11);
+      const double det_s = __builtin_fma(s00, s11, -s01 * s01);
+      const double ids = fast_rcp(det_s);
+      const double is00 = s11 * ids, is01 = -s01 * ids, is11 = s00 * ids;  // S^-1
+      // pivots of the sequential elimination: a, det_a / a, s00, det_s / s00  (all must be > 0)
+      ok = ok && (a > 0.0) && (det_a > 0.0) && (s00 > 0.0) && (det_s > 0.0);
+      // U = T S^-1;  P^-1 = [A^-1 + U T^T, -U; -U^T, S^-1]
+      const double u00 = __builtin_fma(t00, is00, t01 * is01), u01 = __builtin_fma(t00, is01, t01 * is11);
+      const double u10 = __builtin_fma(t10, is00, t11 * is01), u11 = __builtin_fma(t10, is01, t11 * is11);
+      const double p00 = ia00 + __builtin_fma(u00, t00, u01 * t01);
+      const double p01 = ia01 + __builtin_fma(u00, t10, u01 * t11);
+      const double p11 = ia11 + __builtin_fma(u10, t10, u11 * t11);
+      // this lane's column of the panel, minus the identity on the block's own columns
+      d4 q = *reinterpret_cast<const d4*>(w.qt + (lane << 2));
+      const int s = lane - k0;
+      const bool in_k = (s >= 0) && (s < 4);
+      q[0] -= (s == 0) ? 1.0 : 0.0;
+      q[1] -= (s == 1) ? 1.0 : 0.0;
+      q[2] -= (s == 2) ? 1.0 : 0.0;
+      q[3] -= (s == 3) ? 1.0 : 0.0;
+      if (in_k) *reinterpret_cast<d4*>(w.qt + (lane << 2)) = q;
+      // -W[:, c] = -P^-1 q
+      wv[0] = -(__builtin_fma(p00, q[0], p01 * q[1]) - __builtin_fma(u00, q[2], u01 * q[3]));
+      wv[1] = -(__builtin_fma(p01, q[0], p11 * q[1]) - __builtin_fma(u10, q[2], u11 * q[3]));
+      wv[2] = __builtin_fma(u00, q[0], u10 * q[1]) - __builtin_fma(is00, q[2], is01 * q[3]);
+      wv[3] = __builtin_fma(u01, q[0], u11 * q[1]) - __builtin_fma(is01, q[2], is11 * q[3]);
+    }
+    *reinterpret_cast<d4*>(w.wt + (lane << 2)) = wv;
+    wave_sync();
+    // (3) rank-4 update on the matrix cores
+    double av[4], bv[4];
+#pragma unroll
+    for (int X = 0; X < 4; ++X) {
+      av[X] = w.wt[((16 * X + j) << 2) + g];
+      bv[X] = w.qt[((16 * X + j) << 2) + g];
+    }
+    // tiles that feed the next blocks' panels first (tile row I0 and tile column I0)
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J)
+        acc[tix(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], bv[J], acc[tix(I, J)], 0, 0, 0);
+    if (j == 4 * R0 + g) acc[tix(I0, I0)][R0] -= 2.0;
+    wave_sync();  // the next block overwrites Qt / Wt
+  }
+
+  __device__ __forceinline__ bool sweep() {
+    bool ok = true;
+#pragma unroll
+    for (int I0 = 0; I0 < 4; ++I0)
+#pragma unroll
+      for (int R0 = 0; R0 < 4; ++R0) block_step(I0, R0, ok);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) acc[t] = -acc[t];
+    return ok;
+  }
+
+  __device__ __forceinline__ bool build_and_invert(double x) {
+    bool ok = build(x);
+    ok = sweep() && ok;
+    return ok;
+  }
+  __device__ __forceinline__ bool build_and_solve(double x, double rhs, double* u) {
+    const bool ok = build_and_invert(x);
+    *u = matvec(rhs);
+    return ok;
+  }
+
+  // ---- y = T v for the symmetric matrix held as lower tiles -------------------------------------------
+  __device__ __forceinline__ double matvec(double v) {
+    const int g = lane >> 4, j = lane & 15;
+    w.nat[lane] = (lane < dim) ? v : 0.0;
+    w.vperm[(((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = (lane < dim) ? v : 0.0;
+    wave_sync();
+    double vc[4];
+    d4 vr[4];
+#pragma unroll
+    for (int X = 0; X < 4; ++X) {
+      vc[X] = w.nat[16 * X + j];
+      vr[X] = *reinterpret_cast<const d4*>(w.vperm + ((X * 4 + g) << 2));
+    }
+    // direct: rows of tile-row I, summed over this lane's column j of tiles J <= I
+#pragma unroll
+    for (int I = 0; I < 4; ++I) {
+      d4 s = acc[tix(I, 0)] * vc[0];
+#pragma unroll
+      for (int J = 1; J <= I; ++J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = __builtin_fma(acc[tix(I, J)][r], vc[J], s[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w.part[(16 * I + 4 * r + g) * kPartStride + j] = s[r];
+    }
+    // mirrored: column 16 J + j of the tiles (I, J), I > J, against the row operand
+#pragma unroll
+    for (int J = 0; J < 3; ++J) {
+      double s = 0.0;
+#pragma unroll
+      for (int I = J + 1; I < 4; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s = __builtin_fma(acc[tix(I, J)][r], vr[I][r], s);
+      w.mpart[(J * 4 + g) * 16 + j] = s;
+    }
+    wave_sync();
+    double y = 0.0;
+    {
+      const double* src = w.part + lane * kPartStride;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) y += src[k];
+      if (lane < 48) {
+        const double* m = w.mpart + (lane >> 4) * 64 + (lane & 15);
+        y += (m[0] + m[16]) + (m[32] + m[48]);
+      }
+    }
+    wave_sync();
+    return lane < dim ? y : 0.0;
+  }
+
+  __device__ __forceinline__ double diag() {
+    const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (j == 4 * r + g) w.nat[16 * I + 4 * r + g] = acc[tix(I, I)][r];
+    wave_sync();
+    const double y = (lane < dim) ? w.nat[lane] : 0.0;
+    wave_sync();
+    return y;
+  }
+
+  // 0.5 * vjp_metric(M^-1): rank-one metric M^-1 q / D; diag-quad metric q_i (M^-1)_ii
+  __device__ __forceinline__ double half_vjp_inv(double q) {
+    if constexpr (RMETRIC == MM_RMETRIC_RANK1) return matvec(q) / (double)dim;
+    else return q * diag();
+  }
+  // dense metric: grad_quadratic_form_inv(p) = -(M^-1 p)(M^-1 p)^T   (matrices.py:1179-1181)
+  __device__ __forceinline__ double dh2_dpos(double p, double q) {
+    const double u = matvec(p);
+    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+      const double uq = wave_sum(lane < dim ? u * q : 0.0);
+      return -(u * uq) / (double)dim;
+    } else {
+      return -q * (u * u);
+    }
+  }
+  __device__ __forceinline__ double norm(double x, int kind) {
+    const double a = wave_norm_accum(0.0, lane < dim ? x : 0.0, kind);
+    return wave_norm_finish(a, kind);
+  }
+  __device__ __forceinline__ double grad(double q) {
+    w.nat[lane] = (lane < dim) ? q : 0.0;
+    wave_sync();
+    const TargetAux aux = target_prepare<false>(target, w.nat, dim, tparams, lane);
+    const double gr = (lane < dim) ? target_grad_elem<false>(target, aux, w.nat, lane, dim, tparams) : 0.0;
+    wave_sync();
+    return gr;
+  }
+};
+
+template <int RMETRIC>
+__global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* base_lds = lds;
+  const int base_elems = (RMETRIC == MM_RMETRIC_RANK1) ? kBaseDoubles : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dim = A.dim;
+  if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+    // base_lds[((t*2 + h)*64 + lane)*2 + e] = B[16 I + 4 (2h + e) + g][16 J + j], zero outside dim x dim
+    for (int idx = threadIdx.x; idx < kBaseDoubles; idx += blockDim.x) {
+      const int e = idx & 1, l = (idx >> 1) & 63, th = idx >> 7, h = th & 1, t = th >> 1;
+      int I = 0;
+      while (tix(I + 1, 0) <= t) ++I;
+      const int J = t - tix(I, 0);
+      const int row = 16 * I + 4 * (2 * h + e) + (l >> 4), col = 16 * J + (l & 15);
+      base_lds[idx] = (row < dim && col < dim) ? A.rparams[(int64_t)row * dim + col] : 0.0;
+    }
+  }
+  __syncthreads();
+  const int64_t chain = (int64_t)blockIdx.x * kWaves + wave;
+  if (chain >= A.n_chains) return;  // no block-level barrier below this point
+  double* wl = lds + base_elems + wave * kMfmaWaveDoubles;
+  const bool act = lane < dim;
+  double q = act ? A.pos[chain * dim + lane] : 0.0;
+  double p = act ? A.mom[chain * dim + lane] : 0.0;
+  const double t = (double)A.dir[chain] * A.step_size;
+
+  MfmaBackend<RMETRIC> bk;
+  bk.dim = dim;
+  bk.lane = lane;
+  bk.target = A.target;
+  bk.w.qt = wl;
+  bk.w.wt = wl + 256;
+  bk.w.nat = wl + 512;
+  bk.w.vperm = wl + 576;
+  bk.w.aux = wl + 640;
+  bk.w.part = wl + 704;
+  bk.w.mpart = bk.w.part + 64 * kPartStride;
+  bk.w.stash = bk.w.mpart + 192;
+  bk.base_lds = base_lds;
+  bk.tparams = A.tparams;
+  bk.slot(SL_Q) = q;
+  bk.slot(SL_P) = p;
+  const ChainResult r = implicit_leapfrog_chain(bk, t, A.n_steps, A.opts);
+  q = bk.slot(SL_Q);
+  p = bk.slot(SL_P);
+  if (act) {
+    A.pos[chain * dim + lane] = q;
+    A.mom[chain * dim + lane] = p;
+  }
+  if (lane == 0) {
+    A.status[chain] = r.status;
+    A.n_done[chain] = r.done;
+    add_counters(A.counters, r);
+  }
+}
+
+}  // namespace
+
+int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                            const mm_fp_opts& opts, mm_counters* d_counters) {
+  if (m->dim > 64) {
+    mm_set_error(ctx, "matrix-core dense-Riemannian kernel supports dim <= 64");
+    return MM_ERR_UNSUPPORTED;
+  }
+  ImplicitArgs a{};
+  a.pos = s->d_pos;
+  a.mom = s->d_mom;
+  a.dir = s->d_dir;
+  a.status = s->d_status;
+  a.n_done = s->d_n_done;
+  a.n_chains = s->n;
+  a.dim = s->dim;
+  a.target = m->target;
+  a.tparams = m->d_target_params;
+  a.rparams = m->d_rmetric_params;
+  a.step_size = h;
+  a.n_steps = n_steps;
+  a.opts = opts;
+  a.counters = d_counters;
+  const unsigned blocks = (unsigned)((s->n + kWaves - 1) / kWaves);
+  const bool r1 = m->rmetric == MM_RMETRIC_RANK1;
+  const size_t lds = ((r1 ? kBaseDoubles : 0) + kWaves * kMfmaWaveDoubles) * sizeof(double);
+  if (r1) {
+    MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(implicit_mfma_kernel<MM_RMETRIC_RANK1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((implicit_mfma_kernel<MM_RMETRIC_RANK1>), dim3(blocks), dim3(64 * kWaves), lds,
+                       ctx->stream, a);
+  } else {
+    MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(implicit_mfma_kernel<MM_RMETRIC_DIAGQUAD>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((implicit_mfma_kernel<MM_RMETRIC_DIAGQUAD>), dim3(blocks), dim3(64 * kWaves), lds,
+                       ctx->stream, a);
+  }
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
