@@ -24,6 +24,14 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          "-Wno-unused-function", "-ffp-contract=on"]
 
 
+# per-file code-generation switches
+EXTRA_FLAGS = {
+    # keep the MFMA accumulators (= the metric tiles) in architected VGPRs: the sweep reads them back every
+    # block, and from AGPRs that is one v_accvgpr_read per dword
+    "k_implicit_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+}
+
+
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -54,7 +62,7 @@ def build(force=False, jobs=None, verbose=True):
 
     def compile_one(pair):
         src, obj = pair
-        cmd = [cc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r.returncode, r.stdout + r.stderr
 

@@ -123,31 +123,57 @@ struct MfmaBackend {
     return __all(chk == 0.0);
   }
 
-  // ---- one block of the sweep (I0, R0 compile-time after unrolling) ----------------------------------
-  __device__ __forceinline__ void block_step(const int I0, const int R0, bool& ok) {
+  // operands of one block's rank-4 update.  They stay in registers after the block so that the six
+  // "cold" tiles (those the NEXT block's panel does not read) are updated while the next block's scalar
+  // work (P^-1, W) is being issued: the matrix core runs asynchronously to the VALU.
+  struct Ops {
+    double av[4], bv[4];
+  };
+
+  // update the tiles of tile-row/column `in` (hot == true) or all the others (hot == false); in < 0: all
+  __device__ __forceinline__ void apply(const Ops& o, const int in, const bool hot) {
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J) {
+        const bool is_hot = (I == in) || (J == in);
+        if (in < 0 || is_hot == hot)
+          acc[tix(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.av[I], o.bv[J], acc[tix(I, J)], 0, 0, 0);
+      }
+  }
+
+  // ---- one block of the sweep (B compile-time after unrolling) ----------------------------------------
+  __device__ __forceinline__ void block_step(const int B, Ops& ops, bool& ok) {
+    const int I0 = B >> 2, R0 = B & 3;
     const int g = lane >> 4, j = lane & 15;
     const int k0 = 16 * I0 + 4 * R0;
-    // (1) publish rows K of the matrix as Qt[c][s] = A[k0 + s][c]
+    // (1) publish rows K of the matrix as Qt[c][s] = A[k0 + s][c].  The transposed part comes from the 16
+    // lanes holding columns K of the tiles below the diagonal tile; the other lanes store into the (dead)
+    // W buffer instead of branching, which keeps the whole sweep one basic block for the scheduler.
 #pragma unroll
     for (int J = 0; J <= I0; ++J) w.qt[((16 * J + j) << 2) + g] = acc[tix(I0, J)][R0];
-    if ((j >> 2) == R0) {
+    {
+      double* dst = ((j >> 2) == R0) ? w.qt + (g << 2) + (j & 3) : w.wt + j;
 #pragma unroll
       for (int I = I0 + 1; I < 4; ++I)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w.qt[((16 * I + 4 * r + g) << 2) + (j & 3)] = acc[tix(I, I0)][r];
+        for (int r = 0; r < 4; ++r) dst[(16 * I + 4 * r) << 2] = acc[tix(I, I0)][r];
     }
     wave_sync();
     // (2) P^-1 (uniform) and this lane's column of W
+    const d4 c0 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 0) << 2));
+    const d4 c1 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 1) << 2));
+    const d4 c2 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 2) << 2));
+    const d4 c3 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 3) << 2));
+    d4 q = *reinterpret_cast<const d4*>(w.qt + (lane << 2));
+    // the previous block's cold tiles: independent of everything below until this block's own update
+    if (B > 0) apply(ops, I0, false);
     d4 wv;
     {
-      const d4 c0 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 0) << 2));
-      const d4 c1 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 1) << 2));
-      const d4 c2 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 2) << 2));
-      const d4 c3 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 3) << 2));
-      // P = [A B; B^T C] with 2 x 2 blocks (P symmetric; use the lower triangle)
-      const double a = c0[0], b = c0[1], e = c1[1];                   // A = [a b; b e]
-      const double b00 = c0[2], b01 = c0[3], b10 = c1[2], b11 = c1[3];  // B = P[0:2, 2:4] (c_s is column s of P)
-      const double h = c2[2], i2 = c2[3], jj = c3[3];                 // C = [h i2; i2 jj]
+      // P = [A B; B^T C] with 2 x 2 blocks; c_s is column s of P
+      const double a = c0[0], b = c0[1], e = c1[1];                    // A = [a b; b e]
+      const double b00 = c0[2], b01 = c0[3], b10 = c1[2], b11 = c1[3];  // B = P[0:2, 2:4]
+      const double h = c2[2], i2 = c2[3], jj = c3[3];                  // C = [h i2; i2 jj]
       const double det_a = __builtin_fma(a, e, -b * b);
       const double ida = fast_rcp(det_a);
       const double ia00 = e * ida, ia01 = -b * ida, ia11 = a * ida;  // A^-1
@@ -170,45 +196,46 @@ struct MfmaBackend {
       const double p01 = ia01 + __builtin_fma(u00, t10, u01 * t11);
       const double p11 = ia11 + __builtin_fma(u10, t10, u11 * t11);
       // this lane's column of the panel, minus the identity on the block's own columns
-      d4 q = *reinterpret_cast<const d4*>(w.qt + (lane << 2));
       const int s = lane - k0;
-      const bool in_k = (s >= 0) && (s < 4);
       q[0] -= (s == 0) ? 1.0 : 0.0;
       q[1] -= (s == 1) ? 1.0 : 0.0;
       q[2] -= (s == 2) ? 1.0 : 0.0;
       q[3] -= (s == 3) ? 1.0 : 0.0;
-      if (in_k) *reinterpret_cast<d4*>(w.qt + (lane << 2)) = q;
       // -W[:, c] = -P^-1 q
       wv[0] = -(__builtin_fma(p00, q[0], p01 * q[1]) - __builtin_fma(u00, q[2], u01 * q[3]));
       wv[1] = -(__builtin_fma(p01, q[0], p11 * q[1]) - __builtin_fma(u10, q[2], u11 * q[3]));
       wv[2] = __builtin_fma(u00, q[0], u10 * q[1]) - __builtin_fma(is00, q[2], is01 * q[3]);
       wv[3] = __builtin_fma(u01, q[0], u11 * q[1]) - __builtin_fma(is01, q[2], is11 * q[3]);
     }
+    *reinterpret_cast<d4*>(w.qt + (lane << 2)) = q;  // only the block's own four columns changed
     *reinterpret_cast<d4*>(w.wt + (lane << 2)) = wv;
+    if (B > 0) {
+      // scheduling pipeline for this region: one cold MFMA per ~15 VALU instructions (an MFMA occupies the
+      // matrix core for 64 cycles, a lone wave issues a VALU instruction about every 6)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 15, 0);
+      }
+    }
     wave_sync();
-    // (3) rank-4 update on the matrix cores
-    double av[4], bv[4];
+    // (3) rank-4 update on the matrix cores: now only the tiles the next block's panel reads
 #pragma unroll
     for (int X = 0; X < 4; ++X) {
-      av[X] = w.wt[((16 * X + j) << 2) + g];
-      bv[X] = w.qt[((16 * X + j) << 2) + g];
+      ops.av[X] = w.wt[((16 * X + j) << 2) + g];
+      ops.bv[X] = w.qt[((16 * X + j) << 2) + g];
     }
-    // tiles that feed the next blocks' panels first (tile row I0 and tile column I0)
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-#pragma unroll
-      for (int J = 0; J <= I; ++J)
-        acc[tix(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], bv[J], acc[tix(I, J)], 0, 0, 0);
+    if (B < 15) apply(ops, (B + 1) >> 2, true);
+    else apply(ops, -1, true);
     if (j == 4 * R0 + g) acc[tix(I0, I0)][R0] -= 2.0;
     wave_sync();  // the next block overwrites Qt / Wt
   }
 
   __device__ __forceinline__ bool sweep() {
     bool ok = true;
+    Ops ops;
 #pragma unroll
-    for (int I0 = 0; I0 < 4; ++I0)
-#pragma unroll
-      for (int R0 = 0; R0 < 4; ++R0) block_step(I0, R0, ok);
+    for (int B = 0; B < 16; ++B) block_step(B, ops, ok);
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) acc[t] = -acc[t];
     return ok;
@@ -374,6 +401,69 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs
   }
 }
 
+
+// ---- developer profile (not part of the ABI header; tools/ubench_primitives.py): shader-clock cycles of
+// the backend's primitives, measured in-kernel with s_memtime on every wave, chain 0 reported
+__global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs A, int repeats, double* out) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* base_lds = lds;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dim = A.dim;
+  for (int idx = threadIdx.x; idx < kBaseDoubles; idx += blockDim.x) {
+    const int e = idx & 1, l = (idx >> 1) & 63, th = idx >> 7, h = th & 1, t = th >> 1;
+    int I = 0;
+    while (tix(I + 1, 0) <= t) ++I;
+    const int J = t - tix(I, 0);
+    const int row = 16 * I + 4 * (2 * h + e) + (l >> 4), col = 16 * J + (l & 15);
+    base_lds[idx] = (row < dim && col < dim) ? A.rparams[(int64_t)row * dim + col] : 0.0;
+  }
+  __syncthreads();
+  const int64_t chain = (int64_t)blockIdx.x * kWaves + wave;
+  if (chain >= A.n_chains) return;
+  double* wl = lds + kBaseDoubles + wave * kMfmaWaveDoubles;
+  MfmaBackend<MM_RMETRIC_RANK1> bk;
+  bk.dim = dim;
+  bk.lane = lane;
+  bk.target = A.target;
+  bk.w.qt = wl;
+  bk.w.wt = wl + 256;
+  bk.w.nat = wl + 512;
+  bk.w.vperm = wl + 576;
+  bk.w.aux = wl + 640;
+  bk.w.part = wl + 704;
+  bk.w.mpart = bk.w.part + 64 * kPartStride;
+  bk.w.stash = bk.w.mpart + 192;
+  bk.base_lds = base_lds;
+  bk.tparams = A.tparams;
+  double q = lane < dim ? A.pos[chain * dim + lane] : 0.0;
+  double p = lane < dim ? A.mom[chain * dim + lane] : 0.0;
+  long long c[5] = {0, 0, 0, 0, 0};
+  double sink = 0.0;
+  for (int r = 0; r < repeats; ++r) {
+    const long long t0 = __builtin_readcyclecounter();
+    bool ok = bk.build(q);
+    const long long t1 = __builtin_readcyclecounter();
+    ok = bk.sweep() && ok;
+    const long long t2 = __builtin_readcyclecounter();
+    const double u = bk.matvec(p);
+    const long long t3 = __builtin_readcyclecounter();
+    const double gq = bk.grad(q);
+    const long long t4 = __builtin_readcyclecounter();
+    const double nn = bk.norm(u, MM_NORM_LINF);
+    const long long t5 = __builtin_readcyclecounter();
+    c[0] += t1 - t0;
+    c[1] += t2 - t1;
+    c[2] += t3 - t2;
+    c[3] += t4 - t3;
+    c[4] += t5 - t4;
+    sink += u + gq + nn + (ok ? 0.0 : 1.0);
+    q += 1e-12 * sink;
+  }
+  if (chain == 0 && lane == 0)
+    for (int i = 0; i < 5; ++i) out[i] = (double)c[i] / repeats;
+  if (lane == 0) out[8 + chain] = sink;
+}
+
 }  // namespace
 
 int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
@@ -412,5 +502,29 @@ int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
                        ctx->stream, a);
   }
   MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
+// developer hook: cycles of {build, sweep, mat-vec, grad, norm} into out[0..4]
+extern "C" int mm_debug_mfma_profile(mm_ctx* ctx, const mm_model* m, mm_state* s, int repeats, double* out) {
+  if (!ctx || !m || !s || m->dim > 64 || m->rmetric != MM_RMETRIC_RANK1) return MM_ERR_INVALID;
+  ImplicitArgs a{};
+  a.pos = s->d_pos;
+  a.mom = s->d_mom;
+  a.n_chains = s->n;
+  a.dim = s->dim;
+  a.target = m->target;
+  a.tparams = m->d_target_params;
+  a.rparams = m->d_rmetric_params;
+  double* d_out = nullptr;
+  MM_HIP_CHECK(ctx, hipMalloc(&d_out, (8 + s->n) * sizeof(double)));
+  const unsigned blocks = (unsigned)((s->n + kWaves - 1) / kWaves);
+  const size_t lds = (kBaseDoubles + kWaves * kMfmaWaveDoubles) * sizeof(double);
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_profile_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(mfma_profile_kernel, dim3(blocks), dim3(64 * kWaves), lds, ctx->stream, a, repeats, d_out);
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d_out);
   return MM_OK;
 }

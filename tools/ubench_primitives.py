@@ -31,3 +31,16 @@ for n in (1024, 2048, 4096):
         us = ms.value * 1e3 / reps
         print(f"N={n:5d} {name:24s}: {us:8.2f} us per call per wave-slot  (~{us * 2250:9.0f} cycles @2.25GHz)")
     batch.close()
+
+# matrix-core backend (32 < D <= 64): in-kernel cycle counters per primitive
+lib.mm_debug_mfma_profile.restype = C.c_int
+lib.mm_debug_mfma_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+for n in (256, 1024, 4096):
+    batch = DeviceBatch(ctx, n, dim)
+    batch.upload(rng.standard_normal((n, dim)), rng.standard_normal((n, dim)), 1)
+    out = (C.c_double * 8)()
+    rc = lib.mm_debug_mfma_profile(ctx.handle, model.handle, batch.handle, 50, out)
+    assert rc == 0, rc
+    print(f"mfma backend N={n:5d}: build {out[0]:7.0f}  sweep {out[1]:7.0f}  matvec {out[2]:7.0f}  "
+          f"grad {out[3]:7.0f}  norm {out[4]:7.0f}  cycles")
+    batch.close()
