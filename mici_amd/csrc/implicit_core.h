@@ -158,9 +158,16 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
     // INIT / BADJ need the explicit inverse (applied ~12 times: momentum solves, both A half-steps, the
     // general-VJP path); the position-space iterations use their metric for a single solve.
     double u_pos = 0.0;
-    const bool okm = (mode == MODE_INIT || mode == MODE_BADJ)
-                         ? bk.build_and_invert(bk.slot(SL_XQ))
-                         : bk.build_and_solve(bk.slot(SL_XQ), bk.slot(SL_PW), &u_pos);
+    bool okm;
+    if constexpr (BK::kSolveByInverse) {
+      // one construction site (the blocked matrix-core sweeps are several thousand instructions)
+      okm = bk.build_and_invert(bk.slot(SL_XQ));
+      if (!(mode == MODE_INIT || mode == MODE_BADJ)) u_pos = bk.matvec(bk.slot(SL_PW));
+    } else {
+      okm = (mode == MODE_INIT || mode == MODE_BADJ)
+                ? bk.build_and_invert(bk.slot(SL_XQ))
+                : bk.build_and_solve(bk.slot(SL_XQ), bk.slot(SL_PW), &u_pos);
+    }
     r.n_metric += (mode == MODE_CFIRST) ? 2 : 1;
     if (!okm) {
       r.status = (mode == MODE_INIT || mode == MODE_BADJ) ? MM_ST_LINALG : MM_ST_SOLVER_LINALG;

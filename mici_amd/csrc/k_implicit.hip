@@ -325,6 +325,7 @@ __device__ __forceinline__ void stage_base(double* base_lds, const double* rpara
 // Backend of implicit_core.h for one wave per chain.
 template <int TS, int RMETRIC>
 struct WaveBackend {
+  static constexpr bool kSolveByInverse = false;  // implicit_core.h: solve = invert + mat-vec, one construction site
   double T[TS][TS];
   int dim, lane, target;
   WaveLds w;
@@ -578,6 +579,8 @@ int mm_launch_implicit_large(mm_ctx*, const mm_model*, mm_state*, double, int, c
                              mm_counters*);
 int mm_launch_riemann_aux_large(mm_ctx*, const mm_model*, mm_state*, int, double*, const double*);
 int mm_launch_implicit_mfma(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
+int mm_launch_implicit_mfma_team(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
+                                 mm_counters*);
 
 int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
                                 const mm_fp_opts& opts, mm_counters* d_counters) {
@@ -592,6 +595,10 @@ int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, dou
     if (!e) return 0;
     return strcmp(e, "wave") == 0 ? 1 : strcmp(e, "team") == 0 ? 2 : 0;
   }();
+  // 75 < D <= 256: team of 8 waves with the sweep on the matrix cores (k_implicit_mfma_team.hip);
+  // MICI_AMD_IMPLICIT_KERNEL=team keeps the VALU team kernel there as well
+  if (m->dim > 75 && m->dim <= 256 && force != 2)
+    return mm_launch_implicit_mfma_team(ctx, m, s, h, n_steps, opts, d_counters);
   if (m->dim > 64 || (m->dim > 32 && force == 2))
     return mm_launch_implicit_large(ctx, m, s, h, n_steps, opts, d_counters);
   if (m->dim > 32 && force == 0) return mm_launch_implicit_mfma(ctx, m, s, h, n_steps, opts, d_counters);

@@ -61,6 +61,7 @@ __device__ __forceinline__ double block_reduce4(double v, int kind_max, double* 
 }
 
 struct SoftAbsBackend {
+  static constexpr bool kSolveByInverse = false;  // implicit_core.h
   int dim, tid, target;
   double coeff;
   SaLds w;
