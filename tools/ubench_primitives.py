@@ -44,3 +44,4 @@ for n in (256, 1024, 4096):
     print(f"mfma backend N={n:5d}: build {out[0]:7.0f}  sweep {out[1]:7.0f}  matvec {out[2]:7.0f}  "
           f"grad {out[3]:7.0f}  norm {out[4]:7.0f}  cycles")
     batch.close()
+
