@@ -100,7 +100,11 @@ def test_single_state_step_raises_reference_exceptions():
 @pytest.mark.parametrize("dim,n,target_kind,metric_kind,h,steps", [
     (64, 1024, "banana", "rank1", 0.02, 4),    # BASELINE config c3(a) at full size
     (64, 64, "poly", "rank1", 0.05, 6),
-    (37, 21, "banana", "rank1", 0.02, 5),      # ragged: D not a multiple of 8
+    (37, 21, "banana", "rank1", 0.02, 5),      # ragged: D not a multiple of 8 / 16 (matrix-core wave kernel)
+    (33, 7, "poly", "rank1", 0.05, 4),         # smallest size of the matrix-core wave kernel
+    (48, 9, "poly", "diagquad", 0.1, 6),       # diag-quad metric on the matrix-core wave kernel
+    (63, 5, "banana", "rank1", 0.02, 3),
+    (32, 11, "banana", "rank1", 0.02, 4),      # largest size of the VALU wave kernel
     (13, 9, "poly", "diagquad", 0.1, 10),
     (3, 5, "poly", "rank1", 0.1, 10),
 ])
@@ -199,9 +203,11 @@ def test_softabs_full_size_matches_oracle():
     assert_close(qb, q0, 1e-6, "reversed q")
 
 
-@pytest.mark.parametrize("dim,n,steps", [(65, 3, 2), (100, 2, 2), (279, 1, 1)])
+@pytest.mark.parametrize("dim,n,steps", [(65, 3, 2), (75, 2, 2), (76, 2, 2), (100, 2, 2), (128, 2, 2),
+                                         (255, 1, 1), (256, 2, 1), (257, 1, 1), (279, 1, 1)])
 def test_large_kernel_boundaries_match_oracle(dim, n, steps):
-    """Workgroup-per-chain kernel at its smallest (65), a ragged (100) and its largest (279) dim."""
+    """Workgroup-per-chain kernels at their boundaries: VALU team 65..75, matrix-core team 76..256 (c4's
+    D = 256 included), VALU team 257..279."""
     rng = np.random.default_rng(dim)
     om = omdl.Rank1Metric(omdl.make_spd(dim, rng))
     ot = omdl.Banana(dim)
@@ -221,6 +227,39 @@ def test_large_kernel_boundaries_match_oracle(dim, n, steps):
         assert_close(p[c], po, 1e-10, f"p chain {c}")
         st = orc._State(q[c], p[c])
         assert_close(system.h_batch(q[c:c + 1], p[c:c + 1])[0], osys.h(st), 1e-10, "h")
+
+
+def test_diagquad_metric_on_the_team_kernels():
+    for dim in (70, 100):
+        rng = np.random.default_rng(dim)
+        ot, om = omdl.Poly(dim, 1.0, 1.0 / 3.0), omdl.DiagQuadMetric(dim)
+        osys = orc.RiemannianSystem(ot, om, None)
+        system = systems.DenseRiemannianMetricSystem(
+            models.target_from_id(ot.tid, ot.params(), dim), models.rmetric_from_id(om.mid, om.params(), dim))
+        integ = integrators.ImplicitLeapfrogIntegrator(system, 0.05)
+        q0 = rng.standard_normal((2, dim))
+        p0 = system.sample_momentum_batch(q0, rng.standard_normal((2, dim)))
+        q, p, status, _ = integ.step_batch(q0, p0, 1, n_steps=3)
+        assert np.all(status == 0)
+        for c in range(2):
+            qo, po, so, _ = orc.implicit_leapfrog_steps(osys, q0[c], p0[c], 0.05, 3)
+            assert so == 0
+            assert_close(q[c], qo, 1e-10, f"q chain {c}")
+            assert_close(p[c], po, 1e-10, f"p chain {c}")
+
+
+@pytest.mark.parametrize("kernel", ["wave", "team"])
+def test_alternative_kernels_selected_by_env(kernel):
+    """The non-default kernels for 32 < D <= 256 (VALU wave kernel, VALU team kernels) stay reachable through
+    MICI_AMD_IMPLICIT_KERNEL and must pass the same parity tests (the choice is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MICI_AMD_IMPLICIT_KERNEL=kernel)
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
+                        "matches_oracle and not env"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_unsupported_sizes_fail_loudly():
