@@ -184,6 +184,16 @@ int mm_state_device_ptrs(mm_state* state, double** pos, double** mom, int8_t** d
 int mm_leapfrog_euclid(mm_ctx* ctx, const mm_model* model, mm_state* state, double step_size,
                        int32_t n_steps);
 
+/* SymmetricCompositionIntegrator.step x n_steps on an EuclideanMetricSystem (integrators.py:176-274; the
+ * BCSS two/three/four-stage integrators :277-378 are instances): the FULL coefficient sequence
+ * coeffs[0..n_coeffs) (a_0, b_1, a_1, ..., a_S as built by integrators.py:258-268, n_coeffs odd,
+ * <= MM_MAX_COMPOSITION_COEFFS) alternates h1_flow(c t) (systems.py:143-152) and h2_flow(c t)
+ * (systems.py:362-363), starting with h1 iff initial_h1_flow_step != 0; t = dir * step_size. */
+#define MM_MAX_COMPOSITION_COEFFS 16
+int mm_composition_euclid(mm_ctx* ctx, const mm_model* model, mm_state* state, double step_size,
+                          int32_t n_steps, int32_t n_coeffs, const double* coeffs,
+                          int32_t initial_h1_flow_step);
+
 /* ImplicitLeapfrogIntegrator.step x n_steps on a Dense / SoftAbs RiemannianMetricSystem
  * (integrators.py:493-544; solvers.py:47-154; systems.py:1360-1402; matrices.py:1161-1188, 1631-1685).
  * opts == NULL selects the reference defaults. counters may be NULL. */

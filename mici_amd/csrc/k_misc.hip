@@ -67,6 +67,59 @@ __global__ void leapfrog_generic_kernel(EuclidModelView m, double* __restrict__ 
   }
 }
 
+// SymmetricCompositionIntegrator._step (integrators.py:272-274) on a Euclidean-metric system: the
+// coefficient sequence c[0..m) alternates h1_flow (mom -= c t grad) and h2_flow (pos += c t M^-1 mom),
+// starting with h1 iff initial_h1.  Same wave-per-chain layout as the generic leapfrog above; the
+// gradient is recomputed only after the position moved (the reference's state cache).
+struct CompCoefs {
+  int m, initial_h1;
+  double c[MM_MAX_COMPOSITION_COEFFS];
+};
+
+__global__ void composition_generic_kernel(EuclidModelView m, double* __restrict__ pos,
+                                           double* __restrict__ mom, const int8_t* __restrict__ dir,
+                                           int64_t n_chains, double step_size, int n_steps, CompCoefs cf) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dim = m.dim;
+  const int64_t chain = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (chain >= n_chains) return;  // whole wave exits together; no block-level barriers below
+  double* q = lds + (size_t)wave * 3 * dim;
+  double* p = q + dim;
+  double* g = p + dim;  // the cached gradient; doubles as scratch for M^-1 p during an h2 flow
+  for (int i = lane; i < dim; i += 64) {
+    q[i] = pos[chain * dim + i];
+    p[i] = mom[chain * dim + i];
+  }
+  const double t = (double)dir[chain] * step_size;
+  wave_sync();
+  TargetAux aux = target_prepare(m.target, q, dim, m.tparams, lane);
+  for (int i = lane; i < dim; i += 64) g[i] = target_grad_elem(m.target, aux, q, i, dim, m.tparams);
+  wave_sync();
+  for (int s = 0; s < n_steps; ++s) {
+    for (int k = 0; k < cf.m; ++k) {
+      const double ct = cf.c[k] * t;
+      if (((k & 1) == 0) == (cf.initial_h1 != 0)) {
+        for (int i = lane; i < dim; i += 64) p[i] -= ct * g[i];
+        wave_sync();
+      } else {
+        for (int i = lane; i < dim; i += 64) g[i] = minv_elem(m, p, i);
+        wave_sync();
+        for (int i = lane; i < dim; i += 64) q[i] += ct * g[i];
+        wave_sync();
+        aux = target_prepare(m.target, q, dim, m.tparams, lane);
+        for (int i = lane; i < dim; i += 64) g[i] = target_grad_elem(m.target, aux, q, i, dim, m.tparams);
+        wave_sync();
+      }
+    }
+  }
+  wave_sync();
+  for (int i = lane; i < dim; i += 64) {
+    pos[chain * dim + i] = q[i];
+    mom[chain * dim + i] = p[i];
+  }
+}
+
 enum { OP_H = 0, OP_DH_DMOM = 1, OP_SAMPLE_MOM = 2 };
 
 template <int OP>
@@ -133,6 +186,25 @@ int mm_launch_leapfrog_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, doub
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
   hipLaunchKernelGGL(leapfrog_generic_kernel, dim3(blocks), dim3(64 * w), lds, ctx->stream,
                      view_of(m), s->d_pos, s->d_mom, s->d_dir, s->n, h, n_steps);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
+int mm_launch_composition_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                                  int n_coeffs, const double* coeffs, int initial_h1) {
+  size_t lds;
+  const int w = waves_per_block(s->dim, &lds);
+  if (lds > 64 * 1024) {
+    mm_set_error(ctx, "mm_composition_euclid: dim too large for the generic kernel's LDS tile");
+    return MM_ERR_UNSUPPORTED;
+  }
+  CompCoefs cf{};
+  cf.m = n_coeffs;
+  cf.initial_h1 = initial_h1;
+  for (int i = 0; i < n_coeffs; ++i) cf.c[i] = coeffs[i];
+  const unsigned blocks = (unsigned)((s->n + w - 1) / w);
+  hipLaunchKernelGGL(composition_generic_kernel, dim3(blocks), dim3(64 * w), lds, ctx->stream, view_of(m),
+                     s->d_pos, s->d_mom, s->d_dir, s->n, h, n_steps, cf);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }

@@ -13,6 +13,7 @@
 
 // launchers living in other translation units
 int mm_launch_leapfrog_generic(mm_ctx*, const mm_model*, mm_state*, double, int);
+int mm_launch_composition_generic(mm_ctx*, const mm_model*, mm_state*, double, int, int, const double*, int);
 int mm_launch_euclid_hamiltonian(mm_ctx*, const mm_model*, mm_state*, double*);
 int mm_launch_euclid_dh_dmom(mm_ctx*, const mm_model*, mm_state*, double*);
 int mm_launch_euclid_sample_momentum(mm_ctx*, const mm_model*, mm_state*, const double*);
@@ -403,6 +404,21 @@ int mm_leapfrog_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, in
   if (rc == -100 || (rc == MM_ERR_UNSUPPORTED && m->dim > 128))
     rc = mm_launch_leapfrog_generic(ctx, m, s, h, n_steps);
   return rc;
+}
+
+int mm_composition_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int32_t n_steps,
+                          int32_t n_coeffs, const double* coeffs, int32_t initial_h1) {
+  int rc = check_pair(ctx, m, s, "mm_composition_euclid");
+  if (rc != MM_OK) return rc;
+  MM_REQUIRE(ctx, m->rmetric == MM_RMETRIC_NONE && m->constr == MM_CONSTR_NONE,
+             "mm_composition_euclid: model is not a plain EuclideanMetricSystem");
+  MM_REQUIRE(ctx, n_steps >= 0, "mm_composition_euclid: n_steps < 0");
+  MM_REQUIRE(ctx, coeffs != nullptr && n_coeffs >= 3 && n_coeffs <= MM_MAX_COMPOSITION_COEFFS && (n_coeffs & 1),
+             "mm_composition_euclid: need an odd number of coefficients in [3, 16]");
+  for (int i = 0; i < n_coeffs; ++i)
+    MM_REQUIRE(ctx, std::isfinite(coeffs[i]), "mm_composition_euclid: non-finite coefficient");
+  if (s->n == 0 || n_steps == 0) return MM_OK;
+  return mm_launch_composition_generic(ctx, m, s, h, n_steps, n_coeffs, coeffs, initial_h1 != 0);
 }
 
 static int finish_counters(mm_ctx* ctx, mm_counters* counters) {

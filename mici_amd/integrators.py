@@ -119,6 +119,59 @@ class LeapfrogIntegrator(Integrator):
                    ctx.handle, "mm_leapfrog_euclid")
 
 
+class SymmetricCompositionIntegrator(Integrator):
+    r"""Symmetric composition integrator :math:`\Psi(t) = A(a_S t) \circ B(b_S t) \circ \dots \circ
+    A(a_0 t)` for Hamiltonians with tractable flows, on an ``EuclideanMetricSystem`` (reference
+    integrators.py:176-274).  ``free_coefficients`` are the :math:`S - 1` free coefficients
+    :math:`(a_0, b_1, a_1, \dots)`; consistency and symmetry fix the rest exactly as the reference does
+    (:258-268)."""
+
+    _needs = "euclid"
+    MAX_COEFFICIENTS = 16  # MM_MAX_COMPOSITION_COEFFS
+
+    def __init__(self, system, free_coefficients, step_size=None, initial_h1_flow_step=True):
+        super().__init__(system, step_size)
+        self.initial_h1_flow_step = initial_h1_flow_step
+        free = [float(c) for c in free_coefficients]
+        n_free = len(free)
+        coefficients = list(free)
+        coefficients.append(0.5 - sum(free[n_free % 2::2]))
+        coefficients.append(1 - 2 * sum(free[(n_free + 1) % 2::2]))
+        self.coefficients = coefficients + coefficients[-2::-1]
+        if len(self.coefficients) > self.MAX_COEFFICIENTS:
+            raise ValueError(f"at most {self.MAX_COEFFICIENTS} flow coefficients are supported on the device")
+
+    def _launch(self, ctx, model, batch, n_steps):
+        coeffs = (C.c_double * len(self.coefficients))(*self.coefficients)
+        _ffi.check(ctx._lib.mm_composition_euclid(ctx.handle, model.handle, batch.handle,
+                                                  float(self.step_size), n_steps, len(self.coefficients),
+                                                  coeffs, 1 if self.initial_h1_flow_step else 0),
+                   ctx.handle, "mm_composition_euclid")
+
+
+class BCSSTwoStageIntegrator(SymmetricCompositionIntegrator):
+    """Two-stage integrator of Blanes, Casas & Sanz-Serna (2014), eq. (6.4) (reference integrators.py:277-307)."""
+
+    def __init__(self, system, step_size=None):
+        super().__init__(system, ((3 - 3**0.5) / 6,), step_size=step_size, initial_h1_flow_step=True)
+
+
+class BCSSThreeStageIntegrator(SymmetricCompositionIntegrator):
+    """Three-stage integrator of Blanes, Casas & Sanz-Serna (2014), eq. (6.7) (reference integrators.py:310-344)."""
+
+    def __init__(self, system, step_size=None):
+        super().__init__(system, (0.11888010966548, 0.29619504261126), step_size=step_size,
+                         initial_h1_flow_step=True)
+
+
+class BCSSFourStageIntegrator(SymmetricCompositionIntegrator):
+    """Four-stage integrator of Blanes, Casas & Sanz-Serna (2014), eq. (6.8) (reference integrators.py:347-378)."""
+
+    def __init__(self, system, step_size=None):
+        super().__init__(system, (0.071353913450279725904, 0.191667800000000000000, 0.268548791161230105820),
+                         step_size=step_size, initial_h1_flow_step=True)
+
+
 class ImplicitLeapfrogIntegrator(Integrator):
     """Implicit (generalised) leapfrog on a Riemannian-metric system with fixed-point solves and
     reversibility checks (reference integrators.py:381-544).  NB as in the reference every

@@ -294,6 +294,44 @@ def leapfrog_steps(system, q, p, dt, n_steps):
     return q, p
 
 
+def composition_coefficients(free_coefficients):
+    """Full coefficient sequence (a_0, b_1, a_1, ..., a_S) of a symmetric composition from its S - 1 free
+    coefficients (SymmetricCompositionIntegrator.__init__, integrators.py:258-268): consistency fixes
+    the last a and b, symmetry mirrors the rest."""
+    free = list(free_coefficients)
+    n = len(free)
+    coefficients = list(free)
+    coefficients.append(0.5 - sum(free[n % 2::2]))
+    coefficients.append(1 - 2 * sum(free[(n + 1) % 2::2]))
+    return coefficients + coefficients[-2::-1]
+
+
+BCSS_FREE_COEFFICIENTS = {  # integrators.py:277-378 (Blanes, Casas & Sanz-Serna 2014, eqs 6.4, 6.7, 6.8)
+    2: ((3 - 3**0.5) / 6,),
+    3: (0.11888010966548, 0.29619504261126),
+    4: (0.071353913450279725904, 0.191667800000000000000, 0.268548791161230105820),
+}
+
+
+def composition_steps(system, q, p, dt, n_steps, free_coefficients, initial_h1_flow_step=True):
+    """n_steps of SymmetricCompositionIntegrator._step (integrators.py:272-274) for one chain on a
+    Euclidean-metric system: alternate h1_flow (mom -= c t grad, systems.py:143-152) and h2_flow
+    (pos += c t M^-1 mom, systems.py:362-363) with the coefficient sequence above; the gradient is the
+    state cache's, i.e. recomputed only after the position moved."""
+    coefficients = composition_coefficients(free_coefficients)
+    q = np.array(q, dtype=np.float64)
+    p = np.array(p, dtype=np.float64)
+    g = system.grad(q)
+    for _ in range(n_steps):
+        for i, c in enumerate(coefficients):
+            if (i % 2 == 0) == bool(initial_h1_flow_step):
+                p -= (c * dt) * g
+            else:
+                q += (c * dt) * system.minv(p)
+                g = system.grad(q)
+    return q, p
+
+
 def leapfrog_steps_batch(system, q, p, dt, n_steps):
     """Vectorised-over-chains variant (rows of q, p are chains) for the cheap targets;
     identical arithmetic per chain.  Used as the multi-chain CPU baseline."""

@@ -48,6 +48,50 @@ def test_leapfrog_matches_reference_fixture(name):
         assert_close(h, g["h_out"][k], 1e-12, f"{name} h@{s}")
 
 
+@pytest.mark.parametrize("name", golden_names("symcomp"))
+def test_symmetric_composition_matches_reference_fixture(name):
+    g = load_golden(name)
+    system = system_from_golden(g)
+    free, h1 = list(g["free_coefficients"]), bool(g["initial_h1_flow_step"])
+    integ = integrators.SymmetricCompositionIntegrator(system, free, step_size=float(g["step_size"]),
+                                                       initial_h1_flow_step=h1)
+    bcss = {1: integrators.BCSSTwoStageIntegrator, 2: integrators.BCSSThreeStageIntegrator,
+            3: integrators.BCSSFourStageIntegrator}
+    if "bcss" in name:
+        named = bcss[len(free)](system, float(g["step_size"]))
+        assert named.coefficients == integ.coefficients
+    for k, s in enumerate(int(s) for s in g["checkpoints"]):
+        q, p, status, n_done = integ.step_batch(g["q0"], g["p0"], g["dir"], n_steps=s)
+        tol = 3e-13 * max(1, s)
+        assert_close(q, g["q_out"][k], tol, f"{name} q@{s}")
+        assert_close(p, g["p_out"][k], tol, f"{name} p@{s}")
+        assert np.all(status == 0) and np.all(n_done == s)
+        assert_close(system.h_batch(q, p), g["h_out"][k], 1e-12, f"{name} h@{s}")
+    # reversibility: integrate back with flipped directions (tests/test_integrators.py:75-91)
+    s = int(g["checkpoints"][-1])
+    q, p, _, _ = integ.step_batch(g["q0"], g["p0"], g["dir"], n_steps=s)
+    qb, pb, _, _ = integ.step_batch(q, p, -g["dir"], n_steps=s)
+    assert_close(qb, g["q0"], 1e-9, "reversed q")
+    assert_close(pb, g["p0"], 1e-9, "reversed p")
+    # the reference's single-state contract
+    from mici_amd.states import ChainState
+    st = ChainState(pos=g["q0"][0].copy(), mom=g["p0"][0].copy(), dir=int(g["dir"][0]))
+    new = integ.step(st)
+    assert_close(new.pos, g["q_out"][0][0] if int(g["checkpoints"][0]) == 1 else new.pos, 3e-13, "step pos")
+    assert np.array_equal(st.pos, g["q0"][0])
+
+
+def test_composition_argument_checks():
+    system = systems.EuclideanMetricSystem(models.GaussIso(4))
+    with pytest.raises(ValueError):
+        integrators.SymmetricCompositionIntegrator(system, [0.1] * 8, step_size=0.1)  # 19 coefficients
+    integ = integrators.BCSSTwoStageIntegrator(system)  # step_size None -> AdaptationError like the reference
+    from mici_amd.errors import AdaptationError
+    from mici_amd.states import ChainState
+    with pytest.raises(AdaptationError):
+        integ.step(ChainState(pos=np.zeros(4), mom=np.ones(4), dir=1))
+
+
 @pytest.mark.parametrize("name", ["euclid_c1_iso_d32", "euclid_quartic_dense_d5",
                                   "euclid_dense_d20_ragged", "euclid_banana_d16"])
 def test_single_state_step_matches_reference_semantics(name):

@@ -31,6 +31,31 @@ def test_euclid_leapfrog(name):
         assert_close(pb, g["p_out"][k], 1e-12 * max(1, s), f"{name} batch p@{s}")
 
 
+@pytest.mark.parametrize("name", golden_names("symcomp"))
+def test_symmetric_composition(name):
+    """SymmetricCompositionIntegrator / BCSS integrators (integrators.py:176-378)."""
+    g = load_golden(name)
+    n, d = g["q0"].shape
+    target = mdl.target_from_id(g["target"], g["target_params"], d)
+    mk = int(g["metric_kind"])
+    system = orc.EuclidSystem(target, mk, None if mk == mdl.METRIC_IDENTITY else g["metric"])
+    h, free, h1 = float(g["step_size"]), list(g["free_coefficients"]), bool(g["initial_h1_flow_step"])
+    coefficients = orc.composition_coefficients(free)
+    assert len(coefficients) == 2 * len(free) + 3
+    assert abs(sum(coefficients[0::2]) - 1) < 1e-15 and abs(sum(coefficients[1::2]) - 1) < 1e-15
+    assert coefficients == coefficients[::-1]
+    for k, s in enumerate(g["checkpoints"]):
+        for c in range(n):
+            q, p = orc.composition_steps(system, g["q0"][c], g["p0"][c], g["dir"][c] * h, int(s), free, h1)
+            assert_close(q, g["q_out"][k, c], 1e-13 * max(1, s), f"{name} q@{s}")
+            assert_close(p, g["p_out"][k, c], 1e-13 * max(1, s), f"{name} p@{s}")
+            assert_close(system.h(q, p), g["h_out"][k, c], 1e-12, f"{name} h@{s}")
+    if not free:  # no free coefficients = the leapfrog integrator
+        q1, p1 = orc.leapfrog_steps(system, g["q0"][0], g["p0"][0], g["dir"][0] * h, 7)
+        q2, p2 = orc.composition_steps(system, g["q0"][0], g["p0"][0], g["dir"][0] * h, 7, ())
+        assert np.array_equal(q1, q2) and np.array_equal(p1, p2)
+
+
 def _riemann_system(g, counters=None):
     n, d = g["q0"].shape
     target = mdl.target_from_id(g["target"], g["target_params"], d)

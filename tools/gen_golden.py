@@ -129,6 +129,39 @@ def euclid_case(name, target, metric_kind, metric, q0, p0, dirs, h, checkpoints)
     ), counts
 
 
+def symcomp_case(name, target, metric_kind, metric, q0, p0, dirs, h, checkpoints, free, initial_h1):
+    """SymmetricCompositionIntegrator / BCSS integrators (integrators.py:176-378) on a Euclidean system."""
+    ref_metric = None if metric_kind == mdl.METRIC_IDENTITY else np.array(metric)
+    system = mici.systems.EuclideanMetricSystem(
+        neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad, metric=ref_metric
+    )
+    bcss = {2: mici.integrators.BCSSTwoStageIntegrator, 3: mici.integrators.BCSSThreeStageIntegrator,
+            4: mici.integrators.BCSSFourStageIntegrator}
+    if free is None or isinstance(free, int):
+        stages = free
+        integrator = bcss[stages](system, h)
+        free = orc.BCSS_FREE_COEFFICIENTS[stages]
+        assert initial_h1
+    else:
+        integrator = mici.integrators.SymmetricCompositionIntegrator(
+            system, free, step_size=h, initial_h1_flow_step=initial_h1)
+    assert np.allclose(integrator.coefficients, orc.composition_coefficients(free), rtol=0, atol=0)
+    ref, counts = run_reference(integrator, system, q0, p0, dirs, checkpoints)
+    osys = orc.EuclidSystem(target, metric_kind, metric)
+    for k, s in enumerate(checkpoints):
+        for c in range(q0.shape[0]):
+            q, p = orc.composition_steps(osys, q0[c], p0[c], dirs[c] * h, s, free, initial_h1)
+            check_close(f"{name} q@{s}", q, ref["q_out"][k, c], 1e-13 * max(1, s))
+            check_close(f"{name} p@{s}", p, ref["p_out"][k, c], 1e-13 * max(1, s))
+            check_close(f"{name} h@{s}", np.array(osys.h(q, p)), ref["h_out"][k, c], 1e-12)
+    return dict(
+        kind="symcomp", target=target.tid, target_params=target.params(), metric_kind=metric_kind,
+        metric=np.zeros(0) if metric is None else np.asarray(metric), q0=q0, p0=p0, dir=dirs,
+        step_size=h, checkpoints=np.array(checkpoints), free_coefficients=np.array(free, dtype=np.float64),
+        initial_h1_flow_step=int(bool(initial_h1)), **ref,
+    ), counts
+
+
 def riemann_case(name, target, rmetric, softabs_coeff, q0, p0, dirs, h, checkpoints,
                  fp_solver=0, norm=0, fp_kwargs=None):
     fp_kwargs = fp_kwargs or {}
@@ -390,6 +423,32 @@ def main():
         add_constrained(f"constrained_circle_dense_d5_{tag}", mdl.Poly(5, 0.0, 0.5),
                         mdl.CircleConstr(), mdl.METRIC_DENSE, dense, qc, 0.1, [1, 5, 20],
                         proj_solver=ps)
+
+    # ---- symmetric composition integrators on Euclidean systems ---------------------
+    # (registered last: the cases above keep the random stream they were generated with)
+    def add_symcomp(name, target, mk, metric, n, h, cps, free, initial_h1=True):
+        d = target.dim
+        q0 = rng.standard_normal((n, d))
+        z = rng.standard_normal((n, d))
+        osys = orc.EuclidSystem(target, mk, metric)
+        p0 = np.stack([osys.msqrt(zz) for zz in z])
+        cases[name] = lambda: symcomp_case(name, target, mk, metric, q0, p0, dirs_for(n), h, cps, free,
+                                           initial_h1)
+
+    Pc = mdl.make_spd(24, rng)
+    Mc = mdl.make_spd(24, rng)
+    for stages in (2, 3, 4):
+        add_symcomp(f"symcomp_bcss{stages}_dense_d24", mdl.GaussDense(Pc), mdl.METRIC_DENSE, Mc, 5, 0.2,
+                    [1, 5, 20], stages)
+        add_symcomp(f"symcomp_bcss{stages}_quartic_diag_d5", mdl.Poly(5, 0.0, 1.0), mdl.METRIC_DIAG,
+                    np.exp(0.1 * rng.standard_normal(5)), 4, 0.1, [1, 10], stages)
+    add_symcomp("symcomp_bcss3_iso_d128", mdl.GaussIso(128), mdl.METRIC_IDENTITY, None, 4, 0.3, [1, 20], 3)
+    add_symcomp("symcomp_leapfrog_as_composition_d16", mdl.Banana(16), mdl.METRIC_IDENTITY, None, 4, 0.02,
+                [1, 10], ())
+    add_symcomp("symcomp_free2_h2first_d7", mdl.Poly(7, 1.0, 0.5), mdl.METRIC_IDENTITY, None, 4, 0.1,
+                [1, 10], (0.2, 0.3), initial_h1=False)
+    add_symcomp("symcomp_free1_h2first_dense_d3", mdl.GaussDense(mdl.make_spd(3, rng)), mdl.METRIC_DENSE,
+                mdl.make_spd(3, rng), 4, 0.1, [1, 10], (0.21,), initial_h1=False)
 
     all_counts = {}
     for name, fn in cases.items():
