@@ -177,6 +177,10 @@ int mm_state_download_status(mm_state* state, int32_t* status, int32_t* n_done);
 /* raw device pointers (zero-copy interop / RCCL): any of the outputs may be NULL */
 int mm_state_device_ptrs(mm_state* state, double** pos, double** mom, int8_t** dir);
 
+/* device-to-device copy of pos, mom, dir, status, n_done (same n_chains and dim): the proposal copy of
+ * Integrator.step / state.copy() (integrators.py:78, states.py:263-279) without a host round trip */
+int mm_state_copy(mm_state* dst, const mm_state* src);
+
 /* ---- the hot path ------------------------------------------------------------------------------------ */
 /* LeapfrogIntegrator.step x n_steps on an EuclideanMetricSystem (integrators.py:63-80, 170-173;
  * systems.py:143-152, 352-363): p -= t/2 grad(q); q += t M^-1 p; p -= t/2 grad(q), t = dir*step_size,
@@ -215,6 +219,21 @@ int mm_dh_dmom(mm_ctx* ctx, const mm_model* model, mm_state* state, double* out)
  * mom = M^{1/2} z (systems.py:365-366, 1401-1402), then projected onto the cotangent space for a
  * constrained system (systems.py:614-616). z is host [N][D]. */
 int mm_sample_momentum(mm_ctx* ctx, const mm_model* model, mm_state* state, const double* z);
+
+/* ---- Metropolis accept step of an integration transition, device resident ------
+ * MetropolisIntegrationTransition._sample_n_step after the trajectory (transitions.py:275-315): `state` is
+ * the chain state BEFORE the trajectory, `proposal` a copy of it (mm_state_copy) advanced by one of the
+ * integrator entry points above (its status / n_done are read here).  Per chain:
+ *   integration_error = status != 0;  moved = n_done > 0 (else the proposal IS the state, accept_prob 0);
+ *   h_diff = h(state) - h(proposal);  accept_prob = isnan(h_diff) ? 0 : exp(min(0, h_diff));
+ *   accepted = !integration_error && u < accept_prob;
+ *   accepted: state <- proposal's pos, mom (dir unchanged: negated for the involution, negated again);
+ *   rejected: state.dir = -state.dir.
+ * u[N]: uniform(0,1) draws (host).  accept_prob[N] / accepted[N] (host) may be NULL.  The statistics
+ * "metrop_accept_prob" = accept_prob, "accept_stat" = integration_error ? 0 : accept_prob, "n_step" = n_done,
+ * "convergence_error" / "non_reversible_step" follow from the proposal's status (mm_state_download_status). */
+int mm_metropolis_accept(mm_ctx* ctx, const mm_model* model, mm_state* state, mm_state* proposal,
+                         const double* u, double* accept_prob, int8_t* accepted);
 
 /* ---- multi-GPU: chains are sharded, no collective inside integration; one RCCL all-gather over
  * xGMI per trace collection (the role of the reference's process pool + memmaps,

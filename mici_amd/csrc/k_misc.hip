@@ -209,6 +209,47 @@ int mm_launch_composition_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, d
   return MM_OK;
 }
 
+// Metropolis accept / select (transitions.py:296-314): one wave per chain; lane 0 decides, all lanes copy.
+__global__ void metropolis_select_kernel(double* __restrict__ pos, double* __restrict__ mom,
+                                         int8_t* __restrict__ dir, const double* __restrict__ ppos,
+                                         const double* __restrict__ pmom, const int32_t* __restrict__ pstatus,
+                                         const int32_t* __restrict__ pn_done, const double* __restrict__ h0,
+                                         const double* __restrict__ h1, const double* __restrict__ u,
+                                         double* __restrict__ accept_prob, int8_t* __restrict__ accepted,
+                                         int64_t n_chains, int dim) {
+  const int lane = threadIdx.x & 63;
+  const int64_t chain = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (chain >= n_chains) return;
+  const bool error = pstatus[chain] != 0;
+  const bool moved = pn_done[chain] > 0;
+  const double h_diff = h0[chain] - h1[chain];
+  double prob = 0.0;
+  if (moved && h_diff == h_diff) prob = exp(h_diff < 0.0 ? h_diff : 0.0);
+  const bool acc = !error && (u[chain] < prob);
+  if (acc) {
+    for (int i = lane; i < dim; i += 64) {
+      pos[chain * dim + i] = ppos[chain * dim + i];
+      mom[chain * dim + i] = pmom[chain * dim + i];
+    }
+  }
+  if (lane == 0) {
+    if (!acc) dir[chain] = (int8_t)(-dir[chain]);
+    accept_prob[chain] = prob;
+    accepted[chain] = acc ? 1 : 0;
+  }
+}
+
+int mm_launch_metropolis_select(mm_ctx* ctx, mm_state* s, mm_state* prop, const double* d_h0, const double* d_h1,
+                                const double* d_u, double* d_prob, int8_t* d_acc) {
+  const int w = 4;
+  const unsigned blocks = (unsigned)((s->n + w - 1) / w);
+  hipLaunchKernelGGL(metropolis_select_kernel, dim3(blocks), dim3(64 * w), 0, ctx->stream, s->d_pos, s->d_mom,
+                     s->d_dir, prop->d_pos, prop->d_mom, prop->d_status, prop->d_n_done, d_h0, d_h1, d_u, d_prob,
+                     d_acc, s->n, s->dim);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
 template <int OP>
 static int launch_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, double* out, const double* z) {
   size_t lds;

@@ -14,6 +14,8 @@
 // launchers living in other translation units
 int mm_launch_leapfrog_generic(mm_ctx*, const mm_model*, mm_state*, double, int);
 int mm_launch_composition_generic(mm_ctx*, const mm_model*, mm_state*, double, int, int, const double*, int);
+int mm_launch_metropolis_select(mm_ctx*, mm_state*, mm_state*, const double*, const double*, const double*, double*,
+                                int8_t*);
 int mm_launch_euclid_hamiltonian(mm_ctx*, const mm_model*, mm_state*, double*);
 int mm_launch_euclid_dh_dmom(mm_ctx*, const mm_model*, mm_state*, double*);
 int mm_launch_euclid_sample_momentum(mm_ctx*, const mm_model*, mm_state*, const double*);
@@ -333,6 +335,7 @@ int mm_state_free(mm_state* s) {
   (void)hipFree(s->d_n_done);
   (void)hipFree(s->d_scratch);
   (void)hipFree(s->d_work);
+  (void)hipFree(s->d_tr);
   delete s;
   return MM_OK;
 }
@@ -375,6 +378,22 @@ int mm_state_download_status(mm_state* s, int32_t* status, int32_t* n_done) {
   return MM_OK;
 }
 
+int mm_state_copy(mm_state* dst, const mm_state* src) {
+  MM_REQUIRE(nullptr, dst != nullptr && src != nullptr, "mm_state_copy: NULL state");
+  mm_ctx* ctx = dst->ctx;
+  MM_REQUIRE(ctx, src->ctx == ctx && src->n == dst->n && src->dim == dst->dim,
+             "mm_state_copy: states differ in ctx / n_chains / dim");
+  if (dst == src || dst->n == 0) return MM_OK;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t nd = (size_t)src->n * src->dim * sizeof(double), n = (size_t)src->n;
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_pos, src->d_pos, nd, hipMemcpyDeviceToDevice, ctx->stream));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_mom, src->d_mom, nd, hipMemcpyDeviceToDevice, ctx->stream));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_dir, src->d_dir, n, hipMemcpyDeviceToDevice, ctx->stream));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_status, src->d_status, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_n_done, src->d_n_done, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  return MM_OK;
+}
+
 int mm_state_device_ptrs(mm_state* s, double** pos, double** mom, int8_t** dir) {
   MM_REQUIRE(nullptr, s != nullptr, "mm_state_device_ptrs: state is NULL");
   if (pos) *pos = s->d_pos;
@@ -393,6 +412,14 @@ static int check_pair(mm_ctx* ctx, const mm_model* m, mm_state* s, const char* w
   return MM_OK;
 }
 
+// explicit integrators cannot fail: status 0, n_done = n_steps for every chain (read by mm_metropolis_accept)
+static int mark_explicit_done(mm_ctx* ctx, mm_state* s, int32_t n_steps) {
+  MM_HIP_CHECK(ctx, hipMemsetAsync(s->d_status, 0, (size_t)s->n * 4, ctx->stream));
+  MM_HIP_CHECK(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s->d_n_done), n_steps, (size_t)s->n,
+                                      ctx->stream));
+  return MM_OK;
+}
+
 int mm_leapfrog_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int32_t n_steps) {
   int rc = check_pair(ctx, m, s, "mm_leapfrog_euclid");
   if (rc != MM_OK) return rc;
@@ -403,7 +430,8 @@ int mm_leapfrog_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, in
   rc = mm_launch_leapfrog_euclid(ctx, m, s, h, n_steps);
   if (rc == -100 || (rc == MM_ERR_UNSUPPORTED && m->dim > 128))
     rc = mm_launch_leapfrog_generic(ctx, m, s, h, n_steps);
-  return rc;
+  if (rc != MM_OK) return rc;
+  return mark_explicit_done(ctx, s, n_steps);
 }
 
 int mm_composition_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int32_t n_steps,
@@ -418,7 +446,9 @@ int mm_composition_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h,
   for (int i = 0; i < n_coeffs; ++i)
     MM_REQUIRE(ctx, std::isfinite(coeffs[i]), "mm_composition_euclid: non-finite coefficient");
   if (s->n == 0 || n_steps == 0) return MM_OK;
-  return mm_launch_composition_generic(ctx, m, s, h, n_steps, n_coeffs, coeffs, initial_h1 != 0);
+  rc = mm_launch_composition_generic(ctx, m, s, h, n_steps, n_coeffs, coeffs, initial_h1 != 0);
+  if (rc != MM_OK) return rc;
+  return mark_explicit_done(ctx, s, n_steps);
 }
 
 static int finish_counters(mm_ctx* ctx, mm_counters* counters) {
@@ -507,6 +537,44 @@ int mm_sample_momentum(mm_ctx* ctx, const mm_model* m, mm_state* s, const double
     if (rc != MM_OK) return rc;
   }
   MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return MM_OK;
+}
+
+// ---- Metropolis accept (transitions.py:275-315) ------------------------------------------------------------
+int mm_metropolis_accept(mm_ctx* ctx, const mm_model* m, mm_state* s, mm_state* prop, const double* u,
+                         double* accept_prob, int8_t* accepted) {
+  int rc = check_pair(ctx, m, s, "mm_metropolis_accept");
+  if (rc != MM_OK) return rc;
+  MM_REQUIRE(ctx, prop != nullptr && prop != s && prop->ctx == ctx && prop->n == s->n && prop->dim == s->dim,
+             "mm_metropolis_accept: proposal must be a distinct state of the same shape");
+  MM_REQUIRE(ctx, u != nullptr, "mm_metropolis_accept: u is NULL");
+  if (s->n == 0) return MM_OK;
+  const size_t n = (size_t)s->n;
+  // h(state) -> state scratch[0..N), h(proposal) -> proposal scratch[0..N)
+  rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 0, s->d_scratch, nullptr)
+                                       : mm_launch_euclid_hamiltonian(ctx, m, s, s->d_scratch);
+  if (rc != MM_OK) return rc;
+  rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, prop, 0, prop->d_scratch, nullptr)
+                                       : mm_launch_euclid_hamiltonian(ctx, m, prop, prop->d_scratch);
+  if (rc != MM_OK) return rc;
+  // u -> device (the proposal's momentum buffer is dead after the select; use a small dedicated buffer)
+  if (s->tr_elems < 2 * n) {
+    (void)hipFree(s->d_tr);
+    s->d_tr = nullptr;
+    s->tr_elems = 0;
+    MM_HIP_CHECK(ctx, hipMalloc(&s->d_tr, 2 * n * sizeof(double) + n));
+    s->tr_elems = 2 * n;
+  }
+  double* d_u = s->d_tr;
+  double* d_prob = s->d_tr + n;
+  int8_t* d_acc = reinterpret_cast<int8_t*>(s->d_tr + 2 * n);
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(d_u, u, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  rc = mm_launch_metropolis_select(ctx, s, prop, s->d_scratch, prop->d_scratch, d_u, d_prob, d_acc);
+  if (rc != MM_OK) return rc;
+  if (accept_prob)
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(accept_prob, d_prob, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (accepted) MM_HIP_CHECK(ctx, hipMemcpyAsync(accepted, d_acc, n, hipMemcpyDeviceToHost, ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // u is only borrowed
   return MM_OK;
 }
 

@@ -1,0 +1,144 @@
+"""Momentum refresh and Metropolis static-integration transitions with the reference's ``Transition``
+surface (mici/transitions.py), device resident: the trajectory, both Hamiltonian evaluations and the
+accept / select step run on the GPU with no per-step host round trip.
+
+Each class offers
+  * ``sample(state, rng) -> (state, stats)``  - the reference contract for ONE chain
+    (transitions.py:129-142, 275-352): same draws from ``rng`` in the same order (the accept uniform is
+    drawn only when the trajectory raised no integrator error), same statistics dictionary;
+  * ``sample_batch(batch, ...)``              - N chains resident in HBM (``DeviceBatch``).
+There is no CPU path: a missing library or device raises ``DeviceError``."""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _ffi
+from .errors import LinAlgError
+from .runtime import DeviceBatch, default_context
+
+
+class IndependentMomentumTransition:
+    """Independently resample the momentum from its conditional distribution (transitions.py:129-142)."""
+
+    state_variables = {"mom"}
+    statistic_types = None
+
+    def __init__(self, system):
+        self.system = system
+
+    def sample(self, state, rng):
+        state.mom = self.system.sample_momentum(state, rng)
+        return state, None
+
+    def sample_batch(self, batch, z, ctx=None):
+        """``z``: standard-normal draws [N, D] (host); the momentum of every chain in ``batch`` is replaced."""
+        ctx = ctx or batch.ctx
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        if z.shape != (batch.n_chains, batch.dim):
+            raise ValueError(f"z must have shape ({batch.n_chains}, {batch.dim})")
+        model = self.system.device_model(ctx)
+        _ffi.check(ctx._lib.mm_sample_momentum(ctx.handle, model.handle, batch.handle,
+                                               z.ctypes.data_as(_ffi.c_double_p)),
+                   ctx.handle, "mm_sample_momentum")
+
+
+class MetropolisStaticIntegrationTransition:
+    """Static-trajectory HMC transition with a Metropolis accept step (transitions.py:236-352): integrate
+    ``n_step`` steps in the current direction, accept the end point with probability
+    min(1, exp(h_init - h_final)), negate the direction on rejection."""
+
+    state_variables = {"pos", "mom", "dir"}
+
+    def __init__(self, system, integrator, n_step):
+        if n_step <= 0:
+            raise ValueError("Number of integrator steps must be positive.")
+        self.system = system
+        self.integrator = integrator
+        self.n_step = int(n_step)
+        self._statistic_types = {
+            "n_step": (np.int64, -1),
+            "accept_stat": (np.float64, np.nan),
+            "non_reversible_step": (bool, False),
+            "convergence_error": (bool, False),
+            "step_size": (np.float64, np.nan),
+            "metrop_accept_prob": (np.float64, np.nan),
+        }
+        self._proposals = {}
+
+    @property
+    def statistic_types(self):
+        return self._statistic_types
+
+    def _proposal_for(self, batch):
+        key = (id(batch.ctx), batch.n_chains, batch.dim)
+        prop = self._proposals.get(key)
+        if prop is None or prop.handle is None:
+            prop = self._proposals[key] = DeviceBatch(batch.ctx, batch.n_chains, batch.dim)
+        return prop
+
+    # ---- N chains, device resident ---------------------------------------------------------------------
+    def propose_batch(self, batch, ctx=None):
+        """Copy the chains and run the trajectory on the copy; returns the proposal batch and its per-chain
+        (status, n_done).  Split from :py:meth:`accept_batch` so that a caller that replays a reference
+        random stream can draw the accept uniforms only for the chains without an integration error."""
+        ctx = ctx or batch.ctx
+        prop = self._proposal_for(batch)
+        _ffi.check(ctx._lib.mm_state_copy(prop.handle, batch.handle), ctx.handle, "mm_state_copy")
+        self.integrator.step_device(prop, self.n_step, ctx)
+        status, n_done = prop.download_status()
+        if np.any(status == 5):  # a LinAlgError outside a solver is not an IntegratorError: it propagates
+            raise LinAlgError("metric construction failed outside a solver for chain(s) "
+                              f"{np.flatnonzero(status == 5).tolist()}")
+        return prop, status, n_done
+
+    def accept_batch(self, batch, prop, status, n_done, u, ctx=None):
+        ctx = ctx or batch.ctx
+        n = batch.n_chains
+        u = np.ascontiguousarray(np.broadcast_to(np.asarray(u, dtype=np.float64), (n,)))
+        prob = np.zeros(n)
+        acc = np.zeros(n, dtype=np.int8)
+        model = self.system.device_model(ctx)
+        _ffi.check(ctx._lib.mm_metropolis_accept(
+            ctx.handle, model.handle, batch.handle, prop.handle, u.ctypes.data_as(_ffi.c_double_p),
+            prob.ctypes.data_as(_ffi.c_double_p), acc.ctypes.data_as(_ffi.c_int8_p)),
+            ctx.handle, "mm_metropolis_accept")
+        error = status != 0
+        return {
+            "n_step": n_done.astype(np.int64),
+            "metrop_accept_prob": prob,
+            "accept_stat": np.where(error, 0.0, prob),
+            "convergence_error": (status >= 1) & (status <= 3),
+            "non_reversible_step": status == 4,
+            "step_size": np.full(n, self.integrator.step_size, dtype=np.float64),
+            "accepted": acc.astype(bool),
+        }
+
+    def sample_batch(self, batch, u, ctx=None):
+        """One transition for every chain of ``batch`` with the accept uniforms ``u[N]`` given up front."""
+        prop, status, n_done = self.propose_batch(batch, ctx)
+        return self.accept_batch(batch, prop, status, n_done, u, ctx)
+
+    # ---- one chain, the reference's contract -----------------------------------------------------------
+    def sample(self, state, rng):
+        ctx = default_context()
+        pos = np.ascontiguousarray(state.pos, dtype=np.float64)
+        batch = getattr(self, "_one", None)
+        if batch is None or batch.handle is None or batch.dim != pos.shape[0] or batch.ctx is not ctx:
+            batch = self._one = DeviceBatch(ctx, 1, pos.shape[0])
+        batch.upload(pos[None], np.asarray(state.mom, dtype=np.float64)[None], [int(state.dir)])
+        prop, status, n_done = self.propose_batch(batch, ctx)
+        # `not integration_error and rng.uniform() < accept_prob`: no draw after an integration error
+        u = rng.uniform() if status[0] == 0 else 2.0
+        st = self.accept_batch(batch, prop, status, n_done, [u], ctx)
+        q, p, d = batch.download()
+        state.pos, state.mom, state.dir = q[0], p[0], int(d[0])
+        stats = {
+            "convergence_error": bool(st["convergence_error"][0]),
+            "non_reversible_step": bool(st["non_reversible_step"][0]),
+            "step_size": self.integrator.step_size,
+            "n_step": int(st["n_step"][0]),
+            "metrop_accept_prob": float(st["metrop_accept_prob"][0]),
+            "accept_stat": float(st["accept_stat"][0]),
+        }
+        return state, stats

@@ -56,6 +56,44 @@ def test_symmetric_composition(name):
         assert np.array_equal(q1, q2) and np.array_equal(p1, p2)
 
 
+@pytest.mark.parametrize("name", golden_names("transition"))
+def test_metropolis_static_transitions(name):
+    """oracle/transitions.py replays the reference's recorded draws (transitions.py:129-142, 275-352)."""
+    from oracle import transitions as otr
+    g = load_golden(name)
+    n_tr, n, d = g["z"].shape
+    kind = str(g["kind"])
+    target = mdl.target_from_id(g["target"], g["target_params"], d)
+    if kind == "transition_euclid":
+        mk = int(g["metric_kind"])
+        system = orc.EuclidSystem(target, mk, None if mk == mdl.METRIC_IDENTITY else g["metric"])
+        ad = otr.euclid_adapter(system, list(g["free_coefficients"]) if int(g["composition"]) else None)
+    elif kind == "transition_riemann":
+        ad = otr.riemann_adapter(orc.RiemannianSystem(
+            target, mdl.rmetric_from_id(g["rmetric"], g["rmetric_params"], d), None))
+    else:
+        ad = otr.constrained_adapter(orc.ConstrainedSystem(target, mdl.constr_from_id(g["constr"], g["constr_params"])))
+    h, n_step = float(g["step_size"]), int(g["n_step"])
+    for c in range(n):
+        q, direction = g["q0"][c].copy(), 1
+        for t in range(n_tr):
+            p = ad.sample_momentum(q, g["z"][t, c])
+            drew = []
+
+            def draw(t=t, c=c, drew=drew):
+                drew.append(1)
+                assert not np.isnan(g["u"][t, c])
+                return g["u"][t, c]
+
+            q, p, direction, st = otr.metropolis_static_transition(ad, q, p, direction, h, n_step, draw)
+            assert len(drew) == (0 if np.isnan(g["u"][t, c]) else 1)
+            assert_close(q, g["q_out"][t, c], 1e-11, f"{name} q t{t} c{c}")
+            assert_close(p, g["p_out"][t, c], 1e-11, f"{name} p t{t} c{c}")
+            assert direction == g["dir_out"][t, c]
+            for k in ("n_step", "accept_stat", "metrop_accept_prob", "convergence_error", "non_reversible_step"):
+                assert_close(float(st[k]), g[f"stat_{k}"][t, c], 1e-10, f"{name} {k}")
+
+
 def _riemann_system(g, counters=None):
     n, d = g["q0"].shape
     target = mdl.target_from_id(g["target"], g["target_params"], d)

@@ -162,6 +162,83 @@ def symcomp_case(name, target, metric_kind, metric, q0, p0, dirs, h, checkpoints
     ), counts
 
 
+class RecordingRng:
+    """Wraps a numpy Generator and logs what the reference draws (transition fixtures)."""
+
+    def __init__(self, seed):
+        self._rng = np.random.default_rng(seed)
+        self.log = []
+
+    def standard_normal(self, size=None):
+        v = self._rng.standard_normal(size)
+        self.log.append(("z", np.array(v, dtype=np.float64)))
+        return v
+
+    def normal(self, size=None):  # RiemannianMetricSystem.sample_momentum, systems.py:1402
+        v = self._rng.normal(size=size)
+        self.log.append(("z", np.array(v, dtype=np.float64)))
+        return v
+
+    def uniform(self, *a, **k):
+        v = self._rng.uniform(*a, **k)
+        self.log.append(("u", float(v)))
+        return v
+
+
+def transition_case(name, kind, ref_system, ref_integrator, adapter, q0, n_step, n_transitions, seed0, extra):
+    """IndependentMomentumTransition + MetropolisStaticIntegrationTransition (transitions.py:129-142,
+    275-352), several successive transitions per chain, reference vs oracle/transitions.py."""
+    from oracle import transitions as otr
+    n, d = q0.shape
+    mom_tr = mici.transitions.IndependentMomentumTransition(ref_system)
+    int_tr = mici.transitions.MetropolisStaticIntegrationTransition(ref_system, ref_integrator, n_step)
+    z = np.zeros((n_transitions, n, d))
+    u = np.full((n_transitions, n), np.nan)  # NaN = the reference drew no uniform (integration error)
+    q_out = np.zeros((n_transitions, n, d))
+    p_out = np.zeros((n_transitions, n, d))
+    dir_out = np.zeros((n_transitions, n), dtype=np.int8)
+    stat = {k: np.zeros((n_transitions, n)) for k in
+            ("n_step", "accept_stat", "metrop_accept_prob", "convergence_error", "non_reversible_step")}
+    step_size = float(ref_integrator.step_size)
+    for c in range(n):
+        rng = RecordingRng(seed0 + c)
+        state = ChainState(pos=q0[c].copy(), mom=None, dir=1)
+        oq, odir = q0[c].copy(), 1
+        for t in range(n_transitions):
+            rng.log.clear()
+            state, _ = mom_tr.sample(state, rng)
+            state, stats = int_tr.sample(state, rng)
+            kinds = [k for k, _ in rng.log]
+            assert kinds in (["z"], ["z", "u"]), kinds
+            z[t, c] = rng.log[0][1]
+            if len(rng.log) == 2:
+                u[t, c] = rng.log[1][1]
+            q_out[t, c], p_out[t, c], dir_out[t, c] = state.pos, state.mom, state.dir
+            for k in stat:
+                stat[k][t, c] = float(stats[k])
+            # oracle replay
+            op = adapter.sample_momentum(oq, z[t, c])
+            drew = []
+
+            def draw(t=t, c=c, drew=drew):
+                drew.append(1)
+                assert not np.isnan(u[t, c]), "oracle draws a uniform the reference did not"
+                return u[t, c]
+
+            oq, op, odir, ost = otr.metropolis_static_transition(adapter, oq, op, odir, step_size, n_step, draw)
+            assert len(drew) == (0 if np.isnan(u[t, c]) else 1)
+            check_close(f"{name} q t{t} c{c}", oq, state.pos, 1e-11)
+            check_close(f"{name} p t{t} c{c}", op, state.mom, 1e-11)
+            assert odir == state.dir
+            for k in stat:
+                check_close(f"{name} {k} t{t} c{c}", float(ost[k]), stat[k][t, c], 1e-10)
+    print(f"   {name}: accepted {np.mean(stat['accept_stat']):.2f} mean accept_stat, "
+          f"{int(np.sum(np.isnan(u)))} integration errors, mean n_step {np.mean(stat['n_step']):.2f}")
+    return dict(kind=kind, q0=q0, z=z, u=u, q_out=q_out, p_out=p_out, dir_out=dir_out, n_step=n_step,
+                step_size=step_size, status=np.zeros(n, dtype=np.int32), n_done=np.zeros(n, dtype=np.int32),
+                **{f"stat_{k}": v for k, v in stat.items()}, **extra), collections.Counter()
+
+
 def riemann_case(name, target, rmetric, softabs_coeff, q0, p0, dirs, h, checkpoints,
                  fp_solver=0, norm=0, fp_kwargs=None):
     fp_kwargs = fp_kwargs or {}
@@ -449,6 +526,78 @@ def main():
                 [1, 10], (0.2, 0.3), initial_h1=False)
     add_symcomp("symcomp_free1_h2first_dense_d3", mdl.GaussDense(mdl.make_spd(3, rng)), mdl.METRIC_DENSE,
                 mdl.make_spd(3, rng), 4, 0.1, [1, 10], (0.21,), initial_h1=False)
+
+    # ---- momentum refresh + Metropolis static-integration transitions ---------------
+    from oracle import transitions as otr
+
+    def model_keys(target, mk, metric, **more):
+        return dict(target=target.tid, target_params=target.params(), metric_kind=mk,
+                    metric=np.zeros(0) if metric is None else np.asarray(metric), **more)
+
+    def add_transition_euclid(name, target, mk, metric, n, h, n_step, n_tr, seed0, free=None):
+        q0 = rng.standard_normal((n, target.dim))
+
+        def make():
+            rsys = mici.systems.EuclideanMetricSystem(
+                neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+                metric=None if mk == mdl.METRIC_IDENTITY else np.array(metric))
+            if free is None:
+                rint = mici.integrators.LeapfrogIntegrator(rsys, h)
+            else:
+                rint = mici.integrators.SymmetricCompositionIntegrator(rsys, free, step_size=h)
+            ad = otr.euclid_adapter(orc.EuclidSystem(target, mk, metric), free)
+            return transition_case(name, "transition_euclid", rsys, rint, ad, q0, n_step, n_tr, seed0,
+                                   model_keys(target, mk, metric, free_coefficients=np.array(
+                                       [] if free is None else free, dtype=np.float64),
+                                       composition=int(free is not None)))
+        cases[name] = make
+
+    Pt = mdl.make_spd(16, rng)
+    add_transition_euclid("transition_euclid_dense_d16", mdl.GaussDense(Pt), mdl.METRIC_DENSE,
+                          mdl.make_spd(16, rng), 6, 0.35, 5, 6, 1000)
+    add_transition_euclid("transition_euclid_quartic_d5_bigstep", mdl.Poly(5, 0.0, 1.0), mdl.METRIC_IDENTITY, None,
+                          6, 0.9, 4, 6, 2000)
+    add_transition_euclid("transition_euclid_bcss3_d8", mdl.Poly(8, 1.0, 0.5), mdl.METRIC_DIAG,
+                          np.exp(0.2 * rng.standard_normal(8)), 4, 0.5, 3, 5, 3000,
+                          free=orc.BCSS_FREE_COEFFICIENTS[3])
+
+    def add_transition_riemann(name, target, rmetric, n, h, n_step, n_tr, seed0):
+        q0 = rng.standard_normal((n, target.dim))
+
+        def make():
+            rsys = mici.systems.DenseRiemannianMetricSystem(
+                neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+                metric_func=rmetric.metric_func, vjp_metric_func=rmetric.vjp_metric_func)
+            rint = mici.integrators.ImplicitLeapfrogIntegrator(rsys, h)
+            ad = otr.riemann_adapter(orc.RiemannianSystem(target, rmetric, None))
+            return transition_case(name, "transition_riemann", rsys, rint, ad, q0, n_step, n_tr, seed0,
+                                   dict(target=target.tid, target_params=target.params(), rmetric=rmetric.mid,
+                                        rmetric_params=rmetric.params()))
+        cases[name] = make
+
+    add_transition_riemann("transition_riemann_rank1_banana_d8", mdl.Banana(8),
+                           mdl.Rank1Metric(mdl.make_spd(8, rng)), 5, 0.05, 4, 5, 4000)
+    add_transition_riemann("transition_riemann_diagquad_poly_d5_bigstep", mdl.Poly(5, 1.0, 1.0 / 3.0),
+                           mdl.DiagQuadMetric(5), 6, 0.45, 3, 6, 5000)
+
+    def add_transition_constrained(name, n, h, n_step, n_tr, seed0):
+        q0 = mdl.torus_init(n, rng)
+        target, constraint = mdl.Torus(), mdl.TorusConstr()
+
+        def make():
+            rsys = mici.systems.DenseConstrainedEuclideanMetricSystem(
+                neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+                constr=constraint.constr, jacob_constr=constraint.jacob_constr)
+            rint = mici.integrators.ConstrainedLeapfrogIntegrator(rsys, h)
+            ad = otr.constrained_adapter(orc.ConstrainedSystem(target, constraint))
+            return transition_case(name, "transition_constrained", rsys, rint, ad, q0, n_step, n_tr, seed0,
+                                   dict(target=target.tid, target_params=target.params(),
+                                        constr=constraint.cid, constr_params=constraint.params(),
+                                        metric_kind=mdl.METRIC_IDENTITY, metric=np.zeros(0)))
+        cases[name] = make
+
+    add_transition_constrained("transition_constrained_torus", 6, 0.3, 4, 6, 6000)
+    add_transition_constrained("transition_constrained_torus_bigstep", 6, 1.2, 3, 6, 7000)
 
     all_counts = {}
     for name, fn in cases.items():
