@@ -204,6 +204,13 @@ int mm_composition_euclid(mm_ctx* ctx, const mm_model* model, mm_state* state, d
 int mm_implicit_leapfrog(mm_ctx* ctx, const mm_model* model, mm_state* state, double step_size,
                          int32_t n_steps, const mm_fp_opts* opts, mm_counters* counters);
 
+/* ImplicitMidpointIntegrator.step x n_steps (integrators.py:547-681): implicit Euler half step solved as a
+ * fixed point in the concatenated (pos, mom) vector (solvers.py:47-154), explicit Euler half step, and the
+ * reversibility check.  Euclidean-metric systems (dim <= 128) and dense-Riemannian systems (dim <= 64);
+ * opts / counters as for mm_implicit_leapfrog. */
+int mm_implicit_midpoint(mm_ctx* ctx, const mm_model* model, mm_state* state, double step_size,
+                         int32_t n_steps, const mm_fp_opts* opts, mm_counters* counters);
+
 /* ConstrainedLeapfrogIntegrator.step x n_steps on a DenseConstrainedEuclideanMetricSystem
  * (integrators.py:929-984; solvers.py:429-469; systems.py:786-873, 1010-1022). */
 int mm_constrained_leapfrog(mm_ctx* ctx, const mm_model* model, mm_state* state, double step_size,

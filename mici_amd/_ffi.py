@@ -98,6 +98,8 @@ SIGNATURES = {
     "mm_composition_euclid": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int32, C.c_int32, c_double_p, C.c_int32]),
     "mm_implicit_leapfrog": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int32,
                                        C.POINTER(FpOpts), C.POINTER(Counters)]),
+    "mm_implicit_midpoint": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int32,
+                                       C.POINTER(FpOpts), C.POINTER(Counters)]),
     "mm_constrained_leapfrog": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int32,
                                           C.POINTER(ProjOpts), C.POINTER(Counters)]),
     "mm_hamiltonian": (C.c_int, [_VP, _VP, _VP, c_double_p]),

@@ -301,6 +301,158 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
   return r;
 }
 
+// ---- implicit midpoint integrator (integrators.py:547-681) on a Riemannian-metric backend ---------------
+// Fixed-point solve in the concatenated (pos, mom) vector: every thread holds one element of each half.
+// Same resumable structure as fp_feed above, for pairs.
+template <class BK>
+__device__ __forceinline__ double pair_norm(BK& bk, double dq, double dp, int kind) {
+  const double a = bk.norm(dq, kind), b = bk.norm(dp, kind);
+  if (kind == MM_NORM_LINF) return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
+  return sqrt(a * a + b * b);
+}
+
+// slots of the midpoint step (they alias the leapfrog's; a kernel runs one integrator)
+enum {
+  MP_Q = 0, MP_P,      // committed state
+  MP_XIQ, MP_XIP,      // x_init of the solve in flight
+  MP_X0Q, MP_X0P,      // current iterate
+  MP_X1Q, MP_X1P,      // Steffensen: f(x0)
+  MP_PTQ, MP_PTP,      // point the function is evaluated at
+  MP_PRQ, MP_PRP,      // state after the implicit half step (reference point of the reversibility check)
+  MP_COUNT
+};
+static_assert(MP_COUNT <= SL_COUNT, "midpoint slots must fit the backends' slot storage");
+
+template <class BK>
+__device__ __forceinline__ int fp_feed2(BK& bk, FpCtl& c, double fq, double fp, const mm_fp_opts& o,
+                                        int* status) {
+  double xq, xp;
+  if (o.solver == MM_FP_DIRECT) {
+    xq = fq;
+    xp = fp;
+  } else {
+    if (c.stage == 0) {  // x1 = f(x0); next evaluate f(x1)
+      bk.slot(MP_X1Q) = fq;
+      bk.slot(MP_X1P) = fp;
+      c.stage = 1;
+      bk.slot(MP_PTQ) = fq;
+      bk.slot(MP_PTP) = fp;
+      return FP_CONT;
+    }
+    const double eps = 2.220446049250313e-16;  // np.finfo(float64).eps (solvers.py:134-138)
+    const double a0q = bk.slot(MP_X0Q), a1q = bk.slot(MP_X1Q), a0p = bk.slot(MP_X0P), a1p = bk.slot(MP_X1P);
+    double dnq = fq - 2.0 * a1q + a0q, dnp = fp - 2.0 * a1p + a0p;
+    if (fabs(dnq) == 0.0) dnq = eps;
+    if (fabs(dnp) == 0.0) dnp = eps;
+    xq = a0q - (a1q - a0q) * (a1q - a0q) / dnq;
+    xp = a0p - (a1p - a0p) * (a1p - a0p) / dnp;
+    c.stage = 0;
+  }
+  const double err = pair_norm(bk, xq - bk.slot(MP_X0Q), xp - bk.slot(MP_X0P), o.norm);
+  if (err > o.div_tol || err != err) {
+    *status = MM_ST_DIVERGED;
+    return FP_FAIL;
+  }
+  bk.slot(MP_PTQ) = xq;
+  bk.slot(MP_PTP) = xp;
+  if (err < o.conv_tol) return FP_DONE;
+  bk.slot(MP_X0Q) = xq;
+  bk.slot(MP_X0P) = xp;
+  if (++c.iter >= o.max_iters) {
+    *status = MM_ST_MAX_ITERS;
+    return FP_FAIL;
+  }
+  return FP_CONT;
+}
+
+enum { MPM_FWD = 0, MPM_ADJ = 1, MPM_BACK = 2 };
+
+// Advance one chain by up to n_steps of ImplicitMidpointIntegrator._step: A(t/2) implicit Euler half step
+// (fixed point), A*(t/2) explicit Euler half step, reversibility check = A(-t/2) from the new state must
+// return to the state after the first half step.  One evaluation site of (dh_dmom, dh_dpos):
+//   dh_dmom = M^-1 p;  dh_dpos = (grad + 0.5 vjp(M^-1)) + 0.5 vjp(-(M^-1 p)(M^-1 p)^T)  (systems.py:1381-1399)
+template <class BK>
+__device__ __forceinline__ ChainResult implicit_midpoint_chain(BK& bk, double t, int n_steps,
+                                                               const mm_fp_opts& o) {
+  ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0};
+  const double half = 0.5 * t;
+  int mode = MPM_FWD;
+  FpCtl c{0, 0};
+  double tt = half;  // time step of the solve in flight
+  bk.slot(MP_XIQ) = bk.slot(MP_Q);
+  bk.slot(MP_XIP) = bk.slot(MP_P);
+  bk.slot(MP_X0Q) = bk.slot(MP_Q);
+  bk.slot(MP_X0P) = bk.slot(MP_P);
+  bk.slot(MP_PTQ) = bk.slot(MP_Q);
+  bk.slot(MP_PTP) = bk.slot(MP_P);
+  r.n_solves = 1;
+  while (n_steps > 0) {
+    const double xq = bk.slot(MP_PTQ), xp = bk.slot(MP_PTP);
+    const double gq = bk.grad(xq);
+    ++r.n_grad;
+    const bool okm = bk.build_and_invert(xq);
+    ++r.n_metric;
+    if (!okm) {  // LinAlgError: inside a solver it becomes a ConvergenceError (solvers.py:89-93)
+      r.status = (mode == MPM_ADJ) ? MM_ST_LINALG : MM_ST_SOLVER_LINALG;
+      break;
+    }
+    const double dq = bk.matvec(xp);
+    const double dp = (gq + bk.half_vjp_inv(xq)) + bk.dh2_dpos(xp, xq);
+    if (mode == MPM_ADJ) {
+      // explicit Euler half step from the implicit half step's result, then start the reverse solve
+      const double q2 = xq + half * dq, p2 = xp - half * dp;
+      bk.slot(MP_PRQ) = xq;
+      bk.slot(MP_PRP) = xp;
+      bk.slot(MP_XIQ) = q2;
+      bk.slot(MP_XIP) = p2;
+      bk.slot(MP_X0Q) = q2;
+      bk.slot(MP_X0P) = p2;
+      bk.slot(MP_PTQ) = q2;
+      bk.slot(MP_PTP) = p2;
+      c = FpCtl{0, 0};
+      tt = -half;
+      mode = MPM_BACK;
+      ++r.n_solves;
+      continue;
+    }
+    ++r.n_evals;
+    const double fq = bk.slot(MP_XIQ) + tt * dq, fp = bk.slot(MP_XIP) - tt * dp;
+    int status = MM_ST_OK;
+    const int act = fp_feed2(bk, c, fq, fp, o, &status);
+    if (act == FP_FAIL) {
+      r.status = status;
+      break;
+    }
+    if (act == FP_CONT) continue;
+    if (mode == MPM_FWD) {
+      mode = MPM_ADJ;  // evaluate dh at the converged point (MP_PT holds it)
+      continue;
+    }
+    // MPM_BACK converged: reversibility check, then commit
+    const double rev = pair_norm(bk, bk.slot(MP_PTQ) - bk.slot(MP_PRQ), bk.slot(MP_PTP) - bk.slot(MP_PRP),
+                                 o.rev_norm);
+    if (rev > o.rev_tol) {
+      r.status = MM_ST_NON_REVERSIBLE;
+      break;
+    }
+    bk.slot(MP_Q) = bk.slot(MP_XIQ);
+    bk.slot(MP_P) = bk.slot(MP_XIP);
+    ++r.done;
+    --n_steps;
+    if (n_steps > 0) {
+      bk.slot(MP_X0Q) = bk.slot(MP_Q);
+      bk.slot(MP_X0P) = bk.slot(MP_P);
+      bk.slot(MP_PTQ) = bk.slot(MP_Q);
+      bk.slot(MP_PTP) = bk.slot(MP_P);
+      c = FpCtl{0, 0};
+      tt = half;
+      mode = MPM_FWD;
+      ++r.n_solves;
+    }
+  }
+  return r;
+}
+
 __device__ __forceinline__ void add_counters(mm_counters* c, const ChainResult& r) {
   if (!c) return;
   atomicAdd((unsigned long long*)&c->n_grad, (unsigned long long)r.n_grad);

@@ -407,6 +407,43 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_leapfrog_kernel(Implicit
   }
 }
 
+// ---- ImplicitMidpointIntegrator (integrators.py:547-681) on the wave-per-chain backend, D <= 64 -----------
+template <int TS, int RMETRIC>
+__global__ __launch_bounds__(64 * kWaves) void implicit_midpoint_kernel(ImplicitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* base_lds = lds;
+  const int base_elems = (RMETRIC == MM_RMETRIC_RANK1) ? 64 * Geo<TS>::TSTRIDE : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* wl = lds + base_elems + wave * kWaveLdsDoubles;
+  stage_base<TS, RMETRIC>(base_lds, A.rparams, A.dim);
+  const int64_t chain = (int64_t)blockIdx.x * kWaves + wave;
+  if (chain >= A.n_chains) return;  // no block-level barrier below this point
+  const int dim = A.dim;
+  const bool act = lane < dim;
+  WaveBackend<TS, RMETRIC> bk;
+  bk.dim = dim;
+  bk.lane = lane;
+  bk.target = A.target;
+  bk.w = WaveLds{wl, wl + 64, wl + 128, wl + 192, wl + 256};
+  bk.stash = wl + 320;
+  bk.blk = wl + 320 + SL_COUNT * 64;
+  bk.base_lds = base_lds;
+  bk.tparams = A.tparams;
+  bk.slot(MP_Q) = act ? A.pos[chain * dim + lane] : 0.0;
+  bk.slot(MP_P) = act ? A.mom[chain * dim + lane] : 0.0;
+  const double t = (double)A.dir[chain] * A.step_size;
+  const ChainResult r = implicit_midpoint_chain(bk, t, A.n_steps, A.opts);
+  if (act) {  // a failed step leaves the last completed state
+    A.pos[chain * dim + lane] = bk.slot(MP_Q);
+    A.mom[chain * dim + lane] = bk.slot(MP_P);
+  }
+  if (lane == 0) {
+    A.status[chain] = r.status;
+    A.n_done[chain] = r.done;
+    add_counters(A.counters, r);
+  }
+}
+
 // ---- System-level quantities for Riemannian systems: op 0 = h, 1 = dh_dmom, 2 = sample_momentum ------
 template <int TS, int RMETRIC, int OP>
 __global__ __launch_bounds__(64 * kWaves) void riemann_aux_kernel(ImplicitArgs A) {
@@ -561,6 +598,22 @@ struct StepFn {
   template <int TS, int RM>
   int operator()() { return launch_step<TS, RM>(ctx, a, n); }
 };
+template <int TS, int RMETRIC>
+int launch_midpoint(mm_ctx* ctx, const ImplicitArgs& a, int64_t n) {
+  const unsigned blocks = (unsigned)((n + kWaves - 1) / kWaves);
+  const size_t lds = lds_bytes<TS, RMETRIC>();
+  hipLaunchKernelGGL((implicit_midpoint_kernel<TS, RMETRIC>), dim3(blocks), dim3(64 * kWaves), lds,
+                     ctx->stream, a);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+struct MidpointFn {
+  mm_ctx* ctx;
+  ImplicitArgs a;
+  int64_t n;
+  template <int TS, int RM>
+  int operator()() { return launch_midpoint<TS, RM>(ctx, a, n); }
+};
 struct AuxFn {
   mm_ctx* ctx;
   ImplicitArgs a;
@@ -608,6 +661,20 @@ int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, dou
   a.opts = opts;
   a.counters = d_counters;
   return dispatch(ctx, m, StepFn{ctx, a, s->n});
+}
+
+int mm_launch_implicit_midpoint_riemann(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                                        const mm_fp_opts& opts, mm_counters* d_counters) {
+  if (m->rmetric == MM_RMETRIC_SOFTABS || m->dim > 64) {
+    mm_set_error(ctx, "mm_implicit_midpoint: Riemannian systems are supported for the dense metrics, dim <= 64");
+    return MM_ERR_UNSUPPORTED;
+  }
+  ImplicitArgs a = make_args(m, s);
+  a.step_size = h;
+  a.n_steps = n_steps;
+  a.opts = opts;
+  a.counters = d_counters;
+  return dispatch(ctx, m, MidpointFn{ctx, a, s->n});
 }
 
 int mm_launch_riemann_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* d_out,

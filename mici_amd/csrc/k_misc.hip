@@ -209,6 +209,187 @@ int mm_launch_composition_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, d
   return MM_OK;
 }
 
+// ImplicitMidpointIntegrator (integrators.py:547-681) on a Euclidean-metric system, one wave per chain.
+// LDS per wave: 11 vectors of dim doubles.  dh_dmom = M^-1 p, dh_dpos = grad(q).
+struct MidpointLds {
+  double *q, *p, *xiq, *xip, *x0q, *x0p, *x1q, *x1p, *ptq, *ptp, *tmp;
+};
+
+__device__ __forceinline__ double pair_norm_lds(const double* aq, const double* bq, const double* ap,
+                                                const double* bp, int dim, int lane, int kind) {
+  double acc = 0.0;
+  for (int i = lane; i < dim; i += 64) {
+    acc = wave_norm_accum(acc, aq[i] - bq[i], kind);
+    acc = wave_norm_accum(acc, ap[i] - bp[i], kind);
+  }
+  return wave_norm_finish(acc, kind);
+}
+
+// x = fixed point of x_init + tt * (dh_dmom(x), -dh_dpos(x)) started at x_init (L.xiq, L.xip); the
+// solution is left in (L.ptq, L.ptp).  solve_fixed_point_direct / _steffensen (solvers.py:47-154).
+__device__ __forceinline__ int midpoint_solve(const EuclidModelView& m, const MidpointLds& L, double tt,
+                                              const mm_fp_opts& o, int lane, long long* n_evals) {
+  const int dim = m.dim;
+  for (int i = lane; i < dim; i += 64) {
+    L.x0q[i] = L.xiq[i];
+    L.x0p[i] = L.xip[i];
+    L.ptq[i] = L.xiq[i];
+    L.ptp[i] = L.xip[i];
+  }
+  wave_sync();
+  int stage = 0;
+  for (int iter = 0; iter < o.max_iters;) {
+    // f(pt) -> (tmp holds M^-1 p first), result overwrites pt
+    const TargetAux aux = target_prepare(m.target, L.ptq, dim, m.tparams, lane);
+    for (int i = lane; i < dim; i += 64) L.tmp[i] = minv_elem(m, L.ptp, i);
+    wave_sync();
+    for (int i = lane; i < dim; i += 64) {
+      const double g = target_grad_elem(m.target, aux, L.ptq, i, dim, m.tparams);
+      L.ptp[i] = L.xip[i] - tt * g;
+    }
+    wave_sync();  // every lane has read ptq before it is overwritten
+    for (int i = lane; i < dim; i += 64) L.ptq[i] = L.xiq[i] + tt * L.tmp[i];
+    wave_sync();
+    *n_evals += 1;
+    if (o.solver != MM_FP_DIRECT) {
+      if (stage == 0) {  // x1 = f(x0); evaluate f(x1) next
+        for (int i = lane; i < dim; i += 64) {
+          L.x1q[i] = L.ptq[i];
+          L.x1p[i] = L.ptp[i];
+        }
+        stage = 1;
+        wave_sync();
+        continue;
+      }
+      const double eps = 2.220446049250313e-16;
+      for (int i = lane; i < dim; i += 64) {
+        double dq = L.ptq[i] - 2.0 * L.x1q[i] + L.x0q[i], dp = L.ptp[i] - 2.0 * L.x1p[i] + L.x0p[i];
+        if (fabs(dq) == 0.0) dq = eps;
+        if (fabs(dp) == 0.0) dp = eps;
+        const double eq = L.x1q[i] - L.x0q[i], ep = L.x1p[i] - L.x0p[i];
+        L.ptq[i] = L.x0q[i] - eq * eq / dq;
+        L.ptp[i] = L.x0p[i] - ep * ep / dp;
+      }
+      stage = 0;
+      wave_sync();
+    }
+    const double err = pair_norm_lds(L.ptq, L.x0q, L.ptp, L.x0p, dim, lane, o.norm);
+    if (err > o.div_tol || err != err) return MM_ST_DIVERGED;
+    if (err < o.conv_tol) return MM_ST_OK;
+    for (int i = lane; i < dim; i += 64) {
+      L.x0q[i] = L.ptq[i];
+      L.x0p[i] = L.ptp[i];
+    }
+    wave_sync();
+    ++iter;
+  }
+  return MM_ST_MAX_ITERS;
+}
+
+__global__ void midpoint_euclid_kernel(EuclidModelView m, double* __restrict__ pos, double* __restrict__ mom,
+                                       const int8_t* __restrict__ dir, int32_t* __restrict__ status,
+                                       int32_t* __restrict__ n_done, int64_t n_chains, double step_size,
+                                       int n_steps, mm_fp_opts o, mm_counters* counters) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dim = m.dim;
+  const int64_t chain = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (chain >= n_chains) return;
+  double* b = lds + (size_t)wave * 11 * dim;
+  const MidpointLds L{b,           b + dim,     b + 2 * dim, b + 3 * dim, b + 4 * dim, b + 5 * dim,
+                      b + 6 * dim, b + 7 * dim, b + 8 * dim, b + 9 * dim, b + 10 * dim};
+  for (int i = lane; i < dim; i += 64) {
+    L.q[i] = pos[chain * dim + i];
+    L.p[i] = mom[chain * dim + i];
+  }
+  wave_sync();
+  const double half = 0.5 * (double)dir[chain] * step_size;
+  int st = MM_ST_OK, done = 0;
+  long long n_evals = 0, n_solves = 0, n_grad = 0;
+  for (int s = 0; s < n_steps; ++s) {
+    // A(t/2): implicit Euler half step
+    for (int i = lane; i < dim; i += 64) {
+      L.xiq[i] = L.q[i];
+      L.xip[i] = L.p[i];
+    }
+    wave_sync();
+    ++n_solves;
+    st = midpoint_solve(m, L, half, o, lane, &n_evals);
+    if (st != MM_ST_OK) break;
+    // A*(t/2): explicit Euler half step from (q1, p1) = pt; keep (q1, p1) in x1 for the check
+    {
+      const TargetAux aux = target_prepare(m.target, L.ptq, dim, m.tparams, lane);
+      for (int i = lane; i < dim; i += 64) L.tmp[i] = minv_elem(m, L.ptp, i);
+      wave_sync();
+      ++n_grad;
+      for (int i = lane; i < dim; i += 64) {
+        const double g = target_grad_elem(m.target, aux, L.ptq, i, dim, m.tparams);
+        L.xiq[i] = L.ptq[i] + half * L.tmp[i];
+        L.xip[i] = L.ptp[i] - half * g;
+      }
+      wave_sync();
+    }
+    // reversibility check: A(-t/2) from the new state must return to (q1, p1), kept in registers across
+    // the solve (dim <= 128: a lane holds at most two elements)
+    double q1r[2], p1r[2];
+    for (int k = 0, i = lane; i < dim; i += 64, ++k) {
+      q1r[k] = L.ptq[i];
+      p1r[k] = L.ptp[i];
+    }
+    ++n_solves;
+    st = midpoint_solve(m, L, -half, o, lane, &n_evals);
+    if (st != MM_ST_OK) break;
+    {
+      double acc = 0.0;
+      for (int k = 0, i = lane; i < dim; i += 64, ++k) {
+        acc = wave_norm_accum(acc, L.ptq[i] - q1r[k], o.rev_norm);
+        acc = wave_norm_accum(acc, L.ptp[i] - p1r[k], o.rev_norm);
+      }
+      const double rev = wave_norm_finish(acc, o.rev_norm);
+      if (rev > o.rev_tol) {
+        st = MM_ST_NON_REVERSIBLE;
+        break;
+      }
+    }
+    for (int i = lane; i < dim; i += 64) {
+      L.q[i] = L.xiq[i];
+      L.p[i] = L.xip[i];
+    }
+    wave_sync();
+    ++done;
+  }
+  wave_sync();
+  for (int i = lane; i < dim; i += 64) {
+    pos[chain * dim + i] = L.q[i];
+    mom[chain * dim + i] = L.p[i];
+  }
+  if (lane == 0) {
+    status[chain] = st;
+    n_done[chain] = done;
+    if (counters) {
+      atomicAdd((unsigned long long*)&counters->n_fp_evals, (unsigned long long)n_evals);
+      atomicAdd((unsigned long long*)&counters->n_fp_solves, (unsigned long long)n_solves);
+      atomicAdd((unsigned long long*)&counters->n_grad, (unsigned long long)(n_evals + n_grad));
+    }
+  }
+}
+
+int mm_launch_implicit_midpoint_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                                       const mm_fp_opts& opts, mm_counters* d_counters) {
+  if (s->dim > 128) {
+    mm_set_error(ctx, "mm_implicit_midpoint: Euclidean systems are supported for dim <= 128");
+    return MM_ERR_UNSUPPORTED;
+  }
+  const size_t per_wave = (size_t)11 * s->dim * sizeof(double);
+  int w = (int)(60 * 1024 / per_wave);
+  w = w > 4 ? 4 : (w < 1 ? 1 : w);
+  const unsigned blocks = (unsigned)((s->n + w - 1) / w);
+  hipLaunchKernelGGL(midpoint_euclid_kernel, dim3(blocks), dim3(64 * w), w * per_wave, ctx->stream, view_of(m),
+                     s->d_pos, s->d_mom, s->d_dir, s->d_status, s->d_n_done, s->n, h, n_steps, opts, d_counters);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
 // Metropolis accept / select (transitions.py:296-314): one wave per chain; lane 0 decides, all lanes copy.
 __global__ void metropolis_select_kernel(double* __restrict__ pos, double* __restrict__ mom,
                                          int8_t* __restrict__ dir, const double* __restrict__ ppos,

@@ -14,6 +14,10 @@
 // launchers living in other translation units
 int mm_launch_leapfrog_generic(mm_ctx*, const mm_model*, mm_state*, double, int);
 int mm_launch_composition_generic(mm_ctx*, const mm_model*, mm_state*, double, int, int, const double*, int);
+int mm_launch_implicit_midpoint_euclid(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
+                                       mm_counters*);
+int mm_launch_implicit_midpoint_riemann(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
+                                        mm_counters*);
 int mm_launch_metropolis_select(mm_ctx*, mm_state*, mm_state*, const double*, const double*, const double*, double*,
                                 int8_t*);
 int mm_launch_euclid_hamiltonian(mm_ctx*, const mm_model*, mm_state*, double*);
@@ -472,6 +476,27 @@ int mm_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, 
   MM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(mm_counters), ctx->stream));
   if (s->n > 0) {
     rc = mm_launch_implicit_leapfrog(ctx, m, s, h, n_steps, o, ctx->d_counters);
+    if (rc != MM_OK) return rc;
+  }
+  return finish_counters(ctx, counters);
+}
+
+int mm_implicit_midpoint(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int32_t n_steps,
+                         const mm_fp_opts* opts, mm_counters* counters) {
+  int rc = check_pair(ctx, m, s, "mm_implicit_midpoint");
+  if (rc != MM_OK) return rc;
+  MM_REQUIRE(ctx, m->constr == MM_CONSTR_NONE, "mm_implicit_midpoint: constrained systems are not supported");
+  MM_REQUIRE(ctx, n_steps >= 0, "mm_implicit_midpoint: n_steps < 0");
+  mm_fp_opts o = {1e-9, 1e10, 100, MM_NORM_LINF, MM_FP_DIRECT, MM_NORM_LINF, 2e-8};
+  if (opts) o = *opts;
+  MM_REQUIRE(ctx, o.max_iters >= 0 && (o.norm == 0 || o.norm == 1) && (o.rev_norm == 0 || o.rev_norm == 1) &&
+                      (o.solver == MM_FP_DIRECT || o.solver == MM_FP_STEFFENSEN),
+             "mm_implicit_midpoint: bad solver options");
+  MM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(mm_counters), ctx->stream));
+  if (s->n > 0) {
+    rc = (m->rmetric != MM_RMETRIC_NONE)
+             ? mm_launch_implicit_midpoint_riemann(ctx, m, s, h, n_steps, o, ctx->d_counters)
+             : mm_launch_implicit_midpoint_euclid(ctx, m, s, h, n_steps, o, ctx->d_counters);
     if (rc != MM_OK) return rc;
   }
   return finish_counters(ctx, counters);

@@ -218,6 +218,36 @@ class ImplicitLeapfrogIntegrator(Integrator):
         return batch.download_status()
 
 
+class ImplicitMidpointIntegrator(ImplicitLeapfrogIntegrator):
+    """Implicit midpoint integrator for general Hamiltonians (reference integrators.py:547-681): implicit
+    Euler half step (fixed point in the concatenated (pos, mom) vector), explicit Euler half step,
+    reversibility check.  Device support: Euclidean-metric systems (dim <= 128) and dense-Riemannian systems
+    (dim <= 64).  Same constructor arguments and solver options as :py:class:`ImplicitLeapfrogIntegrator`."""
+
+    _needs = None  # euclid or riemann
+
+    def __init__(self, system, step_size=None, reverse_check_tol=2e-8,
+                 reverse_check_norm=solvers.maximum_norm,
+                 fixed_point_solver=solvers.solve_fixed_point_direct, fixed_point_solver_kwargs=None):
+        if getattr(system, "_kind", None) not in ("euclid", "riemann"):
+            raise ValueError(f"ImplicitMidpointIntegrator needs a Euclidean- or Riemannian-metric system, got "
+                             f"{type(system).__name__}")
+        Integrator.__init__(self, system, step_size)
+        self.reverse_check_tol = reverse_check_tol
+        self.reverse_check_norm = reverse_check_norm
+        self.fixed_point_solver = fixed_point_solver
+        self.fixed_point_solver_kwargs = dict(fixed_point_solver_kwargs or {})
+
+    def _launch(self, ctx, model, batch, n_steps):
+        opts = self._opts()
+        counters = _ffi.Counters()
+        _ffi.check(ctx._lib.mm_implicit_midpoint(ctx.handle, model.handle, batch.handle,
+                                                 float(self.step_size), n_steps, C.byref(opts),
+                                                 C.byref(counters)),
+                   ctx.handle, "mm_implicit_midpoint")
+        self.last_counters = counters.as_dict()
+
+
 class ConstrainedLeapfrogIntegrator(Integrator):
     """Constrained leapfrog with Newton projection onto the manifold and reversibility check
     (reference integrators.py:684-984)."""

@@ -527,6 +527,70 @@ def implicit_leapfrog_steps(system, q, p, dt, n_steps, **kw):
     return st.pos, st.mom, status, n_done
 
 
+# ---- implicit midpoint integrator (integrators.py:547-681) ---------------------------------------------------
+def _midpoint_dh(system, q, p):
+    """(dh_dmom, dh_dpos) at (q, p) for a Euclidean-metric or Riemannian-metric oracle system
+    (System.dh_dmom / dh_dpos, systems.py:198-224: dh1_dpos + dh2_dpos)."""
+    if isinstance(system, RiemannianSystem):
+        st = _State(q, p)
+        return system.dh2_dmom(st), system.dh1_dpos(st) + system.dh2_dpos(st)
+    return system.minv(p), system.grad(q)
+
+
+def implicit_midpoint_step(system, q, p, dt, fp_solver=solve_fixed_point_direct, rev_tol=2e-8,
+                           rev_norm=maximum_norm, fp_kwargs=None):
+    """One ImplicitMidpointIntegrator._step (integrators.py:634-681): implicit Euler half step A(t/2)
+    solved as a fixed point in the concatenated (pos, mom) vector, explicit Euler half step A*(t/2), then
+    the reversibility check (another implicit half step backwards from the new state)."""
+    fp_kwargs = dict(fp_kwargs or {})
+    counters = getattr(system, "counters", None)
+    if counters is not None:
+        fp_kwargs.setdefault("counters", counters)
+    d = q.shape[0]
+
+    def a_fwd(q0, p0, t):
+        x_init = np.concatenate([q0, p0])
+
+        def func(x):
+            dq, dp = _midpoint_dh(system, x[:d], x[d:])
+            return x_init + np.concatenate([t * dq, -t * dp])
+
+        if counters is not None:
+            counters.bump("fp_solves")
+        x = fp_solver(func, x_init, **fp_kwargs)
+        return x[:d], x[d:]
+
+    half = dt / 2
+    q1, p1 = a_fwd(q, p, half)
+    dq, dp = _midpoint_dh(system, q1, p1)
+    q2, p2 = q1 + half * dq, p1 - half * dp
+    qb, pb = a_fwd(q2, p2, -half)
+    rev_diff = rev_norm(np.concatenate([qb - q1, pb - p1]))
+    if rev_diff > rev_tol:
+        raise NonReversibleStepError(f"Non-reversible step. Distance between initial and forward-backward "
+                                     f"integrated (pos, mom) pairs = {rev_diff:.1e}.")
+    return q2, p2
+
+
+def implicit_midpoint_steps(system, q, p, dt, n_steps, **kw):
+    """Run up to n_steps; returns (q, p, status, n_done), frozen at the last completed step on failure."""
+    q = np.array(q, dtype=np.float64)
+    p = np.array(p, dtype=np.float64)
+    status, n_done = ST_OK, 0
+    for _ in range(n_steps):
+        try:
+            q2, p2 = implicit_midpoint_step(system, q, p, dt, **kw)
+        except IntegratorError as e:
+            status = e.status
+            break
+        except LinAlgError:
+            status = ST_LINALG
+            break
+        q, p = q2, p2
+        n_done += 1
+    return q, p, status, n_done
+
+
 # ---- constrained system (systems.py:619-873, 876-1031) ----------------------------------------------
 class ConstrainedSystem(EuclidSystem):
     """DenseConstrainedEuclideanMetricSystem, dens_wrt_hausdorff=True (the default)."""

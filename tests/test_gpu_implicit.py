@@ -262,6 +262,49 @@ def test_alternative_kernels_selected_by_env(kernel):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("name", golden_names("midpoint"))
+def test_implicit_midpoint_matches_reference_fixture(name):
+    """ImplicitMidpointIntegrator (integrators.py:547-681): status, completed steps and state of every chain."""
+    g = load_golden(name)
+    n, d = g["q0"].shape
+    target = models.target_from_id(g["target"], g["target_params"], d)
+    if str(g["system"]) == "euclid":
+        mk = int(g["metric_kind"])
+        system = systems.EuclideanMetricSystem(target, metric=None if mk == models.METRIC_IDENTITY else g["metric"])
+    else:
+        system = systems.DenseRiemannianMetricSystem(target, models.rmetric_from_id(g["rmetric"], g["rmetric_params"], d))
+    norm = {0: solvers.maximum_norm, 1: solvers.euclidean_norm}[int(g["norm"])]
+    fps = {0: solvers.solve_fixed_point_direct, 1: solvers.solve_fixed_point_steffensen}[int(g["fp_solver"])]
+    integ = integrators.ImplicitMidpointIntegrator(
+        system, float(g["step_size"]), reverse_check_norm=norm, fixed_point_solver=fps,
+        fixed_point_solver_kwargs=dict(norm=norm, convergence_tol=float(g["fp_conv_tol"]),
+                                       divergence_tol=float(g["fp_div_tol"]), max_iters=int(g["fp_max_iters"])))
+    for k, s in enumerate(int(s) for s in g["checkpoints"]):
+        q, p, status, n_done = integ.step_batch(g["q0"], g["p0"], g["dir"], n_steps=s)
+        assert np.array_equal(n_done, np.minimum(s, g["n_done"])), f"{name} n_done@{s}"
+        assert np.array_equal(status, np.where(g["n_done"] >= s, 0, g["status"])), f"{name} status@{s}"
+        assert_close(q, g["q_out"][k], 1e-8, f"{name} q@{s}")
+        assert_close(p, g["p_out"][k], 1e-8, f"{name} p@{s}")
+    if np.all(g["status"] == 0):  # time reversibility (tests/test_integrators.py:75-91)
+        s = int(g["checkpoints"][-1])
+        q, p, _, _ = integ.step_batch(g["q0"], g["p0"], g["dir"], n_steps=s)
+        qb, pb, sb, _ = integ.step_batch(q, p, -g["dir"], n_steps=s)
+        assert np.all(sb == 0)
+        assert_close(qb, g["q0"], 1e-6, "reversed q")
+        assert_close(pb, g["p0"], 1e-6, "reversed p")
+
+
+def test_implicit_midpoint_unsupported_systems_fail_loudly():
+    from mici_amd.errors import DeviceError
+    system = systems.DenseRiemannianMetricSystem(models.Banana(70), models.Rank1Metric(omdl.make_spd(70, np.random.default_rng(0))))
+    integ = integrators.ImplicitMidpointIntegrator(system, 0.01)
+    with pytest.raises(DeviceError):
+        integ.step_batch(np.zeros((1, 70)), np.ones((1, 70)), 1, n_steps=1)
+    with pytest.raises(ValueError):
+        integrators.ImplicitMidpointIntegrator(
+            systems.DenseConstrainedEuclideanMetricSystem(models.Torus(), models.TorusConstr()), 0.1)
+
+
 def test_unsupported_sizes_fail_loudly():
     from mici_amd.errors import DeviceError
     rng = np.random.default_rng(0)

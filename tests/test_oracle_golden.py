@@ -94,6 +94,31 @@ def test_metropolis_static_transitions(name):
                 assert_close(float(st[k]), g[f"stat_{k}"][t, c], 1e-10, f"{name} {k}")
 
 
+@pytest.mark.parametrize("name", golden_names("midpoint"))
+def test_implicit_midpoint(name):
+    """ImplicitMidpointIntegrator (integrators.py:547-681) on Euclidean and dense-Riemannian systems."""
+    g = load_golden(name)
+    n, d = g["q0"].shape
+    target = mdl.target_from_id(g["target"], g["target_params"], d)
+    if str(g["system"]) == "euclid":
+        mk = int(g["metric_kind"])
+        system = orc.EuclidSystem(target, mk, None if mk == mdl.METRIC_IDENTITY else g["metric"])
+    else:
+        system = orc.RiemannianSystem(target, mdl.rmetric_from_id(g["rmetric"], g["rmetric_params"], d), None)
+    norm = orc.NORMS[int(g["norm"])]
+    kw = dict(fp_solver=orc.FP_SOLVERS[int(g["fp_solver"])], rev_norm=norm,
+              fp_kwargs=dict(norm=norm, convergence_tol=float(g["fp_conv_tol"]),
+                             divergence_tol=float(g["fp_div_tol"]), max_iters=int(g["fp_max_iters"])))
+    h = float(g["step_size"])
+    for k, s in enumerate(int(s) for s in g["checkpoints"]):
+        for c in range(n):
+            q, p, st, nd = orc.implicit_midpoint_steps(system, g["q0"][c], g["p0"][c], g["dir"][c] * h, s, **kw)
+            assert nd == min(s, g["n_done"][c])
+            assert st == (0 if g["n_done"][c] >= s else g["status"][c])
+            assert_close(q, g["q_out"][k, c], 1e-9, f"{name} q@{s}")
+            assert_close(p, g["p_out"][k, c], 1e-9, f"{name} p@{s}")
+
+
 def _riemann_system(g, counters=None):
     n, d = g["q0"].shape
     target = mdl.target_from_id(g["target"], g["target_params"], d)

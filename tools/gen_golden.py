@@ -162,6 +162,35 @@ def symcomp_case(name, target, metric_kind, metric, q0, p0, dirs, h, checkpoints
     ), counts
 
 
+def midpoint_case(name, ref_system, osys, extra, q0, p0, dirs, h, checkpoints, fp_solver=0, norm=0,
+                  fp_kwargs=None):
+    """ImplicitMidpointIntegrator (integrators.py:547-681) on a Euclidean or dense-Riemannian system."""
+    fp_kwargs = fp_kwargs or {}
+    ref_solvers = {0: mici.solvers.solve_fixed_point_direct, 1: mici.solvers.solve_fixed_point_steffensen}
+    ref_norms = {0: mici.solvers.maximum_norm, 1: mici.solvers.euclidean_norm}
+    ref_kwargs = dict(fp_kwargs)
+    ref_kwargs["norm"] = ref_norms[norm]
+    integrator = mici.integrators.ImplicitMidpointIntegrator(
+        ref_system, h, reverse_check_norm=ref_norms[norm], fixed_point_solver=ref_solvers[fp_solver],
+        fixed_point_solver_kwargs=ref_kwargs)
+    ref, counts = run_reference(integrator, ref_system, q0, p0, dirs, checkpoints)
+    okw = dict(fp_solver=orc.FP_SOLVERS[fp_solver], rev_norm=orc.NORMS[norm],
+               fp_kwargs=dict(fp_kwargs, norm=orc.NORMS[norm]))
+    n = q0.shape[0]
+    for k, s in enumerate(checkpoints):
+        for c in range(n):
+            q, p, st, nd = orc.implicit_midpoint_steps(osys, q0[c], p0[c], dirs[c] * h, s, **okw)
+            assert st == (ref["status"][c] if ref["n_done"][c] < s else 0) or ref["n_done"][c] >= s, (name, st)
+            assert nd == min(s, ref["n_done"][c]), (name, nd, ref["n_done"][c])
+            check_close(f"{name} q@{s}", q, ref["q_out"][k, c], 1e-9)
+            check_close(f"{name} p@{s}", p, ref["p_out"][k, c], 1e-9)
+    full = dict(convergence_tol=1e-9, divergence_tol=1e10, max_iters=100)
+    full.update(fp_kwargs)
+    return dict(kind="midpoint", q0=q0, p0=p0, dir=dirs, step_size=h, checkpoints=np.array(checkpoints),
+                fp_solver=fp_solver, norm=norm, fp_conv_tol=full["convergence_tol"],
+                fp_div_tol=full["divergence_tol"], fp_max_iters=full["max_iters"], **extra, **ref), counts
+
+
 class RecordingRng:
     """Wraps a numpy Generator and logs what the reference draws (transition fixtures)."""
 
@@ -598,6 +627,56 @@ def main():
 
     add_transition_constrained("transition_constrained_torus", 6, 0.3, 4, 6, 6000)
     add_transition_constrained("transition_constrained_torus_bigstep", 6, 1.2, 3, 6, 7000)
+
+    # ---- implicit midpoint integrator ------------------------------------------------
+    def add_midpoint_euclid(name, target, mk, metric, n, h, cps, **kw):
+        q0 = rng.standard_normal((n, target.dim))
+        osys = orc.EuclidSystem(target, mk, metric)
+        p0 = np.stack([osys.msqrt(zz) for zz in rng.standard_normal((n, target.dim))])
+
+        def make():
+            rsys = mici.systems.EuclideanMetricSystem(
+                neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+                metric=None if mk == mdl.METRIC_IDENTITY else np.array(metric))
+            return midpoint_case(name, rsys, osys, model_keys(target, mk, metric, system="euclid"), q0, p0,
+                                 dirs_for(n), h, cps, **kw)
+        cases[name] = make
+
+    def add_midpoint_riemann(name, target, rmetric, n, h, cps, qscale=1.0, **kw):
+        q0 = qscale * rng.standard_normal((n, target.dim))
+        osys = orc.RiemannianSystem(target, rmetric, None)
+        p0 = np.stack([osys.sample_momentum(orc._State(q0[c], None), zz)
+                       for c, zz in enumerate(rng.standard_normal((n, target.dim)))])
+
+        def make():
+            rsys = mici.systems.DenseRiemannianMetricSystem(
+                neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+                metric_func=rmetric.metric_func, vjp_metric_func=rmetric.vjp_metric_func)
+            return midpoint_case(name, rsys, osys, dict(system="riemann", target=target.tid,
+                                                        target_params=target.params(), rmetric=rmetric.mid,
+                                                        rmetric_params=rmetric.params()),
+                                 q0, p0, dirs_for(n), h, cps, **kw)
+        cases[name] = make
+
+    for size in (1, 2, 5):  # the reference's own test systems (tests/test_integrators.py:236-253, 492-516)
+        eigval = np.exp(0.1 * rng.standard_normal(size))
+        eigvec = np.linalg.qr(rng.standard_normal((size, size)))[0]
+        add_midpoint_euclid(f"midpoint_euclid_quartic_dense_d{size}", mdl.Poly(size, 0.0, 1.0), mdl.METRIC_DENSE,
+                            (eigvec * eigval) @ eigvec.T, 4, 0.1, [1, 5, 20])
+        add_midpoint_riemann(f"midpoint_riemann_diagquad_poly_d{size}", mdl.Poly(size, 1.0, 1.0 / 3.0),
+                             mdl.DiagQuadMetric(size), 4, 0.1, [1, 5, 20])
+    add_midpoint_euclid("midpoint_euclid_dense_d24", mdl.GaussDense(mdl.make_spd(24, rng)), mdl.METRIC_DIAG,
+                        np.exp(0.2 * rng.standard_normal(24)), 4, 0.3, [1, 10])
+    add_midpoint_euclid("midpoint_euclid_quartic_d5_steffensen_l2", mdl.Poly(5, 0.0, 1.0), mdl.METRIC_IDENTITY, None,
+                        4, 0.2, [1, 10], fp_solver=1, norm=1)
+    add_midpoint_euclid("midpoint_euclid_quartic_d3_fail_bigstep", mdl.Poly(3, 0.0, 1.0), mdl.METRIC_IDENTITY, None,
+                        8, 2.5, [1, 4])
+    add_midpoint_riemann("midpoint_riemann_rank1_banana_d40", mdl.Banana(40), mdl.Rank1Metric(mdl.make_spd(40, rng)),
+                         4, 0.02, [1, 5])
+    add_midpoint_riemann("midpoint_riemann_rank1_poly_d12", mdl.Poly(12, 1.0, 1.0 / 3.0),
+                         mdl.Rank1Metric(mdl.make_spd(12, rng)), 4, 0.1, [1, 10])
+    add_midpoint_riemann("midpoint_riemann_diagquad_d5_fail_bigstep", mdl.Poly(5, 1.0, 1.0 / 3.0),
+                         mdl.DiagQuadMetric(5), 8, 0.9, [1, 4], qscale=1.5)
 
     all_counts = {}
     for name, fn in cases.items():
