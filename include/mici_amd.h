@@ -177,6 +177,12 @@ int mm_state_download_status(mm_state* state, int32_t* status, int32_t* n_done);
 /* raw device pointers (zero-copy interop / RCCL): any of the outputs may be NULL */
 int mm_state_device_ptrs(mm_state* state, double** pos, double** mom, int8_t** dir);
 
+/* Per-chain step sizes (step-size adaptation runs every chain at its own step size; the reference keeps one
+ * integrator copy per chain, adapters.py:322-340, samplers.py:1124-1129): scale[N] (host) multiplies the
+ * step_size argument of every integrator entry point for this state, i.e. pass step_size = 1 and the step
+ * sizes as scale.  NULL removes the factors.  mm_state_copy propagates them. */
+int mm_state_set_step_scale(mm_state* state, const double* scale);
+
 /* device-to-device copy of pos, mom, dir, status, n_done (same n_chains and dim): the proposal copy of
  * Integrator.step / state.copy() (integrators.py:78, states.py:263-279) without a host round trip */
 int mm_state_copy(mm_state* dst, const mm_state* src);

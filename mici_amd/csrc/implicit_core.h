@@ -26,6 +26,7 @@ struct ImplicitArgs {
   double* pos;
   double* mom;
   const int8_t* dir;
+  const double* step_scale;  // per-chain step-size factors or nullptr
   int32_t* status;
   int32_t* n_done;
   int64_t n_chains;

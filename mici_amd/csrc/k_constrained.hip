@@ -21,6 +21,7 @@ struct ConArgs {
   double* pos;
   double* mom;
   const int8_t* dir;
+  const double* step_scale;
   int32_t* status;
   int32_t* n_done;
   int64_t n_chains;
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void constrained_leapfrog_kernel(ConArgs A) {
     q.v[i] = A.pos[chain * D + i];
     p.v[i] = A.mom[chain * D + i];
   }
-  const double t = (double)A.dir[chain] * A.step_size;
+  const double t = mmdev::signed_step(A.dir, A.step_scale, chain, A.step_size);
   const int n_inner = A.opts.n_inner;
   const double t_in = t / n_inner;
   long long n_newton = 0, n_grad = 0;
@@ -377,6 +378,7 @@ ConArgs make_args(const mm_model* m, mm_state* s) {
   a.pos = s->d_pos;
   a.mom = s->d_mom;
   a.dir = s->d_dir;
+  a.step_scale = s->d_step_scale;
   a.status = s->d_status;
   a.n_done = s->d_n_done;
   a.n_chains = s->n;

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "mm_internal.h"
+#include "mm_device.h"
 
 namespace {
 
@@ -40,7 +41,8 @@ __device__ __forceinline__ double elem_grad(double q, double tp0, double tp1) {
 template <int TARGET, int METRIC, int VEC>
 __global__ __launch_bounds__(256) void leapfrog_elem_kernel(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    int64_t n_chains, int dim, double step_size, int n_steps, const double* __restrict__ tparams,
+    const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
+    const double* __restrict__ tparams,
     const double* __restrict__ minv_diag) {
   const int vec_per_chain = dim / VEC;
   const int64_t total = n_chains * vec_per_chain;
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void leapfrog_elem_kernel(
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t chain = idx / vec_per_chain;
     const int d0 = (int)(idx - chain * vec_per_chain) * VEC;
-    const double t = (double)dir[chain] * step_size;
+    const double t = mmdev::signed_step(dir, step_scale, chain, step_size);
     const double ht = 0.5 * t;
     double q[VEC], p[VEC], g[VEC], tp0[VEC], tp1[VEC], mi[VEC];
     const int64_t off = chain * dim + d0;
@@ -143,7 +145,8 @@ __device__ __forceinline__ void tile_times_slabs(const double* __restrict__ tile
 template <int DP, int CT, int TARGET, int METRIC>
 __global__ __launch_bounds__(DP * 4 / CT) void leapfrog_mfma_kernel(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    int64_t n_chains, int dim, double step_size, int n_steps, const double* __restrict__ tparams,
+    const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
+    const double* __restrict__ tparams,
     const double* __restrict__ minv) {
   using Cfg = MfmaCfg<DP, CT>;
   __shared__ __attribute__((aligned(16))) double lds[(METRIC == M_DENSE ? 4 : 2) * Cfg::TILE];
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(DP * 4 / CT) void leapfrog_mfma_kernel(
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t chain = chain0 + (lane >> 4) + 4 * r;
-    t[r] = (chain < n_chains) ? (double)dir[chain] * step_size : 0.0;
+    t[r] = (chain < n_chains) ? mmdev::signed_step(dir, step_scale, chain, step_size) : 0.0;
     ht[r] = 0.5 * t[r];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -272,11 +275,11 @@ int launch_elem(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_ste
   if (blocks < 1) blocks = 1;
   if (vec2)
     hipLaunchKernelGGL((leapfrog_elem_kernel<TARGET, METRIC, 2>), dim3((unsigned)blocks), dim3(256),
-                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->n, dim, h, n_steps,
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, dim, h, n_steps,
                        m->d_target_params, m->d_metric_inv);
   else
     hipLaunchKernelGGL((leapfrog_elem_kernel<TARGET, METRIC, 1>), dim3((unsigned)blocks), dim3(256),
-                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->n, dim, h, n_steps,
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, dim, h, n_steps,
                        m->d_target_params, m->d_metric_inv);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
@@ -286,7 +289,7 @@ template <int DP, int CT, int TARGET, int METRIC>
 int launch_mfma_dp(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
   const unsigned blocks = (unsigned)((s->n + 15) / 16);
   hipLaunchKernelGGL((leapfrog_mfma_kernel<DP, CT, TARGET, METRIC>), dim3(blocks),
-                     dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->n, s->dim, h,
+                     dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, s->dim, h,
                      n_steps, m->d_target_params, m->d_metric_inv);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_leapfrog_kernel(Implicit
   const bool act = lane < dim;
   double q = act ? A.pos[chain * dim + lane] : 0.0;
   double p = act ? A.mom[chain * dim + lane] : 0.0;
-  const double t = (double)A.dir[chain] * A.step_size;
+  const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
 
   WaveBackend<TS, RMETRIC> bk;
   bk.dim = dim;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_midpoint_kernel(Implicit
   bk.tparams = A.tparams;
   bk.slot(MP_Q) = act ? A.pos[chain * dim + lane] : 0.0;
   bk.slot(MP_P) = act ? A.mom[chain * dim + lane] : 0.0;
-  const double t = (double)A.dir[chain] * A.step_size;
+  const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
   const ChainResult r = implicit_midpoint_chain(bk, t, A.n_steps, A.opts);
   if (act) {  // a failed step leaves the last completed state
     A.pos[chain * dim + lane] = bk.slot(MP_Q);
@@ -581,6 +581,7 @@ ImplicitArgs make_args(const mm_model* m, mm_state* s) {
   a.pos = s->d_pos;
   a.mom = s->d_mom;
   a.dir = s->d_dir;
+  a.step_scale = s->d_step_scale;
   a.status = s->d_status;
   a.n_done = s->d_n_done;
   a.n_chains = s->n;

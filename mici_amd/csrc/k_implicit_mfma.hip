@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs
   const bool act = lane < dim;
   double q = act ? A.pos[chain * dim + lane] : 0.0;
   double p = act ? A.mom[chain * dim + lane] : 0.0;
-  const double t = (double)A.dir[chain] * A.step_size;
+  const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
 
   MfmaBackend<RMETRIC> bk;
   bk.dim = dim;
@@ -477,6 +477,7 @@ int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
   a.pos = s->d_pos;
   a.mom = s->d_mom;
   a.dir = s->d_dir;
+  a.step_scale = s->d_step_scale;
   a.status = s->d_status;
   a.n_done = s->d_n_done;
   a.n_chains = s->n;

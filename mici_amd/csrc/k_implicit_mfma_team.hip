@@ -418,7 +418,7 @@ __global__ __launch_bounds__(NTHR, 2) void implicit_mfma_team_kernel(ImplicitArg
   const bool act = tid < dim;
   double q = act ? A.pos[chain * dim + tid] : 0.0;
   double p = act ? A.mom[chain * dim + tid] : 0.0;
-  const double t = (double)A.dir[chain] * A.step_size;
+  const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
   const ChainResult r = implicit_leapfrog_chain(bk, t, A.n_steps, A.opts);
@@ -463,6 +463,7 @@ int mm_launch_implicit_mfma_team(mm_ctx* ctx, const mm_model* m, mm_state* s, do
   a.pos = s->d_pos;
   a.mom = s->d_mom;
   a.dir = s->d_dir;
+  a.step_scale = s->d_step_scale;
   a.status = s->d_status;
   a.n_done = s->d_n_done;
   a.n_chains = s->n;

@@ -30,7 +30,8 @@ __device__ __forceinline__ double minv_elem(const EuclidModelView& m, const doub
 // dynamic LDS: per wave 3*dim doubles (q, p, scratch)
 __global__ void leapfrog_generic_kernel(EuclidModelView m, double* __restrict__ pos,
                                         double* __restrict__ mom, const int8_t* __restrict__ dir,
-                                        int64_t n_chains, double step_size, int n_steps) {
+                                        const double* __restrict__ step_scale, int64_t n_chains,
+                                        double step_size, int n_steps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dim = m.dim;
@@ -43,7 +44,7 @@ __global__ void leapfrog_generic_kernel(EuclidModelView m, double* __restrict__ 
     q[i] = pos[chain * dim + i];
     p[i] = mom[chain * dim + i];
   }
-  const double t = (double)dir[chain] * step_size, ht = 0.5 * t;
+  const double t = signed_step(dir, step_scale, chain, step_size), ht = 0.5 * t;
   wave_sync();
   TargetAux aux = target_prepare(m.target, q, dim, m.tparams, lane);
   for (int i = lane; i < dim; i += 64) g[i] = target_grad_elem(m.target, aux, q, i, dim, m.tparams);
@@ -78,7 +79,8 @@ struct CompCoefs {
 
 __global__ void composition_generic_kernel(EuclidModelView m, double* __restrict__ pos,
                                            double* __restrict__ mom, const int8_t* __restrict__ dir,
-                                           int64_t n_chains, double step_size, int n_steps, CompCoefs cf) {
+                                           const double* __restrict__ step_scale, int64_t n_chains,
+                                           double step_size, int n_steps, CompCoefs cf) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dim = m.dim;
@@ -91,7 +93,7 @@ __global__ void composition_generic_kernel(EuclidModelView m, double* __restrict
     q[i] = pos[chain * dim + i];
     p[i] = mom[chain * dim + i];
   }
-  const double t = (double)dir[chain] * step_size;
+  const double t = signed_step(dir, step_scale, chain, step_size);
   wave_sync();
   TargetAux aux = target_prepare(m.target, q, dim, m.tparams, lane);
   for (int i = lane; i < dim; i += 64) g[i] = target_grad_elem(m.target, aux, q, i, dim, m.tparams);
@@ -185,7 +187,7 @@ int mm_launch_leapfrog_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, doub
   }
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
   hipLaunchKernelGGL(leapfrog_generic_kernel, dim3(blocks), dim3(64 * w), lds, ctx->stream,
-                     view_of(m), s->d_pos, s->d_mom, s->d_dir, s->n, h, n_steps);
+                     view_of(m), s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, h, n_steps);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }
@@ -204,7 +206,7 @@ int mm_launch_composition_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, d
   for (int i = 0; i < n_coeffs; ++i) cf.c[i] = coeffs[i];
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
   hipLaunchKernelGGL(composition_generic_kernel, dim3(blocks), dim3(64 * w), lds, ctx->stream, view_of(m),
-                     s->d_pos, s->d_mom, s->d_dir, s->n, h, n_steps, cf);
+                     s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, h, n_steps, cf);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }
@@ -287,8 +289,9 @@ __device__ __forceinline__ int midpoint_solve(const EuclidModelView& m, const Mi
 }
 
 __global__ void midpoint_euclid_kernel(EuclidModelView m, double* __restrict__ pos, double* __restrict__ mom,
-                                       const int8_t* __restrict__ dir, int32_t* __restrict__ status,
-                                       int32_t* __restrict__ n_done, int64_t n_chains, double step_size,
+                                       const int8_t* __restrict__ dir, const double* __restrict__ step_scale,
+                                       int32_t* __restrict__ status, int32_t* __restrict__ n_done,
+                                       int64_t n_chains, double step_size,
                                        int n_steps, mm_fp_opts o, mm_counters* counters) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -303,7 +306,7 @@ __global__ void midpoint_euclid_kernel(EuclidModelView m, double* __restrict__ p
     L.p[i] = mom[chain * dim + i];
   }
   wave_sync();
-  const double half = 0.5 * (double)dir[chain] * step_size;
+  const double half = 0.5 * signed_step(dir, step_scale, chain, step_size);
   int st = MM_ST_OK, done = 0;
   long long n_evals = 0, n_solves = 0, n_grad = 0;
   for (int s = 0; s < n_steps; ++s) {
@@ -385,7 +388,8 @@ int mm_launch_implicit_midpoint_euclid(mm_ctx* ctx, const mm_model* m, mm_state*
   w = w > 4 ? 4 : (w < 1 ? 1 : w);
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
   hipLaunchKernelGGL(midpoint_euclid_kernel, dim3(blocks), dim3(64 * w), w * per_wave, ctx->stream, view_of(m),
-                     s->d_pos, s->d_mom, s->d_dir, s->d_status, s->d_n_done, s->n, h, n_steps, opts, d_counters);
+                     s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_status, s->d_n_done, s->n, h, n_steps, opts,
+                     d_counters);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
   const bool act = tid < dim;
   const double q = act ? A.pos[chain * dim + tid] : 0.0;
   const double p = act ? A.mom[chain * dim + tid] : 0.0;
-  const double t = (double)A.dir[chain] * A.step_size;
+  const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
   __syncthreads();
@@ -444,6 +444,7 @@ SaArgs make_args(const mm_model* m, mm_state* s) {
   S.a.pos = s->d_pos;
   S.a.mom = s->d_mom;
   S.a.dir = s->d_dir;
+  S.a.step_scale = s->d_step_scale;
   S.a.status = s->d_status;
   S.a.n_done = s->d_n_done;
   S.a.n_chains = s->n;

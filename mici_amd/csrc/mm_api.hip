@@ -340,6 +340,7 @@ int mm_state_free(mm_state* s) {
   (void)hipFree(s->d_scratch);
   (void)hipFree(s->d_work);
   (void)hipFree(s->d_tr);
+  (void)hipFree(s->d_step_scale);
   delete s;
   return MM_OK;
 }
@@ -395,6 +396,33 @@ int mm_state_copy(mm_state* dst, const mm_state* src) {
   MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_dir, src->d_dir, n, hipMemcpyDeviceToDevice, ctx->stream));
   MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_status, src->d_status, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
   MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_n_done, src->d_n_done, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  if (src->d_step_scale) {  // the copy integrates with the same per-chain step sizes
+    if (!dst->d_step_scale) MM_HIP_CHECK(ctx, hipMalloc(&dst->d_step_scale, n * sizeof(double)));
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_step_scale, src->d_step_scale, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  } else if (dst->d_step_scale) {
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(dst->d_step_scale);
+    dst->d_step_scale = nullptr;
+  }
+  return MM_OK;
+}
+
+int mm_state_set_step_scale(mm_state* s, const double* scale) {
+  MM_REQUIRE(nullptr, s != nullptr, "mm_state_set_step_scale: state is NULL");
+  mm_ctx* ctx = s->ctx;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!scale) {  // back to one shared step size
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(s->d_step_scale);
+    s->d_step_scale = nullptr;
+    return MM_OK;
+  }
+  if (s->n == 0) return MM_OK;
+  for (int64_t i = 0; i < s->n; ++i)
+    MM_REQUIRE(ctx, std::isfinite(scale[i]) && scale[i] > 0.0, "mm_state_set_step_scale: factors must be positive and finite");
+  if (!s->d_step_scale) MM_HIP_CHECK(ctx, hipMalloc(&s->d_step_scale, (size_t)s->n * sizeof(double)));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_step_scale, scale, (size_t)s->n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // host buffer is only borrowed
   return MM_OK;
 }
 

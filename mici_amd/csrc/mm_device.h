@@ -7,6 +7,13 @@
 
 namespace mmdev {
 
+// signed time step of a chain: dir * step_size, times the chain's own scale when the state carries per-chain
+// step sizes (mm_state_set_step_scale: step-size adaptation runs every chain at its own step size)
+__device__ __forceinline__ double signed_step(const int8_t* __restrict__ dir, const double* __restrict__ scale,
+                                              int64_t chain, double step_size) {
+  return (double)dir[chain] * (scale ? step_size * scale[chain] : step_size);
+}
+
 // Order LDS traffic between the lanes of ONE wave (the wave executes DS instructions in order; this
 // only stops the compiler from moving loads/stores across the exchange point).
 __device__ __forceinline__ void wave_sync() {

@@ -169,6 +169,17 @@ class DeviceBatch:
             n_done.ctypes.data_as(_ffi.c_int32_p)), self.ctx.handle, "mm_state_download_status")
         return status, n_done
 
+    def set_step_scale(self, scale):
+        """Per-chain step-size factors [N] (``None`` removes them): every integrator call on this batch uses
+        ``step_size * scale[chain]``."""
+        if scale is None:
+            ptr = None
+        else:
+            scale = np.ascontiguousarray(np.broadcast_to(np.asarray(scale, dtype=np.float64), (self.n_chains,)))
+            ptr = _dptr(scale)
+        _ffi.check(self._lib.mm_state_set_step_scale(self.handle, ptr), self.ctx.handle,
+                   "mm_state_set_step_scale")
+
     def device_ptrs(self):
         p, m, d = C.c_void_p(), C.c_void_p(), C.c_void_p()
         _ffi.check(self._lib.mm_state_device_ptrs(self.handle, C.byref(p), C.byref(m), C.byref(d)),

@@ -119,6 +119,39 @@ def test_implicit_midpoint(name):
             assert_close(p, g["p_out"][k, c], 1e-9, f"{name} p@{s}")
 
 
+@pytest.mark.parametrize("name", golden_names("adapt_"))
+def test_dual_averaging_adaptation(name):
+    """oracle/adapters.py against the reference's DualAveragingStepSizeAdapter run (adapters.py:174-389)."""
+    from oracle import adapters as oad
+    from oracle import transitions as otr
+    g = load_golden(name)
+    n_iters, n, d = g["z"].shape
+    target = mdl.target_from_id(g["target"], g["target_params"], d)
+    if str(g["kind"]) == "adapt_euclid":
+        mk = int(g["metric_kind"])
+        ad = otr.euclid_adapter(orc.EuclidSystem(target, mk, None if mk == mdl.METRIC_IDENTITY else g["metric"]))
+    else:
+        ad = otr.riemann_adapter(orc.RiemannianSystem(
+            target, mdl.rmetric_from_id(g["rmetric"], g["rmetric_params"], d), None))
+    states = []
+    for c in range(n):
+        q, direction = g["q0"][c].copy(), 1
+        eps = oad.find_init_step_size(ad, q, ad.sample_momentum(q, g["z_init"][c]), 1)
+        assert eps == g["init_step_size"][c]
+        st = oad.initial_state(eps)
+        for t in range(n_iters):
+            p = ad.sample_momentum(q, g["z"][t, c])
+            q, p, direction, stats = otr.metropolis_static_transition(
+                ad, q, p, direction, eps, int(g["n_step"]), lambda t=t, c=c: g["u"][t, c])
+            assert_close(stats["accept_stat"], g["accept_stat"][t, c], 1e-9, f"{name} accept t{t}")
+            eps = oad.update(st, stats["accept_stat"])
+            assert_close(eps, g["step_sizes"][t, c], 1e-9, f"{name} step size t{t} c{c}")
+        assert_close(q, g["q_final"][c], 1e-8, f"{name} q final")
+        states.append(st)
+    assert_close(oad.finalize(states), float(g["final_step_size"]), 1e-9, "final step size")
+    assert_close(oad.finalize(states[0]), float(np.exp(g["smoothed_log_step_size"][0])), 1e-9, "single chain")
+
+
 def _riemann_system(g, counters=None):
     n, d = g["q0"].shape
     target = mdl.target_from_id(g["target"], g["target_params"], d)

@@ -191,6 +191,64 @@ def midpoint_case(name, ref_system, osys, extra, q0, p0, dirs, h, checkpoints, f
                 fp_div_tol=full["divergence_tol"], fp_max_iters=full["max_iters"], **extra, **ref), counts
 
 
+def adapt_case(name, kind, ref_system, ref_integrator, adapter, q0, n_step, n_iters, seed0, extra):
+    """DualAveragingStepSizeAdapter (adapters.py:174-389) driving momentum refresh + Metropolis static
+    transitions the way the sampler's warm-up does (samplers.py: initial momentum, adapter.initialize, then
+    per iteration momentum transition, integration transition, adapter.update), one chain at a time."""
+    from oracle import adapters as oad
+    from oracle import transitions as otr
+    n, d = q0.shape
+    mom_tr = mici.transitions.IndependentMomentumTransition(ref_system)
+    int_tr = mici.transitions.MetropolisStaticIntegrationTransition(ref_system, ref_integrator, n_step)
+    ref_adapter = mici.adapters.DualAveragingStepSizeAdapter()
+    z_init = np.zeros((n, d))
+    z = np.zeros((n_iters, n, d))
+    u = np.full((n_iters, n), np.nan)
+    init_step = np.zeros(n)
+    step_sizes = np.zeros((n_iters, n))   # step size set by update() after iteration t
+    accept = np.zeros((n_iters, n))
+    q_final = np.zeros((n, d))
+    adapt_states = []
+    for c in range(n):
+        rng = RecordingRng(seed0 + c)
+        state = ChainState(pos=q0[c].copy(), mom=None, dir=1)
+        state.mom = ref_system.sample_momentum(state, rng)
+        z_init[c] = rng.log[0][1]
+        adapt_state = ref_adapter.initialize(state, int_tr)
+        init_step[c] = ref_integrator.step_size
+        # oracle replay of the search
+        p_init = adapter.sample_momentum(q0[c], z_init[c])
+        check_close(f"{name} init step c{c}", oad.find_init_step_size(adapter, q0[c], p_init, 1), init_step[c], 1e-15)
+        ost = oad.initial_state(init_step[c])
+        oq, odir, oeps = q0[c].copy(), 1, init_step[c]
+        for t in range(n_iters):
+            rng.log.clear()
+            state, _ = mom_tr.sample(state, rng)
+            state, stats = int_tr.sample(state, rng)
+            ref_adapter.update(adapt_state, state, stats, int_tr)
+            z[t, c] = rng.log[0][1]
+            if len(rng.log) == 2:
+                u[t, c] = rng.log[1][1]
+            step_sizes[t, c] = ref_integrator.step_size
+            accept[t, c] = stats["accept_stat"]
+            op = adapter.sample_momentum(oq, z[t, c])
+            oq, op, odir, ostats = otr.metropolis_static_transition(
+                adapter, oq, op, odir, oeps, n_step, lambda t=t, c=c: u[t, c])
+            oeps = oad.update(ost, ostats["accept_stat"])
+            check_close(f"{name} step size t{t} c{c}", oeps, step_sizes[t, c], 1e-9)
+            check_close(f"{name} q t{t} c{c}", oq, state.pos, 1e-8)
+        q_final[c] = state.pos
+        adapt_states.append(adapt_state)
+        assert abs(ost["smoothed_log_step_size"] - adapt_state["smoothed_log_step_size"]) < 1e-9
+    ref_adapter.finalize(adapt_states, None, int_tr, None)
+    final_step = ref_integrator.step_size
+    print(f"   {name}: init step sizes {init_step.tolist()}, final {final_step:.4f}, mean accept {accept.mean():.2f}")
+    return dict(kind=kind, q0=q0, z_init=z_init, z=z, u=u, init_step_size=init_step, step_sizes=step_sizes,
+                accept_stat=accept, q_final=q_final, final_step_size=final_step, n_step=n_step,
+                smoothed_log_step_size=np.array([s["smoothed_log_step_size"] for s in adapt_states]),
+                status=np.zeros(n, dtype=np.int32), n_done=np.zeros(n, dtype=np.int32), **extra), collections.Counter()
+
+
 class RecordingRng:
     """Wraps a numpy Generator and logs what the reference draws (transition fixtures)."""
 
@@ -677,6 +735,42 @@ def main():
                          mdl.Rank1Metric(mdl.make_spd(12, rng)), 4, 0.1, [1, 10])
     add_midpoint_riemann("midpoint_riemann_diagquad_d5_fail_bigstep", mdl.Poly(5, 1.0, 1.0 / 3.0),
                          mdl.DiagQuadMetric(5), 8, 0.9, [1, 4], qscale=1.5)
+
+    # ---- dual-averaging step-size adaptation -----------------------------------------
+    def add_adapt_euclid(name, target, mk, metric, n, n_step, n_iters, seed0, qscale=1.0):
+        q0 = qscale * rng.standard_normal((n, target.dim))
+
+        def make():
+            rsys = mici.systems.EuclideanMetricSystem(
+                neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+                metric=None if mk == mdl.METRIC_IDENTITY else np.array(metric))
+            rint = mici.integrators.LeapfrogIntegrator(rsys)
+            ad = otr.euclid_adapter(orc.EuclidSystem(target, mk, metric))
+            return adapt_case(name, "adapt_euclid", rsys, rint, ad, q0, n_step, n_iters, seed0,
+                              model_keys(target, mk, metric))
+        cases[name] = make
+
+    add_adapt_euclid("adapt_euclid_dense_d16", mdl.GaussDense(mdl.make_spd(16, rng)), mdl.METRIC_IDENTITY, None,
+                     5, 4, 40, 8000)
+    add_adapt_euclid("adapt_euclid_quartic_d5_far_start", mdl.Poly(5, 0.0, 1.0), mdl.METRIC_DIAG,
+                     np.exp(0.3 * rng.standard_normal(5)), 5, 3, 40, 9000, qscale=3.0)
+
+    def add_adapt_riemann(name, target, rmetric, n, n_step, n_iters, seed0):
+        q0 = rng.standard_normal((n, target.dim))
+
+        def make():
+            rsys = mici.systems.DenseRiemannianMetricSystem(
+                neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+                metric_func=rmetric.metric_func, vjp_metric_func=rmetric.vjp_metric_func)
+            rint = mici.integrators.ImplicitLeapfrogIntegrator(rsys)
+            ad = otr.riemann_adapter(orc.RiemannianSystem(target, rmetric, None))
+            return adapt_case(name, "adapt_riemann", rsys, rint, ad, q0, n_step, n_iters, seed0,
+                              dict(target=target.tid, target_params=target.params(), rmetric=rmetric.mid,
+                                   rmetric_params=rmetric.params()))
+        cases[name] = make
+
+    add_adapt_riemann("adapt_riemann_diagquad_poly_d5", mdl.Poly(5, 1.0, 1.0 / 3.0), mdl.DiagQuadMetric(5),
+                      4, 3, 30, 10000)
 
     all_counts = {}
     for name, fn in cases.items():
