@@ -16,6 +16,7 @@ steps and the reference's call counters.  Fixtures are data only - no reference 
 from __future__ import annotations
 
 import argparse
+from pathlib import Path
 import collections
 import os
 import sys
@@ -771,6 +772,33 @@ def main():
 
     add_adapt_riemann("adapt_riemann_diagquad_poly_d5", mdl.Poly(5, 1.0, 1.0 / 3.0), mdl.DiagQuadMetric(5),
                       4, 3, 30, 10000)
+
+    # ---- trace / statistics file format ---------------------------------------------
+    def make_tracefmt():
+        import tempfile
+        from mici import samplers as msamp
+        keys = ["pos", "hamiltonian", "weird key/with:chars*", "a.b-c_d"]
+        names = {k: [p.name for p in msamp._generate_memmap_filenames("/tmp/x", "trace", k, range(3))] for k in keys}
+        rsys = mici.systems.EuclideanMetricSystem(neg_log_dens=lambda q: 0.5 * q @ q, grad_neg_log_dens=lambda q: q)
+        tr = mici.transitions.MetropolisStaticIntegrationTransition(rsys, mici.integrators.LeapfrogIntegrator(rsys, 0.1), 2)
+        stat_names = sorted(tr.statistic_types)
+        with tempfile.TemporaryDirectory() as tmp:
+            stats = msamp._init_stats({"integration_transition": tr}, 2, 5, use_memmap=True, memmap_path=tmp)
+            traces = msamp._init_traces([lambda s: {"pos": s.pos, "count": 3, "flag": np.array(True)}],
+                                        [ChainState(pos=np.zeros(4), mom=np.zeros(4), dir=1)] * 2, 5,
+                                        use_memmap=True, memmap_path=tmp)
+            files = sorted(p.name for p in Path(tmp).iterdir())
+            stat_dtypes = [str(stats["integration_transition"][k][0].dtype) for k in stat_names]
+            stat_defaults = np.array([float(stats["integration_transition"][k][0][0]) for k in stat_names])
+            trace_meta = {k: (str(v[0].dtype), list(v[0].shape), float(np.asarray(v[0]).ravel()[0])) for k, v in traces.items()}
+        return dict(kind="tracefmt", keys=np.array(keys), status=np.zeros(1, dtype=np.int32), n_done=np.zeros(1, dtype=np.int32),
+                    **{f"names_{i}": np.array(names[k]) for i, k in enumerate(keys)},
+                    files=np.array(files), stat_names=np.array(stat_names), stat_dtypes=np.array(stat_dtypes),
+                    stat_defaults=stat_defaults, trace_keys=np.array(sorted(trace_meta)),
+                    trace_dtypes=np.array([trace_meta[k][0] for k in sorted(trace_meta)]),
+                    trace_ndim=np.array([len(trace_meta[k][1]) for k in sorted(trace_meta)]),
+                    trace_init=np.array([trace_meta[k][2] for k in sorted(trace_meta)])), collections.Counter()
+    cases["tracefmt_reference"] = make_tracefmt
 
     all_counts = {}
     for name, fn in cases.items():
