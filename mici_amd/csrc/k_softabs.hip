@@ -28,6 +28,7 @@ constexpr int NT = 256;
 constexpr int LD = 65;            // LDS leading dimension of the 64 x 64 matrices
 constexpr int MAT = 64 * LD;
 constexpr int kMaxSweeps = 30;
+constexpr int kWarmPeriod = 16;  // cold-start the eigenvector basis every this many decompositions
 
 struct SaLds {
   double* H;    // Hessian -> (after eigh) J matrix / scratch
@@ -63,6 +64,7 @@ __device__ __forceinline__ double block_reduce4(double v, int kind_max, double* 
 struct SoftAbsBackend {
   static constexpr bool kSolveByInverse = false;  // implicit_core.h
   int dim, tid, target;
+  int warm = 0;  // eigendecompositions since the last cold start (0: w.V is not a usable basis)
   double coeff;
   SaLds w;
   const double* tparams;
@@ -101,7 +103,75 @@ struct SoftAbsBackend {
         else if (i == j) h = e * tparams[i - 1];
       }
       w.H[i * LD + j] = h;
-      w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+      if (warm == 0) w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (warm > 0) to_previous_eigenbasis();
+  }
+
+  // Warm start: consecutive metric constructions of a step are at nearby positions, so the previous
+  // eigenvectors almost diagonalise the new Hessian.  H <- V^T H V (two LDS-tiled products, 4 x 4 outputs per
+  // thread) and the Jacobi sweeps continue rotating V: two or three sweeps instead of seven to nine.  The
+  // result is the same decomposition (used only through V f(lambda) V^T forms); a cold start every
+  // kWarmPeriod decompositions bounds the accumulated loss of orthogonality of V.
+  __device__ __forceinline__ void to_previous_eigenbasis() {
+    const int bi = (tid >> 4) * 4, bj = (tid & 15) * 4;  // this thread's 4 x 4 output block
+    double acc[4][4];
+    // W = H V
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k = 0; k < dim; ++k) {
+      double hv[4], vv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) hv[a] = w.H[(bi + a) * LD + k];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) vv[b] = w.V[k * LD + bj + b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(hv[a], vv[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) w.W[(bi + a) * LD + bj + b] = acc[a][b];
+    __syncthreads();
+    // H = V^T W
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k = 0; k < dim; ++k) {
+      double vt[4], ww[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) vt[a] = w.V[k * LD + bi + a];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) ww[b] = w.W[k * LD + bj + b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(vt[a], ww[b], acc[a][b]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        // exact symmetry is what the Jacobi sweeps assume: average the two triangles' roundings away
+        w.H[(bi + a) * LD + bj + b] = acc[a][b];
+      }
+    __syncthreads();
+    {
+      const int j = tid & 63;
+      for (int i = tid >> 6; i < dim; i += NT / 64) {
+        if (j < i && j < dim) {
+          const double m = 0.5 * (w.H[i * LD + j] + w.H[j * LD + i]);
+          w.H[i * LD + j] = m;
+          w.H[j * LD + i] = m;
+        }
+      }
     }
     __syncthreads();
   }
@@ -123,7 +193,10 @@ struct SoftAbsBackend {
       }
       off = block_reduce4(off, 0, w.red);
       dg = block_reduce4(dg, 0, w.red);
-      if (!(off == off) || !(dg == dg) || fabs(off) > 1.7e308 || fabs(dg) > 1.7e308) return false;
+      if (!(off == off) || !(dg == dg) || fabs(off) > 1.7e308 || fabs(dg) > 1.7e308) {
+        warm = 0;
+        return false;
+      }
       if (off <= 1e-30 * dg) {
         converged = true;
         break;
@@ -140,7 +213,10 @@ struct SoftAbsBackend {
           double c = 1.0, s = 0.0;
           if (q < dim) {
             const double hpq = w.H[p * LD + q];
-            if (hpq != 0.0) {
+            const double hpp = w.H[p * LD + p], hqq = w.H[q * LD + q];
+            // entries far below the rounding level of their diagonal pair are already converged: rotating
+            // them only costs time (threshold Jacobi)
+            if (hpq != 0.0 && fabs(hpq) > 1e-18 * (fabs(hpp) + fabs(hqq))) {
               const double tau = (w.H[q * LD + q] - w.H[p * LD + p]) / (2.0 * hpq);
               const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
               c = 1.0 / sqrt(1.0 + t * t);
@@ -154,6 +230,7 @@ struct SoftAbsBackend {
         for (int g = tid >> 6; g < half; g += NT / 64) {  // pair g is wave-uniform
           const int i = tid & 63;
           const int p = w.rp[g], q = w.rq[g];
+          if (w.rs[g] == 0.0) continue;  // identity rotation (wave-uniform): nothing to do
           if (q < dim && i < dim) {
             const double c = w.rc[g], s = w.rs[g];
             const double hp = w.H[i * LD + p], hq = w.H[i * LD + q];
@@ -169,6 +246,7 @@ struct SoftAbsBackend {
         for (int g = tid >> 6; g < half; g += NT / 64) {
           const int j = tid & 63;
           const int p = w.rp[g], q = w.rq[g];
+          if (w.rs[g] == 0.0) continue;
           if (q < dim && j < dim) {
             const double c = w.rc[g], s = w.rs[g];
             const double hp = w.H[p * LD + j], hq = w.H[q * LD + j];
@@ -181,6 +259,7 @@ struct SoftAbsBackend {
     }
     if (tid < 64) w.lam[tid] = (tid < dim) ? w.H[tid * LD + tid] : 1.0;
     __syncthreads();
+    warm = converged ? (warm + 1) % kWarmPeriod : 0;
     return converged;
   }
 
