@@ -1,4 +1,4 @@
-// Implicit leapfrog on SoftAbsRiemannianMetricSystem (D <= 64): one 256-thread workgroup per chain,
+// Implicit leapfrog on SoftAbsRiemannianMetricSystem (D <= 64): one 1024-thread workgroup per chain,
 // the Hessian / eigenvectors / work matrices in LDS.  gfx950 / CDNA4.
 //
 // Replaces, per chain and per step (reference /root/reference/src/mici):
@@ -24,7 +24,10 @@ namespace {
 using namespace mmdev;
 using namespace mmimp;
 
-constexpr int NT = 256;
+constexpr int NT = 1024;           // 16 waves per chain: the kernel is LDS-latency bound, four waves per SIMD hide it
+constexpr int TPD = 32;            // threads per matrix dimension in the 64 x 64 products (TPD^2 = NT)
+constexpr int BS = 64 / TPD;       // output block side per thread
+constexpr int RP = NT / 64;        // threads per output element of the row-wise reductions
 constexpr int LD = 65;            // LDS leading dimension of the 64 x 64 matrices
 constexpr int MAT = 64 * LD;
 constexpr int kMaxSweeps = 30;
@@ -44,10 +47,10 @@ struct SaLds {
   double* rs;   // rotation sin [32]
   int* rp;      // pair p [32]
   int* rq;      // pair q [32]
-  double* red;  // [8]
+  double* red;  // [16]
   double* stash;  // [SL_COUNT][65]
 };
-constexpr int kLdsDoubles = 3 * MAT + 6 * 64 + 4 * 32 + 8 + SL_COUNT * 65;
+constexpr int kLdsDoubles = 3 * MAT + 6 * 64 + 4 * 32 + 16 + SL_COUNT * 65;
 
 __device__ __forceinline__ double block_reduce4(double v, int kind_max, double* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -61,10 +64,18 @@ __device__ __forceinline__ double block_reduce4(double v, int kind_max, double* 
   return r;
 }
 
+// sum over the RP = 16 consecutive lanes (one DPP row) that share an output element
+__device__ __forceinline__ double rp_sum(double v) {
+  v = group8_sum(v);
+  return v + dpp_move<kDppMirror>(v);
+}
+static_assert(RP == 16, "rp_sum reduces a 16-lane DPP row");
+
 struct SoftAbsBackend {
   static constexpr bool kSolveByInverse = false;  // implicit_core.h
   int dim, tid, target;
   int warm = 0;  // eigendecompositions since the last cold start (0: w.V is not a usable basis)
+  long long n_sweeps = 0, n_eigh = 0;  // work counters (reported as n_newton_iters / n_inverse)
   double coeff;
   SaLds w;
   const double* tparams;
@@ -115,50 +126,50 @@ struct SoftAbsBackend {
   // result is the same decomposition (used only through V f(lambda) V^T forms); a cold start every
   // kWarmPeriod decompositions bounds the accumulated loss of orthogonality of V.
   __device__ __forceinline__ void to_previous_eigenbasis() {
-    const int bi = (tid >> 4) * 4, bj = (tid & 15) * 4;  // this thread's 4 x 4 output block
-    double acc[4][4];
+    const int bi = (tid / TPD) * BS, bj = (tid % TPD) * BS;  // this thread's BS x BS output block
+    double acc[BS][BS];
     // W = H V
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < BS; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+      for (int b = 0; b < BS; ++b) acc[a][b] = 0.0;
     for (int k = 0; k < dim; ++k) {
-      double hv[4], vv[4];
+      double hv[BS], vv[BS];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) hv[a] = w.H[(bi + a) * LD + k];
+      for (int a = 0; a < BS; ++a) hv[a] = w.H[(bi + a) * LD + k];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) vv[b] = w.V[k * LD + bj + b];
+      for (int b = 0; b < BS; ++b) vv[b] = w.V[k * LD + bj + b];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < BS; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(hv[a], vv[b], acc[a][b]);
+        for (int b = 0; b < BS; ++b) acc[a][b] = __builtin_fma(hv[a], vv[b], acc[a][b]);
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < BS; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) w.W[(bi + a) * LD + bj + b] = acc[a][b];
+      for (int b = 0; b < BS; ++b) w.W[(bi + a) * LD + bj + b] = acc[a][b];
     __syncthreads();
     // H = V^T W
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < BS; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+      for (int b = 0; b < BS; ++b) acc[a][b] = 0.0;
     for (int k = 0; k < dim; ++k) {
-      double vt[4], ww[4];
+      double vt[BS], ww[BS];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) vt[a] = w.V[k * LD + bi + a];
+      for (int a = 0; a < BS; ++a) vt[a] = w.V[k * LD + bi + a];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) ww[b] = w.W[k * LD + bj + b];
+      for (int b = 0; b < BS; ++b) ww[b] = w.W[k * LD + bj + b];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < BS; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(vt[a], ww[b], acc[a][b]);
+        for (int b = 0; b < BS; ++b) acc[a][b] = __builtin_fma(vt[a], ww[b], acc[a][b]);
     }
     __syncthreads();
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < BS; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < BS; ++b) {
         // exact symmetry is what the Jacobi sweeps assume: average the two triangles' roundings away
         w.H[(bi + a) * LD + bj + b] = acc[a][b];
       }
@@ -181,6 +192,7 @@ struct SoftAbsBackend {
     const int n2 = dim + (dim & 1);
     const int half = n2 >> 1;
     bool converged = false;
+    ++n_eigh;
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
       double off = 0.0, dg = 0.0;
       {
@@ -201,6 +213,7 @@ struct SoftAbsBackend {
         converged = true;
         break;
       }
+      ++n_sweeps;
       for (int r = 0; r < n2 - 1; ++r) {
         if (tid < half) {
           int a, b;
@@ -287,25 +300,41 @@ struct SoftAbsBackend {
     return regularise();
   }
 
-  // V^T v (flat in, flat out): thread k < dim sums column k
+  // V^T v (flat in, flat out): RP threads share output k, each sums every RP-th term
   __device__ __forceinline__ double vt_times(double v) {
     if (tid < 64) w.v1[tid] = (tid < dim) ? v : 0.0;
     __syncthreads();
-    double s = 0.0;
-    if (tid < dim)
-      for (int i = 0; i < dim; ++i) s = __builtin_fma(w.V[i * LD + tid], w.v1[i], s);
+    {
+      const int k = tid / RP, part = tid % RP;
+      double s = 0.0;
+      if (k < dim)
+        for (int i = part; i < dim; i += RP) s = __builtin_fma(w.V[i * LD + k], w.v1[i], s);
+      s = rp_sum(s);
+      __syncthreads();  // every thread has read v1
+      if (part == 0) w.v1[k] = s;
+    }
     __syncthreads();
-    return s;
+    const double out = (tid < dim) ? w.v1[tid] : 0.0;
+    __syncthreads();
+    return out;
   }
   // V v
   __device__ __forceinline__ double v_times(double v) {
     if (tid < 64) w.v2[tid] = (tid < dim) ? v : 0.0;
     __syncthreads();
-    double s = 0.0;
-    if (tid < dim)
-      for (int k = 0; k < dim; ++k) s = __builtin_fma(w.V[tid * LD + k], w.v2[k], s);
+    {
+      const int i = tid / RP, part = tid % RP;
+      double s = 0.0;
+      if (i < dim)
+        for (int k = part; k < dim; k += RP) s = __builtin_fma(w.V[i * LD + k], w.v2[k], s);
+      s = rp_sum(s);
+      __syncthreads();
+      if (part == 0) w.v2[i] = s;
+    }
     __syncthreads();
-    return s;
+    const double out = (tid < dim) ? w.v2[tid] : 0.0;
+    __syncthreads();
+    return out;
   }
 
   // M^-1 v = V diag(1/lamt) V^T v   (matrices.py:1568-1575, 1623-1624)
@@ -355,16 +384,26 @@ struct SoftAbsBackend {
 
   // 0.5 * mtp(grad_log_abs_det), grad_log_abs_det = V diag(grad_softabs(lam)/lamt) V^T  (:1671-1674)
   __device__ __forceinline__ double half_vjp_inv(double q) {
-    double md = 0.0, m0 = 0.0;
-    if (tid < dim) {
-      for (int k = 0; k < dim; ++k) {
-        const double g = w.gsa[k] / w.lamt[k];
-        const double vik = w.V[tid * LD + k];
-        md = __builtin_fma(vik * vik, g, md);
-        m0 = __builtin_fma(w.V[k] * vik, g, m0);  // V[0][k] V[i][k] g_k
+    {
+      const int i = tid / RP, part = tid % RP;
+      double md = 0.0, m0 = 0.0;
+      if (i < dim) {
+        for (int k = part; k < dim; k += RP) {
+          const double g = w.gsa[k] / w.lamt[k];
+          const double vik = w.V[i * LD + k];
+          md = __builtin_fma(vik * vik, g, md);
+          m0 = __builtin_fma(w.V[k] * vik, g, m0);  // V[0][k] V[i][k] g_k
+        }
       }
+      md = rp_sum(md);
+      m0 = rp_sum(m0);
+      if (part == 0) { w.v2[i] = md; w.v1[i] = m0; }
     }
-    return 0.5 * mtp(q, md, m0);
+    __syncthreads();
+    const double mdf = (tid < dim) ? w.v2[tid] : 0.0;
+    const double m0f = (tid < dim) ? w.v1[tid] : 0.0;
+    __syncthreads();
+    return 0.5 * mtp(q, mdf, m0f);
   }
 
   // 0.5 * mtp(grad_quadratic_form_inv(p)),  -(V (e e^T o J) V^T) = -A J A^T, A = V diag(e),
@@ -384,12 +423,12 @@ struct SoftAbsBackend {
     }
     __syncthreads();
     // md_i = sum_kl A_ik J_kl A_il ; m0_i = sum_kl A_0k J_kl A_il : thread i accumulates over l of
-    // (sum_k A_ik J_kl) A_il.  Work split: 4 threads per row i (each a quarter of the l range).
+    // (sum_k A_ik J_kl) A_il.  Work split: RP threads per row i (each every RP-th l).
     double md = 0.0, m0 = 0.0;
     {
-      const int i = tid >> 2, part = tid & 3;
+      const int i = tid / RP, part = tid % RP;
       if (i < dim) {
-        for (int l = part; l < dim; l += 4) {
+        for (int l = part; l < dim; l += RP) {
           double bi = 0.0, b0 = 0.0;
           for (int k = 0; k < dim; ++k) {
             const double jkl = w.H[k * LD + l];
@@ -401,8 +440,8 @@ struct SoftAbsBackend {
           m0 = __builtin_fma(b0, ail, m0);
         }
       }
-      md += __shfl_xor(md, 1, 64); md += __shfl_xor(md, 2, 64);
-      m0 += __shfl_xor(m0, 1, 64); m0 += __shfl_xor(m0, 2, 64);
+      md = rp_sum(md);
+      m0 = rp_sum(m0);
       __syncthreads();
       if (part == 0 && i < 64) { w.v2[i] = -md; w.nat[i] = -m0; }
       __syncthreads();
@@ -451,7 +490,7 @@ __device__ __forceinline__ void init_backend(SoftAbsBackend& bk, const ImplicitA
   bk.w.rs = p; p += 32;
   bk.w.rp = reinterpret_cast<int*>(p); p += 32;
   bk.w.rq = reinterpret_cast<int*>(p); p += 32;
-  bk.w.red = p; p += 8;
+  bk.w.red = p; p += 16;
   bk.w.stash = p;
 }
 
@@ -485,6 +524,10 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
     A.status[chain] = r.status;
     A.n_done[chain] = r.done;
     add_counters(A.counters, r);
+    if (A.counters) {
+      atomicAdd((unsigned long long*)&A.counters->n_newton_iters, (unsigned long long)bk.n_sweeps);
+      atomicAdd((unsigned long long*)&A.counters->reserved, (unsigned long long)bk.n_eigh);
+    }
   }
 }
 
