@@ -38,72 +38,104 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_MFMA_PEAK_TF = 78.6   # MI355X dense FP64 matrix peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 
 
+def _make_spd(dim, rng):
+    """P = A A^T / D + I with A ~ N(0,1)^{DxD}."""
+    a = rng.standard_normal((dim, dim))
+    return a @ a.T / dim + np.eye(dim)
+
+
+def _torus_init(n, rng, R=1.0, r=0.5):
+    """Initial positions on the torus from (theta, phi) ~ U(0, 2 pi) (reference README.md:344-355)."""
+    theta, phi = rng.uniform(0, 2 * np.pi, size=(2, n))
+    return np.stack([(R + r * np.cos(phi)) * np.cos(theta), (R + r * np.cos(phi)) * np.sin(theta),
+                     r * np.sin(phi)], -1)
+
+
 def make_workload(config, n_chains, rng):
-    """Synthetic inputs of SURVEY.md section 8d.  Returns dict with the device system, integrator
-    factory args, initial state, the oracle twin and the algorithmic work per chain-step."""
+    """Synthetic inputs of SURVEY.md section 8d.  Returns dict with the device system, integrator, initial
+    state and the algorithmic work per chain-step.  The oracle twin (`make_oracle`) is only constructed by the
+    cpu_baseline leg: nothing under oracle/ is imported on the measured path."""
     from mici_amd import integrators, models, systems
-    from oracle import integrators as orc
-    from oracle import models as omdl
 
     if config in ("c2", "c2i", "c2iv"):
         dim, h, traj = 128, 0.05, 1000
         if config == "c2i":
-            target, otarget = models.GaussIso(dim), omdl.GaussIso(dim)
+            target, P = models.GaussIso(dim), None
             metric = None
             flops = 8.0 * dim
             name = "c2(i) iso-Gaussian"
         else:
-            P = omdl.make_spd(dim, rng)
-            target, otarget = models.GaussDense(P), omdl.GaussDense(P)
+            P = _make_spd(dim, rng)
+            target = models.GaussDense(P)
             metric = P if config == "c2iv" else None
             flops = 2.0 * dim * dim * (2 if config == "c2iv" else 1) + 8.0 * dim
             name = "c2(iv) dense-Gaussian + dense metric" if config == "c2iv" else \
                 "c2(iii) dense-precision Gaussian"
         system = systems.EuclideanMetricSystem(target, metric=metric)
         mk = 0 if metric is None else 2
-        osys = orc.EuclidSystem(otarget, mk, metric)
+
+        def make_oracle():
+            from oracle import integrators as orc
+            from oracle import models as omdl
+            return orc.EuclidSystem(omdl.GaussIso(dim) if P is None else omdl.GaussDense(P), mk, metric)
+
         integ = integrators.LeapfrogIntegrator(system, h)
         q0 = rng.standard_normal((n_chains, dim))
         z = rng.standard_normal((n_chains, dim))
         p0 = z if metric is None else z @ np.linalg.cholesky(metric).T
         return dict(name=f"{name}, EuclideanMetricSystem + LeapfrogIntegrator", dim=dim, h=h,
-                    traj=traj, integ=integ, system=system, osys=osys, q0=q0, p0=p0,
+                    traj=traj, integ=integ, system=system, make_oracle=make_oracle, q0=q0, p0=p0,
                     bytes_per_chain_step=32.0 * dim, flops_per_chain_step=flops,
                     bound="hbm" if config == "c2i" else "mfma", kind="euclid")
     if config in ("c3", "c4"):
         dim, h, traj = (64, 0.02, 100) if config == "c3" else (256, 0.01, 50)
-        base = omdl.make_spd(dim, rng)
+        base = _make_spd(dim, rng)
         system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(base))
-        osys = orc.RiemannianSystem(omdl.Banana(dim), omdl.Rank1Metric(base))
+
+        def make_oracle():
+            from oracle import integrators as orc
+            from oracle import models as omdl
+            return orc.RiemannianSystem(omdl.Banana(dim), omdl.Rank1Metric(base))
+
         integ = integrators.ImplicitLeapfrogIntegrator(system, h)
         q0 = rng.standard_normal((n_chains, dim))
         p0 = system.sample_momentum_batch(q0, rng.standard_normal((n_chains, dim)))
         return dict(name=f"{config}(a) DenseRiemannianMetricSystem (rank-one-update dense metric, banana "
                          "target) + ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
-                    system=system, osys=osys, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
+                    system=system, make_oracle=make_oracle, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
                     flops_per_chain_step=None, bound="mfma", kind="riemann")
     if config == "c3b":
         dim, h, traj = 64, 0.02, 100
         wts = np.linspace(0.5, 2.0, dim - 1)
         system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(wts), softabs_coeff=1.0)
-        osys = orc.RiemannianSystem(omdl.Funnel(wts), None, 1.0)
+
+        def make_oracle():
+            from oracle import integrators as orc
+            from oracle import models as omdl
+            return orc.RiemannianSystem(omdl.Funnel(wts), None, 1.0)
+
         integ = integrators.ImplicitLeapfrogIntegrator(system, h)
         q0 = rng.standard_normal((n_chains, dim))
         p0 = system.sample_momentum_batch(q0, rng.standard_normal((n_chains, dim)))
         return dict(name="c3(b) SoftAbsRiemannianMetricSystem (scaled funnel) + "
                          "ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
-                    system=system, osys=osys, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
+                    system=system, make_oracle=make_oracle, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
                     flops_per_chain_step=None, bound="mfma", kind="softabs")
     if config == "c5":
         dim, h, traj = 3, 0.1, 1000
         system = systems.DenseConstrainedEuclideanMetricSystem(models.Torus(), models.TorusConstr())
-        osys = orc.ConstrainedSystem(omdl.Torus(), omdl.TorusConstr())
+
+        def make_oracle():
+            from oracle import integrators as orc
+            from oracle import models as omdl
+            return orc.ConstrainedSystem(omdl.Torus(), omdl.TorusConstr())
+
         integ = integrators.ConstrainedLeapfrogIntegrator(system, h)
-        q0 = omdl.torus_init(n_chains, rng)
+        q0 = _torus_init(n_chains, rng)
         p0 = system.sample_momentum_batch(q0, rng.standard_normal((n_chains, dim)))
         return dict(name="c5 DenseConstrainedEuclideanMetricSystem (README torus) + "
                          "ConstrainedLeapfrogIntegrator (Newton)", dim=dim, h=h, traj=traj, integ=integ,
-                    system=system, osys=osys, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
+                    system=system, make_oracle=make_oracle, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
                     flops_per_chain_step=1500.0, bound="hbm", kind="constrained")
     raise SystemExit(f"unknown --config {config}")
 
@@ -113,6 +145,7 @@ def cpu_baseline(w, budget_s=20.0):
     sample of the same workload on this box's host cores."""
     from oracle import integrators as orc
 
+    osys = w["make_oracle"]()
     try:
         from threadpoolctl import threadpool_info
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
@@ -125,7 +158,7 @@ def cpu_baseline(w, budget_s=20.0):
         done, n1 = 0, 0
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < budget_s and n1 < w["q0"].shape[0]:
-            _, _, _, nd = fn(w["osys"], w["q0"][n1], w["p0"][n1], w["h"], steps)
+            _, _, _, nd = fn(osys, w["q0"][n1], w["p0"][n1], w["h"], steps)
             done += nd
             n1 += 1
         dt = time.perf_counter() - t0
@@ -134,19 +167,19 @@ def cpu_baseline(w, budget_s=20.0):
                            f"in {dt:.1f} s (1 thread; BLAS single-threaded at these sizes)")
     n, steps = w["q0"].shape[0], 20
     t0 = time.perf_counter()
-    orc.leapfrog_steps_batch(w["osys"], w["q0"], w["p0"], w["h"], steps)
+    orc.leapfrog_steps_batch(osys, w["q0"], w["p0"], w["h"], steps)
     dt = time.perf_counter() - t0
     # scale the sample to ~budget_s of CPU work, capped at the real trajectory length
     steps2 = int(min(w["traj"], max(steps, steps * budget_s / max(dt, 1e-6))))
     t0 = time.perf_counter()
-    orc.leapfrog_steps_batch(w["osys"], w["q0"], w["p0"], w["h"], steps2)
+    orc.leapfrog_steps_batch(osys, w["q0"], w["p0"], w["h"], steps2)
     dt = time.perf_counter() - t0
     value = n * steps2 / dt
     # reference-style figure: one chain at a time on one core
     t0 = time.perf_counter()
     n1 = 0
     while time.perf_counter() - t0 < 2.0:
-        orc.leapfrog_steps(w["osys"], w["q0"][n1 % n], w["p0"][n1 % n], w["h"], 100)
+        orc.leapfrog_steps(osys, w["q0"][n1 % n], w["p0"][n1 % n], w["h"], 100)
         n1 += 1
     single = n1 * 100 / (time.perf_counter() - t0)
     return dict(value=value, unit="leapfrog-steps/s", cores=int(cores), kind="port",
