@@ -144,7 +144,7 @@ struct MfmaBackend {
   }
 
   // ---- one block of the sweep (B compile-time after unrolling) ----------------------------------------
-  __device__ __forceinline__ void block_step(const int B, Ops& ops, bool& ok) {
+  __device__ __forceinline__ void block_step(const int B, Ops& ops, double& pmin) {
     const int I0 = B >> 2, R0 = B & 3;
     const int g = lane >> 4, j = lane & 15;
     const int k0 = 16 * I0 + 4 * R0;
@@ -189,7 +189,9 @@ struct MfmaBackend {
       const double ids = fast_rcp(det_s);
       const double is00 = s11 * ids, is01 = -s01 * ids, is11 = s00 * ids;  // S^-1
       // pivots of the sequential elimination: a, det_a / a, s00, det_s / s00  (all must be > 0)
-      ok = ok && (a > 0.0) && (det_a > 0.0) && (s00 > 0.0) && (det_s > 0.0);
+      // v_min_f64 drops NaNs, so a NaN pivot is caught separately at the end of the sweep: it poisons
+      // every entry of W and with it every tile
+      pmin = __builtin_fmin(__builtin_fmin(pmin, a), __builtin_fmin(det_a, __builtin_fmin(s00, det_s)));
       // U = T S^-1;  P^-1 = [A^-1 + U T^T, -U; -U^T, S^-1]
       const double u00 = __builtin_fma(t00, is00, t01 * is01), u01 = __builtin_fma(t00, is01, t01 * is11);
       const double u10 = __builtin_fma(t10, is00, t11 * is01), u11 = __builtin_fma(t10, is01, t11 * is11);
@@ -203,10 +205,11 @@ struct MfmaBackend {
       q[2] -= (s == 2) ? 1.0 : 0.0;
       q[3] -= (s == 3) ? 1.0 : 0.0;
       // -W[:, c] = -P^-1 q
-      wv[0] = -(__builtin_fma(p00, q[0], p01 * q[1]) - __builtin_fma(u00, q[2], u01 * q[3]));
-      wv[1] = -(__builtin_fma(p01, q[0], p11 * q[1]) - __builtin_fma(u10, q[2], u11 * q[3]));
-      wv[2] = __builtin_fma(u00, q[0], u10 * q[1]) - __builtin_fma(is00, q[2], is01 * q[3]);
-      wv[3] = __builtin_fma(u01, q[0], u11 * q[1]) - __builtin_fma(is01, q[2], is11 * q[3]);
+      // (one multiply and three fused multiply-adds per component; the signs ride on operand modifiers)
+      wv[0] = __builtin_fma(-p00, q[0], __builtin_fma(-p01, q[1], __builtin_fma(u00, q[2], u01 * q[3])));
+      wv[1] = __builtin_fma(-p01, q[0], __builtin_fma(-p11, q[1], __builtin_fma(u10, q[2], u11 * q[3])));
+      wv[2] = __builtin_fma(u00, q[0], __builtin_fma(u10, q[1], __builtin_fma(-is00, q[2], -is01 * q[3])));
+      wv[3] = __builtin_fma(u01, q[0], __builtin_fma(u11, q[1], __builtin_fma(-is01, q[2], -is11 * q[3])));
     }
     *reinterpret_cast<d4*>(w.qt + (lane << 2)) = q;  // only the block's own four columns changed
     *reinterpret_cast<d4*>(w.wt + (lane << 2)) = wv;
@@ -233,13 +236,14 @@ struct MfmaBackend {
   }
 
   __device__ __forceinline__ bool sweep() {
-    bool ok = true;
+    double pmin = 1.0;  // smallest pivot seen
     Ops ops;
 #pragma unroll
-    for (int B = 0; B < 16; ++B) block_step(B, ops, ok);
+    for (int B = 0; B < 16; ++B) block_step(B, ops, pmin);
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) acc[t] = -acc[t];
-    return ok;
+    const double probe = acc[0][0];
+    return (pmin > 0.0) && __all(probe == probe);
   }
 
   __device__ __forceinline__ bool build_and_invert(double x) {
