@@ -242,10 +242,10 @@ struct TeamMfma {
       q[2] -= (s == 2) ? 1.0 : 0.0;
       q[3] -= (s == 3) ? 1.0 : 0.0;
       d4 wv;
-      wv[0] = -(__builtin_fma(p00, q[0], p01 * q[1]) - __builtin_fma(u00, q[2], u01 * q[3]));
-      wv[1] = -(__builtin_fma(p01, q[0], p11 * q[1]) - __builtin_fma(u10, q[2], u11 * q[3]));
-      wv[2] = __builtin_fma(u00, q[0], u10 * q[1]) - __builtin_fma(is00, q[2], is01 * q[3]);
-      wv[3] = __builtin_fma(u01, q[0], u11 * q[1]) - __builtin_fma(is01, q[2], is11 * q[3]);
+      wv[0] = __builtin_fma(-p00, q[0], __builtin_fma(-p01, q[1], __builtin_fma(u00, q[2], u01 * q[3])));
+      wv[1] = __builtin_fma(-p01, q[0], __builtin_fma(-p11, q[1], __builtin_fma(u10, q[2], u11 * q[3])));
+      wv[2] = __builtin_fma(u00, q[0], __builtin_fma(u10, q[1], __builtin_fma(-is00, q[2], -is01 * q[3])));
+      wv[3] = __builtin_fma(u01, q[0], __builtin_fma(u11, q[1], __builtin_fma(-is01, q[2], -is11 * q[3])));
       if (s >= 0 && s < 4) *reinterpret_cast<d4*>(qt + (tid << 2)) = q;
       *reinterpret_cast<d4*>(wt + (tid << 2)) = wv;
     }
