@@ -233,6 +233,12 @@ int mm_dh_dmom(mm_ctx* ctx, const mm_model* model, mm_state* state, double* out)
  * constrained system (systems.py:614-616). z is host [N][D]. */
 int mm_sample_momentum(mm_ctx* ctx, const mm_model* model, mm_state* state, const double* z);
 
+/* ---- momentum transitions (transitions.py:129-198) ---------------------------------------------------------
+ * IndependentMomentumTransition (coeff == 1): mom = sample_momentum(state, z), i.e. mm_sample_momentum.
+ * CorrelatedMomentumTransition (0 <= coeff < 1; Horowitz 1991): mom = sqrt(1 - coeff^2) mom + coeff mom_ind
+ * with mom_ind = sample_momentum(state, z) (transitions.py:190-196).  z[N*D]: standard-normal draws (host). */
+int mm_momentum_refresh(mm_ctx* ctx, const mm_model* model, mm_state* state, const double* z, double coeff);
+
 /* ---- Metropolis accept step of an integration transition, device resident ------
  * MetropolisIntegrationTransition._sample_n_step after the trajectory (transitions.py:275-315): `state` is
  * the chain state BEFORE the trajectory, `proposal` a copy of it (mm_state_copy) advanced by one of the

@@ -394,6 +394,21 @@ int mm_launch_implicit_midpoint_euclid(mm_ctx* ctx, const mm_model* m, mm_state*
   return MM_OK;
 }
 
+// y <- a x + b y  (CorrelatedMomentumTransition: mom *= sqrt(1 - c^2); mom += c mom_ind, transitions.py:194-196)
+__global__ void axpby_kernel(double* __restrict__ y, const double* __restrict__ x, double a, double b, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double scaled = a * x[i];
+    y[i] = scaled + b * y[i];
+  }
+}
+
+int mm_launch_axpby(mm_ctx* ctx, double* y, const double* x, double a, double b, size_t n) {
+  const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(axpby_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, ctx->stream, y, x, a, b, n);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
 // Metropolis accept / select (transitions.py:296-314): one wave per chain; lane 0 decides, all lanes copy.
 __global__ void metropolis_select_kernel(double* __restrict__ pos, double* __restrict__ mom,
                                          int8_t* __restrict__ dir, const double* __restrict__ ppos,

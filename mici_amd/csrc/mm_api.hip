@@ -20,6 +20,7 @@ int mm_launch_implicit_midpoint_riemann(mm_ctx*, const mm_model*, mm_state*, dou
                                         mm_counters*);
 int mm_launch_metropolis_select(mm_ctx*, mm_state*, mm_state*, const double*, const double*, const double*, double*,
                                 int8_t*);
+int mm_launch_axpby(mm_ctx*, double* y, const double* x, double a, double b, size_t n);
 int mm_launch_euclid_hamiltonian(mm_ctx*, const mm_model*, mm_state*, double*);
 int mm_launch_euclid_dh_dmom(mm_ctx*, const mm_model*, mm_state*, double*);
 int mm_launch_euclid_sample_momentum(mm_ctx*, const mm_model*, mm_state*, const double*);
@@ -340,6 +341,7 @@ int mm_state_free(mm_state* s) {
   (void)hipFree(s->d_scratch);
   (void)hipFree(s->d_work);
   (void)hipFree(s->d_tr);
+  (void)hipFree(s->d_mom_save);
   (void)hipFree(s->d_step_scale);
   delete s;
   return MM_OK;
@@ -589,6 +591,30 @@ int mm_sample_momentum(mm_ctx* ctx, const mm_model* m, mm_state* s, const double
     rc = mm_launch_constrained_project_momentum(ctx, m, s);  // systems.py:614-616
     if (rc != MM_OK) return rc;
   }
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return MM_OK;
+}
+
+// ---- momentum transitions (transitions.py:129-198) -----------------------------------------------------------
+int mm_momentum_refresh(mm_ctx* ctx, const mm_model* m, mm_state* s, const double* z, double coeff) {
+  int rc = check_pair(ctx, m, s, "mm_momentum_refresh");
+  if (rc != MM_OK) return rc;
+  MM_REQUIRE(ctx, coeff >= 0.0 && coeff <= 1.0, "mom_resample_coeff should have a value in the interval [0, 1].");
+  if (coeff == 0.0 || s->n == 0) return MM_OK;  // transitions.py:193: the momentum is left alone
+  if (coeff == 1.0) return mm_sample_momentum(ctx, m, s, z);
+  const size_t nd = (size_t)s->n * s->dim;
+  if (s->mom_save_elems < nd) {
+    (void)hipFree(s->d_mom_save);
+    s->d_mom_save = nullptr;
+    s->mom_save_elems = 0;
+    MM_HIP_CHECK(ctx, hipMalloc(&s->d_mom_save, nd * sizeof(double)));
+    s->mom_save_elems = nd;
+  }
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_mom_save, s->d_mom, nd * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  rc = mm_sample_momentum(ctx, m, s, z);  // mom <- independent draw (projected for constrained systems)
+  if (rc != MM_OK) return rc;
+  rc = mm_launch_axpby(ctx, s->d_mom, s->d_mom_save, std::sqrt(1.0 - coeff * coeff), coeff, nd);
+  if (rc != MM_OK) return rc;
   MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return MM_OK;
 }

@@ -55,6 +55,8 @@ struct mm_state {
   size_t scratch_elems = 0;
   void* d_work = nullptr;  // per-chain workspace of the large-D implicit path
   size_t work_bytes = 0;
+  double* d_mom_save = nullptr;  // previous momentum during a correlated refresh (mm_momentum_refresh)
+  size_t mom_save_elems = 0;
   double* d_step_scale = nullptr;  // optional per-chain step-size factors (mm_state_set_step_scale)
   double* d_tr = nullptr;  // transition scratch: u[N], accept_prob[N], accepted[N] (mm_metropolis_accept)
   size_t tr_elems = 0;

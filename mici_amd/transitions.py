@@ -43,6 +43,41 @@ class IndependentMomentumTransition:
                    ctx.handle, "mm_sample_momentum")
 
 
+class CorrelatedMomentumTransition(IndependentMomentumTransition):
+    """Partial momentum refresh mom <- sqrt(1 - c^2) mom + c mom_ind (Horowitz 1991; transitions.py:143-198)."""
+
+    def __init__(self, system, mom_resample_coeff=1.0):
+        super().__init__(system)
+        if not (mom_resample_coeff >= 0 and mom_resample_coeff <= 1):
+            raise ValueError("mom_resample_coeff should have a value in the interval [0, 1].")
+        self.mom_resample_coeff = mom_resample_coeff
+
+    def sample(self, state, rng):
+        if state.mom is None or self.mom_resample_coeff == 1:
+            state.mom = self.system.sample_momentum(state, rng)
+        elif self.mom_resample_coeff != 0:
+            ctx = default_context()
+            pos = np.ascontiguousarray(state.pos, dtype=np.float64)
+            batch = DeviceBatch(ctx, 1, pos.shape[0])
+            try:
+                batch.upload(pos[None], np.asarray(state.mom, dtype=np.float64)[None], [int(state.dir)])
+                self.sample_batch(batch, rng.standard_normal(pos.shape)[None], ctx)
+                state.mom = batch.download()[1][0]
+            finally:
+                batch.close()
+        return state, None
+
+    def sample_batch(self, batch, z, ctx=None):
+        ctx = ctx or batch.ctx
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        if z.shape != (batch.n_chains, batch.dim):
+            raise ValueError(f"z must have shape ({batch.n_chains}, {batch.dim})")
+        model = self.system.device_model(ctx)
+        _ffi.check(ctx._lib.mm_momentum_refresh(ctx.handle, model.handle, batch.handle,
+                                                z.ctypes.data_as(_ffi.c_double_p), float(self.mom_resample_coeff)),
+                   ctx.handle, "mm_momentum_refresh")
+
+
 class MetropolisStaticIntegrationTransition:
     """Static-trajectory HMC transition with a Metropolis accept step (transitions.py:236-352): integrate
     ``n_step`` steps in the current direction, accept the end point with probability
@@ -142,3 +177,28 @@ class MetropolisStaticIntegrationTransition:
             "accept_stat": float(st["accept_stat"][0]),
         }
         return state, stats
+
+
+class MetropolisRandomIntegrationTransition(MetropolisStaticIntegrationTransition):
+    """As the static transition with the number of steps drawn per transition from
+    ``rng.integers(*n_step_range)`` (transitions.py:355-402).  ``sample_batch`` runs every chain of the batch
+    with one common draw (pass ``n_step``); the single-chain ``sample`` draws exactly like the reference."""
+
+    def __init__(self, system, integrator, n_step_range):
+        n_step_lower, n_step_upper = n_step_range
+        if not (n_step_lower > 0 and n_step_lower < n_step_upper):
+            raise ValueError("Range bounds must be non-negative and first entry less than last.")
+        super().__init__(system, integrator, n_step_lower)
+        self.n_step_range = tuple(int(v) for v in n_step_range)
+
+    def sample(self, state, rng):
+        self.n_step = int(rng.integers(*self.n_step_range))
+        return super().sample(state, rng)
+
+    def sample_batch(self, batch, u, n_step=None, rng=None, ctx=None):
+        if n_step is None:
+            if rng is None:
+                raise ValueError("pass n_step or an rng to draw it from")
+            n_step = rng.integers(*self.n_step_range)
+        self.n_step = int(n_step)
+        return super().sample_batch(batch, u, ctx)

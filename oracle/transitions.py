@@ -76,3 +76,13 @@ def metropolis_static_transition(ad, q, p, direction, step_size, n_step, draw_un
     else:
         direction = -direction
     return np.array(q, dtype=np.float64), np.array(p, dtype=np.float64), int(direction), stats
+
+
+def correlated_momentum(ad, q, p, z, coeff):
+    """CorrelatedMomentumTransition.sample (transitions.py:185-197): ``z`` is consumed only when the reference
+    draws (coeff != 0 or no momentum yet)."""
+    if p is None or coeff == 1:
+        return ad.sample_momentum(q, z)
+    if coeff != 0:
+        return p * (1.0 - coeff**2) ** 0.5 + coeff * ad.sample_momentum(q, z)
+    return p

@@ -133,3 +133,59 @@ def test_transition_argument_checks_and_invariance():
     assert 0.8 < np.mean(acc[10:]) <= 1.0
     assert abs(q.mean()) < 0.05 and abs(q.var() - 1.0) < 0.06
     batch.close()
+
+
+def test_correlated_momentum_and_random_trajectory_length_match_reference():
+    """CorrelatedMomentumTransition (mm_momentum_refresh) + MetropolisRandomIntegrationTransition, single-chain
+    contract with the reference's recorded draws (standard_normal, integers, uniform in that order)."""
+    g = load_golden("corrmom_random_nstep_d10")
+    n_tr, n, d = g["z"].shape
+    system = systems.EuclideanMetricSystem(models.target_from_id(g["target"], g["target_params"], d), metric=g["metric"])
+    integ = integrators.LeapfrogIntegrator(system, float(g["step_size"]))
+    mom_tr = transitions.CorrelatedMomentumTransition(system, float(g["coeff"]))
+    int_tr = transitions.MetropolisRandomIntegrationTransition(system, integ, tuple(int(v) for v in g["n_step_range"]))
+
+    class Replay:
+        def __init__(self, c):
+            self.c, self.t, self.log = c, 0, []
+
+        def standard_normal(self, size=None):
+            self.log.append("z")
+            return g["z"][self.t, self.c].copy()
+
+        def integers(self, lo, hi):
+            assert (lo, hi) == tuple(int(v) for v in g["n_step_range"])
+            self.log.append("n")
+            return int(g["n_steps"][self.t, self.c])
+
+        def uniform(self):
+            self.log.append("u")
+            return float(g["u"][self.t, self.c])
+
+    for c in range(n):
+        rng = Replay(c)
+        state = ChainState(pos=g["q0"][c].copy(), mom=None, dir=1)
+        for t in range(n_tr):
+            rng.t, rng.log = t, []
+            state, _ = mom_tr.sample(state, rng)
+            state, stats = int_tr.sample(state, rng)
+            assert rng.log == (["z", "n", "u"] if not np.isnan(g["u"][t, c]) else ["z", "n"])
+            assert_close(state.pos, g["q_out"][t, c], 1e-9, f"q t{t} c{c}")
+            assert_close(state.mom, g["p_out"][t, c], 1e-9, f"p t{t} c{c}")
+            assert state.dir == g["dir_out"][t, c] and stats["n_step"] == g["n_steps"][t, c]
+            assert_close(stats["accept_stat"], g["accept_stat"][t, c], 1e-9, "accept_stat")
+    # batched partial refresh against the closed form
+    ctx = default_context()
+    batch = DeviceBatch(ctx, n, d)
+    rs = np.random.default_rng(4)
+    p0, z = rs.standard_normal((n, d)), rs.standard_normal((n, d))
+    batch.upload(g["q0"], p0, 1)
+    mom_tr.sample_batch(batch, z)
+    coeff = float(g["coeff"])
+    expect = np.sqrt(1 - coeff**2) * p0 + coeff * system.sample_momentum_batch(g["q0"], z)
+    assert_close(batch.download()[1], expect, 1e-14, "partial refresh")
+    with pytest.raises(ValueError):
+        transitions.CorrelatedMomentumTransition(system, 1.5)
+    with pytest.raises(ValueError):
+        transitions.MetropolisRandomIntegrationTransition(system, integ, (3, 3))
+    batch.close()

@@ -152,6 +152,25 @@ def test_dual_averaging_adaptation(name):
     assert_close(oad.finalize(states[0]), float(np.exp(g["smoothed_log_step_size"][0])), 1e-9, "single chain")
 
 
+def test_correlated_momentum_and_random_trajectory_length():
+    """CorrelatedMomentumTransition + MetropolisRandomIntegrationTransition (transitions.py:143-198, 355-402)."""
+    from oracle import transitions as otr
+    g = load_golden("corrmom_random_nstep_d10")
+    n_tr, n, d = g["z"].shape
+    ad = otr.euclid_adapter(orc.EuclidSystem(mdl.target_from_id(g["target"], g["target_params"], d),
+                                             int(g["metric_kind"]), g["metric"]))
+    for c in range(n):
+        q, p, direction = g["q0"][c].copy(), None, 1
+        for t in range(n_tr):
+            p = otr.correlated_momentum(ad, q, p, g["z"][t, c], float(g["coeff"]))
+            q, p, direction, st = otr.metropolis_static_transition(
+                ad, q, p, direction, float(g["step_size"]), int(g["n_steps"][t, c]), lambda t=t, c=c: g["u"][t, c])
+            assert_close(q, g["q_out"][t, c], 1e-11, f"q t{t} c{c}")
+            assert_close(p, g["p_out"][t, c], 1e-11, f"p t{t} c{c}")
+            assert direction == g["dir_out"][t, c]
+            assert_close(st["accept_stat"], g["accept_stat"][t, c], 1e-10, "accept_stat")
+
+
 def _riemann_system(g, counters=None):
     n, d = g["q0"].shape
     target = mdl.target_from_id(g["target"], g["target_params"], d)

@@ -267,6 +267,11 @@ class RecordingRng:
         self.log.append(("z", np.array(v, dtype=np.float64)))
         return v
 
+    def integers(self, *a, **k):
+        v = self._rng.integers(*a, **k)
+        self.log.append(("n", int(v)))
+        return v
+
     def uniform(self, *a, **k):
         v = self._rng.uniform(*a, **k)
         self.log.append(("u", float(v)))
@@ -736,6 +741,48 @@ def main():
                          mdl.Rank1Metric(mdl.make_spd(12, rng)), 4, 0.1, [1, 10])
     add_midpoint_riemann("midpoint_riemann_diagquad_d5_fail_bigstep", mdl.Poly(5, 1.0, 1.0 / 3.0),
                          mdl.DiagQuadMetric(5), 8, 0.9, [1, 4], qscale=1.5)
+
+    # ---- correlated momentum refresh + random trajectory length (transitions.py:143-198, 355-402) ----------
+    def make_corr_random():
+        name = "corrmom_random_nstep_d10"
+        target, d, n, n_tr, coeff, rng_range = mdl.Poly(10, 1.0, 0.5), 10, 5, 8, 0.6, (2, 7)
+        metric = np.exp(0.2 * np.random.default_rng(77).standard_normal(d))
+        q0 = np.random.default_rng(78).standard_normal((n, d))
+        rsys = mici.systems.EuclideanMetricSystem(neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+                                                  metric=metric)
+        rint = mici.integrators.LeapfrogIntegrator(rsys, 0.45)
+        mom_tr = mici.transitions.CorrelatedMomentumTransition(rsys, coeff)
+        int_tr = mici.transitions.MetropolisRandomIntegrationTransition(rsys, rint, rng_range)
+        ad = otr.euclid_adapter(orc.EuclidSystem(target, mdl.METRIC_DIAG, metric))
+        z = np.zeros((n_tr, n, d)); u = np.full((n_tr, n), np.nan); n_steps = np.zeros((n_tr, n), dtype=np.int64)
+        q_out = np.zeros((n_tr, n, d)); p_out = np.zeros((n_tr, n, d)); dir_out = np.zeros((n_tr, n), dtype=np.int8)
+        acc = np.zeros((n_tr, n))
+        for c in range(n):
+            r = RecordingRng(11000 + c)
+            state = ChainState(pos=q0[c].copy(), mom=None, dir=1)
+            oq, op, odir = q0[c].copy(), None, 1
+            for t in range(n_tr):
+                r.log.clear()
+                state, _ = mom_tr.sample(state, r)
+                state, stats = int_tr.sample(state, r)
+                kinds = [k for k, _ in r.log]
+                assert kinds in (["z", "n", "u"], ["z", "n"]), kinds
+                z[t, c], n_steps[t, c] = r.log[0][1], r.log[1][1]
+                if len(r.log) == 3:
+                    u[t, c] = r.log[2][1]
+                q_out[t, c], p_out[t, c], dir_out[t, c], acc[t, c] = state.pos, state.mom, state.dir, stats["accept_stat"]
+                op = otr.correlated_momentum(ad, oq, op, z[t, c], coeff)
+                oq, op, odir, ost = otr.metropolis_static_transition(ad, oq, op, odir, 0.45, int(n_steps[t, c]),
+                                                                     lambda t=t, c=c: u[t, c])
+                check_close(f"{name} q t{t} c{c}", oq, state.pos, 1e-11)
+                check_close(f"{name} p t{t} c{c}", op, state.mom, 1e-11)
+                assert odir == state.dir
+        print(f"   {name}: mean accept {acc.mean():.2f}, n_step range {n_steps.min()}..{n_steps.max()}")
+        return dict(kind="transition2", q0=q0, z=z, u=u, n_steps=n_steps, q_out=q_out, p_out=p_out, dir_out=dir_out,
+                    accept_stat=acc, coeff=coeff, n_step_range=np.array(rng_range), step_size=0.45,
+                    status=np.zeros(n, dtype=np.int32), n_done=np.zeros(n, dtype=np.int32),
+                    **model_keys(target, mdl.METRIC_DIAG, metric)), collections.Counter()
+    cases["corrmom_random_nstep_d10"] = make_corr_random
 
     # ---- dual-averaging step-size adaptation -----------------------------------------
     def add_adapt_euclid(name, target, mk, metric, n, n_step, n_iters, seed0, qscale=1.0):
