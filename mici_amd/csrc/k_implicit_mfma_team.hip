@@ -79,12 +79,15 @@ __device__ __forceinline__ double team_reduce(double v, int kind_max, double* re
   return r;
 }
 
-template <int RMETRIC>
+template <int RMETRIC, int W>
 struct TeamMfma {
   static constexpr bool kSolveByInverse = true;  // implicit_core.h: solve = invert + mat-vec, one construction site
   d4 accA[NSA];  // tile row Ia = wave:      slot k <-> tile (Ia, Ia - k), valid for k <= Ia
   d4 accB[NSB];  // tile row Ib = 15 - wave: slot k <-> tile (Ib, Ib - k), valid for k <= Ib
-  int Ia, Ib;    // wave-uniform
+  // The wave index is a TEMPLATE parameter: the kernel switches on it once and each wave runs its own
+  // instance, in which the tile rows, the validity of every register slot and most LDS addresses are
+  // compile-time (no per-slot branches around the MFMAs, operand loads hoisted by the compiler).
+  static constexpr int Ia = W, Ib = NT16 - 1 - W;
   int dim, tid, lane, gq, jq, target;
   double* lds;
   const double* base;  // rank-one metric: base matrix zero-padded, leading dimension base_ld
@@ -147,8 +150,8 @@ struct TeamMfma {
   __device__ __forceinline__ bool build(double x) {
     publish_vector(x);
     double chk = 0.0;
-    build_row<NSA>(accA, opaque_s(Ia), chk);
-    build_row<NSB>(accB, opaque_s(Ib), chk);
+    build_row<NSA>(accA, Ia, chk);
+    build_row<NSB>(accB, Ib, chk);
     const double bad = team_reduce(chk == 0.0 ? 0.0 : 1.0, 0, lds + kOffRed);
     return bad == 0.0;
   }
@@ -203,7 +206,7 @@ struct TeamMfma {
     double* wt = lds + kOffWt + par * (DPM * 4);
     const int k0 = 16 * I0 + 4 * R0;
     const int tid = opaque(this->tid);
-    const int ia = opaque_s(Ia), ib = opaque_s(Ib);
+    const int ia = Ia, ib = Ib;
     publish_row<NSA, R0>(accA, ia, I0, qt);
     publish_row<NSB, R0>(accB, ib, I0, qt);
     __syncthreads();
@@ -264,7 +267,7 @@ struct TeamMfma {
       block_step<2>(I0, 0, ok);
       block_step<3>(I0, 1, ok);
     }
-    const int ia = opaque_s(Ia), ib = opaque_s(Ib);
+    const int ia = Ia, ib = Ib;
 #pragma unroll
     for (int k = 0; k < NSA; ++k)
       if (k <= ia) accA[k] = -accA[k];
@@ -338,8 +341,8 @@ struct TeamMfma {
 
   __device__ __forceinline__ double matvec(double v) {
     publish_vector(v);
-    matvec_row<NSA>(accA, opaque_s(Ia));
-    matvec_row<NSB>(accB, opaque_s(Ib));
+    matvec_row<NSA>(accA, Ia);
+    matvec_row<NSB>(accB, Ib);
     __syncthreads();
     double y = 0.0;
     if (tid < DPM) {
@@ -392,12 +395,11 @@ struct TeamMfma {
   }
 };
 
-template <int RMETRIC>
-__global__ __launch_bounds__(NTHR, 2) void implicit_mfma_team_kernel(ImplicitArgs A, int base_ld) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+template <int RMETRIC, int W>
+__device__ __forceinline__ void run_team_chain(const ImplicitArgs& A, int base_ld, double* lds) {
   const int64_t chain = blockIdx.x;
   const int tid = threadIdx.x, dim = A.dim;
-  TeamMfma<RMETRIC> bk;
+  TeamMfma<RMETRIC, W> bk;
   bk.dim = dim;
   bk.tid = tid;
   bk.lane = tid & 63;
@@ -408,13 +410,6 @@ __global__ __launch_bounds__(NTHR, 2) void implicit_mfma_team_kernel(ImplicitArg
   bk.base = A.rparams;
   bk.base_ld = base_ld;
   bk.tparams = A.tparams;
-  {
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    bk.Ia = wave;
-    bk.Ib = NT16 - 1 - wave;
-  }
-  for (int i = tid; i < DPM * PSTR; i += NTHR) lds[kOffPart + i] = 0.0;  // unused partial-sum slots stay 0
-  __syncthreads();
   const bool act = tid < dim;
   double q = act ? A.pos[chain * dim + tid] : 0.0;
   double p = act ? A.mom[chain * dim + tid] : 0.0;
@@ -432,6 +427,24 @@ __global__ __launch_bounds__(NTHR, 2) void implicit_mfma_team_kernel(ImplicitArg
     A.status[chain] = r.status;
     A.n_done[chain] = r.done;
     add_counters(A.counters, r);
+  }
+}
+
+template <int RMETRIC>
+__global__ __launch_bounds__(NTHR, 2) void implicit_mfma_team_kernel(ImplicitArgs A, int base_ld) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  for (int i = threadIdx.x; i < DPM * PSTR; i += NTHR) lds[kOffPart + i] = 0.0;  // unused partial-sum slots stay 0
+  __syncthreads();
+  // every wave executes the same sequence of barriers; only the tile bookkeeping differs
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: run_team_chain<RMETRIC, 0>(A, base_ld, lds); break;
+    case 1: run_team_chain<RMETRIC, 1>(A, base_ld, lds); break;
+    case 2: run_team_chain<RMETRIC, 2>(A, base_ld, lds); break;
+    case 3: run_team_chain<RMETRIC, 3>(A, base_ld, lds); break;
+    case 4: run_team_chain<RMETRIC, 4>(A, base_ld, lds); break;
+    case 5: run_team_chain<RMETRIC, 5>(A, base_ld, lds); break;
+    case 6: run_team_chain<RMETRIC, 6>(A, base_ld, lds); break;
+    default: run_team_chain<RMETRIC, 7>(A, base_ld, lds); break;
   }
 }
 
