@@ -47,7 +47,10 @@ constexpr int VLM = DPM + 8;          // flat vectors: DPM elements + a dummy ce
 // LDS (doubles): panel/W double buffers, flat vectors, partial sums, reduction scratch, step state
 constexpr int kOffQt = 0;                          // [2][DPM][4]
 constexpr int kOffWt = kOffQt + 2 * DPM * 4;       // [2][DPM][4]
-constexpr int kOffNat = kOffWt + 2 * DPM * 4;      // [VLM]
+constexpr int kOffXt = kOffWt + 2 * DPM * 4;       // [2][DPM][4] X = Q - E.  NOT written over the panel: while thread
+                                                   // c stores its column, other waves may still be reading the
+                                                   // pivot block P = Q[:, K] from the panel
+constexpr int kOffNat = kOffXt + 2 * DPM * 4;      // [VLM]
 constexpr int kOffVperm = kOffNat + VLM;           // [DPM]
 constexpr int kOffAux = kOffVperm + DPM;           // [VLM]
 constexpr int kOffRed = kOffAux + VLM;             // [16]
@@ -204,6 +207,7 @@ struct TeamMfma {
   __device__ __forceinline__ void block_step(const int I0, const int par, bool& ok) {
     double* qt = lds + kOffQt + par * (DPM * 4);
     double* wt = lds + kOffWt + par * (DPM * 4);
+    double* xt = lds + kOffXt + par * (DPM * 4);
     const int k0 = 16 * I0 + 4 * R0;
     const int tid = opaque(this->tid);
     const int ia = Ia, ib = Ib;
@@ -249,12 +253,12 @@ struct TeamMfma {
       wv[1] = __builtin_fma(-p01, q[0], __builtin_fma(-p11, q[1], __builtin_fma(u10, q[2], u11 * q[3])));
       wv[2] = __builtin_fma(u00, q[0], __builtin_fma(u10, q[1], __builtin_fma(-is00, q[2], -is01 * q[3])));
       wv[3] = __builtin_fma(u01, q[0], __builtin_fma(u11, q[1], __builtin_fma(-is01, q[2], -is11 * q[3])));
-      if (s >= 0 && s < 4) *reinterpret_cast<d4*>(qt + (tid << 2)) = q;
+      *reinterpret_cast<d4*>(xt + (tid << 2)) = q;
       *reinterpret_cast<d4*>(wt + (tid << 2)) = wv;
     }
     __syncthreads();
-    update_row<NSA, R0>(accA, ia, I0, qt, wt);
-    update_row<NSB, R0>(accB, ib, I0, qt, wt);
+    update_row<NSA, R0>(accA, ia, I0, xt, wt);
+    update_row<NSB, R0>(accB, ib, I0, xt, wt);
     // no barrier: the next block uses the other panel / W buffers
   }
 
