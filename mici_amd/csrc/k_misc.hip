@@ -394,6 +394,22 @@ int mm_launch_implicit_midpoint_euclid(mm_ctx* ctx, const mm_model* m, mm_state*
   return MM_OK;
 }
 
+__global__ void fill_done_kernel(int32_t* __restrict__ status, int32_t* __restrict__ n_done, int64_t n, int32_t n_steps) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) {
+    status[i] = 0;
+    n_done[i] = n_steps;
+  }
+}
+
+int mm_launch_fill_done(mm_ctx* ctx, mm_state* s, int32_t n_steps) {
+  if (s->n == 0) return MM_OK;
+  hipLaunchKernelGGL(fill_done_kernel, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, ctx->stream, s->d_status,
+                     s->d_n_done, s->n, n_steps);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
 // y <- a x + b y  (CorrelatedMomentumTransition: mom *= sqrt(1 - c^2); mom += c mom_ind, transitions.py:194-196)
 __global__ void axpby_kernel(double* __restrict__ y, const double* __restrict__ x, double a, double b, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
