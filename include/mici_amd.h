@@ -101,6 +101,10 @@ typedef struct mm_model_desc {
   const double* target_params;
   size_t n_target_params;
   int32_t metric_kind; /* fixed metric (Euclidean / constrained systems) */
+  int32_t gaussian_split; /* 1 = GaussianEuclideanMetricSystem (systems.py:369-474): the target is a density
+                           * with respect to the standard Gaussian, h2 = q.q/2 + p.M^-1 p/2 and h2_flow is the
+                           * exact rotation in the metric's eigenbasis (systems.py:464-474).  Plain Euclidean
+                           * systems only (no rmetric, no constr). */
   const double* metric;
   size_t n_metric;
   int32_t rmetric; /* position-dependent metric (Riemannian systems) */

@@ -26,6 +26,7 @@ class ModelDesc(C.Structure):
         ("target_params", c_double_p),
         ("n_target_params", C.c_size_t),
         ("metric_kind", C.c_int32),
+        ("gaussian_split", C.c_int32),
         ("metric", c_double_p),
         ("n_metric", C.c_size_t),
         ("rmetric", C.c_int32),

@@ -16,6 +16,9 @@ struct EuclidModelView {
   const double* tparams;
   const double* minv;   // diag: 1/diag[D]; dense: explicit inverse [D*D]
   const double* mchol;  // diag: sqrt(diag)[D]; dense: lower Cholesky factor [D*D]
+  int gaussian;         // GaussianEuclideanMetricSystem: h2 = q.q/2 + p.M^-1 p/2, exact h2 flow
+  const double* omega;  // gaussian: 1/sqrt(eigval)[D] (nullptr for the identity metric)
+  const double* eigvec; // gaussian + dense: V [D*D] followed by V^T [D*D], row-major
 };
 
 __device__ __forceinline__ double minv_elem(const EuclidModelView& m, const double* p, int i) {
@@ -27,7 +30,59 @@ __device__ __forceinline__ double minv_elem(const EuclidModelView& m, const doub
   return s;
 }
 
-// dynamic LDS: per wave 3*dim doubles (q, p, scratch)
+// GaussianEuclideanMetricSystem.h2_flow (systems.py:464-474): with M = V diag(e) V^T and w = 1/sqrt(e),
+//   pos <- V (cos(w dt) V^T pos + sin(w dt) w V^T mom),  mom <- V (cos(w dt) V^T mom - sin(w dt)/w V^T pos)
+// an exact rotation, so the split integrator only discretises the non-Gaussian part of the target.
+// a, b are two scratch vectors; V and V^T are both stored so lane i always walks a contiguous column.
+__device__ __forceinline__ void gaussian_h2_flow(const EuclidModelView& m, double* q, double* p, double* a,
+                                                 double* b, double dt, int lane) {
+  const int dim = m.dim;
+  const bool dense = m.metric_kind == MM_METRIC_DENSE;
+  if (dense) {
+    for (int i = lane; i < dim; i += 64) {
+      double sa = 0.0, sb = 0.0;
+      for (int j = 0; j < dim; ++j) {
+        const double v = m.eigvec[(int64_t)j * dim + i];
+        sa += v * q[j];
+        sb += v * p[j];
+      }
+      a[i] = sa;
+      b[i] = sb;
+    }
+    wave_sync();
+  }
+  for (int i = lane; i < dim; i += 64) {
+    const double om = m.omega ? m.omega[i] : 1.0;
+    double sn, cs;
+    sincos(om * dt, &sn, &cs);
+    const double ai = dense ? a[i] : q[i], bi = dense ? b[i] : p[i];
+    const double na = cs * ai + (sn * om) * bi, nb = cs * bi - (sn / om) * ai;
+    if (dense) {
+      a[i] = na;
+      b[i] = nb;
+    } else {
+      q[i] = na;
+      p[i] = nb;
+    }
+  }
+  wave_sync();
+  if (dense) {
+    const double* vt = m.eigvec + (int64_t)dim * dim;
+    for (int i = lane; i < dim; i += 64) {
+      double sq = 0.0, sp = 0.0;
+      for (int j = 0; j < dim; ++j) {
+        const double v = vt[(int64_t)j * dim + i];
+        sq += v * a[j];
+        sp += v * b[j];
+      }
+      q[i] = sq;
+      p[i] = sp;
+    }
+    wave_sync();
+  }
+}
+
+// dynamic LDS: per wave 3*dim doubles (q, p, scratch), 4*dim for the Gaussian split
 __global__ void leapfrog_generic_kernel(EuclidModelView m, double* __restrict__ pos,
                                         double* __restrict__ mom, const int8_t* __restrict__ dir,
                                         const double* __restrict__ step_scale, int64_t n_chains,
@@ -37,7 +92,8 @@ __global__ void leapfrog_generic_kernel(EuclidModelView m, double* __restrict__ 
   const int dim = m.dim;
   const int64_t chain = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
   if (chain >= n_chains) return;  // whole wave exits together; no block-level barriers below
-  double* q = lds + (size_t)wave * 3 * dim;
+  const int nvec = m.gaussian ? 4 : 3;
+  double* q = lds + (size_t)wave * nvec * dim;
   double* p = q + dim;
   double* g = p + dim;
   for (int i = lane; i < dim; i += 64) {
@@ -51,11 +107,15 @@ __global__ void leapfrog_generic_kernel(EuclidModelView m, double* __restrict__ 
   for (int s = 0; s < n_steps; ++s) {
     for (int i = lane; i < dim; i += 64) p[i] -= ht * g[i];
     wave_sync();
-    // q += t * M^-1 p  (dense rows read the whole p, so stage the update through g)
-    for (int i = lane; i < dim; i += 64) g[i] = minv_elem(m, p, i);
-    wave_sync();
-    for (int i = lane; i < dim; i += 64) q[i] += t * g[i];
-    wave_sync();
+    if (m.gaussian) {
+      gaussian_h2_flow(m, q, p, g, g + dim, t, lane);
+    } else {
+      // q += t * M^-1 p  (dense rows read the whole p, so stage the update through g)
+      for (int i = lane; i < dim; i += 64) g[i] = minv_elem(m, p, i);
+      wave_sync();
+      for (int i = lane; i < dim; i += 64) q[i] += t * g[i];
+      wave_sync();
+    }
     aux = target_prepare(m.target, q, dim, m.tparams, lane);
     for (int i = lane; i < dim; i += 64) g[i] = target_grad_elem(m.target, aux, q, i, dim, m.tparams);
     wave_sync();
@@ -86,7 +146,8 @@ __global__ void composition_generic_kernel(EuclidModelView m, double* __restrict
   const int dim = m.dim;
   const int64_t chain = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
   if (chain >= n_chains) return;  // whole wave exits together; no block-level barriers below
-  double* q = lds + (size_t)wave * 3 * dim;
+  const int nvec = m.gaussian ? 4 : 3;
+  double* q = lds + (size_t)wave * nvec * dim;
   double* p = q + dim;
   double* g = p + dim;  // the cached gradient; doubles as scratch for M^-1 p during an h2 flow
   for (int i = lane; i < dim; i += 64) {
@@ -105,10 +166,14 @@ __global__ void composition_generic_kernel(EuclidModelView m, double* __restrict
         for (int i = lane; i < dim; i += 64) p[i] -= ct * g[i];
         wave_sync();
       } else {
-        for (int i = lane; i < dim; i += 64) g[i] = minv_elem(m, p, i);
-        wave_sync();
-        for (int i = lane; i < dim; i += 64) q[i] += ct * g[i];
-        wave_sync();
+        if (m.gaussian) {
+          gaussian_h2_flow(m, q, p, g, g + dim, ct, lane);
+        } else {
+          for (int i = lane; i < dim; i += 64) g[i] = minv_elem(m, p, i);
+          wave_sync();
+          for (int i = lane; i < dim; i += 64) q[i] += ct * g[i];
+          wave_sync();
+        }
         aux = target_prepare(m.target, q, dim, m.tparams, lane);
         for (int i = lane; i < dim; i += 64) g[i] = target_grad_elem(m.target, aux, q, i, dim, m.tparams);
         wave_sync();
@@ -144,7 +209,8 @@ __global__ void euclid_aux_kernel(EuclidModelView m, const double* __restrict__ 
     const TargetAux aux = target_prepare(m.target, q, dim, m.tparams, lane);
     double acc = 0.0;
     for (int i = lane; i < dim; i += 64)
-      acc += target_nld_elem(m.target, aux, q, i, dim, m.tparams) + 0.5 * p[i] * minv_elem(m, p, i);
+      acc += target_nld_elem(m.target, aux, q, i, dim, m.tparams) + 0.5 * p[i] * minv_elem(m, p, i) +
+             (m.gaussian ? 0.5 * q[i] * q[i] : 0.0);  // GaussianEuclideanMetricSystem.h2, systems.py:451-454
     acc = wave_sum(acc);
     if (lane == 0) out[chain] = acc;
   } else if constexpr (OP == OP_DH_DMOM) {
@@ -166,13 +232,13 @@ __global__ void euclid_aux_kernel(EuclidModelView m, const double* __restrict__ 
 
 EuclidModelView view_of(const mm_model* m) {
   return EuclidModelView{m->target, m->metric_kind, m->dim, m->d_target_params, m->d_metric_inv,
-                         m->d_metric_chol};
+                         m->d_metric_chol, m->gaussian_split, m->d_metric_omega, m->d_metric_eigvec};
 }
 
-int waves_per_block(int dim, size_t* lds_bytes) {
+int waves_per_block(int dim, size_t* lds_bytes, int nvec = 3) {
   int w = 4;
-  while (w > 1 && (size_t)w * 3 * dim * sizeof(double) > 60 * 1024) w >>= 1;
-  *lds_bytes = (size_t)w * 3 * dim * sizeof(double);
+  while (w > 1 && (size_t)w * nvec * dim * sizeof(double) > 60 * 1024) w >>= 1;
+  *lds_bytes = (size_t)w * nvec * dim * sizeof(double);
   return w;
 }
 
@@ -180,7 +246,7 @@ int waves_per_block(int dim, size_t* lds_bytes) {
 
 int mm_launch_leapfrog_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
   size_t lds;
-  const int w = waves_per_block(s->dim, &lds);
+  const int w = waves_per_block(s->dim, &lds, m->gaussian_split ? 4 : 3);
   if (lds > 64 * 1024) {
     mm_set_error(ctx, "mm_leapfrog_euclid: dim too large for the generic kernel's LDS tile");
     return MM_ERR_UNSUPPORTED;
@@ -195,7 +261,7 @@ int mm_launch_leapfrog_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, doub
 int mm_launch_composition_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
                                   int n_coeffs, const double* coeffs, int initial_h1) {
   size_t lds;
-  const int w = waves_per_block(s->dim, &lds);
+  const int w = waves_per_block(s->dim, &lds, m->gaussian_split ? 4 : 3);
   if (lds > 64 * 1024) {
     mm_set_error(ctx, "mm_composition_euclid: dim too large for the generic kernel's LDS tile");
     return MM_ERR_UNSUPPORTED;

@@ -169,6 +169,51 @@ static bool host_chol_inverse(const double* a, int n, std::vector<double>& l, st
   return true;
 }
 
+// Symmetric eigendecomposition by cyclic Jacobi rotations (host side, once per model): a = V diag(w) V^T
+// with V row-major, eigenvector k in column k.  Replaces DensePositiveDefiniteMatrix.eigval / eigvec
+// (matrices.py:1203-1219, numpy.linalg.eigh); only V f(w) V^T is ever formed from it, which does not
+// depend on the ordering or sign conventions of the decomposition.
+static bool host_jacobi_eigh(const double* a_in, int n, std::vector<double>& w, std::vector<double>& v) {
+  std::vector<double> a(a_in, a_in + (size_t)n * n);
+  v.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) v[(size_t)i * n + i] = 1.0;
+  double total = 0.0;
+  for (double x : a) total += x * x;
+  if (!std::isfinite(total)) return false;
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    double off = 0.0;
+    for (int i = 0; i < n; ++i)
+      for (int j = i + 1; j < n; ++j) off += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+    if (off <= 1e-34 * total) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = a[(size_t)p * n + q];
+        if (apq == 0.0) continue;
+        const double theta = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {  // columns p, q of a
+          const double akp = a[(size_t)k * n + p], akq = a[(size_t)k * n + q];
+          a[(size_t)k * n + p] = c * akp - s * akq;
+          a[(size_t)k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {  // rows p, q of a
+          const double apk = a[(size_t)p * n + k], aqk = a[(size_t)q * n + k];
+          a[(size_t)p * n + k] = c * apk - s * aqk;
+          a[(size_t)q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = v[(size_t)k * n + p], vkq = v[(size_t)k * n + q];
+          v[(size_t)k * n + p] = c * vkp - s * vkq;
+          v[(size_t)k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  w.resize(n);
+  for (int i = 0; i < n; ++i) w[i] = a[(size_t)i * n + i];
+  return true;
+}
+
 int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
   MM_REQUIRE(nullptr, ctx != nullptr, "mm_model_create: ctx is NULL");
   MM_REQUIRE(ctx, d != nullptr && out != nullptr, "mm_model_create: NULL argument");
@@ -221,6 +266,9 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
   MM_REQUIRE(ctx, d->target != MM_TARGET_FUNNEL || d->rmetric == MM_RMETRIC_NONE ||
                       d->rmetric == MM_RMETRIC_SOFTABS,
              "mm_model_create: the funnel target pairs with a fixed metric or the SoftAbs metric");
+  MM_REQUIRE(ctx, d->gaussian_split == 0 || d->gaussian_split == 1, "mm_model_create: gaussian_split must be 0 or 1");
+  MM_REQUIRE(ctx, !d->gaussian_split || (d->rmetric == MM_RMETRIC_NONE && d->constr == MM_CONSTR_NONE),
+             "mm_model_create: the Gaussian split is defined for plain Euclidean-metric systems only");
   if (d->rmetric == MM_RMETRIC_SOFTABS) {
     MM_REQUIRE(ctx, d->rmetric_params[0] > 0.0, "softabs_coeff must be positive");  // matrices.py:1652-1654
     MM_REQUIRE(ctx, d->target == MM_TARGET_FUNNEL || d->target == MM_TARGET_POLY,
@@ -233,6 +281,7 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
   m->dim = D;
   m->target = d->target;
   m->metric_kind = d->metric_kind;
+  m->gaussian_split = d->gaussian_split;
   m->rmetric = d->rmetric;
   m->constr = d->constr;
   m->n_target_params = need_t;
@@ -267,6 +316,11 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
     }
     if (rc == MM_OK) rc = upload(ctx, inv.data(), D, &m->d_metric_inv);
     if (rc == MM_OK) rc = upload(ctx, sq.data(), D, &m->d_metric_chol);
+    if (rc == MM_OK && d->gaussian_split) {  // omega = 1 / eigval**0.5 (systems.py:465), eigval = diagonal
+      std::vector<double> om(D);
+      for (int i = 0; i < D; ++i) om[i] = 1.0 / sq[i];
+      rc = upload(ctx, om.data(), D, &m->d_metric_omega);
+    }
   }
   if (rc == MM_OK && d->metric_kind == MM_METRIC_DENSE) {
     std::vector<double> l, inv;
@@ -276,6 +330,24 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
     }
     if (rc == MM_OK) rc = upload(ctx, inv.data(), (size_t)D * D, &m->d_metric_inv);
     if (rc == MM_OK) rc = upload(ctx, l.data(), (size_t)D * D, &m->d_metric_chol);
+    if (rc == MM_OK && d->gaussian_split) {
+      std::vector<double> w, v;
+      if (!host_jacobi_eigh(d->metric, D, w, v)) {
+        mm_set_error(ctx, "mm_model_create: eigendecomposition of the metric failed");
+        rc = MM_ERR_INVALID;
+      }
+      if (rc == MM_OK) {
+        std::vector<double> om(D), vv((size_t)2 * D * D);
+        for (int i = 0; i < D; ++i) om[i] = 1.0 / std::sqrt(w[i]);
+        for (int i = 0; i < D; ++i)
+          for (int j = 0; j < D; ++j) {
+            vv[(size_t)i * D + j] = v[(size_t)i * D + j];
+            vv[(size_t)D * D + (size_t)j * D + i] = v[(size_t)i * D + j];
+          }
+        rc = upload(ctx, om.data(), D, &m->d_metric_omega);
+        if (rc == MM_OK) rc = upload(ctx, vv.data(), vv.size(), &m->d_metric_eigvec);
+      }
+    }
   }
   if (rc != MM_OK) {
     mm_model_destroy(m);
@@ -292,6 +364,8 @@ int mm_model_destroy(mm_model* m) {
   (void)hipFree(m->d_metric);
   (void)hipFree(m->d_metric_inv);
   (void)hipFree(m->d_metric_chol);
+  (void)hipFree(m->d_metric_omega);
+  (void)hipFree(m->d_metric_eigvec);
   (void)hipFree(m->d_rmetric_params);
   (void)hipFree(m->d_rmetric_padded);
   (void)hipFree(m->d_constr_params);
@@ -461,7 +535,8 @@ int mm_leapfrog_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, in
              "mm_leapfrog_euclid: model is not a plain EuclideanMetricSystem");
   MM_REQUIRE(ctx, n_steps >= 0, "mm_leapfrog_euclid: n_steps < 0");
   if (s->n == 0 || n_steps == 0) return MM_OK;
-  rc = mm_launch_leapfrog_euclid(ctx, m, s, h, n_steps);
+  // the Gaussian split's exact h2 flow lives in the generic kernel only
+  rc = m->gaussian_split ? -100 : mm_launch_leapfrog_euclid(ctx, m, s, h, n_steps);
   if (rc == -100 || (rc == MM_ERR_UNSUPPORTED && m->dim > 128))
     rc = mm_launch_leapfrog_generic(ctx, m, s, h, n_steps);
   if (rc != MM_OK) return rc;

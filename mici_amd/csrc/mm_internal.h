@@ -31,6 +31,9 @@ struct mm_model {
   double* d_metric = nullptr;       // as given: diag[D] or dense[D*D]
   double* d_metric_inv = nullptr;   // diag: 1/diag [D]; dense: explicit inverse [D*D]
   double* d_metric_chol = nullptr;  // diag: sqrt(diag) [D]; dense: lower Cholesky factor [D*D]
+  int gaussian_split = 0;             // GaussianEuclideanMetricSystem (systems.py:369-474)
+  double* d_metric_omega = nullptr;   // gaussian_split: 1/sqrt(eigval) [D] (nullptr for the identity metric)
+  double* d_metric_eigvec = nullptr;  // gaussian_split + dense: V [D*D] then V^T [D*D]
   double* d_rmetric_params = nullptr;
   double* d_rmetric_padded = nullptr;  // rank-one base matrix zero-padded for the team kernels (dim > 32)
   int rmetric_pad_dim = 0;             // its leading dimension (mm_team_padded_dim)

@@ -78,7 +78,7 @@ class DeviceModel:
     """Device copy of a built-in model (target + fixed metric + Riemannian metric + constraint)."""
 
     def __init__(self, ctx, dim, target, metric_kind=0, metric=None, rmetric=0, rmetric_params=None,
-                 constr=0, constr_params=None):
+                 constr=0, constr_params=None, gaussian_split=False):
         self.ctx = ctx
         self._lib = ctx._lib
         self._keep = []
@@ -93,6 +93,7 @@ class DeviceModel:
         d.target = target.tid
         d.target_params, d.n_target_params = arr(target.params)
         d.metric_kind = metric_kind
+        d.gaussian_split = int(bool(gaussian_split))
         d.metric, d.n_metric = arr(metric)
         d.rmetric = rmetric
         d.rmetric_params, d.n_rmetric_params = arr(rmetric_params)

@@ -147,6 +147,17 @@ class EuclideanMetricSystem(System):
         return dict(metric_kind=self.metric_kind, metric=self.metric)
 
 
+class GaussianEuclideanMetricSystem(EuclideanMetricSystem):
+    """Euclidean-metric system whose target is a density with respect to the standard Gaussian measure
+    (reference systems.py:369-474): h1 = neg_log_dens, h2 = q.q/2 + p.M^-1 p/2, and ``h2_flow`` is the
+    exact rotation in the metric's eigenbasis (systems.py:464-474), so the splitting integrators only
+    discretise the non-Gaussian part.  As in the reference, ``dh_dpos`` is inherited from
+    EuclideanMetricSystem (systems.py:359-360) and therefore ImplicitMidpointIntegrator sees dh1_dpos only."""
+
+    def _model_args(self):
+        return dict(metric_kind=self.metric_kind, metric=self.metric, gaussian_split=True)
+
+
 class DenseRiemannianMetricSystem(System):
     """Position-dependent dense metric M(q) (reference systems.py:1690-1734, 1187-1402)."""
 

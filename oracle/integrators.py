@@ -278,6 +278,44 @@ class EuclidSystem:
     def h(self, q, p):
         return self.target.neg_log_dens(q) + 0.5 * p @ self.minv(p)
 
+    def h2_flow(self, q, p, dt):
+        """pos += dt M^-1 mom (systems.py:362-363); returns the new (q, p)."""
+        return q + dt * self.minv(p), p
+
+    def dh_dpos(self, q):
+        return self.grad(q)
+
+
+class GaussianEuclidSystem(EuclidSystem):
+    """GaussianEuclideanMetricSystem (systems.py:369-474): the target density is given with respect to the
+    standard Gaussian measure, h2 = q^T q / 2 + p^T M^-1 p / 2 and its flow is an exact rotation in the
+    metric's eigenbasis (split HMC, Shahbaba et al. 2014)."""
+
+    def __init__(self, target, metric_kind=mdl.METRIC_IDENTITY, metric=None):
+        super().__init__(target, metric_kind, metric)
+        d = target.dim
+        if metric_kind == mdl.METRIC_IDENTITY:
+            self.eigval, self.eigvec = np.ones(d), None
+        elif metric_kind == mdl.METRIC_DIAG:
+            self.eigval, self.eigvec = self.metric, None
+        else:
+            self.eigval, self.eigvec = np.linalg.eigh(self.metric)  # matrices.py:1207-1213
+
+    def h(self, q, p):
+        return self.target.neg_log_dens(q) + 0.5 * q @ q + 0.5 * p @ self.minv(p)
+
+    def h2_flow(self, q, p, dt):
+        omega = 1.0 / self.eigval**0.5
+        s, c = np.sin(omega * dt), np.cos(omega * dt)
+        if self.eigvec is None:
+            return c * q + (s * omega) * p, c * p - (s / omega) * q
+        a, b = self.eigvec.T @ q, self.eigvec.T @ p
+        return self.eigvec @ (c * a + (s * omega) * b), self.eigvec @ (c * b - (s / omega) * a)
+
+    # dh_dpos is deliberately NOT overridden: the reference's EuclideanMetricSystem.dh_dpos returns
+    # dh1_dpos alone (systems.py:359-360) and the Gaussian subclass inherits it, so its dh2_dpos = pos
+    # (systems.py:461-462) never reaches ImplicitMidpointIntegrator.  Parity follows the reference.
+
 
 def leapfrog_steps(system, q, p, dt, n_steps):
     """n_steps of LeapfrogIntegrator._step (integrators.py:170-173) for one chain, with
@@ -288,7 +326,7 @@ def leapfrog_steps(system, q, p, dt, n_steps):
     g = system.grad(q)
     for _ in range(n_steps):
         p -= (0.5 * dt) * g          # h1_flow(t/2), systems.py:143-152
-        q += dt * system.minv(p)     # h2_flow(t),   systems.py:362-363
+        q, p = system.h2_flow(q, p, dt)  # h2_flow(t), systems.py:362-363 (exact rotation for the Gaussian split)
         g = system.grad(q)
         p -= (0.5 * dt) * g          # h1_flow(t/2)
     return q, p
@@ -327,7 +365,7 @@ def composition_steps(system, q, p, dt, n_steps, free_coefficients, initial_h1_f
             if (i % 2 == 0) == bool(initial_h1_flow_step):
                 p -= (c * dt) * g
             else:
-                q += (c * dt) * system.minv(p)
+                q, p = system.h2_flow(q, p, c * dt)
                 g = system.grad(q)
     return q, p
 
@@ -534,7 +572,7 @@ def _midpoint_dh(system, q, p):
     if isinstance(system, RiemannianSystem):
         st = _State(q, p)
         return system.dh2_dmom(st), system.dh1_dpos(st) + system.dh2_dpos(st)
-    return system.minv(p), system.grad(q)
+    return system.minv(p), system.dh_dpos(q)
 
 
 def implicit_midpoint_step(system, q, p, dt, fp_solver=solve_fixed_point_direct, rev_tol=2e-8,

@@ -94,6 +94,39 @@ def test_metropolis_static_transitions(name):
                 assert_close(float(st[k]), g[f"stat_{k}"][t, c], 1e-10, f"{name} {k}")
 
 
+@pytest.mark.parametrize("name", golden_names("gausseuclid"))
+def test_gaussian_euclidean_metric_system(name):
+    """GaussianEuclideanMetricSystem (systems.py:369-474): h2 = q.q/2 + p.M^-1 p/2 with the exact
+    rotation as h2_flow, under the leapfrog, a BCSS composition and the implicit midpoint rule."""
+    g = load_golden(name)
+    n, d = g["q0"].shape
+    target = mdl.target_from_id(g["target"], g["target_params"], d)
+    mk = int(g["metric_kind"])
+    system = orc.GaussianEuclidSystem(target, mk, None if mk == mdl.METRIC_IDENTITY else g["metric"])
+    h, kind, free = float(g["step_size"]), int(g["integrator"]), list(g["free_coefficients"])
+    for k, s in enumerate(int(s) for s in g["checkpoints"]):
+        for c in range(n):
+            dt = g["dir"][c] * h
+            if kind == 0:
+                q, p = orc.leapfrog_steps(system, g["q0"][c], g["p0"][c], dt, s)
+            elif kind == 1:
+                q, p = orc.composition_steps(system, g["q0"][c], g["p0"][c], dt, s, free)
+            else:
+                q, p, st, nd = orc.implicit_midpoint_steps(system, g["q0"][c], g["p0"][c], dt, s)
+                assert st == 0 and nd == s
+            tol = 1e-12 * max(1, s) if kind < 2 else 1e-9
+            assert_close(q, g["q_out"][k, c], tol, f"{name} q@{s}")
+            assert_close(p, g["p_out"][k, c], tol, f"{name} p@{s}")
+            assert_close(system.h(q, p), g["h_out"][k, c], 1e-11, f"{name} h@{s}")
+    # the rotation is exact: composing +dt and -dt returns to the start, and h2 is conserved by it
+    q, p = g["q0"][0], g["p0"][0]
+    q1, p1 = system.h2_flow(q, p, 0.7)
+    q2, p2 = system.h2_flow(q1, p1, -0.7)
+    assert_close(q2, q, 1e-13, "h2_flow inverse q")
+    assert_close(p2, p, 1e-13, "h2_flow inverse p")
+    assert_close(0.5 * q1 @ q1 + 0.5 * p1 @ system.minv(p1), 0.5 * q @ q + 0.5 * p @ system.minv(p), 1e-13, "h2")
+
+
 @pytest.mark.parametrize("name", golden_names("midpoint"))
 def test_implicit_midpoint(name):
     """ImplicitMidpointIntegrator (integrators.py:547-681) on Euclidean and dense-Riemannian systems."""

@@ -742,6 +742,51 @@ def main():
     add_midpoint_riemann("midpoint_riemann_diagquad_d5_fail_bigstep", mdl.Poly(5, 1.0, 1.0 / 3.0),
                          mdl.DiagQuadMetric(5), 8, 0.9, [1, 4], qscale=1.5)
 
+    # ---- GaussianEuclideanMetricSystem: exact h2 flow (systems.py:369-474) ------------
+    def add_gauss(name, target, mk, metric, n, h, cps, integ_kind, free=()):
+        q0 = rng.standard_normal((n, target.dim))
+        osys = orc.GaussianEuclidSystem(target, mk, metric)
+        p0 = np.stack([osys.msqrt(zz) for zz in rng.standard_normal((n, target.dim))])
+
+        def make():
+            rsys = mici.systems.GaussianEuclideanMetricSystem(
+                neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+                metric=None if mk == mdl.METRIC_IDENTITY else np.array(metric))
+            if integ_kind == 0:
+                rint = mici.integrators.LeapfrogIntegrator(rsys, h)
+            elif integ_kind == 1:
+                rint = mici.integrators.SymmetricCompositionIntegrator(rsys, free, step_size=h)
+            else:
+                rint = mici.integrators.ImplicitMidpointIntegrator(rsys, h)
+            dirs = dirs_for(n)
+            ref, counts = run_reference(rint, rsys, q0, p0, dirs, cps)
+            for k, s in enumerate(cps):
+                for c in range(n):
+                    if integ_kind == 0:
+                        q, p = orc.leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, s)
+                    elif integ_kind == 1:
+                        q, p = orc.composition_steps(osys, q0[c], p0[c], dirs[c] * h, s, free)
+                    else:
+                        q, p, st, nd = orc.implicit_midpoint_steps(osys, q0[c], p0[c], dirs[c] * h, s)
+                        assert st == 0 and nd == s
+                    check_close(f"{name} q@{s}", q, ref["q_out"][k, c], 1e-12 * max(1, s) if integ_kind < 2 else 1e-9)
+                    check_close(f"{name} p@{s}", p, ref["p_out"][k, c], 1e-12 * max(1, s) if integ_kind < 2 else 1e-9)
+                    check_close(f"{name} h@{s}", np.array(osys.h(q, p)), ref["h_out"][k, c], 1e-11)
+            return dict(kind="gausseuclid", integrator=integ_kind, free_coefficients=np.array(free, dtype=np.float64),
+                        q0=q0, p0=p0, dir=dirs, step_size=h, checkpoints=np.array(cps),
+                        **model_keys(target, mk, metric), **ref), counts
+        cases[name] = make
+
+    add_gauss("gausseuclid_leapfrog_identity_d8", mdl.Poly(8, 0.3, 0.5), mdl.METRIC_IDENTITY, None, 4, 0.3, [1, 10], 0)
+    add_gauss("gausseuclid_leapfrog_diag_d8", mdl.Banana(8), mdl.METRIC_DIAG, np.exp(0.3 * rng.standard_normal(8)),
+              4, 0.05, [1, 10], 0)
+    add_gauss("gausseuclid_leapfrog_dense_d12", mdl.Poly(12, 0.0, 0.25), mdl.METRIC_DENSE, mdl.make_spd(12, rng),
+              4, 0.3, [1, 10, 40], 0)
+    add_gauss("gausseuclid_bcss3_dense_d12", mdl.GaussDense(mdl.make_spd(12, rng)), mdl.METRIC_DENSE,
+              mdl.make_spd(12, rng), 4, 0.4, [1, 10], 1, orc.BCSS_FREE_COEFFICIENTS[3])
+    add_gauss("gausseuclid_midpoint_diag_d5", mdl.Poly(5, 0.0, 1.0), mdl.METRIC_DIAG,
+              np.exp(0.2 * rng.standard_normal(5)), 4, 0.1, [1, 10], 2)
+
     # ---- correlated momentum refresh + random trajectory length (transitions.py:143-198, 355-402) ----------
     def make_corr_random():
         name = "corrmom_random_nstep_d10"
