@@ -103,14 +103,18 @@ typedef struct mm_model_desc {
   int32_t metric_kind; /* fixed metric (Euclidean / constrained systems) */
   int32_t gaussian_split; /* 1 = GaussianEuclideanMetricSystem (systems.py:369-474): the target is a density
                            * with respect to the standard Gaussian, h2 = q.q/2 + p.M^-1 p/2 and h2_flow is the
-                           * exact rotation in the metric's eigenbasis (systems.py:464-474).  Plain Euclidean
-                           * systems only (no rmetric, no constr). */
+                           * exact rotation in the metric's eigenbasis (systems.py:464-474).  With a constraint
+                           * this is GaussianDenseConstrainedEuclideanMetricSystem (systems.py:1034-1184), which
+                           * implies dens_wrt_ambient.  Not for Riemannian systems. */
   const double* metric;
   size_t n_metric;
   int32_t rmetric; /* position-dependent metric (Riemannian systems) */
   const double* rmetric_params;
   size_t n_rmetric_params;
   int32_t constr;
+  int32_t dens_wrt_ambient; /* constrained systems: 1 = dens_wrt_hausdorff=False, h1 includes the half
+                             * log-determinant of the Gram matrix (systems.py:829-831, 846-862, 1024-1031);
+                             * 0 = the reference default dens_wrt_hausdorff=True */
   const double* constr_params;
   size_t n_constr_params;
 } mm_model_desc;

@@ -33,6 +33,7 @@ class ModelDesc(C.Structure):
         ("rmetric_params", c_double_p),
         ("n_rmetric_params", C.c_size_t),
         ("constr", C.c_int32),
+        ("dens_wrt_ambient", C.c_int32),
         ("constr_params", c_double_p),
         ("n_constr_params", C.c_size_t),
     ]

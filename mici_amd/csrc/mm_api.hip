@@ -28,6 +28,7 @@ int mm_launch_euclid_sample_momentum(mm_ctx*, const mm_model*, mm_state*, const 
 int mm_launch_riemann_aux(mm_ctx*, const mm_model*, mm_state*, int op, double* d_out,
                           const double* d_z);
 int mm_launch_constrained_project_momentum(mm_ctx*, const mm_model*, mm_state*);
+int mm_launch_constrained_add_log_det_sqrt_gram(mm_ctx*, const mm_model*, mm_state*, double*);
 
 namespace {
 thread_local std::string g_last_error;
@@ -267,8 +268,12 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
                       d->rmetric == MM_RMETRIC_SOFTABS,
              "mm_model_create: the funnel target pairs with a fixed metric or the SoftAbs metric");
   MM_REQUIRE(ctx, d->gaussian_split == 0 || d->gaussian_split == 1, "mm_model_create: gaussian_split must be 0 or 1");
-  MM_REQUIRE(ctx, !d->gaussian_split || (d->rmetric == MM_RMETRIC_NONE && d->constr == MM_CONSTR_NONE),
-             "mm_model_create: the Gaussian split is defined for plain Euclidean-metric systems only");
+  MM_REQUIRE(ctx, !d->gaussian_split || d->rmetric == MM_RMETRIC_NONE,
+             "mm_model_create: the Gaussian split is defined for fixed-metric systems only");
+  MM_REQUIRE(ctx, d->dens_wrt_ambient == 0 || d->dens_wrt_ambient == 1,
+             "mm_model_create: dens_wrt_ambient must be 0 or 1");
+  MM_REQUIRE(ctx, !d->dens_wrt_ambient || d->constr != MM_CONSTR_NONE,
+             "mm_model_create: dens_wrt_ambient needs a constraint");
   if (d->rmetric == MM_RMETRIC_SOFTABS) {
     MM_REQUIRE(ctx, d->rmetric_params[0] > 0.0, "softabs_coeff must be positive");  // matrices.py:1652-1654
     MM_REQUIRE(ctx, d->target == MM_TARGET_FUNNEL || d->target == MM_TARGET_POLY,
@@ -282,6 +287,8 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
   m->target = d->target;
   m->metric_kind = d->metric_kind;
   m->gaussian_split = d->gaussian_split;
+  // GaussianDenseConstrainedEuclideanMetricSystem always passes dens_wrt_hausdorff=False (systems.py:1114-1124)
+  m->dens_wrt_ambient = (d->dens_wrt_ambient || (d->gaussian_split && d->constr != MM_CONSTR_NONE)) ? 1 : 0;
   m->rmetric = d->rmetric;
   m->constr = d->constr;
   m->n_target_params = need_t;
@@ -627,13 +634,20 @@ int mm_constrained_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
   return finish_counters(ctx, counters);
 }
 
+// System.h for every chain of s into d_out[N] (device): h1 + h2 of the model's system class.
+static int launch_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_out) {
+  int rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 0, d_out, nullptr)
+                                           : mm_launch_euclid_hamiltonian(ctx, m, s, d_out);
+  if (rc == MM_OK && m->dens_wrt_ambient) rc = mm_launch_constrained_add_log_det_sqrt_gram(ctx, m, s, d_out);
+  return rc;
+}
+
 int mm_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* h) {
   int rc = check_pair(ctx, m, s, "mm_hamiltonian");
   if (rc != MM_OK) return rc;
   MM_REQUIRE(ctx, h != nullptr, "mm_hamiltonian: h is NULL");
   if (s->n == 0) return MM_OK;
-  rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 0, s->d_scratch, nullptr)
-                                       : mm_launch_euclid_hamiltonian(ctx, m, s, s->d_scratch);
+  rc = launch_hamiltonian(ctx, m, s, s->d_scratch);
   if (rc != MM_OK) return rc;
   MM_HIP_CHECK(ctx, hipMemcpyAsync(h, s->d_scratch, (size_t)s->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -705,11 +719,9 @@ int mm_metropolis_accept(mm_ctx* ctx, const mm_model* m, mm_state* s, mm_state* 
   if (s->n == 0) return MM_OK;
   const size_t n = (size_t)s->n;
   // h(state) -> state scratch[0..N), h(proposal) -> proposal scratch[0..N)
-  rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 0, s->d_scratch, nullptr)
-                                       : mm_launch_euclid_hamiltonian(ctx, m, s, s->d_scratch);
+  rc = launch_hamiltonian(ctx, m, s, s->d_scratch);
   if (rc != MM_OK) return rc;
-  rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, prop, 0, prop->d_scratch, nullptr)
-                                       : mm_launch_euclid_hamiltonian(ctx, m, prop, prop->d_scratch);
+  rc = launch_hamiltonian(ctx, m, prop, prop->d_scratch);
   if (rc != MM_OK) return rc;
   // u -> device (the proposal's momentum buffer is dead after the select; use a small dedicated buffer)
   if (s->tr_elems < 2 * n) {

@@ -32,6 +32,7 @@ struct mm_model {
   double* d_metric_inv = nullptr;   // diag: 1/diag [D]; dense: explicit inverse [D*D]
   double* d_metric_chol = nullptr;  // diag: sqrt(diag) [D]; dense: lower Cholesky factor [D*D]
   int gaussian_split = 0;             // GaussianEuclideanMetricSystem (systems.py:369-474)
+  int dens_wrt_ambient = 0;           // constrained systems with dens_wrt_hausdorff=False (systems.py:846-862)
   double* d_metric_omega = nullptr;   // gaussian_split: 1/sqrt(eigval) [D] (nullptr for the identity metric)
   double* d_metric_eigvec = nullptr;  // gaussian_split + dense: V [D*D] then V^T [D*D]
   double* d_rmetric_params = nullptr;

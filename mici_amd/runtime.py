@@ -78,7 +78,7 @@ class DeviceModel:
     """Device copy of a built-in model (target + fixed metric + Riemannian metric + constraint)."""
 
     def __init__(self, ctx, dim, target, metric_kind=0, metric=None, rmetric=0, rmetric_params=None,
-                 constr=0, constr_params=None, gaussian_split=False):
+                 constr=0, constr_params=None, gaussian_split=False, dens_wrt_ambient=False):
         self.ctx = ctx
         self._lib = ctx._lib
         self._keep = []
@@ -98,6 +98,7 @@ class DeviceModel:
         d.rmetric = rmetric
         d.rmetric_params, d.n_rmetric_params = arr(rmetric_params)
         d.constr = constr
+        d.dens_wrt_ambient = int(bool(dens_wrt_ambient))
         d.constr_params, d.n_constr_params = arr(constr_params)
         h = C.c_void_p()
         _ffi.check(self._lib.mm_model_create(ctx.handle, C.byref(d), C.byref(h)), ctx.handle,

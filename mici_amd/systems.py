@@ -197,8 +197,9 @@ class SoftAbsRiemannianMetricSystem(System):
 
 
 class DenseConstrainedEuclideanMetricSystem(EuclideanMetricSystem):
-    """Euclidean-metric system on the manifold {q : constr(q) = 0}, density w.r.t. the Hausdorff
-    measure (reference systems.py:876-1031, 619-873; ``dens_wrt_hausdorff=True``)."""
+    """Euclidean-metric system on the manifold {q : constr(q) = 0} (reference systems.py:876-1031,
+    619-873).  ``dens_wrt_hausdorff=False`` adds the half log-determinant of the Gram matrix to h1 and its
+    gradient (through the device model's constraint Hessian) to dh1_dpos (systems.py:829-862, 1024-1031)."""
 
     _kind = "constrained"
 
@@ -210,12 +211,28 @@ class DenseConstrainedEuclideanMetricSystem(EuclideanMetricSystem):
             raise TypeError("constr must be a built-in mici_amd.models.Constraint")
         if jacob_constr is not None or mhp_constr is not None:
             raise ValueError("constraint derivatives are supplied by the device model")
-        if not dens_wrt_hausdorff:
-            raise NotImplementedError(
-                "dens_wrt_hausdorff=False (Gram log-det term) is outside the accelerated path")
+        self.dens_wrt_hausdorff = bool(dens_wrt_hausdorff)
         self.constraint = constr
 
     def _model_args(self):
+        args = EuclideanMetricSystem._model_args(self)
+        args.update(constr=self.constraint.cid, constr_params=self.constraint.params,
+                    dens_wrt_ambient=not self.dens_wrt_hausdorff)
+        return args
+
+
+class GaussianDenseConstrainedEuclideanMetricSystem(DenseConstrainedEuclideanMetricSystem):
+    """Gaussian split on a constrained system (reference systems.py:1034-1184): h2 = q.q/2 + p.M^-1 p/2 with
+    the exact rotation as h2_flow, dh2_flow_dmom = (V diag(sin(w|t|) w) V^T, V diag(cos(w|t|)) V^T), symmetric
+    (eigendecomposed) Gram-type matrices, and always ``dens_wrt_hausdorff=False``."""
+
+    def __init__(self, neg_log_dens, constr, *, metric=None, grad_neg_log_dens=None, jacob_constr=None,
+                 mhp_constr=None, backend=None):
+        super().__init__(neg_log_dens, constr, metric=metric, dens_wrt_hausdorff=False,
+                         grad_neg_log_dens=grad_neg_log_dens, jacob_constr=jacob_constr,
+                         mhp_constr=mhp_constr, backend=backend)
+
+    def _model_args(self):
         args = super()._model_args()
-        args.update(constr=self.constraint.cid, constr_params=self.constraint.params)
+        args.update(gaussian_split=True)
         return args

@@ -630,14 +630,43 @@ def implicit_midpoint_steps(system, q, p, dt, n_steps, **kw):
 
 
 # ---- constrained system (systems.py:619-873, 876-1031) ----------------------------------------------
+class DenseSymmetric:
+    """DenseSymmetricMatrix as used on the path (matrices.py:1414-1447, 428-459): eigendecomposition-based
+    inverse and log|det|, no definiteness required."""
+
+    def __init__(self, array):
+        self.array = _chk_finite(np.asarray(array, dtype=np.float64))
+        self._eig = None
+
+    @property
+    def eig(self):
+        if self._eig is None:
+            try:
+                self._eig = np.linalg.eigh(self.array)
+            except np.linalg.LinAlgError as e:
+                raise LinAlgError(str(e)) from e
+        return self._eig
+
+    @property
+    def inv(self):
+        w, v = self.eig
+        return v @ ((1 / w)[:, None] * v.T)
+
+    @property
+    def log_abs_det(self):
+        return np.log(np.abs(self.eig[0])).sum()
+
+
 class ConstrainedSystem(EuclidSystem):
-    """DenseConstrainedEuclideanMetricSystem, dens_wrt_hausdorff=True (the default)."""
+    """DenseConstrainedEuclideanMetricSystem (systems.py:876-1031, 619-873).  ``dens_wrt_hausdorff=False``
+    adds the half log-determinant of the Gram matrix to h1 (systems.py:846-862, 1024-1031)."""
 
     def __init__(self, target, constraint, metric_kind=mdl.METRIC_IDENTITY, metric=None,
-                 counters=None):
+                 counters=None, dens_wrt_hausdorff=True):
         super().__init__(target, metric_kind, metric)
         self.constraint = constraint
         self.counters = counters if counters is not None else Counters()
+        self.dens_wrt_hausdorff = dens_wrt_hausdorff
 
     def constr(self, q):
         self.counters.bump("constr")
@@ -655,10 +684,86 @@ class ConstrainedSystem(EuclidSystem):
             return self._inv_diag[:, None] * a
         return self._inv @ a
 
+    # ---- the pieces the Gaussian split replaces -------------------------------------------------
+    def inner_product(self, a):
+        """jacob_constr_inner_product with a single Jacobian (systems.py:1016-1019): Cholesky-factored."""
+        return DensePD(a)
+
+    def flow_pos_dmom_mat(self, abs_t, a):
+        """dh2_flow_dmom(|t|)[0] @ a for a (D, C) array: |t| M^-1 (systems.py:794-799)."""
+        return abs_t * self.minv_mat(a)
+
+    def flow_pos_dmom_vec(self, abs_t, v):
+        return abs_t * self.minv(v)
+
+    def flow_mom_dmom_vec(self, abs_t, v):
+        """dh2_flow_dmom(|t|)[1] @ v: the identity for a plain Euclidean metric."""
+        return v
+
+    # ---- gram-matrix terms ---------------------------------------------------------------------------
+    def gram(self, jac):
+        return self.inner_product(jac @ self.minv_mat(jac.T))  # systems.py:800-818
+
     def project_onto_cotangent_space(self, mom, jac):
-        # systems.py:863-873;  gram = J M^-1 J^T (Cholesky-factored, :1016-1019)
-        gram = DensePD(jac @ self.minv_mat(jac.T))
-        return mom - jac.T @ (gram.inv_matvec(jac @ self.minv(mom)))
+        # systems.py:863-873;  gram = J M^-1 J^T
+        return mom - jac.T @ (self.gram(jac).inv @ (jac @ self.minv(mom)))
+
+    def log_det_sqrt_gram(self, q):
+        return 0.5 * self.gram(self.constraint.jacob_constr(q)).log_abs_det  # systems.py:829-831
+
+    def grad_log_det_sqrt_gram(self, q):
+        # systems.py:1024-1031: mhp_constr(inv_gram @ jacob_constr @ metric.inv)
+        mhp = self.constraint.mhp_constr(q)
+        jac = self.constraint.jacob_constr(q)
+        return mhp(self.minv_mat((self.gram(jac).inv @ jac).T).T)
+
+    def dh1_dpos(self, q):
+        if self.dens_wrt_hausdorff:
+            return self.grad(q)
+        return self.grad(q) + self.grad_log_det_sqrt_gram(q)  # systems.py:858-862
+
+    def h(self, q, p):
+        h = super().h(q, p)
+        return h if self.dens_wrt_hausdorff else h + self.log_det_sqrt_gram(q)  # systems.py:853-856
+
+
+class GaussianConstrainedSystem(ConstrainedSystem):
+    """GaussianDenseConstrainedEuclideanMetricSystem (systems.py:1034-1184): the Gaussian split on a
+    constrained system.  Always dens_wrt_hausdorff=False; Gram-type matrices are DenseSymmetricMatrix
+    (:1148-1161) and dh2_flow_dmom = (V diag(sin(w|t|) w) V^T, V diag(cos(w|t|)) V^T) (:1163-1176)."""
+
+    def __init__(self, target, constraint, metric_kind=mdl.METRIC_IDENTITY, metric=None, counters=None):
+        super().__init__(target, constraint, metric_kind, metric, counters, dens_wrt_hausdorff=False)
+        d = target.dim
+        if metric_kind == mdl.METRIC_IDENTITY:
+            self.eigval, self.eigvec = np.ones(d), None
+        elif metric_kind == mdl.METRIC_DIAG:
+            self.eigval, self.eigvec = self.metric, None
+        else:
+            self.eigval, self.eigvec = np.linalg.eigh(self.metric)
+
+    h2_flow = GaussianEuclidSystem.h2_flow
+
+    def inner_product(self, a):
+        return DenseSymmetric(a)
+
+    def _eig_apply(self, coef, a):
+        if self.eigvec is None:
+            return (coef * a.T).T
+        return self.eigvec @ ((coef * (self.eigvec.T @ a).T).T)
+
+    def flow_pos_dmom_mat(self, abs_t, a):
+        omega = 1.0 / self.eigval**0.5
+        return self._eig_apply(np.sin(omega * abs_t) * omega, a)
+
+    flow_pos_dmom_vec = flow_pos_dmom_mat
+
+    def flow_mom_dmom_vec(self, abs_t, v):
+        omega = 1.0 / self.eigval**0.5
+        return self._eig_apply(np.cos(omega * abs_t), v)
+
+    def h(self, q, p):
+        return super().h(q, p) + 0.5 * q @ q  # systems.py:451-454
 
 
 def solve_projection_newton(
@@ -678,15 +783,15 @@ def solve_projection_newton(
             jac = system.jacob(q)
             c = system.constr(q)
             error = norm(c)
-            a = _chk_finite(jac @ (abs_t * system.minv_mat(jac_prev.T)))
+            a = _chk_finite(jac @ system.flow_pos_dmom_mat(abs_t, jac_prev.T))
             lu, piv = sla.lu_factor(a, check_finite=False)
             delta_mu = jac_prev.T @ sla.lu_solve((lu, piv), c, check_finite=False)
-            delta_pos = abs_t * system.minv(delta_mu)
+            delta_pos = system.flow_pos_dmom_vec(abs_t, delta_mu)
             if error > divergence_tol or np.isnan(error):
                 raise ConvergenceError(f"Newton solver diverged at iteration {i}.",
                                        ST_DIVERGED, i)
             if error < constraint_tol and norm(delta_pos) < position_tol:
-                p = p - np.sign(t) * mu
+                p = p - np.sign(t) * system.flow_mom_dmom_vec(abs_t, mu)
                 return q, p
             mu = mu + delta_mu
             q = q - delta_pos
@@ -706,8 +811,7 @@ def solve_projection_quasi_newton(
     LinAlgError outside the solver); only constr is re-evaluated in the loop."""
     mu = np.zeros_like(q)
     abs_t = abs(t)
-    gram = DensePD(jac_prev @ (abs_t * system.minv_mat(jac_prev.T)))
-    inv_gram = gram.inv
+    inv_gram = system.inner_product(jac_prev @ system.flow_pos_dmom_mat(abs_t, jac_prev.T)).inv
     error = np.nan
     i = -1
     try:
@@ -716,12 +820,12 @@ def solve_projection_quasi_newton(
             c = system.constr(q)
             error = norm(c)
             delta_mu = jac_prev.T @ (inv_gram @ c)
-            delta_pos = abs_t * system.minv(delta_mu)
+            delta_pos = system.flow_pos_dmom_vec(abs_t, delta_mu)
             if error > divergence_tol or np.isnan(error):
                 raise ConvergenceError(f"Quasi-Newton solver diverged on iteration {i}.",
                                        ST_DIVERGED, i)
             if error < constraint_tol and norm(delta_pos) < position_tol:
-                p = p - np.sign(t) * mu
+                p = p - np.sign(t) * system.flow_mom_dmom_vec(abs_t, mu)
                 return q, p, system.jacob(q)
             mu = mu + delta_mu
             q = q - delta_pos
@@ -750,12 +854,12 @@ def solve_projection_newton_line_search(
             if i > 0 and (error > divergence_tol or np.isnan(error)):
                 raise ConvergenceError(f"Newton solver diverged at iteration {i}.", ST_DIVERGED, i)
             if error < constraint_tol and (i == 0 or norm(step_size * delta_pos) < position_tol):
-                p = p - np.sign(t) * mu
+                p = p - np.sign(t) * system.flow_mom_dmom_vec(abs_t, mu)
                 return q, p, jac
-            a = _chk_finite(jac @ (abs_t * system.minv_mat(jac_prev.T)))
+            a = _chk_finite(jac @ system.flow_pos_dmom_mat(abs_t, jac_prev.T))
             lu, piv = sla.lu_factor(a, check_finite=False)
             delta_mu = jac_prev.T @ sla.lu_solve((lu, piv), c, check_finite=False)
-            delta_pos = -(abs_t * system.minv(delta_mu))
+            delta_pos = -system.flow_pos_dmom_vec(abs_t, delta_mu)
             pos_curr = q.copy()
             step_size = 1.0
             for _ in range(max_line_search_iters):
@@ -788,7 +892,7 @@ def constrained_leapfrog_step(system, q, p, dt, n_inner_step=1, rev_tol=2e-8,
     proj_kwargs = proj_kwargs or {}
     solve = PROJ_SOLVERS[proj_solver]
     if grad_jac is None:
-        grad_jac = (system.grad(q), system.jacob(q))
+        grad_jac = (system.dh1_dpos(q), system.jacob(q))
     g, jac = grad_jac
 
     # A(t/2): h1_flow then cotangent projection (:947-949)
@@ -798,15 +902,15 @@ def constrained_leapfrog_step(system, q, p, dt, n_inner_step=1, rev_tol=2e-8,
     t_in = dt / n_inner_step
     for i in range(n_inner_step):
         q_prev, jac_prev = q, jac
-        q_new = q + t_in * system.minv(p)  # h2_flow, systems.py:362-363
+        q_new, p = system.h2_flow(q, p, t_in)  # systems.py:362-363 (exact rotation for the Gaussian split)
         q_new, p, _ = solve(system, q_new, p, q_prev, jac_prev, t_in, **proj_kwargs)
         jac_new = system.jacob(q_new)
         if i == n_inner_step - 1:
-            g = system.grad(q_new)  # pre-evaluated dh1_dpos, :956-969
+            g = system.dh1_dpos(q_new)  # pre-evaluated dh1_dpos, :956-969
         p = system.project_onto_cotangent_space(p, jac_new)
         # reversibility check (:971-979)
-        q_back = q_new + (-t_in) * system.minv(p)
-        q_back, _, _ = solve(system, q_back, p.copy(), q_new, jac_new, -t_in, **proj_kwargs)
+        q_back, p_back = system.h2_flow(q_new, p, -t_in)
+        q_back, _, _ = solve(system, q_back, p_back.copy(), q_new, jac_new, -t_in, **proj_kwargs)
         if rev_norm(q_back - q_prev) > rev_tol:
             raise NonReversibleStepError("Non-reversible step (positions).")
         q, jac = q_new, jac_new

@@ -313,6 +313,16 @@ class TorusConstr:
         f = 2.0 * (rho - self.R) / rho
         return np.array([[f * x, f * y, 2.0 * z]])
 
+    def mhp_constr(self, q):
+        """m[C, D] -> sum_{c,i} m[c, i] d2 constr_c / dq_i dq_k (the MatrixHessianProduct of systems.py:1006-1008)."""
+        x, y, z = q
+        rho = np.sqrt(x * x + y * y)
+        dr = rho - self.R
+        hess = np.array([[2 * x * x / rho**2 + 2 * dr * y * y / rho**3, 2 * x * y * self.R / rho**3, 0.0],
+                         [2 * x * y * self.R / rho**3, 2 * y * y / rho**2 + 2 * dr * x * x / rho**3, 0.0],
+                         [0.0, 0.0, 2.0]])
+        return lambda m: hess @ m[0]
+
 
 class FirstCoordConstr:
     cid = CONSTR_FIRST
@@ -325,6 +335,9 @@ class FirstCoordConstr:
 
     def jacob_constr(self, q):
         return np.eye(1, q.shape[0], 0)
+
+    def mhp_constr(self, q):
+        return lambda m: np.zeros_like(q)
 
 
 class CircleConstr:
@@ -341,6 +354,13 @@ class CircleConstr:
         j[0, 0] = 2.0 * q[0]
         j[0, 1] = 2.0 * q[1]
         return j
+
+    def mhp_constr(self, q):
+        def mhp(m):
+            out = np.zeros_like(q)
+            out[0], out[1] = 2.0 * m[0, 0], 2.0 * m[0, 1]
+            return out
+        return mhp
 
 
 # ---- synthetic parameter generators -----------------------------------------

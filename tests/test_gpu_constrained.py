@@ -22,7 +22,12 @@ def build(g):
     constr = models.constr_from_id(g["constr"], g["constr_params"])
     mk = int(g["metric_kind"])
     metric = None if mk == models.METRIC_IDENTITY else g["metric"]
-    system = systems.DenseConstrainedEuclideanMetricSystem(target, constr, metric=metric)
+    variant = str(g.get("variant", "hausdorff"))
+    if variant == "gaussian":  # GaussianDenseConstrainedEuclideanMetricSystem, systems.py:1034-1184
+        system = systems.GaussianDenseConstrainedEuclideanMetricSystem(target, constr, metric=metric)
+    else:
+        system = systems.DenseConstrainedEuclideanMetricSystem(target, constr, metric=metric,
+                                                               dens_wrt_hausdorff=(variant == "hausdorff"))
     proj = {0: solvers.solve_projection_onto_manifold_newton,
             1: solvers.solve_projection_onto_manifold_quasi_newton,
             2: solvers.solve_projection_onto_manifold_newton_with_line_search}[int(g.get("proj_solver", 0))]
@@ -84,6 +89,49 @@ def test_torus_full_size_properties():
     assert back.mean() > 0.95
     assert np.allclose(qb[back], q0[ok5][back], rtol=1e-5, atol=1e-6)
     assert np.allclose(pb[back], p0[ok5][back], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("variant", ["ambient", "gaussian"])
+@pytest.mark.parametrize("metric_kind", ["identity", "diag", "dense"])
+def test_gram_term_and_gaussian_split_match_oracle(variant, metric_kind):
+    """dens_wrt_hausdorff=False and the Gaussian split at a c5-sized shard: oracle on a sample, manifold and
+    cotangent residuals, and h (with its log-det-sqrt-Gram term) on every chain."""
+    rng = np.random.default_rng(99)
+    n, h, steps = 1024, 0.08, 12
+    target, constr = omdl.Torus(), omdl.TorusConstr()
+    if metric_kind == "identity":
+        mk, metric = omdl.METRIC_IDENTITY, None
+    elif metric_kind == "diag":
+        mk, metric = omdl.METRIC_DIAG, np.exp(0.3 * rng.standard_normal(3))
+    else:
+        mk, metric = omdl.METRIC_DENSE, omdl.make_spd(3, rng)
+    if variant == "gaussian":
+        osys = orc.GaussianConstrainedSystem(target, constr, mk, metric)
+        system = systems.GaussianDenseConstrainedEuclideanMetricSystem(models.Torus(), models.TorusConstr(),
+                                                                       metric=metric)
+    else:
+        osys = orc.ConstrainedSystem(target, constr, mk, metric, dens_wrt_hausdorff=False)
+        system = systems.DenseConstrainedEuclideanMetricSystem(models.Torus(), models.TorusConstr(),
+                                                               metric=metric, dens_wrt_hausdorff=False)
+    integ = integrators.ConstrainedLeapfrogIntegrator(system, h)
+    q0 = omdl.torus_init(n, rng)
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, 3)))
+    dirs = np.where(rng.random(n) < 0.5, 1, -1).astype(np.int8)
+    q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=steps)
+    ok = status == 0
+    assert ok.mean() > 0.9
+    c = np.array([constr.constr(x)[0] for x in q[ok]])
+    assert np.max(np.abs(c)) < 1e-8
+    jac = np.stack([constr.jacob_constr(x)[0] for x in q[ok]])
+    minv_p = np.stack([osys.minv(x) for x in p[ok]])
+    assert np.max(np.abs(np.sum(jac * minv_p, 1))) < 1e-8
+    for cidx in np.concatenate([np.arange(5), rng.integers(0, n, 5)]):
+        qo, po, so, no = orc.constrained_leapfrog_steps(osys, q0[cidx], p0[cidx], dirs[cidx] * h, steps)
+        assert so == status[cidx] and no == n_done[cidx]
+        assert_close(q[cidx], qo, 1e-9, f"q chain {cidx}")
+        assert_close(p[cidx], po, 1e-9, f"p chain {cidx}")
+    ho = np.array([osys.h(q[i], p[i]) for i in range(64)])
+    assert_close(system.h_batch(q[:64], p[:64]), ho, 1e-12, "h with the Gram term")
 
 
 def test_single_state_step_raises_reference_exceptions():

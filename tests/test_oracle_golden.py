@@ -267,7 +267,11 @@ def test_constrained_leapfrog(name):
     constraint = mdl.constr_from_id(g["constr"], g["constr_params"])
     mk = int(g["metric_kind"])
     metric = None if mk == mdl.METRIC_IDENTITY else g["metric"]
-    system = orc.ConstrainedSystem(target, constraint, mk, metric)
+    variant = str(g.get("variant", "hausdorff"))  # "ambient": dens_wrt_hausdorff=False; "gaussian": Gaussian split
+    if variant == "gaussian":
+        system = orc.GaussianConstrainedSystem(target, constraint, mk, metric)
+    else:
+        system = orc.ConstrainedSystem(target, constraint, mk, metric, dens_wrt_hausdorff=(variant == "hausdorff"))
     h = float(g["step_size"])
     s_max = int(g["checkpoints"].max())
     for c in range(n):
@@ -277,6 +281,8 @@ def test_constrained_leapfrog(name):
                 proj_solver=int(g.get("proj_solver", 0)))
             assert_close(q, g["q_out"][k, c], 1e-10, f"{name} q@{s} chain {c}")
             assert_close(p, g["p_out"][k, c], 1e-10, f"{name} p@{s} chain {c}")
+            if nd == s:
+                assert_close(system.h(q, p), g["h_out"][k, c], 1e-10, f"{name} h@{s} chain {c}")
             if s == s_max:
                 assert st == g["status"][c]
                 assert nd == g["n_done"][c]

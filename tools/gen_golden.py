@@ -403,20 +403,35 @@ def riemann_case(name, target, rmetric, softabs_coeff, q0, p0, dirs, h, checkpoi
     ), counts
 
 
+def oracle_constrained_system(target, constraint, metric_kind, metric, variant):
+    if variant == "gaussian":
+        return orc.GaussianConstrainedSystem(target, constraint, metric_kind, metric)
+    return orc.ConstrainedSystem(target, constraint, metric_kind, metric,
+                                 dens_wrt_hausdorff=(variant == "hausdorff"))
+
+
 def constrained_case(name, target, constraint, metric_kind, metric, q0, p0, dirs, h,
-                     checkpoints, n_inner=1, proj_solver=0):
+                     checkpoints, n_inner=1, proj_solver=0, variant="hausdorff"):
     ref_metric = None if metric_kind == mdl.METRIC_IDENTITY else np.array(metric)
-    system = mici.systems.DenseConstrainedEuclideanMetricSystem(
-        neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
-        constr=constraint.constr, jacob_constr=constraint.jacob_constr, metric=ref_metric,
-    )
+    if variant == "gaussian":
+        system = mici.systems.GaussianDenseConstrainedEuclideanMetricSystem(
+            neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+            constr=constraint.constr, jacob_constr=constraint.jacob_constr,
+            mhp_constr=constraint.mhp_constr, metric=ref_metric,
+        )
+    else:
+        system = mici.systems.DenseConstrainedEuclideanMetricSystem(
+            neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+            constr=constraint.constr, jacob_constr=constraint.jacob_constr, metric=ref_metric,
+            **({} if variant == "hausdorff" else dict(dens_wrt_hausdorff=False, mhp_constr=constraint.mhp_constr)),
+        )
     ref_proj = {0: mici.solvers.solve_projection_onto_manifold_newton,
                 1: mici.solvers.solve_projection_onto_manifold_quasi_newton,
                 2: mici.solvers.solve_projection_onto_manifold_newton_with_line_search}[proj_solver]
     integrator = mici.integrators.ConstrainedLeapfrogIntegrator(
         system, h, n_inner_step=n_inner, projection_solver=ref_proj)
     ref, counts = run_reference(integrator, system, q0, p0, dirs, checkpoints)
-    osys = orc.ConstrainedSystem(target, constraint, metric_kind, metric)
+    osys = oracle_constrained_system(target, constraint, metric_kind, metric, variant)
     n_max = max(checkpoints)
     for c in range(q0.shape[0]):
         for k, s in enumerate(checkpoints):
@@ -424,6 +439,8 @@ def constrained_case(name, target, constraint, metric_kind, metric, q0, p0, dirs
                 osys, q0[c], p0[c], dirs[c] * h, s, n_inner_step=n_inner, proj_solver=proj_solver)
             check_close(f"{name} q@{s} chain {c}", q, ref["q_out"][k, c], 1e-10)
             check_close(f"{name} p@{s} chain {c}", p, ref["p_out"][k, c], 1e-10)
+            if variant != "hausdorff" and nd == s:
+                check_close(f"{name} h@{s} chain {c}", np.array(osys.h(q, p)), ref["h_out"][k, c], 1e-10)
             if s == n_max:
                 assert st == ref["status"][c], (name, c, st, ref["status"][c])
                 assert nd == ref["n_done"][c], (name, c, nd, ref["n_done"][c])
@@ -432,6 +449,7 @@ def constrained_case(name, target, constraint, metric_kind, metric, q0, p0, dirs
         constr=constraint.cid, constr_params=constraint.params(), metric_kind=metric_kind,
         metric=np.zeros(0) if metric is None else np.asarray(metric), q0=q0, p0=p0, dir=dirs,
         step_size=h, checkpoints=np.array(checkpoints), n_inner=n_inner, proj_solver=proj_solver,
+        **({} if variant == "hausdorff" else dict(variant=variant)),
         **ref,
     ), counts
 
@@ -547,13 +565,14 @@ def main():
     add_riemann("softabs_poly_d5", mdl.Poly(5, 1.0, 1.0 / 3.0), None, 1.0, 5, 0.1, [1, 5, 20])
 
     # ---- constrained leapfrog (c5 + the reference's own constrained test systems) ------------------
-    def add_constrained(name, target, constraint, mk, metric, q0, h, cps, n_inner=1, proj_solver=0):
+    def add_constrained(name, target, constraint, mk, metric, q0, h, cps, n_inner=1, proj_solver=0,
+                        variant="hausdorff"):
         n, d = q0.shape
         z = rng.standard_normal((n, d))
         osys = orc.ConstrainedSystem(target, constraint, mk, metric)
         p0 = project_momentum(osys, q0, np.stack([osys.msqrt(zz) for zz in z]))
         cases[name] = lambda: constrained_case(name, target, constraint, mk, metric, q0, p0,
-                                               dirs_for(n), h, cps, n_inner, proj_solver)
+                                               dirs_for(n), h, cps, n_inner, proj_solver, variant)
 
     add_constrained("constrained_c5_torus", mdl.Torus(), mdl.TorusConstr(), mdl.METRIC_IDENTITY,
                     None, mdl.torus_init(16, rng), 0.1, [1, 5, 20, 100])
@@ -786,6 +805,30 @@ def main():
               mdl.make_spd(12, rng), 4, 0.4, [1, 10], 1, orc.BCSS_FREE_COEFFICIENTS[3])
     add_gauss("gausseuclid_midpoint_diag_d5", mdl.Poly(5, 0.0, 1.0), mdl.METRIC_DIAG,
               np.exp(0.2 * rng.standard_normal(5)), 4, 0.1, [1, 10], 2)
+
+    # ---- dens_wrt_hausdorff=False and the Gaussian split on constrained systems (systems.py:846-862,
+    #      1024-1031, 1034-1184; tests/test_integrators.py:568-615).  Registered after all older cases. ---------
+    for variant, tag in (("ambient", "ambient"), ("gaussian", "gauss")):
+        eigval = np.exp(0.1 * rng.standard_normal(5))
+        eigvec = np.linalg.qr(rng.standard_normal((5, 5)))[0]
+        dense = (eigvec * eigval) @ eigvec.T
+        theta = rng.uniform(size=6) * 2 * np.pi
+        qc = np.concatenate([np.cos(theta)[:, None], np.sin(theta)[:, None], rng.standard_normal((6, 3))], 1)
+        hh = 0.1 if variant == "ambient" else 0.05
+        add_constrained(f"constrained_{tag}_torus", mdl.Torus(), mdl.TorusConstr(), mdl.METRIC_IDENTITY, None,
+                        mdl.torus_init(12, rng), hh, [1, 5, 20], variant=variant)
+        add_constrained(f"constrained_{tag}_torus_diag_inner2", mdl.Torus(), mdl.TorusConstr(), mdl.METRIC_DIAG,
+                        np.exp(0.2 * rng.standard_normal(3)), mdl.torus_init(6, rng), hh, [1, 10], n_inner=2,
+                        variant=variant)
+        add_constrained(f"constrained_{tag}_torus_fail_bigstep", mdl.Torus(), mdl.TorusConstr(),
+                        mdl.METRIC_IDENTITY, None, mdl.torus_init(12, rng), 1.2, [1, 5], variant=variant)
+        for ps, ptag in ((0, "newton"), (1, "quasi")) + (((2, "linesearch"),) if variant == "ambient" else ()):
+            add_constrained(f"constrained_{tag}_circle_dense_d5_{ptag}", mdl.Poly(5, 0.0, 0.5), mdl.CircleConstr(),
+                            mdl.METRIC_DENSE, dense, qc.copy(), hh, [1, 5, 20], proj_solver=ps, variant=variant)
+        ql = np.concatenate([np.zeros((5, 1)), rng.standard_normal((5, 4))], 1)
+        add_constrained(f"constrained_{tag}_linear_dense_d5", mdl.Poly(5, 1.0, 0.0), mdl.FirstCoordConstr(),
+                        mdl.METRIC_DENSE, dense, ql, 0.5 if variant == "gaussian" else 0.1, [1, 5, 20],
+                        variant=variant)
 
     # ---- correlated momentum refresh + random trajectory length (transitions.py:143-198, 355-402) ----------
     def make_corr_random():
