@@ -250,12 +250,26 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
              "mm_model_create: wrong number of Riemannian metric params");
   MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE || d->metric_kind == MM_METRIC_IDENTITY,
              "mm_model_create: a Riemannian system has no fixed metric");
-  size_t need_c = d->constr == MM_CONSTR_NONE     ? 0
-                  : d->constr == MM_CONSTR_TORUS  ? 2
-                  : d->constr == MM_CONSTR_FIRST  ? 0
-                  : d->constr == MM_CONSTR_CIRCLE ? 0
-                                                  : (size_t)-1;
+  size_t need_c = d->constr == MM_CONSTR_NONE           ? 0
+                  : d->constr == MM_CONSTR_TORUS        ? 2
+                  : d->constr == MM_CONSTR_FIRST        ? 0
+                  : d->constr == MM_CONSTR_CIRCLE       ? 0
+                  : d->constr == MM_CONSTR_LINEAR       ? d->n_constr_params
+                  : d->constr == MM_CONSTR_SPHERE_PLANE ? (size_t)D
+                                                        : (size_t)-1;
   MM_REQUIRE(ctx, need_c != (size_t)-1, "mm_model_create: unknown constraint id");
+  int n_constr = d->constr == MM_CONSTR_NONE ? 0 : 1;
+  if (d->constr == MM_CONSTR_LINEAR) {
+    MM_REQUIRE(ctx, need_c > 0 && need_c % (size_t)(D + 1) == 0,
+               "mm_model_create: linear constraint needs C*(D+1) params (A[C*D] then b[C])");
+    n_constr = (int)(need_c / (size_t)(D + 1));
+    MM_REQUIRE(ctx, n_constr >= 1 && n_constr <= 3 && (n_constr < D || D == 1),
+               "mm_model_create: linear constraint supports 1 <= C <= 3 rows, C < dim");
+  }
+  if (d->constr == MM_CONSTR_SPHERE_PLANE) {
+    MM_REQUIRE(ctx, D >= 3, "sphere-plane constraint needs dim >= 3");
+    n_constr = 2;
+  }
   MM_REQUIRE(ctx, d->n_constr_params == need_c && (need_c == 0 || d->constr_params),
              "mm_model_create: wrong number of constraint params");
   MM_REQUIRE(ctx, d->constr != MM_CONSTR_TORUS || D == 3, "torus constraint needs dim == 3");
@@ -291,6 +305,7 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
   m->dens_wrt_ambient = (d->dens_wrt_ambient || (d->gaussian_split && d->constr != MM_CONSTR_NONE)) ? 1 : 0;
   m->rmetric = d->rmetric;
   m->constr = d->constr;
+  m->n_constr = n_constr;
   m->n_target_params = need_t;
   m->n_rmetric_params = need_r;
   m->n_constr_params = need_c;

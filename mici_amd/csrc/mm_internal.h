@@ -25,6 +25,7 @@ struct mm_model {
   int metric_kind = 0;
   int rmetric = 0;
   int constr = 0;
+  int n_constr = 0;  // number of constraint functions C (rows of the constraint Jacobian)
   // device copies (nullptr when absent)
   double* d_target_params = nullptr;
   size_t n_target_params = 0;

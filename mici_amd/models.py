@@ -14,7 +14,7 @@ TARGET_GAUSS_ISO, TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_POLY = 0, 1, 2, 
 TARGET_BANANA, TARGET_FUNNEL, TARGET_TORUS = 4, 5, 6
 METRIC_IDENTITY, METRIC_DIAG, METRIC_DENSE = 0, 1, 2
 RMETRIC_NONE, RMETRIC_RANK1, RMETRIC_DIAGQUAD, RMETRIC_SOFTABS = 0, 1, 2, 3
-CONSTR_NONE, CONSTR_TORUS, CONSTR_FIRST, CONSTR_CIRCLE = 0, 1, 2, 3
+CONSTR_NONE, CONSTR_TORUS, CONSTR_FIRST, CONSTR_CIRCLE, CONSTR_LINEAR, CONSTR_SPHERE_PLANE = 0, 1, 2, 3, 4, 5
 
 
 def _f64(a):
@@ -140,6 +140,26 @@ class CircleConstr(Constraint):
         super().__init__(CONSTR_CIRCLE)
 
 
+class LinearConstr(Constraint):
+    """c(q) = A q - b with A of shape [C, D], 1 <= C <= 3 rows."""
+
+    def __init__(self, a, b=None):
+        a = np.atleast_2d(_f64(a))
+        b = np.zeros(a.shape[0]) if b is None else _f64(b).ravel()
+        if b.shape[0] != a.shape[0]:
+            raise ValueError("b must have one entry per row of A")
+        super().__init__(CONSTR_LINEAR, np.concatenate([a.ravel(), b]))
+        self.n_constr = a.shape[0]
+
+
+class SpherePlaneConstr(Constraint):
+    """Two constraints: c_0(q) = |q|^2 - 1 and c_1(q) = n . q (a great circle / sphere of the unit sphere)."""
+
+    def __init__(self, normal):
+        super().__init__(CONSTR_SPHERE_PLANE, normal)
+        self.n_constr = 2
+
+
 def target_from_id(tid, params, dim):
     tid = int(tid)
     params = _f64(params)
@@ -169,8 +189,14 @@ def rmetric_from_id(mid, params, dim):
     raise ValueError(f"unknown Riemannian metric id {mid}")
 
 
-def constr_from_id(cid, params):
+def constr_from_id(cid, params, dim=None):
     cid = int(cid)
+    if cid == CONSTR_LINEAR:
+        params = _f64(params)
+        c = params.size // (dim + 1)
+        return LinearConstr(params[:c * dim].reshape(c, dim), params[c * dim:])
+    if cid == CONSTR_SPHERE_PLANE:
+        return SpherePlaneConstr(params)
     if cid == CONSTR_TORUS:
         return TorusConstr(*params)
     if cid == CONSTR_FIRST:

@@ -35,6 +35,8 @@ CONSTR_NONE = 0
 CONSTR_TORUS = 1
 CONSTR_FIRST = 2
 CONSTR_CIRCLE = 3
+CONSTR_LINEAR = 4
+CONSTR_SPHERE_PLANE = 5
 
 
 # ---- targets ---------------------------------------------------------------------------
@@ -363,6 +365,47 @@ class CircleConstr:
         return mhp
 
 
+class LinearConstr:
+    """c(q) = A q - b, A of shape [C, D]."""
+    cid = CONSTR_LINEAR
+
+    def __init__(self, a, b=None):
+        self.a = np.atleast_2d(np.asarray(a, dtype=np.float64))
+        self.b = np.zeros(self.a.shape[0]) if b is None else np.asarray(b, dtype=np.float64)
+
+    def params(self):
+        return np.concatenate([self.a.ravel(), self.b])
+
+    def constr(self, q):
+        return self.a @ q - self.b
+
+    def jacob_constr(self, q):
+        return self.a.copy()
+
+    def mhp_constr(self, q):
+        return lambda m: np.zeros_like(q)
+
+
+class SpherePlaneConstr:
+    """c_0 = |q|^2 - 1, c_1 = n . q."""
+    cid = CONSTR_SPHERE_PLANE
+
+    def __init__(self, normal):
+        self.normal = np.asarray(normal, dtype=np.float64)
+
+    def params(self):
+        return self.normal.copy()
+
+    def constr(self, q):
+        return np.array([q @ q - 1.0, self.normal @ q])
+
+    def jacob_constr(self, q):
+        return np.stack([2.0 * q, self.normal])
+
+    def mhp_constr(self, q):
+        return lambda m: 2.0 * m[0]
+
+
 # ---- synthetic parameter generators (SURVEY.md section 8d) -----------------------------------------
 def make_spd(dim, rng):
     """P = A A^T / D + I with A ~ N(0,1)^{DxD}."""
@@ -415,8 +458,14 @@ def rmetric_from_id(mid, params, dim):
     raise ValueError(f"unknown Riemannian metric id {mid}")
 
 
-def constr_from_id(cid, params):
+def constr_from_id(cid, params, dim=None):
     cid = int(cid)
+    if cid == CONSTR_LINEAR:
+        params = np.asarray(params, dtype=np.float64)
+        c = params.size // (dim + 1)
+        return LinearConstr(params[:c * dim].reshape(c, dim), params[c * dim:])
+    if cid == CONSTR_SPHERE_PLANE:
+        return SpherePlaneConstr(params)
     if cid == CONSTR_TORUS:
         return TorusConstr(*params)
     if cid == CONSTR_FIRST:

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def build(g):
     n, d = g["q0"].shape
     target = models.target_from_id(g["target"], g["target_params"], d)
-    constr = models.constr_from_id(g["constr"], g["constr_params"])
+    constr = models.constr_from_id(g["constr"], g["constr_params"], g["q0"].shape[1])
     mk = int(g["metric_kind"])
     metric = None if mk == models.METRIC_IDENTITY else g["metric"]
     variant = str(g.get("variant", "hausdorff"))
@@ -132,6 +132,60 @@ def test_gram_term_and_gaussian_split_match_oracle(variant, metric_kind):
         assert_close(p[cidx], po, 1e-9, f"p chain {cidx}")
     ho = np.array([osys.h(q[i], p[i]) for i in range(64)])
     assert_close(system.h_batch(q[:64], p[:64]), ho, 1e-12, "h with the Gram term")
+
+
+@pytest.mark.parametrize("variant", ["hausdorff", "ambient", "gaussian"])
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_two_and_three_constraints_match_oracle(variant, solver):
+    """C = 2 (sphere and plane, D = 6) and C = 3 (linear, D = 7): C x C Cholesky / symmetric inverse of the Gram
+    matrix and pivoted LU of the residual Jacobian per chain, against the oracle on a sample of a 512-chain batch."""
+    if variant == "gaussian" and solver == 2:
+        pytest.skip("the reference tests the Gaussian split with the Newton and quasi-Newton solvers only")
+    rng = np.random.default_rng(5 + solver)
+    proj = [solvers.solve_projection_onto_manifold_newton, solvers.solve_projection_onto_manifold_quasi_newton,
+            solvers.solve_projection_onto_manifold_newton_with_line_search][solver]
+    n, steps = 512, 10
+    for dim, make in ((6, "sphere"), (7, "linear")):
+        metric = omdl.make_spd(dim, rng)
+        if make == "sphere":
+            normal = rng.standard_normal(dim)
+            oc, pc = omdl.SpherePlaneConstr(normal), models.SpherePlaneConstr(normal)
+            q0 = rng.standard_normal((n, dim))
+            q0 -= np.outer(q0 @ normal, normal) / (normal @ normal)
+            q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
+            h = 0.05
+        else:
+            a, b = rng.standard_normal((3, dim)), rng.standard_normal(3)
+            oc, pc = omdl.LinearConstr(a, b), models.LinearConstr(a, b)
+            null = np.linalg.svd(a)[2][3:].T
+            q0 = np.linalg.lstsq(a, b, rcond=None)[0] + rng.standard_normal((n, dim - 3)) @ null.T
+            h = 0.1
+        ot, pt = omdl.Poly(dim, 0.5, 0.25), models.Poly(dim, 0.5, 0.25)
+        if variant == "gaussian":
+            osys = orc.GaussianConstrainedSystem(ot, oc, omdl.METRIC_DENSE, metric)
+            system = systems.GaussianDenseConstrainedEuclideanMetricSystem(pt, pc, metric=metric)
+        else:
+            osys = orc.ConstrainedSystem(ot, oc, omdl.METRIC_DENSE, metric, dens_wrt_hausdorff=(variant == "hausdorff"))
+            system = systems.DenseConstrainedEuclideanMetricSystem(pt, pc, metric=metric,
+                                                                   dens_wrt_hausdorff=(variant == "hausdorff"))
+        integ = integrators.ConstrainedLeapfrogIntegrator(system, h, projection_solver=proj)
+        p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+        jac0 = np.stack([oc.jacob_constr(x) for x in q0])
+        minv_p0 = np.stack([osys.minv(x) for x in p0])
+        assert np.max(np.abs(np.einsum("ncd,nd->nc", jac0, minv_p0))) < 1e-11  # cotangent space
+        dirs = np.where(rng.random(n) < 0.5, 1, -1).astype(np.int8)
+        q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=steps)
+        ok = status == 0
+        assert ok.mean() > 0.9
+        assert np.max(np.abs(np.stack([oc.constr(x) for x in q[ok]]))) < 1e-8
+        for cidx in np.concatenate([np.arange(4), rng.integers(0, n, 4)]):
+            qo, po, so, no = orc.constrained_leapfrog_steps(osys, q0[cidx], p0[cidx], dirs[cidx] * h, steps,
+                                                            proj_solver=solver)
+            assert so == status[cidx] and no == n_done[cidx]
+            assert_close(q[cidx], qo, 1e-9, f"{make} q chain {cidx}")
+            assert_close(p[cidx], po, 1e-9, f"{make} p chain {cidx}")
+        ho = np.array([osys.h(q[i], p[i]) for i in range(32)])
+        assert_close(system.h_batch(q[:32], p[:32]), ho, 1e-12, f"{make} h")
 
 
 def test_single_state_step_raises_reference_exceptions():

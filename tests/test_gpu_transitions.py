@@ -32,7 +32,7 @@ def build(g):
         integ = integrators.ImplicitLeapfrogIntegrator(system, h)
     else:
         system = systems.DenseConstrainedEuclideanMetricSystem(
-            target, models.constr_from_id(g["constr"], g["constr_params"]))
+            target, models.constr_from_id(g["constr"], g["constr_params"], g["q0"].shape[1]))
         integ = integrators.ConstrainedLeapfrogIntegrator(system, h)
     return system, integ
 

@@ -72,7 +72,7 @@ def test_metropolis_static_transitions(name):
         ad = otr.riemann_adapter(orc.RiemannianSystem(
             target, mdl.rmetric_from_id(g["rmetric"], g["rmetric_params"], d), None))
     else:
-        ad = otr.constrained_adapter(orc.ConstrainedSystem(target, mdl.constr_from_id(g["constr"], g["constr_params"])))
+        ad = otr.constrained_adapter(orc.ConstrainedSystem(target, mdl.constr_from_id(g["constr"], g["constr_params"], g["q0"].shape[1])))
     h, n_step = float(g["step_size"]), int(g["n_step"])
     for c in range(n):
         q, direction = g["q0"][c].copy(), 1
@@ -264,7 +264,7 @@ def test_constrained_leapfrog(name):
     g = load_golden(name)
     n, d = g["q0"].shape
     target = mdl.target_from_id(g["target"], g["target_params"], d)
-    constraint = mdl.constr_from_id(g["constr"], g["constr_params"])
+    constraint = mdl.constr_from_id(g["constr"], g["constr_params"], g["q0"].shape[1])
     mk = int(g["metric_kind"])
     metric = None if mk == mdl.METRIC_IDENTITY else g["metric"]
     variant = str(g.get("variant", "hausdorff"))  # "ambient": dens_wrt_hausdorff=False; "gaussian": Gaussian split

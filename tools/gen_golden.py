@@ -830,6 +830,46 @@ def main():
                         mdl.METRIC_DENSE, dense, ql, 0.5 if variant == "gaussian" else 0.1, [1, 5, 20],
                         variant=variant)
 
+    # ---- more than one constraint: C x C Cholesky / pivoted LU / symmetric inverses (matrices.py:1161-1188,
+    #      1270-1411, 1414-1447).  Registered after all older cases. ----------------------------------------------
+    def sphere_plane_init(n, d, normal):
+        x = rng.standard_normal((n, d))
+        x -= np.outer(x @ normal, normal) / (normal @ normal)
+        return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+    def linear_init(n, a, b):
+        part = np.linalg.lstsq(a, b, rcond=None)[0]
+        null = np.linalg.svd(a)[2][a.shape[0]:].T
+        return part + rng.standard_normal((n, null.shape[1])) @ null.T
+
+    nrm = rng.standard_normal(4)
+    dense4 = mdl.make_spd(4, rng)
+    for ps, ptag in ((0, "newton"), (1, "quasi"), (2, "linesearch")):
+        add_constrained(f"constrained_c2_sphereplane_d4_{ptag}", mdl.Poly(4, 0.5, 0.25), mdl.SpherePlaneConstr(nrm),
+                        mdl.METRIC_DENSE, dense4, sphere_plane_init(6, 4, nrm), 0.1, [1, 5, 20], proj_solver=ps)
+    add_constrained("constrained_c2_sphereplane_d4_inner2_identity", mdl.Poly(4, 0.5, 0.25),
+                    mdl.SpherePlaneConstr(nrm), mdl.METRIC_IDENTITY, None, sphere_plane_init(6, 4, nrm), 0.2, [1, 10],
+                    n_inner=2)
+    add_constrained("constrained_c2_sphereplane_d4_fail_bigstep", mdl.Poly(4, 0.5, 0.25), mdl.SpherePlaneConstr(nrm),
+                    mdl.METRIC_DENSE, dense4, sphere_plane_init(8, 4, nrm), 1.5, [1, 4])
+    add_constrained("constrained_c2_sphereplane_ambient_d4", mdl.Poly(4, 0.5, 0.25), mdl.SpherePlaneConstr(nrm),
+                    mdl.METRIC_DIAG, np.exp(0.3 * rng.standard_normal(4)), sphere_plane_init(6, 4, nrm), 0.1,
+                    [1, 5, 20], variant="ambient")
+    for ps, ptag in ((0, "newton"), (1, "quasi")):
+        add_constrained(f"constrained_c2_sphereplane_gauss_d4_{ptag}", mdl.Poly(4, 0.0, 0.5),
+                        mdl.SpherePlaneConstr(nrm), mdl.METRIC_DENSE, dense4, sphere_plane_init(6, 4, nrm), 0.05,
+                        [1, 5, 20], proj_solver=ps, variant="gaussian")
+    a2, b2 = rng.standard_normal((2, 5)), rng.standard_normal(2)
+    add_constrained("constrained_c2_linear_d5", mdl.Poly(5, 1.0, 0.25), mdl.LinearConstr(a2, b2), mdl.METRIC_DENSE,
+                    mdl.make_spd(5, rng), linear_init(5, a2, b2), 0.1, [1, 5, 20])
+    a3, b3 = rng.standard_normal((3, 6)), rng.standard_normal(3)
+    add_constrained("constrained_c3_linear_ambient_d6", mdl.Poly(6, 1.0, 0.25), mdl.LinearConstr(a3, b3),
+                    mdl.METRIC_DENSE, mdl.make_spd(6, rng), linear_init(5, a3, b3), 0.1, [1, 5, 20],
+                    variant="ambient")
+    add_constrained("constrained_c3_linear_gauss_d6", mdl.Poly(6, 0.0, 0.25), mdl.LinearConstr(a3, b3),
+                    mdl.METRIC_DENSE, mdl.make_spd(6, rng), linear_init(5, a3, b3), 0.3, [1, 5, 20],
+                    variant="gaussian")
+
     # ---- correlated momentum refresh + random trajectory length (transitions.py:143-198, 355-402) ----------
     def make_corr_random():
         name = "corrmom_random_nstep_d10"
