@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - leapfrog-steps/sec (all chains) of the MI355X integrator hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2iv|c3|c5] [--traj-len L]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2iv|c2bcss|c3|c3b|c4|c5] [--traj-len L]
 
 Contract (driver): W untimed warm-up passes, then EXACTLY K timed passes bracketed by a barrier +
 device synchronise on both sides; the maximum over ranks is the job time; rank 0 prints ONE JSON
@@ -57,8 +57,9 @@ def make_workload(config, n_chains, rng):
     cpu_baseline leg: nothing under oracle/ is imported on the measured path."""
     from mici_amd import integrators, models, systems
 
-    if config in ("c2", "c2i", "c2iv"):
+    if config in ("c2", "c2i", "c2iv", "c2bcss"):
         dim, h, traj = 128, 0.05, 1000
+        stages = 3 if config == "c2bcss" else 1  # gradient evaluations per integrator step
         if config == "c2i":
             target, P = models.GaussIso(dim), None
             metric = None
@@ -68,7 +69,7 @@ def make_workload(config, n_chains, rng):
             P = _make_spd(dim, rng)
             target = models.GaussDense(P)
             metric = P if config == "c2iv" else None
-            flops = 2.0 * dim * dim * (2 if config == "c2iv" else 1) + 8.0 * dim
+            flops = stages * (2.0 * dim * dim * (2 if config == "c2iv" else 1) + 8.0 * dim)
             name = "c2(iv) dense-Gaussian + dense metric" if config == "c2iv" else \
                 "c2(iii) dense-precision Gaussian"
         system = systems.EuclideanMetricSystem(target, metric=metric)
@@ -79,11 +80,17 @@ def make_workload(config, n_chains, rng):
             from oracle import models as omdl
             return orc.EuclidSystem(omdl.GaussIso(dim) if P is None else omdl.GaussDense(P), mk, metric)
 
-        integ = integrators.LeapfrogIntegrator(system, h)
+        if config == "c2bcss":  # the three-stage BCSS composition on the c2(iii) workload
+            integ = integrators.BCSSThreeStageIntegrator(system, h)
+            iname = "BCSSThreeStageIntegrator (one step = 3 gradient evaluations)"
+        else:
+            integ = integrators.LeapfrogIntegrator(system, h)
+            iname = "LeapfrogIntegrator"
         q0 = rng.standard_normal((n_chains, dim))
         z = rng.standard_normal((n_chains, dim))
         p0 = z if metric is None else z @ np.linalg.cholesky(metric).T
-        return dict(name=f"{name}, EuclideanMetricSystem + LeapfrogIntegrator", dim=dim, h=h,
+        return dict(name=f"{name}, EuclideanMetricSystem + {iname}", dim=dim, h=h,
+                    coefficients=getattr(integ, "coefficients", None),
                     traj=traj, integ=integ, system=system, make_oracle=make_oracle, q0=q0, p0=p0,
                     bytes_per_chain_step=32.0 * dim, flops_per_chain_step=flops,
                     bound="hbm" if config == "c2i" else "mfma", kind="euclid")
@@ -166,20 +173,28 @@ def cpu_baseline(w, budget_s=20.0):
                     sample=f"oracle per-chain NumPy: {n1} chains x {steps} steps of the same workload "
                            f"in {dt:.1f} s (1 thread; BLAS single-threaded at these sizes)")
     n, steps = w["q0"].shape[0], 20
+    coefs = w.get("coefficients")
+    if coefs is not None:
+        import functools
+        orc_batch = functools.partial(orc.leapfrog_steps_batch, coefficients=list(coefs))
+        orc_single = lambda s_, q_, p_, h_, n_: orc.composition_steps(  # noqa: E731
+            s_, q_, p_, h_, n_, list(coefs)[:(len(coefs) - 3) // 2])
+    else:
+        orc_batch, orc_single = orc.leapfrog_steps_batch, orc.leapfrog_steps
     t0 = time.perf_counter()
-    orc.leapfrog_steps_batch(osys, w["q0"], w["p0"], w["h"], steps)
+    orc_batch(osys, w["q0"], w["p0"], w["h"], steps)
     dt = time.perf_counter() - t0
     # scale the sample to ~budget_s of CPU work, capped at the real trajectory length
     steps2 = int(min(w["traj"], max(steps, steps * budget_s / max(dt, 1e-6))))
     t0 = time.perf_counter()
-    orc.leapfrog_steps_batch(osys, w["q0"], w["p0"], w["h"], steps2)
+    orc_batch(osys, w["q0"], w["p0"], w["h"], steps2)
     dt = time.perf_counter() - t0
     value = n * steps2 / dt
     # reference-style figure: one chain at a time on one core
     t0 = time.perf_counter()
     n1 = 0
     while time.perf_counter() - t0 < 2.0:
-        orc.leapfrog_steps(osys, w["q0"][n1 % n], w["p0"][n1 % n], w["h"], 100)
+        orc_single(osys, w["q0"][n1 % n], w["p0"][n1 % n], w["h"], 100)
         n1 += 1
     single = n1 * 100 / (time.perf_counter() - t0)
     return dict(value=value, unit="leapfrog-steps/s", cores=int(cores), kind="port",

@@ -38,12 +38,14 @@ __device__ __forceinline__ double elem_grad(double q, double tp0, double tp1) {
 
 // ---------------------------------------------------------------------------------------------------
 // Separable targets: each lane owns VEC consecutive dims of one chain.
-template <int TARGET, int METRIC, int VEC>
-__global__ __launch_bounds__(256) void leapfrog_elem_kernel(
+// COMP: a symmetric composition (SymmetricCompositionIntegrator._step, integrators.py:272-274) instead of the
+// leapfrog: cf.c[k] t alternately kicks (h1_flow) and drifts (h2_flow), starting with h1 iff cf.initial_h1.
+template <int TARGET, int METRIC, int VEC, bool COMP>
+__device__ __forceinline__ void leapfrog_elem_body(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
     const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
     const double* __restrict__ tparams,
-    const double* __restrict__ minv_diag) {
+    const double* __restrict__ minv_diag, const mm_comp_coefs& cf) {
   const int vec_per_chain = dim / VEC;
   const int64_t total = n_chains * vec_per_chain;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
@@ -69,15 +71,33 @@ __global__ __launch_bounds__(256) void leapfrog_elem_kernel(
       mi[v] = (METRIC == M_DIAG) ? minv_diag[d0 + v] : 1.0;
       g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
     }
-    for (int s = 0; s < n_steps; ++s) {
+    if constexpr (!COMP) {
+      for (int s = 0; s < n_steps; ++s) {
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        p[v] -= ht * g[v];
-        if constexpr (METRIC == M_DIAG) q[v] += t * (mi[v] * p[v]);
-        else q[v] += t * p[v];
-        g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
-        p[v] -= ht * g[v];
+        for (int v = 0; v < VEC; ++v) {
+          p[v] -= ht * g[v];
+          if constexpr (METRIC == M_DIAG) q[v] += t * (mi[v] * p[v]);
+          else q[v] += t * p[v];
+          g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
+          p[v] -= ht * g[v];
+        }
       }
+    } else {
+      for (int s = 0; s < n_steps; ++s)
+        for (int k = 0; k < cf.m; ++k) {
+          const double ct = cf.c[k] * t;
+          const bool kick = ((k & 1) == 0) == (cf.initial_h1 != 0);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            if (kick) {
+              p[v] -= ct * g[v];
+            } else {
+              if constexpr (METRIC == M_DIAG) q[v] += ct * (mi[v] * p[v]);
+              else q[v] += ct * p[v];
+              g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
+            }
+          }
+        }
     }
     if constexpr (VEC == 2) {
       *reinterpret_cast<double2*>(pos + off) = make_double2(q[0], q[1]);
@@ -86,6 +106,24 @@ __global__ __launch_bounds__(256) void leapfrog_elem_kernel(
       pos[off] = q[0]; mom[off] = p[0];
     }
   }
+}
+
+template <int TARGET, int METRIC, int VEC>
+__global__ __launch_bounds__(256) void leapfrog_elem_kernel(
+    double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
+    const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
+    const double* __restrict__ tparams, const double* __restrict__ minv_diag) {
+  leapfrog_elem_body<TARGET, METRIC, VEC, false>(pos, mom, dir, step_scale, n_chains, dim, step_size, n_steps,
+                                                 tparams, minv_diag, mm_comp_coefs{});
+}
+
+template <int TARGET, int METRIC, int VEC>
+__global__ __launch_bounds__(256) void composition_elem_kernel(
+    double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
+    const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
+    const double* __restrict__ tparams, const double* __restrict__ minv_diag, mm_comp_coefs cf) {
+  leapfrog_elem_body<TARGET, METRIC, VEC, true>(pos, mom, dir, step_scale, n_chains, dim, step_size, n_steps,
+                                                tparams, minv_diag, cf);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -142,12 +180,12 @@ __device__ __forceinline__ void tile_times_slabs(const double* __restrict__ tile
   for (int c = 0; c < CT; ++c) out[c] = acc0[c] + acc1[c];
 }
 
-template <int DP, int CT, int TARGET, int METRIC>
-__global__ __launch_bounds__(DP * 4 / CT) void leapfrog_mfma_kernel(
+template <int DP, int CT, int TARGET, int METRIC, bool COMP>
+__device__ __forceinline__ void leapfrog_mfma_body(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
     const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
     const double* __restrict__ tparams,
-    const double* __restrict__ minv) {
+    const double* __restrict__ minv, const mm_comp_coefs& cf) {
   using Cfg = MfmaCfg<DP, CT>;
   __shared__ __attribute__((aligned(16))) double lds[(METRIC == M_DENSE ? 4 : 2) * Cfg::TILE];
   double* qbuf = lds;                    // two q tiles (double buffered)
@@ -220,12 +258,8 @@ __global__ __launch_bounds__(DP * 4 / CT) void leapfrog_mfma_kernel(
     }
   };
 
-  gradient(1);  // g(q0); uses buffer 1 so that step 0 starts on buffer 0
-  for (int s = 0; s < n_steps; ++s) {
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) p[c][r] -= ht[r] * g[c][r];
+  // q += tt M^-1 p with the product on buffer parity s (dense metric) or elementwise
+  auto drift = [&](const double (&tt)[4], int s) {
     if constexpr (METRIC == M_DENSE) {
       double* tile = pbuf + (s & 1) * Cfg::TILE;
       publish(tile, p);
@@ -235,21 +269,52 @@ __global__ __launch_bounds__(DP * 4 / CT) void leapfrog_mfma_kernel(
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) q[c][r] += t[r] * v[c][r];
+        for (int r = 0; r < 4; ++r) q[c][r] += tt[r] * v[c][r];
     } else {
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if constexpr (METRIC == M_DIAG) q[c][r] += t[r] * (mi[c] * p[c][r]);
-          else q[c][r] += t[r] * p[c][r];
+          if constexpr (METRIC == M_DIAG) q[c][r] += tt[r] * (mi[c] * p[c][r]);
+          else q[c][r] += tt[r] * p[c][r];
         }
     }
-    gradient(s);
+  };
+
+  gradient(1);  // g(q0); uses buffer 1 so that step 0 starts on buffer 0
+  if constexpr (!COMP) {
+    for (int s = 0; s < n_steps; ++s) {
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
+      for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[c][r] -= ht[r] * g[c][r];
+        for (int r = 0; r < 4; ++r) p[c][r] -= ht[r] * g[c][r];
+      drift(t, s);
+      gradient(s);
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[c][r] -= ht[r] * g[c][r];
+    }
+  } else {
+    // SymmetricCompositionIntegrator._step (integrators.py:272-274); nd counts the h2 flows done so far and
+    // selects the LDS buffer, so consecutive products never share a tile
+    int nd = 0;
+    for (int s = 0; s < n_steps; ++s)
+      for (int k = 0; k < cf.m; ++k) {
+        double ct[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ct[r] = cf.c[k] * t[r];
+        if (((k & 1) == 0) == (cf.initial_h1 != 0)) {
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[c][r] -= ct[r] * g[c][r];
+        } else {
+          drift(ct, nd);
+          gradient(nd);
+          ++nd;
+        }
+      }
   }
 
 #pragma unroll
@@ -264,8 +329,26 @@ __global__ __launch_bounds__(DP * 4 / CT) void leapfrog_mfma_kernel(
     }
 }
 
+template <int DP, int CT, int TARGET, int METRIC>
+__global__ __launch_bounds__(DP * 4 / CT) void leapfrog_mfma_kernel(
+    double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
+    const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
+    const double* __restrict__ tparams, const double* __restrict__ minv) {
+  leapfrog_mfma_body<DP, CT, TARGET, METRIC, false>(pos, mom, dir, step_scale, n_chains, dim, step_size, n_steps,
+                                                    tparams, minv, mm_comp_coefs{});
+}
+
+template <int DP, int CT, int TARGET, int METRIC>
+__global__ __launch_bounds__(DP * 4 / CT) void composition_mfma_kernel(
+    double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
+    const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
+    const double* __restrict__ tparams, const double* __restrict__ minv, mm_comp_coefs cf) {
+  leapfrog_mfma_body<DP, CT, TARGET, METRIC, true>(pos, mom, dir, step_scale, n_chains, dim, step_size, n_steps,
+                                                   tparams, minv, cf);
+}
+
 template <int TARGET, int METRIC>
-int launch_elem(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
+int launch_elem(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_comp_coefs* cf) {
   const int dim = s->dim;
   const bool vec2 = (dim % 2 == 0);
   const int64_t total = s->n * (vec2 ? dim / 2 : dim);
@@ -273,7 +356,15 @@ int launch_elem(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_ste
   const int64_t cap = (int64_t)ctx->n_cu * 8;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  if (vec2)
+  if (cf && vec2)
+    hipLaunchKernelGGL((composition_elem_kernel<TARGET, METRIC, 2>), dim3((unsigned)blocks), dim3(256),
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, dim, h, n_steps,
+                       m->d_target_params, m->d_metric_inv, *cf);
+  else if (cf)
+    hipLaunchKernelGGL((composition_elem_kernel<TARGET, METRIC, 1>), dim3((unsigned)blocks), dim3(256),
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, dim, h, n_steps,
+                       m->d_target_params, m->d_metric_inv, *cf);
+  else if (vec2)
     hipLaunchKernelGGL((leapfrog_elem_kernel<TARGET, METRIC, 2>), dim3((unsigned)blocks), dim3(256),
                        0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, dim, h, n_steps,
                        m->d_target_params, m->d_metric_inv);
@@ -286,8 +377,13 @@ int launch_elem(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_ste
 }
 
 template <int DP, int CT, int TARGET, int METRIC>
-int launch_mfma_dp(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
+int launch_mfma_dp(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_comp_coefs* cf) {
   const unsigned blocks = (unsigned)((s->n + 15) / 16);
+  if (cf)
+    hipLaunchKernelGGL((composition_mfma_kernel<DP, CT, TARGET, METRIC>), dim3(blocks),
+                       dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, s->dim,
+                       h, n_steps, m->d_target_params, m->d_metric_inv, *cf);
+  else
   hipLaunchKernelGGL((leapfrog_mfma_kernel<DP, CT, TARGET, METRIC>), dim3(blocks),
                      dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, s->dim, h,
                      n_steps, m->d_target_params, m->d_metric_inv);
@@ -306,14 +402,14 @@ int mfma_ct() {
 }
 
 template <int TARGET, int METRIC>
-int launch_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
+int launch_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_comp_coefs* cf) {
   const int dim = s->dim;
-  if (dim <= 16) return launch_mfma_dp<16, 1, TARGET, METRIC>(ctx, m, s, h, n_steps);
-  if (dim <= 32) return launch_mfma_dp<32, 1, TARGET, METRIC>(ctx, m, s, h, n_steps);
-  if (dim <= 64) return launch_mfma_dp<64, 1, TARGET, METRIC>(ctx, m, s, h, n_steps);
+  if (dim <= 16) return launch_mfma_dp<16, 1, TARGET, METRIC>(ctx, m, s, h, n_steps, cf);
+  if (dim <= 32) return launch_mfma_dp<32, 1, TARGET, METRIC>(ctx, m, s, h, n_steps, cf);
+  if (dim <= 64) return launch_mfma_dp<64, 1, TARGET, METRIC>(ctx, m, s, h, n_steps, cf);
   if (dim <= 128) {
-    if (mfma_ct() == 2) return launch_mfma_dp<128, 2, TARGET, METRIC>(ctx, m, s, h, n_steps);
-    return launch_mfma_dp<128, 1, TARGET, METRIC>(ctx, m, s, h, n_steps);
+    if (mfma_ct() == 2) return launch_mfma_dp<128, 2, TARGET, METRIC>(ctx, m, s, h, n_steps, cf);
+    return launch_mfma_dp<128, 1, TARGET, METRIC>(ctx, m, s, h, n_steps, cf);
   }
   mm_set_error(ctx, "mm_leapfrog_euclid: dense target/metric kernels support dim <= 128");
   return MM_ERR_UNSUPPORTED;
@@ -321,12 +417,14 @@ int launch_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_ste
 
 }  // namespace
 
-int mm_launch_leapfrog_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
+// cf == nullptr: leapfrog; otherwise the symmetric composition with those coefficients
+static int launch_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                         const mm_comp_coefs* cf) {
   const int T = m->target, M = m->metric_kind;
 #define MM_CASE_ELEM(TT, MM_) \
-  if (T == TT && M == MM_) return launch_elem<TT, MM_>(ctx, m, s, h, n_steps);
+  if (T == TT && M == MM_) return launch_elem<TT, MM_>(ctx, m, s, h, n_steps, cf);
 #define MM_CASE_MFMA(TT, MM_) \
-  if (T == TT && M == MM_) return launch_mfma<TT, MM_>(ctx, m, s, h, n_steps);
+  if (T == TT && M == MM_) return launch_mfma<TT, MM_>(ctx, m, s, h, n_steps, cf);
   MM_CASE_ELEM(T_ISO, M_ID)
   MM_CASE_ELEM(T_ISO, M_DIAG)
   MM_CASE_ELEM(T_DIAG, M_ID)
@@ -342,4 +440,13 @@ int mm_launch_leapfrog_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, doubl
 #undef MM_CASE_ELEM
 #undef MM_CASE_MFMA
   return -100;  // not a separable / dense-Gaussian target: caller falls through to the generic kernel
+}
+
+int mm_launch_leapfrog_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
+  return launch_euclid(ctx, m, s, h, n_steps, nullptr);
+}
+
+int mm_launch_composition_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                                 const mm_comp_coefs& cf) {
+  return launch_euclid(ctx, m, s, h, n_steps, &cf);
 }

@@ -132,10 +132,7 @@ __global__ void leapfrog_generic_kernel(EuclidModelView m, double* __restrict__ 
 // coefficient sequence c[0..m) alternates h1_flow (mom -= c t grad) and h2_flow (pos += c t M^-1 mom),
 // starting with h1 iff initial_h1.  Same wave-per-chain layout as the generic leapfrog above; the
 // gradient is recomputed only after the position moved (the reference's state cache).
-struct CompCoefs {
-  int m, initial_h1;
-  double c[MM_MAX_COMPOSITION_COEFFS];
-};
+using CompCoefs = mm_comp_coefs;
 
 __global__ void composition_generic_kernel(EuclidModelView m, double* __restrict__ pos,
                                            double* __restrict__ mom, const int8_t* __restrict__ dir,

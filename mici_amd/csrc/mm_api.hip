@@ -14,6 +14,7 @@
 // launchers living in other translation units
 int mm_launch_leapfrog_generic(mm_ctx*, const mm_model*, mm_state*, double, int);
 int mm_launch_composition_generic(mm_ctx*, const mm_model*, mm_state*, double, int, int, const double*, int);
+int mm_launch_composition_euclid(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_comp_coefs&);
 int mm_launch_implicit_midpoint_euclid(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
                                        mm_counters*);
 int mm_launch_implicit_midpoint_riemann(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
@@ -577,7 +578,15 @@ int mm_composition_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h,
   for (int i = 0; i < n_coeffs; ++i)
     MM_REQUIRE(ctx, std::isfinite(coeffs[i]), "mm_composition_euclid: non-finite coefficient");
   if (s->n == 0 || n_steps == 0) return MM_OK;
-  rc = mm_launch_composition_generic(ctx, m, s, h, n_steps, n_coeffs, coeffs, initial_h1 != 0);
+  // separable / dense-Gaussian models run on the kernels of the leapfrog (elementwise or FP64 MFMA); anything
+  // else, and the Gaussian split's exact h2 flow, on the generic wave-per-chain kernel
+  mm_comp_coefs cf{};
+  cf.m = n_coeffs;
+  cf.initial_h1 = initial_h1 != 0;
+  for (int i = 0; i < n_coeffs; ++i) cf.c[i] = coeffs[i];
+  rc = m->gaussian_split ? -100 : mm_launch_composition_euclid(ctx, m, s, h, n_steps, cf);
+  if (rc == -100 || (rc == MM_ERR_UNSUPPORTED && m->dim > 128))
+    rc = mm_launch_composition_generic(ctx, m, s, h, n_steps, n_coeffs, coeffs, initial_h1 != 0);
   if (rc != MM_OK) return rc;
   return mark_explicit_done(ctx, s, n_steps);
 }

@@ -18,6 +18,13 @@ struct mm_ctx {
   mm_counters* d_counters = nullptr;  // device scratch for work counters
 };
 
+// Coefficient sequence of a SymmetricCompositionIntegrator (integrators.py:176-274), alternating h1 / h2 flows.
+struct mm_comp_coefs {
+  int m;
+  int initial_h1;
+  double c[MM_MAX_COMPOSITION_COEFFS];
+};
+
 struct mm_model {
   mm_ctx* ctx = nullptr;
   int dim = 0;

@@ -370,9 +370,10 @@ def composition_steps(system, q, p, dt, n_steps, free_coefficients, initial_h1_f
     return q, p
 
 
-def leapfrog_steps_batch(system, q, p, dt, n_steps):
+def leapfrog_steps_batch(system, q, p, dt, n_steps, coefficients=None, initial_h1_flow_step=True):
     """Vectorised-over-chains variant (rows of q, p are chains) for the cheap targets;
-    identical arithmetic per chain.  Used as the multi-chain CPU baseline."""
+    identical arithmetic per chain.  Used as the multi-chain CPU baseline.  With ``coefficients`` (the full
+    sequence from composition_coefficients) it runs that symmetric composition instead of the leapfrog."""
     q = np.array(q, dtype=np.float64)
     p = np.array(p, dtype=np.float64)
     dt = np.broadcast_to(np.asarray(dt, dtype=np.float64), (q.shape[0],))[:, None]
@@ -397,11 +398,20 @@ def leapfrog_steps_batch(system, q, p, dt, n_steps):
         return x @ system._inv.T
 
     g = grad(q)
-    for _ in range(n_steps):
-        p -= (0.5 * dt) * g
-        q += dt * minv(p)
-        g = grad(q)
-        p -= (0.5 * dt) * g
+    if coefficients is None:
+        for _ in range(n_steps):
+            p -= (0.5 * dt) * g
+            q += dt * minv(p)
+            g = grad(q)
+            p -= (0.5 * dt) * g
+        return q, p
+    for _ in range(n_steps):  # SymmetricCompositionIntegrator._step, integrators.py:272-274
+        for k, c in enumerate(coefficients):
+            if (k % 2 == 0) == initial_h1_flow_step:
+                p -= (c * dt) * g
+            else:
+                q += (c * dt) * minv(p)
+                g = grad(q)
     return q, p
 
 

@@ -81,6 +81,52 @@ def test_symmetric_composition_matches_reference_fixture(name):
     assert np.array_equal(st.pos, g["q0"][0])
 
 
+@pytest.mark.parametrize("dim,n,target_kind,metric_kind", [
+    (128, 4096, "dense", "identity"),   # BASELINE config c2(iii) with a BCSS integrator: FP64 MFMA path
+    (128, 512, "dense", "dense"),
+    (100, 300, "diag", "dense"),
+    (128, 2048, "iso", "diag"),         # elementwise path
+    (37, 100, "poly", "identity"),
+])
+@pytest.mark.parametrize("stages", [2, 4])
+def test_composition_fast_paths_match_oracle(dim, n, target_kind, metric_kind, stages):
+    """BCSS compositions on the kernels of the leapfrog (MFMA / elementwise), oracle on a sample of chains."""
+    rng = np.random.default_rng(dim + stages)
+    if target_kind == "dense":
+        P = omdl.make_spd(dim, rng)
+        target, otarget = models.GaussDense(P), omdl.GaussDense(P)
+    elif target_kind == "diag":
+        prec = np.exp(0.2 * rng.standard_normal(dim))
+        target, otarget = models.GaussDiag(prec), omdl.GaussDiag(prec)
+    elif target_kind == "iso":
+        target, otarget = models.GaussIso(dim), omdl.GaussIso(dim)
+    else:
+        target, otarget = models.Poly(dim, 1.0, 0.25), omdl.Poly(dim, 1.0, 0.25)
+    if metric_kind == "identity":
+        mk, metric = omdl.METRIC_IDENTITY, None
+    elif metric_kind == "diag":
+        mk, metric = omdl.METRIC_DIAG, np.exp(0.2 * rng.standard_normal(dim))
+    else:
+        mk, metric = omdl.METRIC_DENSE, omdl.make_spd(dim, rng)
+    system = systems.EuclideanMetricSystem(target, metric=metric)
+    osys = orc.EuclidSystem(otarget, mk, metric)
+    cls = {2: integrators.BCSSTwoStageIntegrator, 4: integrators.BCSSFourStageIntegrator}[stages]
+    h, n_steps = 0.1, 25
+    integ = cls(system, h)
+    q0 = rng.standard_normal((n, dim))
+    p0 = np.stack([osys.msqrt(z) for z in rng.standard_normal((n, dim))])
+    dirs = np.where(rng.random(n) < 0.5, 1, -1).astype(np.int8)
+    q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=n_steps)
+    assert np.all(status == 0) and np.all(n_done == n_steps)
+    free = orc.BCSS_FREE_COEFFICIENTS[stages]
+    for c in np.concatenate([[0, 1, 15, 16, n - 1], rng.integers(0, n, 5)]):
+        qo, po = orc.composition_steps(osys, q0[c], p0[c], dirs[c] * h, n_steps, free)
+        assert_close(q[c], qo, 1e-11, f"q chain {c}")
+        assert_close(p[c], po, 1e-11, f"p chain {c}")
+    qb, pb, _, _ = integ.step_batch(q, p, -dirs, n_steps=n_steps)
+    assert_close(qb, q0, 1e-9, "reversed q")
+
+
 def test_composition_argument_checks():
     system = systems.EuclideanMetricSystem(models.GaussIso(4))
     with pytest.raises(ValueError):
