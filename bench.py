@@ -424,9 +424,15 @@ def main():
             roof = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
                         frac=achieved / FP64_MFMA_PEAK_TF, traffic=None)
         else:
-            achieved = w["bytes_per_chain_step"] * chain_steps_per_launch / launch_s / 1e9
+            # a launch integrates the whole trajectory with the chain state in registers: the algorithmic HBM
+            # traffic is one read and one write of (pos, mom) per chain per LAUNCH, not per step
+            achieved = w["bytes_per_chain_step"] * n_local / launch_s / 1e9
             roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=None)
+            if w.get("flops_per_chain_step"):  # what actually limits these kernels: FP64 vector issue
+                tf = w["flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
+                roof["fp64_valu"] = dict(achieved=tf, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                                         frac=tf / FP64_MFMA_PEAK_TF)
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
         # (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); null when not profiled
         pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm.json")
@@ -436,7 +442,7 @@ def main():
             roof["traffic_source"] = "profiles/r01_c2_pmc_hbm.json (rocprofv3 --pmc, corrected)"
         roof["kernel_ms_per_launch"] = kernel_ms / args.steps
         roof["algorithmic_flops_per_chain_step"] = w["flops_per_chain_step"]
-        roof["algorithmic_bytes_per_chain_step"] = w["bytes_per_chain_step"]
+        roof["algorithmic_bytes_per_chain_step"] = w["bytes_per_chain_step"] / (traj if w["bound"] == "hbm" else 1)
         if counters_acc:
             roof["work_counters"] = counters_acc
         out = {
