@@ -602,13 +602,30 @@ int mm_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, 
                          const mm_fp_opts* opts, mm_counters* counters) {
   int rc = check_pair(ctx, m, s, "mm_implicit_leapfrog");
   if (rc != MM_OK) return rc;
-  MM_REQUIRE(ctx, m->rmetric != MM_RMETRIC_NONE, "mm_implicit_leapfrog: model has no Riemannian metric");
   MM_REQUIRE(ctx, n_steps >= 0, "mm_implicit_leapfrog: n_steps < 0");
   mm_fp_opts o = {1e-9, 1e10, 100, MM_NORM_LINF, MM_FP_DIRECT, MM_NORM_LINF, 2e-8};
   if (opts) o = *opts;
   MM_REQUIRE(ctx, o.max_iters >= 0 && (o.norm == 0 || o.norm == 1) && (o.rev_norm == 0 || o.rev_norm == 1) &&
                       (o.solver == MM_FP_DIRECT || o.solver == MM_FP_STEFFENSEN),
              "mm_implicit_leapfrog: bad solver options");
+  if (m->rmetric == MM_RMETRIC_NONE) {
+    // The reference runs this integrator on any System (tests/test_integrators.py:435-462).  On a plain
+    // Euclidean-metric system dh2_dpos = 0 and dh2_dmom does not depend on pos, so B and B* are the identity,
+    // C and C* are both pos += t M^-1 mom (their fixed-point solves reproduce the explicit value on the second
+    // evaluation) and every reversibility check passes exactly: the step is A(t) C(t) C(t) A(t), i.e. the
+    // composition with coefficients (1, 1, 0, 1, 1) -- a leapfrog step of size 2t taken as two half drifts.
+    MM_REQUIRE(ctx, m->constr == MM_CONSTR_NONE && !m->gaussian_split,
+               "mm_implicit_leapfrog: needs a Riemannian-metric or a plain Euclidean-metric system");
+    MM_REQUIRE(ctx, o.max_iters >= 2, "mm_implicit_leapfrog: the position solve needs max_iters >= 2");
+    const double coeffs[5] = {1.0, 1.0, 0.0, 1.0, 1.0};
+    rc = mm_composition_euclid(ctx, m, s, h, n_steps, 5, coeffs, 1);
+    if (rc != MM_OK) return rc;
+    if (counters) {
+      *counters = mm_counters{};
+      counters->n_grad = (int64_t)s->n * (2 * (int64_t)n_steps + 1);
+    }
+    return MM_OK;
+  }
   MM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(mm_counters), ctx->stream));
   if (s->n > 0) {
     rc = mm_launch_implicit_leapfrog(ctx, m, s, h, n_steps, o, ctx->d_counters);

@@ -175,14 +175,20 @@ class BCSSFourStageIntegrator(SymmetricCompositionIntegrator):
 class ImplicitLeapfrogIntegrator(Integrator):
     """Implicit (generalised) leapfrog on a Riemannian-metric system with fixed-point solves and
     reversibility checks (reference integrators.py:381-544).  NB as in the reference every
-    sub-map uses the full ``step_size`` (SURVEY.md hazard H1)."""
+    sub-map uses the full ``step_size`` (SURVEY.md hazard H1).  A plain Euclidean-metric system is accepted
+    too, as in the reference's own tests (tests/test_integrators.py:435-462): its implicit maps are explicit
+    and the step is A(t) C(t) C(t) A(t)."""
 
-    _needs = "riemann"
+    _needs = None  # riemann, or plain euclid
 
     def __init__(self, system, step_size=None, reverse_check_tol=2e-8,
                  reverse_check_norm=solvers.maximum_norm,
                  fixed_point_solver=solvers.solve_fixed_point_direct,
                  fixed_point_solver_kwargs=None):
+        kind = getattr(system, "_kind", None)
+        if kind not in ("riemann", "euclid") or getattr(system, "_gaussian_split", False):
+            raise ValueError(f"{type(self).__name__} needs a Riemannian- or plain Euclidean-metric system, got "
+                             f"{type(system).__name__}")
         super().__init__(system, step_size)
         self.reverse_check_tol = reverse_check_tol
         self.reverse_check_norm = reverse_check_norm

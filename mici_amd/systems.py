@@ -154,6 +154,8 @@ class GaussianEuclideanMetricSystem(EuclideanMetricSystem):
     discretise the non-Gaussian part.  As in the reference, ``dh_dpos`` is inherited from
     EuclideanMetricSystem (systems.py:359-360) and therefore ImplicitMidpointIntegrator sees dh1_dpos only."""
 
+    _gaussian_split = True
+
     def _model_args(self):
         return dict(metric_kind=self.metric_kind, metric=self.metric, gaussian_split=True)
 

@@ -555,6 +555,28 @@ def implicit_leapfrog_step(
     step_a(st)
 
 
+class EuclidAsGeneralSystem:
+    """A plain EuclideanMetricSystem seen through the generic System interface the implicit leapfrog uses
+    (systems.py:132-141, 352-360): dh1_dpos = grad, dh2_dpos = 0, dh2_dmom = M^-1 mom.  The reference runs
+    ImplicitLeapfrogIntegrator on such systems in its own tests (tests/test_integrators.py:435-462)."""
+
+    def __init__(self, euclid_system):
+        self.inner = euclid_system
+        self.counters = Counters()
+
+    def dh1_dpos(self, s):
+        return self.inner.grad(s.pos)
+
+    def dh2_dpos(self, s):
+        return np.zeros_like(s.pos)
+
+    def dh2_dmom(self, s):
+        return self.inner.minv(s.mom)
+
+    def h(self, q, p):
+        return self.inner.h(q, p)
+
+
 def implicit_leapfrog_steps(system, q, p, dt, n_steps, **kw):
     """Run up to n_steps; returns (q, p, status, n_done).  On failure the chain is frozen at
     its last successfully completed step (transitions.py:292-295)."""

@@ -90,7 +90,12 @@ def test_constructor_validation():
     with pytest.raises(ValueError):
         systems.SoftAbsRiemannianMetricSystem(models.Funnel(np.ones(3)), softabs_coeff=0.0)
     with pytest.raises(ValueError):
-        integrators.ImplicitLeapfrogIntegrator(systems.EuclideanMetricSystem(models.GaussIso(3)), 0.1)
+        integrators.ImplicitLeapfrogIntegrator(systems.GaussianEuclideanMetricSystem(models.GaussIso(3)), 0.1)
+    # plain Euclidean systems are accepted, as in the reference's own tests (tests/test_integrators.py:435-462)
+    integrators.ImplicitLeapfrogIntegrator(systems.EuclideanMetricSystem(models.GaussIso(3)), 0.1)
+    with pytest.raises(ValueError):
+        integrators.ImplicitLeapfrogIntegrator(
+            systems.DenseConstrainedEuclideanMetricSystem(models.GaussIso(3), models.FirstCoordConstr()), 0.1)
     with pytest.raises(TypeError):
         solvers.solve_fixed_point_direct(np.cos, np.ones(1))
     assert solvers.norm_code(solvers.maximum_norm) == 0

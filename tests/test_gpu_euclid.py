@@ -127,6 +127,23 @@ def test_composition_fast_paths_match_oracle(dim, n, target_kind, metric_kind, s
     assert_close(qb, q0, 1e-9, "reversed q")
 
 
+@pytest.mark.parametrize("name", golden_names("impliciteuclid"))
+def test_implicit_leapfrog_on_euclidean_system_matches_reference_fixture(name):
+    """ImplicitLeapfrogIntegrator accepts plain Euclidean systems as in the reference
+    (tests/test_integrators.py:435-462); on the device it is the composition (1, 1, 0, 1, 1)."""
+    g = load_golden(name)
+    system = system_from_golden(g)
+    integ = integrators.ImplicitLeapfrogIntegrator(system, float(g["step_size"]))
+    for k, s in enumerate(int(s) for s in g["checkpoints"]):
+        q, p, status, n_done = integ.step_batch(g["q0"], g["p0"], g["dir"], n_steps=s)
+        assert np.all(status == 0) and np.all(n_done == s)
+        assert_close(q, g["q_out"][k], 3e-13 * max(1, s), f"{name} q@{s}")
+        assert_close(p, g["p_out"][k], 3e-13 * max(1, s), f"{name} p@{s}")
+        assert_close(system.h_batch(q, p), g["h_out"][k], 1e-12, f"{name} h@{s}")
+    with pytest.raises(ValueError):
+        integrators.ImplicitLeapfrogIntegrator(systems.GaussianEuclideanMetricSystem(models.GaussIso(3)), 0.1)
+
+
 def test_composition_argument_checks():
     system = systems.EuclideanMetricSystem(models.GaussIso(4))
     with pytest.raises(ValueError):

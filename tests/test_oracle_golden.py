@@ -127,6 +127,29 @@ def test_gaussian_euclidean_metric_system(name):
     assert_close(0.5 * q1 @ q1 + 0.5 * p1 @ system.minv(p1), 0.5 * q @ q + 0.5 * p @ system.minv(p), 1e-13, "h2")
 
 
+@pytest.mark.parametrize("name", golden_names("impliciteuclid"))
+def test_implicit_leapfrog_on_a_euclidean_system(name):
+    """The reference runs ImplicitLeapfrogIntegrator on plain Euclidean systems too
+    (tests/test_integrators.py:435-462): dh2_dpos = 0, so the implicit maps are explicit."""
+    g = load_golden(name)
+    n, d = g["q0"].shape
+    target = mdl.target_from_id(g["target"], g["target_params"], d)
+    mk = int(g["metric_kind"])
+    esys = orc.EuclidSystem(target, mk, None if mk == mdl.METRIC_IDENTITY else g["metric"])
+    system = orc.EuclidAsGeneralSystem(esys)
+    h = float(g["step_size"])
+    for k, s in enumerate(int(s) for s in g["checkpoints"]):
+        for c in range(n):
+            q, p, st, nd = orc.implicit_leapfrog_steps(system, g["q0"][c], g["p0"][c], g["dir"][c] * h, s)
+            assert st == 0 and nd == s
+            assert_close(q, g["q_out"][k, c], 1e-12 * max(1, s), f"{name} q@{s}")
+            assert_close(p, g["p_out"][k, c], 1e-12 * max(1, s), f"{name} p@{s}")
+    coefficients = [1.0, 1.0, 0.0, 1.0, 1.0]
+    qb, pb = orc.leapfrog_steps_batch(esys, g["q0"], g["p0"], g["dir"] * h, int(g["checkpoints"][-1]),
+                                      coefficients=coefficients)
+    assert_close(qb, g["q_out"][-1], 1e-11, f"{name} as the (1, 1, 0, 1, 1) composition")
+
+
 @pytest.mark.parametrize("name", golden_names("midpoint"))
 def test_implicit_midpoint(name):
     """ImplicitMidpointIntegrator (integrators.py:547-681) on Euclidean and dense-Riemannian systems."""

@@ -870,6 +870,35 @@ def main():
                     mdl.METRIC_DENSE, mdl.make_spd(6, rng), linear_init(5, a3, b3), 0.3, [1, 5, 20],
                     variant="gaussian")
 
+    # ---- ImplicitLeapfrogIntegrator on a plain Euclidean-metric system (tests/test_integrators.py:435-462) ---------
+    def add_implicit_euclid(name, target, mk, metric, n, h, cps):
+        q0 = rng.standard_normal((n, target.dim))
+        esys = orc.EuclidSystem(target, mk, metric)
+        p0 = np.stack([esys.msqrt(zz) for zz in rng.standard_normal((n, target.dim))])
+
+        def make():
+            rsys = mici.systems.EuclideanMetricSystem(
+                neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+                metric=None if mk == mdl.METRIC_IDENTITY else np.array(metric))
+            rint = mici.integrators.ImplicitLeapfrogIntegrator(rsys, h)
+            dirs = dirs_for(n)
+            ref, counts = run_reference(rint, rsys, q0, p0, dirs, cps)
+            osys = orc.EuclidAsGeneralSystem(esys)
+            for k, s in enumerate(cps):
+                for c in range(n):
+                    q, p, st, nd = orc.implicit_leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, s)
+                    assert st == 0 and nd == s
+                    check_close(f"{name} q@{s}", q, ref["q_out"][k, c], 1e-12 * max(1, s))
+                    check_close(f"{name} p@{s}", p, ref["p_out"][k, c], 1e-12 * max(1, s))
+            return dict(kind="impliciteuclid", q0=q0, p0=p0, dir=dirs, step_size=h, checkpoints=np.array(cps),
+                        **model_keys(target, mk, metric), **ref), counts
+        cases[name] = make
+
+    add_implicit_euclid("impliciteuclid_quartic_dense_d5", mdl.Poly(5, 0.0, 1.0), mdl.METRIC_DENSE,
+                        mdl.make_spd(5, rng), 5, 0.1, [1, 5, 20])
+    add_implicit_euclid("impliciteuclid_gauss_dense_d24", mdl.GaussDense(mdl.make_spd(24, rng)), mdl.METRIC_IDENTITY,
+                        None, 4, 0.2, [1, 10])
+
     # ---- correlated momentum refresh + random trajectory length (transitions.py:143-198, 355-402) ----------
     def make_corr_random():
         name = "corrmom_random_nstep_d10"
