@@ -76,7 +76,8 @@ typedef enum mm_constr { /* holonomic constraint, C = 1 */
   MM_CONSTR_FIRST = 2,  /* q_0                                          */
   MM_CONSTR_CIRCLE = 3, /* q_0^2 + q_1^2 - 1                            */
   MM_CONSTR_LINEAR = 4, /* A q - b, C rows: params A[C*D] (row-major) then b[C]; C = n_constr_params / (D + 1) <= 3 */
-  MM_CONSTR_SPHERE_PLANE = 5 /* two constraints: |q|^2 - 1 and n . q; params n[D], D >= 3 */
+  MM_CONSTR_SPHERE_PLANE = 5, /* two constraints: |q|^2 - 1 and n . q; params n[D], D >= 3 */
+  MM_CONSTR_SPHERE = 6  /* |q|^2 - 1 (the constrained system of the reference's adapter tests), D >= 2 */
 } mm_constr;
 
 /* Per-chain status: which reference exception the failed step would have raised (errors.py:6-35). */

@@ -257,6 +257,7 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
                   : d->constr == MM_CONSTR_CIRCLE       ? 0
                   : d->constr == MM_CONSTR_LINEAR       ? d->n_constr_params
                   : d->constr == MM_CONSTR_SPHERE_PLANE ? (size_t)D
+                  : d->constr == MM_CONSTR_SPHERE       ? 0
                                                         : (size_t)-1;
   MM_REQUIRE(ctx, need_c != (size_t)-1, "mm_model_create: unknown constraint id");
   int n_constr = d->constr == MM_CONSTR_NONE ? 0 : 1;
@@ -267,6 +268,7 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
     MM_REQUIRE(ctx, n_constr >= 1 && n_constr <= 3 && (n_constr < D || D == 1),
                "mm_model_create: linear constraint supports 1 <= C <= 3 rows, C < dim");
   }
+  MM_REQUIRE(ctx, d->constr != MM_CONSTR_SPHERE || D >= 2, "sphere constraint needs dim >= 2");
   if (d->constr == MM_CONSTR_SPHERE_PLANE) {
     MM_REQUIRE(ctx, D >= 3, "sphere-plane constraint needs dim >= 3");
     n_constr = 2;

@@ -14,7 +14,7 @@ TARGET_GAUSS_ISO, TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_POLY = 0, 1, 2, 
 TARGET_BANANA, TARGET_FUNNEL, TARGET_TORUS = 4, 5, 6
 METRIC_IDENTITY, METRIC_DIAG, METRIC_DENSE = 0, 1, 2
 RMETRIC_NONE, RMETRIC_RANK1, RMETRIC_DIAGQUAD, RMETRIC_SOFTABS = 0, 1, 2, 3
-CONSTR_NONE, CONSTR_TORUS, CONSTR_FIRST, CONSTR_CIRCLE, CONSTR_LINEAR, CONSTR_SPHERE_PLANE = 0, 1, 2, 3, 4, 5
+CONSTR_NONE, CONSTR_TORUS, CONSTR_FIRST, CONSTR_CIRCLE, CONSTR_LINEAR, CONSTR_SPHERE_PLANE, CONSTR_SPHERE = 0, 1, 2, 3, 4, 5, 6
 
 
 def _f64(a):
@@ -152,6 +152,13 @@ class LinearConstr(Constraint):
         self.n_constr = a.shape[0]
 
 
+class SphereConstr(Constraint):
+    """c(q) = |q|^2 - 1."""
+
+    def __init__(self):
+        super().__init__(CONSTR_SPHERE)
+
+
 class SpherePlaneConstr(Constraint):
     """Two constraints: c_0(q) = |q|^2 - 1 and c_1(q) = n . q (a great circle / sphere of the unit sphere)."""
 
@@ -197,6 +204,8 @@ def constr_from_id(cid, params, dim=None):
         return LinearConstr(params[:c * dim].reshape(c, dim), params[c * dim:])
     if cid == CONSTR_SPHERE_PLANE:
         return SpherePlaneConstr(params)
+    if cid == CONSTR_SPHERE:
+        return SphereConstr()
     if cid == CONSTR_TORUS:
         return TorusConstr(*params)
     if cid == CONSTR_FIRST:

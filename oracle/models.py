@@ -37,6 +37,7 @@ CONSTR_FIRST = 2
 CONSTR_CIRCLE = 3
 CONSTR_LINEAR = 4
 CONSTR_SPHERE_PLANE = 5
+CONSTR_SPHERE = 6
 
 
 # ---- targets ---------------------------------------------------------------------------
@@ -386,6 +387,23 @@ class LinearConstr:
         return lambda m: np.zeros_like(q)
 
 
+class SphereConstr:
+    """c(q) = |q|^2 - 1 (tests/test_adapters.py:174-181)."""
+    cid = CONSTR_SPHERE
+
+    def params(self):
+        return np.zeros(0)
+
+    def constr(self, q):
+        return np.array([q @ q - 1.0])
+
+    def jacob_constr(self, q):
+        return 2.0 * q[None]
+
+    def mhp_constr(self, q):
+        return lambda m: 2.0 * m[0]
+
+
 class SpherePlaneConstr:
     """c_0 = |q|^2 - 1, c_1 = n . q."""
     cid = CONSTR_SPHERE_PLANE
@@ -466,6 +484,8 @@ def constr_from_id(cid, params, dim=None):
         return LinearConstr(params[:c * dim].reshape(c, dim), params[c * dim:])
     if cid == CONSTR_SPHERE_PLANE:
         return SpherePlaneConstr(params)
+    if cid == CONSTR_SPHERE:
+        return SphereConstr()
     if cid == CONSTR_TORUS:
         return TorusConstr(*params)
     if cid == CONSTR_FIRST:

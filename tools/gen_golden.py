@@ -899,6 +899,25 @@ def main():
     add_implicit_euclid("impliciteuclid_gauss_dense_d24", mdl.GaussDense(mdl.make_spd(24, rng)), mdl.METRIC_IDENTITY,
                         None, 4, 0.2, [1, 10])
 
+    # ---- 8 < D <= 16 constrained systems (capacity-16 kernels); the D = 10 unit sphere with the quasi-Newton
+    #      solver is the system of the reference's adapter tests (tests/test_adapters.py:156-188) ---------------------
+    def sphere_init(n, d):
+        x = rng.standard_normal((n, d))
+        return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+    add_constrained("constrained_sphere_d10_quasi", mdl.GaussIso(10), mdl.SphereConstr(), mdl.METRIC_IDENTITY, None,
+                    sphere_init(6, 10), 0.2, [1, 5, 20], proj_solver=1)
+    add_constrained("constrained_sphere_ambient_dense_d9", mdl.Poly(9, 0.5, 0.25), mdl.SphereConstr(),
+                    mdl.METRIC_DENSE, mdl.make_spd(9, rng), sphere_init(5, 9), 0.1, [1, 5, 20], variant="ambient")
+    a12, b12 = rng.standard_normal((3, 12)), rng.standard_normal(3)
+    add_constrained("constrained_c3_linear_d12_linesearch", mdl.Poly(12, 1.0, 0.25), mdl.LinearConstr(a12, b12),
+                    mdl.METRIC_DIAG, np.exp(0.2 * rng.standard_normal(12)), linear_init(5, a12, b12), 0.1, [1, 5, 20],
+                    proj_solver=2)
+    n16 = rng.standard_normal(16)
+    add_constrained("constrained_c2_sphereplane_gauss_d16", mdl.Poly(16, 0.0, 0.5), mdl.SpherePlaneConstr(n16),
+                    mdl.METRIC_DENSE, mdl.make_spd(16, rng), sphere_plane_init(5, 16, n16), 0.05, [1, 5, 20],
+                    variant="gaussian")
+
     # ---- correlated momentum refresh + random trajectory length (transitions.py:143-198, 355-402) ----------
     def make_corr_random():
         name = "corrmom_random_nstep_d10"
