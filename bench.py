@@ -435,11 +435,13 @@ def main():
                                          frac=tf / FP64_MFMA_PEAK_TF)
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
         # (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); null when not profiled
-        pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_hbm.json")
-        if args.config == "c2" and n_local == 4096 and traj == 1000 and os.path.exists(pmc):
+        pmc_name = "r01_c2_pmc_hbm.json" if args.config == "c2" else f"r01b_{args.config}_pmc_hbm.json"
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
+        default_shape = args.chains_per_gpu is None and args.traj_len is None
+        if default_shape and os.path.exists(pmc):
             with open(pmc) as fh:
                 roof["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r01_c2_pmc_hbm.json (rocprofv3 --pmc, corrected)"
+            roof["traffic_source"] = f"profiles/{pmc_name} (rocprofv3 --pmc, corrected)"
         roof["kernel_ms_per_launch"] = kernel_ms / args.steps
         roof["algorithmic_flops_per_chain_step"] = w["flops_per_chain_step"]
         roof["algorithmic_bytes_per_chain_step"] = w["bytes_per_chain_step"] / (traj if w["bound"] == "hbm" else 1)

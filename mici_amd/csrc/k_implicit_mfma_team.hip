@@ -64,6 +64,14 @@ __device__ __forceinline__ int opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+// The lane index straight from the hardware (two VALU instructions).  The sweep needs lane-derived LDS
+// addresses right after every barrier; held in a member they were spilled (the register file is full of tiles)
+// and every block waited on a scratch reload at its most latency-critical point.
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 __device__ __forceinline__ int opaque_s(int v) {
   v = __builtin_amdgcn_readfirstlane(v);
   asm volatile("" : "+s"(v));
@@ -118,7 +126,7 @@ struct TeamMfma {
   // ---- metric_func(x) into one tile row -------------------------------------------------------------
   template <int NS>
   __device__ __forceinline__ void build_row(d4 (&acc)[NS], const int I, double& chk) {
-    const int g = opaque(gq), j = opaque(jq);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
     const double inv_d = 1.0 / (double)dim;
     const d4 qr = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
     const double* nat_row = lds + kOffNat + 16 * I + j;                          // - 16 k
@@ -162,7 +170,7 @@ struct TeamMfma {
   // ---- sweep, phase (1): this row's share of the panel  qt[c][s] = A[k0 + s][c] ------------------------
   template <int NS, int R0>
   __device__ __forceinline__ void publish_row(const d4 (&acc)[NS], const int I, const int I0, double* qt) {
-    const int g = opaque(gq), j = opaque(jq);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
     if (I == I0) {
       double* dst = qt + ((16 * I + j) << 2) + g;  // - 64 k
 #pragma unroll
@@ -190,7 +198,7 @@ struct TeamMfma {
   template <int NS, int R0>
   __device__ __forceinline__ void update_row(d4 (&acc)[NS], const int I, const int I0, const double* qt,
                                              const double* wt) {
-    const int g = opaque(gq), j = opaque(jq);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
     const double av = wt[((16 * I + j) << 2) + g];
     const double* src = qt + ((16 * I + j) << 2) + g;  // - 64 k
 #pragma unroll
@@ -209,7 +217,7 @@ struct TeamMfma {
     double* wt = lds + kOffWt + par * (DPM * 4);
     double* xt = lds + kOffXt + par * (DPM * 4);
     const int k0 = 16 * I0 + 4 * R0;
-    const int tid = opaque(this->tid);
+    const int tid = W * 64 + fresh_lane();
     const int ia = Ia, ib = Ib;
     publish_row<NSA, R0>(accA, ia, I0, qt);
     publish_row<NSB, R0>(accB, ib, I0, qt);
@@ -297,7 +305,7 @@ struct TeamMfma {
   // ---- y = T v, one tile row's contributions ----------------------------------------------------------
   template <int NS>
   __device__ __forceinline__ void matvec_row(const d4 (&acc)[NS], const int I) {
-    const int g = opaque(gq), j = opaque(jq);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
     double* part = lds + kOffPart;
     const double* vcol = lds + kOffNat + 16 * I + j;  // - 16 k
     const d4 vr = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
@@ -360,7 +368,7 @@ struct TeamMfma {
   }
 
   __device__ __forceinline__ double diag() {
-    const int g = opaque(gq), j = opaque(jq);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (j == 4 * r + g) {

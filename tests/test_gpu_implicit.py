@@ -317,10 +317,10 @@ def test_unsupported_sizes_fail_loudly():
     with pytest.raises(DeviceError):
         integrators.ImplicitLeapfrogIntegrator(system, 0.01).step_batch(
             rng.standard_normal((1, 65)), rng.standard_normal((1, 65)), 1, 1)
-    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(9, 1.0, 0.0), models.CircleConstr())
-    with pytest.raises(DeviceError):
+    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(17, 1.0, 0.0), models.CircleConstr())
+    with pytest.raises(DeviceError):  # lane-per-chain kernels stop at dim 16
         integrators.ConstrainedLeapfrogIntegrator(system, 0.1).step_batch(
-            rng.standard_normal((1, 9)), rng.standard_normal((1, 9)), 1, 1)
+            rng.standard_normal((1, 17)), rng.standard_normal((1, 17)), 1, 1)
 
 
 def test_empty_batches():
