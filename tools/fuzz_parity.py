@@ -1,0 +1,162 @@
+"""Randomised parity sweep: HIP path vs the oracle over random sizes / models / integrators.
+
+    python tools/fuzz_parity.py [--seed S] [--cases N]
+
+Test infrastructure (imports oracle/).  Prints one line per case and a summary; exits non-zero on a mismatch."""
+import argparse
+import sys
+import os
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import integrators as orc  # noqa: E402
+from oracle import models as omdl  # noqa: E402
+from mici_amd import integrators, models, solvers, systems  # noqa: E402
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.all(
+        np.abs(np.nan_to_num(a) - np.nan_to_num(b)) <= tol * np.maximum(1.0, np.abs(np.nan_to_num(b))))
+
+
+def targets(dim, rng, kinds):
+    k = rng.choice(kinds)
+    if k == "iso":
+        return models.GaussIso(dim), omdl.GaussIso(dim)
+    if k == "diag":
+        pr = np.exp(0.3 * rng.standard_normal(dim))
+        return models.GaussDiag(pr), omdl.GaussDiag(pr)
+    if k == "dense":
+        P = omdl.make_spd(dim, rng)
+        return models.GaussDense(P), omdl.GaussDense(P)
+    if k == "poly":
+        a, b = rng.uniform(0, 1.5), rng.uniform(0, 0.5)
+        return models.Poly(dim, a, b), omdl.Poly(dim, a, b)
+    return models.Banana(dim), omdl.Banana(dim)
+
+
+def metric_of(dim, rng):
+    k = rng.choice(["identity", "diag", "dense"])
+    if k == "identity":
+        return omdl.METRIC_IDENTITY, None
+    if k == "diag":
+        return omdl.METRIC_DIAG, np.exp(0.3 * rng.standard_normal(dim))
+    return omdl.METRIC_DENSE, omdl.make_spd(dim, rng)
+
+
+def euclid_case(rng):
+    dim = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 31, 33, 48, 64, 65, 100, 127, 128, 129, 200]))
+    n = int(rng.choice([1, 3, 15, 16, 17, 70, 300]))
+    gaussian = rng.random() < 0.3
+    pt, ot = targets(dim, rng, ["iso", "diag", "dense", "poly", "banana"] if dim >= 2 else ["iso", "poly"])
+    mk, metric = metric_of(dim, rng)
+    if gaussian:
+        system, osys = systems.GaussianEuclideanMetricSystem(pt, metric=metric), orc.GaussianEuclidSystem(ot, mk, metric)
+    else:
+        system, osys = systems.EuclideanMetricSystem(pt, metric=metric), orc.EuclidSystem(ot, mk, metric)
+    kind = rng.choice(["leapfrog", "bcss2", "bcss3", "bcss4", "midpoint"] if dim <= 128 else
+                      ["leapfrog", "bcss2", "bcss3", "bcss4"])
+    h, steps = float(rng.uniform(0.02, 0.15)), int(rng.integers(1, 12))
+    if isinstance(ot, omdl.Banana):
+        h *= 0.2
+    q0 = rng.standard_normal((n, dim))
+    p0 = np.stack([osys.msqrt(z) for z in rng.standard_normal((n, dim))])
+    dirs = np.where(rng.random(n) < 0.5, 1, -1).astype(np.int8)
+    desc = f"euclid{'-gauss' if gaussian else ''} {kind} D={dim} N={n} {type(ot).__name__} metric={mk} h={h:.3f} steps={steps}"
+    if kind == "leapfrog":
+        integ = integrators.LeapfrogIntegrator(system, h)
+        ref = lambda c: orc.leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, steps) + (0, steps)  # noqa: E731
+    elif kind == "midpoint":
+        integ = integrators.ImplicitMidpointIntegrator(system, h)
+        ref = lambda c: orc.implicit_midpoint_steps(osys, q0[c], p0[c], dirs[c] * h, steps)  # noqa: E731
+    else:
+        st = int(kind[-1])
+        integ = {2: integrators.BCSSTwoStageIntegrator, 3: integrators.BCSSThreeStageIntegrator,
+                 4: integrators.BCSSFourStageIntegrator}[st](system, h)
+        ref = lambda c: orc.composition_steps(osys, q0[c], p0[c], dirs[c] * h, steps,  # noqa: E731
+                                              orc.BCSS_FREE_COEFFICIENTS[st]) + (0, steps)
+    return desc, integ, system, osys, q0, p0, dirs, steps, ref, (1e-9 if kind == "midpoint" else 1e-11)
+
+
+def riemann_case(rng):
+    dim = int(rng.choice([1, 2, 5, 8, 9, 16, 31, 32, 33, 40, 63, 64, 65, 70, 75, 76, 90, 128]))
+    n = int(rng.choice([1, 2, 5, 9]))
+    which = rng.choice(["rank1", "diagquad"])
+    pt, ot = targets(dim, rng, ["poly", "banana"] if dim >= 2 else ["poly"])
+    if which == "rank1":
+        B = omdl.make_spd(dim, rng)
+        pm, om = models.Rank1Metric(B), omdl.Rank1Metric(B)
+    else:
+        pm, om = models.DiagQuadMetric(dim), omdl.DiagQuadMetric(dim)
+    system = systems.DenseRiemannianMetricSystem(pt, pm)
+    osys = orc.RiemannianSystem(ot, om, None, orc.Counters())
+    h, steps = float(rng.uniform(0.01, 0.06)), int(rng.integers(1, 5))
+    if isinstance(ot, omdl.Banana):
+        h *= 0.4
+    solver = int(rng.integers(0, 2))
+    integ = integrators.ImplicitLeapfrogIntegrator(
+        system, h, fixed_point_solver=[solvers.solve_fixed_point_direct, solvers.solve_fixed_point_steffensen][solver])
+    q0 = rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+    dirs = np.where(rng.random(n) < 0.5, 1, -1).astype(np.int8)
+    desc = f"riemann {which} D={dim} N={n} {type(ot).__name__} solver={solver} h={h:.3f} steps={steps}"
+    ref = lambda c: orc.implicit_leapfrog_steps(  # noqa: E731
+        osys, q0[c], p0[c], dirs[c] * h, steps, fp_solver=orc.FP_SOLVERS[solver])
+    return desc, integ, system, osys, q0, p0, dirs, steps, ref, 1e-9
+
+
+def softabs_case(rng):
+    dim = int(rng.choice([2, 3, 5, 8, 16, 17, 33, 48, 64]))
+    n = int(rng.choice([1, 2, 5]))
+    if rng.random() < 0.5:
+        w = np.linspace(0.5, 2.0, dim - 1)
+        pt, ot = models.Funnel(w), omdl.Funnel(w)
+    else:
+        a, b = rng.uniform(0.5, 1.5), rng.uniform(0.1, 0.5)
+        pt, ot = models.Poly(dim, a, b), omdl.Poly(dim, a, b)
+    coeff = float(rng.choice([0.5, 1.0, 2.0]))
+    system = systems.SoftAbsRiemannianMetricSystem(pt, softabs_coeff=coeff)
+    osys = orc.RiemannianSystem(ot, None, coeff, orc.Counters())
+    h, steps = float(rng.uniform(0.01, 0.05)), int(rng.integers(1, 4))
+    integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+    q0 = 0.5 * rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+    dirs = np.where(rng.random(n) < 0.5, 1, -1).astype(np.int8)
+    desc = f"softabs D={dim} N={n} {type(ot).__name__} coeff={coeff} h={h:.3f} steps={steps}"
+    ref = lambda c: orc.implicit_leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, steps)  # noqa: E731
+    return desc, integ, system, osys, q0, p0, dirs, steps, ref, 5e-8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cases", type=int, default=60)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    bad = 0
+    for i in range(a.cases):
+        u = rng.random()
+        make = euclid_case if u < 0.55 else (riemann_case if u < 0.9 else softabs_case)
+        desc, integ, system, osys, q0, p0, dirs, steps, ref, tol = make(rng)
+        try:
+            q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=steps)
+        except Exception as e:  # unsupported sizes must fail loudly, never silently
+            print(f"[{i}] {desc}: device refused ({type(e).__name__}: {str(e)[:80]})")
+            continue
+        ok = True
+        for c in sorted(set([0, len(q0) - 1, int(rng.integers(0, len(q0)))])):
+            qo, po, so, no = ref(c)
+            if so != status[c] or no != n_done[c] or not close(q[c], qo, tol) or not close(p[c], po, tol):
+                ok = False
+                err = np.max(np.abs(np.nan_to_num(q[c]) - np.nan_to_num(qo)))
+                print(f"    chain {c}: status {status[c]} vs {so}, n_done {n_done[c]} vs {no}, max |dq| = {err:.2e}")
+        print(f"[{i}] {desc}: {'ok' if ok else 'MISMATCH'}")
+        bad += not ok
+    print(f"{a.cases} cases, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
