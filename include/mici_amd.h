@@ -185,6 +185,10 @@ int mm_state_upload(mm_state* state, const double* pos, const double* mom, const
 int mm_state_download(mm_state* state, double* pos, double* mom, int8_t* dir);
 /* status[N] / n_done[N] of the last implicit / constrained call on this state */
 int mm_state_download_status(mm_state* state, int32_t* status, int32_t* n_done);
+/* pos, mom, dir, status and n_done in one transfer (any pointer may be NULL).  A small batch (<= 1 MiB of
+ * state) moves through a pinned mirror in a single copy each way: the transfer pattern of the reference's
+ * single-state Integrator.step (integrators.py:63-80), which is latency- not bandwidth-bound. */
+int mm_state_download_all(mm_state* s, double* pos, double* mom, int8_t* dir, int32_t* status, int32_t* n_done);
 /* raw device pointers (zero-copy interop / RCCL): any of the outputs may be NULL */
 int mm_state_device_ptrs(mm_state* state, double** pos, double** mom, int8_t** dir);
 

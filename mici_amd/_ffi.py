@@ -93,6 +93,7 @@ SIGNATURES = {
     "mm_state_upload": (C.c_int, [_VP, c_double_p, c_double_p, c_int8_p]),
     "mm_state_download": (C.c_int, [_VP, c_double_p, c_double_p, c_int8_p]),
     "mm_state_download_status": (C.c_int, [_VP, c_int32_p, c_int32_p]),
+    "mm_state_download_all": (C.c_int, [_VP, c_double_p, c_double_p, c_int8_p, c_int32_p, c_int32_p]),
     "mm_state_device_ptrs": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
     "mm_momentum_refresh": (C.c_int, [_VP, _VP, _VP, c_double_p, C.c_double]),
     "mm_state_copy": (C.c_int, [_VP, _VP]),

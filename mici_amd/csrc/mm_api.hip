@@ -54,6 +54,10 @@ int mm_device_count(int* count) {
   return MM_OK;
 }
 
+// batches whose pos | mom | dir | status | n_done block is at most this big travel through the context's
+// pinned staging buffer (one copy each way)
+static constexpr size_t kStageLimit = (size_t)1 << 20;
+
 int mm_ctx_create(int device, mm_ctx** out) {
   MM_REQUIRE(nullptr, out != nullptr, "mm_ctx_create: out is NULL");
   *out = nullptr;
@@ -82,7 +86,8 @@ int mm_ctx_create(int device, mm_ctx** out) {
       return MM_ERR_HIP;
     }
   }
-  if (hipMalloc(&ctx->d_counters, sizeof(mm_counters)) != hipSuccess) {
+  if (hipMalloc(&ctx->d_counters, sizeof(mm_counters)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), kStageLimit, hipHostMallocDefault) != hipSuccess) {
     mm_set_error(nullptr, "mm_ctx_create: hipMalloc failed");
     return MM_ERR_NOMEM;
   }
@@ -96,6 +101,7 @@ int mm_ctx_destroy(mm_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& e : ctx->events) (void)hipEventDestroy(e);
   (void)hipFree(ctx->d_counters);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return MM_OK;
@@ -411,12 +417,22 @@ int mm_state_alloc(mm_ctx* ctx, int64_t n, int32_t dim, mm_state** out) {
   s->dim = dim;
   const size_t nd = (size_t)(n > 0 ? n : 1) * dim, n1 = (size_t)(n > 0 ? n : 1);
   s->scratch_elems = nd;
-  bool ok = hipMalloc(&s->d_pos, nd * sizeof(double)) == hipSuccess &&
-            hipMalloc(&s->d_mom, nd * sizeof(double)) == hipSuccess &&
-            hipMalloc(&s->d_scratch, nd * sizeof(double)) == hipSuccess &&
-            hipMalloc(&s->d_dir, n1) == hipSuccess &&
-            hipMalloc(&s->d_status, n1 * sizeof(int32_t)) == hipSuccess &&
-            hipMalloc(&s->d_n_done, n1 * sizeof(int32_t)) == hipSuccess;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  s->off_mom = up(nd * sizeof(double));
+  s->off_dir = s->off_mom + up(nd * sizeof(double));
+  s->off_status = s->off_dir + up(n1);
+  s->off_n_done = s->off_status + up(n1 * sizeof(int32_t));
+  s->block_bytes = s->off_n_done + up(n1 * sizeof(int32_t));
+  bool ok = hipMalloc(&s->d_block, s->block_bytes) == hipSuccess &&
+            hipMalloc(&s->d_scratch, nd * sizeof(double)) == hipSuccess;
+  if (ok) {
+    s->d_pos = reinterpret_cast<double*>(s->d_block);
+    s->d_mom = reinterpret_cast<double*>(s->d_block + s->off_mom);
+    s->d_dir = reinterpret_cast<int8_t*>(s->d_block + s->off_dir);
+    s->d_status = reinterpret_cast<int32_t*>(s->d_block + s->off_status);
+    s->d_n_done = reinterpret_cast<int32_t*>(s->d_block + s->off_n_done);
+    if (s->block_bytes <= kStageLimit) s->h_stage = ctx->h_stage;  // every use drains the stream first
+  }
   if (!ok) {
     mm_state_free(s);
     mm_set_error(ctx, "mm_state_alloc: hipMalloc failed");
@@ -433,11 +449,7 @@ int mm_state_free(mm_state* s) {
   if (!s) return MM_OK;
   (void)hipSetDevice(s->ctx->device);
   (void)hipStreamSynchronize(s->ctx->stream);
-  (void)hipFree(s->d_pos);
-  (void)hipFree(s->d_mom);
-  (void)hipFree(s->d_dir);
-  (void)hipFree(s->d_status);
-  (void)hipFree(s->d_n_done);
+  (void)hipFree(s->d_block);
   (void)hipFree(s->d_scratch);
   (void)hipFree(s->d_work);
   (void)hipFree(s->d_tr);
@@ -452,13 +464,23 @@ int mm_state_upload(mm_state* s, const double* pos, const double* mom, const int
   mm_ctx* ctx = s->ctx;
   if (s->n == 0) return MM_OK;
   const size_t nd = (size_t)s->n * s->dim;
-  if (pos) MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_pos, pos, nd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if (mom) MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_mom, mom, nd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if (dir) {
+  if (dir)
     for (int64_t i = 0; i < s->n; ++i)
       MM_REQUIRE(ctx, dir[i] == 1 || dir[i] == -1, "mm_state_upload: dir entries must be +1 or -1");
-    MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_dir, dir, (size_t)s->n, hipMemcpyHostToDevice, ctx->stream));
+  if (s->h_stage && pos && mom && dir) {
+    // one copy: the caller's buffers are consumed here (into the pinned mirror), so nothing has to be waited
+    // for; the stream is drained first because an earlier transfer may still be reading the mirror
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(s->h_stage, pos, nd * sizeof(double));
+    std::memcpy(s->h_stage + s->off_mom, mom, nd * sizeof(double));
+    std::memcpy(s->h_stage + s->off_dir, dir, (size_t)s->n);
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_block, s->h_stage, s->off_dir + (size_t)s->n, hipMemcpyHostToDevice,
+                                     ctx->stream));
+    return MM_OK;
   }
+  if (pos) MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_pos, pos, nd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (mom) MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_mom, mom, nd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (dir) MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_dir, dir, (size_t)s->n, hipMemcpyHostToDevice, ctx->stream));
   MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // host buffers are only borrowed
   return MM_OK;
 }
@@ -472,6 +494,25 @@ int mm_state_download(mm_state* s, double* pos, double* mom, int8_t* dir) {
   if (mom) MM_HIP_CHECK(ctx, hipMemcpyAsync(mom, s->d_mom, nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (dir) MM_HIP_CHECK(ctx, hipMemcpyAsync(dir, s->d_dir, (size_t)s->n, hipMemcpyDeviceToHost, ctx->stream));
   MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return MM_OK;
+}
+
+int mm_state_download_all(mm_state* s, double* pos, double* mom, int8_t* dir, int32_t* status, int32_t* n_done) {
+  MM_REQUIRE(nullptr, s != nullptr, "mm_state_download_all: state is NULL");
+  mm_ctx* ctx = s->ctx;
+  if (s->n == 0) return MM_OK;
+  if (!s->h_stage) {
+    int rc = mm_state_download(s, pos, mom, dir);
+    return rc != MM_OK ? rc : mm_state_download_status(s, status, n_done);
+  }
+  const size_t nd = (size_t)s->n * s->dim;
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(s->h_stage, s->d_block, s->block_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (pos) std::memcpy(pos, s->h_stage, nd * sizeof(double));
+  if (mom) std::memcpy(mom, s->h_stage + s->off_mom, nd * sizeof(double));
+  if (dir) std::memcpy(dir, s->h_stage + s->off_dir, (size_t)s->n);
+  if (status) std::memcpy(status, s->h_stage + s->off_status, (size_t)s->n * sizeof(int32_t));
+  if (n_done) std::memcpy(n_done, s->h_stage + s->off_n_done, (size_t)s->n * sizeof(int32_t));
   return MM_OK;
 }
 

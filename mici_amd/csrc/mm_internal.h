@@ -16,6 +16,7 @@ struct mm_ctx {
   int n_cu = 0;
   std::string last_error;
   mm_counters* d_counters = nullptr;  // device scratch for work counters
+  char* h_stage = nullptr;  // pinned staging buffer (kStageLimit bytes) shared by the small batches of this context
 };
 
 // Coefficient sequence of a SymmetricCompositionIntegrator (integrators.py:176-274), alternating h1 / h2 flows.
@@ -63,6 +64,12 @@ struct mm_state {
   int8_t* d_dir = nullptr;
   int32_t* d_status = nullptr;
   int32_t* d_n_done = nullptr;
+  // pos | mom | dir | status | n_done live in ONE device allocation (256-byte aligned sections) mirrored by a
+  // pinned host buffer: a small batch goes up in one copy and comes back in one copy (the single-state
+  // Integrator.step of the reference's calling pattern is transfer-latency bound)
+  char* d_block = nullptr;
+  char* h_stage = nullptr;  // the context's pinned staging buffer, nullptr for batches above kStageLimit
+  size_t block_bytes = 0, off_mom = 0, off_dir = 0, off_status = 0, off_n_done = 0;
   double* d_scratch = nullptr;  // [N] or [N*D] doubles for h / dh_dmom / z
   size_t scratch_elems = 0;
   void* d_work = nullptr;  // per-chain workspace of the large-D implicit path

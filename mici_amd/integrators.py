@@ -78,15 +78,13 @@ class Integrator:
         try:
             batch.upload(pos, mom, dir)
             self.step_device(batch, n_steps, ctx)
-            q, p, _ = batch.download()
-            status, n_done = self._status(batch, n_steps)
+            q, p, _, status, n_done = batch.download_all()
         finally:
             batch.close()
         return q, p, status, n_done
 
     def _status(self, batch, n_steps):
-        return (np.zeros(batch.n_chains, dtype=np.int32),
-                np.full(batch.n_chains, n_steps, dtype=np.int32))
+        return batch.download_status()
 
     def step(self, state):
         """Single-chain step with the reference's semantics (integrators.py:63-80)."""
@@ -98,9 +96,8 @@ class Integrator:
             batch = self._one[id(ctx)] = DeviceBatch(ctx, 1, pos.shape[0])
         batch.upload(pos[None], np.asarray(state.mom, dtype=np.float64)[None], [int(state.dir)])
         self.step_device(batch, 1, ctx)
-        status, _ = self._status(batch, 1)
+        q, p, _, status, _ = batch.download_all()  # one transfer each way for a single state
         raise_for_status(status[0])
-        q, p, _ = batch.download()
         new = state.copy()
         new.pos = q[0]
         new.mom = p[0]

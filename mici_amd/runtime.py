@@ -163,6 +163,19 @@ class DeviceBatch:
                    self.ctx.handle, "mm_state_download")
         return pos, mom, dir_
 
+    def download_all(self):
+        """(pos, mom, dir, status, n_done) in one transfer."""
+        pos = np.empty((self.n_chains, self.dim))
+        mom = np.empty((self.n_chains, self.dim))
+        dir_ = np.empty(self.n_chains, dtype=np.int8)
+        status = np.zeros(self.n_chains, dtype=np.int32)
+        n_done = np.zeros(self.n_chains, dtype=np.int32)
+        _ffi.check(self._lib.mm_state_download_all(
+            self.handle, _dptr(pos), _dptr(mom), dir_.ctypes.data_as(_ffi.c_int8_p),
+            status.ctypes.data_as(_ffi.c_int32_p), n_done.ctypes.data_as(_ffi.c_int32_p)),
+            self.ctx.handle, "mm_state_download_all")
+        return pos, mom, dir_, status, n_done
+
     def download_status(self):
         status = np.zeros(self.n_chains, dtype=np.int32)
         n_done = np.zeros(self.n_chains, dtype=np.int32)
@@ -188,13 +201,17 @@ class DeviceBatch:
                    self.ctx.handle, "mm_state_device_ptrs")
         return p.value, m.value, d.value
 
-    def close(self):
+    keep = False  # a cached batch ignores close() and is freed with its owner
+
+    def close(self, force=False):
+        if self.keep and not force:
+            return
         if getattr(self, "handle", None) and self.ctx.handle:
             self._lib.mm_state_free(self.handle)
         self.handle = None
 
     def __del__(self):
         try:
-            self.close()
+            self.close(force=True)
         except Exception:
             pass

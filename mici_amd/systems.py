@@ -35,6 +35,7 @@ class System:
         self.target = neg_log_dens
         self.dim = neg_log_dens.dim
         self._device = {}
+        self._one = {}  # cached single-chain DeviceBatch per context (h / dh_dmom / sample_momentum of one state)
 
     # ---- description -> device model --------------------------------------------------------
     def _model_args(self):
@@ -50,13 +51,14 @@ class System:
     def __getstate__(self):
         d = self.__dict__.copy()
         d["_device"] = {}  # device handles are re-created lazily after unpickling
+        d["_one"] = {}
         return d
 
     def __deepcopy__(self, memo):
         import copy
         new = object.__new__(type(self))
         for k, v in self.__dict__.items():
-            new.__dict__[k] = {} if k == "_device" else copy.deepcopy(v, memo)
+            new.__dict__[k] = {} if k in ("_device", "_one") else copy.deepcopy(v, memo)
         return new
 
     # ---- batched quantities ---------------------------------------------------------------------
@@ -65,7 +67,13 @@ class System:
         pos = np.ascontiguousarray(pos, dtype=np.float64)
         if pos.ndim != 2 or pos.shape[1] != self.dim:
             raise ValueError(f"pos must have shape [N, {self.dim}]")
-        batch = DeviceBatch(ctx, pos.shape[0], self.dim)
+        if pos.shape[0] == 1:  # the single-state calls of mici.transitions: keep the device buffers
+            batch = self._one.get(id(ctx))
+            if batch is None or batch.handle is None:
+                batch = self._one[id(ctx)] = DeviceBatch(ctx, 1, self.dim)
+                batch.keep = True  # close() is a no-op; the buffers go when the system does
+        else:
+            batch = DeviceBatch(ctx, pos.shape[0], self.dim)
         batch.upload(pos, mom, None)
         return ctx, batch
 
