@@ -180,6 +180,11 @@ int mm_model_destroy(mm_model* model);
 
 /* ---- chain state: batched ChainState(pos, mom, dir) (states.py:160-305) ---------------------------- */
 int mm_state_alloc(mm_ctx* ctx, int64_t n_chains, int32_t dim, mm_state** out);
+/* As mm_state_alloc, with pos / mom / dir / status / n_done in pinned host memory that the kernels access in
+ * place: upload and download become plain host copies around a stream synchronisation.  For small, long-lived
+ * batches (n * dim <= 65536) -- the reused single-state buffer behind Integrator.step (integrators.py:63-80);
+ * allocation itself is slow. */
+int mm_state_alloc_mapped(mm_ctx* ctx, int64_t n_chains, int32_t dim, mm_state** out);
 int mm_state_free(mm_state* state);
 int mm_state_upload(mm_state* state, const double* pos, const double* mom, const int8_t* dir);
 int mm_state_download(mm_state* state, double* pos, double* mom, int8_t* dir);

@@ -89,6 +89,7 @@ SIGNATURES = {
     "mm_model_create": (C.c_int, [_VP, C.POINTER(ModelDesc), C.POINTER(_VP)]),
     "mm_model_destroy": (C.c_int, [_VP]),
     "mm_state_alloc": (C.c_int, [_VP, C.c_int64, C.c_int32, C.POINTER(_VP)]),
+    "mm_state_alloc_mapped": (C.c_int, [_VP, C.c_int64, C.c_int32, C.POINTER(_VP)]),
     "mm_state_free": (C.c_int, [_VP]),
     "mm_state_upload": (C.c_int, [_VP, c_double_p, c_double_p, c_int8_p]),
     "mm_state_download": (C.c_int, [_VP, c_double_p, c_double_p, c_int8_p]),

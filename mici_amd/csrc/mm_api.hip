@@ -405,7 +405,19 @@ int mm_model_destroy(mm_model* m) {
 }
 
 // ---- state ---------------------------------------------------------------------------------------------
+static int state_alloc(mm_ctx* ctx, int64_t n, int32_t dim, bool mapped, mm_state** out);
+
 int mm_state_alloc(mm_ctx* ctx, int64_t n, int32_t dim, mm_state** out) {
+  return state_alloc(ctx, n, dim, false, out);
+}
+
+int mm_state_alloc_mapped(mm_ctx* ctx, int64_t n, int32_t dim, mm_state** out) {
+  MM_REQUIRE(ctx, ctx == nullptr || (n >= 0 && (size_t)n * (size_t)(dim > 0 ? dim : 1) <= 65536),
+             "mm_state_alloc_mapped: meant for small, long-lived batches (n * dim <= 65536)");
+  return state_alloc(ctx, n, dim, true, out);
+}
+
+static int state_alloc(mm_ctx* ctx, int64_t n, int32_t dim, bool mapped, mm_state** out) {
   MM_REQUIRE(nullptr, ctx != nullptr, "mm_state_alloc: ctx is NULL");
   MM_REQUIRE(ctx, out != nullptr, "mm_state_alloc: out is NULL");
   *out = nullptr;
@@ -423,7 +435,9 @@ int mm_state_alloc(mm_ctx* ctx, int64_t n, int32_t dim, mm_state** out) {
   s->off_status = s->off_dir + up(n1);
   s->off_n_done = s->off_status + up(n1 * sizeof(int32_t));
   s->block_bytes = s->off_n_done + up(n1 * sizeof(int32_t));
-  bool ok = hipMalloc(&s->d_block, s->block_bytes) == hipSuccess &&
+  s->mapped = mapped;
+  bool ok = (mapped ? hipHostMalloc(reinterpret_cast<void**>(&s->d_block), s->block_bytes, hipHostMallocDefault)
+                    : hipMalloc(&s->d_block, s->block_bytes)) == hipSuccess &&
             hipMalloc(&s->d_scratch, nd * sizeof(double)) == hipSuccess;
   if (ok) {
     s->d_pos = reinterpret_cast<double*>(s->d_block);
@@ -431,16 +445,22 @@ int mm_state_alloc(mm_ctx* ctx, int64_t n, int32_t dim, mm_state** out) {
     s->d_dir = reinterpret_cast<int8_t*>(s->d_block + s->off_dir);
     s->d_status = reinterpret_cast<int32_t*>(s->d_block + s->off_status);
     s->d_n_done = reinterpret_cast<int32_t*>(s->d_block + s->off_n_done);
-    if (s->block_bytes <= kStageLimit) s->h_stage = ctx->h_stage;  // every use drains the stream first
+    if (!mapped && s->block_bytes <= kStageLimit) s->h_stage = ctx->h_stage;  // every use drains the stream first
   }
   if (!ok) {
     mm_state_free(s);
     mm_set_error(ctx, "mm_state_alloc: hipMalloc failed");
     return MM_ERR_NOMEM;
   }
-  (void)hipMemsetAsync(s->d_status, 0, n1 * sizeof(int32_t), ctx->stream);
-  (void)hipMemsetAsync(s->d_n_done, 0, n1 * sizeof(int32_t), ctx->stream);
-  (void)hipMemsetAsync(s->d_dir, 1, n1, ctx->stream);
+  if (mapped) {
+    std::memset(s->d_status, 0, n1 * sizeof(int32_t));
+    std::memset(s->d_n_done, 0, n1 * sizeof(int32_t));
+    std::memset(s->d_dir, 1, n1);
+  } else {
+    (void)hipMemsetAsync(s->d_status, 0, n1 * sizeof(int32_t), ctx->stream);
+    (void)hipMemsetAsync(s->d_n_done, 0, n1 * sizeof(int32_t), ctx->stream);
+    (void)hipMemsetAsync(s->d_dir, 1, n1, ctx->stream);
+  }
   *out = s;
   return MM_OK;
 }
@@ -449,7 +469,8 @@ int mm_state_free(mm_state* s) {
   if (!s) return MM_OK;
   (void)hipSetDevice(s->ctx->device);
   (void)hipStreamSynchronize(s->ctx->stream);
-  (void)hipFree(s->d_block);
+  if (s->mapped) (void)hipHostFree(s->d_block);
+  else (void)hipFree(s->d_block);
   (void)hipFree(s->d_scratch);
   (void)hipFree(s->d_work);
   (void)hipFree(s->d_tr);
@@ -467,6 +488,14 @@ int mm_state_upload(mm_state* s, const double* pos, const double* mom, const int
   if (dir)
     for (int64_t i = 0; i < s->n; ++i)
       MM_REQUIRE(ctx, dir[i] == 1 || dir[i] == -1, "mm_state_upload: dir entries must be +1 or -1");
+  if (s->mapped) {
+    // the kernels read this memory in place: wait for whatever still uses it, then plain stores
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (pos) std::memcpy(s->d_pos, pos, nd * sizeof(double));
+    if (mom) std::memcpy(s->d_mom, mom, nd * sizeof(double));
+    if (dir) std::memcpy(s->d_dir, dir, (size_t)s->n);
+    return MM_OK;
+  }
   if (s->h_stage && pos && mom && dir) {
     // one copy: the caller's buffers are consumed here (into the pinned mirror), so nothing has to be waited
     // for; the stream is drained first because an earlier transfer may still be reading the mirror
@@ -501,11 +530,20 @@ int mm_state_download_all(mm_state* s, double* pos, double* mom, int8_t* dir, in
   MM_REQUIRE(nullptr, s != nullptr, "mm_state_download_all: state is NULL");
   mm_ctx* ctx = s->ctx;
   if (s->n == 0) return MM_OK;
+  const size_t nd = (size_t)s->n * s->dim;
+  if (s->mapped) {
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (pos) std::memcpy(pos, s->d_pos, nd * sizeof(double));
+    if (mom) std::memcpy(mom, s->d_mom, nd * sizeof(double));
+    if (dir) std::memcpy(dir, s->d_dir, (size_t)s->n);
+    if (status) std::memcpy(status, s->d_status, (size_t)s->n * sizeof(int32_t));
+    if (n_done) std::memcpy(n_done, s->d_n_done, (size_t)s->n * sizeof(int32_t));
+    return MM_OK;
+  }
   if (!s->h_stage) {
     int rc = mm_state_download(s, pos, mom, dir);
     return rc != MM_OK ? rc : mm_state_download_status(s, status, n_done);
   }
-  const size_t nd = (size_t)s->n * s->dim;
   MM_HIP_CHECK(ctx, hipMemcpyAsync(s->h_stage, s->d_block, s->block_bytes, hipMemcpyDeviceToHost, ctx->stream));
   MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (pos) std::memcpy(pos, s->h_stage, nd * sizeof(double));

@@ -70,6 +70,7 @@ struct mm_state {
   char* d_block = nullptr;
   char* h_stage = nullptr;  // the context's pinned staging buffer, nullptr for batches above kStageLimit
   size_t block_bytes = 0, off_mom = 0, off_dir = 0, off_status = 0, off_n_done = 0;
+  bool mapped = false;  // d_block is pinned host memory the kernels access in place (mm_state_alloc_mapped)
   double* d_scratch = nullptr;  // [N] or [N*D] doubles for h / dh_dmom / z
   size_t scratch_elems = 0;
   void* d_work = nullptr;  // per-chain workspace of the large-D implicit path

@@ -93,7 +93,7 @@ class Integrator:
         pos = np.ascontiguousarray(state.pos, dtype=np.float64)
         batch = self._one.get(id(ctx))
         if batch is None or batch.handle is None or batch.dim != pos.shape[0]:
-            batch = self._one[id(ctx)] = DeviceBatch(ctx, 1, pos.shape[0])
+            batch = self._one[id(ctx)] = DeviceBatch(ctx, 1, pos.shape[0], mapped=True)
         batch.upload(pos[None], np.asarray(state.mom, dtype=np.float64)[None], [int(state.dir)])
         self.step_device(batch, 1, ctx)
         q, p, _, status, _ = batch.download_all()  # one transfer each way for a single state

@@ -122,12 +122,14 @@ class DeviceModel:
 class DeviceBatch:
     """N chains resident in HBM: pos[N,D], mom[N,D] (fp64, row-major), dir[N] (int8)."""
 
-    def __init__(self, ctx, n_chains, dim):
+    def __init__(self, ctx, n_chains, dim, mapped=False):
+        """``mapped``: keep the chain state in pinned host memory the kernels access in place (small, long-lived
+        batches: the reused single-state buffers behind ``Integrator.step`` / ``System.h``)."""
         self.ctx = ctx
         self._lib = ctx._lib
         h = C.c_void_p()
-        _ffi.check(self._lib.mm_state_alloc(ctx.handle, int(n_chains), int(dim), C.byref(h)),
-                   ctx.handle, "mm_state_alloc")
+        alloc = self._lib.mm_state_alloc_mapped if mapped else self._lib.mm_state_alloc
+        _ffi.check(alloc(ctx.handle, int(n_chains), int(dim), C.byref(h)), ctx.handle, "mm_state_alloc")
         self.handle = h
         self.n_chains = int(n_chains)
         self.dim = int(dim)

@@ -70,7 +70,7 @@ class System:
         if pos.shape[0] == 1:  # the single-state calls of mici.transitions: keep the device buffers
             batch = self._one.get(id(ctx))
             if batch is None or batch.handle is None:
-                batch = self._one[id(ctx)] = DeviceBatch(ctx, 1, self.dim)
+                batch = self._one[id(ctx)] = DeviceBatch(ctx, 1, self.dim, mapped=True)
                 batch.keep = True  # close() is a no-op; the buffers go when the system does
         else:
             batch = DeviceBatch(ctx, pos.shape[0], self.dim)
