@@ -202,6 +202,11 @@ int mm_state_device_ptrs(mm_state* state, double** pos, double** mom, int8_t** d
  * step_size argument of every integrator entry point for this state, i.e. pass step_size = 1 and the step
  * sizes as scale.  NULL removes the factors.  mm_state_copy propagates them. */
 int mm_state_set_step_scale(mm_state* state, const double* scale);
+/* Per-chain trajectory lengths: with steps[N] set, every integrator call on this state advances chain i by
+ * min(n_steps, steps[i]) steps (n_done reports it); NULL removes them.  This is how one launch serves
+ * MetropolisRandomIntegrationTransition, which draws n_step per chain and per transition
+ * (transitions.py:355-402). */
+int mm_state_set_chain_steps(mm_state* s, const int32_t* steps);
 
 /* device-to-device copy of pos, mom, dir, status, n_done (same n_chains and dim): the proposal copy of
  * Integrator.step / state.copy() (integrators.py:78, states.py:263-279) without a host round trip */

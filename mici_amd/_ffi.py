@@ -99,6 +99,7 @@ SIGNATURES = {
     "mm_momentum_refresh": (C.c_int, [_VP, _VP, _VP, c_double_p, C.c_double]),
     "mm_state_copy": (C.c_int, [_VP, _VP]),
     "mm_state_set_step_scale": (C.c_int, [_VP, c_double_p]),
+    "mm_state_set_chain_steps": (C.c_int, [_VP, c_int32_p]),
     "mm_metropolis_accept": (C.c_int, [_VP, _VP, _VP, _VP, c_double_p, c_double_p, c_int8_p]),
     "mm_leapfrog_euclid": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int32]),
     "mm_composition_euclid": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int32, C.c_int32, c_double_p, C.c_int32]),

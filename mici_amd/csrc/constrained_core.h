@@ -17,6 +17,7 @@ struct ConArgs {
   double* mom;
   const int8_t* dir;
   const double* step_scale;
+  const int32_t* chain_steps;
   int32_t* status;
   int32_t* n_done;
   int64_t n_chains;
@@ -783,7 +784,8 @@ __global__ __launch_bounds__(256) void constrained_leapfrog_kernel(ConArgs A) {
   if (!dh1_dpos<C, D>(A, q, &g)) status = MM_ST_LINALG;
   Jac<C, D> jac = constr_jacob<C, D>(A, q);
   ++n_grad;
-  for (int s = 0; s < A.n_steps && status == MM_ST_OK; ++s) {
+  const int my_steps = mmdev::chain_steps(A.chain_steps, chain, A.n_steps);
+  for (int s = 0; s < my_steps && status == MM_ST_OK; ++s) {
     Vec<D> qs = q, ps = p;
     Jac<C, D> js = jac;
     // ---- A(t/2): h1_flow then cotangent projection                    integrators.py:947-949
@@ -884,6 +886,7 @@ inline ConArgs make_args(const mm_model* m, mm_state* s) {
   a.mom = s->d_mom;
   a.dir = s->d_dir;
   a.step_scale = s->d_step_scale;
+  a.chain_steps = s->d_chain_steps;
   a.status = s->d_status;
   a.n_done = s->d_n_done;
   a.n_chains = s->n;

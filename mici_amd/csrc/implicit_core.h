@@ -27,6 +27,7 @@ struct ImplicitArgs {
   double* mom;
   const int8_t* dir;
   const double* step_scale;  // per-chain step-size factors or nullptr
+  const int32_t* chain_steps;  // per-chain step counts or nullptr
   int32_t* status;
   int32_t* n_done;
   int64_t n_chains;

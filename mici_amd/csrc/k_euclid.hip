@@ -43,7 +43,8 @@ __device__ __forceinline__ double elem_grad(double q, double tp0, double tp1) {
 template <int TARGET, int METRIC, int VEC, bool COMP>
 __device__ __forceinline__ void leapfrog_elem_body(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int64_t n_chains, int dim,
+    double step_size, int n_steps,
     const double* __restrict__ tparams,
     const double* __restrict__ minv_diag, const mm_comp_coefs& cf) {
   const int vec_per_chain = dim / VEC;
@@ -54,6 +55,7 @@ __device__ __forceinline__ void leapfrog_elem_body(
     const int d0 = (int)(idx - chain * vec_per_chain) * VEC;
     const double t = mmdev::signed_step(dir, step_scale, chain, step_size);
     const double ht = 0.5 * t;
+    const int my_steps = mmdev::chain_steps(chain_steps, chain, n_steps);
     double q[VEC], p[VEC], g[VEC], tp0[VEC], tp1[VEC], mi[VEC];
     const int64_t off = chain * dim + d0;
     if constexpr (VEC == 2) {
@@ -71,34 +73,40 @@ __device__ __forceinline__ void leapfrog_elem_body(
       mi[v] = (METRIC == M_DIAG) ? minv_diag[d0 + v] : 1.0;
       g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
     }
-    if constexpr (!COMP) {
-      for (int s = 0; s < n_steps; ++s) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          p[v] -= ht * g[v];
-          if constexpr (METRIC == M_DIAG) q[v] += t * (mi[v] * p[v]);
-          else q[v] += t * p[v];
-          g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
-          p[v] -= ht * g[v];
-        }
-      }
-    } else {
-      for (int s = 0; s < n_steps; ++s)
-        for (int k = 0; k < cf.m; ++k) {
-          const double ct = cf.c[k] * t;
-          const bool kick = ((k & 1) == 0) == (cf.initial_h1 != 0);
+    auto run = [&](const int steps) {
+      if constexpr (!COMP) {
+        for (int s = 0; s < steps; ++s) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            if (kick) {
-              p[v] -= ct * g[v];
-            } else {
-              if constexpr (METRIC == M_DIAG) q[v] += ct * (mi[v] * p[v]);
-              else q[v] += ct * p[v];
-              g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
-            }
+            p[v] -= ht * g[v];
+            if constexpr (METRIC == M_DIAG) q[v] += t * (mi[v] * p[v]);
+            else q[v] += t * p[v];
+            g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
+            p[v] -= ht * g[v];
           }
         }
-    }
+      } else {
+        for (int s = 0; s < steps; ++s)
+          for (int k = 0; k < cf.m; ++k) {
+            const double ct = cf.c[k] * t;
+            const bool kick = ((k & 1) == 0) == (cf.initial_h1 != 0);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              if (kick) {
+                p[v] -= ct * g[v];
+              } else {
+                if constexpr (METRIC == M_DIAG) q[v] += ct * (mi[v] * p[v]);
+                else q[v] += ct * p[v];
+                g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
+              }
+            }
+          }
+      }
+    };
+    // two instances on purpose: with a uniform trip count the loop runs on scalar control flow (a per-lane
+    // count cost 30 % on the c2(i) workload)
+    if (chain_steps == nullptr) run(n_steps);
+    else run(my_steps);
     if constexpr (VEC == 2) {
       *reinterpret_cast<double2*>(pos + off) = make_double2(q[0], q[1]);
       *reinterpret_cast<double2*>(mom + off) = make_double2(p[0], p[1]);
@@ -111,18 +119,20 @@ __device__ __forceinline__ void leapfrog_elem_body(
 template <int TARGET, int METRIC, int VEC>
 __global__ __launch_bounds__(256) void leapfrog_elem_kernel(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int64_t n_chains, int dim,
+    double step_size, int n_steps,
     const double* __restrict__ tparams, const double* __restrict__ minv_diag) {
-  leapfrog_elem_body<TARGET, METRIC, VEC, false>(pos, mom, dir, step_scale, n_chains, dim, step_size, n_steps,
+  leapfrog_elem_body<TARGET, METRIC, VEC, false>(pos, mom, dir, step_scale, chain_steps, n_chains, dim, step_size, n_steps,
                                                  tparams, minv_diag, mm_comp_coefs{});
 }
 
 template <int TARGET, int METRIC, int VEC>
 __global__ __launch_bounds__(256) void composition_elem_kernel(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int64_t n_chains, int dim,
+    double step_size, int n_steps,
     const double* __restrict__ tparams, const double* __restrict__ minv_diag, mm_comp_coefs cf) {
-  leapfrog_elem_body<TARGET, METRIC, VEC, true>(pos, mom, dir, step_scale, n_chains, dim, step_size, n_steps,
+  leapfrog_elem_body<TARGET, METRIC, VEC, true>(pos, mom, dir, step_scale, chain_steps, n_chains, dim, step_size, n_steps,
                                                 tparams, minv_diag, cf);
 }
 
@@ -183,7 +193,8 @@ __device__ __forceinline__ void tile_times_slabs(const double* __restrict__ tile
 template <int DP, int CT, int TARGET, int METRIC, bool COMP>
 __device__ __forceinline__ void leapfrog_mfma_body(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int64_t n_chains, int dim,
+    double step_size, int n_steps,
     const double* __restrict__ tparams,
     const double* __restrict__ minv, const mm_comp_coefs& cf) {
   using Cfg = MfmaCfg<DP, CT>;
@@ -220,11 +231,14 @@ __device__ __forceinline__ void leapfrog_mfma_body(
   // chain state in the C layout: q[c][r], p[c][r] <-> chain (lane>>4)+4r, column col[c]
   double q[CT][4], p[CT][4], g[CT][4], t[4], ht[4];
   bool live[CT][4];
+  int my_steps[4];  // per-chain step counts: a chain that is done has its time step zeroed, so the rest of the
+                    // workgroup's steps leave it exactly where it is
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t chain = chain0 + (lane >> 4) + 4 * r;
     t[r] = (chain < n_chains) ? mmdev::signed_step(dir, step_scale, chain, step_size) : 0.0;
     ht[r] = 0.5 * t[r];
+    my_steps[r] = (chain < n_chains) ? mmdev::chain_steps(chain_steps, chain, n_steps) : 0;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       live[c][r] = chain < n_chains && col[c] < dim;
@@ -282,8 +296,19 @@ __device__ __forceinline__ void leapfrog_mfma_body(
   };
 
   gradient(1);  // g(q0); uses buffer 1 so that step 0 starts on buffer 0
+  auto retire = [&](int s) {  // uniform branch: free when the state has no per-chain counts
+    if (chain_steps) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (s >= my_steps[r]) {
+          t[r] = 0.0;
+          ht[r] = 0.0;
+        }
+    }
+  };
   if constexpr (!COMP) {
     for (int s = 0; s < n_steps; ++s) {
+      retire(s);
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -299,7 +324,8 @@ __device__ __forceinline__ void leapfrog_mfma_body(
     // SymmetricCompositionIntegrator._step (integrators.py:272-274); nd counts the h2 flows done so far and
     // selects the LDS buffer, so consecutive products never share a tile
     int nd = 0;
-    for (int s = 0; s < n_steps; ++s)
+    for (int s = 0; s < n_steps; ++s) {
+      retire(s);
       for (int k = 0; k < cf.m; ++k) {
         double ct[4];
 #pragma unroll
@@ -315,6 +341,7 @@ __device__ __forceinline__ void leapfrog_mfma_body(
           ++nd;
         }
       }
+    }
   }
 
 #pragma unroll
@@ -332,18 +359,20 @@ __device__ __forceinline__ void leapfrog_mfma_body(
 template <int DP, int CT, int TARGET, int METRIC>
 __global__ __launch_bounds__(DP * 4 / CT) void leapfrog_mfma_kernel(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int64_t n_chains, int dim,
+    double step_size, int n_steps,
     const double* __restrict__ tparams, const double* __restrict__ minv) {
-  leapfrog_mfma_body<DP, CT, TARGET, METRIC, false>(pos, mom, dir, step_scale, n_chains, dim, step_size, n_steps,
+  leapfrog_mfma_body<DP, CT, TARGET, METRIC, false>(pos, mom, dir, step_scale, chain_steps, n_chains, dim, step_size, n_steps,
                                                     tparams, minv, mm_comp_coefs{});
 }
 
 template <int DP, int CT, int TARGET, int METRIC>
 __global__ __launch_bounds__(DP * 4 / CT) void composition_mfma_kernel(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    const double* __restrict__ step_scale, int64_t n_chains, int dim, double step_size, int n_steps,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int64_t n_chains, int dim,
+    double step_size, int n_steps,
     const double* __restrict__ tparams, const double* __restrict__ minv, mm_comp_coefs cf) {
-  leapfrog_mfma_body<DP, CT, TARGET, METRIC, true>(pos, mom, dir, step_scale, n_chains, dim, step_size, n_steps,
+  leapfrog_mfma_body<DP, CT, TARGET, METRIC, true>(pos, mom, dir, step_scale, chain_steps, n_chains, dim, step_size, n_steps,
                                                    tparams, minv, cf);
 }
 
@@ -358,19 +387,19 @@ int launch_elem(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_ste
   if (blocks < 1) blocks = 1;
   if (cf && vec2)
     hipLaunchKernelGGL((composition_elem_kernel<TARGET, METRIC, 2>), dim3((unsigned)blocks), dim3(256),
-                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, dim, h, n_steps,
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, dim, h, n_steps,
                        m->d_target_params, m->d_metric_inv, *cf);
   else if (cf)
     hipLaunchKernelGGL((composition_elem_kernel<TARGET, METRIC, 1>), dim3((unsigned)blocks), dim3(256),
-                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, dim, h, n_steps,
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, dim, h, n_steps,
                        m->d_target_params, m->d_metric_inv, *cf);
   else if (vec2)
     hipLaunchKernelGGL((leapfrog_elem_kernel<TARGET, METRIC, 2>), dim3((unsigned)blocks), dim3(256),
-                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, dim, h, n_steps,
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, dim, h, n_steps,
                        m->d_target_params, m->d_metric_inv);
   else
     hipLaunchKernelGGL((leapfrog_elem_kernel<TARGET, METRIC, 1>), dim3((unsigned)blocks), dim3(256),
-                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, dim, h, n_steps,
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, dim, h, n_steps,
                        m->d_target_params, m->d_metric_inv);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
@@ -381,11 +410,11 @@ int launch_mfma_dp(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_
   const unsigned blocks = (unsigned)((s->n + 15) / 16);
   if (cf)
     hipLaunchKernelGGL((composition_mfma_kernel<DP, CT, TARGET, METRIC>), dim3(blocks),
-                       dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, s->dim,
+                       dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, s->dim,
                        h, n_steps, m->d_target_params, m->d_metric_inv, *cf);
   else
   hipLaunchKernelGGL((leapfrog_mfma_kernel<DP, CT, TARGET, METRIC>), dim3(blocks),
-                     dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, s->dim, h,
+                     dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, s->dim, h,
                      n_steps, m->d_target_params, m->d_metric_inv);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_leapfrog_kernel(Implicit
   bk.tparams = A.tparams;
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
-  const ChainResult r = implicit_leapfrog_chain(bk, t, A.n_steps, A.opts);
+  const ChainResult r = implicit_leapfrog_chain(bk, t, mmdev::chain_steps(A.chain_steps, chain, A.n_steps), A.opts);
   q = bk.slot(SL_Q);
   p = bk.slot(SL_P);
 
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_midpoint_kernel(Implicit
   bk.slot(MP_Q) = act ? A.pos[chain * dim + lane] : 0.0;
   bk.slot(MP_P) = act ? A.mom[chain * dim + lane] : 0.0;
   const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
-  const ChainResult r = implicit_midpoint_chain(bk, t, A.n_steps, A.opts);
+  const ChainResult r = implicit_midpoint_chain(bk, t, mmdev::chain_steps(A.chain_steps, chain, A.n_steps), A.opts);
   if (act) {  // a failed step leaves the last completed state
     A.pos[chain * dim + lane] = bk.slot(MP_Q);
     A.mom[chain * dim + lane] = bk.slot(MP_P);
@@ -582,6 +582,7 @@ ImplicitArgs make_args(const mm_model* m, mm_state* s) {
   a.mom = s->d_mom;
   a.dir = s->d_dir;
   a.step_scale = s->d_step_scale;
+  a.chain_steps = s->d_chain_steps;
   a.status = s->d_status;
   a.n_done = s->d_n_done;
   a.n_chains = s->n;

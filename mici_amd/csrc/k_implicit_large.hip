@@ -518,7 +518,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void implicit_team_kernel(ImplicitA
   const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
-  const ChainResult r = implicit_leapfrog_chain(bk, t, A.n_steps, A.opts);
+  const ChainResult r = implicit_leapfrog_chain(bk, t, mmdev::chain_steps(A.chain_steps, chain, A.n_steps), A.opts);
   q = bk.slot(SL_Q);
   p = bk.slot(SL_P);
   if (act) {
@@ -570,6 +570,7 @@ ImplicitArgs make_args(const mm_model* m, mm_state* s) {
   a.mom = s->d_mom;
   a.dir = s->d_dir;
   a.step_scale = s->d_step_scale;
+  a.chain_steps = s->d_chain_steps;
   a.status = s->d_status;
   a.n_done = s->d_n_done;
   a.n_chains = s->n;

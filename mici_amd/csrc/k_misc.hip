@@ -11,6 +11,10 @@ namespace {
 
 using namespace mmdev;
 
+__device__ __forceinline__ int chain_steps_of(const int32_t* cs, int64_t chain, int n_steps) {
+  return mmdev::chain_steps(cs, chain, n_steps);  // (a kernel parameter of the same name shadows the function)
+}
+
 struct EuclidModelView {
   int target, metric_kind, dim;
   const double* tparams;
@@ -85,7 +89,8 @@ __device__ __forceinline__ void gaussian_h2_flow(const EuclidModelView& m, doubl
 // dynamic LDS: per wave 3*dim doubles (q, p, scratch), 4*dim for the Gaussian split
 __global__ void leapfrog_generic_kernel(EuclidModelView m, double* __restrict__ pos,
                                         double* __restrict__ mom, const int8_t* __restrict__ dir,
-                                        const double* __restrict__ step_scale, int64_t n_chains,
+                                        const double* __restrict__ step_scale,
+                                        const int32_t* __restrict__ chain_steps, int64_t n_chains,
                                         double step_size, int n_steps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -101,6 +106,7 @@ __global__ void leapfrog_generic_kernel(EuclidModelView m, double* __restrict__ 
     p[i] = mom[chain * dim + i];
   }
   const double t = signed_step(dir, step_scale, chain, step_size), ht = 0.5 * t;
+  n_steps = chain_steps_of(chain_steps, chain, n_steps);
   wave_sync();
   TargetAux aux = target_prepare(m.target, q, dim, m.tparams, lane);
   for (int i = lane; i < dim; i += 64) g[i] = target_grad_elem(m.target, aux, q, i, dim, m.tparams);
@@ -136,7 +142,8 @@ using CompCoefs = mm_comp_coefs;
 
 __global__ void composition_generic_kernel(EuclidModelView m, double* __restrict__ pos,
                                            double* __restrict__ mom, const int8_t* __restrict__ dir,
-                                           const double* __restrict__ step_scale, int64_t n_chains,
+                                           const double* __restrict__ step_scale,
+                                           const int32_t* __restrict__ chain_steps, int64_t n_chains,
                                            double step_size, int n_steps, CompCoefs cf) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,6 +159,7 @@ __global__ void composition_generic_kernel(EuclidModelView m, double* __restrict
     p[i] = mom[chain * dim + i];
   }
   const double t = signed_step(dir, step_scale, chain, step_size);
+  n_steps = chain_steps_of(chain_steps, chain, n_steps);
   wave_sync();
   TargetAux aux = target_prepare(m.target, q, dim, m.tparams, lane);
   for (int i = lane; i < dim; i += 64) g[i] = target_grad_elem(m.target, aux, q, i, dim, m.tparams);
@@ -250,7 +258,7 @@ int mm_launch_leapfrog_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, doub
   }
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
   hipLaunchKernelGGL(leapfrog_generic_kernel, dim3(blocks), dim3(64 * w), lds, ctx->stream,
-                     view_of(m), s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, h, n_steps);
+                     view_of(m), s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, h, n_steps);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }
@@ -269,7 +277,7 @@ int mm_launch_composition_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, d
   for (int i = 0; i < n_coeffs; ++i) cf.c[i] = coeffs[i];
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
   hipLaunchKernelGGL(composition_generic_kernel, dim3(blocks), dim3(64 * w), lds, ctx->stream, view_of(m),
-                     s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->n, h, n_steps, cf);
+                     s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, h, n_steps, cf);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }
@@ -353,6 +361,7 @@ __device__ __forceinline__ int midpoint_solve(const EuclidModelView& m, const Mi
 
 __global__ void midpoint_euclid_kernel(EuclidModelView m, double* __restrict__ pos, double* __restrict__ mom,
                                        const int8_t* __restrict__ dir, const double* __restrict__ step_scale,
+                                       const int32_t* __restrict__ chain_steps,
                                        int32_t* __restrict__ status, int32_t* __restrict__ n_done,
                                        int64_t n_chains, double step_size,
                                        int n_steps, mm_fp_opts o, mm_counters* counters) {
@@ -370,6 +379,7 @@ __global__ void midpoint_euclid_kernel(EuclidModelView m, double* __restrict__ p
   }
   wave_sync();
   const double half = 0.5 * signed_step(dir, step_scale, chain, step_size);
+  n_steps = chain_steps_of(chain_steps, chain, n_steps);
   int st = MM_ST_OK, done = 0;
   long long n_evals = 0, n_solves = 0, n_grad = 0;
   for (int s = 0; s < n_steps; ++s) {
@@ -451,24 +461,26 @@ int mm_launch_implicit_midpoint_euclid(mm_ctx* ctx, const mm_model* m, mm_state*
   w = w > 4 ? 4 : (w < 1 ? 1 : w);
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
   hipLaunchKernelGGL(midpoint_euclid_kernel, dim3(blocks), dim3(64 * w), w * per_wave, ctx->stream, view_of(m),
-                     s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_status, s->d_n_done, s->n, h, n_steps, opts,
+                     s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done, s->n, h,
+                     n_steps, opts,
                      d_counters);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }
 
-__global__ void fill_done_kernel(int32_t* __restrict__ status, int32_t* __restrict__ n_done, int64_t n, int32_t n_steps) {
+__global__ void fill_done_kernel(int32_t* __restrict__ status, int32_t* __restrict__ n_done,
+                                 const int32_t* __restrict__ chain_steps, int64_t n, int32_t n_steps) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) {
     status[i] = 0;
-    n_done[i] = n_steps;
+    n_done[i] = chain_steps_of(chain_steps, i, n_steps);
   }
 }
 
 int mm_launch_fill_done(mm_ctx* ctx, mm_state* s, int32_t n_steps) {
   if (s->n == 0) return MM_OK;
   hipLaunchKernelGGL(fill_done_kernel, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, ctx->stream, s->d_status,
-                     s->d_n_done, s->n, n_steps);
+                     s->d_n_done, s->d_chain_steps, s->n, n_steps);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }

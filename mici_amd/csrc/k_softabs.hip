@@ -515,7 +515,7 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
   __syncthreads();
-  const ChainResult r = implicit_leapfrog_chain(bk, t, A.n_steps, A.opts);
+  const ChainResult r = implicit_leapfrog_chain(bk, t, mmdev::chain_steps(A.chain_steps, chain, A.n_steps), A.opts);
   if (act) {
     A.pos[chain * dim + tid] = bk.slot(SL_Q);
     A.mom[chain * dim + tid] = bk.slot(SL_P);
@@ -567,6 +567,7 @@ SaArgs make_args(const mm_model* m, mm_state* s) {
   S.a.mom = s->d_mom;
   S.a.dir = s->d_dir;
   S.a.step_scale = s->d_step_scale;
+  S.a.chain_steps = s->d_chain_steps;
   S.a.status = s->d_status;
   S.a.n_done = s->d_n_done;
   S.a.n_chains = s->n;

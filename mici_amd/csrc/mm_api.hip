@@ -476,6 +476,7 @@ int mm_state_free(mm_state* s) {
   (void)hipFree(s->d_tr);
   (void)hipFree(s->d_mom_save);
   (void)hipFree(s->d_step_scale);
+  (void)hipFree(s->d_chain_steps);
   delete s;
   return MM_OK;
 }
@@ -577,6 +578,14 @@ int mm_state_copy(mm_state* dst, const mm_state* src) {
   MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_dir, src->d_dir, n, hipMemcpyDeviceToDevice, ctx->stream));
   MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_status, src->d_status, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
   MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_n_done, src->d_n_done, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  if (src->d_chain_steps) {  // ... and the same per-chain trajectory lengths
+    if (!dst->d_chain_steps) MM_HIP_CHECK(ctx, hipMalloc(&dst->d_chain_steps, n * sizeof(int32_t)));
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_chain_steps, src->d_chain_steps, n * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+  } else if (dst->d_chain_steps) {
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(dst->d_chain_steps);
+    dst->d_chain_steps = nullptr;
+  }
   if (src->d_step_scale) {  // the copy integrates with the same per-chain step sizes
     if (!dst->d_step_scale) MM_HIP_CHECK(ctx, hipMalloc(&dst->d_step_scale, n * sizeof(double)));
     MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_step_scale, src->d_step_scale, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -585,6 +594,25 @@ int mm_state_copy(mm_state* dst, const mm_state* src) {
     (void)hipFree(dst->d_step_scale);
     dst->d_step_scale = nullptr;
   }
+  return MM_OK;
+}
+
+int mm_state_set_chain_steps(mm_state* s, const int32_t* steps) {
+  MM_REQUIRE(nullptr, s != nullptr, "mm_state_set_chain_steps: state is NULL");
+  mm_ctx* ctx = s->ctx;
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (!steps) {
+    (void)hipFree(s->d_chain_steps);
+    s->d_chain_steps = nullptr;
+    return MM_OK;
+  }
+  if (s->n == 0) return MM_OK;
+  for (int64_t i = 0; i < s->n; ++i)
+    MM_REQUIRE(ctx, steps[i] >= 0, "mm_state_set_chain_steps: counts must be non-negative");
+  if (!s->d_chain_steps) MM_HIP_CHECK(ctx, hipMalloc(&s->d_chain_steps, (size_t)s->n * sizeof(int32_t)));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_chain_steps, steps, (size_t)s->n * sizeof(int32_t), hipMemcpyHostToDevice,
+                                   ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer is only borrowed
   return MM_OK;
 }
 

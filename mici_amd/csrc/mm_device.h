@@ -14,6 +14,15 @@ __device__ __forceinline__ double signed_step(const int8_t* __restrict__ dir, co
   return (double)dir[chain] * (scale ? step_size * scale[chain] : step_size);
 }
 
+// number of steps a chain takes in this call: n_steps, capped by the chain's own count when the state carries
+// per-chain trajectory lengths (mm_state_set_chain_steps: MetropolisRandomIntegrationTransition draws one
+// n_step per chain and transition, transitions.py:355-402)
+__device__ __forceinline__ int chain_steps(const int32_t* __restrict__ cs, int64_t chain, int n_steps) {
+  if (!cs) return n_steps;
+  const int c = cs[chain];
+  return c < 0 ? 0 : (c < n_steps ? c : n_steps);
+}
+
 // Order LDS traffic between the lanes of ONE wave (the wave executes DS instructions in order; this
 // only stops the compiler from moving loads/stores across the exchange point).
 __device__ __forceinline__ void wave_sync() {

@@ -78,6 +78,7 @@ struct mm_state {
   double* d_mom_save = nullptr;  // previous momentum during a correlated refresh (mm_momentum_refresh)
   size_t mom_save_elems = 0;
   double* d_step_scale = nullptr;  // optional per-chain step-size factors (mm_state_set_step_scale)
+  int32_t* d_chain_steps = nullptr;  // optional per-chain step counts (mm_state_set_chain_steps)
   double* d_tr = nullptr;  // transition scratch: u[N], accept_prob[N], accepted[N] (mm_metropolis_accept)
   size_t tr_elems = 0;
 };

@@ -197,6 +197,17 @@ class DeviceBatch:
         _ffi.check(self._lib.mm_state_set_step_scale(self.handle, ptr), self.ctx.handle,
                    "mm_state_set_step_scale")
 
+    def set_chain_steps(self, steps):
+        """Per-chain trajectory lengths [N] (``None`` removes them): an integrator call with ``n_steps`` advances
+        chain i by ``min(n_steps, steps[i])`` steps."""
+        if steps is None:
+            ptr = None
+        else:
+            steps = np.ascontiguousarray(np.broadcast_to(np.asarray(steps, dtype=np.int32), (self.n_chains,)))
+            ptr = steps.ctypes.data_as(_ffi.c_int32_p)
+        _ffi.check(self._lib.mm_state_set_chain_steps(self.handle, ptr), self.ctx.handle,
+                   "mm_state_set_chain_steps")
+
     def device_ptrs(self):
         p, m, d = C.c_void_p(), C.c_void_p(), C.c_void_p()
         _ffi.check(self._lib.mm_state_device_ptrs(self.handle, C.byref(p), C.byref(m), C.byref(d)),

@@ -181,8 +181,10 @@ class MetropolisStaticIntegrationTransition:
 
 class MetropolisRandomIntegrationTransition(MetropolisStaticIntegrationTransition):
     """As the static transition with the number of steps drawn per transition from
-    ``rng.integers(*n_step_range)`` (transitions.py:355-402).  ``sample_batch`` runs every chain of the batch
-    with one common draw (pass ``n_step``); the single-chain ``sample`` draws exactly like the reference."""
+    ``rng.integers(*n_step_range)`` (transitions.py:355-402).  In the reference every chain draws its own
+    ``n_step`` for every transition; ``sample_batch`` does the same in one launch through per-chain trajectory
+    lengths on the device (``mm_state_set_chain_steps``): pass ``n_step`` as an [N] array, a scalar for one
+    common length, or ``rngs`` (one generator per chain, drawn in chain order exactly like ``sample``)."""
 
     def __init__(self, system, integrator, n_step_range):
         n_step_lower, n_step_upper = n_step_range
@@ -195,10 +197,24 @@ class MetropolisRandomIntegrationTransition(MetropolisStaticIntegrationTransitio
         self.n_step = int(rng.integers(*self.n_step_range))
         return super().sample(state, rng)
 
-    def sample_batch(self, batch, u, n_step=None, rng=None, ctx=None):
+    def sample_batch(self, batch, u, n_step=None, rng=None, ctx=None, rngs=None):
         if n_step is None:
-            if rng is None:
-                raise ValueError("pass n_step or an rng to draw it from")
-            n_step = rng.integers(*self.n_step_range)
-        self.n_step = int(n_step)
-        return super().sample_batch(batch, u, ctx)
+            if rngs is not None:
+                n_step = np.array([int(r.integers(*self.n_step_range)) for r in rngs], dtype=np.int32)
+            elif rng is not None:
+                n_step = rng.integers(*self.n_step_range, size=batch.n_chains).astype(np.int32)
+            else:
+                raise ValueError("pass n_step, an rng or one rng per chain to draw it from")
+        n_step = np.asarray(n_step)
+        if n_step.ndim == 0:
+            self.n_step = int(n_step)
+            return super().sample_batch(batch, u, ctx)
+        if n_step.shape != (batch.n_chains,) or np.any(n_step < 1):
+            raise ValueError("n_step must be a positive integer per chain")
+        self.n_step = int(n_step.max())
+        batch.set_chain_steps(n_step)
+        try:
+            return super().sample_batch(batch, u, ctx)
+        finally:
+            batch.set_chain_steps(None)
+            self._proposal_for(batch).set_chain_steps(None)
