@@ -630,6 +630,9 @@ struct AuxFn {
 int mm_launch_softabs_leapfrog(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
                                mm_counters*);
 int mm_launch_softabs_aux(mm_ctx*, const mm_model*, mm_state*, int, double*, const double*);
+int mm_launch_softabs_midpoint(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
+int mm_launch_implicit_midpoint_large(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
+                                      mm_counters*);
 int mm_launch_implicit_large(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
                              mm_counters*);
 int mm_launch_riemann_aux_large(mm_ctx*, const mm_model*, mm_state*, int, double*, const double*);
@@ -667,10 +670,8 @@ int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, dou
 
 int mm_launch_implicit_midpoint_riemann(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
                                         const mm_fp_opts& opts, mm_counters* d_counters) {
-  if (m->rmetric == MM_RMETRIC_SOFTABS || m->dim > 64) {
-    mm_set_error(ctx, "mm_implicit_midpoint: Riemannian systems are supported for the dense metrics, dim <= 64");
-    return MM_ERR_UNSUPPORTED;
-  }
+  if (m->rmetric == MM_RMETRIC_SOFTABS) return mm_launch_softabs_midpoint(ctx, m, s, h, n_steps, opts, d_counters);
+  if (m->dim > 64) return mm_launch_implicit_midpoint_large(ctx, m, s, h, n_steps, opts, d_counters);
   ImplicitArgs a = make_args(m, s);
   a.step_size = h;
   a.n_steps = n_steps;

@@ -505,7 +505,8 @@ __device__ __forceinline__ void init_backend(BlockBackend<C, RMETRIC>& bk, const
   bk.tparams = A.tparams;
 }
 
-template <class C, int RMETRIC>
+// MIDPOINT: ImplicitMidpointIntegrator (integrators.py:547-681) on the same backend and slot storage
+template <class C, int RMETRIC, bool MIDPOINT>
 __global__ __launch_bounds__(C::NT, C::MINW) void implicit_team_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int64_t chain = blockIdx.x;
@@ -518,7 +519,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void implicit_team_kernel(ImplicitA
   const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
-  const ChainResult r = implicit_leapfrog_chain(bk, t, mmdev::chain_steps(A.chain_steps, chain, A.n_steps), A.opts);
+  const int my_steps = mmdev::chain_steps(A.chain_steps, chain, A.n_steps);
+  const ChainResult r = MIDPOINT ? implicit_midpoint_chain(bk, t, my_steps, A.opts)
+                                 : implicit_leapfrog_chain(bk, t, my_steps, A.opts);
   q = bk.slot(SL_Q);
   p = bk.slot(SL_P);
   if (act) {
@@ -592,9 +595,13 @@ int launch(mm_ctx* ctx, K kernel, const ImplicitArgs& a) {
 }
 
 template <class C>
-int launch_step(mm_ctx* ctx, const mm_model* m, const ImplicitArgs& a) {
-  if (m->rmetric == MM_RMETRIC_RANK1) return launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_RANK1>, a);
-  return launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_DIAGQUAD>, a);
+int launch_step(mm_ctx* ctx, const mm_model* m, const ImplicitArgs& a, bool midpoint) {
+  const bool r1 = m->rmetric == MM_RMETRIC_RANK1;
+  if (midpoint)
+    return r1 ? launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_RANK1, true>, a)
+              : launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_DIAGQUAD, true>, a);
+  return r1 ? launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_RANK1, false>, a)
+            : launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_DIAGQUAD, false>, a);
 }
 
 template <class C>
@@ -644,8 +651,8 @@ int mm_team_padded_dim(int dim) {
   return v == 0 ? CfgMid::DP : v == 1 ? CfgSmall::DP : CfgLarge::DP;
 }
 
-int mm_launch_implicit_large(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
-                             const mm_fp_opts& opts, mm_counters* d_counters) {
+static int launch_large(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_fp_opts& opts,
+                        mm_counters* d_counters, bool midpoint) {
   if (!check_team_model(ctx, m)) return MM_ERR_UNSUPPORTED;
   ImplicitArgs a = make_args(m, s);
   a.step_size = h;
@@ -653,7 +660,19 @@ int mm_launch_implicit_large(mm_ctx* ctx, const mm_model* m, mm_state* s, double
   a.opts = opts;
   a.counters = d_counters;
   const int v = team_variant(m->dim);
-  return v == 0 ? launch_step<CfgMid>(ctx, m, a) : v == 1 ? launch_step<CfgSmall>(ctx, m, a) : launch_step<CfgLarge>(ctx, m, a);
+  return v == 0   ? launch_step<CfgMid>(ctx, m, a, midpoint)
+         : v == 1 ? launch_step<CfgSmall>(ctx, m, a, midpoint)
+                  : launch_step<CfgLarge>(ctx, m, a, midpoint);
+}
+
+int mm_launch_implicit_large(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                             const mm_fp_opts& opts, mm_counters* d_counters) {
+  return launch_large(ctx, m, s, h, n_steps, opts, d_counters, false);
+}
+
+int mm_launch_implicit_midpoint_large(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                                      const mm_fp_opts& opts, mm_counters* d_counters) {
+  return launch_large(ctx, m, s, h, n_steps, opts, d_counters, true);
 }
 
 int mm_launch_riemann_aux_large(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* d_out,

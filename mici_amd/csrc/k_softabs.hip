@@ -500,6 +500,8 @@ struct SaArgs {
   int op;
 };
 
+// MIDPOINT: ImplicitMidpointIntegrator (integrators.py:547-681) on the same backend
+template <bool MIDPOINT>
 __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   ImplicitArgs A = S.a;
@@ -515,7 +517,9 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
   __syncthreads();
-  const ChainResult r = implicit_leapfrog_chain(bk, t, mmdev::chain_steps(A.chain_steps, chain, A.n_steps), A.opts);
+  const int my_steps = mmdev::chain_steps(A.chain_steps, chain, A.n_steps);
+  const ChainResult r = MIDPOINT ? implicit_midpoint_chain(bk, t, my_steps, A.opts)
+                                 : implicit_leapfrog_chain(bk, t, my_steps, A.opts);
   if (act) {
     A.pos[chain * dim + tid] = bk.slot(SL_Q);
     A.mom[chain * dim + tid] = bk.slot(SL_P);
@@ -588,8 +592,9 @@ int check_dim(mm_ctx* ctx, const mm_model* m) {
 
 }  // namespace
 
-int mm_launch_softabs_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
-                               const mm_fp_opts& opts, mm_counters* d_counters) {
+template <bool MIDPOINT>
+static int launch_softabs(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                          const mm_fp_opts& opts, mm_counters* d_counters) {
   int rc = check_dim(ctx, m);
   if (rc != MM_OK) return rc;
   SaArgs S = make_args(m, s);
@@ -598,11 +603,21 @@ int mm_launch_softabs_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, doub
   S.a.opts = opts;
   S.a.counters = d_counters;
   const size_t lds = kLdsDoubles * sizeof(double);
-  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(softabs_leapfrog_kernel),
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(softabs_leapfrog_kernel<MIDPOINT>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(softabs_leapfrog_kernel, dim3((unsigned)s->n), dim3(NT), lds, ctx->stream, S);
+  hipLaunchKernelGGL(softabs_leapfrog_kernel<MIDPOINT>, dim3((unsigned)s->n), dim3(NT), lds, ctx->stream, S);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
+}
+
+int mm_launch_softabs_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                               const mm_fp_opts& opts, mm_counters* d_counters) {
+  return launch_softabs<false>(ctx, m, s, h, n_steps, opts, d_counters);
+}
+
+int mm_launch_softabs_midpoint(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                               const mm_fp_opts& opts, mm_counters* d_counters) {
+  return launch_softabs<true>(ctx, m, s, h, n_steps, opts, d_counters);
 }
 
 int mm_launch_softabs_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* d_out,

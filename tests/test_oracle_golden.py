@@ -159,6 +159,8 @@ def test_implicit_midpoint(name):
     if str(g["system"]) == "euclid":
         mk = int(g["metric_kind"])
         system = orc.EuclidSystem(target, mk, None if mk == mdl.METRIC_IDENTITY else g["metric"])
+    elif str(g["system"]) == "softabs":
+        system = orc.RiemannianSystem(target, None, float(g["rmetric_params"][0]))
     else:
         system = orc.RiemannianSystem(target, mdl.rmetric_from_id(g["rmetric"], g["rmetric_params"], d), None)
     norm = orc.NORMS[int(g["norm"])]

@@ -918,6 +918,31 @@ def main():
                     mdl.METRIC_DENSE, mdl.make_spd(16, rng), sphere_plane_init(5, 16, n16), 0.05, [1, 5, 20],
                     variant="gaussian")
 
+    # ---- implicit midpoint on the team kernels (D > 64) and on the SoftAbs metric -------------------------------------
+    add_midpoint_riemann("midpoint_riemann_rank1_poly_d70", mdl.Poly(70, 1.0, 1.0 / 3.0),
+                         mdl.Rank1Metric(mdl.make_spd(70, rng)), 3, 0.05, [1, 4])
+    add_midpoint_riemann("midpoint_riemann_rank1_banana_d100", mdl.Banana(100), mdl.Rank1Metric(mdl.make_spd(100, rng)),
+                         3, 0.01, [1, 3])
+
+    def add_midpoint_softabs(name, target, coeff, n, h, cps, qscale=0.5, **kw):
+        q0 = qscale * rng.standard_normal((n, target.dim))
+        osys = orc.RiemannianSystem(target, None, coeff)
+        p0 = np.stack([osys.sample_momentum(orc._State(q0[c], None), zz)
+                       for c, zz in enumerate(rng.standard_normal((n, target.dim)))])
+
+        def make():
+            rsys = mici.systems.SoftAbsRiemannianMetricSystem(
+                neg_log_dens=target.neg_log_dens, grad_neg_log_dens=target.grad,
+                hess_neg_log_dens=target.hess, mtp_neg_log_dens=target.mtp, softabs_coeff=coeff)
+            return midpoint_case(name, rsys, osys, dict(system="softabs", target=target.tid,
+                                                        target_params=target.params(), rmetric=mdl.RMETRIC_SOFTABS,
+                                                        rmetric_params=np.array([coeff])),
+                                 q0, p0, dirs_for(n), h, cps, **kw)
+        cases[name] = make
+
+    add_midpoint_softabs("midpoint_softabs_funnel_d8", mdl.Funnel(np.linspace(0.5, 2.0, 7)), 1.0, 4, 0.05, [1, 5])
+    add_midpoint_softabs("midpoint_softabs_poly_d16", mdl.Poly(16, 1.0, 0.3), 2.0, 3, 0.05, [1, 5])
+
     # ---- correlated momentum refresh + random trajectory length (transitions.py:143-198, 355-402) ----------
     def make_corr_random():
         name = "corrmom_random_nstep_d10"
