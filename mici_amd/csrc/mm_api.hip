@@ -515,11 +515,14 @@ int mm_state_upload(mm_state* s, const double* pos, const double* mom, const int
   return MM_OK;
 }
 
+int mm_state_download_all(mm_state* s, double* pos, double* mom, int8_t* dir, int32_t* status, int32_t* n_done);
+
 int mm_state_download(mm_state* s, double* pos, double* mom, int8_t* dir) {
   MM_REQUIRE(nullptr, s != nullptr, "mm_state_download: state is NULL");
   mm_ctx* ctx = s->ctx;
   if (s->n == 0) return MM_OK;
   const size_t nd = (size_t)s->n * s->dim;
+  if (s->mapped) return mm_state_download_all(s, pos, mom, dir, nullptr, nullptr);
   if (pos) MM_HIP_CHECK(ctx, hipMemcpyAsync(pos, s->d_pos, nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (mom) MM_HIP_CHECK(ctx, hipMemcpyAsync(mom, s->d_mom, nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (dir) MM_HIP_CHECK(ctx, hipMemcpyAsync(dir, s->d_dir, (size_t)s->n, hipMemcpyDeviceToHost, ctx->stream));
@@ -559,6 +562,7 @@ int mm_state_download_status(mm_state* s, int32_t* status, int32_t* n_done) {
   MM_REQUIRE(nullptr, s != nullptr, "mm_state_download_status: state is NULL");
   mm_ctx* ctx = s->ctx;
   if (s->n == 0) return MM_OK;
+  if (s->mapped) return mm_state_download_all(s, nullptr, nullptr, nullptr, status, n_done);
   if (status) MM_HIP_CHECK(ctx, hipMemcpyAsync(status, s->d_status, (size_t)s->n * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (n_done) MM_HIP_CHECK(ctx, hipMemcpyAsync(n_done, s->d_n_done, (size_t)s->n * 4, hipMemcpyDeviceToHost, ctx->stream));
   MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -573,11 +577,11 @@ int mm_state_copy(mm_state* dst, const mm_state* src) {
   if (dst == src || dst->n == 0) return MM_OK;
   MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t nd = (size_t)src->n * src->dim * sizeof(double), n = (size_t)src->n;
-  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_pos, src->d_pos, nd, hipMemcpyDeviceToDevice, ctx->stream));
-  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_mom, src->d_mom, nd, hipMemcpyDeviceToDevice, ctx->stream));
-  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_dir, src->d_dir, n, hipMemcpyDeviceToDevice, ctx->stream));
-  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_status, src->d_status, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_n_done, src->d_n_done, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_pos, src->d_pos, nd, hipMemcpyDefault, ctx->stream));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_mom, src->d_mom, nd, hipMemcpyDefault, ctx->stream));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_dir, src->d_dir, n, hipMemcpyDefault, ctx->stream));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_status, src->d_status, n * 4, hipMemcpyDefault, ctx->stream));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_n_done, src->d_n_done, n * 4, hipMemcpyDefault, ctx->stream));
   if (src->d_chain_steps) {  // ... and the same per-chain trajectory lengths
     if (!dst->d_chain_steps) MM_HIP_CHECK(ctx, hipMalloc(&dst->d_chain_steps, n * sizeof(int32_t)));
     MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_chain_steps, src->d_chain_steps, n * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));

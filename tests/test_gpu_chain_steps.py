@@ -123,3 +123,32 @@ def test_random_integration_transition_draws_per_chain():
     with pytest.raises(ValueError):
         trans.sample_batch(batch := DeviceBatch(ctx, 2, dim), [0.5, 0.5], n_step=np.array([0, 3]))
     batch.close()
+
+
+def test_host_mapped_state_behaves_like_a_device_one():
+    """mm_state_alloc_mapped: upload / step / copy / accept / download on pinned host memory the kernels access in
+    place must give the same bits as the device-resident state."""
+    rng = np.random.default_rng(5)
+    n, dim = 6, 24
+    P = omdl.make_spd(dim, rng)
+    system = systems.EuclideanMetricSystem(models.GaussDense(P))
+    integ = integrators.LeapfrogIntegrator(system, 0.1)
+    trans = transitions.MetropolisStaticIntegrationTransition(system, integ, n_step=7)
+    q0, p0 = rng.standard_normal((n, dim)), rng.standard_normal((n, dim))
+    u = rng.uniform(size=n)
+    ctx = default_context()
+    out = []
+    for mapped in (False, True):
+        batch = DeviceBatch(ctx, n, dim, mapped=mapped)
+        batch.upload(q0, p0, np.ones(n, dtype=np.int8))
+        integ.step_device(batch, 3, ctx)
+        stats = trans.sample_batch(batch, u)  # copies the state into a (device) proposal and back
+        q, p, d, status, n_done = batch.download_all()
+        q2, p2, d2 = batch.download()
+        st2, nd2 = batch.download_status()
+        assert np.array_equal(q, q2) and np.array_equal(p, p2) and np.array_equal(d, d2)
+        assert np.array_equal(status, st2) and np.array_equal(n_done, nd2)
+        out.append((q, p, d, stats["metrop_accept_prob"]))
+        batch.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
