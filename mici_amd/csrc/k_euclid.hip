@@ -43,8 +43,8 @@ __device__ __forceinline__ double elem_grad(double q, double tp0, double tp1) {
 template <int TARGET, int METRIC, int VEC, bool COMP>
 __device__ __forceinline__ void leapfrog_elem_body(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int64_t n_chains, int dim,
-    double step_size, int n_steps,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int32_t* __restrict__ status,
+    int32_t* __restrict__ n_done, int64_t n_chains, int dim, double step_size, int n_steps,
     const double* __restrict__ tparams,
     const double* __restrict__ minv_diag, const mm_comp_coefs& cf) {
   const int vec_per_chain = dim / VEC;
@@ -113,26 +113,32 @@ __device__ __forceinline__ void leapfrog_elem_body(
     } else {
       pos[off] = q[0]; mom[off] = p[0];
     }
+    if (d0 == 0) {  // explicit steps cannot fail: status 0, n_done = the chain's step count
+      status[chain] = 0;
+      n_done[chain] = my_steps;
+    }
   }
 }
 
 template <int TARGET, int METRIC, int VEC>
 __global__ __launch_bounds__(256) void leapfrog_elem_kernel(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int64_t n_chains, int dim,
-    double step_size, int n_steps,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int32_t* __restrict__ status,
+    int32_t* __restrict__ n_done, int64_t n_chains, int dim, double step_size, int n_steps,
     const double* __restrict__ tparams, const double* __restrict__ minv_diag) {
-  leapfrog_elem_body<TARGET, METRIC, VEC, false>(pos, mom, dir, step_scale, chain_steps, n_chains, dim, step_size, n_steps,
+  leapfrog_elem_body<TARGET, METRIC, VEC, false>(pos, mom, dir, step_scale, chain_steps, status, n_done, n_chains, dim, step_size,
+      n_steps,
                                                  tparams, minv_diag, mm_comp_coefs{});
 }
 
 template <int TARGET, int METRIC, int VEC>
 __global__ __launch_bounds__(256) void composition_elem_kernel(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int64_t n_chains, int dim,
-    double step_size, int n_steps,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int32_t* __restrict__ status,
+    int32_t* __restrict__ n_done, int64_t n_chains, int dim, double step_size, int n_steps,
     const double* __restrict__ tparams, const double* __restrict__ minv_diag, mm_comp_coefs cf) {
-  leapfrog_elem_body<TARGET, METRIC, VEC, true>(pos, mom, dir, step_scale, chain_steps, n_chains, dim, step_size, n_steps,
+  leapfrog_elem_body<TARGET, METRIC, VEC, true>(pos, mom, dir, step_scale, chain_steps, status, n_done, n_chains, dim, step_size,
+      n_steps,
                                                 tparams, minv_diag, cf);
 }
 
@@ -193,8 +199,8 @@ __device__ __forceinline__ void tile_times_slabs(const double* __restrict__ tile
 template <int DP, int CT, int TARGET, int METRIC, bool COMP>
 __device__ __forceinline__ void leapfrog_mfma_body(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int64_t n_chains, int dim,
-    double step_size, int n_steps,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int32_t* __restrict__ status,
+    int32_t* __restrict__ n_done, int64_t n_chains, int dim, double step_size, int n_steps,
     const double* __restrict__ tparams,
     const double* __restrict__ minv, const mm_comp_coefs& cf) {
   using Cfg = MfmaCfg<DP, CT>;
@@ -352,6 +358,10 @@ __device__ __forceinline__ void leapfrog_mfma_body(
         const int64_t chain = chain0 + (lane >> 4) + 4 * r;
         pos[chain * dim + col[c]] = q[c][r];
         mom[chain * dim + col[c]] = p[c][r];
+        if (col[c] == 0) {  // explicit steps cannot fail
+          status[chain] = 0;
+          n_done[chain] = my_steps[r];
+        }
       }
     }
 }
@@ -359,20 +369,22 @@ __device__ __forceinline__ void leapfrog_mfma_body(
 template <int DP, int CT, int TARGET, int METRIC>
 __global__ __launch_bounds__(DP * 4 / CT) void leapfrog_mfma_kernel(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int64_t n_chains, int dim,
-    double step_size, int n_steps,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int32_t* __restrict__ status,
+    int32_t* __restrict__ n_done, int64_t n_chains, int dim, double step_size, int n_steps,
     const double* __restrict__ tparams, const double* __restrict__ minv) {
-  leapfrog_mfma_body<DP, CT, TARGET, METRIC, false>(pos, mom, dir, step_scale, chain_steps, n_chains, dim, step_size, n_steps,
+  leapfrog_mfma_body<DP, CT, TARGET, METRIC, false>(pos, mom, dir, step_scale, chain_steps, status, n_done, n_chains, dim, step_size,
+      n_steps,
                                                     tparams, minv, mm_comp_coefs{});
 }
 
 template <int DP, int CT, int TARGET, int METRIC>
 __global__ __launch_bounds__(DP * 4 / CT) void composition_mfma_kernel(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
-    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int64_t n_chains, int dim,
-    double step_size, int n_steps,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int32_t* __restrict__ status,
+    int32_t* __restrict__ n_done, int64_t n_chains, int dim, double step_size, int n_steps,
     const double* __restrict__ tparams, const double* __restrict__ minv, mm_comp_coefs cf) {
-  leapfrog_mfma_body<DP, CT, TARGET, METRIC, true>(pos, mom, dir, step_scale, chain_steps, n_chains, dim, step_size, n_steps,
+  leapfrog_mfma_body<DP, CT, TARGET, METRIC, true>(pos, mom, dir, step_scale, chain_steps, status, n_done, n_chains, dim, step_size,
+      n_steps,
                                                    tparams, minv, cf);
 }
 
@@ -387,19 +399,19 @@ int launch_elem(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_ste
   if (blocks < 1) blocks = 1;
   if (cf && vec2)
     hipLaunchKernelGGL((composition_elem_kernel<TARGET, METRIC, 2>), dim3((unsigned)blocks), dim3(256),
-                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, dim, h, n_steps,
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done, s->n, dim, h, n_steps,
                        m->d_target_params, m->d_metric_inv, *cf);
   else if (cf)
     hipLaunchKernelGGL((composition_elem_kernel<TARGET, METRIC, 1>), dim3((unsigned)blocks), dim3(256),
-                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, dim, h, n_steps,
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done, s->n, dim, h, n_steps,
                        m->d_target_params, m->d_metric_inv, *cf);
   else if (vec2)
     hipLaunchKernelGGL((leapfrog_elem_kernel<TARGET, METRIC, 2>), dim3((unsigned)blocks), dim3(256),
-                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, dim, h, n_steps,
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done, s->n, dim, h, n_steps,
                        m->d_target_params, m->d_metric_inv);
   else
     hipLaunchKernelGGL((leapfrog_elem_kernel<TARGET, METRIC, 1>), dim3((unsigned)blocks), dim3(256),
-                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, dim, h, n_steps,
+                       0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done, s->n, dim, h, n_steps,
                        m->d_target_params, m->d_metric_inv);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
@@ -410,11 +422,11 @@ int launch_mfma_dp(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_
   const unsigned blocks = (unsigned)((s->n + 15) / 16);
   if (cf)
     hipLaunchKernelGGL((composition_mfma_kernel<DP, CT, TARGET, METRIC>), dim3(blocks),
-                       dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, s->dim,
+                       dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done, s->n, s->dim,
                        h, n_steps, m->d_target_params, m->d_metric_inv, *cf);
   else
   hipLaunchKernelGGL((leapfrog_mfma_kernel<DP, CT, TARGET, METRIC>), dim3(blocks),
-                     dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, s->dim, h,
+                     dim3(DP * 4 / CT), 0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done, s->n, s->dim, h,
                      n_steps, m->d_target_params, m->d_metric_inv);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;

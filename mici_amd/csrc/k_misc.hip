@@ -90,8 +90,9 @@ __device__ __forceinline__ void gaussian_h2_flow(const EuclidModelView& m, doubl
 __global__ void leapfrog_generic_kernel(EuclidModelView m, double* __restrict__ pos,
                                         double* __restrict__ mom, const int8_t* __restrict__ dir,
                                         const double* __restrict__ step_scale,
-                                        const int32_t* __restrict__ chain_steps, int64_t n_chains,
-                                        double step_size, int n_steps) {
+                                        const int32_t* __restrict__ chain_steps, int32_t* __restrict__ status,
+                                        int32_t* __restrict__ n_done, int64_t n_chains, double step_size,
+                                        int n_steps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dim = m.dim;
@@ -132,6 +133,10 @@ __global__ void leapfrog_generic_kernel(EuclidModelView m, double* __restrict__ 
     pos[chain * dim + i] = q[i];
     mom[chain * dim + i] = p[i];
   }
+  if (lane == 0) {  // explicit steps cannot fail
+    status[chain] = 0;
+    n_done[chain] = n_steps;
+  }
 }
 
 // SymmetricCompositionIntegrator._step (integrators.py:272-274) on a Euclidean-metric system: the
@@ -143,8 +148,9 @@ using CompCoefs = mm_comp_coefs;
 __global__ void composition_generic_kernel(EuclidModelView m, double* __restrict__ pos,
                                            double* __restrict__ mom, const int8_t* __restrict__ dir,
                                            const double* __restrict__ step_scale,
-                                           const int32_t* __restrict__ chain_steps, int64_t n_chains,
-                                           double step_size, int n_steps, CompCoefs cf) {
+                                           const int32_t* __restrict__ chain_steps, int32_t* __restrict__ status,
+                                           int32_t* __restrict__ n_done, int64_t n_chains, double step_size,
+                                           int n_steps, CompCoefs cf) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dim = m.dim;
@@ -189,6 +195,10 @@ __global__ void composition_generic_kernel(EuclidModelView m, double* __restrict
   for (int i = lane; i < dim; i += 64) {
     pos[chain * dim + i] = q[i];
     mom[chain * dim + i] = p[i];
+  }
+  if (lane == 0) {  // explicit steps cannot fail
+    status[chain] = 0;
+    n_done[chain] = n_steps;
   }
 }
 
@@ -258,7 +268,8 @@ int mm_launch_leapfrog_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, doub
   }
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
   hipLaunchKernelGGL(leapfrog_generic_kernel, dim3(blocks), dim3(64 * w), lds, ctx->stream,
-                     view_of(m), s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, h, n_steps);
+                     view_of(m), s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done,
+                     s->n, h, n_steps);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }
@@ -277,7 +288,8 @@ int mm_launch_composition_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, d
   for (int i = 0; i < n_coeffs; ++i) cf.c[i] = coeffs[i];
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
   hipLaunchKernelGGL(composition_generic_kernel, dim3(blocks), dim3(64 * w), lds, ctx->stream, view_of(m),
-                     s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->n, h, n_steps, cf);
+                     s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done, s->n, h, n_steps,
+                     cf);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }

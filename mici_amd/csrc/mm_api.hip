@@ -657,7 +657,8 @@ static int check_pair(mm_ctx* ctx, const mm_model* m, mm_state* s, const char* w
   return MM_OK;
 }
 
-// explicit integrators cannot fail: status 0, n_done = n_steps for every chain (read by mm_metropolis_accept).
+// explicit integrators cannot fail: status 0, n_done = the chain's step count (read by mm_metropolis_accept).
+// Their kernels write both themselves; this is only for the call that has nothing to launch.
 // One tiny kernel in the stream rather than hipMemset*Async: those were measured to stall the host between
 // launches (a 3.9 ms trajectory kernel became a 6-7.5 ms pass).
 static int mark_explicit_done(mm_ctx* ctx, mm_state* s, int32_t n_steps) {
@@ -670,13 +671,13 @@ int mm_leapfrog_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, in
   MM_REQUIRE(ctx, m->rmetric == MM_RMETRIC_NONE && m->constr == MM_CONSTR_NONE,
              "mm_leapfrog_euclid: model is not a plain EuclideanMetricSystem");
   MM_REQUIRE(ctx, n_steps >= 0, "mm_leapfrog_euclid: n_steps < 0");
-  if (s->n == 0 || n_steps == 0) return MM_OK;
+  if (s->n == 0) return MM_OK;
+  if (n_steps == 0) return mark_explicit_done(ctx, s, 0);
   // the Gaussian split's exact h2 flow lives in the generic kernel only
   rc = m->gaussian_split ? -100 : mm_launch_leapfrog_euclid(ctx, m, s, h, n_steps);
   if (rc == -100 || (rc == MM_ERR_UNSUPPORTED && m->dim > 128))
     rc = mm_launch_leapfrog_generic(ctx, m, s, h, n_steps);
-  if (rc != MM_OK) return rc;
-  return mark_explicit_done(ctx, s, n_steps);
+  return rc;
 }
 
 int mm_composition_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int32_t n_steps,
@@ -690,7 +691,8 @@ int mm_composition_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h,
              "mm_composition_euclid: need an odd number of coefficients in [3, 16]");
   for (int i = 0; i < n_coeffs; ++i)
     MM_REQUIRE(ctx, std::isfinite(coeffs[i]), "mm_composition_euclid: non-finite coefficient");
-  if (s->n == 0 || n_steps == 0) return MM_OK;
+  if (s->n == 0) return MM_OK;
+  if (n_steps == 0) return mark_explicit_done(ctx, s, 0);
   // separable / dense-Gaussian models run on the kernels of the leapfrog (elementwise or FP64 MFMA); anything
   // else, and the Gaussian split's exact h2 flow, on the generic wave-per-chain kernel
   mm_comp_coefs cf{};
@@ -700,8 +702,7 @@ int mm_composition_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h,
   rc = m->gaussian_split ? -100 : mm_launch_composition_euclid(ctx, m, s, h, n_steps, cf);
   if (rc == -100 || (rc == MM_ERR_UNSUPPORTED && m->dim > 128))
     rc = mm_launch_composition_generic(ctx, m, s, h, n_steps, n_coeffs, coeffs, initial_h1 != 0);
-  if (rc != MM_OK) return rc;
-  return mark_explicit_done(ctx, s, n_steps);
+  return rc;
 }
 
 static int finish_counters(mm_ctx* ctx, mm_counters* counters) {
