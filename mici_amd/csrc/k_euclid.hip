@@ -204,9 +204,10 @@ __device__ __forceinline__ void leapfrog_mfma_body(
     const double* __restrict__ tparams,
     const double* __restrict__ minv, const mm_comp_coefs& cf) {
   using Cfg = MfmaCfg<DP, CT>;
-  __shared__ __attribute__((aligned(16))) double lds[(METRIC == M_DENSE ? 4 : 2) * Cfg::TILE];
+  __shared__ __attribute__((aligned(16))) double lds[(METRIC == M_DENSE ? 3 : 2) * Cfg::TILE];
   double* qbuf = lds;                    // two q tiles (double buffered)
-  double* pbuf = lds + 2 * Cfg::TILE;    // two p tiles (dense metric only)
+  double* pbuf = lds + 2 * Cfg::TILE;    // one p tile (dense metric only): with a dense target the q-tile barrier of
+                                         // the gradient already separates its readers from the next publish
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -281,7 +282,9 @@ __device__ __forceinline__ void leapfrog_mfma_body(
   // q += tt M^-1 p with the product on buffer parity s (dense metric) or elementwise
   auto drift = [&](const double (&tt)[4], int s) {
     if constexpr (METRIC == M_DENSE) {
-      double* tile = pbuf + (s & 1) * Cfg::TILE;
+      double* tile = pbuf;
+      (void)s;
+      if constexpr (TARGET != T_DENSE) __syncthreads();  // no gradient barrier since the last read of this tile
       publish(tile, p);
       __syncthreads();
       double4_t v[CT];
