@@ -386,7 +386,7 @@ def main():
                     box["ms"] = (time.perf_counter() - tg) * 1e3
                 box["mode"] = "rccl, outside the timed region"
             except Exception as e:
-                box["mode"] = f"rccl unavailable ({type(e).__name__})"
+                box["mode"] = f"rccl unavailable ({type(e).__name__}: {str(e)[:160]})"
 
         th = threading.Thread(target=timed_gather, daemon=True)
         th.start()
