@@ -31,7 +31,7 @@ constexpr int RP = NT / 64;        // threads per output element of the row-wise
 constexpr int LD = 65;            // LDS leading dimension of the 64 x 64 matrices
 constexpr int MAT = 64 * LD;
 constexpr int kMaxSweeps = 30;
-constexpr int kWarmPeriod = 16;  // cold-start the eigenvector basis every this many decompositions
+constexpr int kWarmPeriod = 256;  // cold-start the eigenvector basis every this many decompositions
 
 struct SaLds {
   double* H;    // Hessian -> (after eigh) J matrix / scratch

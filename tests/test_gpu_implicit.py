@@ -334,3 +334,26 @@ def test_empty_batches():
     q, p, st, nd = integrators.ConstrainedLeapfrogIntegrator(system, 0.1).step_batch(
         np.zeros((0, 3)), np.zeros((0, 3)), 1, 3)
     assert q.shape == (0, 3)
+
+
+def test_softabs_long_trajectory_matches_oracle():
+    """More decompositions than the warm-start period of the Jacobi eigensolver (k_softabs.hip: eigenvectors carried
+    from one metric construction to the next, cold restart every 256): the accumulated rounding of the carried basis
+    must stay far below the solver tolerances."""
+    rng = np.random.default_rng(17)
+    dim, n, h, steps = 16, 3, 0.04, 40
+    w = np.linspace(0.5, 2.0, dim - 1)
+    system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(w), softabs_coeff=1.0)
+    osys = orc.RiemannianSystem(omdl.Funnel(w), None, 1.0, orc.Counters())
+    integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+    q0 = 0.4 * rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+    q, p, status, n_done = integ.step_batch(q0, p0, 1, n_steps=steps)
+    assert integ.last_counters["n_metric"] > 3 * 256  # several warm-start periods per chain
+    for c in range(n):
+        qo, po, so, no = orc.implicit_leapfrog_steps(osys, q0[c], p0[c], h, steps)
+        assert so == status[c] and no == n_done[c]
+        assert_close(q[c], qo, 1e-7, f"q chain {c}")
+        assert_close(p[c], po, 1e-7, f"p chain {c}")
+    h0, h1 = system.h_batch(q0, p0), system.h_batch(q, p)
+    assert np.all(np.abs(h1 - h0) < 5e-2)
