@@ -1,4 +1,6 @@
-"""Dual-averaging step-size adaptation (Hoffman & Gelman 2014) with the reference's ``Adapter`` surface
+"""Warm-up adapters with the reference's ``Adapter`` surface (mici/adapters.py).
+
+Dual-averaging step-size adaptation (Hoffman & Gelman 2014) with the reference's ``Adapter`` surface
 (mici/adapters.py:174-389), batched over device-resident chains: every chain adapts ITS OWN step size, as in
 the reference (one integrator copy per chain), through per-chain step-size factors attached to the batch
 (``DeviceBatch.set_step_scale`` / ``mm_state_set_step_scale``) while the integrator's own ``step_size`` is
@@ -173,3 +175,136 @@ class DualAveragingStepSizeAdapter:
         else:
             transition.integrator.step_size = self.log_step_size_reducer(
                 [a["smoothed_log_step_size"] for a in adapt_states])
+
+
+class _OnlineMomentsAdapter:
+    """Shared part of the two metric adapters: Welford's running mean / second-moment update per chain
+    (adapters.py:444-460, 574-590), the pairwise combination of the per-chain statistics at the end
+    (Chan et al. / Schubert & Gertz, adapters.py:486-499, 616-630), the regularisation towards ``reg_scale``
+    times the identity, and the momentum refresh under the new metric."""
+
+    is_fast = False
+    _outer = False  # full second-moment matrix instead of its diagonal
+
+    def __init__(self, reg_iter_offset=5, reg_scale=1e-3):
+        self.reg_iter_offset = reg_iter_offset
+        self.reg_scale = reg_scale
+
+    def _zeros(self, dim):
+        return np.zeros((dim, dim) if self._outer else (dim,))
+
+    def _accumulate(self, acc, before, after):
+        if self._outer:
+            acc += before[None, :] * after[:, None]
+        else:
+            acc += before * after
+
+    # ---- the reference's single-chain contract ------------------------------------------------------------
+    def initialize(self, chain_state, transition):
+        dim = np.asarray(chain_state.pos).shape[0]
+        return {"iter": 0, "mean": np.zeros(dim), self._key: self._zeros(dim)}
+
+    def update(self, adapt_state, chain_state, trans_stats, transition):
+        pos = np.asarray(chain_state.pos, dtype=np.float64)
+        adapt_state["iter"] += 1
+        before = pos - adapt_state["mean"]
+        adapt_state["mean"] += before / adapt_state["iter"]
+        self._accumulate(adapt_state[self._key], before, pos - adapt_state["mean"])
+
+    def _combine(self, adapt_states):
+        """(n_iter, accumulated second moment) over one or several chains."""
+        if isinstance(adapt_states, dict):
+            return adapt_states["iter"], adapt_states.pop(self._key)
+        n_iter = mean = acc = None
+        for i, st in enumerate(adapt_states):
+            if i == 0:
+                n_iter, mean, acc = st["iter"], st.pop("mean"), st.pop(self._key)
+                continue
+            n_prev = n_iter
+            n_iter += st["iter"]
+            mean_diff = mean - st["mean"]
+            mean *= n_prev
+            mean += st["iter"] * st["mean"]
+            mean /= n_iter
+            acc += st[self._key]
+            cross = np.outer(mean_diff, mean_diff) if self._outer else mean_diff**2
+            acc += cross * (st["iter"] * n_prev) / n_iter
+        return n_iter, acc
+
+    def _estimate(self, adapt_states):
+        n_iter, est = self._combine(adapt_states)
+        if n_iter < 2:
+            raise AdaptationError("At least two chain samples required to compute a variance estimates.")
+        est /= n_iter - 1
+        if not self._outer and (self.reg_iter_offset is None or self.reg_iter_offset == 0):
+            return est
+        est *= n_iter / (self.reg_iter_offset + n_iter)
+        shrink = self.reg_scale * (self.reg_iter_offset / (self.reg_iter_offset + n_iter))
+        if self._outer:
+            est[np.diag_indices_from(est)] += shrink
+        else:
+            est += shrink
+        return est
+
+    def finalize(self, adapt_states, chain_states, transition, rngs):
+        single = isinstance(adapt_states, dict)
+        est = self._estimate(adapt_states)
+        self._install(transition.system, est)
+        # resample the momenta: their distribution changed with the metric (adapters.py:507-509, 634-636)
+        for chain_state, rng in zip([chain_states] if single else chain_states, [rngs] if single else rngs):
+            chain_state.mom = transition.system.sample_momentum(chain_state, rng)
+
+    # ---- N device-resident chains ---------------------------------------------------------------------------
+    def initialize_batch(self, batch, transition=None, ctx=None):
+        n, dim = batch.n_chains, batch.dim
+        return {"iter": 0, "mean": np.zeros((n, dim)),
+                self._key: np.zeros((n, dim, dim) if self._outer else (n, dim))}
+
+    def update_batch(self, adapt_state, batch, trans_stats=None):
+        """One Welford update per chain from the batch's current positions (one download of pos[N, D])."""
+        pos, _, _ = batch.download()
+        adapt_state["iter"] += 1
+        before = pos - adapt_state["mean"]
+        adapt_state["mean"] += before / adapt_state["iter"]
+        after = pos - adapt_state["mean"]
+        if self._outer:
+            adapt_state[self._key] += before[:, None, :] * after[:, :, None]
+        else:
+            adapt_state[self._key] += before * after
+
+    def finalize_batch(self, adapt_state, batch, transition, z):
+        """Combine the chains' statistics exactly as ``finalize`` does for a list of per-chain states, install the
+        metric and resample every chain's momentum on the device from the standard normal draws ``z[N, D]``."""
+        n = batch.n_chains
+        states = [{"iter": adapt_state["iter"], "mean": adapt_state["mean"][c].copy(),
+                   self._key: adapt_state[self._key][c].copy()} for c in range(n)]
+        est = self._estimate(states)
+        self._install(transition.system, est)
+        ctx = batch.ctx
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        if z.shape != (n, batch.dim):
+            raise ValueError("z must be [N, D] standard normal draws")
+        _ffi.check(ctx._lib.mm_sample_momentum(ctx.handle, transition.system.device_model(ctx).handle, batch.handle,
+                                               z.ctypes.data_as(_ffi.c_double_p)), ctx.handle, "mm_sample_momentum")
+        return est
+
+
+class OnlineVarianceMetricAdapter(_OnlineMomentsAdapter):
+    """Diagonal metric from an online estimate of the posterior variances (reference adapters.py:392-514): the
+    metric is the INVERSE of the regularised variance estimate."""
+
+    _key = "sum_diff_sq"
+
+    def _install(self, system, var_est):
+        system.set_metric(1.0 / var_est)  # PositiveDiagonalMatrix(var_est).inv
+
+
+class OnlineCovarianceMetricAdapter(_OnlineMomentsAdapter):
+    """Dense metric from an online estimate of the posterior covariance (reference adapters.py:517-644): the
+    metric is the inverse of the regularised covariance estimate."""
+
+    _key = "sum_diff_outer"
+    _outer = True
+
+    def _install(self, system, covar_est):
+        system.set_metric(np.linalg.inv(covar_est))  # DensePositiveDefiniteMatrix(covar_est).inv

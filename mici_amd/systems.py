@@ -154,6 +154,22 @@ class EuclideanMetricSystem(System):
     def _model_args(self):
         return dict(metric_kind=self.metric_kind, metric=self.metric)
 
+    def set_metric(self, metric):
+        """Replace the fixed metric (``system.metric = ...`` of the reference's metric adapters,
+        adapters.py:506, 633): ``None`` for the identity, a 1-D array for a diagonal metric, a 2-D array for a
+        dense one.  Device models and cached single-state buffers are dropped and rebuilt on next use."""
+        if metric is None:
+            kind, metric = models.METRIC_IDENTITY, None
+        else:
+            metric = np.array(metric, dtype=np.float64)
+            if metric.ndim not in (1, 2) or metric.shape[0] != self.dim or metric.shape[-1] != self.dim:
+                raise ValueError("metric must be [D] (diagonal) or [D, D] (dense) for this system's dimension")
+            kind = models.METRIC_DIAG if metric.ndim == 1 else models.METRIC_DENSE
+        self.metric_kind, self.metric = kind, metric
+        for m in self._device.values():
+            m.close()
+        self._device = {}
+
 
 class GaussianEuclideanMetricSystem(EuclideanMetricSystem):
     """Euclidean-metric system whose target is a density with respect to the standard Gaussian measure

@@ -112,3 +112,67 @@ def test_step_scale_is_per_chain_and_validated():
     with pytest.raises(DeviceError):
         batch.set_step_scale([0.1, -1.0, 0.1, 0.1])
     batch.close()
+
+
+# ---- metric adapters (reference adapters.py:392-644) -------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("metricadapt"))
+def test_metric_adapter_installs_the_reference_metric_on_the_device(name):
+    import types
+    from mici_amd.runtime import DeviceBatch, default_context
+    g = load_golden(name)
+    which, multi = str(g["which"]), bool(g["multi"])
+    cls = adapters.OnlineVarianceMetricAdapter if which == "variance" else adapters.OnlineCovarianceMetricAdapter
+    n_updates, n_chains, dim = g["pos_seq"].shape
+    ref_metric = g["metric"]
+    ref_metric = np.diag(ref_metric) if (which == "variance" and ref_metric.ndim == 2) else ref_metric
+
+    class Replay:
+        def __init__(self, z):
+            self.z = z
+
+        def standard_normal(self, size=None):
+            return self.z.copy()
+
+    # the reference's contract: one adapter state per chain, list finalize
+    system = systems.EuclideanMetricSystem(models.GaussIso(dim))
+    transition = types.SimpleNamespace(system=system)
+    adapter = cls()
+    states = [ChainState(pos=g["pos_seq"][0, c].copy(), mom=np.zeros(dim), dir=1) for c in range(n_chains)]
+    adapt_states = [adapter.initialize(states[c], transition) for c in range(n_chains)]
+    for k in range(n_updates):
+        for c in range(n_chains):
+            states[c].pos = g["pos_seq"][k, c].copy()
+            adapter.update(adapt_states[c], states[c], {}, transition)
+    rngs = [Replay(z) for z in g["z"]]
+    if multi:
+        adapter.finalize(adapt_states, states, transition, rngs)
+    else:
+        adapter.finalize(adapt_states[0], states[0], transition, rngs[0])
+    assert_close(system.metric, ref_metric, 1e-11, "installed metric")
+    minv = np.linalg.inv(np.diag(system.metric) if system.metric.ndim == 1 else system.metric)
+    for c in range(len(g["z"])):
+        if which == "variance":
+            assert_close(states[c].mom, g["mom"][c], 1e-13, f"resampled momentum {c}")
+        assert_close(states[c].mom @ minv @ states[c].mom, g["z"][c] @ g["z"][c], 1e-10, "p.M^-1 p = z.z")
+    # the new metric is live on the device: h uses it
+    h = system.h_batch(g["pos_seq"][-1], np.stack([s.mom for s in states] + [np.zeros(dim)] * (n_chains - len(g["z"]))))
+    expect = np.array([0.5 * q @ q for q in g["pos_seq"][-1]])
+    expect[:len(g["z"])] += 0.5 * np.array([z @ z for z in g["z"]])
+    assert_close(h, expect, 1e-10, "h under the adapted metric")
+    if not multi:
+        return
+    # N device-resident chains: same estimate, momenta resampled on the device
+    system2 = systems.EuclideanMetricSystem(models.GaussIso(dim))
+    transition2 = types.SimpleNamespace(system=system2)
+    ctx = default_context()
+    batch = DeviceBatch(ctx, n_chains, dim)
+    astate = cls().initialize_batch(batch)
+    ad2 = cls()
+    for k in range(n_updates):
+        batch.upload(g["pos_seq"][k], np.zeros((n_chains, dim)), np.ones(n_chains, dtype=np.int8))
+        ad2.update_batch(astate, batch)
+    ad2.finalize_batch(astate, batch, transition2, g["z"])
+    assert_close(system2.metric, system.metric, 1e-13, "batched estimate")
+    _, mom, _ = batch.download()
+    batch.close()
+    assert_close(mom, np.stack([s.mom for s in states]), 1e-13, "batched momentum refresh")

@@ -943,6 +943,44 @@ def main():
     add_midpoint_softabs("midpoint_softabs_funnel_d8", mdl.Funnel(np.linspace(0.5, 2.0, 7)), 1.0, 4, 0.05, [1, 5])
     add_midpoint_softabs("midpoint_softabs_poly_d16", mdl.Poly(16, 1.0, 0.3), 2.0, 3, 0.05, [1, 5])
 
+    # ---- metric adapters (adapters.py:392-644): Welford updates per chain, pairwise combination, regularisation,
+    #      metric = inverse of the estimate, momenta resampled.  No integrator involved: the adapters only read pos. ---
+    def add_metric_adapter(name, which, dim, n_chains, n_updates, seed0, multi=True):
+        pos_seq = rng.standard_normal((n_updates, n_chains, dim)) * np.exp(0.5 * rng.standard_normal(dim)) + \
+            rng.standard_normal(dim)
+
+        def make():
+            import types
+            adapter = (mici.adapters.OnlineVarianceMetricAdapter() if which == "variance"
+                       else mici.adapters.OnlineCovarianceMetricAdapter())
+            rsys = mici.systems.EuclideanMetricSystem(neg_log_dens=lambda q: 0.5 * np.sum(q**2),
+                                                      grad_neg_log_dens=lambda q: q)
+            transition = types.SimpleNamespace(system=rsys)
+            states = [ChainState(pos=pos_seq[0, c].copy(), mom=np.zeros(dim), dir=1) for c in range(n_chains)]
+            adapt_states = [adapter.initialize(states[c], transition) for c in range(n_chains)]
+            for k in range(n_updates):
+                for c in range(n_chains):
+                    states[c].pos = pos_seq[k, c].copy()
+                    adapter.update(adapt_states[c], states[c], {}, transition)
+            rngs = [RecordingRng(seed0 + c) for c in range(n_chains)]
+            if multi:
+                adapter.finalize(adapt_states, states, transition, rngs)
+            else:
+                adapter.finalize(adapt_states[0], states[0], transition, rngs[0])
+            n_fin = n_chains if multi else 1
+            metric = rsys.metric.array
+            z = np.stack([rngs[c].log[0][1] for c in range(n_fin)])
+            mom = np.stack([states[c].mom for c in range(n_fin)])
+            return dict(kind="metricadapt", which=which, multi=multi, pos_seq=pos_seq, metric=np.array(metric),
+                        status=np.zeros(0, dtype=np.int32), n_done=np.zeros(0, dtype=np.int32),
+                        z=z, mom=mom, reg_iter_offset=adapter.reg_iter_offset, reg_scale=adapter.reg_scale), {}
+        cases[name] = make
+
+    add_metric_adapter("metricadapt_variance_d6_3chains", "variance", 6, 3, 12, 4100)
+    add_metric_adapter("metricadapt_variance_d4_single", "variance", 4, 1, 9, 4200, multi=False)
+    add_metric_adapter("metricadapt_covariance_d5_4chains", "covariance", 5, 4, 15, 4300)
+    add_metric_adapter("metricadapt_covariance_d3_single", "covariance", 3, 1, 8, 4400, multi=False)
+
     # ---- correlated momentum refresh + random trajectory length (transitions.py:143-198, 355-402) ----------
     def make_corr_random():
         name = "corrmom_random_nstep_d10"
