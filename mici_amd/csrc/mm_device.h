@@ -150,18 +150,29 @@ __device__ __forceinline__ double target_grad_elem(int target, const TargetAux& 
       return a.s1 * tp[i - 1] * q[i];
     } else { return 0.0; }
     case MM_TARGET_TORUS: if constexpr (TRIG) {
+      // The density is written in the angles theta = atan2(y, x), phi = atan2(z, rho - R); its gradient only
+      // needs sin / cos of phi and of 4 theta, which are algebraic in (x, y, z): no atan2 / sin / cos in the
+      // constrained kernel's per-step critical path (they were a third of its instructions).
       const double R = tp[0], r = tp[1], al = tp[2];
       const double x = q[0], y = q[1], z = q[2];
       const double rho2 = x * x + y * y, rho = sqrt(rho2);
-      const double theta = atan2(y, x), phi = atan2(z, rho - R);
-      const double s4 = sin(4.0 * theta), c4 = cos(4.0 * theta), sp = sin(phi), cp = cos(phi);
-      const double d1 = 1.0 + r * cp / R, d2 = 1.0 + al * s4 * cp;
-      const double dl_dphi = -(r / R) * sp / d1 + al * s4 * sp / d2;
-      const double dl_dth = -4.0 * al * c4 * cp / d2;
-      const double s2 = (rho - R) * (rho - R) + z * z;
-      const double dphi_drho = -z / s2, dphi_dz = (rho - R) / s2;
-      if (i == 0) return dl_dth * (-y / rho2) + dl_dphi * dphi_drho * (x / rho);
-      if (i == 1) return dl_dth * (x / rho2) + dl_dphi * dphi_drho * (y / rho);
+      const double irho = 1.0 / rho;
+      const double ct = x * irho, st = y * irho;            // cos theta, sin theta
+      const double ct2 = ct * ct, st2 = st * st;
+      const double s4 = 4.0 * st * ct * (ct2 - st2);        // sin 4 theta
+      const double c4 = 1.0 - 8.0 * ct2 * st2;              // cos 4 theta
+      const double u = rho - R;
+      const double iw = 1.0 / sqrt(u * u + z * z);
+      const double sp = z * iw, cp = u * iw;                // sin phi, cos phi
+      const double r_over_R = r / R;
+      const double d1 = 1.0 + r_over_R * cp, d2 = 1.0 + al * s4 * cp;
+      const double id2 = 1.0 / d2;
+      const double dl_dphi = -r_over_R * sp / d1 + al * s4 * sp * id2;
+      const double dl_dth = -4.0 * al * c4 * cp * id2;
+      const double iw2 = iw * iw, irho2 = irho * irho;
+      const double dphi_drho = -z * iw2, dphi_dz = u * iw2;
+      if (i == 0) return dl_dth * (-y * irho2) + dl_dphi * dphi_drho * ct;
+      if (i == 1) return dl_dth * (x * irho2) + dl_dphi * dphi_drho * st;
       return dl_dphi * dphi_dz;
     } else { return 0.0; }
     default:
