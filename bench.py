@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py - leapfrog-steps/sec (all chains) of the MI355X integrator hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2iv|c2bcss|c3|c3b|c4|c5] [--traj-len L]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2iv|c2bcss|c3|c3b|c4|c5]
+                    [--traj-len L] [--chains-per-gpu M] [--no-extra-configs] [--no-cpu-baseline]
 
 Contract (driver): W untimed warm-up passes, then EXACTLY K timed passes bracketed by a barrier +
 device synchronise on both sides; the maximum over ranks is the job time; rank 0 prints ONE JSON
@@ -11,13 +12,22 @@ rank's shard (L = the trajectory length SURVEY.md section 8d quotes for the conf
 leapfrog steps (Integrator.step equivalents) per second summed over all chains and ranks, with the
 inputs resident in HBM when the timed region starts; failed chains count only completed steps.
 
-Default (N=1) workload = BASELINE.json configs[1] (c2): EuclideanMetricSystem, dense-precision
+Headline (N=1) workload = BASELINE.json configs[1] (c2): EuclideanMetricSystem, dense-precision
 Gaussian target, D=128, 4096 chains per GPU, identity metric, explicit leapfrog h=0.05, L=1000.
-Multi-GPU: chains are sharded (weak scaling: 4096 chains per GPU); the path has no exchange step, so the
+The same JSON line carries a `configs` object with the other BASELINE configs measured in the same
+process by the same procedure (c2(i), c2(iv), c3(a), c3(b), the c4 per-GPU shard, the c5 per-GPU shard):
+value, ms_per_step, roofline and (N=1) cpu_baseline each.  Their pass counts are capped so that the
+default run stays within a few minutes (`steps` is reported per entry).
+
+Multi-GPU: one process per GPU.  Launched under `python -m torch.distributed.run` the ranks come from
+RANK / LOCAL_RANK / WORLD_SIZE; started plainly as `python bench.py --gpus N` the script starts the N
+rank processes itself and fails if fewer than N devices are visible.  The ranks rendezvous over a
+Unix-domain socket (mici_amd/rendezvous.py, standard library only - no torch anywhere in this file).
+Chains are sharded (weak scaling: the per-GPU shard is fixed); the path has no exchange step, so the
 timed region contains NO collective.  The one collective of a sampling job - the
-RCCL all-gather of positions at trace collection - is timed once, separately, after the timed region and
-reported as `config.trace_gather_ms`; MICI_AMD_BENCH_GATHER=rccl|gloo-host puts one gather per trajectory
-inside the timed region instead (overlapped with the next trajectory).
+RCCL all-gather of positions over xGMI at trace collection - is timed once, separately, after the timed
+region of the headline config and reported as `config.trace_gather_ms`; MICI_AMD_BENCH_GATHER=rccl puts
+one gather per trajectory inside the timed region instead (overlapped with the next trajectory).
 """
 
 from __future__ import annotations
@@ -25,6 +35,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -51,10 +62,38 @@ def _torus_init(n, rng, R=1.0, r=0.5):
                      r * np.sin(phi)], -1)
 
 
-def make_workload(config, n_chains, rng):
+class _OracleMomenta:
+    """Initial momenta for the CPU-baseline worker (no device there): p = M(q)^{1/2} z through the oracle, filled
+    in for the chain ranges the bounded CPU sample actually touches (`fix(lo, hi)`, outside the timed loops)."""
+
+    def __init__(self, kind, osys, q0, z):
+        self.kind, self.osys, self.q0, self.z = kind, osys, q0, z
+        self.p0 = np.array(z, copy=True)
+        self.done = np.zeros(q0.shape[0], dtype=bool)
+
+    def fix(self, lo, hi):
+        from oracle import integrators as orc
+
+        for c in range(lo, min(hi, self.q0.shape[0])):
+            if self.done[c]:
+                continue
+            if self.kind == "constrained":
+                self.p0[c] = self.osys.project_onto_cotangent_space(
+                    self.osys.msqrt(self.z[c]), self.osys.constraint.jacob_constr(self.q0[c]))
+            else:
+                self.p0[c] = self.osys.sample_momentum(orc._State(self.q0[c], self.z[c]), self.z[c])
+            self.done[c] = True
+
+
+def _oracle_momenta(kind, osys, q0, z):
+    return _OracleMomenta(kind, osys, q0, z)
+
+
+def make_workload(config, n_chains, rng, device=True):
     """Synthetic inputs of SURVEY.md section 8d.  Returns dict with the device system, integrator, initial
     state and the algorithmic work per chain-step.  The oracle twin (`make_oracle`) is only constructed by the
-    cpu_baseline leg: nothing under oracle/ is imported on the measured path."""
+    cpu_baseline leg (`device=False`: its own interpreter, initial momenta through the oracle, no device objects
+    touched): nothing under oracle/ is imported on the measured path."""
     from mici_amd import integrators, models, systems
 
     if config in ("c2", "c2i", "c2iv", "c2bcss"):
@@ -106,10 +145,13 @@ def make_workload(config, n_chains, rng):
 
         integ = integrators.ImplicitLeapfrogIntegrator(system, h)
         q0 = rng.standard_normal((n_chains, dim))
-        p0 = system.sample_momentum_batch(q0, rng.standard_normal((n_chains, dim)))
+        z = rng.standard_normal((n_chains, dim))
+        p0 = system.sample_momentum_batch(q0, z) if device else _oracle_momenta("riemann", make_oracle(), q0, z)
+        mom = None if device else p0
+        p0 = p0 if device else mom.p0
         return dict(name=f"{config}(a) DenseRiemannianMetricSystem (rank-one-update dense metric, banana "
                          "target) + ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
-                    system=system, make_oracle=make_oracle, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
+                    system=system, make_oracle=make_oracle, q0=q0, p0=p0, momenta=mom, bytes_per_chain_step=32.0 * dim,
                     flops_per_chain_step=None, bound="mfma", kind="riemann")
     if config == "c3b":
         dim, h, traj = 64, 0.02, 100
@@ -123,10 +165,13 @@ def make_workload(config, n_chains, rng):
 
         integ = integrators.ImplicitLeapfrogIntegrator(system, h)
         q0 = rng.standard_normal((n_chains, dim))
-        p0 = system.sample_momentum_batch(q0, rng.standard_normal((n_chains, dim)))
+        z = rng.standard_normal((n_chains, dim))
+        p0 = system.sample_momentum_batch(q0, z) if device else _oracle_momenta("softabs", make_oracle(), q0, z)
+        mom = None if device else p0
+        p0 = p0 if device else mom.p0
         return dict(name="c3(b) SoftAbsRiemannianMetricSystem (scaled funnel) + "
                          "ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
-                    system=system, make_oracle=make_oracle, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
+                    system=system, make_oracle=make_oracle, q0=q0, p0=p0, momenta=mom, bytes_per_chain_step=32.0 * dim,
                     flops_per_chain_step=None, bound="mfma", kind="softabs")
     if config == "c5":
         dim, h, traj = 3, 0.1, 1000
@@ -139,174 +184,198 @@ def make_workload(config, n_chains, rng):
 
         integ = integrators.ConstrainedLeapfrogIntegrator(system, h)
         q0 = _torus_init(n_chains, rng)
-        p0 = system.sample_momentum_batch(q0, rng.standard_normal((n_chains, dim)))
+        z = rng.standard_normal((n_chains, dim))
+        p0 = system.sample_momentum_batch(q0, z) if device else _oracle_momenta("constrained", make_oracle(), q0, z)
+        mom = None if device else p0
+        p0 = p0 if device else mom.p0
         return dict(name="c5 DenseConstrainedEuclideanMetricSystem (README torus) + "
                          "ConstrainedLeapfrogIntegrator (Newton)", dim=dim, h=h, traj=traj, integ=integ,
-                    system=system, make_oracle=make_oracle, q0=q0, p0=p0, bytes_per_chain_step=32.0 * dim,
+                    system=system, make_oracle=make_oracle, q0=q0, p0=p0, momenta=mom, bytes_per_chain_step=32.0 * dim,
                     flops_per_chain_step=1500.0, bound="hbm", kind="constrained")
     raise SystemExit(f"unknown --config {config}")
 
 
-def cpu_baseline(w, budget_s=20.0):
-    """The NumPy oracle (vectorised over chains, BLAS threads as configured) timed on a bounded
-    sample of the same workload on this box's host cores."""
+
+DEFAULT_CHAINS = {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048}  # per GPU; everything else 4096
+EXTRA_CONFIGS = ("c2i", "c2iv", "c3", "c3b", "c4", "c5")
+# pass counts of the extra configs are capped (a c3(b) pass is ~1 s, a c4 pass ~0.1-0.3 s)
+EXTRA_STEP_CAP = {"c3b": 5, "c4": 10}
+BASELINE_CONFIG = {"c2": "BASELINE.json configs[1]", "c2i": "BASELINE.json configs[1] (iso-Gaussian variant, SURVEY 8d c2(i))",
+                   "c2iv": "BASELINE.json configs[1] (dense-metric variant, SURVEY 8d c2(iv))",
+                   "c3": "BASELINE.json configs[2] (Cholesky path)", "c3b": "BASELINE.json configs[2] (SoftAbs path)",
+                   "c4": "BASELINE.json configs[3] (per-GPU shard)", "c5": "BASELINE.json configs[4] (per-GPU shard)"}
+
+
+# ---- CPU baseline: the oracle on this box's host cores ------------
+def _cpu_shard_euclid(job):
+    """Pool worker: vectorised-over-chains oracle on one shard of chains."""
+    osys, q, p, h, steps, coefs = job
+    from oracle import integrators as orc
+    t0 = time.perf_counter()
+    if coefs is not None:
+        orc.leapfrog_steps_batch(osys, q, p, h, steps, coefficients=list(coefs))
+    else:
+        orc.leapfrog_steps_batch(osys, q, p, h, steps)
+    return q.shape[0] * steps, time.perf_counter() - t0
+
+
+def _cpu_shard_chains(job):
+    """Pool worker: per-chain oracle (how the reference itself runs) on a few chains."""
+    osys, kind, q, p, h, steps = job
+    from oracle import integrators as orc
+    fn = orc.constrained_leapfrog_steps if kind == "constrained" else orc.implicit_leapfrog_steps
+    done = 0
+    t0 = time.perf_counter()
+    for c in range(q.shape[0]):
+        done += fn(osys, q[c], p[c], h, steps)[3]
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline_measure(config, budget_s):
+    """Runs in its own interpreter (see cpu_baseline): 1 BLAS thread per process, no HIP anywhere.
+    (a) reference-style: one chain at a time on one core; (c) sharded over all host cores with a process pool."""
+    import multiprocessing as mp
+
     from oracle import integrators as orc
 
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = DEFAULT_CHAINS.get(config, 4096)
+    w = make_workload(config, n, np.random.default_rng(1234), device=False)
     osys = w["make_oracle"]()
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    if w["kind"] != "euclid":
-        # per-chain NumPy oracle (how the reference itself runs: one chain at a time, one core)
-        fn = orc.constrained_leapfrog_steps if w["kind"] == "constrained" else orc.implicit_leapfrog_steps
-        steps = {"riemann": 5, "softabs": 3, "constrained": 50}[w["kind"]]
-        done, n1 = 0, 0
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < budget_s and n1 < w["q0"].shape[0]:
-            _, _, _, nd = fn(osys, w["q0"][n1], w["p0"][n1], w["h"], steps)
-            done += nd
-            n1 += 1
-        dt = time.perf_counter() - t0
-        return dict(value=done / dt, unit="leapfrog-steps/s", cores=1, kind="port",
-                    sample=f"oracle per-chain NumPy: {n1} chains x {steps} steps of the same workload "
-                           f"in {dt:.1f} s (1 thread; BLAS single-threaded at these sizes)")
-    n, steps = w["q0"].shape[0], 20
     coefs = w.get("coefficients")
-    if coefs is not None:
-        import functools
-        orc_batch = functools.partial(orc.leapfrog_steps_batch, coefficients=list(coefs))
-        orc_single = lambda s_, q_, p_, h_, n_: orc.composition_steps(  # noqa: E731
-            s_, q_, p_, h_, n_, list(coefs)[:(len(coefs) - 3) // 2])
+    out = dict(unit="leapfrog-steps/s", cores=cores, kind="port")
+    if w["kind"] == "euclid":
+        if coefs is not None:
+            free = list(coefs)[:(len(coefs) - 3) // 2]
+            single_fn = lambda q_, p_, n_: orc.composition_steps(osys, q_, p_, w["h"], n_, free)  # noqa: E731
+        else:
+            single_fn = lambda q_, p_, n_: orc.leapfrog_steps(osys, q_, p_, w["h"], n_)  # noqa: E731
+        t0, n1 = time.perf_counter(), 0
+        while time.perf_counter() - t0 < min(2.0, budget_s / 4):
+            single_fn(w["q0"][n1 % n], w["p0"][n1 % n], 100)
+            n1 += 1
+        single = n1 * 100 / (time.perf_counter() - t0)
+        # calibrate the vectorised shard, then give every core ~budget_s/2 of work
+        shard = max(1, n // cores)
+        _, dt = _cpu_shard_euclid((osys, w["q0"][:shard], w["p0"][:shard], w["h"], 5, coefs))
+        steps = int(max(5, min(w["traj"], 5 * (budget_s / 2) / max(dt, 1e-6))))
+        jobs = [(osys, w["q0"][r * shard:(r + 1) * shard], w["p0"][r * shard:(r + 1) * shard], w["h"], steps, coefs)
+                for r in range(cores)]
+        sample = (f"oracle.leapfrog_steps_batch (NumPy, vectorised over chains): {cores} workers x {shard} chains x "
+                  f"{steps} steps of the same workload")
+        worker = _cpu_shard_euclid
     else:
-        orc_batch, orc_single = orc.leapfrog_steps_batch, orc.leapfrog_steps
+        steps = {"riemann": 2 if w["dim"] > 128 else 5, "softabs": 3, "constrained": 50}[w["kind"]]
+        fn = orc.constrained_leapfrog_steps if w["kind"] == "constrained" else orc.implicit_leapfrog_steps
+        n_single = min(n // 2, 64)
+        w["momenta"].fix(0, n_single)
+        t0, n1, done = time.perf_counter(), 0, 0
+        while time.perf_counter() - t0 < budget_s / 4 and n1 < n_single:
+            done += fn(osys, w["q0"][n1], w["p0"][n1], w["h"], steps)[3]
+            n1 += 1
+        dt1 = time.perf_counter() - t0
+        single = done / dt1
+        per_chain = dt1 / max(n1, 1)
+        k = int(max(1, min((n - n1) // cores, (budget_s / 2) / max(per_chain, 1e-6))))
+        w["momenta"].fix(n1, n1 + cores * k)
+        jobs = [(osys, w["kind"], w["q0"][n1 + r * k:n1 + (r + 1) * k], w["p0"][n1 + r * k:n1 + (r + 1) * k],
+                 w["h"], steps) for r in range(cores)]
+        jobs = [j for j in jobs if j[2].shape[0] > 0]
+        sample = (f"oracle per-chain NumPy (reference style): {len(jobs)} workers x {k} chains x {steps} steps of the "
+                  "same workload")
+        worker = _cpu_shard_chains
     t0 = time.perf_counter()
-    orc_batch(osys, w["q0"], w["p0"], w["h"], steps)
-    dt = time.perf_counter() - t0
-    # scale the sample to ~budget_s of CPU work, capped at the real trajectory length
-    steps2 = int(min(w["traj"], max(steps, steps * budget_s / max(dt, 1e-6))))
-    t0 = time.perf_counter()
-    orc_batch(osys, w["q0"], w["p0"], w["h"], steps2)
-    dt = time.perf_counter() - t0
-    value = n * steps2 / dt
-    # reference-style figure: one chain at a time on one core
-    t0 = time.perf_counter()
-    n1 = 0
-    while time.perf_counter() - t0 < 2.0:
-        orc_single(osys, w["q0"][n1 % n], w["p0"][n1 % n], w["h"], 100)
-        n1 += 1
-    single = n1 * 100 / (time.perf_counter() - t0)
-    return dict(value=value, unit="leapfrog-steps/s", cores=int(cores), kind="port",
-                sample=f"oracle.leapfrog_steps_batch (NumPy, vectorised over chains): {n} chains x "
-                       f"{steps2} steps of the same workload in {dt:.1f} s",
-                single_chain_1core=single)
+    with mp.get_context("fork").Pool(len(jobs)) as pool:
+        res = pool.map(worker, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
+    total = float(sum(r[0] for r in res))
+    out.update(value=total / wall, sample=sample + f" in {wall:.1f} s wall (process pool, 1 BLAS thread per worker)",
+               single_chain_1core=single)
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2")
-    ap.add_argument("--chains-per-gpu", type=int, default=None)
-    ap.add_argument("--traj-len", type=int, default=None)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def cpu_baseline(config, budget_s=16.0):
+    """CPU baseline of one config in a SEPARATE interpreter (the pool forks; this process holds HIP state) under a
+    hard timeout, so that a wedged pool cannot cost the bench its result line.  Adds the reference-equivalent
+    figure: the 1-core oracle rate x the reference/oracle ratio measured in the build container
+    (profiles/cpu_calibration.json, tools/calibrate_cpu_baseline.py)."""
+    env = dict(os.environ)
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        env[k] = "1"
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", config, "--cpu-budget", str(budget_s)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=4 * budget_s + 60)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return dict(value=None, unit="leapfrog-steps/s", cores=0, kind="port",
+                        sample=f"cpu baseline worker failed (rc={r.returncode}): {r.stderr[-300:]}")
+        out = json.loads(line[-1])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="leapfrog-steps/s", cores=0, kind="port",
+                    sample=f"cpu baseline worker timed out after {4 * budget_s + 60:.0f} s")
+    cal = os.path.join(ROOT, "profiles", "cpu_calibration.json")
+    if os.path.exists(cal):
+        with open(cal) as fh:
+            ratio = json.load(fh).get("reference_over_oracle", {}).get(config)
+        if ratio:
+            out["reference_equiv"] = dict(
+                value=out["single_chain_1core"] * ratio, unit="leapfrog-steps/s per core",
+                note=f"1-core per-chain oracle rate x {ratio:.3f} (reference/oracle speed ratio measured with the "
+                     "imported reference in the build container, profiles/cpu_calibration.json)")
+    return out
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    dist = None
-    if world > 1:
-        import torch  # plumbing only: rendezvous, barrier, max-over-ranks (CPU tensors over gloo)
-        import torch.distributed as dist
-
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-
+# ---- one config, measured ---------------------------------------------------------------------------------------
+def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=None, traj_len=None,
+               gather_mode="off"):
+    """W warm-up passes, then exactly `steps` timed passes between (device sync + rank barrier) pairs.
+    Returns the result dict of this config (identical on every rank)."""
     from mici_amd import _ffi
-    from mici_amd.runtime import Context, DeviceBatch
+    from mici_amd.runtime import DeviceBatch
 
-    ctx = Context(local_rank)
-    n_local = args.chains_per_gpu or {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048}.get(args.config, 4096)
+    n_local = chains_per_gpu or DEFAULT_CHAINS.get(config, 4096)
     rng = np.random.default_rng(1234 + rank)
-    w = make_workload(args.config, n_local, rng)
-    traj = args.traj_len or w["traj"]
+    w = make_workload(config, n_local, rng)
+    traj = traj_len or w["traj"]
     integ = w["integ"]
-
     batch = DeviceBatch(ctx, n_local, w["dim"])
     dirs = np.ones(n_local, dtype=np.int8)
 
-    # optional RCCL communicator for the per-trajectory trace gather
     comm = None
-    gather_mode = "none"
     pos_all = None
-    if world > 1:
-        import ctypes as C
-        import torch
-
-        gather_mode = os.environ.get("MICI_AMD_BENCH_GATHER", "off")
-        in_loop = gather_mode in ("rccl", "gloo-host")
-
-        def setup_comm():
-            idbuf = torch.zeros(_ffi.MM_COMM_ID_BYTES, dtype=torch.uint8)
-            if rank == 0:
-                raw = (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)()
-                _ffi.check(ctx._lib.mm_comm_unique_id(raw), None, "mm_comm_unique_id")
-                idbuf = torch.tensor(list(raw), dtype=torch.uint8)
-            dist.broadcast(idbuf, src=0)
-            raw = (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)(*idbuf.tolist())
-            h = C.c_void_p()
-            _ffi.check(ctx._lib.mm_comm_create(ctx.handle, world, rank, raw, C.byref(h)),
-                       ctx.handle, "mm_comm_create")
-            return h, np.empty((world * n_local, w["dim"]))
-
-        if gather_mode == "rccl":
-            try:
-                comm, pos_all = setup_comm()
-            except Exception as e:  # keep the scaling run alive, but say so in the JSON line
-                print(f"[bench] RCCL gather unavailable ({e}); falling back to host gather",
-                      file=sys.stderr)
-                gather_mode = "gloo-host"
-
+    in_loop = world > 1 and gather_mode == "rccl"
     want_host = 1 if rank == 0 else 0  # only the trace-writing rank needs the gathered array on the host
 
+    def setup_comm():
+        import ctypes as C
+
+        from mici_amd import distributed as mdist
+        raw = mdist.exchange_unique_id(ctx, rdzv)
+        h = C.c_void_p()
+        _ffi.check(ctx._lib.mm_comm_create(ctx.handle, world, rank, raw, C.byref(h)), ctx.handle, "mm_comm_create")
+        return h, np.empty((world * n_local, w["dim"]))
+
+    if in_loop:
+        comm, pos_all = setup_comm()
+
     def collect_traces():
-        """Trace collection, once per trajectory: RCCL all-gather over xGMI on the communicator's own
-        stream (overlapped with the next trajectory), pinned host copy on rank 0 only."""
-        if comm is not None:
-            _ffi.check(ctx._lib.mm_comm_allgather_pos_async(comm, batch.handle, want_host),
-                       ctx.handle, "mm_comm_allgather_pos_async")
-        elif gather_mode == "gloo-host":
-            import torch
-            q, _, _ = batch.download()
-            out = [torch.empty_like(torch.from_numpy(q)) for _ in range(world)]
-            dist.all_gather(out, torch.from_numpy(q))
+        _ffi.check(ctx._lib.mm_comm_allgather_pos_async(comm, batch.handle, want_host), ctx.handle,
+                   "mm_comm_allgather_pos_async")
 
     def finish_traces():
-        if comm is not None:
-            _ffi.check(ctx._lib.mm_comm_wait(
-                comm, pos_all.ctypes.data_as(_ffi.c_double_p) if want_host else None),
-                ctx.handle, "mm_comm_wait")
-
-    in_loop = world > 1 and gather_mode in ("rccl", "gloo-host")
-
-    def one_pass():
-        integ.step_device(batch, traj, ctx)
-        if in_loop:
-            collect_traces()
+        _ffi.check(ctx._lib.mm_comm_wait(comm, pos_all.ctypes.data_as(_ffi.c_double_p) if want_host else None),
+                   ctx.handle, "mm_comm_wait")
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            dist.barrier()
+        if rdzv is not None:
+            rdzv.barrier()
 
     batch.upload(w["q0"], w["p0"], dirs)
-    for _ in range(args.warmup):
-        one_pass()
+    for _ in range(warmup):
+        integ.step_device(batch, traj, ctx)
+        if in_loop:
+            collect_traces()
     if in_loop:
         finish_traces()
     batch.upload(w["q0"], w["p0"], dirs)  # timed region starts from the same resident state
@@ -323,7 +392,7 @@ def main():
     per_launch_events = w["kind"] != "euclid"
     if not per_launch_events:
         ctx.record(0)
-    for k in range(args.steps):
+    for k in range(steps):
         s = (k % n_pairs) * 2
         if per_launch_events:
             if k >= n_pairs:
@@ -346,30 +415,21 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if per_launch_events:
-        for k in range(max(0, args.steps - n_pairs), args.steps):  # the launches whose events were not read yet
+        for k in range(max(0, steps - n_pairs), steps):  # the launches whose events were not read yet
             s = (k % n_pairs) * 2
             kernel_ms += ctx.elapsed_ms(s, s + 1)
     else:
         kernel_ms = ctx.elapsed_ms(0, 1)  # K launches back to back
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    done_local = float(n_local) * traj * args.steps if w["kind"] == "euclid" else done_acc
+    done_local = float(n_local) * traj * steps if w["kind"] == "euclid" else done_acc
     total_steps = done_local
-    if dist is not None:
-        import torch
-        t = torch.tensor([done_local], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        total_steps = float(t.item())
+    if rdzv is not None:
+        elapsed = rdzv.reduce_max(elapsed)
+        total_steps = rdzv.reduce_sum(done_local)
 
     # The job's one collective, timed on its own AFTER the timed region (communicator creation included in
     # neither).  Guarded by a timeout: a wedged RCCL bootstrap must not cost the scaling run its result line.
-    trace_gather_ms = None
-    exit_hard = False
-    if world > 1 and not in_loop:
+    trace_gather_ms, gather_note, exit_hard = None, "none", False
+    if world > 1 and gather_mode == "after":
         import threading
         box = {}
 
@@ -377,14 +437,14 @@ def main():
             nonlocal comm, pos_all
             try:
                 comm, pos_all = setup_comm()
-                for rep in range(2):  # first gather warms the rings up
+                for _rep in range(2):  # first gather warms the rings up
                     barrier()
                     tg = time.perf_counter()
                     collect_traces()
                     finish_traces()
                     barrier()
                     box["ms"] = (time.perf_counter() - tg) * 1e3
-                box["mode"] = "rccl, outside the timed region"
+                box["mode"] = "rccl all-gather over xGMI, outside the timed region"
             except Exception as e:
                 box["mode"] = f"rccl unavailable ({type(e).__name__}: {str(e)[:160]})"
 
@@ -392,102 +452,191 @@ def main():
         th.start()
         th.join(timeout=90.0)
         if th.is_alive():
-            gather_mode, exit_hard = "rccl bootstrap timed out", True
+            gather_note, exit_hard = "rccl bootstrap timed out", True
         else:
-            gather_mode, trace_gather_ms = box.get("mode", "?"), box.get("ms")
+            gather_note, trace_gather_ms = box.get("mode", "?"), box.get("ms")
+    elif in_loop:
+        gather_note = "rccl all-gather per pass, inside the timed region"
 
-    if rank == 0:
-        value = total_steps / elapsed
-        launch_s = kernel_ms / 1e3 / args.steps
-        chain_steps_per_launch = n_local * traj
-        if w["kind"] == "softabs":
-            # algorithmic flops: n_eig * 9 D^3 (symmetric eigendecomposition
-            # with vectors) + 4 D^3 per momentum-solve evaluation (grad_quadratic_form_inv's two GEMMs)
-            d = float(w["dim"])
-            n_m = counters_acc.get("n_metric", 0)
-            n_b = max(counters_acc.get("n_fp_evals", 0) - n_m, 0)
-            flops_total = n_m * 9 * d**3 + n_b * 4 * d**3
-            w["flops_per_chain_step"] = flops_total / max(done_local, 1.0)
-            chain_steps_per_launch = done_local / args.steps
-        if w["kind"] == "riemann":
-            # algorithmic flops of SURVEY.md section 8d from the device work counters:
-            #   n_M D^3/3 (factorisations) + n_inv 2D^3/3 (one explicit inverse per completed step)
-            #   + (2 n_M + 3 n_B) D^2 (solves / mat-vecs / outer products), n_B = momentum-solve evals
-            d = float(w["dim"])
-            n_m = counters_acc.get("n_metric", 0)
-            n_b = max(counters_acc.get("n_fp_evals", 0) - n_m, 0)
-            flops_total = n_m * d**3 / 3 + done_local * 2 * d**3 / 3 + (2 * n_m + 3 * n_b) * d * d
-            w["flops_per_chain_step"] = flops_total / max(done_local, 1.0)
-            chain_steps_per_launch = done_local / args.steps
-        if w["bound"] == "mfma":
-            achieved = w["flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
-            roof = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
-                        frac=achieved / FP64_MFMA_PEAK_TF, traffic=None)
-        else:
-            # a launch integrates the whole trajectory with the chain state in registers: the algorithmic HBM
-            # traffic is one read and one write of (pos, mom) per chain per LAUNCH, not per step
-            achieved = w["bytes_per_chain_step"] * n_local / launch_s / 1e9
-            roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None)
-            if w.get("flops_per_chain_step"):  # what actually limits these kernels: FP64 vector issue
-                tf = w["flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
-                roof["fp64_valu"] = dict(achieved=tf, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
-                                         frac=tf / FP64_MFMA_PEAK_TF)
-        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-        # (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process); null when not profiled
-        pmc_name = "r01_c2_pmc_hbm.json" if args.config == "c2" else f"r01b_{args.config}_pmc_hbm.json"
+    launch_s = kernel_ms / 1e3 / steps
+    chain_steps_per_launch = n_local * traj
+    d = float(w["dim"])
+    if w["kind"] == "softabs":
+        # algorithmic flops: n_eig * 9 D^3 (symmetric eigendecomposition
+        # with vectors) + 4 D^3 per momentum-solve evaluation (grad_quadratic_form_inv's two GEMMs)
+        n_m = counters_acc.get("n_metric", 0)
+        n_b = max(counters_acc.get("n_fp_evals", 0) - n_m, 0)
+        w["flops_per_chain_step"] = (n_m * 9 * d**3 + n_b * 4 * d**3) / max(done_local, 1.0)
+        chain_steps_per_launch = done_local / steps
+    if w["kind"] == "riemann":
+        # algorithmic flops of SURVEY.md section 8d from the device work counters:
+        #   n_M D^3/3 (factorisations) + n_inv 2D^3/3 (one explicit inverse per completed step)
+        #   + (2 n_M + 3 n_B) D^2 (solves / mat-vecs / outer products), n_B = momentum-solve evals
+        n_m = counters_acc.get("n_metric", 0)
+        n_b = max(counters_acc.get("n_fp_evals", 0) - n_m, 0)
+        w["flops_per_chain_step"] = (n_m * d**3 / 3 + done_local * 2 * d**3 / 3 + (2 * n_m + 3 * n_b) * d * d) \
+            / max(done_local, 1.0)
+        chain_steps_per_launch = done_local / steps
+    if w["bound"] == "mfma":
+        achieved = w["flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
+        roof = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                    frac=achieved / FP64_MFMA_PEAK_TF, traffic=None)
+    else:
+        # a launch integrates the whole trajectory with the chain state in registers: the algorithmic HBM
+        # traffic is one read and one write of (pos, mom) per chain per LAUNCH, not per step
+        achieved = w["bytes_per_chain_step"] * n_local / launch_s / 1e9
+        roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS, traffic=None)
+        if w.get("flops_per_chain_step"):  # what actually limits these kernels: FP64 vector issue
+            tf = w["flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
+            roof["fp64_valu"] = dict(achieved=tf, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s", frac=tf / FP64_MFMA_PEAK_TF)
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE /
+    # WRITE_SIZE cannot be read from inside the process); null when this shape was not profiled
+    default_shape = chains_per_gpu is None and traj_len is None
+    for pmc_name in (f"r02_{config}_pmc_hbm.json", "r01_c2_pmc_hbm.json" if config == "c2" else f"r01b_{config}_pmc_hbm.json"):
         pmc = os.path.join(ROOT, "profiles", pmc_name)
-        default_shape = args.chains_per_gpu is None and args.traj_len is None
         if default_shape and os.path.exists(pmc):
             with open(pmc) as fh:
                 roof["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
             roof["traffic_source"] = f"profiles/{pmc_name} (rocprofv3 --pmc, corrected)"
-        roof["kernel_ms_per_launch"] = kernel_ms / args.steps
-        roof["algorithmic_flops_per_chain_step"] = w["flops_per_chain_step"]
-        roof["algorithmic_bytes_per_chain_step"] = w["bytes_per_chain_step"] / (traj if w["bound"] == "hbm" else 1)
-        if counters_acc:
-            roof["work_counters"] = counters_acc
+            break
+    roof["kernel_ms_per_launch"] = kernel_ms / steps
+    roof["algorithmic_flops_per_chain_step"] = w["flops_per_chain_step"]
+    roof["algorithmic_bytes_per_chain_step"] = w["bytes_per_chain_step"] / (traj if w["bound"] == "hbm" else 1)
+    if counters_acc:
+        roof["work_counters"] = counters_acc
+
+    if comm is not None and not exit_hard:
+        ctx._lib.mm_comm_destroy(comm)
+    batch.close()
+    return dict(
+        value=total_steps / elapsed, unit="leapfrog-steps/s", steps=steps, warmup=warmup,
+        ms_per_step=elapsed / steps * 1e3, roofline=roof,
+        workload=f"{w['name']}, D={w['dim']}, {n_local} chains/GPU x {world} GPU, h={w['h']}, one pass = a trajectory "
+                 f"of {traj} leapfrog steps per chain",
+        baseline_config=BASELINE_CONFIG.get(config, config), chains_per_gpu=n_local, dim=w["dim"], traj_len=traj,
+        trace_gather=gather_note, trace_gather_ms=trace_gather_ms, _exit_hard=exit_hard)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2")
+    ap.add_argument("--chains-per-gpu", type=int, default=None)
+    ap.add_argument("--traj-len", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="only the --config workload (no `configs` object)")
+    ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=16.0, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    if args.cpu_baseline_worker:  # child interpreter of cpu_baseline(): no HIP in here
+        print(json.dumps(cpu_baseline_measure(args.cpu_baseline_worker, args.cpu_budget)), flush=True)
+        return
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if env_world is None and args.gpus > 1:
+        # started plainly: be the launcher.  One rank process per GPU, rendezvous over a Unix socket; the ranks
+        # check the device count together once they have met and all fail if the box has fewer than N devices.
+        from mici_amd.rendezvous import spawn_ranks
+        codes = spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        if any(codes):
+            print(f"bench.py --gpus {args.gpus}: rank exit codes {codes}", file=sys.stderr)
+        raise SystemExit(max(abs(c) for c in codes))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import ctypes as C
+
+    from mici_amd import _ffi
+    from mici_amd.rendezvous import Rendezvous
+    from mici_amd.runtime import Context
+
+    rdzv = Rendezvous.from_env() if world > 1 else None
+    count = C.c_int(0)
+    n_dev = count.value if _ffi.load().mm_device_count(C.byref(count)) == 0 else 0
+    if rdzv is not None:  # every rank learns the smallest count: all leave together, none waits in a collective
+        n_dev = int(min(int(x) for x in rdzv.allgather(str(n_dev).encode())))
+    if n_dev < world or n_dev <= local_rank:
+        if rdzv is not None:
+            rdzv.close()
+        raise SystemExit(f"bench.py --gpus {world}: rank {rank} needs HIP device {local_rank} but only {n_dev} HIP "
+                         "device(s) are visible (one process per GPU, no oversubscription, no CPU fallback)")
+    ctx = Context(local_rank)
+
+    gather_mode = "off"
+    if world > 1:
+        gather_mode = "rccl" if os.environ.get("MICI_AMD_BENCH_GATHER", "") == "rccl" else "after"
+    head = run_config(ctx, rdzv, args.config, args.steps, args.warmup, rank, world, args.chains_per_gpu,
+                      args.traj_len, gather_mode)
+    exit_hard = head.pop("_exit_hard")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        head["cpu_baseline"] = cpu_baseline(args.config, 20.0)
+
+    configs = {}
+    default_shape = args.chains_per_gpu is None and args.traj_len is None
+    if not args.no_extra_configs and args.config == "c2" and default_shape and not exit_hard:
+        for cfg in EXTRA_CONFIGS:
+            k = min(args.steps, EXTRA_STEP_CAP.get(cfg, args.steps))
+            wu = min(args.warmup, 1 if cfg in EXTRA_STEP_CAP else args.warmup)
+            try:
+                res = run_config(ctx, rdzv, cfg, k, wu, rank, world)
+            except Exception as e:  # keep the headline line alive; every rank fails the same way
+                configs[cfg] = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
+                continue
+            res.pop("_exit_hard")
+            for key in ("trace_gather", "trace_gather_ms"):
+                res.pop(key)
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(cfg, 8.0)
+            configs[cfg] = res
+
+    if rank == 0:
         out = {
             "metric": "leapfrog-steps/sec (all chains)",
-            "value": value,
+            "value": head["value"],
             "unit": "leapfrog-steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{w['name']}, D={w['dim']}, {n_local} chains/GPU x {world} GPU, "
-                            f"h={w['h']}, one pass = a trajectory of {traj} leapfrog steps per chain",
-                "baseline_config": {"c2": "BASELINE.json configs[1]", "c3": "BASELINE.json configs[2] (Cholesky path)",
-                                    "c3b": "BASELINE.json configs[2] (SoftAbs path)",
-                                    "c4": "BASELINE.json configs[3] (per-GPU shard)",
-                                    "c5": "BASELINE.json configs[4] (per-GPU shard)"}.get(args.config, args.config),
-                "chains_per_gpu": n_local, "dim": w["dim"], "traj_len": traj,
-                "parallelism": f"chains sharded x{world}, no collective in the timed region"
-                               if not in_loop else f"chains sharded x{world}, trace gather per pass: {gather_mode}",
-                "trace_gather": gather_mode if world > 1 else "none",
-                "trace_gather_ms": trace_gather_ms,
+                "workload": head["workload"],
+                "baseline_config": head["baseline_config"],
+                "chains_per_gpu": head["chains_per_gpu"], "dim": head["dim"], "traj_len": head["traj_len"],
+                "parallelism": f"chains sharded x{world}, one process per GPU, no collective in the timed region"
+                               if gather_mode != "rccl" else f"chains sharded x{world}, RCCL trace gather per pass",
+                "trace_gather": head["trace_gather"],
+                "trace_gather_ms": head["trace_gather_ms"],
             },
-            "roofline": roof,
+            "roofline": head["roofline"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w)
+        if "cpu_baseline" in head:
+            out["cpu_baseline"] = head["cpu_baseline"]
+        if configs:
+            out["configs"] = configs
         print(json.dumps(out), flush=True)
 
     if exit_hard:  # a collective is wedged in the helper thread: the result line is out, leave without cleanup
         sys.stdout.flush()
         os._exit(0)
-    if comm is not None:
-        ctx._lib.mm_comm_destroy(comm)
-    batch.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
 
 
 if __name__ == "__main__":

@@ -86,6 +86,12 @@ class DualAveragingStepSizeAdapter:
                 _ffi.check(ctx._lib.mm_state_copy(trial.handle, batch.handle), ctx.handle, "mm_state_copy")
                 integrator.step_device(trial, 1, ctx)
                 status, _ = integrator._status(trial, 1)
+                if np.any(status == 5):
+                    # a LinAlgError outside a solver is not an IntegratorError: the reference's search only
+                    # catches IntegratorError (adapters.py:326-331), so it propagates (as in propose_batch)
+                    from .errors import LinAlgError
+                    raise LinAlgError("metric construction failed outside a solver for chain(s) "
+                                      f"{np.flatnonzero(status == 5).tolist()}")
                 failed = status != 0
                 with np.errstate(invalid="ignore"):
                     delta_h = np.abs(h_init - self._hamiltonians(system, trial, ctx))

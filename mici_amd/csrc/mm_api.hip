@@ -484,6 +484,7 @@ int mm_state_free(mm_state* s) {
 int mm_state_upload(mm_state* s, const double* pos, const double* mom, const int8_t* dir) {
   MM_REQUIRE(nullptr, s != nullptr, "mm_state_upload: state is NULL");
   mm_ctx* ctx = s->ctx;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a process may own contexts on several GPUs
   if (s->n == 0) return MM_OK;
   const size_t nd = (size_t)s->n * s->dim;
   if (dir)
@@ -520,6 +521,7 @@ int mm_state_download_all(mm_state* s, double* pos, double* mom, int8_t* dir, in
 int mm_state_download(mm_state* s, double* pos, double* mom, int8_t* dir) {
   MM_REQUIRE(nullptr, s != nullptr, "mm_state_download: state is NULL");
   mm_ctx* ctx = s->ctx;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a process may own contexts on several GPUs
   if (s->n == 0) return MM_OK;
   const size_t nd = (size_t)s->n * s->dim;
   if (s->mapped) return mm_state_download_all(s, pos, mom, dir, nullptr, nullptr);
@@ -533,6 +535,7 @@ int mm_state_download(mm_state* s, double* pos, double* mom, int8_t* dir) {
 int mm_state_download_all(mm_state* s, double* pos, double* mom, int8_t* dir, int32_t* status, int32_t* n_done) {
   MM_REQUIRE(nullptr, s != nullptr, "mm_state_download_all: state is NULL");
   mm_ctx* ctx = s->ctx;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a process may own contexts on several GPUs
   if (s->n == 0) return MM_OK;
   const size_t nd = (size_t)s->n * s->dim;
   if (s->mapped) {
@@ -561,6 +564,7 @@ int mm_state_download_all(mm_state* s, double* pos, double* mom, int8_t* dir, in
 int mm_state_download_status(mm_state* s, int32_t* status, int32_t* n_done) {
   MM_REQUIRE(nullptr, s != nullptr, "mm_state_download_status: state is NULL");
   mm_ctx* ctx = s->ctx;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a process may own contexts on several GPUs
   if (s->n == 0) return MM_OK;
   if (s->mapped) return mm_state_download_all(s, nullptr, nullptr, nullptr, status, n_done);
   if (status) MM_HIP_CHECK(ctx, hipMemcpyAsync(status, s->d_status, (size_t)s->n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -604,6 +608,7 @@ int mm_state_copy(mm_state* dst, const mm_state* src) {
 int mm_state_set_chain_steps(mm_state* s, const int32_t* steps) {
   MM_REQUIRE(nullptr, s != nullptr, "mm_state_set_chain_steps: state is NULL");
   mm_ctx* ctx = s->ctx;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a process may own contexts on several GPUs
   MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (!steps) {
     (void)hipFree(s->d_chain_steps);

@@ -5,7 +5,8 @@ handed out through queues and traces collected through per-chain ``.npy`` memmap
 (reference samplers.py:546-565, 668-772, 104-138).  Here each rank (one process per GPU) owns a
 contiguous shard of the chains; there is no communication during integration; trace collection is
 one all-gather of the shard positions - RCCL over xGMI on device buffers (``RcclTraceGather``) or,
-for host arrays / CPU tests, any ``torch.distributed`` group (``gather_host``).
+for host arrays, the standard-library rendezvous of ``mici_amd.rendezvous`` (``gather_host``; a
+``torch.distributed`` group is accepted too, for callers already inside such a job).
 
 Shards are padded to equal length (the collective needs equal counts); padding rows are dropped
 again after the gather."""
@@ -59,29 +60,46 @@ def unpad_gathered(gathered, n_chains, world_size):
     return np.concatenate(parts, axis=0)
 
 
+def _is_rendezvous(group):
+    from .rendezvous import Rendezvous
+
+    return isinstance(group, Rendezvous)
+
+
 def gather_host(local, n_chains, group=None):
-    """All-gather padded host shards through torch.distributed (any backend; gloo in the CPU
-    tests) and return the un-padded global array on every rank."""
+    """All-gather padded host shards and return the un-padded global array on every rank.  ``group`` is a
+    :class:`mici_amd.rendezvous.Rendezvous` (the product path: standard library only) or, for callers that
+    already live inside a ``torch.distributed`` job, a torch process group / ``None`` for its default group."""
+    local = np.ascontiguousarray(local)
+    if _is_rendezvous(group):
+        stacked = group.allgather_array(local)
+        return unpad_gathered(stacked.reshape((-1,) + local.shape[1:]), n_chains, group.world)
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    t = torch.from_numpy(np.ascontiguousarray(local))
+    t = torch.from_numpy(local)
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t, group=group)
     return unpad_gathered(np.concatenate([o.numpy() for o in out], axis=0), n_chains, world)
 
 
 def exchange_unique_id(ctx, group=None):
-    """Rank 0 creates the RCCL unique id; it is broadcast as 128 bytes over the host group."""
+    """Rank 0 creates the RCCL unique id; its 128 bytes travel over the host rendezvous (or a torch group)."""
+    def make():
+        raw = (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)()
+        _ffi.check(ctx._lib.mm_comm_unique_id(raw), None, "mm_comm_unique_id")
+        return bytes(raw)
+
+    if _is_rendezvous(group):
+        blob = group.broadcast(make() if group.rank == 0 else None)
+        return (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)(*blob)
     import torch
     import torch.distributed as dist
 
     buf = torch.zeros(_ffi.MM_COMM_ID_BYTES, dtype=torch.uint8)
     if dist.get_rank(group) == 0:
-        raw = (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)()
-        _ffi.check(ctx._lib.mm_comm_unique_id(raw), None, "mm_comm_unique_id")
-        buf = torch.tensor(list(raw), dtype=torch.uint8)
+        buf = torch.tensor(list(make()), dtype=torch.uint8)
     dist.broadcast(buf, src=0, group=group)
     return (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)(*buf.tolist())
 

@@ -60,18 +60,22 @@ class Context:
             pass
 
 
-_default = {}
-_default_lock = threading.Lock()
+_default = threading.local()
 
 
 def default_context(device=None):
-    """Process-wide context per device (created lazily)."""
+    """Default context of the CALLING THREAD for a device (created lazily).  A context owns one stream and one
+    pinned staging buffer and is not thread safe (include/mici_amd.h), while ctypes releases the GIL during calls:
+    the reference's thread-pool chain parallelism (per-chain deep copies of the transitions, each calling
+    ``sample``) must therefore never share one - so the default is one context per (host thread, device)."""
     key = device if device is not None else int(os.environ.get("LOCAL_RANK", "0"))
-    with _default_lock:
-        ctx = _default.get(key)
-        if ctx is None or ctx.handle is None:
-            ctx = _default[key] = Context(key)
-        return ctx
+    table = getattr(_default, "ctxs", None)
+    if table is None:
+        table = _default.ctxs = {}
+    ctx = table.get(key)
+    if ctx is None or ctx.handle is None:
+        ctx = table[key] = Context(key)
+    return ctx
 
 
 class DeviceModel:

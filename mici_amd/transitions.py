@@ -105,6 +105,28 @@ class MetropolisStaticIntegrationTransition:
     def statistic_types(self):
         return self._statistic_types
 
+    # Device handles never travel: the reference's sampler deep-copies its transitions per chain and per stage and
+    # pickles them for process pools (samplers.py:1124-1129); a copy starts without cached device batches and
+    # re-creates them lazily on whatever context its own thread / process uses.
+    _DEVICE_CACHES = ("_proposals", "_one")
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_proposals"] = {}
+        d.pop("_one", None)
+        return d
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = object.__new__(type(self))
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_proposals":
+                new.__dict__[k] = {}
+            elif k != "_one":
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def _proposal_for(self, batch):
         key = (id(batch.ctx), batch.n_chains, batch.dim)
         prop = self._proposals.get(key)

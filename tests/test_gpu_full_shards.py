@@ -1,0 +1,136 @@
+"""GPU parity at the REAL per-GPU shard sizes and trajectory lengths of the BASELINE configs (bench.py's
+workloads, same seeds): scheduling / occupancy dependent defects - a workgroup-level LDS race, a tail-effect
+bug in the last workgroup, drift over a 1000-step fused trajectory - only show at these sizes.
+
+Every config: status / n_done checked on ALL chains, the oracle on a sample of chains that includes the first
+and the last workgroup, and size-independent properties (reversibility after a direction flip; constraint and
+cotangent residuals) on ALL chains.  Tolerances as stated in SURVEY.md section 8c:
+  explicit leapfrog 2e-13 x steps relative; implicit 1e-10 * max(1, |x|) with identical status / n_done;
+  SoftAbs 2e-9 (Jacobi vs LAPACK eigenvectors through the divided differences of grad_quadratic_form_inv)."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_close
+from oracle import integrators as orc
+
+pytestmark = pytest.mark.gpu
+
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _workload(config, n):
+    import bench
+    w = bench.make_workload(config, n, np.random.default_rng(1234))  # rank 0's inputs in bench.py
+    return w, w["make_oracle"]()
+
+
+def _sample(n, rng, per_group):
+    """First and last workgroup (whatever the kernel's chains-per-workgroup is: `per_group` chains at both ends)
+    plus a few chains in between."""
+    return np.unique(np.concatenate([np.arange(per_group), np.arange(n - per_group, n), rng.integers(0, n, 4)]))
+
+
+def test_c2_full_trajectory_matches_oracle():
+    """c2: D=128, 4096 chains, ONE launch of 1000 fused leapfrog steps (what bench.py times)."""
+    n = 4096
+    w, osys = _workload("c2", n)
+    steps = w["traj"]
+    assert steps == 1000
+    dirs = np.ones(n, dtype=np.int8)
+    dirs[1::3] = -1
+    q, p, status, n_done = w["integ"].step_batch(w["q0"], w["p0"], dirs, n_steps=steps)
+    assert np.all(status == 0) and np.all(n_done == steps)
+    rng = np.random.default_rng(5)
+    for c in _sample(n, rng, 3):
+        qo, po = orc.leapfrog_steps(osys, w["q0"][c], w["p0"][c], dirs[c] * w["h"], steps)
+        assert_close(q[c], qo, 2e-13 * steps, f"c2 q chain {c}")
+        assert_close(p[c], po, 2e-13 * steps, f"c2 p chain {c}")
+    # all chains: energy is conserved to O(h^2) over the trajectory and the map is reversible
+    h0, h1 = w["system"].h_batch(w["q0"], w["p0"]), w["system"].h_batch(q, p)
+    assert np.max(np.abs(h1 - h0) / np.maximum(1.0, np.abs(h0))) < 5e-2
+    qb, pb, _, _ = w["integ"].step_batch(q, p, -dirs, n_steps=steps)
+    assert_close(qb, w["q0"], 1e-8, "c2 reversed q")
+    assert_close(pb, w["p0"], 1e-8, "c2 reversed p")
+
+
+def test_c2iv_dense_metric_full_trajectory_matches_oracle():
+    n = 4096
+    w, osys = _workload("c2iv", n)
+    steps = w["traj"]
+    q, p, status, n_done = w["integ"].step_batch(w["q0"], w["p0"], 1, n_steps=steps)
+    assert np.all(status == 0) and np.all(n_done == steps)
+    rng = np.random.default_rng(6)
+    for c in _sample(n, rng, 2):
+        qo, po = orc.leapfrog_steps(osys, w["q0"][c], w["p0"][c], w["h"], steps)
+        assert_close(q[c], qo, 2e-13 * steps, f"c2iv q chain {c}")
+        assert_close(p[c], po, 2e-13 * steps, f"c2iv p chain {c}")
+
+
+@pytest.mark.parametrize("config,steps,tol,per_group", [
+    ("c3", 4, 1e-10, 4),     # c3(a): D=64, 1024 chains, one wave per chain
+    ("c4", 2, 1e-10, 2),     # c4 shard: D=256, 1024 chains, one workgroup (a whole CU) per chain: 4 waves of CUs
+    ("c3b", 2, 2e-9, 2),     # c3(b): SoftAbs D=64, 1024 chains, one 1024-thread workgroup per chain
+])
+def test_riemannian_full_shard_matches_oracle_and_is_reversible(config, steps, tol, per_group):
+    n = 1024
+    w, osys = _workload(config, n)
+    integ = w["integ"]
+    q, p, status, n_done = integ.step_batch(w["q0"], w["p0"], 1, n_steps=steps)
+    counters = dict(integ.last_counters)
+    assert np.all(status == 0), np.flatnonzero(status)[:10]
+    assert np.all(n_done == steps)
+    rng = np.random.default_rng(7)
+    sample = _sample(n, rng, per_group)
+    assert len(sample) >= 8
+    for c in sample:
+        qo, po, so, no = orc.implicit_leapfrog_steps(osys, w["q0"][c], w["p0"][c], w["h"], steps)
+        assert so == 0 and no == steps
+        assert_close(q[c], qo, tol, f"{config} q chain {c}")
+        assert_close(p[c], po, tol, f"{config} p chain {c}")
+    # work counters are sums over ALL chains: they must be in the range the sampled chains imply
+    assert counters["n_fp_solves"] == 4 * n * steps
+    per_chain_evals = counters["n_fp_evals"] / n / steps
+    assert 8 <= per_chain_evals <= 60, per_chain_evals
+    # every chain: reversible (direction flip) and energy-conserving
+    qb, pb, sb, nb = integ.step_batch(q, p, -1, n_steps=steps)
+    assert np.all(sb == 0) and np.all(nb == steps)
+    assert_close(qb, w["q0"], 1e-6, f"{config} reversed q")
+    assert_close(pb, w["p0"], 1e-6, f"{config} reversed p")
+    h0, h1 = w["system"].h_batch(w["q0"], w["p0"]), w["system"].h_batch(q, p)
+    assert np.all(np.isfinite(h1))
+    assert np.max(np.abs(h1 - h0)) < 0.5, np.max(np.abs(h1 - h0))
+    # two launches of `steps` == bitwise the same as themselves (no run-to-run nondeterminism from scheduling)
+    q2, p2, _, _ = integ.step_batch(w["q0"], w["p0"], 1, n_steps=steps)
+    assert np.array_equal(q, q2) and np.array_equal(p, p2)
+
+
+def test_c5_full_shard_trajectory():
+    """c5 shard: torus, 2048 chains x 1000 steps in one launch; the oracle on a sample at 100 steps (the chaotic
+    torus dynamics amplify solver-level differences beyond that), residuals and status on all chains at 1000."""
+    n = 2048
+    w, osys = _workload("c5", n)
+    integ = w["integ"]
+    constr = osys.constraint
+    q, p, status, n_done = integ.step_batch(w["q0"], w["p0"], 1, n_steps=w["traj"])
+    ok = status == 0
+    assert ok.mean() > 0.9
+    assert np.all(n_done[ok] == w["traj"]) and np.all(n_done[~ok] < w["traj"])
+    c = np.array([constr.constr(x)[0] for x in q])  # failed chains are frozen ON the manifold too
+    assert np.max(np.abs(c)) < 1e-8
+    jac = np.stack([constr.jacob_constr(x)[0] for x in q])
+    assert np.max(np.abs(np.sum(jac * p, 1))) < 1e-8
+    q1, p1, s1, n1 = integ.step_batch(w["q0"], w["p0"], 1, n_steps=100)
+    rng = np.random.default_rng(8)
+    for cidx in _sample(n, rng, 4):
+        qo, po, so, no = orc.constrained_leapfrog_steps(osys, w["q0"][cidx], w["p0"][cidx], w["h"], 100)
+        assert so == s1[cidx] and no == n1[cidx]
+        assert_close(q1[cidx], qo, 5e-9, f"c5 q chain {cidx}")
+        assert_close(p1[cidx], po, 5e-9, f"c5 p chain {cidx}")
+    # first-failure bookkeeping is consistent between the two launches
+    early = s1 != 0
+    assert np.array_equal(status[early], s1[early]) and np.array_equal(n_done[early], n1[early])

@@ -37,6 +37,14 @@ from oracle import models as mdl  # noqa: E402
 SEED = 3046987125  # reference tests/test_integrators.py:8
 
 
+def case_rng(name):
+    """Per-case random stream: a case's inputs depend on its NAME only, not on how many cases were registered
+    before it.  Every case added after round 1 draws from here (the round-1 cases keep the shared stream they
+    were recorded with, whose positions are frozen by the registration order below)."""
+    import zlib
+    return np.random.default_rng([SEED, zlib.crc32(name.encode())])
+
+
 def status_of(exc):
     msg = str(exc)
     if isinstance(exc, merr.NonReversibleStepError):
@@ -465,7 +473,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--only", default=None)
+    ap.add_argument("--check", action="store_true",
+                    help="regenerate every case into a temporary directory and compare it with the committed "
+                         "fixture in --out (same keys, shapes, dtypes; values to 1e-11 relative); nothing is written")
     args = ap.parse_args()
+    committed = args.out
+    if args.check:
+        import tempfile
+        tmpdir = tempfile.TemporaryDirectory()
+        args.out = tmpdir.name
     os.makedirs(args.out, exist_ok=True)
     rng = np.random.default_rng(SEED)
     cases = {}
@@ -1025,7 +1041,7 @@ def main():
 
     # ---- dual-averaging step-size adaptation -----------------------------------------
     def add_adapt_euclid(name, target, mk, metric, n, n_step, n_iters, seed0, qscale=1.0):
-        q0 = qscale * rng.standard_normal((n, target.dim))
+        q0 = qscale * case_rng(name).standard_normal((n, target.dim))
 
         def make():
             rsys = mici.systems.EuclideanMetricSystem(
@@ -1037,13 +1053,14 @@ def main():
                               model_keys(target, mk, metric))
         cases[name] = make
 
-    add_adapt_euclid("adapt_euclid_dense_d16", mdl.GaussDense(mdl.make_spd(16, rng)), mdl.METRIC_IDENTITY, None,
-                     5, 4, 40, 8000)
+    add_adapt_euclid("adapt_euclid_dense_d16", mdl.GaussDense(mdl.make_spd(16, case_rng("adapt_euclid_dense_d16/P"))),
+                     mdl.METRIC_IDENTITY, None, 5, 4, 40, 8000)
     add_adapt_euclid("adapt_euclid_quartic_d5_far_start", mdl.Poly(5, 0.0, 1.0), mdl.METRIC_DIAG,
-                     np.exp(0.3 * rng.standard_normal(5)), 5, 3, 40, 9000, qscale=3.0)
+                     np.exp(0.3 * case_rng("adapt_euclid_quartic_d5_far_start/M").standard_normal(5)), 5, 3, 40, 9000,
+                     qscale=3.0)
 
     def add_adapt_riemann(name, target, rmetric, n, n_step, n_iters, seed0):
-        q0 = rng.standard_normal((n, target.dim))
+        q0 = case_rng(name).standard_normal((n, target.dim))
 
         def make():
             rsys = mici.systems.DenseRiemannianMetricSystem(
@@ -1087,15 +1104,52 @@ def main():
     cases["tracefmt_reference"] = make_tracefmt
 
     all_counts = {}
+    n_ok, bad = 0, []
     for name, fn in cases.items():
         if args.only and args.only not in name:
             continue
         data, counts = fn()
-        np.savez_compressed(os.path.join(args.out, name + ".npz"),
-                            **{f"count_{k}": v for k, v in counts.items()}, **data)
+        path = os.path.join(args.out, name + ".npz")
+        np.savez_compressed(path, **{f"count_{k}": v for k, v in counts.items()}, **data)
         all_counts[name] = dict(counts)
         print(f"{name}: ok  status={data['status'].tolist()} n_done={data['n_done'].tolist()} "
               f"counts={dict(counts)}")
+        if args.check:
+            why = compare_fixture(path, os.path.join(committed, name + ".npz"))
+            if why:
+                bad.append((name, why))
+                print(f"   CHECK FAILED {name}: {why}")
+            else:
+                n_ok += 1
+    if args.check:
+        stale = sorted(set(p.stem for p in Path(committed).glob("*.npz")) - set(cases)) if not args.only else []
+        print(f"check: {n_ok}/{n_ok + len(bad)} regenerated cases equal the committed fixtures"
+              + (f"; committed fixtures without a generator case: {stale}" if stale else ""))
+        if bad or stale:
+            raise SystemExit(1)
+
+
+def compare_fixture(new_path, old_path, rtol=1e-11):
+    """Empty string if the regenerated fixture equals the committed one, else the first difference."""
+    if not os.path.exists(old_path):
+        return "no committed fixture"
+    a, b = np.load(new_path, allow_pickle=False), np.load(old_path, allow_pickle=False)
+    if sorted(a.files) != sorted(b.files):
+        return f"keys differ: {sorted(set(a.files) ^ set(b.files))}"
+    for k in a.files:
+        x, y = a[k], b[k]
+        if x.shape != y.shape or x.dtype != y.dtype:
+            return f"{k}: shape/dtype {x.shape}/{x.dtype} vs {y.shape}/{y.dtype}"
+        if x.dtype.kind in "fc":
+            if not np.array_equal(np.isnan(x), np.isnan(y)):
+                return f"{k}: NaN pattern"
+            xx, yy = np.nan_to_num(x), np.nan_to_num(y)
+            err = np.max(np.abs(xx - yy) / np.maximum(1.0, np.abs(yy))) if x.size else 0.0
+            if err > rtol:
+                return f"{k}: max scaled difference {err:.3g}"
+        elif not np.array_equal(x, y):
+            return f"{k}: values differ"
+    return ""
 
 
 if __name__ == "__main__":
