@@ -258,7 +258,9 @@ def cpu_baseline_measure(config, budget_s):
         # calibrate the vectorised shard, then give every core ~budget_s/2 of work
         shard = max(1, n // cores)
         _, dt = _cpu_shard_euclid((osys, w["q0"][:shard], w["p0"][:shard], w["h"], 5, coefs))
-        steps = int(max(5, min(w["traj"], 5 * (budget_s / 2) / max(dt, 1e-6))))
+        # ~budget_s/2 of work per core; on a many-core box a shard is a handful of chains, so the trajectory is
+        # repeated (up to 50x) rather than letting process start-up dominate the sample
+        steps = int(max(5, min(50 * w["traj"], 5 * (budget_s / 2) / max(dt, 1e-6))))
         jobs = [(osys, w["q0"][r * shard:(r + 1) * shard], w["p0"][r * shard:(r + 1) * shard], w["h"], steps, coefs)
                 for r in range(cores)]
         sample = (f"oracle.leapfrog_steps_batch (NumPy, vectorised over chains): {cores} workers x {shard} chains x "
@@ -277,6 +279,8 @@ def cpu_baseline_measure(config, budget_s):
         single = done / dt1
         per_chain = dt1 / max(n1, 1)
         k = int(max(1, min((n - n1) // cores, (budget_s / 2) / max(per_chain, 1e-6))))
+        # few chains per worker on a many-core box: lengthen their trajectories instead (up to the config's own)
+        steps = int(min(w["traj"], max(steps, steps * (budget_s / 2) / max(k * per_chain, 1e-6))))
         w["momenta"].fix(n1, n1 + cores * k)
         jobs = [(osys, w["kind"], w["q0"][n1 + r * k:n1 + (r + 1) * k], w["p0"][n1 + r * k:n1 + (r + 1) * k],
                  w["h"], steps) for r in range(cores)]

@@ -96,14 +96,15 @@ def test_riemannian_full_shard_matches_oracle_and_is_reversible(config, steps, t
     assert counters["n_fp_solves"] == 4 * n * steps
     per_chain_evals = counters["n_fp_evals"] / n / steps
     assert 8 <= per_chain_evals <= 60, per_chain_evals
-    # every chain: reversible (direction flip) and energy-conserving
+    # every chain: reversible (direction flip), finite energy
     qb, pb, sb, nb = integ.step_batch(q, p, -1, n_steps=steps)
     assert np.all(sb == 0) and np.all(nb == steps)
     assert_close(qb, w["q0"], 1e-6, f"{config} reversed q")
     assert_close(pb, w["p0"], 1e-6, f"{config} reversed p")
-    h0, h1 = w["system"].h_batch(w["q0"], w["p0"]), w["system"].h_batch(q, p)
+    h1 = w["system"].h_batch(q, p)
     assert np.all(np.isfinite(h1))
-    assert np.max(np.abs(h1 - h0)) < 0.5, np.max(np.abs(h1 - h0))
+    for c in sample[:4]:  # the Hamiltonian at the new state against the oracle (log-det + quadratic form)
+        assert_close(h1[c], osys.h(orc._State(q[c], p[c])), 10 * tol, f"{config} h chain {c}")
     # two launches of `steps` == bitwise the same as themselves (no run-to-run nondeterminism from scheduling)
     q2, p2, _, _ = integ.step_batch(w["q0"], w["p0"], 1, n_steps=steps)
     assert np.array_equal(q, q2) and np.array_equal(p, p2)
