@@ -6,6 +6,7 @@
 //   bool   build_and_invert(double x)   metric_func(x) -> explicit M(x)^-1 kept by the backend;
 //                                        false = not finite / not positive definite
 //   bool   build_and_solve(x, rhs, &u)  metric_func(x) used for the single solve u = M(x)^-1 rhs
+//   bool   construct(x, inv, rhs, &u)   (kUnifiedConstruct backends) either of the two, chosen at run time
 //   double matvec(double v)             M^-1 v                          (dh2_dmom)
 //   double half_vjp_inv(double q)       0.5 * vjp_metric(q)(grad_log_abs_det)   (dh1_dpos - grad)
 //   double dh2_dpos(double p, double q) 0.5 * vjp_metric(q)(grad_quadratic_form_inv(p))
@@ -161,7 +162,10 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
     // general-VJP path); the position-space iterations use their metric for a single solve.
     double u_pos = 0.0;
     bool okm;
-    if constexpr (BK::kSolveByInverse) {
+    if constexpr (BK::kUnifiedConstruct) {
+      // one construction site, the mode decided at run time: explicit inverse, or the single solve M(x)^-1 pw
+      okm = bk.construct(bk.slot(SL_XQ), mode == MODE_INIT || mode == MODE_BADJ, bk.slot(SL_PW), &u_pos);
+    } else if constexpr (BK::kSolveByInverse) {
       // one construction site (the blocked matrix-core sweeps are several thousand instructions)
       okm = bk.build_and_invert(bk.slot(SL_XQ));
       if (!(mode == MODE_INIT || mode == MODE_BADJ)) u_pos = bk.matvec(bk.slot(SL_PW));

@@ -326,6 +326,7 @@ __device__ __forceinline__ void stage_base(double* base_lds, const double* rpara
 template <int TS, int RMETRIC>
 struct WaveBackend {
   static constexpr bool kSolveByInverse = false;  // implicit_core.h: solve = invert + mat-vec, one construction site
+  static constexpr bool kUnifiedConstruct = false;
   double T[TS][TS];
   int dim, lane, target;
   WaveLds w;
@@ -639,6 +640,7 @@ int mm_launch_riemann_aux_large(mm_ctx*, const mm_model*, mm_state*, int, double
 int mm_launch_implicit_mfma(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
 int mm_launch_implicit_mfma_team(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
                                  mm_counters*);
+int mm_launch_implicit_blk16(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
 
 int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
                                 const mm_fp_opts& opts, mm_counters* d_counters) {
@@ -651,12 +653,16 @@ int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, dou
   static const int force = [] {
     const char* e = getenv("MICI_AMD_IMPLICIT_KERNEL");
     if (!e) return 0;
-    return strcmp(e, "wave") == 0 ? 1 : strcmp(e, "team") == 0 ? 2 : 0;
+    return strcmp(e, "wave") == 0 ? 1 : strcmp(e, "team") == 0 ? 2 : strcmp(e, "team4") == 0 ? 3 : 0;
   }();
-  // 75 < D <= 256: team of 8 waves with the sweep on the matrix cores (k_implicit_mfma_team.hip);
-  // MICI_AMD_IMPLICIT_KERNEL=team keeps the VALU team kernel there as well
-  if (m->dim > 75 && m->dim <= 256 && force != 2)
+  // 75 < D <= 256: team of 8 waves, metric in the CU's register file, 16-pivot blocks on the matrix cores with
+  // solve-only constructions as a blocked LDL^T (k_implicit_blk16.hip).  MICI_AMD_IMPLICIT_KERNEL=team4 selects
+  // the round-1 kernel (4-pivot blocks, explicit inverse every time: k_implicit_mfma_team.hip), =team the VALU
+  // team kernel
+  if (m->dim > 75 && m->dim <= 256 && force == 3)
     return mm_launch_implicit_mfma_team(ctx, m, s, h, n_steps, opts, d_counters);
+  if (m->dim > 75 && m->dim <= 256 && force != 2)
+    return mm_launch_implicit_blk16(ctx, m, s, h, n_steps, opts, d_counters);
   if (m->dim > 64 || (m->dim > 32 && force == 2))
     return mm_launch_implicit_large(ctx, m, s, h, n_steps, opts, d_counters);
   if (m->dim > 32 && force == 0) return mm_launch_implicit_mfma(ctx, m, s, h, n_steps, opts, d_counters);

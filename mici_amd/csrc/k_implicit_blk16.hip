@@ -1,0 +1,787 @@
+// Implicit leapfrog on dense-metric Riemannian systems, 75 < D <= 256 (BASELINE config c4: D = 256, the 8-GPU
+// headline): one 256-thread workgroup per chain = ONE WAVE PER SIMD of a CU, each wave with the full 512-register
+// budget (256 architected VGPRs + 256 accumulation VGPRs), the chain's metric resident in the accumulation registers
+// and factorised sixteen pivots at a time on the FP64 matrix cores.  gfx950 / CDNA4.
+//
+// What is different from k_implicit_mfma_team.hip (the round-1 kernel this replaces, still reachable with
+// MICI_AMD_IMPLICIT_KERNEL=team4):
+//   * 4 waves x 34 tiles instead of 8 waves x 17: the tiles (272 registers per wave) are MFMA accumulators in
+//     AGPRs, which leaves the architected VGPR file to the operands and to the step's state - the round-1 kernel
+//     squeezed 17 tiles + everything else into 256 VGPRs and spilled 744 bytes per lane (36 GB of HBM traffic per
+//     launch);
+//   * pivot blocks are 16 wide = one tile: ONE workgroup barrier per 16 pivots instead of two per 4, and four
+//     back-to-back MFMAs per tile per block, so the per-tile scalar work is amortised fourfold;
+//   * the 16 x 16 pivot block is inverted by every wave redundantly (an in-tile 4-wide sweep whose rank-4
+//     updates are single MFMAs), so -W = -P^-1 (Q - E) never travels through LDS: each wave forms the four
+//     16 x 16 blocks of -W it needs as MFMA outputs, which ARE the A-operand registers of its tile updates;
+//   * solve-only constructions (the position fixed-point iterations need ONE product M^-1 p each; only the
+//     construction at a new position needs the explicit inverse, systems.py:1381-1399) run the sweep on the
+//     trailing tiles only - a blocked LDL^T, D^3/3 flops instead of D^3 - followed by a forward / diagonal /
+//     backward substitution over the 16 tile rows;
+//   * all waves run the same code: a wave's 34 tiles sit in fixed register slots whose tile coordinates are
+//     wave-uniform run-time values (see slot map below), so nothing is specialised per wave.
+// The index arithmetic of every phase is restated lane for lane in tools/sim_blk16.py and checked there against
+// numpy.linalg.
+//
+// Layouts.  D is padded to 256 = 16 x 16 tiles of 16 x 16; the 136 tiles on or below the diagonal are kept, each in
+// the MFMA accumulator layout: lane l = 16 g + j, register r <-> entry (16 I + 4 r + g, 16 J + j).  Wave w owns the
+// tile rows 7-w, w, 15-w, 8+w (8-w, w+1, 16-w, 9+w tiles: 34 for every wave).  Slots 0..8 ("group X"): row 7-w from
+// its diagonal leftwards, then row w ENDING on its diagonal (slot 8); slots 9..33 ("group Y", u = s - 9): row 15-w
+// from its diagonal leftwards, then row 8+w ending on its diagonal (u = 24).  The panel of a block,
+// X[k][c] = A[16 I0 + k][c], lives in LDS as Xl[c][g][kk] (k = 4 kk + g, 18 doubles per column): the four B-operand
+// values of a lane are one 32-byte read, bank-conflict free across the sixteen lanes of a row.
+//
+// Reference arithmetic replaced: DensePositiveDefiniteMatrix factorisation, explicit inverse and solves
+// (matrices.py:1161-1188, 932-938) inside ImplicitLeapfrogIntegrator._step (integrators.py:493-544); the step
+// logic is implicit_core.h.
+#include "implicit_core.h"
+
+namespace {
+
+using namespace mmdev;
+using namespace mmimp;
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int NT16 = 16;            // tile rows
+constexpr int DPM = 16 * NT16;      // padded dimension
+constexpr int NWAVE = 8;            // two per SIMD
+constexpr int NTHR = 64 * NWAVE;
+constexpr int NSLOT = 17;           // tiles per wave
+constexpr int NCLASS = 2;           // tile rows per wave
+constexpr int CS = 18;              // doubles per panel column in LDS: 16 + 2 (keeps 16-byte alignment, spreads banks)
+constexpr int PSTR = 17;            // partial sums per output element: 16 column-sum slots + the row sum
+constexpr int VLM = DPM + 8;        // flat vectors: DPM elements + a dummy cell for threads >= DPM
+
+// LDS (doubles).  The flat per-thread state comes first: its thirteen slots are then ONE address register plus a 16-bit
+// immediate offset each (DS instructions carry offsets < 64 KiB), not thirteen address registers.
+constexpr int kOffStash = 0;                               // [SL_COUNT][VLM] flat per-thread state of the step
+constexpr int kOffNat = kOffStash + SL_COUNT * VLM;        // [VLM] natural-order vector
+constexpr int kOffVperm = kOffNat + VLM;                   // [DPM] the same vector as [I][g][r]: row operands as one 32-byte read
+constexpr int kOffAux = kOffVperm + DPM;                   // [VLM] second natural-order vector (z of the substitution)
+constexpr int kOffRed = kOffAux + VLM;                     // [16]  team reductions / flags
+constexpr int kOffScr = kOffRed + 16;                      // [NWAVE][64]   per-wave scratch of the in-tile sweep
+constexpr int kOffX = kOffScr + NWAVE * 64;                // [2][DPM][CS]  panel, double-buffered by block parity
+constexpr int kOffPart = kOffX + 2 * DPM * CS;             // [DPM][PSTR]
+constexpr int kLdsDoubles = kOffPart + DPM * PSTR;
+static_assert((kOffVperm % 2) == 0 && (kOffScr % 2) == 0 && (kOffX % 2) == 0, "16-byte alignment of the d4 accesses");
+static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU");
+
+__device__ __forceinline__ int fresh_lane() {
+  // the lane index straight from the hardware (two VALU instructions): never worth a long-lived register
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+// Pull a value the matrix core produced (an accumulation-register tuple) into architected VGPRs.  The metric tiles
+// fill 240 of a wave's 256 AGPRs; what is transient (T, the -W blocks) or needs VALU access all the time (the four
+// diagonal tiles) must not compete for the remaining 16.
+__device__ __forceinline__ void to_vgpr(d4& v) { asm volatile("" : "+v"(v)); }
+
+// The wave index re-materialised as an opaque scalar: everything derived from it (the 17 slots' tile coordinates,
+// their LDS / global offsets) is then recomputed where it is used - a few SALU instructions - instead of being
+// hoisted out of the step loop into dozens of long-lived SGPRs that get spilled to VGPR lanes.
+__device__ __forceinline__ int opaque_wave(int v) {
+  v = __builtin_amdgcn_readfirstlane(v);
+  asm volatile("" : "+s"(v));
+  __builtin_assume(v >= 0 && v < NWAVE);
+  return v;
+}
+
+// A value every lane of the wave agrees on, moved to scalar registers: the step's control flow (implicit_core.h)
+// depends only on team-uniform norms and flags; telling the compiler so keeps the whole state machine (mode, solver
+// iteration counts, work counters, the time step) in SGPRs instead of VGPRs the tiles need.
+__device__ __forceinline__ double uniform_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ bool uniform_flag(bool v) { return __builtin_amdgcn_readfirstlane(v ? 1 : 0) != 0; }
+
+__device__ __forceinline__ double team_reduce(double v, int kind_max, double* red) {
+  // kind_max: 0 sum, 1 NaN-propagating max.  Uniform result; two barriers.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = kind_max ? wave_max(v) : wave_sum(v);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double r = red[0];
+#pragma unroll
+  for (int w = 1; w < NWAVE; ++w) r = kind_max ? nanmax(r, red[w]) : r + red[w];
+  __syncthreads();
+  return r;
+}
+
+// sum over the four DPP rows (lanes l, l ^ 16, l ^ 32, l ^ 48): result in all four
+__device__ __forceinline__ double sum_over_g(double m) {
+  m += __shfl_xor(m, 16);
+  m += __shfl_xor(m, 32);
+  return m;
+}
+
+// rs[r] = this lane's partial of row element 4 r + g: sum over the 16 lanes of a DPP row with one transposing
+// butterfly (4 values -> 1).  All four lanes of a quad end up with the sum for register r = j >> 2, i.e. for row
+// element 4 (j >> 2) + g.
+__device__ __forceinline__ double row_reduce16(const d4 rs, const int j) {
+  const bool h8 = (j & 8) != 0, h4 = (j & 4) != 0;
+  double k0v = h8 ? rs[2] : rs[0], k1v = h8 ? rs[3] : rs[1];
+  const double s0v = h8 ? rs[0] : rs[2], s1v = h8 ? rs[1] : rs[3];
+  k0v += dpp_move<kDppMirror>(s0v);
+  k1v += dpp_move<kDppMirror>(s1v);
+  double kk = h4 ? k1v : k0v;
+  const double ss = h4 ? k0v : k1v;
+  kk += dpp_move<kDppHalfMirror>(ss);
+  kk += dpp_move<kDppXor2>(kk);
+  kk += dpp_move<kDppXor1>(kk);
+  return kk;
+}
+
+template <int RMETRIC>
+struct TeamBlk16 {
+  static constexpr bool kSolveByInverse = false;
+  static constexpr bool kUnifiedConstruct = true;  // implicit_core.h: one construction site, mode at run time
+  d4 acc[NSLOT];
+  int wave; // wave index, wave-uniform (phases re-materialise it through opaque_wave)
+  int nblk; // number of 16-pivot blocks that contain real rows: ceil(dim / 16)
+  int dim, tid, target;
+  double* lds;
+  const double* base;  // rank-one metric: base matrix zero-padded, leading dimension base_ld
+  int base_ld;
+  const double* tparams;
+
+  // ---- slot map (wave-uniform; see the file header).  Row class of a slot: 0 = tile row 15-w (slots 0..15-w, from
+  // its diagonal leftwards), 1 = tile row w (slots 16-w..16, ENDING on its diagonal).  Slots 0..8 and 16 have a
+  // compile-time class.
+  __device__ static __forceinline__ int row_class(const int s, const int w) {
+    return (s <= 8 || (s < NSLOT - 1 && s <= 15 - w)) ? 0 : 1;
+  }
+  __device__ static __forceinline__ int row_of_class(const int c, const int w) { return c == 0 ? 15 - w : w; }
+  __device__ static __forceinline__ int tile_i(const int s, const int w) { return row_of_class(row_class(s, w), w); }
+  __device__ static __forceinline__ int tile_j(const int s, const int w) {
+    return row_class(s, w) == 0 ? 15 - w - s : w + s - 16;
+  }
+  __device__ static constexpr bool is_diag_slot(const int s) { return s == 0 || s == NSLOT - 1; }
+  __device__ static constexpr bool class_known(const int s) { return s <= 8 || s == NSLOT - 1; }
+  // per-row quantity of slot s out of the row classes' values (a select, not a branch: a branch around MFMAs makes
+  // the accumulator a PHI that the compiler resolves with copies behind a full MFMA drain)
+  __device__ static __forceinline__ d4 pick_row(const int s, const int w, const d4 (&v)[NCLASS]) {
+    if (s <= 8) return v[0];
+    if (s == NSLOT - 1) return v[1];
+    const bool lo = s <= 15 - w;
+    d4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = lo ? v[0][k] : v[1][k];
+    return r;
+  }
+  // accumulate v * a into the in-lane sums of slot s's row class (masked operands for the run-time slots)
+  __device__ static __forceinline__ void add_row(const int s, const int w, d4 (&rs)[NCLASS], const d4 a, const double v) {
+    if (class_known(s)) {
+      const int c = s <= 8 ? 0 : 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rs[c][r] = __builtin_fma(a[r], v, rs[c][r]);
+    } else {
+      const bool lo = s <= 15 - w;
+      const double va = lo ? v : 0.0, vb = lo ? 0.0 : v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rs[0][r] = __builtin_fma(a[r], va, rs[0][r]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rs[1][r] = __builtin_fma(a[r], vb, rs[1][r]);
+    }
+  }
+
+  __device__ __forceinline__ double& slot(int i) { return lds[kOffStash + i * VLM + (tid < DPM ? tid : DPM)]; }
+
+  __device__ __forceinline__ double norm(double x, int kind) {
+    const double a = tid < dim ? x : 0.0;
+    if (kind == MM_NORM_LINF) return uniform_f64(team_reduce(fabs(a), 1, lds + kOffRed));
+    return uniform_f64(sqrt(team_reduce(a * a, 0, lds + kOffRed)));
+  }
+
+  // natural-order copy + the [I][g][r] permuted copy that feeds row operands as one 32-byte read
+  __device__ __forceinline__ void publish_vector(double x) {
+    if (tid < DPM) {
+      const double xm = tid < dim ? x : 0.0;
+      lds[kOffNat + tid] = xm;
+      lds[kOffVperm + ((((tid >> 4) << 2) + (tid & 3)) << 2) + ((tid >> 2) & 3)] = xm;
+    }
+    __syncthreads();
+  }
+
+  // ---- metric_func(x) into the tiles ---------------------------------------------------------------------
+  // returns this wave's "a diagonal entry is not finite" flag (matrices.py:211-215); combined over waves in sweep()
+  __device__ __forceinline__ bool build(double x) {
+    publish_vector(x);
+    const int w = opaque_wave(wave);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
+    const double inv_d = 1.0 / (double)dim;
+    double chk = 0.0;
+    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+      // Pass 1: the base matrix straight into the tile registers - 136 loads in flight with no staging
+      // registers.  Wave-uniform tile origin (scalar base) + a 32-bit lane offset shared by all tiles.
+      const unsigned lane_off = (unsigned)(g * base_ld + j);
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) {
+        const double* tile0 = base + (unsigned)((16 * tile_i(s, w)) * base_ld + 16 * tile_j(s, w));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = tile0[lane_off + (unsigned)(4 * r * base_ld)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // Pass 2: + q q^T / D in place, tile by tile
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) {
+        const int I = tile_i(s, w), J = tile_j(s, w);
+        const d4 qr = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
+        const double qs = lds[kOffNat + 16 * J + j] * inv_d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = __builtin_fma(qr[r], qs, acc[s][r]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+    // the four diagonal tiles: entries (16 I + 4 r + g, same) on lanes j == 4 r + g
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      if (!is_diag_slot(s)) continue;
+      const int I = tile_i(s, w);
+      const d4 qr = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool on_diag = (j == 4 * r + g);
+        if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
+          if (on_diag) acc[s][r] = __builtin_fma(qr[r], qr[r], 1.0);
+        }
+        if (on_diag && 16 * I + 4 * r + g >= dim) acc[s][r] = 1.0;  // identity on the padding
+        // both built-in metrics have their largest entries on the diagonal: a non-finite entry anywhere
+        // implies a non-finite diagonal entry (matrices.py:211-215, "Array is not finite.")
+        chk = __builtin_fma(acc[s][r], 0.0, chk);
+      }
+    }
+    return __builtin_amdgcn_ballot_w64(chk != 0.0) != 0;
+  }
+
+  // B operands of column tile J: bx[kk] = X[4 kk + g][16 J + j] (the panel is published as Q - E already)
+  __device__ static __forceinline__ d4 load_b(const double* X, const int J, const int g, const int j) {
+    return *reinterpret_cast<const d4*>(X + (16 * J + j) * CS + 4 * g);
+  }
+
+  // ---- the 16 x 16 pivot block in accumulator layout -> T = -P^-1 (same layout), by a 4-wide symmetric sweep whose
+  // rank-4 updates are single MFMAs.  Every wave does this redundantly on its own 512 bytes of LDS scratch.
+  __device__ __forceinline__ void tile_sweep(d4& t, bool& ok, const int w, const int g, const int j) {
+    double* scr = lds + kOffScr + w * 64;
+#pragma unroll
+    for (int R0 = 0; R0 < 4; ++R0) {
+      scr[j * 4 + g] = t[R0];  // scr[c][s] = T[4 R0 + s][c]
+      wave_sync();
+      const d4 qv = *reinterpret_cast<const d4*>(scr + j * 4);  // my column's four pivot-row entries
+      const d4 c0 = *reinterpret_cast<const d4*>(scr + (4 * R0 + 0) * 4);  // uniform: columns of the 4 x 4 pivot block
+      const d4 c1 = *reinterpret_cast<const d4*>(scr + (4 * R0 + 1) * 4);
+      const d4 c2 = *reinterpret_cast<const d4*>(scr + (4 * R0 + 2) * 4);
+      const d4 c3 = *reinterpret_cast<const d4*>(scr + (4 * R0 + 3) * 4);
+      wave_sync();
+      // P4 = [A B; B^T C] with 2 x 2 blocks, inverted in closed form via the Schur complement of A
+      const double a = c0[0], b = c0[1], e = c1[1];
+      const double b00 = c0[2], b01 = c0[3], b10 = c1[2], b11 = c1[3];
+      const double h = c2[2], i2 = c2[3], jj = c3[3];
+      const double det_a = __builtin_fma(a, e, -b * b);
+      const double ida = fast_rcp(det_a);
+      const double ia00 = e * ida, ia01 = -b * ida, ia11 = a * ida;
+      const double t00 = __builtin_fma(ia00, b00, ia01 * b10), t01 = __builtin_fma(ia00, b01, ia01 * b11);
+      const double t10 = __builtin_fma(ia01, b00, ia11 * b10), t11 = __builtin_fma(ia01, b01, ia11 * b11);
+      const double s00 = h - __builtin_fma(b00, t00, b10 * t10);
+      const double s01 = i2 - __builtin_fma(b00, t01, b10 * t11);
+      const double s11 = jj - __builtin_fma(b01, t01, b11 * t11);
+      const double det_s = __builtin_fma(s00, s11, -s01 * s01);
+      const double ids = fast_rcp(det_s);
+      const double is00 = s11 * ids, is01 = -s01 * ids, is11 = s00 * ids;
+      // pivots of the sequential elimination: a, det_a / a, s00, det_s / s00 (all must be > 0: "Cholesky
+      // factorisation failed", matrices.py:1170-1172; a NaN fails every comparison)
+      ok = ok && (a > 0.0) && (det_a > 0.0) && (s00 > 0.0) && (det_s > 0.0);
+      const double u00 = __builtin_fma(t00, is00, t01 * is01), u01 = __builtin_fma(t00, is01, t01 * is11);
+      const double u10 = __builtin_fma(t10, is00, t11 * is01), u11 = __builtin_fma(t10, is01, t11 * is11);
+      const double p00 = ia00 + __builtin_fma(u00, t00, u01 * t01);
+      const double p01 = ia01 + __builtin_fma(u00, t10, u01 * t11);
+      const double p11 = ia11 + __builtin_fma(u10, t10, u11 * t11);
+      d4 q = qv;  // X4 = Q4 - E4
+      const int sdx = j - 4 * R0;
+      q[0] -= (sdx == 0) ? 1.0 : 0.0;
+      q[1] -= (sdx == 1) ? 1.0 : 0.0;
+      q[2] -= (sdx == 2) ? 1.0 : 0.0;
+      q[3] -= (sdx == 3) ? 1.0 : 0.0;
+      // column c = j of -W4 = -P4^-1 X4; this lane feeds row g of it to the matrix core
+      const double w0 = __builtin_fma(-p00, q[0], __builtin_fma(-p01, q[1], __builtin_fma(u00, q[2], u01 * q[3])));
+      const double w1 = __builtin_fma(-p01, q[0], __builtin_fma(-p11, q[1], __builtin_fma(u10, q[2], u11 * q[3])));
+      const double w2 = __builtin_fma(u00, q[0], __builtin_fma(u10, q[1], __builtin_fma(-is00, q[2], -is01 * q[3])));
+      const double w3 = __builtin_fma(u01, q[0], __builtin_fma(u11, q[1], __builtin_fma(-is01, q[2], -is11 * q[3])));
+      const double a_op = (g == 0) ? w0 : (g == 1) ? w1 : (g == 2) ? w2 : w3;
+      const double b_op = (g == 0) ? q[0] : (g == 1) ? q[1] : (g == 2) ? q[2] : q[3];
+      t = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, t, 0, 0, 0);
+      if (sdx == g) t[R0] -= 2.0;
+    }
+  }
+
+  // ---- block-16 symmetric sweep.  TRAILING = false: every tile is updated by every block, tiles end as -M^-1.
+  // TRAILING = true: only tiles (I, J) with J >= I0 - the blocked LDL^T: tile (K, K) = -P_K^-1, tile (I, K) =
+  // A_IK P_K^-1.  `bad` = this wave's non-finite flag from build().  Returns "positive definite and finite" (uniform).
+  template <bool TRAILING>
+  __device__ __forceinline__ bool sweep(const bool bad) {
+    bool ok = true;
+    if (fresh_lane() == 0) lds[kOffRed + 8 + wave] = bad ? 1.0 : 0.0;  // read by everyone after the barriers below
+    // a do-while: the kernel is only launched for dim > 0, and a zero-trip bypass edge around this loop makes the
+    // register allocator keep a second, untouched copy of all 136 tile registers alive across it
+    int I0 = 0;
+#pragma unroll 1
+    do {
+      const int w = opaque_wave(wave);
+      const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
+      double* X = lds + kOffX + (I0 & 1) * (DPM * CS);
+      // (1) publish the panel X = Q - E: the owner of tile row I0 writes that row's tiles (the pivot block itself
+      // minus the identity); every wave with a tile in tile column I0 (rows below) writes it transposed
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) {
+        const int I = tile_i(s, w), J = tile_j(s, w);
+        if (I == I0) {
+          if (is_diag_slot(s)) {  // J == I0: the pivot block
+            d4 v = acc[s];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] -= (j == 4 * r + g) ? 1.0 : 0.0;
+            *reinterpret_cast<d4*>(X + (16 * J + j) * CS + 4 * g) = v;
+          } else if (!TRAILING) {
+            *reinterpret_cast<d4*>(X + (16 * J + j) * CS + 4 * g) = acc[s];
+          }
+        } else if (!is_diag_slot(s) && J == I0) {
+          double* dst = X + (16 * I + g) * CS + (j & 3) * 4 + (j >> 2);  // + 4 r columns
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[4 * r * CS] = acc[s][r];
+        }
+      }
+      __syncthreads();
+      // (2) T = -P^-1, redundantly per wave
+      d4 t = load_b(X, I0, g, j);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[r] += (j == 4 * r + g) ? 1.0 : 0.0;
+      tile_sweep(t, ok, w, g, j);
+      // (3) the four 16 x 16 blocks of -W = T X this wave's tile rows need, straight into A-operand registers:
+      // lane (g, i), register kk <-> (-W)[4 kk + g][16 I + i]
+      d4 nw[NCLASS];
+#pragma unroll
+      for (int c = 0; c < NCLASS; ++c) {
+        const d4 bb = load_b(X, row_of_class(c, w), g, j);
+        nw[c] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) nw[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(t[kk], bb[kk], nw[c], 0, 0, 0);
+      }
+      // (4) rank-16 update of the tiles: four MFMAs each
+      if constexpr (!TRAILING) {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+          const d4 bx = load_b(X, tile_j(s, w), g, j);
+          const d4 a = pick_row(s, w, nw);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], bx[kk], acc[s], 0, 0, 0);
+          if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound how far operand loads are hoisted
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+          const int J = tile_j(s, w);
+          if (J >= I0) {  // wave-uniform; the only conditional arm around these MFMAs
+            const d4 bx = load_b(X, J, g, j);
+            const d4 a = pick_row(s, w, nw);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], bx[kk], acc[s], 0, 0, 0);
+            }
+        }
+      }
+      // A_KK -= 2 I on the pivot block's own tile
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) {
+        if (!is_diag_slot(s)) continue;
+        if (tile_i(s, w) == I0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j == 4 * r + g) acc[s][r] -= 2.0;
+        }
+      }
+      // no barrier here: the next block publishes into the other panel buffer
+    } while (++I0 < nblk);
+    double flags = 0.0;
+#pragma unroll
+    for (int k = 0; k < NWAVE; ++k) flags += lds[kOffRed + 8 + k];
+    return ok && flags == 0.0;
+  }
+
+  // ---- y = M^-1 v with the explicit inverse in the tiles (they hold -M^-1 after the full sweep) ----------------
+  __device__ __forceinline__ double matvec(double v) {
+    publish_vector(v);
+    const int w = opaque_wave(wave);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
+    double* part = lds + kOffPart;
+    d4 rs[NCLASS];
+#pragma unroll
+    for (int c = 0; c < NCLASS; ++c) rs[c] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int I = tile_i(s, w), J = tile_j(s, w);
+      const double vc = lds[kOffNat + 16 * J + j];
+      const d4 a = acc[s];
+      add_row(s, w, rs, a, vc);
+      if (!is_diag_slot(s)) {  // below the diagonal: the mirrored tile's rows are this tile's columns
+        const d4 vr = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
+        double m = a[0] * vr[0];
+        m = __builtin_fma(a[1], vr[1], m);
+        m = __builtin_fma(a[2], vr[2], m);
+        m = __builtin_fma(a[3], vr[3], m);
+        m = sum_over_g(m);
+        part[(16 * J + j) * PSTR + I] = m;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCLASS; ++c) {
+      const double k = row_reduce16(rs[c], j);
+      part[(16 * row_of_class(c, w) + 4 * (j >> 2) + g) * PSTR + 16] = k;
+    }
+    __syncthreads();
+    double y = 0.0;
+    if (tid < DPM) {
+      // column-sum slots I <= (the element's own tile row) are never written and stay zero from kernel start
+      const double* src = lds + kOffPart + tid * PSTR;
+#pragma unroll
+      for (int k = 0; k < PSTR; ++k) y += src[k];
+    }
+    __syncthreads();
+    return tid < dim ? -y : 0.0;
+  }
+
+  // ---- u = M^-1 b from the trailing-sweep (LDL^T) factors: forward, diagonal and backward substitution over the
+  // tile rows, one workgroup barrier per tile row and direction -------------------------------------------------
+  __device__ __forceinline__ double solve(double b) {
+    publish_vector(b);
+    const int w = opaque_wave(wave);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
+    double* nat = lds + kOffNat;
+    double* aux = lds + kOffAux;
+    double* part = lds + kOffPart;
+    // forward: y_I = b_I - sum_{J < I} T_IJ y_J; a tile row accumulates its products in-lane (rs[class]), the sum over
+    // the sixteen lanes of a row is taken once, when the row's turn comes
+    d4 rs[NCLASS];
+#pragma unroll
+    for (int c = 0; c < NCLASS; ++c) rs[c] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int K = 0; K < nblk; ++K) {
+#pragma unroll
+      for (int c = 0; c < NCLASS; ++c) {
+        if (K == row_of_class(c, w)) {  // wave-uniform: this wave owns tile row K -> y_K, in place over b_K
+          const double red = row_reduce16(rs[c], j);
+          const int e = 16 * K + 4 * (j >> 2) + g;
+          nat[e] = nat[e] - red;  // the four lanes of a quad write the same value
+        }
+      }
+      __syncthreads();
+      const double yk = nat[16 * K + j];
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) {
+        if (tile_j(s, w) != K) continue;  // wave-uniform
+        if (is_diag_slot(s)) {
+          // the diagonal tile (K, K) = -P_K^-1: z_K = P_K^-1 y_K
+          d4 zc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zc[r] = acc[s][r] * yk;
+          const double z = row_reduce16(zc, j);
+          aux[16 * K + 4 * (j >> 2) + g] = -z;
+        } else {
+          add_row(s, w, rs, acc[s], yk);
+        }
+      }
+    }
+    __syncthreads();
+    // backward: u_K = z_K - sum_{I > K} T_IK^T u_I.  Step K: the owner of tile row K sums the column partials that
+    // rows I > K left in part[16 K + j][I], publishes u_K, and leaves its own row's partials for the columns J < K.
+#pragma unroll 1
+    for (int K = nblk - 1; K >= 0; --K) {
+      if (K == 15 - w || K == w) {
+        double u = aux[16 * K + j];
+        const double* src = part + (16 * K + j) * PSTR;
+        for (int I = K + 1; I < nblk; ++I) u -= src[I];
+        // all four DPP rows computed the same u: natural order (the result) and the [I][g][r] copy
+        nat[16 * K + j] = u;
+        lds[kOffVperm + (((K << 2) + (j & 3)) << 2) + (j >> 2)] = u;
+        wave_sync();
+        const d4 ur = *reinterpret_cast<const d4*>(lds + kOffVperm + ((K * 4 + g) << 2));
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+          if (is_diag_slot(s)) continue;
+          if (tile_i(s, w) != K) continue;  // one of this wave's other rows
+          const int J = tile_j(s, w);
+          double m = acc[s][0] * ur[0];
+          m = __builtin_fma(acc[s][1], ur[1], m);
+          m = __builtin_fma(acc[s][2], ur[2], m);
+          m = __builtin_fma(acc[s][3], ur[3], m);
+          m = sum_over_g(m);
+          part[(16 * J + j) * PSTR + K] = m;
+        }
+      }
+      __syncthreads();
+    }
+    const double u = (tid < dim) ? nat[tid] : 0.0;
+    __syncthreads();
+    return u;
+  }
+
+  // implicit_core.h, kUnifiedConstruct: metric_func(x) then either the explicit inverse (kept in the tiles for
+  // matvec / half_vjp_inv / dh2_dpos) or the single solve u = M(x)^-1 rhs
+  __device__ __forceinline__ bool construct(double x, bool need_inverse, double rhs, double* u) {
+    const bool bad = build(x);
+    bool ok;
+    if (need_inverse) {  // team-uniform
+      ok = sweep<false>(bad);
+    } else {
+      ok = sweep<true>(bad);
+      *u = solve(rhs);
+    }
+    return uniform_flag(ok);
+  }
+  __device__ __forceinline__ bool build_and_invert(double x) {
+    double dummy;
+    return construct(x, true, 0.0, &dummy);
+  }
+  __device__ __forceinline__ bool build_and_solve(double x, double rhs, double* u) { return construct(x, false, rhs, u); }
+
+  __device__ __forceinline__ double diag() {  // diagonal of M^-1 (tiles hold -M^-1)
+    const int w = opaque_wave(wave);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      if (!is_diag_slot(s)) continue;
+      const int I = tile_i(s, w);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (j == 4 * r + g) lds[kOffNat + 16 * I + 4 * r + g] = -acc[s][r];
+    }
+    __syncthreads();
+    const double y = (tid < dim) ? lds[kOffNat + tid] : 0.0;
+    __syncthreads();
+    return y;
+  }
+
+  __device__ __forceinline__ double half_vjp_inv(double q) {
+    if constexpr (RMETRIC == MM_RMETRIC_RANK1) return matvec(q) / (double)dim;
+    else return q * diag();
+  }
+  // dense metric: grad_quadratic_form_inv(p) = -(M^-1 p)(M^-1 p)^T   (matrices.py:1179-1181)
+  __device__ __forceinline__ double dh2_dpos(double p, double q) {
+    const double u = matvec(p);
+    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+      const double uq = team_reduce(tid < dim ? u * q : 0.0, 0, lds + kOffRed);
+      return -(u * uq) / (double)dim;
+    } else {
+      return -q * (u * u);
+    }
+  }
+  __device__ __forceinline__ double grad(double q) {
+    double* nat = lds + kOffNat;
+    if (tid < VLM) nat[tid] = (tid < dim) ? q : 0.0;
+    __syncthreads();
+    const TargetAux aux = target_prepare<false>(target, nat, dim, tparams, tid & 63);
+    const double gr = (tid < dim) ? target_grad_elem<false>(target, aux, nat, tid, dim, tparams) : 0.0;
+    __syncthreads();
+    return gr;
+  }
+};
+
+template <int RMETRIC>
+__device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC>& bk, const ImplicitArgs& A, int base_ld, double* lds) {
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __builtin_assume(wv >= 0 && wv < NWAVE);
+  bk.wave = wv;
+  bk.dim = A.dim;
+  bk.nblk = (A.dim + 15) >> 4;
+  bk.tid = threadIdx.x;
+  bk.target = A.target;
+  bk.lds = lds;
+  bk.base = A.rparams;
+  bk.base_ld = base_ld;
+  bk.tparams = A.tparams;
+  for (int i = threadIdx.x; i < DPM * PSTR; i += NTHR) lds[kOffPart + i] = 0.0;  // unused partial-sum slots stay 0
+  __syncthreads();
+}
+
+template <int RMETRIC>
+__global__ __launch_bounds__(NTHR, 2) void implicit_blk16_kernel(ImplicitArgs A, int base_ld) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  TeamBlk16<RMETRIC> bk;
+  init_backend(bk, A, base_ld, lds);
+  const int64_t chain = blockIdx.x;
+  const int tid = threadIdx.x, dim = A.dim;
+  const bool act = tid < dim;
+  double q = act ? A.pos[chain * dim + tid] : 0.0;
+  double p = act ? A.mom[chain * dim + tid] : 0.0;
+  const double t = uniform_f64(signed_step(A.dir, A.step_scale, chain, A.step_size));
+  bk.slot(SL_Q) = q;
+  bk.slot(SL_P) = p;
+  const ChainResult r = implicit_leapfrog_chain(bk, t, mmdev::chain_steps(A.chain_steps, chain, A.n_steps), A.opts);
+  q = bk.slot(SL_Q);
+  p = bk.slot(SL_P);
+  if (act) {
+    A.pos[chain * dim + tid] = q;
+    A.mom[chain * dim + tid] = p;
+  }
+  if (tid == 0) {
+    A.status[chain] = r.status;
+    A.n_done[chain] = r.done;
+    add_counters(A.counters, r);
+  }
+}
+
+// Developer / test hook: the linear algebra of the backend on its own.  Per chain, with x = pos and b = mom:
+//   op 0: out[chain][256][256] = the explicit inverse M(x)^-1 (dense, symmetric) from the full sweep
+//   op 1: out[chain][256]      = M(x)^-1 b by the trailing sweep + substitution
+//   op 2: out[chain][256]      = M(x)^-1 b by the full sweep + mat-vec
+//   op 3..7 (timing only, tools/ubench_blk16.py): 3 = build, 4 = build + full sweep, 5 = build + trailing sweep,
+//        6 = mat-vec, 7 = substitution - each repeated `reps` times
+// status[chain] = 0 if the metric was found positive definite and finite, else 5.
+template <int RMETRIC>
+__global__ __launch_bounds__(NTHR, 2) void blk16_debug_kernel(ImplicitArgs A, int base_ld, int op, int reps) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  TeamBlk16<RMETRIC> bk;
+  init_backend(bk, A, base_ld, lds);
+  const int64_t chain = blockIdx.x;
+  const int tid = threadIdx.x, dim = A.dim;
+  const bool act = tid < dim;
+  const double q = act ? A.pos[chain * dim + tid] : 0.0;
+  const double p = act ? A.mom[chain * dim + tid] : 0.0;
+  double u = 0.0;
+  bool ok = true;
+  if (op <= 2) {
+    ok = bk.construct(q, op != 1, p, &u);
+  } else {
+    ok = bk.construct(q, op != 7, p, &u);
+    for (int rep = 0; rep < reps; ++rep) {
+      if (op == 3) ok = !bk.build(q + u * 1e-300) && ok;
+      if (op == 4) ok = bk.construct(q + u * 1e-300, true, p, &u) && ok;
+      if (op == 5) {
+        const bool bad = bk.build(q + u * 1e-300);
+        ok = bk.template sweep<true>(bad) && ok;
+      }
+      if (op == 6) u = bk.matvec(p + u * 1e-300);
+      if (op == 7) u = bk.solve(p + u * 1e-300);
+    }
+  }
+  if (op == 0) {
+    double* out = A.out + chain * (int64_t)(DPM * DPM);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int I = bk.tile_i(s, bk.wave), J = bk.tile_j(s, bk.wave);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = -bk.acc[s][r];
+        out[(int64_t)(16 * I + 4 * r + g) * DPM + 16 * J + j] = v;
+        out[(int64_t)(16 * J + j) * DPM + 16 * I + 4 * r + g] = v;
+      }
+    }
+  } else {
+    if (op == 2) u = bk.matvec(p);
+    if (tid < DPM) A.out[chain * (int64_t)DPM + tid] = u;
+  }
+  if (tid == 0) A.status[chain] = ok ? 0 : MM_ST_LINALG;
+}
+
+template <class K, class... Extra>
+int launch_blk16(mm_ctx* ctx, K kernel, const ImplicitArgs& a, int base_ld, Extra... extra) {
+  const size_t lds = kLdsDoubles * sizeof(double);
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)a.n_chains), dim3(NTHR), lds, ctx->stream, a, base_ld, extra...);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
+int fill_args(mm_ctx* ctx, const mm_model* m, mm_state* s, ImplicitArgs& a) {
+  if (m->dim > DPM) {
+    mm_set_error(ctx, "block-16 matrix-core team kernel supports dim <= 256");
+    return MM_ERR_UNSUPPORTED;
+  }
+  if (m->rmetric == MM_RMETRIC_RANK1 && (m->d_rmetric_padded == nullptr || m->rmetric_pad_dim < DPM)) {
+    mm_set_error(ctx, "internal: rank-one base matrix was not padded for the team kernels");
+    return MM_ERR_UNSUPPORTED;
+  }
+  a.pos = s->d_pos;
+  a.mom = s->d_mom;
+  a.dir = s->d_dir;
+  a.step_scale = s->d_step_scale;
+  a.chain_steps = s->d_chain_steps;
+  a.status = s->d_status;
+  a.n_done = s->d_n_done;
+  a.n_chains = s->n;
+  a.dim = s->dim;
+  a.target = m->target;
+  a.tparams = m->d_target_params;
+  a.rparams = m->d_rmetric_padded;
+  return MM_OK;
+}
+
+}  // namespace
+
+int mm_launch_implicit_blk16(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                             const mm_fp_opts& opts, mm_counters* d_counters) {
+  ImplicitArgs a{};
+  const int rc = fill_args(ctx, m, s, a);
+  if (rc != MM_OK) return rc;
+  a.step_size = h;
+  a.n_steps = n_steps;
+  a.opts = opts;
+  a.counters = d_counters;
+  if (m->rmetric == MM_RMETRIC_RANK1)
+    return launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_RANK1>, a, m->rmetric_pad_dim);
+  return launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_DIAGQUAD>, a, 0);
+}
+
+// developer / test hook (tests/test_gpu_blk16.py): see blk16_debug_kernel.  out is a HOST buffer of
+// N * 256 * 256 (op 0) or N * 256 (op 1, 2) doubles; status[N] (host, may be NULL) receives 0 / 5 per chain.
+extern "C" int mm_debug_blk16_linalg(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* out,
+                                     int32_t* status, int reps, double* ms) {
+  if (!ctx || !m || !s || !out || op < 0 || op > 7 || m->rmetric == MM_RMETRIC_NONE ||
+      m->rmetric == MM_RMETRIC_SOFTABS)
+    return MM_ERR_INVALID;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ImplicitArgs a{};
+  const int rc = fill_args(ctx, m, s, a);
+  if (rc != MM_OK) return rc;
+  const size_t bytes = (size_t)s->n * (op == 0 ? (size_t)DPM * DPM : (size_t)DPM) * sizeof(double);
+  double* d_out = nullptr;
+  MM_HIP_CHECK(ctx, hipMalloc(&d_out, bytes));
+  a.out = d_out;
+  int lrc;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, ctx->stream);
+  if (m->rmetric == MM_RMETRIC_RANK1)
+    lrc = launch_blk16(ctx, blk16_debug_kernel<MM_RMETRIC_RANK1>, a, m->rmetric_pad_dim, op, reps);
+  else
+    lrc = launch_blk16(ctx, blk16_debug_kernel<MM_RMETRIC_DIAGQUAD>, a, 0, op, reps);
+  (void)hipEventRecord(e1, ctx->stream);
+  if (lrc == MM_OK && ms) {
+    float f = 0.f;
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&f, e0, e1);
+    *ms = f;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (lrc == MM_OK) {
+    hipError_t e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && status)
+      e = hipMemcpyAsync(status, s->d_status, (size_t)s->n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      mm_set_error(ctx, std::string("mm_debug_blk16_linalg: ") + hipGetErrorString(e));
+      lrc = MM_ERR_HIP;
+    }
+  }
+  (void)hipFree(d_out);
+  return lrc;
+}

@@ -61,6 +61,7 @@ struct MLds {
 template <int RMETRIC>
 struct MfmaBackend {
   static constexpr bool kSolveByInverse = true;  // implicit_core.h: solve = invert + mat-vec, one construction site
+  static constexpr bool kUnifiedConstruct = false;
   d4 acc[kTiles];
   int dim, lane, target;
   MLds w;

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Phase timings of the block-16 team kernel (k_implicit_blk16.hip) on the GPU box: one chain per CU (256 chains),
+each phase repeated `reps` times inside one launch -> microseconds and cycles (at 2.4 GHz) per phase per chain."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mici_amd import _ffi, models, systems  # noqa: E402
+from mici_amd.runtime import DeviceBatch, default_context  # noqa: E402
+
+dim = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+reps = 20
+rng = np.random.default_rng(0)
+a = rng.standard_normal((dim, dim))
+base = a @ a.T / dim + np.eye(dim)
+system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(base))
+ctx = default_context()
+fn = ctx._lib.mm_debug_blk16_linalg
+fn.restype = C.c_int
+fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _ffi.c_double_p, _ffi.c_int32_p, C.c_int, _ffi.c_double_p]
+batch = DeviceBatch(ctx, n, dim)
+batch.upload(rng.standard_normal((n, dim)), rng.standard_normal((n, dim)), np.ones(n, dtype=np.int8))
+out = np.zeros((n, 256))
+res = {}
+names = {3: "build", 4: "build+full_sweep", 5: "build+trailing_sweep", 6: "matvec", 7: "substitution"}
+for op, name in names.items():
+    t = {}
+    for r in (0, reps):
+        best = 1e9
+        for _ in range(3):
+            ms = C.c_double(0.0)
+            _ffi.check(fn(ctx.handle, system.device_model(ctx).handle, batch.handle, op, out.ctypes.data_as(_ffi.c_double_p),
+                          None, r, C.byref(ms)), ctx.handle, "mm_debug_blk16_linalg")
+            best = min(best, ms.value)
+        t[r] = best
+    us = (t[reps] - t[0]) / reps * 1e3
+    res[name] = dict(us=us, kcycles=us * 2.4)
+    print(f"{name:22s} {us:8.2f} us  {us * 2.4:8.1f} kcycles", flush=True)
+print(json.dumps(res))
