@@ -43,10 +43,6 @@ using namespace mmimp;
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-#ifndef MM_BLK16_PERMLANE
-#define MM_BLK16_PERMLANE 1  // semantics verified on the MI355X by tests/test_gpu_blk16.py::test_permlane_swap_semantics
-#endif
-
 constexpr int NT16 = 16;            // tile rows
 constexpr int DPM = 16 * NT16;      // padded dimension
 constexpr int NWAVE = 8;            // two per SIMD
@@ -64,8 +60,7 @@ constexpr int kOffNat = kOffStash + SL_COUNT * VLM;        // [VLM] natural-orde
 constexpr int kOffVperm = kOffNat + VLM;                   // [DPM] the same vector as [I][g][r]: row operands as one 32-byte read
 constexpr int kOffAux = kOffVperm + DPM;                   // [VLM] second natural-order vector (z of the substitution)
 constexpr int kOffRed = kOffAux + VLM;                     // [16]  team reductions / flags
-constexpr int kOffScr = kOffRed + 16;                      // [NWAVE][64]: [0] scratch of the in-tile sweep, [1..4] T = -P^-1
-                                                           // in lane order, [5][0] its positive-definite flag
+constexpr int kOffScr = kOffRed + 16;                      // [NWAVE][64]   per-wave scratch of the in-tile sweep
 constexpr int kOffX = kOffScr + NWAVE * 64;                // [2][DPM][CS]  panel, double-buffered by block parity
 constexpr int kOffPart = kOffX + 2 * DPM * CS;             // [DPM][PSTR]
 constexpr int kLdsDoubles = kOffPart + DPM * PSTR;
@@ -118,38 +113,11 @@ __device__ __forceinline__ double team_reduce(double v, int kind_max, double* re
   return r;
 }
 
-// sum over the four DPP rows (lanes l, l ^ 16, l ^ 32, l ^ 48): result in all four.
-// gfx950 has VALU row swaps: v_permlane16_swap exchanges the odd rows of its first operand with the even rows of
-// its second, v_permlane32_swap the upper half of the first with the lower half of the second; fed the same value
-// twice, the two results are (x[l], x[l ^ 16]) in some order, so their sum is the xor-16 (xor-32) butterfly step
-// without the LDS crossbar round trip of ds_bpermute (two of them per step for a double).
-constexpr bool kUsePermlaneSwap = MM_BLK16_PERMLANE;
-__device__ __forceinline__ double swap_sum16(double m) {
-  const long long b = __double_as_longlong(m);
-  const unsigned lo = (unsigned)(b & 0xffffffffLL), hi = (unsigned)(b >> 32);
-  const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  const double x0 = __longlong_as_double(((long long)h2[0] << 32) | (unsigned)l2[0]);
-  const double x1 = __longlong_as_double(((long long)h2[1] << 32) | (unsigned)l2[1]);
-  return x0 + x1;
-}
-__device__ __forceinline__ double swap_sum32(double m) {
-  const long long b = __double_as_longlong(m);
-  const unsigned lo = (unsigned)(b & 0xffffffffLL), hi = (unsigned)(b >> 32);
-  const auto l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  const auto h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  const double x0 = __longlong_as_double(((long long)h2[0] << 32) | (unsigned)l2[0]);
-  const double x1 = __longlong_as_double(((long long)h2[1] << 32) | (unsigned)l2[1]);
-  return x0 + x1;
-}
+// sum over the four DPP rows (lanes l, l ^ 16, l ^ 32, l ^ 48): result in all four
 __device__ __forceinline__ double sum_over_g(double m) {
-  if constexpr (kUsePermlaneSwap) {
-    return swap_sum32(swap_sum16(m));
-  } else {
-    m += __shfl_xor(m, 16);
-    m += __shfl_xor(m, 32);
-    return m;
-  }
+  m += __shfl_xor(m, 16);
+  m += __shfl_xor(m, 32);
+  return m;
 }
 
 // rs[r] = this lane's partial of row element 4 r + g: sum over the 16 lanes of a DPP row with one transposing
@@ -248,19 +216,26 @@ struct TeamBlk16 {
     const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
     const double inv_d = 1.0 / (double)dim;
     double chk = 0.0;
-    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-      // base matrix (L2-resident) + q q^T / D.  Wave-uniform tile origin (scalar base) + a 32-bit lane offset shared
-      // by all tiles: the sixty-eight loads share four offset registers.
+    if constexpr (false) {
+      // Pass 1: the base matrix straight into the tile registers - 136 loads in flight with no staging
+      // registers.  Wave-uniform tile origin (scalar base) + a 32-bit lane offset shared by all tiles.
       const unsigned lane_off = (unsigned)(g * base_ld + j);
 #pragma unroll
       for (int s = 0; s < NSLOT; ++s) {
+        const double* tile0 = base + (unsigned)((16 * tile_i(s, w)) * base_ld + 16 * tile_j(s, w));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = tile0[lane_off + (unsigned)(4 * r * base_ld)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // Pass 2: + q q^T / D in place, tile by tile
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) {
         const int I = tile_i(s, w), J = tile_j(s, w);
-        const double* tile0 = base + (unsigned)((16 * I) * base_ld + 16 * J);
         const d4 qr = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
         const double qs = lds[kOffNat + 16 * J + j] * inv_d;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[s][r] = __builtin_fma(qr[r], qs, tile0[lane_off + (unsigned)(4 * r * base_ld)]);
+        for (int r = 0; r < 4; ++r) acc[s][r] = __builtin_fma(qr[r], qs, acc[s][r]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
@@ -348,14 +323,13 @@ struct TeamBlk16 {
   }
 
   // tiles S0 .. S0+N-1: acc += (-W rows)^T X, the N dependent chains interleaved
-  template <int S0, int N, bool NOLOAD = false>
+  template <int S0, int N>
   __device__ __forceinline__ void update_group(const double* X, const int w, const int g, const int j,
                                                const d4 (&nw)[NCLASS]) {
     d4 bx[N], a[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      if constexpr (NOLOAD) bx[i] = nw[i & 1];
-      else bx[i] = load_b(X, tile_j(S0 + i, w), g, j);
+      bx[i] = load_b(X, tile_j(S0 + i, w), g, j);
       a[i] = pick_row(S0 + i, w, nw);
     }
 #pragma unroll
@@ -366,12 +340,36 @@ struct TeamBlk16 {
     }
     __builtin_amdgcn_sched_barrier(0);  // bound how far the next groups' operand loads are hoisted
   }
+  template <int S0, int N>
+  __device__ __forceinline__ void update_group_masked(const double* X, const int w, const int g, const int j,
+                                                      const d4 (&nw)[NCLASS], const int I0) {
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) any = any || tile_j(S0 + i, w) >= I0;
+    if (any) {  // wave-uniform
+      d4 bx[N], a[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int J = tile_j(S0 + i, w);
+        const bool on = J >= I0;
+        bx[i] = load_b(X, on ? J : I0, g, j);  // an inactive tile reads a column that is certainly published
+        const d4 av = pick_row(S0 + i, w, nw);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[i][k] = on ? av[k] : 0.0;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          acc[S0 + i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][kk], bx[i][kk], acc[S0 + i], 0, 0, 0);
+      }
+    }
+  }
+
   // ---- block-16 symmetric sweep.  TRAILING = false: every tile is updated by every block, tiles end as -M^-1.
   // TRAILING = true: only tiles (I, J) with J >= I0 - the blocked LDL^T: tile (K, K) = -P_K^-1, tile (I, K) =
   // A_IK P_K^-1.  `bad` = this wave's non-finite flag from build().  Returns "positive definite and finite" (uniform).
-  // EXPER (timing experiments of tools/ubench_blk16.py only; results are wrong): 1 = no pivot-block inverse,
-  // 2 = no tile updates, 3 = tile updates without their LDS operand loads
-  template <bool TRAILING, bool PROF = false, int EXPER = 0>
+  template <bool TRAILING, bool PROF = false>
   __device__ __forceinline__ bool sweep(const bool bad) {
     bool ok = true;
     long long pc[6] = {0, 0, 0, 0, 0, 0};  // PROF: cycles per phase, summed over the blocks
@@ -387,76 +385,36 @@ struct TeamBlk16 {
       long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
       if constexpr (PROF) c0 = __builtin_readcyclecounter();
       // (1) publish the panel X = Q - E: the owner of tile row I0 writes that row's tiles (the pivot block itself
-      // minus the identity); every wave with a tile in tile column I0 (rows below) writes it transposed.  The slot of
-      // that tile is a run-time value: a switch (binary search) instead of seventeen compare-and-branch pairs.
-      {
-        const int ib = 15 - w, ia = w;
-        auto put_rowtile = [&](const int J, const d4 v) { *reinterpret_cast<d4*>(X + (16 * J + j) * CS + 4 * g) = v; };
-        auto put_coltile = [&](const int I, const d4 v) {
+      // minus the identity); every wave with a tile in tile column I0 (rows below) writes it transposed
+#pragma unroll
+      for (int s = 0; s < NSLOT; ++s) {
+        const int I = tile_i(s, w), J = tile_j(s, w);
+        if (I == I0) {
+          if (is_diag_slot(s)) {  // J == I0: the pivot block
+            d4 v = acc[s];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] -= (j == 4 * r + g) ? 1.0 : 0.0;
+            *reinterpret_cast<d4*>(X + (16 * J + j) * CS + 4 * g) = v;
+          } else if (!TRAILING) {
+            *reinterpret_cast<d4*>(X + (16 * J + j) * CS + 4 * g) = acc[s];
+          }
+        } else if (!is_diag_slot(s) && J == I0) {
           double* dst = X + (16 * I + g) * CS + (j & 3) * 4 + (j >> 2);  // + 4 r columns
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dst[4 * r * CS] = v[r];
-        };
-        auto minus_identity = [&](d4 v) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] -= (j == 4 * r + g) ? 1.0 : 0.0;
-          return v;
-        };
-        if (I0 == ib) {  // tile row 15-w is the pivot row
-          put_rowtile(I0, minus_identity(acc[0]));
-          if constexpr (!TRAILING) {
-#pragma unroll
-            for (int s = 1; s < NSLOT - 1; ++s)
-              if (s <= 15 - w) put_rowtile(15 - w - s, acc[s]);
-          }
-        } else if (I0 < ib) {  // its tile in column I0: slot ib - I0 (1..15)
-          switch (ib - I0) {
-#define MM_PUT(S) case S: put_coltile(ib, acc[S]); break;
-            MM_PUT(1) MM_PUT(2) MM_PUT(3) MM_PUT(4) MM_PUT(5) MM_PUT(6) MM_PUT(7) MM_PUT(8) MM_PUT(9) MM_PUT(10)
-            MM_PUT(11) MM_PUT(12) MM_PUT(13) MM_PUT(14) MM_PUT(15)
-#undef MM_PUT
-            default: break;
-          }
-        }
-        if (I0 == ia) {  // tile row w is the pivot row
-          put_rowtile(I0, minus_identity(acc[NSLOT - 1]));
-          if constexpr (!TRAILING) {
-#pragma unroll
-            for (int s = 9; s < NSLOT - 1; ++s)
-              if (s > 15 - w) put_rowtile(w + s - 16, acc[s]);
-          }
-        } else if (I0 < ia) {  // its tile in column I0: slot 16 - (ia - I0) (9..15)
-          switch (ia - I0) {
-#define MM_PUT(K) case K: put_coltile(ia, acc[16 - K]); break;
-            MM_PUT(1) MM_PUT(2) MM_PUT(3) MM_PUT(4) MM_PUT(5) MM_PUT(6) MM_PUT(7)
-#undef MM_PUT
-            default: break;
-          }
+          for (int r = 0; r < 4; ++r) dst[4 * r * CS] = acc[s][r];
         }
       }
       if constexpr (PROF) c1 = __builtin_readcyclecounter();
       __syncthreads();
       if constexpr (PROF) c2 = __builtin_readcyclecounter();
-      // (2) T = -P^-1 by ONE wave, shared through LDS.  FP64 vector instructions and FP64 MFMAs run on the same units
-      // of a SIMD and the in-tile sweep is bound by FP64 issue (~75 FP64 instructions per 4 x 4 sub-block): measured
-      // with every wave inverting the block redundantly, the two waves of a SIMD took 5.7 k cycles against 3.3 k for
-      // one wave on its own.
-      d4 t;
-      {
-        double* tbuf = lds + kOffScr + 64;  // [64 lanes][4]
-        if (w == 0) {
-          t = load_b(X, I0, g, j);
+      // (2) T = -P^-1, redundantly per wave.  Raised priority: this latency-bound chain (and its four MFMAs) must not
+      // queue behind the other wave of the SIMD streaming its tile updates into the matrix core (measured: the
+      // younger wave's pivot block took 10 k cycles instead of 3 k)
+      __builtin_amdgcn_s_setprio(3);
+      d4 t = load_b(X, I0, g, j);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) t[r] += (j == 4 * r + g) ? 1.0 : 0.0;
-          bool okb = true;
-          if constexpr (EXPER != 1) tile_sweep(t, okb, w, g, j);
-          *reinterpret_cast<d4*>(tbuf + 4 * ln) = t;
-          if (ln == 0) lds[kOffScr + 5 * 64] = okb ? 0.0 : 1.0;
-        }
-        __syncthreads();
-        t = *reinterpret_cast<const d4*>(tbuf + 4 * ln);
-        ok = ok && (lds[kOffScr + 5 * 64] == 0.0);
-      }
+      for (int r = 0; r < 4; ++r) t[r] += (j == 4 * r + g) ? 1.0 : 0.0;
+      tile_sweep(t, ok, w, g, j);
       if constexpr (PROF) {
         asm volatile("" : "+v"(t));
         c3 = __builtin_readcyclecounter();
@@ -478,26 +436,24 @@ struct TeamBlk16 {
       // (4) rank-16 update of the tiles: four MFMAs each.  The four MFMAs of a tile form a dependent chain
       // (measured: ~100 cycles per MFMA when a wave issues one tile after the other, against 64 for the matrix core),
       // so tiles are processed in groups whose chains are interleaved.
-      if constexpr (EXPER == 2) {
-      } else if constexpr (!TRAILING) {
-        update_group<0, 4, EXPER == 3>(X, w, g, j, nw);
-        update_group<4, 4, EXPER == 3>(X, w, g, j, nw);
-        update_group<8, 4, EXPER == 3>(X, w, g, j, nw);
-        update_group<12, 5, EXPER == 3>(X, w, g, j, nw);
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (!TRAILING) {
+        update_group<0, 4>(X, w, g, j, nw);
+        update_group<4, 4>(X, w, g, j, nw);
+        update_group<8, 4>(X, w, g, j, nw);
+        update_group<12, 5>(X, w, g, j, nw);
       } else {
-        // the active tiles (J >= I0) are a prefix of tile row 15-w's slots and a suffix of tile row w's: one
-        // wave-uniform conditional arm per tile.  The four MFMAs of an arm are a dependent chain; the other wave of
-        // the SIMD fills the matrix core in between.
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-          const int J = tile_j(s, w);
-          if (J >= I0) {
-            const d4 bx = load_b(X, J, g, j);
-            const d4 a = pick_row(s, w, nw);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], bx[kk], acc[s], 0, 0, 0);
-          }
-        }
+        // the active tiles (J >= I0) are a prefix of tile row 15-w's slots and a suffix of tile row w's; a group runs
+        // if any of its tiles is active, with the A operands of the inactive ones zeroed (their accumulators are the
+        // finished factor tiles and must stay as they are)
+        update_group_masked<0, 2>(X, w, g, j, nw, I0);
+        update_group_masked<2, 2>(X, w, g, j, nw, I0);
+        update_group_masked<4, 2>(X, w, g, j, nw, I0);
+        update_group_masked<6, 2>(X, w, g, j, nw, I0);
+        update_group_masked<8, 2>(X, w, g, j, nw, I0);
+        update_group_masked<10, 2>(X, w, g, j, nw, I0);
+        update_group_masked<12, 2>(X, w, g, j, nw, I0);
+        update_group_masked<14, 3>(X, w, g, j, nw, I0);
       }
       // A_KK -= 2 I on the pivot block's own tile
 #pragma unroll
@@ -513,7 +469,7 @@ struct TeamBlk16 {
         const long long c5 = __builtin_readcyclecounter();
         pc[0] += c1 - c0;  // publish (includes waiting for the previous block's MFMA results)
         pc[1] += c2 - c1;  // barrier
-        pc[2] += c3 - c2;  // pivot-block inverse by wave 0 + the barrier that hands T over
+        pc[2] += c3 - c2;  // pivot-block inverse
         pc[3] += c4 - c3;  // -W blocks
         pc[4] += c5 - c4;  // tile updates (issue)
         pc[5] += 1;
@@ -584,49 +540,35 @@ struct TeamBlk16 {
     double* nat = lds + kOffNat;
     double* aux = lds + kOffAux;
     double* part = lds + kOffPart;
-    const int ib = 15 - w, ia = w;
     // forward: y_I = b_I - sum_{J < I} T_IJ y_J; a tile row accumulates its products in-lane (rs[class]), the sum over
-    // the sixteen lanes of a row is taken once, when the row's turn comes.  The tile of a row in column K sits in a
-    // run-time slot (ib - K, or 16 - (ia - K)): a switch, not a scan over the seventeen slots.
+    // the sixteen lanes of a row is taken once, when the row's turn comes
     d4 rs[NCLASS];
 #pragma unroll
     for (int c = 0; c < NCLASS; ++c) rs[c] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
     for (int K = 0; K < nblk; ++K) {
-      if (K == ib || K == ia) {  // wave-uniform: this wave owns tile row K -> y_K, in place over b_K
-        const double red = row_reduce16(K == ib ? rs[0] : rs[1], j);
-        const int e = 16 * K + 4 * (j >> 2) + g;
-        nat[e] = nat[e] - red;  // the four lanes of a quad write the same value
+#pragma unroll
+      for (int c = 0; c < NCLASS; ++c) {
+        if (K == row_of_class(c, w)) {  // wave-uniform: this wave owns tile row K -> y_K, in place over b_K
+          const double red = row_reduce16(rs[c], j);
+          const int e = 16 * K + 4 * (j >> 2) + g;
+          nat[e] = nat[e] - red;  // the four lanes of a quad write the same value
+        }
       }
       __syncthreads();
       const double yk = nat[16 * K + j];
-      auto fma_row = [&](d4& r, const d4 a) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = __builtin_fma(a[k], yk, r[k]);
-      };
-      auto diag_solve = [&](const d4 a) {  // the diagonal tile (K, K) = -P_K^-1: z_K = P_K^-1 y_K
-        d4 zc;
+      for (int s = 0; s < NSLOT; ++s) {
+        if (tile_j(s, w) != K) continue;  // wave-uniform
+        if (is_diag_slot(s)) {
+          // the diagonal tile (K, K) = -P_K^-1: z_K = P_K^-1 y_K
+          d4 zc;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) zc[k] = a[k] * yk;
-        aux[16 * K + 4 * (j >> 2) + g] = -row_reduce16(zc, j);
-      };
-      if (K == ib) diag_solve(acc[0]);
-      if (K == ia) diag_solve(acc[NSLOT - 1]);
-      if (K < ib) {
-        switch (ib - K) {
-#define MM_ROW(S) case S: fma_row(rs[0], acc[S]); break;
-          MM_ROW(1) MM_ROW(2) MM_ROW(3) MM_ROW(4) MM_ROW(5) MM_ROW(6) MM_ROW(7) MM_ROW(8) MM_ROW(9) MM_ROW(10)
-          MM_ROW(11) MM_ROW(12) MM_ROW(13) MM_ROW(14) MM_ROW(15)
-#undef MM_ROW
-          default: break;
-        }
-      }
-      if (K < ia) {
-        switch (ia - K) {
-#define MM_ROW(D) case D: fma_row(rs[1], acc[16 - D]); break;
-          MM_ROW(1) MM_ROW(2) MM_ROW(3) MM_ROW(4) MM_ROW(5) MM_ROW(6) MM_ROW(7)
-#undef MM_ROW
-          default: break;
+          for (int r = 0; r < 4; ++r) zc[r] = acc[s][r] * yk;
+          const double z = row_reduce16(zc, j);
+          aux[16 * K + 4 * (j >> 2) + g] = -z;
+        } else {
+          add_row(s, w, rs, acc[s], yk);
         }
       }
     }
@@ -635,7 +577,7 @@ struct TeamBlk16 {
     // rows I > K left in part[16 K + j][I], publishes u_K, and leaves its own row's partials for the columns J < K.
 #pragma unroll 1
     for (int K = nblk - 1; K >= 0; --K) {
-      if (K == ib || K == ia) {
+      if (K == 15 - w || K == w) {
         double u = aux[16 * K + j];
         const double* src = part + (16 * K + j) * PSTR;
         // slots I <= K are never written (zero from kernel start), slots I >= nblk hold the zeros of padding tiles:
@@ -649,23 +591,17 @@ struct TeamBlk16 {
         lds[kOffVperm + (((K << 2) + (j & 3)) << 2) + (j >> 2)] = u;
         wave_sync();
         const d4 ur = *reinterpret_cast<const d4*>(lds + kOffVperm + ((K * 4 + g) << 2));
-        auto col_partial = [&](const d4 a, const int J) {
-          double m = a[0] * ur[0];
-          m = __builtin_fma(a[1], ur[1], m);
-          m = __builtin_fma(a[2], ur[2], m);
-          m = __builtin_fma(a[3], ur[3], m);
-          part[(16 * J + j) * PSTR + K] = sum_over_g(m);
-        };
-        if (K == ib) {  // tile row 15-w: slots 1..15-w, column J = ib - s
 #pragma unroll
-          for (int s = 1; s < NSLOT - 1; ++s)
-            if (s <= 8 || s <= 15 - w) {
-              if (s <= ib) col_partial(acc[s], ib - s);
-            }
-        } else {  // tile row w: slots 16-w..15, column J = w + s - 16
-#pragma unroll
-          for (int s = 9; s < NSLOT - 1; ++s)
-            if (s > 15 - w) col_partial(acc[s], w + s - 16);
+        for (int s = 0; s < NSLOT; ++s) {
+          if (is_diag_slot(s)) continue;
+          if (tile_i(s, w) != K) continue;  // one of this wave's other rows
+          const int J = tile_j(s, w);
+          double m = acc[s][0] * ur[0];
+          m = __builtin_fma(acc[s][1], ur[1], m);
+          m = __builtin_fma(acc[s][2], ur[2], m);
+          m = __builtin_fma(acc[s][3], ur[3], m);
+          m = sum_over_g(m);
+          part[(16 * J + j) * PSTR + K] = m;
         }
       }
       __syncthreads();
@@ -678,17 +614,11 @@ struct TeamBlk16 {
   // implicit_core.h, kUnifiedConstruct: metric_func(x) then either the explicit inverse (kept in the tiles for
   // matvec / half_vjp_inv / dh2_dpos) or the single solve u = M(x)^-1 rhs
   __device__ __forceinline__ bool construct(double x, bool need_inverse, double rhs, double* u) {
-    // build() is instantiated inside each arm on purpose: with one shared copy in front of the branch the register
-    // allocator gives the tiles one home for the full-sweep arm and spills the whole set to scratch for the other.
-    // The distinct asm markers keep the optimiser from hoisting the common code back out.
+    const bool bad = build(x);
     bool ok;
     if (need_inverse) {  // team-uniform
-      asm volatile("; construct: explicit inverse");
-      const bool bad = build(x);
       ok = sweep<false>(bad);
     } else {
-      asm volatile("; construct: factor and solve");
-      const bool bad = build(x);
       ok = sweep<true>(bad);
       *u = solve(rhs);
     }
@@ -804,7 +734,37 @@ __global__ __launch_bounds__(NTHR, 2) void blk16_debug_kernel(ImplicitArgs A, in
   const double q = act ? A.pos[chain * dim + tid] : 0.0;
   const double p = act ? A.mom[chain * dim + tid] : 0.0;
   double u = 0.0;
-  const bool ok = bk.construct(q, op != 1, p, &u);
+  bool ok = true;
+  if (op <= 2) {
+    ok = bk.construct(q, op != 1, p, &u);
+  } else {
+    ok = bk.construct(q, op != 7, p, &u);
+    if (op >= 8) reps = 0;
+    for (int rep = 0; rep < reps; ++rep) {
+      if (op == 3) ok = !bk.build(q + u * 1e-300) && ok;
+      if (op == 4) ok = bk.construct(q + u * 1e-300, true, p, &u) && ok;
+      if (op == 5) {
+        const bool bad = bk.build(q + u * 1e-300);
+        ok = bk.template sweep<true>(bad) && ok;
+      }
+      if (op == 6) u = bk.matvec(p + u * 1e-300);
+      if (op == 7) u = bk.solve(p + u * 1e-300);
+    }
+    if (op == 8 || op == 9) {  // per-phase cycle counts of one sweep (summed over its blocks), per wave -> out
+      const bool bad = bk.build(q);
+      const long long t0 = __builtin_readcyclecounter();
+      ok = (op == 8) ? bk.template sweep<false, true>(bad) : bk.template sweep<true, true>(bad);
+      const long long t1 = __builtin_readcyclecounter();
+      __syncthreads();
+      if (tid < 64) {
+        const long long* src = reinterpret_cast<const long long*>(lds + kOffPart);
+        u = (tid & 7) == 6 ? (double)(t1 - t0) : (tid & 7) == 7 ? 0.0 : (double)src[tid];
+      }
+      __syncthreads();
+      for (int i = tid; i < DPM * PSTR; i += NTHR) lds[kOffPart + i] = 0.0;
+      __syncthreads();
+    }
+  }
   if (op == 0) {
     double* out = A.out + chain * (int64_t)(DPM * DPM);
     const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
@@ -823,64 +783,6 @@ __global__ __launch_bounds__(NTHR, 2) void blk16_debug_kernel(ImplicitArgs A, in
     if (tid < DPM) A.out[chain * (int64_t)DPM + tid] = u;
   }
   if (tid == 0) A.status[chain] = ok ? 0 : MM_ST_LINALG;
-}
-
-// Timing kernels (tools/ubench_blk16.py), one lean instantiation per OP, rank-one metric only:
-//   3 = build, 4 = build + full sweep, 5 = build + trailing sweep, 6 = mat-vec, 7 = substitution   (x reps)
-//   8 / 9 = per-phase cycle counts of one full / trailing sweep (summed over its blocks), per wave -> out[chain][64];
-//   10..12 = as 8 with a phase removed (sweep<>'s EXPER: results are wrong, only the clock is read)
-template <int OP>
-__global__ __launch_bounds__(NTHR, 2) void blk16_bench_kernel(ImplicitArgs A, int base_ld, int reps) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  TeamBlk16<MM_RMETRIC_RANK1> bk;
-  init_backend(bk, A, base_ld, lds);
-  const int64_t chain = blockIdx.x;
-  const int tid = threadIdx.x, dim = A.dim;
-  const bool act = tid < dim;
-  const double q = act ? A.pos[chain * dim + tid] : 0.0;
-  const double p = act ? A.mom[chain * dim + tid] : 0.0;
-  double u = 0.0;
-  bool ok = true;
-  if constexpr (OP <= 7) {
-    if constexpr (OP == 6) ok = bk.construct(q, true, p, &u);
-    if constexpr (OP == 7) ok = bk.construct(q, false, p, &u);
-    for (int rep = 0; rep < reps; ++rep) {
-      if constexpr (OP == 3) ok = !bk.build(q + u * 1e-300) && ok;
-      if constexpr (OP == 4) ok = bk.template sweep<false>(bk.build(q + u * 1e-300)) && ok;
-      if constexpr (OP == 5) ok = bk.template sweep<true>(bk.build(q + u * 1e-300)) && ok;
-      if constexpr (OP == 6) u = bk.matvec(p + u * 1e-300);
-      if constexpr (OP == 7) u = bk.solve(p + u * 1e-300);
-    }
-    if constexpr (OP <= 5) u = bk.acc[0][0] + bk.acc[NSLOT - 1][1];
-  } else {
-    const bool bad = bk.build(q);
-    const long long t0 = __builtin_readcyclecounter();
-    if constexpr (OP == 8) ok = bk.template sweep<false, true>(bad);
-    if constexpr (OP == 9) ok = bk.template sweep<true, true>(bad);
-    if constexpr (OP == 10) ok = bk.template sweep<false, true, 1>(bad);
-    if constexpr (OP == 11) ok = bk.template sweep<false, true, 2>(bad);
-    if constexpr (OP == 12) ok = bk.template sweep<false, true, 3>(bad);
-    const long long t1 = __builtin_readcyclecounter();
-    __syncthreads();
-    if (tid < 64) {
-      const long long* src = reinterpret_cast<const long long*>(lds + kOffPart);
-      u = (tid & 7) == 6 ? (double)(t1 - t0) : (tid & 7) == 7 ? 0.0 : (double)src[tid];
-    }
-  }
-  if (tid < DPM) A.out[chain * (int64_t)DPM + tid] = u;
-  if (tid == 0) A.status[chain] = ok ? 0 : MM_ST_LINALG;
-}
-
-// out[lane] = 1 if the permlane-swap row sums differ from the ds_bpermute ones for this lane (test hook)
-__global__ void blk16_permlane_check_kernel(double* out) {
-  const int l = threadIdx.x;
-  const double x = 1.0 + 0.37 * l + 1e-3 * l * l;  // distinct per lane, exactly representable sums are not needed
-  const double a16 = swap_sum16(x), b16 = x + __shfl_xor(x, 16);
-  const double a32 = swap_sum32(x), b32 = x + __shfl_xor(x, 32);
-  double y = x + __shfl_xor(x, 16);
-  y += __shfl_xor(y, 32);
-  const double z = swap_sum32(swap_sum16(x));
-  out[l] = (a16 != b16 ? 1.0 : 0.0) + (a32 != b32 ? 2.0 : 0.0) + (y != z ? 4.0 : 0.0);
 }
 
 template <class K, class... Extra>
@@ -937,7 +839,7 @@ int mm_launch_implicit_blk16(mm_ctx* ctx, const mm_model* m, mm_state* s, double
 // N * 256 * 256 (op 0) or N * 256 (op 1, 2) doubles; status[N] (host, may be NULL) receives 0 / 5 per chain.
 extern "C" int mm_debug_blk16_linalg(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* out,
                                      int32_t* status, int reps, double* ms) {
-  if (!ctx || !m || !s || !out || op < 0 || op > 13 || m->rmetric == MM_RMETRIC_NONE ||
+  if (!ctx || !m || !s || !out || op < 0 || op > 9 || m->rmetric == MM_RMETRIC_NONE ||
       m->rmetric == MM_RMETRIC_SOFTABS)
     return MM_ERR_INVALID;
   MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -953,22 +855,7 @@ extern "C" int mm_debug_blk16_linalg(mm_ctx* ctx, const mm_model* m, mm_state* s
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   (void)hipEventRecord(e0, ctx->stream);
-  if (op == 13) {
-    hipLaunchKernelGGL(blk16_permlane_check_kernel, dim3(1), dim3(64), 0, ctx->stream, d_out);
-    lrc = hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_HIP;
-  } else if (op >= 3) {
-    if (m->rmetric != MM_RMETRIC_RANK1) {
-      (void)hipFree(d_out);
-      return MM_ERR_INVALID;
-    }
-    switch (op) {
-#define MM_BENCH(OP) case OP: lrc = launch_blk16(ctx, blk16_bench_kernel<OP>, a, m->rmetric_pad_dim, reps); break;
-      MM_BENCH(3) MM_BENCH(4) MM_BENCH(5) MM_BENCH(6) MM_BENCH(7) MM_BENCH(8) MM_BENCH(9) MM_BENCH(10) MM_BENCH(11)
-      MM_BENCH(12)
-#undef MM_BENCH
-      default: lrc = MM_ERR_INVALID; break;
-    }
-  } else if (m->rmetric == MM_RMETRIC_RANK1)
+  if (m->rmetric == MM_RMETRIC_RANK1)
     lrc = launch_blk16(ctx, blk16_debug_kernel<MM_RMETRIC_RANK1>, a, m->rmetric_pad_dim, op, reps);
   else
     lrc = launch_blk16(ctx, blk16_debug_kernel<MM_RMETRIC_DIAGQUAD>, a, 0, op, reps);

@@ -85,3 +85,13 @@ def test_not_positive_definite_is_flagged():
     for op in (0, 1):
         _, st = _linalg(system, x, x, op)
         assert np.all(st == 5)
+
+
+def test_permlane_swap_semantics():
+    """v_permlane16_swap / v_permlane32_swap (gfx950) give the xor-16 / xor-32 butterfly sums the kernel's
+    column reductions assume - checked on the device against ds_bpermute."""
+    dim = 96
+    system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(np.eye(dim)))
+    x = np.zeros((1, dim))
+    out, _ = _linalg(system, x, x, 13)
+    assert np.all(out[0, :64] == 0.0), out[0, :64]

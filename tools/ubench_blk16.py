@@ -42,4 +42,16 @@ for op, name in names.items():
     us = (t[reps] - t[0]) / reps * 1e3
     res[name] = dict(us=us, kcycles=us * 2.4)
     print(f"{name:22s} {us:8.2f} us  {us * 2.4:8.1f} kcycles", flush=True)
+for op, name in ((8, "full sweep"), (9, "trailing sweep"), (10, "full sweep WITHOUT pivot-block inverse"),
+                 (11, "full sweep WITHOUT tile updates"), (12, "full sweep, tile updates WITHOUT operand loads")):
+    ms = C.c_double(0.0)
+    _ffi.check(fn(ctx.handle, system.device_model(ctx).handle, batch.handle, op, out.ctypes.data_as(_ffi.c_double_p),
+                  None, 0, C.byref(ms)), ctx.handle, "mm_debug_blk16_linalg")
+    prof = out[:, :64].reshape(n, 8, 8).mean(0)  # [wave][phase]
+    nb = prof[0, 5]
+    print(f"{name}: cycle-counter ticks per block (mean over chains; {nb:.0f} blocks), per wave:")
+    print("  wave   publish  barrier  pivot-inv   -W     updates   | sweep total")
+    for w in range(8):
+        print(f"  {w}    " + "  ".join(f"{prof[w, k] / nb:8.0f}" for k in range(5)) + f"   | {prof[w, 6]:10.0f}")
+    res[name + " profile"] = prof.tolist()
 print(json.dumps(res))
