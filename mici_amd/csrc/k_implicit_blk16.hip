@@ -68,7 +68,9 @@ constexpr int kOffScr = kOffRed + 16;                      // [NWAVE][64]: [0] s
                                                            // in lane order, [5][0] its positive-definite flag
 constexpr int kOffX = kOffScr + NWAVE * 64;                // [2][DPM][CS]  panel, double-buffered by block parity
 constexpr int kOffPart = kOffX + 2 * DPM * CS;             // [DPM][PSTR]
-constexpr int kLdsDoubles = kOffPart + DPM * PSTR;
+constexpr int kOffB = kOffPart + DPM * PSTR;               // [DPM] right-hand side of a solve-only construction: the forward
+                                                           // substitution runs inside the trailing sweep, in place
+constexpr int kLdsDoubles = kOffB + DPM;
 static_assert((kOffVperm % 2) == 0 && (kOffScr % 2) == 0 && (kOffX % 2) == 0, "16-byte alignment of the d4 accesses");
 static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU");
 
@@ -306,40 +308,39 @@ struct TeamBlk16 {
       const d4 c2 = *reinterpret_cast<const d4*>(scr + (4 * R0 + 2) * 4);
       const d4 c3 = *reinterpret_cast<const d4*>(scr + (4 * R0 + 3) * 4);
       wave_sync();
-      // P4 = [A B; B^T C] with 2 x 2 blocks, inverted in closed form via the Schur complement of A
-      const double a = c0[0], b = c0[1], e = c1[1];
-      const double b00 = c0[2], b01 = c0[3], b10 = c1[2], b11 = c1[3];
-      const double h = c2[2], i2 = c2[3], jj = c3[3];
-      const double det_a = __builtin_fma(a, e, -b * b);
-      const double ida = fast_rcp(det_a);
-      const double ia00 = e * ida, ia01 = -b * ida, ia11 = a * ida;
-      const double t00 = __builtin_fma(ia00, b00, ia01 * b10), t01 = __builtin_fma(ia00, b01, ia01 * b11);
-      const double t10 = __builtin_fma(ia01, b00, ia11 * b10), t11 = __builtin_fma(ia01, b01, ia11 * b11);
-      const double s00 = h - __builtin_fma(b00, t00, b10 * t10);
-      const double s01 = i2 - __builtin_fma(b00, t01, b10 * t11);
-      const double s11 = jj - __builtin_fma(b01, t01, b11 * t11);
-      const double det_s = __builtin_fma(s00, s11, -s01 * s01);
-      const double ids = fast_rcp(det_s);
-      const double is00 = s11 * ids, is01 = -s01 * ids, is11 = s00 * ids;
-      // pivots of the sequential elimination: a, det_a / a, s00, det_s / s00 (all must be > 0: "Cholesky
-      // factorisation failed", matrices.py:1170-1172; a NaN fails every comparison)
-      ok = ok && (a > 0.0) && (det_a > 0.0) && (s00 > 0.0) && (det_s > 0.0);
-      const double u00 = __builtin_fma(t00, is00, t01 * is01), u01 = __builtin_fma(t00, is01, t01 * is11);
-      const double u10 = __builtin_fma(t10, is00, t11 * is01), u11 = __builtin_fma(t10, is01, t11 * is11);
-      const double p00 = ia00 + __builtin_fma(u00, t00, u01 * t01);
-      const double p01 = ia01 + __builtin_fma(u00, t10, u01 * t11);
-      const double p11 = ia11 + __builtin_fma(u10, t10, u11 * t11);
+      // -W4 = -P4^-1 X4 column by column through the LDL^T factors of the 4 x 4 pivot block (uniform, ~36 FP64
+      // instructions) and a 16-instruction substitution per lane: the in-tile sweep is bound by FP64 issue, and the
+      // explicit closed-form inverse + product it replaces took ~75
+      const double pa = c0[0], pb = c0[1], pc = c0[2], pd = c0[3];
+      const double pe = c1[1], pf = c1[2], pg = c1[3], ph = c2[2], pi = c2[3], pj = c3[3];
+      const double r1 = fast_rcp(pa);
+      const double l21 = pb * r1, l31 = pc * r1, l41 = pd * r1;
+      const double d2 = __builtin_fma(-l21, pb, pe);
+      const double t32 = __builtin_fma(-l21, pc, pf), t42 = __builtin_fma(-l21, pd, pg);
+      const double r2 = fast_rcp(d2);
+      const double l32 = t32 * r2, l42 = t42 * r2;
+      const double d3 = __builtin_fma(-l32, t32, __builtin_fma(-l31, pc, ph));
+      const double t43 = __builtin_fma(-l32, t42, __builtin_fma(-l31, pd, pi));
+      const double r3 = fast_rcp(d3);
+      const double l43 = t43 * r3;
+      const double d4v = __builtin_fma(-l43, t43, __builtin_fma(-l42, t42, __builtin_fma(-l41, pd, pj)));
+      const double r4 = fast_rcp(d4v);
+      // the pivots of the sequential elimination (all must be > 0: "Cholesky factorisation failed",
+      // matrices.py:1170-1172; a NaN fails every comparison)
+      ok = ok && (pa > 0.0) && (d2 > 0.0) && (d3 > 0.0) && (d4v > 0.0);
       d4 q = qv;  // X4 = Q4 - E4
       const int sdx = j - 4 * R0;
       q[0] -= (sdx == 0) ? 1.0 : 0.0;
       q[1] -= (sdx == 1) ? 1.0 : 0.0;
       q[2] -= (sdx == 2) ? 1.0 : 0.0;
       q[3] -= (sdx == 3) ? 1.0 : 0.0;
-      // column c = j of -W4 = -P4^-1 X4; this lane feeds row g of it to the matrix core
-      const double w0 = __builtin_fma(-p00, q[0], __builtin_fma(-p01, q[1], __builtin_fma(u00, q[2], u01 * q[3])));
-      const double w1 = __builtin_fma(-p01, q[0], __builtin_fma(-p11, q[1], __builtin_fma(u10, q[2], u11 * q[3])));
-      const double w2 = __builtin_fma(u00, q[0], __builtin_fma(u10, q[1], __builtin_fma(-is00, q[2], -is01 * q[3])));
-      const double w3 = __builtin_fma(u01, q[0], __builtin_fma(u11, q[1], __builtin_fma(-is01, q[2], -is11 * q[3])));
+      const double y2 = __builtin_fma(-l21, q[0], q[1]);
+      const double y3 = __builtin_fma(-l32, y2, __builtin_fma(-l31, q[0], q[2]));
+      const double y4 = __builtin_fma(-l43, y3, __builtin_fma(-l42, y2, __builtin_fma(-l41, q[0], q[3])));
+      const double w3 = -(y4 * r4);
+      const double w2 = __builtin_fma(-l43, w3, -(y3 * r3));
+      const double w1 = __builtin_fma(-l42, w3, __builtin_fma(-l32, w2, -(y2 * r2)));
+      const double w0 = __builtin_fma(-l41, w3, __builtin_fma(-l31, w2, __builtin_fma(-l21, w1, -(q[0] * r1))));
       const double a_op = (g == 0) ? w0 : (g == 1) ? w1 : (g == 2) ? w2 : w3;
       const double b_op = (g == 0) ? q[0] : (g == 1) ? q[1] : (g == 2) ? q[2] : q[3];
       t = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, t, 0, 0, 0);
@@ -509,6 +510,46 @@ struct TeamBlk16 {
             if (j == 4 * r + g) acc[s][r] -= 2.0;
         }
       }
+      if constexpr (TRAILING) {
+        // (5) forward substitution, fused: y_K = b_K is final once block K starts (every contribution to it came from
+        // this row's own tiles in earlier blocks); the tiles (I, K) just became the finished factor tiles T_IK, so
+        // b_I -= T_IK y_K for this wave's rows below K, and z_K = P_K^-1 y_K from the pivot row's own tile (-P_K^-1).
+        const int ib = 15 - w, ia = w;
+        double* bv = lds + kOffB;
+        const double yk = bv[16 * I0 + j];
+        auto sub_row = [&](const int I, const d4 a) {
+          d4 c;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) c[k] = a[k] * yk;
+          const int e = 16 * I + 4 * (j >> 2) + g;
+          bv[e] = bv[e] - row_reduce16(c, j);  // the four lanes of a quad write the same value
+        };
+        auto diag_solve = [&](const d4 a) {
+          d4 c;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) c[k] = a[k] * yk;
+          lds[kOffAux + 16 * I0 + 4 * (j >> 2) + g] = -row_reduce16(c, j);
+        };
+        if (I0 == ib) diag_solve(acc[0]);
+        if (I0 == ia) diag_solve(acc[NSLOT - 1]);
+        if (I0 < ib) {
+          switch (ib - I0) {
+#define MM_ROW(S) case S: sub_row(ib, acc[S]); break;
+            MM_ROW(1) MM_ROW(2) MM_ROW(3) MM_ROW(4) MM_ROW(5) MM_ROW(6) MM_ROW(7) MM_ROW(8) MM_ROW(9) MM_ROW(10)
+            MM_ROW(11) MM_ROW(12) MM_ROW(13) MM_ROW(14) MM_ROW(15)
+#undef MM_ROW
+            default: break;
+          }
+        }
+        if (I0 < ia) {
+          switch (ia - I0) {
+#define MM_ROW(D) case D: sub_row(ia, acc[16 - D]); break;
+            MM_ROW(1) MM_ROW(2) MM_ROW(3) MM_ROW(4) MM_ROW(5) MM_ROW(6) MM_ROW(7)
+#undef MM_ROW
+            default: break;
+          }
+        }
+      }
       if constexpr (PROF) {
         const long long c5 = __builtin_readcyclecounter();
         pc[0] += c1 - c0;  // publish (includes waiting for the previous block's MFMA results)
@@ -575,61 +616,16 @@ struct TeamBlk16 {
     return tid < dim ? -y : 0.0;
   }
 
-  // ---- u = M^-1 b from the trailing-sweep (LDL^T) factors: forward, diagonal and backward substitution over the
-  // tile rows, one workgroup barrier per tile row and direction -------------------------------------------------
-  __device__ __forceinline__ double solve(double b) {
-    publish_vector(b);
+  // ---- u = M^-1 b from the trailing-sweep (LDL^T) factors: the backward substitution over the tile rows, one workgroup
+  // barrier per tile row --------------------------------------------------------------------------------------------
+  // (the forward and diagonal passes ran inside sweep<true>: aux holds z = D^-1 L^-1 b)
+  __device__ __forceinline__ double solve() {
     const int w = opaque_wave(wave);
     const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
     double* nat = lds + kOffNat;
     double* aux = lds + kOffAux;
     double* part = lds + kOffPart;
     const int ib = 15 - w, ia = w;
-    // forward: y_I = b_I - sum_{J < I} T_IJ y_J; a tile row accumulates its products in-lane (rs[class]), the sum over
-    // the sixteen lanes of a row is taken once, when the row's turn comes.  The tile of a row in column K sits in a
-    // run-time slot (ib - K, or 16 - (ia - K)): a switch, not a scan over the seventeen slots.
-    d4 rs[NCLASS];
-#pragma unroll
-    for (int c = 0; c < NCLASS; ++c) rs[c] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-    for (int K = 0; K < nblk; ++K) {
-      if (K == ib || K == ia) {  // wave-uniform: this wave owns tile row K -> y_K, in place over b_K
-        const double red = row_reduce16(K == ib ? rs[0] : rs[1], j);
-        const int e = 16 * K + 4 * (j >> 2) + g;
-        nat[e] = nat[e] - red;  // the four lanes of a quad write the same value
-      }
-      __syncthreads();
-      const double yk = nat[16 * K + j];
-      auto fma_row = [&](d4& r, const d4 a) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = __builtin_fma(a[k], yk, r[k]);
-      };
-      auto diag_solve = [&](const d4 a) {  // the diagonal tile (K, K) = -P_K^-1: z_K = P_K^-1 y_K
-        d4 zc;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) zc[k] = a[k] * yk;
-        aux[16 * K + 4 * (j >> 2) + g] = -row_reduce16(zc, j);
-      };
-      if (K == ib) diag_solve(acc[0]);
-      if (K == ia) diag_solve(acc[NSLOT - 1]);
-      if (K < ib) {
-        switch (ib - K) {
-#define MM_ROW(S) case S: fma_row(rs[0], acc[S]); break;
-          MM_ROW(1) MM_ROW(2) MM_ROW(3) MM_ROW(4) MM_ROW(5) MM_ROW(6) MM_ROW(7) MM_ROW(8) MM_ROW(9) MM_ROW(10)
-          MM_ROW(11) MM_ROW(12) MM_ROW(13) MM_ROW(14) MM_ROW(15)
-#undef MM_ROW
-          default: break;
-        }
-      }
-      if (K < ia) {
-        switch (ia - K) {
-#define MM_ROW(D) case D: fma_row(rs[1], acc[16 - D]); break;
-          MM_ROW(1) MM_ROW(2) MM_ROW(3) MM_ROW(4) MM_ROW(5) MM_ROW(6) MM_ROW(7)
-#undef MM_ROW
-          default: break;
-        }
-      }
-    }
     __syncthreads();
     // backward: u_K = z_K - sum_{I > K} T_IK^T u_I.  Step K: the owner of tile row K sums the column partials that
     // rows I > K left in part[16 K + j][I], publishes u_K, and leaves its own row's partials for the columns J < K.
@@ -688,9 +684,10 @@ struct TeamBlk16 {
       ok = sweep<false>(bad);
     } else {
       asm volatile("; construct: factor and solve");
+      if (tid < DPM) lds[kOffB + tid] = tid < dim ? rhs : 0.0;  // visible after build()'s barrier
       const bool bad = build(x);
       ok = sweep<true>(bad);
-      *u = solve(rhs);
+      *u = solve();
     }
     return uniform_flag(ok);
   }
@@ -849,7 +846,7 @@ __global__ __launch_bounds__(NTHR, 2) void blk16_bench_kernel(ImplicitArgs A, in
       if constexpr (OP == 4) ok = bk.template sweep<false>(bk.build(q + u * 1e-300)) && ok;
       if constexpr (OP == 5) ok = bk.template sweep<true>(bk.build(q + u * 1e-300)) && ok;
       if constexpr (OP == 6) u = bk.matvec(p + u * 1e-300);
-      if constexpr (OP == 7) u = bk.solve(p + u * 1e-300);
+      if constexpr (OP == 7) u = bk.solve() + u * 1e-300;
     }
     if constexpr (OP <= 5) u = bk.acc[0][0] + bk.acc[NSLOT - 1][1];
   } else {
