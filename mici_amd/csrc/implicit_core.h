@@ -98,17 +98,37 @@ __device__ __forceinline__ int fp_feed(BK& bk, FpCtl& c, double& x0, double& x1,
   return FP_CONT;
 }
 
+struct ChainResult {
+  int status, done;
+  long long n_evals, n_solves, n_metric, n_grad;
+};
+
+// Work counters of a chain.  A backend with kCountersInLds keeps them in LDS (bumped by one thread) instead of in
+// four 64-bit registers of every thread that are live across the whole step: the register-resident-metric team
+// kernel has none to spare.
+enum { CNT_EVALS = 0, CNT_SOLVES, CNT_METRIC, CNT_GRAD };
+template <class BK>
+__device__ __forceinline__ void bump(BK& bk, ChainResult& r, const int which, const int n) {
+  if constexpr (BK::kCountersInLds) {
+    bk.count(which, n);
+  } else {
+    if (which == CNT_EVALS) r.n_evals += n;
+    else if (which == CNT_SOLVES) r.n_solves += n;
+    else if (which == CNT_METRIC) r.n_metric += n;
+    else r.n_grad += n;
+  }
+}
+
 // momentum-space fixed point  x = base - tt * dh2_dpos(q, x)  with the metric fixed (B and B-check)
 template <class BK>
 __device__ __forceinline__ int momentum_solve(BK& bk, double base, double tt, double q,
-                                              const mm_fp_opts& o, double* result,
-                                              long long* n_evals) {
+                                              const mm_fp_opts& o, double* result, ChainResult& r) {
   FpCtl c{0, 0};
   double x0 = base, x1 = 0.0, pt = base;
   int status = MM_ST_OK;
   for (;;) {
     const double fx = base - tt * bk.dh2_dpos(pt, q);
-    *n_evals += 1;
+    bump(bk, r, CNT_EVALS, 1);
     const int act = fp_feed(bk, c, x0, x1, fx, o, &pt, &status);
     if (act == FP_DONE) break;
     if (act == FP_FAIL) return status;
@@ -116,11 +136,6 @@ __device__ __forceinline__ int momentum_solve(BK& bk, double base, double tt, do
   *result = pt;
   return MM_ST_OK;
 }
-
-struct ChainResult {
-  int status, done;
-  long long n_evals, n_solves, n_metric, n_grad;
-};
 
 enum { MODE_INIT = 0, MODE_CFIRST = 1, MODE_CHK = 2, MODE_ADJ = 3, MODE_BADJ = 4 };
 
@@ -156,7 +171,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
     // every tile): the gradient at the point whose metric is about to be built for A / B-adj + A.
     if (mode == MODE_INIT || mode == MODE_BADJ) {
       bk.slot(SL_GNEW) = bk.grad(bk.slot(SL_XQ));
-      ++r.n_grad;
+      bump(bk, r, CNT_GRAD, 1);
     }
     // INIT / BADJ need the explicit inverse (applied ~12 times: momentum solves, both A half-steps, the
     // general-VJP path); the position-space iterations use their metric for a single solve.
@@ -174,7 +189,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
                 ? bk.build_and_invert(bk.slot(SL_XQ))
                 : bk.build_and_solve(bk.slot(SL_XQ), bk.slot(SL_PW), &u_pos);
     }
-    r.n_metric += (mode == MODE_CFIRST) ? 2 : 1;
+    bump(bk, r, CNT_METRIC, (mode == MODE_CFIRST) ? 2 : 1);
     if (!okm) {
       r.status = (mode == MODE_INIT || mode == MODE_BADJ) ? MM_ST_LINALG : MM_ST_SOLVER_LINALG;
       break;
@@ -186,8 +201,8 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         const double p_init = bk.slot(SL_PW);
         double pw = p_init - t * bk.dh2_dpos(p_init, qw);
         double p_back;
-        ++r.n_solves;
-        r.status = momentum_solve(bk, pw, -t, qw, o, &p_back, &r.n_evals);
+        bump(bk, r, CNT_SOLVES, 1);
+        r.status = momentum_solve(bk, pw, -t, qw, o, &p_back, r);
         if (r.status != MM_ST_OK) break;
         if (bk.norm(p_back - bk.slot(SL_PW), o.rev_norm) > o.rev_tol) {
           r.status = MM_ST_NON_REVERSIBLE;
@@ -207,8 +222,8 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       const double q = bk.slot(SL_Q);
       double pw = bk.slot(SL_P) - t * (bk.slot(SL_G) + bk.half_vjp_inv(q));
       // ---- B fwd: solve p' = p - t dh2_dpos(q, p')                        integrators.py:496-502
-      ++r.n_solves;
-      r.status = momentum_solve(bk, pw, t, q, o, &pw, &r.n_evals);
+      bump(bk, r, CNT_SOLVES, 1);
+      r.status = momentum_solve(bk, pw, t, q, o, &pw, r);
       if (r.status != MM_ST_OK) break;
       // ---- C fwd: q += t M(q)^-1 p                                        integrators.py:517-519
       bk.slot(SL_QINIT) = q;
@@ -225,8 +240,8 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
     bool chk_done = false, adj_done = false;
     double q_back = 0.0;
     if (mode == MODE_CFIRST) {
-      r.n_solves += 2;
-      r.n_evals += 2;
+      bump(bk, r, CNT_SOLVES, 2);
+      bump(bk, r, CNT_EVALS, 2);
       {
         // first evaluation of the C-adjoint solve; its state stays parked in slots until CHK is done
         FpCtl cA{0, 0};
@@ -255,7 +270,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         continue;
       }
     } else {  // MODE_CHK or MODE_ADJ: one more evaluation of the active solve
-      ++r.n_evals;
+      bump(bk, r, CNT_EVALS, 1);
       double pt;
       int st = MM_ST_OK;
       const double fx = (mode == MODE_CHK) ? qw - t * u : qw + t * u;
@@ -304,6 +319,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       mode = MODE_BADJ;
     }
   }
+  if constexpr (BK::kCountersInLds) bk.read_counts(r);
   return r;
 }
 

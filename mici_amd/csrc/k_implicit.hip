@@ -327,6 +327,7 @@ template <int TS, int RMETRIC>
 struct WaveBackend {
   static constexpr bool kSolveByInverse = false;  // implicit_core.h: solve = invert + mat-vec, one construction site
   static constexpr bool kUnifiedConstruct = false;
+  static constexpr bool kCountersInLds = false;
   double T[TS][TS];
   int dim, lane, target;
   WaveLds w;

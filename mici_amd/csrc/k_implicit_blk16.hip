@@ -43,6 +43,11 @@ using namespace mmimp;
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// Every case of the "which slot holds the tile of column K" switches ENDS with a distinct marker: with identical
+// tails the optimiser sinks the cases into one block that indexes the tile array dynamically - which moves the
+// array from registers to scratch memory (code sinking works from the end of the blocks upwards).
+#define MM_CASE_MARK(N) asm volatile("; tile slot case " #N)
+
 #ifndef MM_BLK16_PERMLANE
 #define MM_BLK16_PERMLANE 1  // semantics verified on the MI355X by tests/test_gpu_blk16.py::test_permlane_swap_semantics
 #endif
@@ -63,8 +68,8 @@ constexpr int kOffStash = 0;                               // [SL_COUNT][VLM] fl
 constexpr int kOffNat = kOffStash + SL_COUNT * VLM;        // [VLM] natural-order vector
 constexpr int kOffVperm = kOffNat + VLM;                   // [DPM] the same vector as [I][g][r]: row operands as one 32-byte read
 constexpr int kOffAux = kOffVperm + DPM;                   // [VLM] second natural-order vector (z of the substitution)
-constexpr int kOffRed = kOffAux + VLM;                     // [16]  team reductions / flags
-constexpr int kOffScr = kOffRed + 16;                      // [NWAVE][64]: [0] scratch of the in-tile sweep, [1..4] T = -P^-1
+constexpr int kOffRed = kOffAux + VLM;                     // [24]  team reductions / flags / work counters
+constexpr int kOffScr = kOffRed + 24;                      // [NWAVE][64]: [0] scratch of the in-tile sweep, [1..4] T = -P^-1
                                                            // in lane order, [5][0] its positive-definite flag
 constexpr int kOffX = kOffScr + NWAVE * 64;                // [2][DPM][CS]  panel, double-buffered by block parity
 constexpr int kOffPart = kOffX + 2 * DPM * CS;             // [DPM][PSTR]
@@ -175,6 +180,7 @@ template <int RMETRIC>
 struct TeamBlk16 {
   static constexpr bool kSolveByInverse = false;
   static constexpr bool kUnifiedConstruct = true;  // implicit_core.h: one construction site, mode at run time
+  static constexpr bool kCountersInLds = true;     // implicit_core.h: work counters in LDS, bumped by thread 0
   d4 acc[NSLOT];
   int wave; // wave index, wave-uniform (phases re-materialise it through opaque_wave)
   int nblk; // number of 16-pivot blocks that contain real rows: ceil(dim / 16)
@@ -224,6 +230,15 @@ struct TeamBlk16 {
     }
   }
 
+  __device__ __forceinline__ void count(const int which, const int n) {
+    if (tid == 0) lds[kOffRed + 16 + which] += (double)n;  // exact in a double far beyond any launch's counts
+  }
+  __device__ __forceinline__ void read_counts(ChainResult& r) const {  // only thread 0's copy is used
+    r.n_evals = (long long)lds[kOffRed + 16 + CNT_EVALS];
+    r.n_solves = (long long)lds[kOffRed + 16 + CNT_SOLVES];
+    r.n_metric = (long long)lds[kOffRed + 16 + CNT_METRIC];
+    r.n_grad = (long long)lds[kOffRed + 16 + CNT_GRAD];
+  }
   __device__ __forceinline__ double& slot(int i) { return lds[kOffStash + i * VLM + (tid < DPM ? tid : DPM)]; }
 
   __device__ __forceinline__ double norm(double x, int kind) {
@@ -367,6 +382,48 @@ struct TeamBlk16 {
     }
     __builtin_amdgcn_sched_barrier(0);  // bound how far the next groups' operand loads are hoisted
   }
+  // Forward substitution, one step, run inside the trailing sweeps after block I0's updates: y_K = b_K is final
+  // once block K starts (every contribution to it came from this row's own tiles in earlier blocks); the tiles
+  // (I, K) just became the finished factor tiles T_IK, so b_I -= T_IK y_K for this wave's rows below K, and
+  // z_K = P_K^-1 y_K from the pivot row's own tile (-P_K^-1).
+  __device__ __forceinline__ void forward_substitution_step(const int I0, const int w, const int g, const int j) {
+    const int ib = 15 - w, ia = w;
+    double* bv = lds + kOffB;
+    const double yk = bv[16 * I0 + j];
+    auto sub_row = [&](const int I, const d4 a) {
+      d4 c;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c[k] = a[k] * yk;
+      const int e = 16 * I + 4 * (j >> 2) + g;
+      bv[e] = bv[e] - row_reduce16(c, j);  // the four lanes of a quad write the same value
+    };
+    auto diag_solve = [&](const d4 a) {
+      d4 c;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c[k] = a[k] * yk;
+      lds[kOffAux + 16 * I0 + 4 * (j >> 2) + g] = -row_reduce16(c, j);
+    };
+    if (I0 == ib) diag_solve(acc[0]);
+    if (I0 == ia) diag_solve(acc[NSLOT - 1]);
+    if (I0 < ib) {
+      switch (ib - I0) {
+#define MM_ROW(S) case S: sub_row(ib, acc[S]); MM_CASE_MARK(S); break;
+        MM_ROW(1) MM_ROW(2) MM_ROW(3) MM_ROW(4) MM_ROW(5) MM_ROW(6) MM_ROW(7) MM_ROW(8) MM_ROW(9) MM_ROW(10)
+        MM_ROW(11) MM_ROW(12) MM_ROW(13) MM_ROW(14) MM_ROW(15)
+#undef MM_ROW
+        default: break;
+      }
+    }
+    if (I0 < ia) {
+      switch (ia - I0) {
+#define MM_ROW(D) case D: sub_row(ia, acc[16 - D]); MM_CASE_MARK(D); break;
+        MM_ROW(1) MM_ROW(2) MM_ROW(3) MM_ROW(4) MM_ROW(5) MM_ROW(6) MM_ROW(7)
+#undef MM_ROW
+        default: break;
+      }
+    }
+  }
+
   // ---- block-16 symmetric sweep.  TRAILING = false: every tile is updated by every block, tiles end as -M^-1.
   // TRAILING = true: only tiles (I, J) with J >= I0 - the blocked LDL^T: tile (K, K) = -P_K^-1, tile (I, K) =
   // A_IK P_K^-1.  `bad` = this wave's non-finite flag from build().  Returns "positive definite and finite" (uniform).
@@ -412,7 +469,7 @@ struct TeamBlk16 {
           }
         } else if (I0 < ib) {  // its tile in column I0: slot ib - I0 (1..15)
           switch (ib - I0) {
-#define MM_PUT(S) case S: put_coltile(ib, acc[S]); break;
+#define MM_PUT(S) case S: put_coltile(ib, acc[S]); MM_CASE_MARK(S); break;
             MM_PUT(1) MM_PUT(2) MM_PUT(3) MM_PUT(4) MM_PUT(5) MM_PUT(6) MM_PUT(7) MM_PUT(8) MM_PUT(9) MM_PUT(10)
             MM_PUT(11) MM_PUT(12) MM_PUT(13) MM_PUT(14) MM_PUT(15)
 #undef MM_PUT
@@ -428,7 +485,7 @@ struct TeamBlk16 {
           }
         } else if (I0 < ia) {  // its tile in column I0: slot 16 - (ia - I0) (9..15)
           switch (ia - I0) {
-#define MM_PUT(K) case K: put_coltile(ia, acc[16 - K]); break;
+#define MM_PUT(K) case K: put_coltile(ia, acc[16 - K]); MM_CASE_MARK(K); break;
             MM_PUT(1) MM_PUT(2) MM_PUT(3) MM_PUT(4) MM_PUT(5) MM_PUT(6) MM_PUT(7)
 #undef MM_PUT
             default: break;
@@ -510,46 +567,7 @@ struct TeamBlk16 {
             if (j == 4 * r + g) acc[s][r] -= 2.0;
         }
       }
-      if constexpr (TRAILING) {
-        // (5) forward substitution, fused: y_K = b_K is final once block K starts (every contribution to it came from
-        // this row's own tiles in earlier blocks); the tiles (I, K) just became the finished factor tiles T_IK, so
-        // b_I -= T_IK y_K for this wave's rows below K, and z_K = P_K^-1 y_K from the pivot row's own tile (-P_K^-1).
-        const int ib = 15 - w, ia = w;
-        double* bv = lds + kOffB;
-        const double yk = bv[16 * I0 + j];
-        auto sub_row = [&](const int I, const d4 a) {
-          d4 c;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) c[k] = a[k] * yk;
-          const int e = 16 * I + 4 * (j >> 2) + g;
-          bv[e] = bv[e] - row_reduce16(c, j);  // the four lanes of a quad write the same value
-        };
-        auto diag_solve = [&](const d4 a) {
-          d4 c;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) c[k] = a[k] * yk;
-          lds[kOffAux + 16 * I0 + 4 * (j >> 2) + g] = -row_reduce16(c, j);
-        };
-        if (I0 == ib) diag_solve(acc[0]);
-        if (I0 == ia) diag_solve(acc[NSLOT - 1]);
-        if (I0 < ib) {
-          switch (ib - I0) {
-#define MM_ROW(S) case S: sub_row(ib, acc[S]); break;
-            MM_ROW(1) MM_ROW(2) MM_ROW(3) MM_ROW(4) MM_ROW(5) MM_ROW(6) MM_ROW(7) MM_ROW(8) MM_ROW(9) MM_ROW(10)
-            MM_ROW(11) MM_ROW(12) MM_ROW(13) MM_ROW(14) MM_ROW(15)
-#undef MM_ROW
-            default: break;
-          }
-        }
-        if (I0 < ia) {
-          switch (ia - I0) {
-#define MM_ROW(D) case D: sub_row(ia, acc[16 - D]); break;
-            MM_ROW(1) MM_ROW(2) MM_ROW(3) MM_ROW(4) MM_ROW(5) MM_ROW(6) MM_ROW(7)
-#undef MM_ROW
-            default: break;
-          }
-        }
-      }
+      if constexpr (TRAILING) forward_substitution_step(I0, w, g, j);
       if constexpr (PROF) {
         const long long c5 = __builtin_readcyclecounter();
         pc[0] += c1 - c0;  // publish (includes waiting for the previous block's MFMA results)
@@ -573,6 +591,11 @@ struct TeamBlk16 {
     for (int k = 0; k < NWAVE; ++k) flags += lds[kOffRed + 8 + k];
     return ok && flags == 0.0;
   }
+
+  // (A look-ahead variant of the trailing sweep - block I0 first updates and publishes only the tiles of column I0+1,
+  // then one wave inverts the next pivot block while the others finish block I0 - was built and measured: 287 k cycles
+  // per sweep against 192 k.  FP64 vector instructions and FP64 MFMAs share the units of a SIMD, so every instruction
+  // of the inverting wave's dependent chain queues behind an MFMA of the wave it shares its SIMD with.  Removed.)
 
   // ---- y = M^-1 v with the explicit inverse in the tiles (they hold -M^-1 after the full sweep) ----------------
   __device__ __forceinline__ double matvec(double v) {
@@ -732,8 +755,11 @@ struct TeamBlk16 {
     double* nat = lds + kOffNat;
     if (tid < VLM) nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
-    const TargetAux aux = target_prepare<false>(target, nat, dim, tparams, tid & 63);
-    const double gr = (tid < dim) ? target_grad_elem<false>(target, aux, nat, tid, dim, tparams) : 0.0;
+    int i = tid;
+    asm volatile("" : "+v"(i));  // opaque: keeps the per-thread global addresses of the dense-Gaussian target's row
+                                 // (tparams + i * dim, ...) from being hoisted out of the step loop into VGPRs
+    const TargetAux aux = target_prepare<false>(target, nat, dim, tparams, i & 63);
+    const double gr = (i < dim) ? target_grad_elem<false>(target, aux, nat, i, dim, tparams) : 0.0;
     __syncthreads();
     return gr;
   }
@@ -753,6 +779,7 @@ __device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC>& bk, const Impli
   bk.base_ld = base_ld;
   bk.tparams = A.tparams;
   for (int i = threadIdx.x; i < DPM * PSTR; i += NTHR) lds[kOffPart + i] = 0.0;  // unused partial-sum slots stay 0
+  if (threadIdx.x < 8) lds[kOffRed + 16 + threadIdx.x] = 0.0;                     // work counters
   __syncthreads();
 }
 

@@ -90,6 +90,7 @@ template <class C, int RMETRIC>
 struct BlockBackend {
   static constexpr bool kSolveByInverse = true;  // implicit_core.h: solve = invert + mat-vec, one construction site
   static constexpr bool kUnifiedConstruct = false;
+  static constexpr bool kCountersInLds = false;
   static constexpr int PG = C::PG, TS = C::TS, DP = C::DP, NT = C::NT, GS = C::GS, SLOTS = C::SLOTS, VL = C::VL;
   __device__ static __forceinline__ int ppos(int i) { return C::ppos(i); }
   // Tile storage: rows 0..TS-2 in registers (144 VGPRs), row TS-1 in LDS.  The compiler could not

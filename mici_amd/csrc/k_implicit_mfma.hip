@@ -62,6 +62,7 @@ template <int RMETRIC>
 struct MfmaBackend {
   static constexpr bool kSolveByInverse = true;  // implicit_core.h: solve = invert + mat-vec, one construction site
   static constexpr bool kUnifiedConstruct = false;
+  static constexpr bool kCountersInLds = false;
   d4 acc[kTiles];
   int dim, lane, target;
   MLds w;

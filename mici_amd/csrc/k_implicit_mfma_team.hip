@@ -94,6 +94,7 @@ template <int RMETRIC, int W>
 struct TeamMfma {
   static constexpr bool kSolveByInverse = true;  // implicit_core.h: solve = invert + mat-vec, one construction site
   static constexpr bool kUnifiedConstruct = false;
+  static constexpr bool kCountersInLds = false;
   d4 accA[NSA];  // tile row Ia = wave:      slot k <-> tile (Ia, Ia - k), valid for k <= Ia
   d4 accB[NSB];  // tile row Ib = 15 - wave: slot k <-> tile (Ib, Ib - k), valid for k <= Ib
   // The wave index is a TEMPLATE parameter: the kernel switches on it once and each wave runs its own

@@ -74,6 +74,7 @@ static_assert(RP == 16, "rp_sum reduces a 16-lane DPP row");
 struct SoftAbsBackend {
   static constexpr bool kSolveByInverse = false;  // implicit_core.h
   static constexpr bool kUnifiedConstruct = false;
+  static constexpr bool kCountersInLds = false;
   int dim, tid, target;
   int warm = 0;  // eigendecompositions since the last cold start (0: w.V is not a usable basis)
   long long n_sweeps = 0, n_eigh = 0;  // work counters (reported as n_newton_iters / n_inverse)
