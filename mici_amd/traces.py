@@ -15,24 +15,30 @@ from pathlib import Path
 import numpy as np
 
 
+_KEEP = frozenset("._- ")
+
+
 def get_valid_filename(string):
-    """Keep alphanumerics and ``._- `` (samplers.py:80-93)."""
-    return "".join(c for c in string if (c.isalnum() or c in "._- "))
+    """File-name form of a trace / statistic key: every character that is neither alphanumeric nor one of
+    ``. _ -`` or a space is dropped (the rule of samplers.py:80-93, pinned by tests/golden/tracefmt_reference.npz)."""
+    kept = [ch for ch in str(string) if ch.isalnum() or ch in _KEEP]
+    return "".join(kept)
 
 
 def generate_memmap_filenames(dir_path, prefix, key, indices):
-    """samplers.py:96-105"""
-    key_str = get_valid_filename(str(key))
-    return [Path(dir_path) / f"{prefix}_{index}_{key_str}.npy" for index in indices]
+    """``{dir}/{prefix}_{index}_{key}.npy`` for every chain index (the naming of samplers.py:96-105)."""
+    stem = get_valid_filename(key)
+    root = Path(dir_path)
+    return [root / "{}_{}_{}.npy".format(prefix, index, stem) for index in indices]
 
 
 def open_new_memmap(file_path, shape, default_val, dtype):
-    """New ``.npy`` memory map filled with a default value (samplers.py:108-131)."""
-    if isinstance(shape, int):
-        shape = (shape,)
-    memmap = np.lib.format.open_memmap(file_path, dtype=dtype, mode="w+", shape=tuple(shape))
-    memmap[:] = default_val
-    return memmap
+    """Create a ``.npy`` file as a writable memory map, every entry set to ``default_val`` (what
+    samplers.py:108-131 produces)."""
+    dims = (int(shape),) if np.isscalar(shape) else tuple(int(n) for n in shape)
+    mm = np.lib.format.open_memmap(str(file_path), mode="w+", dtype=np.dtype(dtype), shape=dims)
+    mm.fill(default_val)
+    return mm
 
 
 class MemmapTraceWriter:

@@ -1103,6 +1103,33 @@ def main():
                     trace_init=np.array([trace_meta[k][2] for k in sorted(trace_meta)])), collections.Counter()
     cases["tracefmt_reference"] = make_tracefmt
 
+    # ---- ArviZ layout: the reference's own stat renaming + stacking (interop.py:31-51), which
+    # is everything convert_to_inference_data / convert_to_data_tree do before handing the dictionaries to ArviZ
+    def make_interop():
+        from mici import interop as mint
+        r = case_rng("interop_arviz_layout")
+        n_chain, n_draw, d = 3, 7, 4
+        traces = {"pos": [r.standard_normal((n_draw, d)) for _ in range(n_chain)],
+                  "energy": [r.standard_normal(n_draw) for _ in range(n_chain)],
+                  "lp": [r.standard_normal(n_draw) for _ in range(n_chain)]}
+        stats = {"n_step": [r.integers(1, 9, n_draw) for _ in range(n_chain)],
+                 "accept_stat": [r.uniform(size=n_draw) for _ in range(n_chain)],
+                 "convergence_error": [r.uniform(size=n_draw) < 0.1 for _ in range(n_chain)],
+                 "step_size": [np.full(n_draw, 0.25) for _ in range(n_chain)]}
+        out = {}
+        for tag, (ek, lk) in {"default": ("energy", "lp"), "nokeys": (None, None), "absent": ("h", "logp")}.items():
+            ss = mint._stack_arrays(mint._preprocess_stats(traces, stats, ek, lk))
+            out[f"{tag}_stat_keys"] = np.array(sorted(ss))
+            for k, v in ss.items():
+                out[f"{tag}_stat_{k}"] = v
+        post = mint._stack_arrays(traces)
+        return dict(kind="interop", status=np.zeros(1, dtype=np.int32), n_done=np.zeros(1, dtype=np.int32),
+                    trace_keys=np.array(sorted(traces)), stat_in_keys=np.array(sorted(stats)),
+                    **{f"in_trace_{k}": np.stack(v) for k, v in traces.items()},
+                    **{f"in_stat_{k}": np.stack(v) for k, v in stats.items()},
+                    **{f"post_{k}": v for k, v in post.items()}, **out), collections.Counter()
+    cases["interop_arviz_layout"] = make_interop
+
     all_counts = {}
     n_ok, bad = 0, []
     for name, fn in cases.items():
