@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 1
+#define MM_ABI_VERSION 2
 
 typedef struct mm_ctx mm_ctx;
 typedef struct mm_model mm_model;
@@ -278,6 +278,29 @@ int mm_momentum_refresh(mm_ctx* ctx, const mm_model* model, mm_state* state, con
  * "convergence_error" / "non_reversible_step" follow from the proposal's status (mm_state_download_status). */
 int mm_metropolis_accept(mm_ctx* ctx, const mm_model* model, mm_state* state, mm_state* proposal,
                          const double* u, double* accept_prob, int8_t* accepted);
+
+/* ---- device-side random draws ("removes the host round-trip per trajectory") ------------
+ * The reference draws from a NumPy Generator on the host: a standard-normal vector per momentum refresh
+ * (transitions.py:136-142 -> systems.py:365-366, 1401-1402), a uniform per Metropolis accept step
+ * (transitions.py:300-309) and an integer per trajectory of MetropolisRandomIntegrationTransition
+ * (transitions.py:383-386).  The entry points above take those draws from the host (parity mode: the caller's
+ * Generator decides every number).  With mm_state_set_rng the draws of chain i of a state become a pure function of
+ * (seed, chain_offset + i, transition, purpose, position) - Philox4x32-10, counter-based - evaluated on the device:
+ * nothing is uploaded per transition, and the stream of a chain does not depend on how chains are sharded over GPUs
+ * or batched.  `transition` is the caller's transition counter (< 2^40).  oracle/rng.py restates the generator. */
+int mm_state_set_rng(mm_state* state, uint64_t seed, uint64_t chain_offset);
+/* mm_momentum_refresh with z ~ N(0, I) drawn on the device; asynchronous on the ctx stream. */
+int mm_momentum_refresh_rng(mm_ctx* ctx, const mm_model* model, mm_state* state, double coeff, uint64_t transition);
+/* mm_metropolis_accept with u ~ U[0, 1) drawn on the device; accept_prob / accepted may be NULL, in which case the
+ * call does not synchronise.  (The reference draws no uniform after an integration error; here the draw of such a
+ * chain is simply unused - streams are per chain and per transition, so nothing shifts.) */
+int mm_metropolis_accept_rng(mm_ctx* ctx, const mm_model* model, mm_state* state, mm_state* proposal,
+                             uint64_t transition, double* accept_prob, int8_t* accepted);
+/* Per-chain trajectory lengths n_step ~ U{lo, ..., hi - 1} drawn on the device into the state's chain-step counts
+ * (see mm_state_set_chain_steps): MetropolisRandomIntegrationTransition's rng.integers(*n_step_range). */
+int mm_rng_chain_steps(mm_state* state, uint64_t transition, int32_t lo, int32_t hi);
+/* The raw draws of `transition` to host arrays z[N][D], u[N], steps[N] (any may be NULL): reproducibility checks. */
+int mm_rng_draws(mm_state* state, uint64_t transition, double* z, double* u, int32_t* steps, int32_t lo, int32_t hi);
 
 /* ---- multi-GPU: chains are sharded, no collective inside integration; one RCCL all-gather over
  * xGMI per trace collection (the role of the reference's process pool + memmaps,

@@ -11,7 +11,7 @@ from .errors import DeviceError
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmici_amd.so")
 
 MM_COMM_ID_BYTES = 128
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_double_p = C.POINTER(C.c_double)
 c_int8_p = C.POINTER(C.c_int8)
@@ -101,6 +101,11 @@ SIGNATURES = {
     "mm_state_set_step_scale": (C.c_int, [_VP, c_double_p]),
     "mm_state_set_chain_steps": (C.c_int, [_VP, c_int32_p]),
     "mm_metropolis_accept": (C.c_int, [_VP, _VP, _VP, _VP, c_double_p, c_double_p, c_int8_p]),
+    "mm_state_set_rng": (C.c_int, [_VP, C.c_uint64, C.c_uint64]),
+    "mm_momentum_refresh_rng": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_uint64]),
+    "mm_metropolis_accept_rng": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint64, c_double_p, c_int8_p]),
+    "mm_rng_chain_steps": (C.c_int, [_VP, C.c_uint64, C.c_int32, C.c_int32]),
+    "mm_rng_draws": (C.c_int, [_VP, C.c_uint64, c_double_p, c_double_p, c_int32_p, C.c_int32, C.c_int32]),
     "mm_leapfrog_euclid": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int32]),
     "mm_composition_euclid": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int32, C.c_int32, c_double_p, C.c_int32]),
     "mm_implicit_leapfrog": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int32,

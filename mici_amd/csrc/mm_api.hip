@@ -23,6 +23,10 @@ int mm_launch_metropolis_select(mm_ctx*, mm_state*, mm_state*, const double*, co
                                 int8_t*);
 int mm_launch_axpby(mm_ctx*, double* y, const double* x, double a, double b, size_t n);
 int mm_launch_fill_done(mm_ctx*, mm_state*, int32_t n_steps);
+int mm_launch_rng_normal(mm_ctx*, double* d_z, int64_t n, int dim, uint64_t seed, uint64_t chain_offset, uint64_t transition);
+int mm_launch_rng_uniform(mm_ctx*, double* d_u, int64_t n, uint64_t seed, uint64_t chain_offset, uint64_t transition);
+int mm_launch_rng_steps(mm_ctx*, int32_t* d_steps, int64_t n, uint64_t seed, uint64_t chain_offset, uint64_t transition,
+                        int32_t lo, int32_t hi);
 int mm_launch_euclid_hamiltonian(mm_ctx*, const mm_model*, mm_state*, double*);
 int mm_launch_euclid_dh_dmom(mm_ctx*, const mm_model*, mm_state*, double*);
 int mm_launch_euclid_sample_momentum(mm_ctx*, const mm_model*, mm_state*, const double*);
@@ -827,55 +831,88 @@ int mm_dh_dmom(mm_ctx* ctx, const mm_model* m, mm_state* s, double* out) {
   return MM_OK;
 }
 
+// mom = M^{1/2} z with z already in s->d_scratch (device), then the cotangent projection of constrained systems
+static int sample_momentum_from_scratch(mm_ctx* ctx, const mm_model* m, mm_state* s) {
+  int rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 2, nullptr, s->d_scratch)
+                                           : mm_launch_euclid_sample_momentum(ctx, m, s, s->d_scratch);
+  if (rc != MM_OK) return rc;
+  if (m->constr != MM_CONSTR_NONE) rc = mm_launch_constrained_project_momentum(ctx, m, s);  // systems.py:614-616
+  return rc;
+}
+
 int mm_sample_momentum(mm_ctx* ctx, const mm_model* m, mm_state* s, const double* z) {
   int rc = check_pair(ctx, m, s, "mm_sample_momentum");
   if (rc != MM_OK) return rc;
   MM_REQUIRE(ctx, z != nullptr, "mm_sample_momentum: z is NULL");
   if (s->n == 0) return MM_OK;
   MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_scratch, z, (size_t)s->n * s->dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 2, nullptr, s->d_scratch)
-                                       : mm_launch_euclid_sample_momentum(ctx, m, s, s->d_scratch);
+  rc = sample_momentum_from_scratch(ctx, m, s);
   if (rc != MM_OK) return rc;
-  if (m->constr != MM_CONSTR_NONE) {
-    rc = mm_launch_constrained_project_momentum(ctx, m, s);  // systems.py:614-616
-    if (rc != MM_OK) return rc;
-  }
   MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return MM_OK;
 }
 
 // ---- momentum transitions (transitions.py:129-198) -----------------------------------------------------------
-int mm_momentum_refresh(mm_ctx* ctx, const mm_model* m, mm_state* s, const double* z, double coeff) {
-  int rc = check_pair(ctx, m, s, "mm_momentum_refresh");
+// z: host draws, or NULL = device draws of `transition` (the state must have an RNG: mm_state_set_rng)
+static int momentum_refresh(mm_ctx* ctx, const mm_model* m, mm_state* s, const double* z, double coeff,
+                            uint64_t transition, const char* who) {
+  int rc = check_pair(ctx, m, s, who);
   if (rc != MM_OK) return rc;
   MM_REQUIRE(ctx, coeff >= 0.0 && coeff <= 1.0, "mom_resample_coeff should have a value in the interval [0, 1].");
+  MM_REQUIRE(ctx, z != nullptr || s->rng_on, std::string(who) + ": the state has no device RNG (mm_state_set_rng)");
   if (coeff == 0.0 || s->n == 0) return MM_OK;  // transitions.py:193: the momentum is left alone
-  if (coeff == 1.0) return mm_sample_momentum(ctx, m, s, z);
   const size_t nd = (size_t)s->n * s->dim;
-  if (s->mom_save_elems < nd) {
-    (void)hipFree(s->d_mom_save);
-    s->d_mom_save = nullptr;
-    s->mom_save_elems = 0;
-    MM_HIP_CHECK(ctx, hipMalloc(&s->d_mom_save, nd * sizeof(double)));
-    s->mom_save_elems = nd;
+  if (coeff != 1.0) {
+    if (s->mom_save_elems < nd) {
+      (void)hipFree(s->d_mom_save);
+      s->d_mom_save = nullptr;
+      s->mom_save_elems = 0;
+      MM_HIP_CHECK(ctx, hipMalloc(&s->d_mom_save, nd * sizeof(double)));
+      s->mom_save_elems = nd;
+    }
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_mom_save, s->d_mom, nd * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   }
-  MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_mom_save, s->d_mom, nd * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  rc = mm_sample_momentum(ctx, m, s, z);  // mom <- independent draw (projected for constrained systems)
+  if (z) {
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_scratch, z, nd * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    rc = mm_launch_rng_normal(ctx, s->d_scratch, s->n, s->dim, s->rng_seed, s->rng_chain_offset, transition);
+    if (rc != MM_OK) return rc;
+  }
+  rc = sample_momentum_from_scratch(ctx, m, s);  // mom <- independent draw (projected for constrained systems)
   if (rc != MM_OK) return rc;
-  rc = mm_launch_axpby(ctx, s->d_mom, s->d_mom_save, std::sqrt(1.0 - coeff * coeff), coeff, nd);
-  if (rc != MM_OK) return rc;
-  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (coeff != 1.0) {
+    rc = mm_launch_axpby(ctx, s->d_mom, s->d_mom_save, std::sqrt(1.0 - coeff * coeff), coeff, nd);
+    if (rc != MM_OK) return rc;
+  }
+  if (z) MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // z is only borrowed; device draws stay asynchronous
+  return MM_OK;
+}
+
+int mm_momentum_refresh(mm_ctx* ctx, const mm_model* m, mm_state* s, const double* z, double coeff) {
+  MM_REQUIRE(ctx, z != nullptr || coeff == 0.0, "mm_momentum_refresh: z is NULL");
+  return momentum_refresh(ctx, m, s, z, coeff, 0, "mm_momentum_refresh");
+}
+
+int mm_momentum_refresh_rng(mm_ctx* ctx, const mm_model* m, mm_state* s, double coeff, uint64_t transition) {
+  return momentum_refresh(ctx, m, s, nullptr, coeff, transition, "mm_momentum_refresh_rng");
+}
+
+int mm_state_set_rng(mm_state* s, uint64_t seed, uint64_t chain_offset) {
+  MM_REQUIRE(nullptr, s != nullptr, "mm_state_set_rng: state is NULL");
+  s->rng_on = true;
+  s->rng_seed = seed;
+  s->rng_chain_offset = chain_offset;
   return MM_OK;
 }
 
 // ---- Metropolis accept (transitions.py:275-315) ------------------------------------------------------------
-int mm_metropolis_accept(mm_ctx* ctx, const mm_model* m, mm_state* s, mm_state* prop, const double* u,
-                         double* accept_prob, int8_t* accepted) {
-  int rc = check_pair(ctx, m, s, "mm_metropolis_accept");
+static int metropolis_accept(mm_ctx* ctx, const mm_model* m, mm_state* s, mm_state* prop, const double* u,
+                             uint64_t transition, double* accept_prob, int8_t* accepted, const char* who) {
+  int rc = check_pair(ctx, m, s, who);
   if (rc != MM_OK) return rc;
   MM_REQUIRE(ctx, prop != nullptr && prop != s && prop->ctx == ctx && prop->n == s->n && prop->dim == s->dim,
-             "mm_metropolis_accept: proposal must be a distinct state of the same shape");
-  MM_REQUIRE(ctx, u != nullptr, "mm_metropolis_accept: u is NULL");
+             std::string(who) + ": proposal must be a distinct state of the same shape");
+  MM_REQUIRE(ctx, u != nullptr || s->rng_on, std::string(who) + ": the state has no device RNG (mm_state_set_rng)");
   if (s->n == 0) return MM_OK;
   const size_t n = (size_t)s->n;
   // h(state) -> state scratch[0..N), h(proposal) -> proposal scratch[0..N)
@@ -894,13 +931,71 @@ int mm_metropolis_accept(mm_ctx* ctx, const mm_model* m, mm_state* s, mm_state* 
   double* d_u = s->d_tr;
   double* d_prob = s->d_tr + n;
   int8_t* d_acc = reinterpret_cast<int8_t*>(s->d_tr + 2 * n);
-  MM_HIP_CHECK(ctx, hipMemcpyAsync(d_u, u, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (u) {
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(d_u, u, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    rc = mm_launch_rng_uniform(ctx, d_u, s->n, s->rng_seed, s->rng_chain_offset, transition);
+    if (rc != MM_OK) return rc;
+  }
   rc = mm_launch_metropolis_select(ctx, s, prop, s->d_scratch, prop->d_scratch, d_u, d_prob, d_acc);
   if (rc != MM_OK) return rc;
   if (accept_prob)
     MM_HIP_CHECK(ctx, hipMemcpyAsync(accept_prob, d_prob, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (accepted) MM_HIP_CHECK(ctx, hipMemcpyAsync(accepted, d_acc, n, hipMemcpyDeviceToHost, ctx->stream));
-  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // u is only borrowed
+  if (u || accept_prob || accepted) MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // u is only borrowed
+  return MM_OK;
+}
+
+int mm_metropolis_accept(mm_ctx* ctx, const mm_model* m, mm_state* s, mm_state* prop, const double* u,
+                         double* accept_prob, int8_t* accepted) {
+  MM_REQUIRE(ctx, u != nullptr, "mm_metropolis_accept: u is NULL");
+  return metropolis_accept(ctx, m, s, prop, u, 0, accept_prob, accepted, "mm_metropolis_accept");
+}
+
+int mm_metropolis_accept_rng(mm_ctx* ctx, const mm_model* m, mm_state* s, mm_state* prop, uint64_t transition,
+                             double* accept_prob, int8_t* accepted) {
+  return metropolis_accept(ctx, m, s, prop, nullptr, transition, accept_prob, accepted, "mm_metropolis_accept_rng");
+}
+
+int mm_rng_chain_steps(mm_state* s, uint64_t transition, int32_t lo, int32_t hi) {
+  MM_REQUIRE(nullptr, s != nullptr, "mm_rng_chain_steps: state is NULL");
+  mm_ctx* ctx = s->ctx;
+  MM_REQUIRE(ctx, s->rng_on, "mm_rng_chain_steps: the state has no device RNG (mm_state_set_rng)");
+  MM_REQUIRE(ctx, lo >= 0 && hi > lo, "mm_rng_chain_steps: need 0 <= lo < hi");
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (s->n == 0) return MM_OK;
+  if (!s->d_chain_steps) MM_HIP_CHECK(ctx, hipMalloc(&s->d_chain_steps, (size_t)s->n * sizeof(int32_t)));
+  return mm_launch_rng_steps(ctx, s->d_chain_steps, s->n, s->rng_seed, s->rng_chain_offset, transition, lo, hi);
+}
+
+int mm_rng_draws(mm_state* s, uint64_t transition, double* z, double* u, int32_t* steps, int32_t lo, int32_t hi) {
+  MM_REQUIRE(nullptr, s != nullptr, "mm_rng_draws: state is NULL");
+  mm_ctx* ctx = s->ctx;
+  MM_REQUIRE(ctx, s->rng_on, "mm_rng_draws: the state has no device RNG (mm_state_set_rng)");
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (s->n == 0) return MM_OK;
+  const size_t n = (size_t)s->n, nd = n * s->dim;
+  int rc = MM_OK;
+  if (z) {
+    rc = mm_launch_rng_normal(ctx, s->d_scratch, s->n, s->dim, s->rng_seed, s->rng_chain_offset, transition);
+    if (rc != MM_OK) return rc;
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(z, s->d_scratch, nd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (u) {
+    rc = mm_launch_rng_uniform(ctx, s->d_scratch, s->n, s->rng_seed, s->rng_chain_offset, transition);
+    if (rc != MM_OK) return rc;
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(u, s->d_scratch, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (steps) {
+    MM_REQUIRE(ctx, lo >= 0 && hi > lo, "mm_rng_draws: need 0 <= lo < hi");
+    rc = mm_launch_rng_steps(ctx, reinterpret_cast<int32_t*>(s->d_scratch), s->n, s->rng_seed, s->rng_chain_offset,
+                             transition, lo, hi);
+    if (rc != MM_OK) return rc;
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(steps, s->d_scratch, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return MM_OK;
 }
 

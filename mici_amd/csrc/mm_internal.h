@@ -79,6 +79,8 @@ struct mm_state {
   size_t mom_save_elems = 0;
   double* d_step_scale = nullptr;  // optional per-chain step-size factors (mm_state_set_step_scale)
   int32_t* d_chain_steps = nullptr;  // optional per-chain step counts (mm_state_set_chain_steps)
+  bool rng_on = false;  // device-side random draws (mm_state_set_rng): Philox keyed by rng_seed, chain = offset + i
+  uint64_t rng_seed = 0, rng_chain_offset = 0;
   double* d_tr = nullptr;  // transition scratch: u[N], accept_prob[N], accepted[N] (mm_metropolis_accept)
   size_t tr_elems = 0;
 };

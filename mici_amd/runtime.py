@@ -212,6 +212,24 @@ class DeviceBatch:
         _ffi.check(self._lib.mm_state_set_chain_steps(self.handle, ptr), self.ctx.handle,
                    "mm_state_set_chain_steps")
 
+    def set_rng(self, seed, chain_offset=0):
+        """Device-side random draws for this batch (include/mici_amd.h, mm_state_set_rng): chain i draws the stream
+        of global chain ``chain_offset + i`` of job ``seed``."""
+        _ffi.check(self._lib.mm_state_set_rng(self.handle, int(seed) & (2**64 - 1), int(chain_offset)),
+                   self.ctx.handle, "mm_state_set_rng")
+
+    def rng_draws(self, transition, lo=None, hi=None):
+        """(z[N, D], u[N], steps[N] or None) of transition number ``transition`` - what the device-draw entry points
+        consume; for reproducibility checks."""
+        z = np.empty((self.n_chains, self.dim))
+        u = np.empty(self.n_chains)
+        steps = np.empty(self.n_chains, dtype=np.int32) if lo is not None else None
+        _ffi.check(self._lib.mm_rng_draws(self.handle, int(transition), _dptr(z), _dptr(u),
+                                          None if steps is None else steps.ctypes.data_as(_ffi.c_int32_p),
+                                          0 if lo is None else int(lo), 1 if hi is None else int(hi)),
+                   self.ctx.handle, "mm_rng_draws")
+        return z, u, steps
+
     def device_ptrs(self):
         p, m, d = C.c_void_p(), C.c_void_p(), C.c_void_p()
         _ffi.check(self._lib.mm_state_device_ptrs(self.handle, C.byref(p), C.byref(m), C.byref(d)),

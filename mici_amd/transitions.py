@@ -43,6 +43,17 @@ class IndependentMomentumTransition:
                    ctx.handle, "mm_sample_momentum")
 
 
+    def sample_batch_device(self, batch, transition, ctx=None):
+        """As ``sample_batch`` with z ~ N(0, I) drawn ON THE DEVICE (``batch.set_rng(seed, chain_offset)`` first):
+        transition number ``transition`` of every chain's own counter-based stream - nothing is uploaded and the
+        call does not synchronise."""
+        ctx = ctx or batch.ctx
+        model = self.system.device_model(ctx)
+        _ffi.check(ctx._lib.mm_momentum_refresh_rng(ctx.handle, model.handle, batch.handle,
+                                                    float(getattr(self, "mom_resample_coeff", 1.0)), int(transition)),
+                   ctx.handle, "mm_momentum_refresh_rng")
+
+
 class CorrelatedMomentumTransition(IndependentMomentumTransition):
     """Partial momentum refresh mom <- sqrt(1 - c^2) mom + c mom_ind (Horowitz 1991; transitions.py:143-198)."""
 
@@ -176,6 +187,43 @@ class MetropolisStaticIntegrationTransition:
         prop, status, n_done = self.propose_batch(batch, ctx)
         return self.accept_batch(batch, prop, status, n_done, u, ctx)
 
+    def sample_batch_device(self, batch, transition, ctx=None, stats=True):
+        """One transition for every chain with the accept uniform drawn ON THE DEVICE (``batch.set_rng`` first):
+        no per-transition upload.  ``stats=False`` also skips every download - the transition is then a pure
+        sequence of asynchronous launches (statuses stay on the device; a LinAlgError outside a solver - status 5,
+        which the reference lets propagate - is then the caller's to check via ``batch`` statistics later)."""
+        ctx = ctx or batch.ctx
+        prop = self._proposal_for(batch)
+        _ffi.check(ctx._lib.mm_state_copy(prop.handle, batch.handle), ctx.handle, "mm_state_copy")
+        self.integrator.step_device(prop, self.n_step, ctx)
+        model = self.system.device_model(ctx)
+        if not stats:
+            _ffi.check(ctx._lib.mm_metropolis_accept_rng(ctx.handle, model.handle, batch.handle, prop.handle,
+                                                         int(transition), None, None),
+                       ctx.handle, "mm_metropolis_accept_rng")
+            return None
+        status, n_done = prop.download_status()
+        if np.any(status == 5):
+            raise LinAlgError("metric construction failed outside a solver for chain(s) "
+                              f"{np.flatnonzero(status == 5).tolist()}")
+        n = batch.n_chains
+        prob = np.zeros(n)
+        acc = np.zeros(n, dtype=np.int8)
+        _ffi.check(ctx._lib.mm_metropolis_accept_rng(
+            ctx.handle, model.handle, batch.handle, prop.handle, int(transition),
+            prob.ctypes.data_as(_ffi.c_double_p), acc.ctypes.data_as(_ffi.c_int8_p)),
+            ctx.handle, "mm_metropolis_accept_rng")
+        error = status != 0
+        return {
+            "n_step": n_done.astype(np.int64),
+            "metrop_accept_prob": prob,
+            "accept_stat": np.where(error, 0.0, prob),
+            "convergence_error": (status >= 1) & (status <= 3),
+            "non_reversible_step": status == 4,
+            "step_size": np.full(n, self.integrator.step_size, dtype=np.float64),
+            "accepted": acc.astype(bool),
+        }
+
     # ---- one chain, the reference's contract -----------------------------------------------------------
     def sample(self, state, rng):
         ctx = default_context()
@@ -237,6 +285,19 @@ class MetropolisRandomIntegrationTransition(MetropolisStaticIntegrationTransitio
         batch.set_chain_steps(n_step)
         try:
             return super().sample_batch(batch, u, ctx)
+        finally:
+            batch.set_chain_steps(None)
+            self._proposal_for(batch).set_chain_steps(None)
+
+    def sample_batch_device(self, batch, transition, ctx=None, stats=True):
+        """Device draws for BOTH the per-chain trajectory length and the accept uniform (``batch.set_rng`` first)."""
+        ctx = ctx or batch.ctx
+        lo, hi = self.n_step_range
+        _ffi.check(ctx._lib.mm_rng_chain_steps(batch.handle, int(transition), int(lo), int(hi)), ctx.handle,
+                   "mm_rng_chain_steps")
+        self.n_step = int(hi) - 1  # the launch runs to the longest possible trajectory; chains stop at their own count
+        try:
+            return super().sample_batch_device(batch, transition, ctx, stats)
         finally:
             batch.set_chain_steps(None)
             self._proposal_for(batch).set_chain_steps(None)
