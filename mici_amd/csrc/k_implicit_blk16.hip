@@ -184,7 +184,17 @@ struct TeamBlk16 {
   d4 acc[NSLOT];
   int wave; // wave index, wave-uniform (phases re-materialise it through opaque_wave)
   int nblk; // number of 16-pivot blocks that contain real rows: ceil(dim / 16)
-  int dim, tid, target;
+  int dim, target;
+  // the thread index, re-materialised opaquely at every use: per-thread addresses derived from it are computed where
+  // needed instead of being hoisted out of the step loop into long-lived VGPRs
+  struct OpaqueTid {
+    int v;
+    __device__ __forceinline__ operator int() const {
+      int x = v;
+      asm volatile("" : "+v"(x));
+      return x;
+    }
+  } tid;
   double* lds;
   const double* base;  // rank-one metric: base matrix zero-padded, leading dimension base_ld
   int base_ld;
@@ -772,7 +782,7 @@ __device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC>& bk, const Impli
   bk.wave = wv;
   bk.dim = A.dim;
   bk.nblk = (A.dim + 15) >> 4;
-  bk.tid = threadIdx.x;
+  bk.tid.v = threadIdx.x;
   bk.target = A.target;
   bk.lds = lds;
   bk.base = A.rparams;

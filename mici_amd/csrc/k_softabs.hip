@@ -48,9 +48,21 @@ struct SaLds {
   int* rp;      // pair p [32]
   int* rq;      // pair q [32]
   double* red;  // [16]
+  double* cnt;  // [8] work counters of the chain (thread 0)
   double* stash;  // [SL_COUNT][65]
 };
-constexpr int kLdsDoubles = 3 * MAT + 6 * 64 + 4 * 32 + 16 + SL_COUNT * 65;
+constexpr int kLdsDoubles = 3 * MAT + 6 * 64 + 4 * 32 + 16 + 8 + SL_COUNT * 65;
+
+// A value every lane agrees on, moved to scalar registers: the step's control flow (implicit_core.h) and the Jacobi
+// sweeps' termination depend only on team-uniform reductions; telling the compiler so keeps the state machine (mode,
+// iteration counts, the time step) in SGPRs.  The kernel runs at four waves per SIMD (128 VGPRs) and used to spill
+// 106 of them (340 bytes per lane of scratch).
+__device__ __forceinline__ double uniform_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 
 __device__ __forceinline__ double block_reduce4(double v, int kind_max, double* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -61,7 +73,7 @@ __device__ __forceinline__ double block_reduce4(double v, int kind_max, double* 
 #pragma unroll
   for (int w = 1; w < NT / 64; ++w) r = kind_max ? nanmax(r, red[w]) : r + red[w];
   __syncthreads();
-  return r;
+  return uniform_f64(r);
 }
 
 // sum over the RP = 16 consecutive lanes (one DPP row) that share an output element
@@ -74,14 +86,33 @@ static_assert(RP == 16, "rp_sum reduces a 16-lane DPP row");
 struct SoftAbsBackend {
   static constexpr bool kSolveByInverse = false;  // implicit_core.h
   static constexpr bool kUnifiedConstruct = false;
-  static constexpr bool kCountersInLds = false;
-  int dim, tid, target;
+  static constexpr bool kCountersInLds = true;  // implicit_core.h: work counters in LDS, bumped by thread 0
+  int dim, tid_raw, target;
   int warm = 0;  // eigendecompositions since the last cold start (0: w.V is not a usable basis)
-  long long n_sweeps = 0, n_eigh = 0;  // work counters (reported as n_newton_iters / n_inverse)
+  int n_sweeps = 0, n_eigh = 0;  // work counters (reported as n_newton_iters / n_inverse)
   double coeff;
   SaLds w;
   const double* tparams;
 
+  // the thread index, re-materialised opaquely at every use: the per-thread global addresses derived from it
+  // (tparams + tid, ...) are then computed where needed instead of being hoisted into long-lived VGPR pairs
+  struct OpaqueTid {
+    int v;
+    __device__ __forceinline__ operator int() const {
+      int x = v;
+      asm volatile("" : "+v"(x));
+      return x;
+    }
+  } tid;
+  __device__ __forceinline__ void count(const int which, const int n) {
+    if (tid == 0) w.cnt[which] += (double)n;  // exact in a double far beyond any launch's counts
+  }
+  __device__ __forceinline__ void read_counts(ChainResult& r) const {  // only thread 0's copy is used
+    r.n_evals = (long long)w.cnt[CNT_EVALS];
+    r.n_solves = (long long)w.cnt[CNT_SOLVES];
+    r.n_metric = (long long)w.cnt[CNT_METRIC];
+    r.n_grad = (long long)w.cnt[CNT_GRAD];
+  }
   // flat state exists for tid < 64; the other threads share a dummy cell (index 64) per slot
   __device__ __forceinline__ double& slot(int i) { return w.stash[i * 65 + (tid < 64 ? tid : 64)]; }
 
@@ -474,9 +505,10 @@ struct SoftAbsBackend {
 
 __device__ __forceinline__ void init_backend(SoftAbsBackend& bk, const ImplicitArgs& A, double* lds) {
   bk.dim = A.dim;
-  bk.tid = threadIdx.x;
+  bk.tid.v = threadIdx.x;
+  bk.tid_raw = threadIdx.x;
   bk.target = A.target;
-  bk.coeff = A.z[0];  // softabs coefficient (device copy of the model's rmetric_params)
+  bk.coeff = uniform_f64(A.z[0]);  // softabs coefficient (device copy of the model's rmetric_params)
   bk.tparams = A.tparams;
   double* p = lds;
   bk.w.H = p; p += MAT;
@@ -493,7 +525,9 @@ __device__ __forceinline__ void init_backend(SoftAbsBackend& bk, const ImplicitA
   bk.w.rp = reinterpret_cast<int*>(p); p += 32;
   bk.w.rq = reinterpret_cast<int*>(p); p += 32;
   bk.w.red = p; p += 16;
+  bk.w.cnt = p; p += 8;
   bk.w.stash = p;
+  if (threadIdx.x < 8) bk.w.cnt[threadIdx.x] = 0.0;
 }
 
 struct SaArgs {
@@ -515,7 +549,7 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
   const bool act = tid < dim;
   const double q = act ? A.pos[chain * dim + tid] : 0.0;
   const double p = act ? A.mom[chain * dim + tid] : 0.0;
-  const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
+  const double t = uniform_f64(signed_step(A.dir, A.step_scale, chain, A.step_size));
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
   __syncthreads();
