@@ -54,7 +54,8 @@ typedef enum mm_target {
   MM_TARGET_POLY = 3,        /* l = a sum q^2/2 + b sum q^4/4                     params: a, b     */
   MM_TARGET_BANANA = 4,      /* l = sum (1-q_i)^2/20 + sum (q_{i+1}-q_i^2)^2      params: -        */
   MM_TARGET_FUNNEL = 5,      /* scaled funnel, q=(v,x): v^2/18 + n v/2 + e^-v sum w x^2 / 2  params: w[D-1] */
-  MM_TARGET_TORUS = 6        /* README torus density, D=3                         params: R, r, alpha */
+  MM_TARGET_TORUS = 6,       /* README torus density, D=3                         params: R, r, alpha */
+  MM_TARGET_USER = 100       /* user-supplied device code: mm_model_create_from_source    params: any      */
 } mm_target;
 
 typedef enum mm_metric_kind { /* fixed (Euclidean) metric, systems.py:327-345 */
@@ -176,6 +177,17 @@ int mm_ctx_elapsed_ms(mm_ctx* ctx, int slot_begin, int slot_end, double* ms);
 
 /* ---- model ------------------------------------------------------------------------------------------ */
 int mm_model_create(mm_ctx* ctx, const mm_model_desc* desc, mm_model** out);
+/* A model whose TARGET is user code - the reference's `neg_log_dens` / `grad_neg_log_dens` constructor arguments
+ * (systems.py:107, 119) for a device: desc->target must be MM_TARGET_USER, desc->target_params any number of
+ * doubles handed to the user functions, and `hip_source` HIP C++ text defining
+ *     __device__ double mm_user_grad(const double* q, int i, int dim, const double* params);     // d nld / d q_i
+ *     __device__ double mm_user_nld_term(const double* q, int i, int dim, const double* params); // nld = sum_i of it
+ * (q: the chain's whole position vector).  The source is compiled for gfx950 with hipRTC when the model is created
+ * (compile errors come back through mm_last_error) around the wave-per-chain kernels of an EuclideanMetricSystem:
+ * mm_leapfrog_euclid, mm_composition_euclid, mm_hamiltonian, mm_dh_dmom, mm_sample_momentum, mm_momentum_refresh*
+ * and mm_metropolis_accept* work on such a model (identity / diagonal / dense fixed metric); the Riemannian,
+ * constrained and Gaussian-split system classes need more derivatives than these two functions and are refused. */
+int mm_model_create_from_source(mm_ctx* ctx, const mm_model_desc* desc, const char* hip_source, mm_model** out);
 int mm_model_destroy(mm_model* model);
 
 /* ---- chain state: batched ChainState(pos, mom, dir) (states.py:160-305) ---------------------------- */

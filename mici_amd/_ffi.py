@@ -87,6 +87,7 @@ SIGNATURES = {
     "mm_ctx_record": (C.c_int, [_VP, C.c_int]),
     "mm_ctx_elapsed_ms": (C.c_int, [_VP, C.c_int, C.c_int, c_double_p]),
     "mm_model_create": (C.c_int, [_VP, C.POINTER(ModelDesc), C.POINTER(_VP)]),
+    "mm_model_create_from_source": (C.c_int, [_VP, C.POINTER(ModelDesc), C.c_char_p, C.POINTER(_VP)]),
     "mm_model_destroy": (C.c_int, [_VP]),
     "mm_state_alloc": (C.c_int, [_VP, C.c_int64, C.c_int32, C.POINTER(_VP)]),
     "mm_state_alloc_mapped": (C.c_int, [_VP, C.c_int64, C.c_int32, C.POINTER(_VP)]),

@@ -49,7 +49,7 @@ def build(force=False, jobs=None, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(
         os.path.join(HERE, "..", "include", "*.h"))
     hdr_time = _newest(headers)
     cc = hipcc()

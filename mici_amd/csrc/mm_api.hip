@@ -226,9 +226,26 @@ static bool host_jacobi_eigh(const double* a_in, int n, std::vector<double>& w, 
   return true;
 }
 
+static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_src, mm_model** out);
+
 int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
   MM_REQUIRE(nullptr, ctx != nullptr, "mm_model_create: ctx is NULL");
   MM_REQUIRE(ctx, d != nullptr && out != nullptr, "mm_model_create: NULL argument");
+  MM_REQUIRE(ctx, d->target != MM_TARGET_USER, "mm_model_create: a user target needs mm_model_create_from_source");
+  return model_create(ctx, d, nullptr, out);
+}
+
+int mm_model_create_from_source(mm_ctx* ctx, const mm_model_desc* d, const char* hip_source, mm_model** out) {
+  MM_REQUIRE(nullptr, ctx != nullptr, "mm_model_create_from_source: ctx is NULL");
+  MM_REQUIRE(ctx, d != nullptr && out != nullptr && hip_source != nullptr, "mm_model_create_from_source: NULL argument");
+  MM_REQUIRE(ctx, d->target == MM_TARGET_USER, "mm_model_create_from_source: desc->target must be MM_TARGET_USER");
+  MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE && d->constr == MM_CONSTR_NONE && !d->gaussian_split,
+             "mm_model_create_from_source: user targets are supported on EuclideanMetricSystem (identity / diagonal / "
+             "dense fixed metric) only");
+  return model_create(ctx, d, hip_source, out);
+}
+
+static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_src, mm_model** out) {
   *out = nullptr;
   const int D = d->dim;
   MM_REQUIRE(ctx, D >= 1, "mm_model_create: dim must be >= 1");
@@ -240,6 +257,7 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
     case MM_TARGET_POLY: need_t = 2; break;
     case MM_TARGET_FUNNEL: need_t = D - 1; MM_REQUIRE(ctx, D >= 2, "funnel target needs dim >= 2"); break;
     case MM_TARGET_TORUS: need_t = 3; MM_REQUIRE(ctx, D == 3, "torus target needs dim == 3"); break;
+    case MM_TARGET_USER: need_t = d->n_target_params; break;
     default: MM_REQUIRE(ctx, false, "mm_model_create: unknown target id");
   }
   MM_REQUIRE(ctx, d->n_target_params == need_t && (need_t == 0 || d->target_params),
@@ -384,6 +402,7 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
       }
     }
   }
+  if (rc == MM_OK && user_src) rc = mm_rtc_attach(ctx, m, user_src);
   if (rc != MM_OK) {
     mm_model_destroy(m);
     return rc;
@@ -395,6 +414,7 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
 int mm_model_destroy(mm_model* m) {
   if (!m) return MM_OK;
   (void)hipSetDevice(m->ctx->device);
+  mm_rtc_detach(m);
   (void)hipFree(m->d_target_params);
   (void)hipFree(m->d_metric);
   (void)hipFree(m->d_metric_inv);
@@ -682,6 +702,7 @@ int mm_leapfrog_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, in
   MM_REQUIRE(ctx, n_steps >= 0, "mm_leapfrog_euclid: n_steps < 0");
   if (s->n == 0) return MM_OK;
   if (n_steps == 0) return mark_explicit_done(ctx, s, 0);
+  if (m->target == MM_TARGET_USER) return mm_rtc_launch_integrate(ctx, m, s, h, n_steps, nullptr);
   // the Gaussian split's exact h2 flow lives in the generic kernel only
   rc = m->gaussian_split ? -100 : mm_launch_leapfrog_euclid(ctx, m, s, h, n_steps);
   if (rc == -100 || (rc == MM_ERR_UNSUPPORTED && m->dim > 128))
@@ -708,6 +729,7 @@ int mm_composition_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h,
   cf.m = n_coeffs;
   cf.initial_h1 = initial_h1 != 0;
   for (int i = 0; i < n_coeffs; ++i) cf.c[i] = coeffs[i];
+  if (m->target == MM_TARGET_USER) return mm_rtc_launch_integrate(ctx, m, s, h, n_steps, &cf);
   rc = m->gaussian_split ? -100 : mm_launch_composition_euclid(ctx, m, s, h, n_steps, cf);
   if (rc == -100 || (rc == MM_ERR_UNSUPPORTED && m->dim > 128))
     rc = mm_launch_composition_generic(ctx, m, s, h, n_steps, n_coeffs, coeffs, initial_h1 != 0);
@@ -765,6 +787,10 @@ int mm_implicit_midpoint(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, 
   MM_REQUIRE(ctx, n_steps >= 0, "mm_implicit_midpoint: n_steps < 0");
   mm_fp_opts o = {1e-9, 1e10, 100, MM_NORM_LINF, MM_FP_DIRECT, MM_NORM_LINF, 2e-8};
   if (opts) o = *opts;
+  if (m->target == MM_TARGET_USER) {
+    mm_set_error(ctx, "mm_implicit_midpoint: user-defined targets run on the explicit Euclidean integrators only");
+    return MM_ERR_UNSUPPORTED;
+  }
   MM_REQUIRE(ctx, o.max_iters >= 0 && (o.norm == 0 || o.norm == 1) && (o.rev_norm == 0 || o.rev_norm == 1) &&
                       (o.solver == MM_FP_DIRECT || o.solver == MM_FP_STEFFENSEN),
              "mm_implicit_midpoint: bad solver options");
@@ -800,6 +826,7 @@ int mm_constrained_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
 
 // System.h for every chain of s into d_out[N] (device): h1 + h2 of the model's system class.
 static int launch_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_out) {
+  if (m->target == MM_TARGET_USER) return mm_rtc_launch_hamiltonian(ctx, m, s, d_out);
   int rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 0, d_out, nullptr)
                                            : mm_launch_euclid_hamiltonian(ctx, m, s, d_out);
   if (rc == MM_OK && m->dens_wrt_ambient) rc = mm_launch_constrained_add_log_det_sqrt_gram(ctx, m, s, d_out);

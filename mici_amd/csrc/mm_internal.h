@@ -50,6 +50,10 @@ struct mm_model {
   size_t n_rmetric_params = 0;
   double* d_constr_params = nullptr;
   size_t n_constr_params = 0;
+  // user-defined target (MM_TARGET_USER): module compiled at model creation by hipRTC (mm_rtc.hip)
+  void* rtc_module = nullptr;
+  void* rtc_integrate = nullptr;
+  void* rtc_hamiltonian = nullptr;
   double h_target_params[4] = {0, 0, 0, 0};  // first few params host-side (scalars)
   double h_rmetric_params[4] = {0, 0, 0, 0};
   double h_constr_params[4] = {0, 0, 0, 0};
@@ -115,4 +119,8 @@ int mm_launch_constrained_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, 
 int mm_launch_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_h);
 int mm_launch_dh_dmom(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_out);
 int mm_launch_sample_momentum(mm_ctx* ctx, const mm_model* m, mm_state* s, const double* d_z);
+int mm_rtc_attach(mm_ctx* ctx, mm_model* m, const char* user_src);
+void mm_rtc_detach(mm_model* m);
+int mm_rtc_launch_integrate(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_comp_coefs* cf);
+int mm_rtc_launch_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_h);
 int mm_team_padded_dim(int dim);  // k_implicit_large.hip: leading dimension of the padded rank-one base matrix

@@ -12,6 +12,7 @@ import numpy as np
 
 TARGET_GAUSS_ISO, TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_POLY = 0, 1, 2, 3
 TARGET_BANANA, TARGET_FUNNEL, TARGET_TORUS = 4, 5, 6
+TARGET_USER = 100
 METRIC_IDENTITY, METRIC_DIAG, METRIC_DENSE = 0, 1, 2
 RMETRIC_NONE, RMETRIC_RANK1, RMETRIC_DIAGQUAD, RMETRIC_SOFTABS = 0, 1, 2, 3
 CONSTR_NONE, CONSTR_TORUS, CONSTR_FIRST, CONSTR_CIRCLE, CONSTR_LINEAR, CONSTR_SPHERE_PLANE, CONSTR_SPHERE = 0, 1, 2, 3, 4, 5, 6
@@ -31,6 +32,24 @@ class Target:
 
     def __repr__(self):
         return f"{type(self).__name__}(dim={self.dim})"
+
+
+class UserTarget(Target):
+    """A target defined by the USER as HIP device code - the device-side form of the reference's ``neg_log_dens`` /
+    ``grad_neg_log_dens`` constructor arguments (systems.py:107, 119).  ``source`` must define
+
+        __device__ double mm_user_grad(const double* q, int i, int dim, const double* params);      // d nld / d q_i
+        __device__ double mm_user_nld_term(const double* q, int i, int dim, const double* params);  // nld = sum_i
+
+    and is compiled for gfx950 (hipRTC) when the system's device model is created; ``params`` are handed to both
+    functions.  Works with ``EuclideanMetricSystem`` (identity / diagonal / dense metric) and the explicit
+    integrators (leapfrog, symmetric compositions)."""
+
+    def __init__(self, dim, source, params=()):
+        super().__init__(TARGET_USER, dim, params)
+        if not isinstance(source, str) or "mm_user_grad" not in source or "mm_user_nld_term" not in source:
+            raise ValueError("source must define mm_user_grad and mm_user_nld_term (see the class docstring)")
+        self.source = source
 
 
 class GaussIso(Target):

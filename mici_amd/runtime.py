@@ -105,8 +105,13 @@ class DeviceModel:
         d.dens_wrt_ambient = int(bool(dens_wrt_ambient))
         d.constr_params, d.n_constr_params = arr(constr_params)
         h = C.c_void_p()
-        _ffi.check(self._lib.mm_model_create(ctx.handle, C.byref(d), C.byref(h)), ctx.handle,
-                   "mm_model_create")
+        source = getattr(target, "source", None)
+        if source is not None:  # user-defined target: compiled by hipRTC inside the library
+            _ffi.check(self._lib.mm_model_create_from_source(ctx.handle, C.byref(d), source.encode(), C.byref(h)),
+                       ctx.handle, "mm_model_create_from_source")
+        else:
+            _ffi.check(self._lib.mm_model_create(ctx.handle, C.byref(d), C.byref(h)), ctx.handle,
+                       "mm_model_create")
         self.handle = h
         self.dim = dim
         self._keep = []
