@@ -207,6 +207,10 @@ BASELINE_CONFIG = {"c2": "BASELINE.json configs[1]", "c2i": "BASELINE.json confi
 
 
 # ---- CPU baseline: the oracle on this box's host cores ------------
+def _cpu_noop(_):
+    return 0
+
+
 def _cpu_shard_euclid(job):
     """Pool worker: vectorised-over-chains oracle on one shard of chains."""
     osys, q, p, h, steps, coefs = job
@@ -220,14 +224,17 @@ def _cpu_shard_euclid(job):
 
 
 def _cpu_shard_chains(job):
-    """Pool worker: per-chain oracle (how the reference itself runs) on a few chains."""
-    osys, kind, q, p, h, steps = job
+    """Pool worker: per-chain oracle (how the reference itself runs) on a few chains.  The worker prepares the
+    initial momenta of its own chains (p = M(q)^{1/2} z, outside the timed part)."""
+    osys, kind, q, z, h, steps = job
     from oracle import integrators as orc
     fn = orc.constrained_leapfrog_steps if kind == "constrained" else orc.implicit_leapfrog_steps
+    mom = _OracleMomenta(kind, osys, q, z)
+    mom.fix(0, q.shape[0])
     done = 0
     t0 = time.perf_counter()
     for c in range(q.shape[0]):
-        done += fn(osys, q[c], p[c], h, steps)[3]
+        done += fn(osys, q[c], mom.p0[c], h, steps)[3]
     return done, time.perf_counter() - t0
 
 
@@ -281,18 +288,21 @@ def cpu_baseline_measure(config, budget_s):
         k = int(max(1, min((n - n1) // cores, (budget_s / 2) / max(per_chain, 1e-6))))
         # few chains per worker on a many-core box: lengthen their trajectories instead (up to the config's own)
         steps = int(min(w["traj"], max(steps, steps * (budget_s / 2) / max(k * per_chain, 1e-6))))
-        w["momenta"].fix(n1, n1 + cores * k)
-        jobs = [(osys, w["kind"], w["q0"][n1 + r * k:n1 + (r + 1) * k], w["p0"][n1 + r * k:n1 + (r + 1) * k],
+        zz = w["momenta"].z
+        jobs = [(osys, w["kind"], w["q0"][n1 + r * k:n1 + (r + 1) * k], zz[n1 + r * k:n1 + (r + 1) * k],
                  w["h"], steps) for r in range(cores)]
         jobs = [j for j in jobs if j[2].shape[0] > 0]
         sample = (f"oracle per-chain NumPy (reference style): {len(jobs)} workers x {k} chains x {steps} steps of the "
                   "same workload")
         worker = _cpu_shard_chains
-    t0 = time.perf_counter()
     with mp.get_context("fork").Pool(len(jobs)) as pool:
+        pool.map(_cpu_noop, range(len(jobs)), chunksize=1)  # start every worker before the clock does
+        t0 = time.perf_counter()
         res = pool.map(worker, jobs, chunksize=1)
-    wall = time.perf_counter() - t0
+        wall = time.perf_counter() - t0
     total = float(sum(r[0] for r in res))
+    if worker is _cpu_shard_chains:  # the workers' momentum preparation is not part of the workload
+        wall = max(r[1] for r in res)
     out.update(value=total / wall, sample=sample + f" in {wall:.1f} s wall (process pool, 1 BLAS thread per worker)",
                single_chain_1core=single)
     return out
@@ -307,16 +317,25 @@ def cpu_baseline(config, budget_s=16.0):
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         env[k] = "1"
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", config, "--cpu-budget", str(budget_s)]
+    import signal
+    limit = 4 * budget_s + 60
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                            start_new_session=True)  # its own process group: the pool's workers die with it
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=4 * budget_s + 60)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        if r.returncode != 0 or not line:
-            return dict(value=None, unit="leapfrog-steps/s", cores=0, kind="port",
-                        sample=f"cpu baseline worker failed (rc={r.returncode}): {r.stderr[-300:]}")
-        out = json.loads(line[-1])
+        stdout, stderr = proc.communicate(timeout=limit)
     except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.communicate()
         return dict(value=None, unit="leapfrog-steps/s", cores=0, kind="port",
-                    sample=f"cpu baseline worker timed out after {4 * budget_s + 60:.0f} s")
+                    sample=f"cpu baseline worker timed out after {limit:.0f} s")
+    line = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not line:
+        return dict(value=None, unit="leapfrog-steps/s", cores=0, kind="port",
+                    sample=f"cpu baseline worker failed (rc={proc.returncode}): {stderr[-300:]}")
+    out = json.loads(line[-1])
     cal = os.path.join(ROOT, "profiles", "cpu_calibration.json")
     if os.path.exists(cal):
         with open(cal) as fh:
@@ -583,8 +602,8 @@ def main():
     head = run_config(ctx, rdzv, args.config, args.steps, args.warmup, rank, world, args.chains_per_gpu,
                       args.traj_len, gather_mode)
     exit_hard = head.pop("_exit_hard")
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        head["cpu_baseline"] = cpu_baseline(args.config, 20.0)
+    # every GPU measurement comes first; the CPU baselines (all host cores busy) run after the last timed region
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
 
     configs = {}
     default_shape = args.chains_per_gpu is None and args.traj_len is None
@@ -600,9 +619,12 @@ def main():
             res.pop("_exit_hard")
             for key in ("trace_gather", "trace_gather_ms"):
                 res.pop(key)
-            if rank == 0 and world == 1 and not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(cfg, 8.0)
             configs[cfg] = res
+    if want_cpu:
+        head["cpu_baseline"] = cpu_baseline(args.config, 20.0)
+        for cfg, res in configs.items():
+            if "error" not in res:
+                res["cpu_baseline"] = cpu_baseline(cfg, 8.0)
 
     if rank == 0:
         out = {

@@ -7,7 +7,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/pmc_hbm_$cfg
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --output-format csv -d $out/$ctr -o $ctr -- python $GRAFT_REPO_ROOT/bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline > $out/$ctr.log 2>&1
+  rocprofv3 --pmc $ctr --output-format csv -d $out/$ctr -o $ctr -- python $GRAFT_REPO_ROOT/bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs > $out/$ctr.log 2>&1
 done
 python - <<PY
 import csv, glob, json
@@ -26,7 +26,7 @@ res = {"FETCH_SIZE": {"per_launch_values_KB": vals["FETCH_SIZE"], "mean_KB": fet
        "kernel": "$kern ($cfg)",
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128 B request -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported",
        "traffic_bytes_per_launch": (2 * fetch + write) * 1024.0,
-       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline (separate passes)"}
+       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs (separate passes)"}
 json.dump(res, open("$GRAFT_REPO_ROOT/gpurun_out/pmc_hbm_$cfg.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:600])
 PY
