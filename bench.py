@@ -211,46 +211,70 @@ def _cpu_noop(_):
     return 0
 
 
+def _host_cores():
+    """Cores this process may really use: the affinity mask, cut down to the cgroup CPU quota if there is one (a
+    container can show 256 schedulable CPUs and be throttled to a handful)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def _cpu_shard_euclid(job):
-    """Pool worker: vectorised-over-chains oracle on one shard of chains."""
-    osys, q, p, h, steps, coefs = job
+    """Pool worker: vectorised-over-chains oracle on one shard of chains, repeated until the common deadline."""
+    osys, q, p, h, steps, coefs, deadline = job
     from oracle import integrators as orc
-    t0 = time.perf_counter()
-    if coefs is not None:
-        orc.leapfrog_steps_batch(osys, q, p, h, steps, coefficients=list(coefs))
-    else:
-        orc.leapfrog_steps_batch(osys, q, p, h, steps)
-    return q.shape[0] * steps, time.perf_counter() - t0
+    done, t0 = 0, time.perf_counter()
+    while True:
+        if coefs is not None:
+            orc.leapfrog_steps_batch(osys, q, p, h, steps, coefficients=list(coefs))
+        else:
+            orc.leapfrog_steps_batch(osys, q, p, h, steps)
+        done += q.shape[0] * steps
+        if time.time() >= deadline:
+            break
+    return done, time.perf_counter() - t0
 
 
 def _cpu_shard_chains(job):
-    """Pool worker: per-chain oracle (how the reference itself runs) on a few chains.  The worker prepares the
-    initial momenta of its own chains (p = M(q)^{1/2} z, outside the timed part)."""
-    osys, kind, q, z, h, steps = job
+    """Pool worker: per-chain oracle (how the reference itself runs), chain after chain until the common deadline.
+    The worker prepares the initial momenta of its own chains (p = M(q)^{1/2} z) outside the timed part."""
+    osys, kind, q, z, h, steps, deadline = job
     from oracle import integrators as orc
     fn = orc.constrained_leapfrog_steps if kind == "constrained" else orc.implicit_leapfrog_steps
     mom = _OracleMomenta(kind, osys, q, z)
-    mom.fix(0, q.shape[0])
-    done = 0
-    t0 = time.perf_counter()
-    for c in range(q.shape[0]):
-        done += fn(osys, q[c], mom.p0[c], h, steps)[3]
-    return done, time.perf_counter() - t0
+    done, spent, c = 0, 0.0, 0
+    while True:
+        mom.fix(c % q.shape[0], c % q.shape[0] + 1)
+        t0 = time.perf_counter()
+        done += fn(osys, q[c % q.shape[0]], mom.p0[c % q.shape[0]], h, steps)[3]
+        spent += time.perf_counter() - t0
+        c += 1
+        if time.time() >= deadline:
+            break
+    return done, spent
 
 
 def cpu_baseline_measure(config, budget_s):
     """Runs in its own interpreter (see cpu_baseline): 1 BLAS thread per process, no HIP anywhere.
-    (a) reference-style: one chain at a time on one core; (c) sharded over all host cores with a process pool."""
+    (a) reference-style: one chain at a time on one core; (c) sharded over all host cores with a process pool whose
+    workers run until a common deadline (the wall time is bounded whatever the box's real parallelism is)."""
     import multiprocessing as mp
 
     from oracle import integrators as orc
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = _host_cores()
     n = DEFAULT_CHAINS.get(config, 4096)
     w = make_workload(config, n, np.random.default_rng(1234), device=False)
     osys = w["make_oracle"]()
     coefs = w.get("coefficients")
     out = dict(unit="leapfrog-steps/s", cores=cores, kind="port")
+    pool_s = budget_s / 2
     if w["kind"] == "euclid":
         if coefs is not None:
             free = list(coefs)[:(len(coefs) - 3) // 2]
@@ -262,48 +286,40 @@ def cpu_baseline_measure(config, budget_s):
             single_fn(w["q0"][n1 % n], w["p0"][n1 % n], 100)
             n1 += 1
         single = n1 * 100 / (time.perf_counter() - t0)
-        # calibrate the vectorised shard, then give every core ~budget_s/2 of work
         shard = max(1, n // cores)
-        _, dt = _cpu_shard_euclid((osys, w["q0"][:shard], w["p0"][:shard], w["h"], 5, coefs))
-        # ~budget_s/2 of work per core; on a many-core box a shard is a handful of chains, so the trajectory is
-        # repeated (up to 50x) rather than letting process start-up dominate the sample
-        steps = int(max(5, min(50 * w["traj"], 5 * (budget_s / 2) / max(dt, 1e-6))))
-        jobs = [(osys, w["q0"][r * shard:(r + 1) * shard], w["p0"][r * shard:(r + 1) * shard], w["h"], steps, coefs)
-                for r in range(cores)]
-        sample = (f"oracle.leapfrog_steps_batch (NumPy, vectorised over chains): {cores} workers x {shard} chains x "
-                  f"{steps} steps of the same workload")
+        nw = min(cores, n // shard)
+        mk = lambda r, dl: (osys, w["q0"][r * shard:(r + 1) * shard], w["p0"][r * shard:(r + 1) * shard], w["h"], 50,  # noqa: E731
+                            coefs, dl)
+        sample = f"oracle.leapfrog_steps_batch (NumPy, vectorised over chains): {nw} workers x {shard} chains"
         worker = _cpu_shard_euclid
     else:
         steps = {"riemann": 2 if w["dim"] > 128 else 5, "softabs": 3, "constrained": 50}[w["kind"]]
         fn = orc.constrained_leapfrog_steps if w["kind"] == "constrained" else orc.implicit_leapfrog_steps
         n_single = min(n // 2, 64)
-        w["momenta"].fix(0, n_single)
-        t0, n1, done = time.perf_counter(), 0, 0
+        t0, n1, done, spent = time.perf_counter(), 0, 0, 0.0
         while time.perf_counter() - t0 < budget_s / 4 and n1 < n_single:
+            w["momenta"].fix(n1, n1 + 1)
+            t1 = time.perf_counter()
             done += fn(osys, w["q0"][n1], w["p0"][n1], w["h"], steps)[3]
+            spent += time.perf_counter() - t1
             n1 += 1
-        dt1 = time.perf_counter() - t0
-        single = done / dt1
-        per_chain = dt1 / max(n1, 1)
-        k = int(max(1, min((n - n1) // cores, (budget_s / 2) / max(per_chain, 1e-6))))
-        # few chains per worker on a many-core box: lengthen their trajectories instead (up to the config's own)
-        steps = int(min(w["traj"], max(steps, steps * (budget_s / 2) / max(k * per_chain, 1e-6))))
+        single = done / spent
+        k = max(1, (n - n1) // cores)
+        nw = min(cores, (n - n1) // k)
         zz = w["momenta"].z
-        jobs = [(osys, w["kind"], w["q0"][n1 + r * k:n1 + (r + 1) * k], zz[n1 + r * k:n1 + (r + 1) * k],
-                 w["h"], steps) for r in range(cores)]
-        jobs = [j for j in jobs if j[2].shape[0] > 0]
-        sample = (f"oracle per-chain NumPy (reference style): {len(jobs)} workers x {k} chains x {steps} steps of the "
-                  "same workload")
+        mk = lambda r, dl: (osys, w["kind"], w["q0"][n1 + r * k:n1 + (r + 1) * k], zz[n1 + r * k:n1 + (r + 1) * k],  # noqa: E731
+                            w["h"], steps, dl)
+        sample = f"oracle per-chain NumPy (reference style): {nw} workers x up to {k} chains x {steps} steps"
         worker = _cpu_shard_chains
-    with mp.get_context("fork").Pool(len(jobs)) as pool:
-        pool.map(_cpu_noop, range(len(jobs)), chunksize=1)  # start every worker before the clock does
-        t0 = time.perf_counter()
-        res = pool.map(worker, jobs, chunksize=1)
-        wall = time.perf_counter() - t0
+    with mp.get_context("fork").Pool(nw) as pool:
+        pool.map(_cpu_noop, range(nw), chunksize=1)  # start every worker before the clock does
+        deadline = time.time() + pool_s
+        res = pool.map(worker, [mk(r, deadline) for r in range(nw)], chunksize=1)
     total = float(sum(r[0] for r in res))
-    if worker is _cpu_shard_chains:  # the workers' momentum preparation is not part of the workload
-        wall = max(r[1] for r in res)
-    out.update(value=total / wall, sample=sample + f" in {wall:.1f} s wall (process pool, 1 BLAS thread per worker)",
+    wall = max(r[1] for r in res)
+    out.update(value=total / wall,
+               sample=sample + f" of the same workload, every worker running for {pool_s:.0f} s (process pool, 1 BLAS "
+                               f"thread per worker; {wall:.1f} s longest)",
                single_chain_1core=single)
     return out
 
