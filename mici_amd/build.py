@@ -34,6 +34,10 @@ EXTRA_FLAGS = {
 }
 
 
+# development builds (in-kernel phase timers etc.): MICI_AMD_HIPCC_FLAGS="-DMM_SOFTABS_PROF" python -m mici_amd.build --force
+DEV_FLAGS = os.environ.get("MICI_AMD_HIPCC_FLAGS", "").split()
+
+
 def hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -64,7 +68,7 @@ def build(force=False, jobs=None, verbose=True):
 
     def compile_one(pair):
         src, obj = pair
-        cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+        cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), *DEV_FLAGS, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r.returncode, r.stdout + r.stderr
 

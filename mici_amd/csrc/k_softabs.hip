@@ -10,9 +10,9 @@
 //       "Eigenvalues must all be positive."                       matrices.py:1529-1628
 //   the integrator step itself is implicit_core.h (integrators.py:493-544, solvers.py:47-154)
 //
-// eigh = parallel cyclic two-sided Jacobi: each round rotates D/2 disjoint (p,q) pairs
-// (round-robin schedule), columns of H and V then rows of H; sweeps repeat until
-// off(H)^2 <= 1e-30 diag(H)^2 (quadratic convergence, 7-9 sweeps at D = 64).  The result is used only
+// eigh = parallel cyclic ONE-SIDED (Hestenes) Jacobi on G = H V: each round rotates D/2 disjoint column pairs
+// (round-robin schedule) of G and V, a pair per half wave, one barrier per round; sweeps repeat until the columns
+// of G are orthogonal (quadratic convergence, 7-8 sweeps cold, ~2 warm-started).  The result is used only
 // through V f(lambda) V^T products, which do not depend on eigenvalue order or eigenvector signs.
 // The matrix-Tressian products of the built-in targets need only the diagonal and the first row of
 // their matrix argument, so V diag(g) V^T and A J A^T are never formed in full; the latter still needs
@@ -30,28 +30,27 @@ constexpr int BS = 64 / TPD;       // output block side per thread
 constexpr int RP = NT / 64;        // threads per output element of the row-wise reductions
 constexpr int LD = 65;            // LDS leading dimension of the 64 x 64 matrices
 constexpr int MAT = 64 * LD;
+constexpr int LDJ = 72;           // leading dimension of the column-major Jacobi work matrices (eigh())
+constexpr int MATJ = 64 * LDJ;
 constexpr int kMaxSweeps = 30;
 constexpr int kWarmPeriod = 256;  // cold-start the eigenvector basis every this many decompositions
 
 struct SaLds {
-  double* H;    // Hessian -> (after eigh) J matrix / scratch
+  double* H;    // Hessian -> V^T during eigh -> (after eigh) J matrix / scratch    [MATJ]
   double* V;    // eigenvectors (columns)
-  double* W;    // A = V diag(e), then B = A J
+  double* W;    // G^T during eigh; A = V diag(e), then B = A J                    [MATJ]
   double* lam;  // unregularised eigenvalues
   double* lamt; // softabs eigenvalues
   double* gsa;  // grad_softabs(lam)
   double* v1;   // vectors
   double* v2;
   double* nat;
-  double* rc;   // rotation cos [32]
-  double* rs;   // rotation sin [32]
-  int* rp;      // pair p [32]
-  int* rq;      // pair q [32]
+  double* rc;   // rotation (c, s) per pair slot, two rounds: [2][32][2]
   double* red;  // [16]
   double* cnt;  // [8] work counters of the chain (thread 0)
   double* stash;  // [SL_COUNT][65]
 };
-constexpr int kLdsDoubles = 3 * MAT + 6 * 64 + 4 * 32 + 16 + 8 + SL_COUNT * 65;
+constexpr int kLdsDoubles = MAT + 2 * MATJ + 6 * 64 + 4 * 32 + 16 + 8 + SL_COUNT * 65;
 
 // A value every lane agrees on, moved to scalar registers: the step's control flow (implicit_core.h) and the Jacobi
 // sweeps' termination depend only on team-uniform reductions; telling the compiler so keeps the state machine (mode,
@@ -82,6 +81,16 @@ __device__ __forceinline__ double rp_sum(double v) {
   return v + dpp_move<kDppMirror>(v);
 }
 static_assert(RP == 16, "rp_sum reduces a 16-lane DPP row");
+
+// -DMM_SOFTABS_PROF: per-phase cycle totals of block 0 (thread 0's clock), printed at the end of the launch
+#ifdef MM_SOFTABS_PROF
+#define SA_PROF_BEGIN() const long long prof_t0_ = __builtin_readcyclecounter()
+#define SA_PROF_END(slot_) \
+  do { if (tid_raw == 0) w.cnt[slot_] += (double)(__builtin_readcyclecounter() - prof_t0_); } while (0)
+#else
+#define SA_PROF_BEGIN() do {} while (0)
+#define SA_PROF_END(slot_) do {} while (0)
+#endif
 
 struct SoftAbsBackend {
   static constexpr bool kSolveByInverse = false;  // implicit_core.h
@@ -150,18 +159,15 @@ struct SoftAbsBackend {
       if (warm == 0) w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
-    if (warm > 0) to_previous_eigenbasis();
   }
 
-  // Warm start: consecutive metric constructions of a step are at nearby positions, so the previous
-  // eigenvectors almost diagonalise the new Hessian.  H <- V^T H V (two LDS-tiled products, 4 x 4 outputs per
-  // thread) and the Jacobi sweeps continue rotating V: two or three sweeps instead of seven to nine.  The
-  // result is the same decomposition (used only through V f(lambda) V^T forms); a cold start every
-  // kWarmPeriod decompositions bounds the accumulated loss of orthogonality of V.
-  __device__ __forceinline__ void to_previous_eigenbasis() {
-    const int bi = (tid / TPD) * BS, bj = (tid % TPD) * BS;  // this thread's BS x BS output block
+  // G = H V, written COLUMN-major (leading dimension LDJ) into w.W, rows >= dim zeroed: the start of the one-sided
+  // Jacobi.  With a cold start V = I and G = H.  Thread (ti, tj) owns rows {ti, ti + 32} x columns {2 tj, 2 tj + 1}:
+  // the H reads of a 32-lane group are 32 consecutive rows (stride LD = 65 doubles: conflict-free), the V reads are
+  // broadcasts and the G writes are contiguous.
+  __device__ __forceinline__ void times_basis() {
+    const int ti = tid % TPD, bj = (tid / TPD) * BS;
     double acc[BS][BS];
-    // W = H V
 #pragma unroll
     for (int a = 0; a < BS; ++a)
 #pragma unroll
@@ -169,7 +175,7 @@ struct SoftAbsBackend {
     for (int k = 0; k < dim; ++k) {
       double hv[BS], vv[BS];
 #pragma unroll
-      for (int a = 0; a < BS; ++a) hv[a] = w.H[(bi + a) * LD + k];
+      for (int a = 0; a < BS; ++a) hv[a] = w.H[(ti + TPD * a) * LD + k];
 #pragma unroll
       for (int b = 0; b < BS; ++b) vv[b] = w.V[k * LD + bj + b];
 #pragma unroll
@@ -180,133 +186,206 @@ struct SoftAbsBackend {
 #pragma unroll
     for (int a = 0; a < BS; ++a)
 #pragma unroll
-      for (int b = 0; b < BS; ++b) w.W[(bi + a) * LD + bj + b] = acc[a][b];
-    __syncthreads();
-    // H = V^T W
-#pragma unroll
-    for (int a = 0; a < BS; ++a)
-#pragma unroll
-      for (int b = 0; b < BS; ++b) acc[a][b] = 0.0;
-    for (int k = 0; k < dim; ++k) {
-      double vt[BS], ww[BS];
-#pragma unroll
-      for (int a = 0; a < BS; ++a) vt[a] = w.V[k * LD + bi + a];
-#pragma unroll
-      for (int b = 0; b < BS; ++b) ww[b] = w.W[k * LD + bj + b];
-#pragma unroll
-      for (int a = 0; a < BS; ++a)
-#pragma unroll
-        for (int b = 0; b < BS; ++b) acc[a][b] = __builtin_fma(vt[a], ww[b], acc[a][b]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < BS; ++a)
-#pragma unroll
-      for (int b = 0; b < BS; ++b) {
-        // exact symmetry is what the Jacobi sweeps assume: average the two triangles' roundings away
-        w.H[(bi + a) * LD + bj + b] = acc[a][b];
-      }
-    __syncthreads();
-    {
-      const int j = tid & 63;
-      for (int i = tid >> 6; i < dim; i += NT / 64) {
-        if (j < i && j < dim) {
-          const double m = 0.5 * (w.H[i * LD + j] + w.H[j * LD + i]);
-          w.H[i * LD + j] = m;
-          w.H[j * LD + i] = m;
-        }
-      }
-    }
+      for (int b = 0; b < BS; ++b) w.W[(bj + b) * LDJ + ti + TPD * a] = (ti + TPD * a < dim) ? acc[a][b] : 0.0;
     __syncthreads();
   }
 
-  // ---- eigh(H) by parallel cyclic Jacobi: w.lam = eigenvalues, w.V = eigenvectors ----------------------
+  // 1/sqrt(x) to rounding accuracy: the hardware estimate and two Newton steps (x in the normal range)
+  __device__ static __forceinline__ double rsqrt_newton(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * __builtin_fma(-hx * y, y, 1.5);
+    y = y * __builtin_fma(-hx * y, y, 1.5);
+    return y;
+  }
+
+  // ---- eigh(H) by parallel ONE-SIDED (Hestenes) Jacobi: w.lam = eigenvalues, w.V = eigenvectors ----------------
+  // Columns of G = H V and of V are rotated together until the columns of G are mutually orthogonal; then
+  // H V = V diag(lam) with lam_i = g_i . v_i (which carries the sign: H is indefinite in general).  A round rotates
+  // D/2 disjoint column pairs (round-robin schedule) and costs ONE workgroup barrier; the two-sided form this
+  // replaces needed three (parameters, columns, rows) and every wave recomputed every rotation's parameters.
+  //
+  // A round is bound by VALU issue (a wave64 FP64 instruction holds its SIMD for 4 cycles whatever the number of
+  // lanes that matter) and by the LDS write port, so the work is laid out to issue as few wave instructions as
+  // possible: a pair belongs to EIGHT lanes (8 rows each), eight pairs to a wave, so four waves - one per SIMD -
+  // cover the 32 pairs and the three dot products of a pair are 3-step DPP reductions.  Waves 0-3 own G: dots,
+  // rotation parameters, rotation of G, and publish (c, s); waves 4-7 (the second wave of each SIMD) apply the
+  // rotations of the PREVIOUS round to V, which nothing reads until the sweeps end - the two roles hide each
+  // other's LDS and dependent-issue latencies.  G^T and V^T live in LDS with a leading dimension of 72 doubles: the
+  // 32 lanes of a ds_read_b64 group (4 adjacent pair slots x 8 rows) then hit 32 distinct 8-byte slots
+  // (8 ((col + j) mod 4) + row mod 8), and likewise the 16-lane groups of ds_write_b64.  V is transposed into the
+  // dead H buffer on the way in and back on the way out (2 x 32 KB of LDS traffic per decomposition, ~1 round's
+  // worth).
+  //
+  // Warm start: consecutive metric constructions of a step are at nearby positions, so the previous eigenvectors
+  // almost diagonalise the new Hessian (G = H V_prev is nearly orthogonal): ~2.5 sweeps instead of 7-8; a cold start
+  // every kWarmPeriod decompositions bounds the accumulated loss of orthogonality of V.  Jacobi converges
+  // quadratically, so a sweep whose largest |cos(g_p, g_q)| was below 1e-7 is the last one.  The result is used only
+  // through V f(lam) V^T forms, which do not depend on eigenvalue order or eigenvector signs.
   __device__ __forceinline__ bool eigh() {
     const int n2 = dim + (dim & 1);
     const int half = n2 >> 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = wave >> 2;                   // 0: G, 1: V, 2-3: only the barriers
+    const int slot = 8 * (wave & 3) + (lane >> 3);  // the pair slot of this group of 8 lanes
+    const int sub = lane & 7;                     // rows sub + 8 j
     bool converged = false;
     ++n_eigh;
+    SA_PROF_BEGIN();
+    times_basis();
+    double* const G = w.W;
+    double* const Vt = w.H;
+    double* const prm = w.rc;  // (c, s) per pair slot, double buffered by round parity: [2][32][2]
+    for (int e = tid; e < 64 * 64; e += NT) {
+      const int i = e & 63, j = e >> 6;
+      Vt[j * LDJ + i] = (i < dim && j < dim) ? w.V[i * LD + j] : 0.0;
+    }
+    __syncthreads();
+    SA_PROF_END(5);
+    // The tournament as byte offsets of the two columns of this pair slot, advanced from round to round without
+    // multiplications: slot 0 keeps column n2 - 1 and meets r; slot t > 0 has (r + t, r - t) mod (n2 - 1).
+    const int span = (n2 - 1) * LDJ * 8;  // one lap of the moving columns
+    const int step_a = slot == 0 ? 0 : LDJ * 8;  // (both moving columns advance by one column a round)
+    const int a_first = (slot == 0 ? n2 - 1 : slot) * LDJ * 8 + sub * 8;
+    const int b_first = (slot == 0 ? 0 : n2 - 1 - slot) * LDJ * 8 + sub * 8;
+    const int lap_a = slot == 0 ? 0x7fffffff : span;  // (slot 0's resident column n2 - 1 is beyond the lap)
+    const int dummy = dim * LDJ * 8 + sub * 8;  // odd dim: the column that does not exist
+    const bool odd = (dim & 1) != 0;
+    const bool mine = slot < half;
+    int oa = a_first, ob = b_first;    // the round this role works on next (G: round g; V: round g - 1)
+    int g = 0;                         // rounds done by the G role
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
-      double off = 0.0, dg = 0.0;
-      {
-        const int j = tid & 63;  // column; rows strided by 4 (no integer division in the hot loops)
-        if (j < dim)
-          for (int i = tid >> 6; i < dim; i += NT / 64) {
-            const double h = w.H[i * LD + j];
-            if (i == j) dg += h * h; else off += h * h;
+      double big = 0.0, bad = 0.0;
+      ++n_sweeps;
+      for (int r = 0; r < n2 - 1; ++r) {
+#ifndef MM_SA_EXP
+#define MM_SA_EXP 0
+#endif
+        if (MM_SA_EXP == 4) {
+        } else if (role == 0) {
+          if (mine) {
+            double c = 1.0, s = 0.0;
+            if (!odd || (oa != dummy && ob != dummy)) {  // (odd dim: the dummy column's partner sits this round out)
+              char* const ca = reinterpret_cast<char*>(G) + oa;
+              char* const cb = reinterpret_cast<char*>(G) + ob;
+              double xa[8], xb[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                xa[j] = lds_read(ca + 64 * j);
+                xb[j] = lds_read(cb + 64 * j);
+              }
+              double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                al = __builtin_fma(xa[j], xa[j], al);
+                be = __builtin_fma(xb[j], xb[j], be);
+                ga = __builtin_fma(xa[j], xb[j], ga);
+              }
+              al = group8_sum(al);
+              be = group8_sum(be);
+              ga = group8_sum(ga);
+              const double ab = al * be, gg = ga * ga;
+              if (!(ab <= 1.7e308) || !(gg <= 1.7e308)) bad = 1.0;  // NaN or overflow
+              if (gg > 1e-14 * ab) big = 1.0;   // |cos| > 1e-7: another sweep is needed after this one
+              if (MM_SA_EXP == 3) {
+                if (gg == 1.2345) big = 2.0;
+              } else if (MM_SA_EXP == 2) {
+                c = 0.8; s = gg == 1.2345 ? 0.5 : 0.6;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  lds_write(ca + 64 * j, __builtin_fma(c, xa[j], -(s * xb[j])));
+                  lds_write(cb + 64 * j, __builtin_fma(s, xa[j], c * xb[j]));
+                }
+              } else
+              if (gg > 1e-30 * ab) {            // |cos| > 1e-15 (threshold Jacobi; uniform over the 8 lanes)
+                // tan 2 theta = 2 ga / (be - al), |theta| <= pi/4:  cos 2theta = |d| / r, sin 2theta = +-2 ga / r
+                const double d = be - al;
+                const double ri = rsqrt_newton(__builtin_fma(d, d, 4.0 * gg));
+                const double c2 = __builtin_fma(0.5 * fabs(d), ri, 0.5);  // cos^2 theta, in [1/2, 1]
+                const double rc = rsqrt_newton(c2);
+                c = c2 * rc;
+                s = ga * ri * rc;
+                if (d < 0.0) s = -s;
+                if (!(fabs(s) <= 1.0)) bad = 1.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  lds_write(ca + 64 * j, __builtin_fma(c, xa[j], -(s * xb[j])));
+                  lds_write(cb + 64 * j, __builtin_fma(s, xa[j], c * xb[j]));
+                }
+              }
+            }
+            if (sub == 0) {
+              prm[(g & 1) * 64 + 2 * slot] = c;
+              prm[(g & 1) * 64 + 2 * slot + 1] = s;
+            }
           }
+        } else if (role == 1 && g > 0 && MM_SA_EXP != 1) {
+          if (mine) rotate_basis(Vt, prm + ((g - 1) & 1) * 64 + 2 * slot, oa, ob);
+        }
+        if (role == 0 || g > 0) {  // next round's columns
+          oa += step_a; if (oa >= lap_a) oa -= span;
+          ob += LDJ * 8; if (ob >= span) ob -= span;
+        }
+        ++g;
+        __syncthreads();
       }
-      off = block_reduce4(off, 0, w.red);
-      dg = block_reduce4(dg, 0, w.red);
-      if (!(off == off) || !(dg == dg) || fabs(off) > 1.7e308 || fabs(dg) > 1.7e308) {
+      bad = block_reduce4(bad, 0, w.red);
+      if (bad != 0.0) {
         warm = 0;
         return false;
       }
-      if (off <= 1e-30 * dg) {
+      big = block_reduce4(big, 0, w.red);
+      if (MM_SA_EXP != 0) big = sweep < 3 ? 1.0 : 0.0;
+      if (big == 0.0) {
         converged = true;
         break;
       }
-      ++n_sweeps;
-      for (int r = 0; r < n2 - 1; ++r) {
-        if (tid < half) {
-          int a, b;
-          if (tid == 0) { a = n2 - 1; b = r; }
-          else {
-            a = r + tid; if (a >= n2 - 1) a -= n2 - 1;
-            b = r - tid; if (b < 0) b += n2 - 1;
-          }
-          const int p = a < b ? a : b, q = a < b ? b : a;
-          double c = 1.0, s = 0.0;
-          if (q < dim) {
-            const double hpq = w.H[p * LD + q];
-            const double hpp = w.H[p * LD + p], hqq = w.H[q * LD + q];
-            // entries far below the rounding level of their diagonal pair are already converged: rotating
-            // them only costs time (threshold Jacobi)
-            if (hpq != 0.0 && fabs(hpq) > 1e-18 * (fabs(hpp) + fabs(hqq))) {
-              const double tau = (w.H[q * LD + q] - w.H[p * LD + p]) / (2.0 * hpq);
-              const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-              c = 1.0 / sqrt(1.0 + t * t);
-              s = t * c;
-            }
-          }
-          w.rp[tid] = p; w.rq[tid] = q; w.rc[tid] = c; w.rs[tid] = s;
-        }
-        __syncthreads();
-        // column rotations of H and V: (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q) for every row
-        for (int g = tid >> 6; g < half; g += NT / 64) {  // pair g is wave-uniform
-          const int i = tid & 63;
-          const int p = w.rp[g], q = w.rq[g];
-          if (w.rs[g] == 0.0) continue;  // identity rotation (wave-uniform): nothing to do
-          if (q < dim && i < dim) {
-            const double c = w.rc[g], s = w.rs[g];
-            const double hp = w.H[i * LD + p], hq = w.H[i * LD + q];
-            w.H[i * LD + p] = c * hp - s * hq;
-            w.H[i * LD + q] = s * hp + c * hq;
-            const double vp = w.V[i * LD + p], vq = w.V[i * LD + q];
-            w.V[i * LD + p] = c * vp - s * vq;
-            w.V[i * LD + q] = s * vp + c * vq;
-          }
-        }
-        __syncthreads();
-        // row rotations of H
-        for (int g = tid >> 6; g < half; g += NT / 64) {
-          const int j = tid & 63;
-          const int p = w.rp[g], q = w.rq[g];
-          if (w.rs[g] == 0.0) continue;
-          if (q < dim && j < dim) {
-            const double c = w.rc[g], s = w.rs[g];
-            const double hp = w.H[p * LD + j], hq = w.H[q * LD + j];
-            w.H[p * LD + j] = c * hp - s * hq;
-            w.H[q * LD + j] = s * hp + c * hq;
-          }
-        }
-        __syncthreads();
-      }
     }
-    if (tid < 64) w.lam[tid] = (tid < dim) ? w.H[tid * LD + tid] : 1.0;
+    if (role == 1 && mine) rotate_basis(Vt, prm + ((g - 1) & 1) * 64 + 2 * slot, oa, ob);
+    __syncthreads();
+    {  // lam_i = g_i . v_i, 16 lanes per column
+      const int i = tid / RP, part = tid % RP;
+      double lam = 0.0;
+#pragma unroll
+      for (int m = 0; m < 64 / RP; ++m) lam = __builtin_fma(G[i * LDJ + part + RP * m], Vt[i * LDJ + part + RP * m], lam);
+      lam = rp_sum(lam);
+      if (part == 0) w.lam[i] = (i < dim) ? lam : 1.0;
+    }
+    for (int e = tid; e < 64 * 64; e += NT) {
+      const int i = e & 63, j = e >> 6;
+      if (i < dim && j < dim) w.V[i * LD + j] = Vt[j * LDJ + i];
+    }
     __syncthreads();
     warm = converged ? (warm + 1) % kWarmPeriod : 0;
+    SA_PROF_END(4);
     return converged;
+  }
+
+  // One 8-byte LDS access per instruction: ds_read_b64 runs at 256 B/clk, the ds_read2_b64 the compiler would merge
+  // two of these into at 128 B/clk (MI355X_MICROARCH.md, LDS), and the Jacobi rounds are bound by the LDS array.
+  __device__ static __forceinline__ double lds_read(const char* p) {
+    return *reinterpret_cast<const double*>(p);
+  }
+  __device__ static __forceinline__ void lds_write(char* p, double v) { *reinterpret_cast<double*>(p) = v; }
+
+  // the V role of a round: the two columns of V^T at byte offsets oa, ob rotated by the (c, s) the G role published
+  __device__ static __forceinline__ void rotate_basis(double* Vt, const double* cs, int oa, int ob) {
+    const double c = cs[0], s = cs[1];
+    if (s == 0.0) return;  // skipped pair (c = 1)
+    char* const ca = reinterpret_cast<char*>(Vt) + oa;
+    char* const cb = reinterpret_cast<char*>(Vt) + ob;
+    double xa[8], xb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      xa[j] = lds_read(ca + 64 * j);
+      xb[j] = lds_read(cb + 64 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      lds_write(ca + 64 * j, __builtin_fma(c, xa[j], -(s * xb[j])));
+      lds_write(cb + 64 * j, __builtin_fma(s, xa[j], c * xb[j]));
+    }
   }
 
   // softabs(x) = x / tanh(coeff x); grad_softabs (matrices.py:1662-1669)
@@ -417,6 +496,7 @@ struct SoftAbsBackend {
 
   // 0.5 * mtp(grad_log_abs_det), grad_log_abs_det = V diag(grad_softabs(lam)/lamt) V^T  (:1671-1674)
   __device__ __forceinline__ double half_vjp_inv(double q) {
+    SA_PROF_BEGIN();
     {
       const int i = tid / RP, part = tid % RP;
       double md = 0.0, m0 = 0.0;
@@ -436,12 +516,15 @@ struct SoftAbsBackend {
     const double mdf = (tid < dim) ? w.v2[tid] : 0.0;
     const double m0f = (tid < dim) ? w.v1[tid] : 0.0;
     __syncthreads();
-    return 0.5 * mtp(q, mdf, m0f);
+    const double out = 0.5 * mtp(q, mdf, m0f);
+    SA_PROF_END(7);
+    return out;
   }
 
   // 0.5 * mtp(grad_quadratic_form_inv(p)),  -(V (e e^T o J) V^T) = -A J A^T, A = V diag(e),
   // e = V^T p / lamt, J_kl = (lamt_k - lamt_l)/(lam_k - lam_l), J_kk = grad_softabs(lam_k)  (:1676-1685)
   __device__ __forceinline__ double dh2_dpos(double p, double q) {
+    SA_PROF_BEGIN();
     const double c = vt_times(p);
     if (tid < 64) w.v1[tid] = (tid < dim) ? c / w.lamt[tid] : 0.0;  // e
     __syncthreads();
@@ -482,7 +565,9 @@ struct SoftAbsBackend {
     const double mdf = (tid < dim) ? w.v2[tid] : 0.0;
     const double m0f = (tid < dim) ? w.nat[tid] : 0.0;
     __syncthreads();
-    return 0.5 * mtp(q, mdf, m0f);
+    const double out = 0.5 * mtp(q, mdf, m0f);
+    SA_PROF_END(6);
+    return out;
   }
 
   __device__ __forceinline__ double grad(double q) {
@@ -511,19 +596,16 @@ __device__ __forceinline__ void init_backend(SoftAbsBackend& bk, const ImplicitA
   bk.coeff = uniform_f64(A.z[0]);  // softabs coefficient (device copy of the model's rmetric_params)
   bk.tparams = A.tparams;
   double* p = lds;
-  bk.w.H = p; p += MAT;
+  bk.w.H = p; p += MATJ;
+  bk.w.W = p; p += MATJ;
   bk.w.V = p; p += MAT;
-  bk.w.W = p; p += MAT;
   bk.w.lam = p; p += 64;
   bk.w.lamt = p; p += 64;
   bk.w.gsa = p; p += 64;
   bk.w.v1 = p; p += 64;
   bk.w.v2 = p; p += 64;
   bk.w.nat = p; p += 64;
-  bk.w.rc = p; p += 32;
-  bk.w.rs = p; p += 32;
-  bk.w.rp = reinterpret_cast<int*>(p); p += 32;
-  bk.w.rq = reinterpret_cast<int*>(p); p += 32;
+  bk.w.rc = p; p += 4 * 32;
   bk.w.red = p; p += 16;
   bk.w.cnt = p; p += 8;
   bk.w.stash = p;
@@ -554,12 +636,21 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
   bk.slot(SL_P) = p;
   __syncthreads();
   const int my_steps = mmdev::chain_steps(A.chain_steps, chain, A.n_steps);
+#ifdef MM_SOFTABS_PROF
+  const long long prof_start = __builtin_readcyclecounter();
+#endif
   const ChainResult r = MIDPOINT ? implicit_midpoint_chain(bk, t, my_steps, A.opts)
                                  : implicit_leapfrog_chain(bk, t, my_steps, A.opts);
   if (act) {
     A.pos[chain * dim + tid] = bk.slot(SL_Q);
     A.mom[chain * dim + tid] = bk.slot(SL_P);
   }
+#ifdef MM_SOFTABS_PROF
+  if (tid == 0 && chain == 0)
+    printf("softabs prof: total %lld eigh(incl basis) %.0f basis %.0f dh2_dpos %.0f half_vjp %.0f | n_eigh %d sweeps %d "
+           "evals %.0f\n", (long long)(__builtin_readcyclecounter() - prof_start), bk.w.cnt[4], bk.w.cnt[5], bk.w.cnt[6],
+           bk.w.cnt[7], bk.n_eigh, bk.n_sweeps, bk.w.cnt[CNT_EVALS]);
+#endif
   if (tid == 0) {
     A.status[chain] = r.status;
     A.n_done[chain] = r.done;

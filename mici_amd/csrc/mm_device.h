@@ -38,8 +38,10 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
   const long long b = __double_as_longlong(v);
   int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  // bound_ctrl with a dead `old`: the controls used here are full permutations of a row, so no lane falls back to
+  // `old`, and the compiler need not copy the source into the destination first (3 instead of 5 VALU slots a step)
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
