@@ -45,12 +45,14 @@ struct SaLds {
   double* v1;   // vectors
   double* v2;
   double* nat;
-  double* rc;   // rotation (c, s) per pair slot, two rounds: [2][32][2]
+  double* ring; // rotation (c, s) of a block round: [2 (parity)][4 (G wave)][15 (local round)][8 (pair slot)][2]
   double* red;  // [16]
   double* cnt;  // [8] work counters of the chain (thread 0)
+  double* prof; // [8] -DMM_SOFTABS_PROF: cycle stamps inside the Jacobi rounds
   double* stash;  // [SL_COUNT][65]
 };
-constexpr int kLdsDoubles = MAT + 2 * MATJ + 6 * 64 + 4 * 32 + 16 + 8 + SL_COUNT * 65;
+constexpr int kRingDoubles = 15 * 8 * 2;  // (c, s) of the 15 local rounds x 8 pair slots of a block round
+constexpr int kLdsDoubles = MAT + 2 * MATJ + 6 * 64 + 2 * 4 * kRingDoubles + 16 + 8 + 8 + SL_COUNT * 65;
 
 // A value every lane agrees on, moved to scalar registers: the step's control flow (implicit_core.h) and the Jacobi
 // sweeps' termination depend only on team-uniform reductions; telling the compiler so keeps the state machine (mode,
@@ -87,9 +89,21 @@ static_assert(RP == 16, "rp_sum reduces a 16-lane DPP row");
 #define SA_PROF_BEGIN() const long long prof_t0_ = __builtin_readcyclecounter()
 #define SA_PROF_END(slot_) \
   do { if (tid_raw == 0) w.cnt[slot_] += (double)(__builtin_readcyclecounter() - prof_t0_); } while (0)
+// -DMM_SOFTABS_PROF=2 adds stamps inside a Jacobi round of G wave 0 (lane 0 accumulates into prof[k]; scheduling
+// barriers pin their place; they cost ~15 % themselves)
+#if MM_SOFTABS_PROF >= 2
+#define SA_STAMP(var_) \
+  __builtin_amdgcn_sched_barrier(0); const long long var_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define SA_STAMP_ADD(k_, a_, b_) do { if (prof) prof[k_] += (double)((b_) - (a_)); } while (0)
+#else
+#define SA_STAMP(var_) do {} while (0)
+#define SA_STAMP_ADD(k_, a_, b_) do {} while (0)
+#endif
 #else
 #define SA_PROF_BEGIN() do {} while (0)
 #define SA_PROF_END(slot_) do {} while (0)
+#define SA_STAMP(var_) do {} while (0)
+#define SA_STAMP_ADD(k_, a_, b_) do {} while (0)
 #endif
 
 struct SoftAbsBackend {
@@ -161,7 +175,7 @@ struct SoftAbsBackend {
     __syncthreads();
   }
 
-  // G = H V, written COLUMN-major (leading dimension LDJ) into w.W, rows >= dim zeroed: the start of the one-sided
+  // G = H V, written COLUMN-major (leading dimension LDJ) into w.W, rows and columns >= dim zeroed: the start of the one-sided
   // Jacobi.  With a cold start V = I and G = H.  Thread (ti, tj) owns rows {ti, ti + 32} x columns {2 tj, 2 tj + 1}:
   // the H reads of a 32-lane group are 32 consecutive rows (stride LD = 65 doubles: conflict-free), the V reads are
   // broadcasts and the G writes are contiguous.
@@ -186,206 +200,256 @@ struct SoftAbsBackend {
 #pragma unroll
     for (int a = 0; a < BS; ++a)
 #pragma unroll
-      for (int b = 0; b < BS; ++b) w.W[(bj + b) * LDJ + ti + TPD * a] = (ti + TPD * a < dim) ? acc[a][b] : 0.0;
+      for (int b = 0; b < BS; ++b) w.W[(bj + b) * LDJ + ti + TPD * a] = (ti + TPD * a < dim && bj + b < dim) ? acc[a][b] : 0.0;
     __syncthreads();
   }
 
-  // 1/sqrt(x) to rounding accuracy: the hardware estimate and two Newton steps (x in the normal range)
+  // 1/sqrt(x) to rounding accuracy (x in the normal range): the hardware estimate (~2^-23) and ONE third-order
+  // step y (1 + e/2 + 3 e^2/8), e = 1 - x y^2 - four dependent operations where two Newton steps are six, and this
+  // sits on the critical path of every Jacobi rotation
   __device__ static __forceinline__ double rsqrt_newton(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    const double hx = 0.5 * x;
-    y = y * __builtin_fma(-hx * y, y, 1.5);
-    y = y * __builtin_fma(-hx * y, y, 1.5);
-    return y;
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-x, y * y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
   }
 
   // ---- eigh(H) by parallel ONE-SIDED (Hestenes) Jacobi: w.lam = eigenvalues, w.V = eigenvectors ----------------
   // Columns of G = H V and of V are rotated together until the columns of G are mutually orthogonal; then
-  // H V = V diag(lam) with lam_i = g_i . v_i (which carries the sign: H is indefinite in general).  A round rotates
-  // D/2 disjoint column pairs (round-robin schedule) and costs ONE workgroup barrier; the two-sided form this
-  // replaces needed three (parameters, columns, rows) and every wave recomputed every rotation's parameters.
+  // H V = V diag(lam) with lam_i = g_i . v_i (which carries the sign: H is indefinite in general).
   //
-  // A round is bound by VALU issue (a wave64 FP64 instruction holds its SIMD for 4 cycles whatever the number of
-  // lanes that matter) and by the LDS write port, so the work is laid out to issue as few wave instructions as
-  // possible: a pair belongs to EIGHT lanes (8 rows each), eight pairs to a wave, so four waves - one per SIMD -
-  // cover the 32 pairs and the three dot products of a pair are 3-step DPP reductions.  Waves 0-3 own G: dots,
-  // rotation parameters, rotation of G, and publish (c, s); waves 4-7 (the second wave of each SIMD) apply the
-  // rotations of the PREVIOUS round to V, which nothing reads until the sweeps end - the two roles hide each
-  // other's LDS and dependent-issue latencies.  G^T and V^T live in LDS with a leading dimension of 72 doubles: the
-  // 32 lanes of a ds_read_b64 group (4 adjacent pair slots x 8 rows) then hit 32 distinct 8-byte slots
-  // (8 ((col + j) mod 4) + row mod 8), and likewise the 16-lane groups of ds_write_b64.  V is transposed into the
-  // dead H buffer on the way in and back on the way out (2 x 32 KB of LDS traffic per decomposition, ~1 round's
-  // worth).
+  // What the layout is built around (measured, profiles/r02_c3b_jacobi_phases.txt): a workgroup barrier of this
+  // 16-wave team costs ~340 cycles, and a rotation round is a dependent chain (LDS read -> dots -> reduction ->
+  // rotation parameters -> rotate -> LDS write) that a wave cannot shorten by issuing faster.  So
+  //  * a pair belongs to EIGHT lanes (8 rows each): the three dot products are 3-step DPP reductions and eight pairs
+  //    share every wave instruction, so FOUR waves - one per SIMD - rotate G;
+  //  * the 64 columns are 8 blocks of 8, each G wave owns TWO blocks for a "block round" and rotates all 64 cross
+  //    pairs A_i x B_(i+k) (8 local rounds, k = 0..7) with no barrier at all: A_i stays in registers, only the B
+  //    columns go through LDS, and the lanes of a wave are ordered by the in-order LDS queue.  The blocks are paired
+  //    by a round-robin tournament (7 block rounds a sweep, barriers only there); the pairs inside a block are done in
+  //    the first block round of a sweep (7 more local rounds).  A sweep is 63 local rounds and 7 barriers, where the
+  //    flat tournament had 63 of each;
+  //  * the G waves publish every rotation's (c, s) in an LDS ring; waves 4-7 (the second wave of each SIMD) replay
+  //    the PREVIOUS block round on V, which nothing reads until the sweeps end.  Their rounds have no parameter chain,
+  //    so they fill the issue slots the G wave of their SIMD leaves idle.
+  // G^T and V^T live in LDS with a leading dimension of 72 doubles: the 32 lanes of a ds_read_b64 group (4 adjacent
+  // pair slots x 8 rows) then hit 32 distinct 8-byte slots (8 ((col + j) mod 4) + row mod 8), and likewise the
+  // 16-lane groups of ds_write_b64.  V is transposed into the dead H buffer on the way in and back on the way out.
+  // Columns and rows beyond dim are zero: a pair with a zero column has gamma = 0 and is skipped, so the schedule is
+  // the 64-column one for every dim.
   //
   // Warm start: consecutive metric constructions of a step are at nearby positions, so the previous eigenvectors
   // almost diagonalise the new Hessian (G = H V_prev is nearly orthogonal): ~2.5 sweeps instead of 7-8; a cold start
   // every kWarmPeriod decompositions bounds the accumulated loss of orthogonality of V.  Jacobi converges
   // quadratically, so a sweep whose largest |cos(g_p, g_q)| was below 1e-7 is the last one.  The result is used only
   // through V f(lam) V^T forms, which do not depend on eigenvalue order or eigenvector signs.
+
+  // One 8-byte LDS access per element (byte offsets from the matrix base)
+  __device__ static __forceinline__ void load_col(const char* M, int off, double (&x)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const double*>(M + off + 64 * j);
+  }
+  __device__ static __forceinline__ void store_col(char* M, int off, const double (&x)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<double*>(M + off + 64 * j) = x[j];
+  }
+  __device__ static __forceinline__ int col_offset(int col, int sub) { return (col * LDJ + sub) * 8; }
+
+  // The rotation of one column pair held in registers.  GROLE: from the columns' dot products (and published);
+  // otherwise the published one.  Returns whether the columns changed.
+  // (c, s) must satisfy c^2 + s^2 = 1 to rounding - V stays orthogonal only then - which rules out the tempting
+  // unnormalised form a - t b, b + t a with a low-precision t: it scales the two columns, the next rotation mixes a
+  // scaled with an unscaled column, and the columns of G come out orthogonal without V being orthogonal.
+  template <bool GROLE>
+  __device__ static __forceinline__ bool rotate_pair(double (&xa)[8], double (&xb)[8], double* cs, bool writer,
+                                                     double& big, double& bad, double* prof) {
+    double c = 1.0, s = 0.0;
+    if (GROLE) {
+      SA_STAMP(t0);
+      double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        al = __builtin_fma(xa[j], xa[j], al);
+        be = __builtin_fma(xb[j], xb[j], be);
+        ga = __builtin_fma(xa[j], xb[j], ga);
+      }
+      SA_STAMP(t1);
+      al = group8_sum(al);
+      be = group8_sum(be);
+      ga = group8_sum(ga);
+      SA_STAMP(t2);
+      SA_STAMP_ADD(0, t0, t1);
+      SA_STAMP_ADD(1, t1, t2);
+      const double ab = al * be, gg = ga * ga;
+      if (!(ab <= 1.7e308) || !(gg <= 1.7e308)) bad = 1.0;  // NaN or overflow
+      if (gg > 1e-14 * ab) big = 1.0;   // |cos| > 1e-7: another sweep is needed after this one
+      if (gg > 1e-30 * ab) {            // |cos| > 1e-15 (threshold Jacobi; uniform over the 8 lanes)
+        // tan 2 theta = 2 ga / (be - al), |theta| <= pi/4:  cos 2theta = |d| / r, sin 2theta = +-2 ga / r
+        const double d = be - al;
+        const double ri = rsqrt_newton(__builtin_fma(d, d, 4.0 * gg));
+        const double c2 = __builtin_fma(0.5 * fabs(d), ri, 0.5);  // cos^2 theta, in [1/2, 1]
+        const double rc = rsqrt_newton(c2);
+        c = c2 * rc;
+        s = ga * ri * rc;
+        if (d < 0.0) s = -s;
+        if (!(fabs(s) <= 1.0)) bad = 1.0;
+      }
+      SA_STAMP(t3);
+      SA_STAMP_ADD(2, t2, t3);
+      if (writer) { cs[0] = c; cs[1] = s; }
+    } else {
+      c = cs[0];
+      s = cs[1];
+    }
+    if (s == 0.0) return false;  // skipped pair (c = 1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double a = xa[j], b = xb[j];
+      xa[j] = __builtin_fma(c, a, -(s * b));
+      xb[j] = __builtin_fma(s, a, c * b);
+    }
+    return true;
+  }
+
+  // One block round of a wave on the column-major matrix M (G^T or V^T): blocks ba, bb (8 columns each).
+  // ring: [15][8][2] doubles of this wave for this block round.
+  template <bool GROLE>
+  __device__ static __forceinline__ void block_round(char* M, double* ring, int ba, int bb, bool intra, int slot,
+                                                     int sub, double& big, double& bad, double* prof) {
+    double xa[8], xb[8];
+    const bool writer = sub == 0;
+    if (intra) {  // the pairs inside each block: slots 0-3 on block ba, 4-7 on bb, a tournament of 8 in 7 rounds
+      const int u = slot & 3, base = (slot < 4 ? ba : bb) * 8;
+      for (int r = 0; r < 7; ++r) {
+        int p, q;
+        if (u == 0) { p = 7; q = r; }
+        else {
+          p = r + u; if (p >= 7) p -= 7;
+          q = r - u; if (q < 0) q += 7;
+        }
+        const int oa = col_offset(base + p, sub), ob = col_offset(base + q, sub);
+        load_col(M, oa, xa);
+        load_col(M, ob, xb);
+        if (rotate_pair<GROLE>(xa, xb, ring + (r * 8 + slot) * 2, writer, big, bad, nullptr)) {
+          store_col(M, oa, xa);
+          store_col(M, ob, xb);
+        }
+        wave_sync();
+      }
+    }
+    // the 64 cross pairs: slot i keeps column i of ba in registers and meets column (i + k) mod 8 of bb in round k
+    const int oa = col_offset(ba * 8 + slot, sub);
+    load_col(M, oa, xa);
+    bool any = false;
+    for (int k = 0; k < 8; ++k) {
+      const int ob = col_offset(bb * 8 + ((slot + k) & 7), sub);
+      SA_STAMP(ta);
+      load_col(M, ob, xb);
+      if (rotate_pair<GROLE>(xa, xb, ring + ((7 + k) * 8 + slot) * 2, writer, big, bad, prof)) {
+        SA_STAMP(tb);
+        store_col(M, ob, xb);
+        any = true;
+        wave_sync();
+        SA_STAMP(tc);
+        SA_STAMP_ADD(4, tb, tc);
+      }
+      wave_sync();
+      SA_STAMP(td);
+      SA_STAMP_ADD(3, ta, td);
+    }
+    if (any) store_col(M, oa, xa);
+  }
+
+  // the two blocks of block-pair slot w in round R of the tournament of the 8 blocks
+  __device__ static __forceinline__ void blocks_of(int w, int R, int& ba, int& bb) {
+    if (w == 0) { ba = 7; bb = R; return; }
+    ba = R + w; if (ba >= 7) ba -= 7;
+    bb = R - w; if (bb < 0) bb += 7;
+  }
+
   __device__ __forceinline__ bool eigh() {
-    const int n2 = dim + (dim & 1);
-    const int half = n2 >> 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int role = wave >> 2;                   // 0: G, 1: V, 2-3: only the barriers
-    const int slot = 8 * (wave & 3) + (lane >> 3);  // the pair slot of this group of 8 lanes
-    const int sub = lane & 7;                     // rows sub + 8 j
+    const int role = wave >> 2;   // 0: G, 1: V, 2-3: only the barriers
+    const int bw = wave & 3;      // block-pair slot of the wave
+    const int slot = lane >> 3;   // pair slot of this group of 8 lanes
+    const int sub = lane & 7;     // rows sub + 8 j
     bool converged = false;
     ++n_eigh;
     SA_PROF_BEGIN();
     times_basis();
-    double* const G = w.W;
-    double* const Vt = w.H;
-    double* const prm = w.rc;  // (c, s) per pair slot, double buffered by round parity: [2][32][2]
+    char* const G = reinterpret_cast<char*>(w.W);
+    char* const Vt = reinterpret_cast<char*>(w.H);
     for (int e = tid; e < 64 * 64; e += NT) {
       const int i = e & 63, j = e >> 6;
-      Vt[j * LDJ + i] = (i < dim && j < dim) ? w.V[i * LD + j] : 0.0;
+      w.H[j * LDJ + i] = (i < dim && j < dim) ? w.V[i * LD + j] : 0.0;
     }
     __syncthreads();
     SA_PROF_END(5);
-    // The tournament as byte offsets of the two columns of this pair slot, advanced from round to round without
-    // multiplications: slot 0 keeps column n2 - 1 and meets r; slot t > 0 has (r + t, r - t) mod (n2 - 1).
-    const int span = (n2 - 1) * LDJ * 8;  // one lap of the moving columns
-    const int step_a = slot == 0 ? 0 : LDJ * 8;  // (both moving columns advance by one column a round)
-    const int a_first = (slot == 0 ? n2 - 1 : slot) * LDJ * 8 + sub * 8;
-    const int b_first = (slot == 0 ? 0 : n2 - 1 - slot) * LDJ * 8 + sub * 8;
-    const int lap_a = slot == 0 ? 0x7fffffff : span;  // (slot 0's resident column n2 - 1 is beyond the lap)
-    const int dummy = dim * LDJ * 8 + sub * 8;  // odd dim: the column that does not exist
-    const bool odd = (dim & 1) != 0;
-    const bool mine = slot < half;
-    int oa = a_first, ob = b_first;    // the round this role works on next (G: round g; V: round g - 1)
-    int g = 0;                         // rounds done by the G role
+    if (role == 0) __builtin_amdgcn_s_setprio(3);  // the G waves' dependent chain is the critical path of a round
+    int done = 0;  // block rounds the G role has done; the V role is one behind
+    int Rprev = 0;
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
       double big = 0.0, bad = 0.0;
       ++n_sweeps;
-      for (int r = 0; r < n2 - 1; ++r) {
-#ifndef MM_SA_EXP
-#define MM_SA_EXP 0
+      for (int R = 0; R < 7; ++R) {
+        int ba, bb;
+        if (role == 0) {
+          blocks_of(bw, R, ba, bb);
+#ifdef MM_SOFTABS_PROF
+          double* const prof = tid_raw == 0 ? w.prof : nullptr;
+#else
+          double* const prof = nullptr;
 #endif
-        if (MM_SA_EXP == 4) {
-        } else if (role == 0) {
-          if (mine) {
-            double c = 1.0, s = 0.0;
-            if (!odd || (oa != dummy && ob != dummy)) {  // (odd dim: the dummy column's partner sits this round out)
-              char* const ca = reinterpret_cast<char*>(G) + oa;
-              char* const cb = reinterpret_cast<char*>(G) + ob;
-              double xa[8], xb[8];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                xa[j] = lds_read(ca + 64 * j);
-                xb[j] = lds_read(cb + 64 * j);
-              }
-              double al = 0.0, be = 0.0, ga = 0.0;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                al = __builtin_fma(xa[j], xa[j], al);
-                be = __builtin_fma(xb[j], xb[j], be);
-                ga = __builtin_fma(xa[j], xb[j], ga);
-              }
-              al = group8_sum(al);
-              be = group8_sum(be);
-              ga = group8_sum(ga);
-              const double ab = al * be, gg = ga * ga;
-              if (!(ab <= 1.7e308) || !(gg <= 1.7e308)) bad = 1.0;  // NaN or overflow
-              if (gg > 1e-14 * ab) big = 1.0;   // |cos| > 1e-7: another sweep is needed after this one
-              if (MM_SA_EXP == 3) {
-                if (gg == 1.2345) big = 2.0;
-              } else if (MM_SA_EXP == 2) {
-                c = 0.8; s = gg == 1.2345 ? 0.5 : 0.6;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                  lds_write(ca + 64 * j, __builtin_fma(c, xa[j], -(s * xb[j])));
-                  lds_write(cb + 64 * j, __builtin_fma(s, xa[j], c * xb[j]));
-                }
-              } else
-              if (gg > 1e-30 * ab) {            // |cos| > 1e-15 (threshold Jacobi; uniform over the 8 lanes)
-                // tan 2 theta = 2 ga / (be - al), |theta| <= pi/4:  cos 2theta = |d| / r, sin 2theta = +-2 ga / r
-                const double d = be - al;
-                const double ri = rsqrt_newton(__builtin_fma(d, d, 4.0 * gg));
-                const double c2 = __builtin_fma(0.5 * fabs(d), ri, 0.5);  // cos^2 theta, in [1/2, 1]
-                const double rc = rsqrt_newton(c2);
-                c = c2 * rc;
-                s = ga * ri * rc;
-                if (d < 0.0) s = -s;
-                if (!(fabs(s) <= 1.0)) bad = 1.0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                  lds_write(ca + 64 * j, __builtin_fma(c, xa[j], -(s * xb[j])));
-                  lds_write(cb + 64 * j, __builtin_fma(s, xa[j], c * xb[j]));
-                }
-              }
-            }
-            if (sub == 0) {
-              prm[(g & 1) * 64 + 2 * slot] = c;
-              prm[(g & 1) * 64 + 2 * slot + 1] = s;
-            }
-          }
-        } else if (role == 1 && g > 0 && MM_SA_EXP != 1) {
-          if (mine) rotate_basis(Vt, prm + ((g - 1) & 1) * 64 + 2 * slot, oa, ob);
+          block_round<true>(G, w.ring + ((done & 1) * 4 + bw) * kRingDoubles, ba, bb, R == 0, slot, sub, big, bad,
+                            prof);
+        } else if (role == 1 && done > 0) {
+          double b0 = 0.0, b1 = 0.0;
+          blocks_of(bw, Rprev, ba, bb);
+          block_round<false>(Vt, w.ring + (((done - 1) & 1) * 4 + bw) * kRingDoubles, ba, bb, Rprev == 0, slot, sub,
+                             b0, b1, nullptr);
         }
-        if (role == 0 || g > 0) {  // next round's columns
-          oa += step_a; if (oa >= lap_a) oa -= span;
-          ob += LDJ * 8; if (ob >= span) ob -= span;
-        }
-        ++g;
+        Rprev = R;
+        ++done;
         __syncthreads();
       }
       bad = block_reduce4(bad, 0, w.red);
       if (bad != 0.0) {
+        __builtin_amdgcn_s_setprio(0);
         warm = 0;
         return false;
       }
       big = block_reduce4(big, 0, w.red);
-      if (MM_SA_EXP != 0) big = sweep < 3 ? 1.0 : 0.0;
       if (big == 0.0) {
         converged = true;
         break;
       }
     }
-    if (role == 1 && mine) rotate_basis(Vt, prm + ((g - 1) & 1) * 64 + 2 * slot, oa, ob);
+    __builtin_amdgcn_s_setprio(0);
+    if (role == 1) {
+      int ba, bb;
+      double b0 = 0.0, b1 = 0.0;
+      blocks_of(bw, Rprev, ba, bb);
+      block_round<false>(Vt, w.ring + (((done - 1) & 1) * 4 + bw) * kRingDoubles, ba, bb, Rprev == 0, slot, sub, b0, b1,
+                         nullptr);
+    }
     __syncthreads();
     {  // lam_i = g_i . v_i, 16 lanes per column
       const int i = tid / RP, part = tid % RP;
       double lam = 0.0;
 #pragma unroll
-      for (int m = 0; m < 64 / RP; ++m) lam = __builtin_fma(G[i * LDJ + part + RP * m], Vt[i * LDJ + part + RP * m], lam);
+      for (int m = 0; m < 64 / RP; ++m)
+        lam = __builtin_fma(w.W[i * LDJ + part + RP * m], w.H[i * LDJ + part + RP * m], lam);
       lam = rp_sum(lam);
       if (part == 0) w.lam[i] = (i < dim) ? lam : 1.0;
     }
     for (int e = tid; e < 64 * 64; e += NT) {
       const int i = e & 63, j = e >> 6;
-      if (i < dim && j < dim) w.V[i * LD + j] = Vt[j * LDJ + i];
+      if (i < dim && j < dim) w.V[i * LD + j] = w.H[j * LDJ + i];
     }
     __syncthreads();
     warm = converged ? (warm + 1) % kWarmPeriod : 0;
     SA_PROF_END(4);
     return converged;
-  }
-
-  // One 8-byte LDS access per instruction: ds_read_b64 runs at 256 B/clk, the ds_read2_b64 the compiler would merge
-  // two of these into at 128 B/clk (MI355X_MICROARCH.md, LDS), and the Jacobi rounds are bound by the LDS array.
-  __device__ static __forceinline__ double lds_read(const char* p) {
-    return *reinterpret_cast<const double*>(p);
-  }
-  __device__ static __forceinline__ void lds_write(char* p, double v) { *reinterpret_cast<double*>(p) = v; }
-
-  // the V role of a round: the two columns of V^T at byte offsets oa, ob rotated by the (c, s) the G role published
-  __device__ static __forceinline__ void rotate_basis(double* Vt, const double* cs, int oa, int ob) {
-    const double c = cs[0], s = cs[1];
-    if (s == 0.0) return;  // skipped pair (c = 1)
-    char* const ca = reinterpret_cast<char*>(Vt) + oa;
-    char* const cb = reinterpret_cast<char*>(Vt) + ob;
-    double xa[8], xb[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      xa[j] = lds_read(ca + 64 * j);
-      xb[j] = lds_read(cb + 64 * j);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      lds_write(ca + 64 * j, __builtin_fma(c, xa[j], -(s * xb[j])));
-      lds_write(cb + 64 * j, __builtin_fma(s, xa[j], c * xb[j]));
-    }
   }
 
   // softabs(x) = x / tanh(coeff x); grad_softabs (matrices.py:1662-1669)
@@ -605,11 +669,13 @@ __device__ __forceinline__ void init_backend(SoftAbsBackend& bk, const ImplicitA
   bk.w.v1 = p; p += 64;
   bk.w.v2 = p; p += 64;
   bk.w.nat = p; p += 64;
-  bk.w.rc = p; p += 4 * 32;
+  bk.w.ring = p; p += 2 * 4 * kRingDoubles;
   bk.w.red = p; p += 16;
   bk.w.cnt = p; p += 8;
+  bk.w.prof = p; p += 8;
   bk.w.stash = p;
   if (threadIdx.x < 8) bk.w.cnt[threadIdx.x] = 0.0;
+  if (threadIdx.x < 8) bk.w.prof[threadIdx.x] = 0.0;
 }
 
 struct SaArgs {
@@ -650,6 +716,9 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
     printf("softabs prof: total %lld eigh(incl basis) %.0f basis %.0f dh2_dpos %.0f half_vjp %.0f | n_eigh %d sweeps %d "
            "evals %.0f\n", (long long)(__builtin_readcyclecounter() - prof_start), bk.w.cnt[4], bk.w.cnt[5], bk.w.cnt[6],
            bk.w.cnt[7], bk.n_eigh, bk.n_sweeps, bk.w.cnt[CNT_EVALS]);
+  if (tid == 0 && chain == 0)
+    printf("softabs prof rounds (cross rounds of G wave 0): dots %.0f reduce %.0f params %.0f whole round %.0f "
+           "store+sync %.0f\n", bk.w.prof[0], bk.w.prof[1], bk.w.prof[2], bk.w.prof[3], bk.w.prof[4]);
 #endif
   if (tid == 0) {
     A.status[chain] = r.status;

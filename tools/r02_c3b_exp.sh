@@ -1,7 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02s; mkdir -p $O
-for e in 1 2 3 4; do
+for e in 0 1 2 3; do
 cp mici_amd/lib/exp$e.so mici_amd/lib/libmici_amd.so
-timeout 120 python bench.py --config c3b --steps 1 --warmup 0 --no-cpu-baseline --no-extra-configs 2>&1 | grep -h "softabs prof" | head -2 | sed "s/^/exp$e: /"
+timeout 120 python bench.py --config c3b --steps 1 --warmup 0 --no-cpu-baseline --no-extra-configs 2>&1 | grep -h "softabs prof:" | head -1 | sed "s/^/exp$e: /"
 done
