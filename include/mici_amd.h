@@ -76,7 +76,7 @@ typedef enum mm_constr { /* holonomic constraint, C = 1 */
   MM_CONSTR_TORUS = 1,  /* (sqrt(x^2+y^2)-R)^2 + z^2 - r^2, params R, r */
   MM_CONSTR_FIRST = 2,  /* q_0                                          */
   MM_CONSTR_CIRCLE = 3, /* q_0^2 + q_1^2 - 1                            */
-  MM_CONSTR_LINEAR = 4, /* A q - b, C rows: params A[C*D] (row-major) then b[C]; C = n_constr_params / (D + 1) <= 3 */
+  MM_CONSTR_LINEAR = 4, /* A q - b, C rows: params A[C*D] (row-major) then b[C]; C = n_constr_params / (D + 1) <= 8 */
   MM_CONSTR_SPHERE_PLANE = 5, /* two constraints: |q|^2 - 1 and n . q; params n[D], D >= 3 */
   MM_CONSTR_SPHERE = 6  /* |q|^2 - 1 (the constrained system of the reference's adapter tests), D >= 2 */
 } mm_constr;

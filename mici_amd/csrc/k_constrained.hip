@@ -56,14 +56,13 @@ int launch(mm_ctx* ctx, const mm_model* m, const ConArgs& a, int which, double* 
     mm_set_error(ctx, "constrained kernels: the funnel target needs a wave-collective gradient");
     return MM_ERR_UNSUPPORTED;
   }
-  if (m->dim > 8) return mm_launch_constrained_wide(ctx, m->n_constr, a, which, h_out);
+  // exact register-resident kernels: D <= 8 with C <= 3; everything else up to D = 64, C = 8 runs the padded
+  // (capacity 16 or 64) instantiations of the same core, whose per-chain arrays live in scratch
+  if (m->dim > 8 || m->n_constr > 3) return mm_launch_constrained_wide(ctx, m->n_constr, a, which, h_out);
   switch (m->n_constr) {
     case 1: return launch_c<1>(ctx, m->dim, a, which, h_out);
     case 2: return launch_c<2>(ctx, m->dim, a, which, h_out);
-    case 3: return launch_c<3>(ctx, m->dim, a, which, h_out);
-    default:
-      mm_set_error(ctx, "constrained leapfrog kernels support at most 3 constraints");
-      return MM_ERR_UNSUPPORTED;
+    default: return launch_c<3>(ctx, m->dim, a, which, h_out);
   }
 }
 

@@ -293,8 +293,8 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
     MM_REQUIRE(ctx, need_c > 0 && need_c % (size_t)(D + 1) == 0,
                "mm_model_create: linear constraint needs C*(D+1) params (A[C*D] then b[C])");
     n_constr = (int)(need_c / (size_t)(D + 1));
-    MM_REQUIRE(ctx, n_constr >= 1 && n_constr <= 3 && (n_constr < D || D == 1),
-               "mm_model_create: linear constraint supports 1 <= C <= 3 rows, C < dim");
+    MM_REQUIRE(ctx, n_constr >= 1 && n_constr <= 8 && (n_constr < D || D == 1),
+               "mm_model_create: linear constraint supports 1 <= C <= 8 rows, C < dim");
   }
   MM_REQUIRE(ctx, d->constr != MM_CONSTR_SPHERE || D >= 2, "sphere constraint needs dim >= 2");
   if (d->constr == MM_CONSTR_SPHERE_PLANE) {

@@ -160,7 +160,7 @@ class CircleConstr(Constraint):
 
 
 class LinearConstr(Constraint):
-    """c(q) = A q - b with A of shape [C, D], 1 <= C <= 3 rows."""
+    """c(q) = A q - b with A of shape [C, D], 1 <= C <= 8 rows (C < D)."""
 
     def __init__(self, a, b=None):
         a = np.atleast_2d(_f64(a))

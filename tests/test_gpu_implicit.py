@@ -321,10 +321,15 @@ def test_unsupported_sizes_fail_loudly():
     with pytest.raises(DeviceError):
         integrators.ImplicitLeapfrogIntegrator(system, 0.01).step_batch(
             rng.standard_normal((1, 65)), rng.standard_normal((1, 65)), 1, 1)
-    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(17, 1.0, 0.0), models.CircleConstr())
-    with pytest.raises(DeviceError):  # lane-per-chain kernels stop at dim 16
+    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(65, 1.0, 0.0), models.CircleConstr())
+    with pytest.raises(DeviceError):  # lane-per-chain kernels stop at dim 64
         integrators.ConstrainedLeapfrogIntegrator(system, 0.1).step_batch(
-            rng.standard_normal((1, 17)), rng.standard_normal((1, 17)), 1, 1)
+            rng.standard_normal((1, 65)), rng.standard_normal((1, 65)), 1, 1)
+    with pytest.raises(DeviceError):  # ... and at 8 constraint functions
+        integrators.ConstrainedLeapfrogIntegrator(
+            systems.DenseConstrainedEuclideanMetricSystem(
+                models.Poly(12, 1.0, 0.0), models.LinearConstr(rng.standard_normal((9, 12)), np.zeros(9))),
+            0.1).step_batch(rng.standard_normal((1, 12)), rng.standard_normal((1, 12)), 1, 1)
 
 
 def test_empty_batches():

@@ -582,9 +582,9 @@ def main():
 
     # ---- constrained leapfrog (c5 + the reference's own constrained test systems) ------------------
     def add_constrained(name, target, constraint, mk, metric, q0, h, cps, n_inner=1, proj_solver=0,
-                        variant="hausdorff"):
+                        variant="hausdorff", r=None):
         n, d = q0.shape
-        z = rng.standard_normal((n, d))
+        z = (rng if r is None else r).standard_normal((n, d))
         osys = orc.ConstrainedSystem(target, constraint, mk, metric)
         p0 = project_momentum(osys, q0, np.stack([osys.msqrt(zz) for zz in z]))
         cases[name] = lambda: constrained_case(name, target, constraint, mk, metric, q0, p0,
@@ -1129,6 +1129,37 @@ def main():
                     **{f"in_stat_{k}": np.stack(v) for k, v in stats.items()},
                     **{f"post_{k}": v for k, v in post.items()}, **out), collections.Counter()
     cases["interop_arviz_layout"] = make_interop
+
+    # ---- constrained systems beyond D = 16 / C = 3 (round 2: the capacity-64 kernels, up to 8 constraint
+    #      functions; systems.py:876-1031, matrices.py:1270-1411).  Per-case random streams. ---------------------------
+    def wide_linear(name, d, c, n, mk, h, cps, **kw):
+        r = case_rng(name)
+        a, b = r.standard_normal((c, d)), r.standard_normal(c)
+        part = np.linalg.lstsq(a, b, rcond=None)[0]
+        null = np.linalg.svd(a)[2][c:].T
+        q0 = part + 0.5 * r.standard_normal((n, d - c)) @ null.T
+        metric = (None if mk == mdl.METRIC_IDENTITY else np.exp(0.2 * r.standard_normal(d)) if mk == mdl.METRIC_DIAG
+                  else mdl.make_spd(d, r))
+        add_constrained(name, mdl.Poly(d, 1.0, 0.25), mdl.LinearConstr(a, b), mk, metric, q0, h, cps, r=r, **kw)
+
+    wide_linear("constrained_c4_linear_dense_d32", 32, 4, 4, mdl.METRIC_DENSE, 0.1, [1, 5, 20])
+    wide_linear("constrained_c8_linear_diag_d64_quasi", 64, 8, 3, mdl.METRIC_DIAG, 0.1, [1, 5], proj_solver=1)
+    wide_linear("constrained_c5_linear_ambient_d20", 20, 5, 4, mdl.METRIC_DENSE, 0.1, [1, 5, 20], variant="ambient")
+    wide_linear("constrained_c4_linear_identity_d8", 8, 4, 5, mdl.METRIC_IDENTITY, 0.1, [1, 5, 20])
+    wide_linear("constrained_c6_linear_gauss_d24", 24, 6, 4, mdl.METRIC_DENSE, 0.2, [1, 5, 20], variant="gaussian")
+
+    def wide_sphere_plane(name, d, n, mk, h, cps, **kw):
+        r = case_rng(name)
+        normal = r.standard_normal(d)
+        x = r.standard_normal((n, d))
+        x -= np.outer(x @ normal, normal) / (normal @ normal)
+        q0 = x / np.linalg.norm(x, axis=1, keepdims=True)
+        metric = np.exp(0.2 * r.standard_normal(d)) if mk == mdl.METRIC_DIAG else mdl.make_spd(d, r)
+        add_constrained(name, mdl.Poly(d, 0.5, 0.25), mdl.SpherePlaneConstr(normal), mk, metric, q0, h, cps, r=r, **kw)
+
+    wide_sphere_plane("constrained_c2_sphereplane_dense_d40", 40, 4, mdl.METRIC_DENSE, 0.05, [1, 5, 20])
+    wide_sphere_plane("constrained_c2_sphereplane_diag_d33_linesearch", 33, 4, mdl.METRIC_DIAG, 0.05, [1, 5, 20],
+                      proj_solver=2)
 
     all_counts = {}
     n_ok, bad = 0, []
