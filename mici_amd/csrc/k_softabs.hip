@@ -25,13 +25,7 @@ using namespace mmdev;
 using namespace mmimp;
 
 constexpr int NT = 1024;           // 16 waves per chain: the kernel is LDS-latency bound, four waves per SIMD hide it
-constexpr int TPD = 32;            // threads per matrix dimension in the 64 x 64 products (TPD^2 = NT)
-constexpr int BS = 64 / TPD;       // output block side per thread
-constexpr int RP = NT / 64;        // threads per output element of the row-wise reductions
-constexpr int LD = 65;            // LDS leading dimension of the 64 x 64 matrices
-constexpr int MAT = 64 * LD;
-constexpr int LDJ = 72;           // leading dimension of the column-major Jacobi work matrices (eigh())
-constexpr int MATJ = 64 * LDJ;
+constexpr int TPD = 32;            // threads per matrix dimension in the NP x NP products (TPD^2 = NT)
 constexpr int kMaxSweeps = 30;
 constexpr int kWarmPeriod = 256;  // cold-start the eigenvector basis every this many decompositions
 
@@ -52,7 +46,6 @@ struct SaLds {
   double* stash;  // [SL_COUNT][65]
 };
 constexpr int kRingDoubles = 15 * 8 * 2;  // (c, s) of the 15 local rounds x 8 pair slots of a block round
-constexpr int kLdsDoubles = MAT + 2 * MATJ + 6 * 64 + 2 * 4 * kRingDoubles + 16 + 8 + 8 + SL_COUNT * 65;
 
 // A value every lane agrees on, moved to scalar registers: the step's control flow (implicit_core.h) and the Jacobi
 // sweeps' termination depend only on team-uniform reductions; telling the compiler so keeps the state machine (mode,
@@ -77,12 +70,13 @@ __device__ __forceinline__ double block_reduce4(double v, int kind_max, double* 
   return uniform_f64(r);
 }
 
-// sum over the RP = 16 consecutive lanes (one DPP row) that share an output element
-__device__ __forceinline__ double rp_sum(double v) {
+// sum over the RP (16 or 8) consecutive lanes that share an output element (one DPP row, or half of one)
+template <int RP>
+__device__ __forceinline__ double rp_sum_n(double v) {
+  static_assert(RP == 16 || RP == 8, "rp_sum reduces a DPP row or half of one");
   v = group8_sum(v);
-  return v + dpp_move<kDppMirror>(v);
+  return RP == 16 ? v + dpp_move<kDppMirror>(v) : v;
 }
-static_assert(RP == 16, "rp_sum reduces a 16-lane DPP row");
 
 // -DMM_SOFTABS_PROF: per-phase cycle totals of block 0 (thread 0's clock), printed at the end of the launch
 #ifdef MM_SOFTABS_PROF
@@ -106,7 +100,27 @@ static_assert(RP == 16, "rp_sum reduces a 16-lane DPP row");
 #define SA_STAMP_ADD(k_, a_, b_) do {} while (0)
 #endif
 
-struct SoftAbsBackend {
+// NP: the padded size of the problem, 64 (matrices in LDS: the BASELINE c3(b) configuration) or 128 (the same code
+// with the three matrices in a per-chain global-memory workspace, for 64 < D <= 128: coverage of the reference's
+// sizes, an order of magnitude slower per flop)
+template <int NP>
+struct SoftAbsBackendT {
+  static_assert(NP == 64 || NP == 128, "SoftAbs backend sizes");
+  static constexpr int BS = NP / TPD;     // output block side per thread in the NP x NP products
+  static constexpr int RP = NT / NP;      // threads per output element of the row-wise reductions
+  static constexpr int LD = NP + 1;       // leading dimension of the row-major matrices (LDS: conflict-free columns)
+  static constexpr int MAT = NP * LD;
+  static constexpr int LDJ = NP + 8;      // leading dimension of the column-major Jacobi work matrices (eigh())
+  static constexpr int MATJ = NP * LDJ;
+  static constexpr int NBLK = NP / 8;     // blocks of 8 columns in eigh()
+  static constexpr int GW = NBLK / 2;     // waves rotating G (as many again replay on V)
+  static constexpr int ROWS = NP / 8;     // rows per lane of a column pair
+  static constexpr bool kMatricesInLds = NP == 64;
+  static constexpr int kLdsVectors = 6 * NP + 2 * GW * kRingDoubles + 16 + 8 + 8 + SL_COUNT * (NP + 1);
+  static constexpr int kLdsDoubles = kLdsVectors + (kMatricesInLds ? MAT + 2 * MATJ : 0);
+  static constexpr int kWorkDoubles = kMatricesInLds ? 0 : MAT + 2 * MATJ;  // per chain, global memory
+  __device__ static __forceinline__ double rp_sum(double v) { return rp_sum_n<RP>(v); }
+
   static constexpr bool kSolveByInverse = false;  // implicit_core.h
   static constexpr bool kUnifiedConstruct = false;
   static constexpr bool kCountersInLds = true;  // implicit_core.h: work counters in LDS, bumped by thread 0
@@ -136,8 +150,8 @@ struct SoftAbsBackend {
     r.n_metric = (long long)w.cnt[CNT_METRIC];
     r.n_grad = (long long)w.cnt[CNT_GRAD];
   }
-  // flat state exists for tid < 64; the other threads share a dummy cell (index 64) per slot
-  __device__ __forceinline__ double& slot(int i) { return w.stash[i * 65 + (tid < 64 ? tid : 64)]; }
+  // flat state exists for tid < NP; the other threads share a dummy cell (index NP) per slot
+  __device__ __forceinline__ double& slot(int i) { return w.stash[i * (NP + 1) + (tid < NP ? tid : NP)]; }
 
   __device__ __forceinline__ double norm(double x, int kind) {
     const double a = tid < dim ? x : 0.0;
@@ -147,7 +161,7 @@ struct SoftAbsBackend {
 
   // ---- hess_neg_log_dens(q) into w.H (systems.py:1870-1888); q flat --------------------------------
   __device__ __forceinline__ void build_hessian(double q) {
-    if (tid < 64) w.nat[tid] = (tid < dim) ? q : 0.0;
+    if (tid < NP) w.nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
     const double* x = w.nat;
     double e = 0.0, s = 0.0;
@@ -157,8 +171,8 @@ struct SoftAbsBackend {
       for (int i = 1 + (threadIdx.x & 63); i < dim; i += 64) acc += tparams[i - 1] * x[i] * x[i];
       s = wave_sum(acc);  // every wave computes the same S = sum w x^2
     }
-    for (int i = tid >> 6; i < dim; i += NT / 64) {
-      const int j = tid & 63;
+    for (int el = tid; el < NP * dim; el += NT) {
+      const int i = el / NP, j = el % NP;
       if (j >= dim) continue;
       double h = 0.0;
       if (target == MM_TARGET_POLY) {
@@ -244,13 +258,13 @@ struct SoftAbsBackend {
   // through V f(lam) V^T forms, which do not depend on eigenvalue order or eigenvector signs.
 
   // One 8-byte LDS access per element (byte offsets from the matrix base)
-  __device__ static __forceinline__ void load_col(const char* M, int off, double (&x)[8]) {
+  __device__ static __forceinline__ void load_col(const char* M, int off, double (&x)[ROWS]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const double*>(M + off + 64 * j);
+    for (int j = 0; j < ROWS; ++j) x[j] = *reinterpret_cast<const double*>(M + off + 64 * j);
   }
-  __device__ static __forceinline__ void store_col(char* M, int off, const double (&x)[8]) {
+  __device__ static __forceinline__ void store_col(char* M, int off, const double (&x)[ROWS]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<double*>(M + off + 64 * j) = x[j];
+    for (int j = 0; j < ROWS; ++j) *reinterpret_cast<double*>(M + off + 64 * j) = x[j];
   }
   __device__ static __forceinline__ int col_offset(int col, int sub) { return (col * LDJ + sub) * 8; }
 
@@ -260,14 +274,14 @@ struct SoftAbsBackend {
   // unnormalised form a - t b, b + t a with a low-precision t: it scales the two columns, the next rotation mixes a
   // scaled with an unscaled column, and the columns of G come out orthogonal without V being orthogonal.
   template <bool GROLE>
-  __device__ static __forceinline__ bool rotate_pair(double (&xa)[8], double (&xb)[8], double* cs, bool writer,
+  __device__ static __forceinline__ bool rotate_pair(double (&xa)[ROWS], double (&xb)[ROWS], double* cs, bool writer,
                                                      double& big, double& bad, double* prof) {
     double c = 1.0, s = 0.0;
     if (GROLE) {
       SA_STAMP(t0);
       double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < ROWS; ++j) {
         al = __builtin_fma(xa[j], xa[j], al);
         be = __builtin_fma(xb[j], xb[j], be);
         ga = __builtin_fma(xa[j], xb[j], ga);
@@ -302,7 +316,7 @@ struct SoftAbsBackend {
     }
     if (s == 0.0) return false;  // skipped pair (c = 1)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < ROWS; ++j) {
       const double a = xa[j], b = xb[j];
       xa[j] = __builtin_fma(c, a, -(s * b));
       xb[j] = __builtin_fma(s, a, c * b);
@@ -315,7 +329,7 @@ struct SoftAbsBackend {
   template <bool GROLE>
   __device__ static __forceinline__ void block_round(char* M, double* ring, int ba, int bb, bool intra, int slot,
                                                      int sub, double& big, double& bad, double* prof) {
-    double xa[8], xb[8];
+    double xa[ROWS], xb[ROWS];
     const bool writer = sub == 0;
     if (intra) {  // the pairs inside each block: slots 0-3 on block ba, 4-7 on bb, a tournament of 8 in 7 rounds
       const int u = slot & 3, base = (slot < 4 ? ba : bb) * 8;
@@ -359,18 +373,18 @@ struct SoftAbsBackend {
     if (any) store_col(M, oa, xa);
   }
 
-  // the two blocks of block-pair slot w in round R of the tournament of the 8 blocks
+  // the two blocks of block-pair slot w in round R of the tournament of the NBLK blocks
   __device__ static __forceinline__ void blocks_of(int w, int R, int& ba, int& bb) {
-    if (w == 0) { ba = 7; bb = R; return; }
-    ba = R + w; if (ba >= 7) ba -= 7;
-    bb = R - w; if (bb < 0) bb += 7;
+    if (w == 0) { ba = NBLK - 1; bb = R; return; }
+    ba = R + w; if (ba >= NBLK - 1) ba -= NBLK - 1;
+    bb = R - w; if (bb < 0) bb += NBLK - 1;
   }
 
   __device__ __forceinline__ bool eigh() {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int role = wave >> 2;   // 0: G, 1: V, 2-3: only the barriers
-    const int bw = wave & 3;      // block-pair slot of the wave
+    const int role = wave / GW;   // 0: G, 1: V, beyond: only the barriers
+    const int bw = wave % GW;     // block-pair slot of the wave
     const int slot = lane >> 3;   // pair slot of this group of 8 lanes
     const int sub = lane & 7;     // rows sub + 8 j
     bool converged = false;
@@ -379,8 +393,8 @@ struct SoftAbsBackend {
     times_basis();
     char* const G = reinterpret_cast<char*>(w.W);
     char* const Vt = reinterpret_cast<char*>(w.H);
-    for (int e = tid; e < 64 * 64; e += NT) {
-      const int i = e & 63, j = e >> 6;
+    for (int e = tid; e < NP * NP; e += NT) {
+      const int i = e % NP, j = e / NP;
       w.H[j * LDJ + i] = (i < dim && j < dim) ? w.V[i * LD + j] : 0.0;
     }
     __syncthreads();
@@ -391,7 +405,7 @@ struct SoftAbsBackend {
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
       double big = 0.0, bad = 0.0;
       ++n_sweeps;
-      for (int R = 0; R < 7; ++R) {
+      for (int R = 0; R < NBLK - 1; ++R) {
         int ba, bb;
         if (role == 0) {
           blocks_of(bw, R, ba, bb);
@@ -400,12 +414,12 @@ struct SoftAbsBackend {
 #else
           double* const prof = nullptr;
 #endif
-          block_round<true>(G, w.ring + ((done & 1) * 4 + bw) * kRingDoubles, ba, bb, R == 0, slot, sub, big, bad,
+          block_round<true>(G, w.ring + ((done & 1) * GW + bw) * kRingDoubles, ba, bb, R == 0, slot, sub, big, bad,
                             prof);
         } else if (role == 1 && done > 0) {
           double b0 = 0.0, b1 = 0.0;
           blocks_of(bw, Rprev, ba, bb);
-          block_round<false>(Vt, w.ring + (((done - 1) & 1) * 4 + bw) * kRingDoubles, ba, bb, Rprev == 0, slot, sub,
+          block_round<false>(Vt, w.ring + (((done - 1) & 1) * GW + bw) * kRingDoubles, ba, bb, Rprev == 0, slot, sub,
                              b0, b1, nullptr);
         }
         Rprev = R;
@@ -429,21 +443,21 @@ struct SoftAbsBackend {
       int ba, bb;
       double b0 = 0.0, b1 = 0.0;
       blocks_of(bw, Rprev, ba, bb);
-      block_round<false>(Vt, w.ring + (((done - 1) & 1) * 4 + bw) * kRingDoubles, ba, bb, Rprev == 0, slot, sub, b0, b1,
+      block_round<false>(Vt, w.ring + (((done - 1) & 1) * GW + bw) * kRingDoubles, ba, bb, Rprev == 0, slot, sub, b0, b1,
                          nullptr);
     }
     __syncthreads();
-    {  // lam_i = g_i . v_i, 16 lanes per column
+    {  // lam_i = g_i . v_i, RP lanes per column
       const int i = tid / RP, part = tid % RP;
       double lam = 0.0;
 #pragma unroll
-      for (int m = 0; m < 64 / RP; ++m)
+      for (int m = 0; m < NP / RP; ++m)
         lam = __builtin_fma(w.W[i * LDJ + part + RP * m], w.H[i * LDJ + part + RP * m], lam);
       lam = rp_sum(lam);
       if (part == 0) w.lam[i] = (i < dim) ? lam : 1.0;
     }
-    for (int e = tid; e < 64 * 64; e += NT) {
-      const int i = e & 63, j = e >> 6;
+    for (int e = tid; e < NP * NP; e += NT) {
+      const int i = e % NP, j = e / NP;
       if (i < dim && j < dim) w.V[i * LD + j] = w.H[j * LDJ + i];
     }
     __syncthreads();
@@ -455,7 +469,7 @@ struct SoftAbsBackend {
   // softabs(x) = x / tanh(coeff x); grad_softabs (matrices.py:1662-1669)
   __device__ __forceinline__ bool regularise() {
     double bad = 0.0;
-    if (tid < 64) {
+    if (tid < NP) {
       double lt = 1.0, gs = 0.0;
       if (tid < dim) {
         const double x = w.lam[tid], ax = coeff * x;
@@ -478,7 +492,7 @@ struct SoftAbsBackend {
 
   // V^T v (flat in, flat out): RP threads share output k, each sums every RP-th term
   __device__ __forceinline__ double vt_times(double v) {
-    if (tid < 64) w.v1[tid] = (tid < dim) ? v : 0.0;
+    if (tid < NP) w.v1[tid] = (tid < dim) ? v : 0.0;
     __syncthreads();
     {
       const int k = tid / RP, part = tid % RP;
@@ -496,7 +510,7 @@ struct SoftAbsBackend {
   }
   // V v
   __device__ __forceinline__ double v_times(double v) {
-    if (tid < 64) w.v2[tid] = (tid < dim) ? v : 0.0;
+    if (tid < NP) w.v2[tid] = (tid < dim) ? v : 0.0;
     __syncthreads();
     {
       const int i = tid / RP, part = tid % RP;
@@ -530,7 +544,7 @@ struct SoftAbsBackend {
   __device__ __forceinline__ double mtp(double q, double md, double m0) {
     if (target == MM_TARGET_POLY) return 6.0 * tparams[1] * q * md;
     // funnel: q = (v, x)
-    if (tid < 64) {
+    if (tid < NP) {
       w.v1[tid] = (tid < dim) ? q : 0.0;
       w.v2[tid] = (tid < dim) ? md : 0.0;
       w.nat[tid] = (tid < dim) ? m0 : 0.0;
@@ -590,11 +604,11 @@ struct SoftAbsBackend {
   __device__ __forceinline__ double dh2_dpos(double p, double q) {
     SA_PROF_BEGIN();
     const double c = vt_times(p);
-    if (tid < 64) w.v1[tid] = (tid < dim) ? c / w.lamt[tid] : 0.0;  // e
+    if (tid < NP) w.v1[tid] = (tid < dim) ? c / w.lamt[tid] : 0.0;  // e
     __syncthreads();
     // J into w.H, A into w.W
-    for (int k = tid >> 6; k < dim; k += NT / 64) {
-      const int l = tid & 63;
+    for (int el = tid; el < NP * dim; el += NT) {
+      const int k = el / NP, l = el % NP;
       if (l >= dim) continue;
       double num = w.lamt[k] - w.lamt[l], den = w.lam[k] - w.lam[l];
       if (k == l) { num += w.gsa[k]; den = 1.0; }
@@ -623,7 +637,7 @@ struct SoftAbsBackend {
       md = rp_sum(md);
       m0 = rp_sum(m0);
       __syncthreads();
-      if (part == 0 && i < 64) { w.v2[i] = -md; w.nat[i] = -m0; }
+      if (part == 0 && i < NP) { w.v2[i] = -md; w.nat[i] = -m0; }
       __syncthreads();
     }
     const double mdf = (tid < dim) ? w.v2[tid] : 0.0;
@@ -635,7 +649,7 @@ struct SoftAbsBackend {
   }
 
   __device__ __forceinline__ double grad(double q) {
-    if (tid < 64) w.nat[tid] = (tid < dim) ? q : 0.0;
+    if (tid < NP) w.nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
     const TargetAux aux = target_prepare<true>(target, w.nat, dim, tparams, threadIdx.x & 63);
     const double g = (tid < dim) ? target_grad_elem<true>(target, aux, w.nat, tid, dim, tparams) : 0.0;
@@ -643,7 +657,7 @@ struct SoftAbsBackend {
     return g;
   }
   __device__ __forceinline__ double nld_elem(double q) {
-    if (tid < 64) w.nat[tid] = (tid < dim) ? q : 0.0;
+    if (tid < NP) w.nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
     const TargetAux aux = target_prepare<true>(target, w.nat, dim, tparams, threadIdx.x & 63);
     const double e = (tid < dim) ? target_nld_elem<true>(target, aux, w.nat, tid, dim, tparams) : 0.0;
@@ -652,7 +666,10 @@ struct SoftAbsBackend {
   }
 };
 
-__device__ __forceinline__ void init_backend(SoftAbsBackend& bk, const ImplicitArgs& A, double* lds) {
+// vectors, ring, counters and the step's stash in LDS; the three matrices in LDS (NP = 64) or in `work` (NP = 128)
+template <int NP>
+__device__ __forceinline__ void init_backend(SoftAbsBackendT<NP>& bk, const ImplicitArgs& A, double* lds, double* work) {
+  using B = SoftAbsBackendT<NP>;
   bk.dim = A.dim;
   bk.tid.v = threadIdx.x;
   bk.tid_raw = threadIdx.x;
@@ -660,16 +677,22 @@ __device__ __forceinline__ void init_backend(SoftAbsBackend& bk, const ImplicitA
   bk.coeff = uniform_f64(A.z[0]);  // softabs coefficient (device copy of the model's rmetric_params)
   bk.tparams = A.tparams;
   double* p = lds;
-  bk.w.H = p; p += MATJ;
-  bk.w.W = p; p += MATJ;
-  bk.w.V = p; p += MAT;
-  bk.w.lam = p; p += 64;
-  bk.w.lamt = p; p += 64;
-  bk.w.gsa = p; p += 64;
-  bk.w.v1 = p; p += 64;
-  bk.w.v2 = p; p += 64;
-  bk.w.nat = p; p += 64;
-  bk.w.ring = p; p += 2 * 4 * kRingDoubles;
+  if (B::kMatricesInLds) {
+    bk.w.H = p; p += B::MATJ;
+    bk.w.W = p; p += B::MATJ;
+    bk.w.V = p; p += B::MAT;
+  } else {
+    bk.w.H = work;
+    bk.w.W = work + B::MATJ;
+    bk.w.V = work + 2 * B::MATJ;
+  }
+  bk.w.lam = p; p += NP;
+  bk.w.lamt = p; p += NP;
+  bk.w.gsa = p; p += NP;
+  bk.w.v1 = p; p += NP;
+  bk.w.v2 = p; p += NP;
+  bk.w.nat = p; p += NP;
+  bk.w.ring = p; p += 2 * B::GW * kRingDoubles;
   bk.w.red = p; p += 16;
   bk.w.cnt = p; p += 8;
   bk.w.prof = p; p += 8;
@@ -681,18 +704,19 @@ __device__ __forceinline__ void init_backend(SoftAbsBackend& bk, const ImplicitA
 struct SaArgs {
   ImplicitArgs a;
   const double* coeff;  // device pointer to softabs_coeff
+  double* work;         // NP = 128: [n_chains][kWorkDoubles] matrices of the chains
   int op;
 };
 
 // MIDPOINT: ImplicitMidpointIntegrator (integrators.py:547-681) on the same backend
-template <bool MIDPOINT>
+template <bool MIDPOINT, int NP>
 __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   ImplicitArgs A = S.a;
   A.z = S.coeff;
   const int64_t chain = blockIdx.x;
-  SoftAbsBackend bk;
-  init_backend(bk, A, lds);
+  SoftAbsBackendT<NP> bk;
+  init_backend(bk, A, lds, S.work + chain * SoftAbsBackendT<NP>::kWorkDoubles);
   const int dim = A.dim, tid = threadIdx.x;
   const bool act = tid < dim;
   const double q = act ? A.pos[chain * dim + tid] : 0.0;
@@ -732,13 +756,14 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
 }
 
 // op 0: h = l + 0.5 logdet + 0.5 p^T M^-1 p ; 1: dh_dmom ; 2: sample_momentum = V diag(sqrt(lamt)) V^T z
+template <int NP>
 __global__ __launch_bounds__(NT) void softabs_aux_kernel(SaArgs S, double* out, const double* z) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   ImplicitArgs A = S.a;
   A.z = S.coeff;
   const int64_t chain = blockIdx.x;
-  SoftAbsBackend bk;
-  init_backend(bk, A, lds);
+  SoftAbsBackendT<NP> bk;
+  init_backend(bk, A, lds, S.work + chain * SoftAbsBackendT<NP>::kWorkDoubles);
   const int dim = A.dim, tid = threadIdx.x;
   const bool act = tid < dim;
   const double q = act ? A.pos[chain * dim + tid] : 0.0;
@@ -779,10 +804,55 @@ SaArgs make_args(const mm_model* m, mm_state* s) {
 }
 
 int check_dim(mm_ctx* ctx, const mm_model* m) {
-  if (m->dim > 64) {
-    mm_set_error(ctx, "SoftAbs kernels support dim <= 64 (LDS-resident eigendecomposition)");
+  if (m->dim > 128) {
+    mm_set_error(ctx, "SoftAbs kernels support dim <= 128 (one workgroup per chain; matrices in LDS up to 64)");
     return MM_ERR_UNSUPPORTED;
   }
+  return MM_OK;
+}
+
+// the global-memory matrices of the NP = 128 kernels: grown on demand, kept with the state
+int ensure_work(mm_ctx* ctx, mm_state* s, size_t doubles_per_chain, double** out) {
+  const size_t need = (size_t)s->n * doubles_per_chain * sizeof(double);
+  if (need > s->work_bytes) {
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (s->d_work) (void)hipFree(s->d_work);
+    s->d_work = nullptr;
+    s->work_bytes = 0;
+    MM_HIP_CHECK(ctx, hipMalloc(&s->d_work, need));
+    s->work_bytes = need;
+  }
+  *out = static_cast<double*>(s->d_work);
+  return MM_OK;
+}
+
+template <bool MIDPOINT, int NP>
+int launch_softabs_np(mm_ctx* ctx, mm_state* s, SaArgs S) {
+  using B = SoftAbsBackendT<NP>;
+  if (B::kWorkDoubles) {
+    const int rc = ensure_work(ctx, s, B::kWorkDoubles, &S.work);
+    if (rc != MM_OK) return rc;
+  }
+  const size_t lds = B::kLdsDoubles * sizeof(double);
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(softabs_leapfrog_kernel<MIDPOINT, NP>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((softabs_leapfrog_kernel<MIDPOINT, NP>), dim3((unsigned)s->n), dim3(NT), lds, ctx->stream, S);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
+template <int NP>
+int launch_aux_np(mm_ctx* ctx, mm_state* s, SaArgs S, double* d_out, const double* d_z) {
+  using B = SoftAbsBackendT<NP>;
+  if (B::kWorkDoubles) {
+    const int rc = ensure_work(ctx, s, B::kWorkDoubles, &S.work);
+    if (rc != MM_OK) return rc;
+  }
+  const size_t lds = B::kLdsDoubles * sizeof(double);
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(softabs_aux_kernel<NP>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(softabs_aux_kernel<NP>, dim3((unsigned)s->n), dim3(NT), lds, ctx->stream, S, d_out, d_z);
+  MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }
 
@@ -793,17 +863,13 @@ static int launch_softabs(mm_ctx* ctx, const mm_model* m, mm_state* s, double h,
                           const mm_fp_opts& opts, mm_counters* d_counters) {
   int rc = check_dim(ctx, m);
   if (rc != MM_OK) return rc;
+  if (s->n == 0) return MM_OK;
   SaArgs S = make_args(m, s);
   S.a.step_size = h;
   S.a.n_steps = n_steps;
   S.a.opts = opts;
   S.a.counters = d_counters;
-  const size_t lds = kLdsDoubles * sizeof(double);
-  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(softabs_leapfrog_kernel<MIDPOINT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(softabs_leapfrog_kernel<MIDPOINT>, dim3((unsigned)s->n), dim3(NT), lds, ctx->stream, S);
-  MM_HIP_CHECK(ctx, hipGetLastError());
-  return MM_OK;
+  return m->dim <= 64 ? launch_softabs_np<MIDPOINT, 64>(ctx, s, S) : launch_softabs_np<MIDPOINT, 128>(ctx, s, S);
 }
 
 int mm_launch_softabs_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
@@ -820,12 +886,8 @@ int mm_launch_softabs_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, d
                           const double* d_z) {
   int rc = check_dim(ctx, m);
   if (rc != MM_OK) return rc;
+  if (s->n == 0) return MM_OK;
   SaArgs S = make_args(m, s);
   S.op = op;
-  const size_t lds = kLdsDoubles * sizeof(double);
-  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(softabs_aux_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(softabs_aux_kernel, dim3((unsigned)s->n), dim3(NT), lds, ctx->stream, S, d_out, d_z);
-  MM_HIP_CHECK(ctx, hipGetLastError());
-  return MM_OK;
+  return m->dim <= 64 ? launch_aux_np<64>(ctx, s, S, d_out, d_z) : launch_aux_np<128>(ctx, s, S, d_out, d_z);
 }

@@ -317,10 +317,10 @@ def test_unsupported_sizes_fail_loudly():
     with pytest.raises(DeviceError):
         integrators.ImplicitLeapfrogIntegrator(system, 0.01).step_batch(
             rng.standard_normal((1, big)), rng.standard_normal((1, big)), 1, 1)
-    system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(np.linspace(0.5, 2, 64)))
-    with pytest.raises(DeviceError):
+    system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(np.linspace(0.5, 2, 128)))
+    with pytest.raises(DeviceError):  # SoftAbs: one workgroup per chain up to D = 128
         integrators.ImplicitLeapfrogIntegrator(system, 0.01).step_batch(
-            rng.standard_normal((1, 65)), rng.standard_normal((1, 65)), 1, 1)
+            rng.standard_normal((1, 129)), rng.standard_normal((1, 129)), 1, 1)
     system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(65, 1.0, 0.0), models.CircleConstr())
     with pytest.raises(DeviceError):  # lane-per-chain kernels stop at dim 64
         integrators.ConstrainedLeapfrogIntegrator(system, 0.1).step_batch(

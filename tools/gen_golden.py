@@ -525,10 +525,10 @@ def main():
     add_euclid("euclid_banana_d16", mdl.Banana(16), mdl.METRIC_IDENTITY, None, 4, 0.02, [1, 10])
 
     # ---- implicit leapfrog, dense Riemannian metric (c3a, c4) -----------------------------------------
-    def add_riemann(name, target, rmetric, coeff, n, h, cps, qscale=1.0, **kw):
+    def add_riemann(name, target, rmetric, coeff, n, h, cps, qscale=1.0, r=None, **kw):
         d = target.dim
-        q0 = qscale * rng.standard_normal((n, d))
-        z = rng.standard_normal((n, d))
+        q0 = qscale * (rng if r is None else r).standard_normal((n, d))
+        z = (rng if r is None else r).standard_normal((n, d))
         osys = orc.RiemannianSystem(target, rmetric, coeff)
         p0 = np.stack([osys.sample_momentum(orc._State(q0[c], None), z[c]) for c in range(n)])
         cases[name] = lambda: riemann_case(name, target, rmetric, coeff, q0, p0, dirs_for(n), h,
@@ -1147,6 +1147,14 @@ def main():
     wide_linear("constrained_c5_linear_ambient_d20", 20, 5, 4, mdl.METRIC_DENSE, 0.1, [1, 5, 20], variant="ambient")
     wide_linear("constrained_c4_linear_identity_d8", 8, 4, 5, mdl.METRIC_IDENTITY, 0.1, [1, 5, 20])
     wide_linear("constrained_c6_linear_gauss_d24", 24, 6, 4, mdl.METRIC_DENSE, 0.2, [1, 5, 20], variant="gaussian")
+
+    # ---- SoftAbs systems beyond D = 64 (round 2: the NP = 128 instantiation of k_softabs.hip) ------------------------
+    add_riemann("softabs_funnel_d100", mdl.Funnel(np.linspace(0.5, 2.0, 99)), None, 1.0, 3, 0.02, [1, 4],
+                r=case_rng("softabs_funnel_d100"))
+    add_riemann("softabs_poly_d72", mdl.Poly(72, 1.0, 1.0 / 3.0), None, 1.5, 3, 0.05, [1, 5],
+                r=case_rng("softabs_poly_d72"))
+    add_riemann("softabs_funnel_d128", mdl.Funnel(np.linspace(0.5, 2.0, 127)), None, 1.0, 2, 0.02, [1, 3],
+                qscale=0.7, r=case_rng("softabs_funnel_d128"))
 
     def wide_sphere_plane(name, d, n, mk, h, cps, **kw):
         r = case_rng(name)
