@@ -547,6 +547,23 @@ struct TeamBlk16 {
       // (measured: ~100 cycles per MFMA when a wave issues one tile after the other, against 64 for the matrix core),
       // so tiles are processed in groups whose chains are interleaved.
       if constexpr (EXPER == 2) {
+      } else if constexpr (EXPER == 4) {
+        // SIMD-isolation experiment: waves 0 and 4 (one SIMD) update nothing; wave 0 repeats the pivot-block inverse
+        // WHILE the six other waves update their tiles, timed into the "-W" column
+        if (w == 0) {
+          d4 t2 = load_b(X, I0, g, j);
+          bool ok2 = true;
+          const long long a0 = __builtin_readcyclecounter();
+          tile_sweep(t2, ok2, w, g, j);
+          asm volatile("" : "+v"(t2));
+          c4 = c3 + (__builtin_readcyclecounter() - a0);
+          if (!ok2) lds[kOffScr + 6 * 64] = 1.0;
+        } else if (w != 4) {
+          update_group<0, 4>(X, w, g, j, nw);
+          update_group<4, 4>(X, w, g, j, nw);
+          update_group<8, 4>(X, w, g, j, nw);
+          update_group<12, 5>(X, w, g, j, nw);
+        }
       } else if constexpr (!TRAILING) {
         update_group<0, 4, EXPER == 3>(X, w, g, j, nw);
         update_group<4, 4, EXPER == 3>(X, w, g, j, nw);
@@ -894,6 +911,7 @@ __global__ __launch_bounds__(NTHR, 2) void blk16_bench_kernel(ImplicitArgs A, in
     if constexpr (OP == 10) ok = bk.template sweep<false, true, 1>(bad);
     if constexpr (OP == 11) ok = bk.template sweep<false, true, 2>(bad);
     if constexpr (OP == 12) ok = bk.template sweep<false, true, 3>(bad);
+    if constexpr (OP == 14) ok = bk.template sweep<false, true, 4>(bad);
     const long long t1 = __builtin_readcyclecounter();
     __syncthreads();
     if (tid < 64) {
@@ -971,7 +989,7 @@ int mm_launch_implicit_blk16(mm_ctx* ctx, const mm_model* m, mm_state* s, double
 // N * 256 * 256 (op 0) or N * 256 (op 1, 2) doubles; status[N] (host, may be NULL) receives 0 / 5 per chain.
 extern "C" int mm_debug_blk16_linalg(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* out,
                                      int32_t* status, int reps, double* ms) {
-  if (!ctx || !m || !s || !out || op < 0 || op > 13 || m->rmetric == MM_RMETRIC_NONE ||
+  if (!ctx || !m || !s || !out || op < 0 || op > 14 || m->rmetric == MM_RMETRIC_NONE ||
       m->rmetric == MM_RMETRIC_SOFTABS)
     return MM_ERR_INVALID;
   MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -998,7 +1016,7 @@ extern "C" int mm_debug_blk16_linalg(mm_ctx* ctx, const mm_model* m, mm_state* s
     switch (op) {
 #define MM_BENCH(OP) case OP: lrc = launch_blk16(ctx, blk16_bench_kernel<OP>, a, m->rmetric_pad_dim, reps); break;
       MM_BENCH(3) MM_BENCH(4) MM_BENCH(5) MM_BENCH(6) MM_BENCH(7) MM_BENCH(8) MM_BENCH(9) MM_BENCH(10) MM_BENCH(11)
-      MM_BENCH(12)
+      MM_BENCH(12) MM_BENCH(14)
 #undef MM_BENCH
       default: lrc = MM_ERR_INVALID; break;
     }

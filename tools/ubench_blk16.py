@@ -43,7 +43,9 @@ for op, name in names.items():
     res[name] = dict(us=us, kcycles=us * 2.4)
     print(f"{name:22s} {us:8.2f} us  {us * 2.4:8.1f} kcycles", flush=True)
 for op, name in ((8, "full sweep"), (9, "trailing sweep"), (10, "full sweep WITHOUT pivot-block inverse"),
-                 (11, "full sweep WITHOUT tile updates"), (12, "full sweep, tile updates WITHOUT operand loads")):
+                 (11, "full sweep WITHOUT tile updates"), (12, "full sweep, tile updates WITHOUT operand loads"),
+                 (14, "SIMD isolation: waves 0/4 update nothing, wave 0 repeats the pivot inverse during the updates "
+                      "(its time in the -W column)")):
     ms = C.c_double(0.0)
     _ffi.check(fn(ctx.handle, system.device_model(ctx).handle, batch.handle, op, out.ctypes.data_as(_ffi.c_double_p),
                   None, 0, C.byref(ms)), ctx.handle, "mm_debug_blk16_linalg")
