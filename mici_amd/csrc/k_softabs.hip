@@ -24,6 +24,8 @@ namespace {
 using namespace mmdev;
 using namespace mmimp;
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+
 constexpr int NT = 1024;           // 16 waves per chain: the kernel is LDS-latency bound, four waves per SIMD hide it
 constexpr int TPD = 32;            // threads per matrix dimension in the NP x NP products (TPD^2 = NT)
 constexpr int kMaxSweeps = 30;
@@ -168,7 +170,7 @@ struct SoftAbsBackendT {
     if (target == MM_TARGET_FUNNEL) {
       e = exp(-x[0]);
       double acc = 0.0;
-      for (int i = 1 + (threadIdx.x & 63); i < dim; i += 64) acc += tparams[i - 1] * x[i] * x[i];
+      for (int i = 1 + ((int)tid & 63); i < dim; i += 64) acc += tparams[i - 1] * x[i] * x[i];  // (opaque lane)
       s = wave_sum(acc);  // every wave computes the same S = sum w x^2
     }
     for (int el = tid; el < NP * dim; el += NT) {
@@ -194,6 +196,28 @@ struct SoftAbsBackendT {
   // the H reads of a 32-lane group are 32 consecutive rows (stride LD = 65 doubles: conflict-free), the V reads are
   // broadcasts and the G writes are contiguous.
   __device__ __forceinline__ void times_basis() {
+    if constexpr (kMatricesInLds) {
+      // on the matrix cores: wave t owns the 16 x 16 tile (t / 4, t % 4) of G; operands beyond dim are masked to zero
+      // (H and V are only defined on dim x dim)
+      const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+      const int g = lane >> 4, j = lane & 15;
+      const int I = wave >> 2, Jt = wave & 3;
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+      const double* arow = w.H + (16 * I + j) * LD + g;   // H[16 I + m][4 kk + g], m = j
+      const double* bcol = w.V + g * LD + 16 * Jt + j;    // V[4 kk + g][16 Jt + n], n = j
+      const bool row_ok = 16 * I + j < dim, col_ok = 16 * Jt + j < dim;
+#pragma unroll 4
+      for (int kk = 0; kk < NP / 4; ++kk) {
+        const bool k_ok = 4 * kk + g < dim;
+        const double a = (row_ok && k_ok) ? arow[4 * kk] : 0.0;
+        const double b = (col_ok && k_ok) ? bcol[4 * kk * LD] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w.W[(16 * Jt + j) * LDJ + 16 * I + 4 * r + g] = acc[r];  // zero beyond dim by the masks
+      __syncthreads();
+      return;
+    }
     const int ti = tid % TPD, bj = (tid / TPD) * BS;
     double acc[BS][BS];
 #pragma unroll
@@ -490,41 +514,41 @@ struct SoftAbsBackendT {
     return regularise();
   }
 
-  // V^T v (flat in, flat out): RP threads share output k, each sums every RP-th term
+  // V^T v (flat in, flat out): RP threads share output k, each sums every RP-th term.  Input and output go through
+  // two buffers of their own (in the ring, idle outside eigh()), so a call needs two workgroup barriers, not four: the
+  // next writer of either buffer is always behind a barrier that every reader of it has passed.
   __device__ __forceinline__ double vt_times(double v) {
-    if (tid < NP) w.v1[tid] = (tid < dim) ? v : 0.0;
+    double* const vin = w.ring + 1024;
+    double* const vout = vin + NP;
+    if (tid < NP) vin[tid] = (tid < dim) ? v : 0.0;
     __syncthreads();
     {
       const int k = tid / RP, part = tid % RP;
       double s = 0.0;
       if (k < dim)
-        for (int i = part; i < dim; i += RP) s = __builtin_fma(w.V[i * LD + k], w.v1[i], s);
+        for (int i = part; i < dim; i += RP) s = __builtin_fma(w.V[i * LD + k], vin[i], s);
       s = rp_sum(s);
-      __syncthreads();  // every thread has read v1
-      if (part == 0) w.v1[k] = s;
+      if (part == 0) vout[k] = s;
     }
     __syncthreads();
-    const double out = (tid < dim) ? w.v1[tid] : 0.0;
-    __syncthreads();
-    return out;
+    return (tid < dim) ? vout[tid] : 0.0;
   }
   // V v
   __device__ __forceinline__ double v_times(double v) {
-    if (tid < NP) w.v2[tid] = (tid < dim) ? v : 0.0;
+    double* const vin = w.ring + 1024;
+    double* const vout = vin + NP;
+    if (tid < NP) vin[tid] = (tid < dim) ? v : 0.0;
     __syncthreads();
     {
       const int i = tid / RP, part = tid % RP;
       double s = 0.0;
       if (i < dim)
-        for (int k = part; k < dim; k += RP) s = __builtin_fma(w.V[i * LD + k], w.v2[k], s);
+        for (int k = part; k < dim; k += RP) s = __builtin_fma(w.V[i * LD + k], vin[k], s);
       s = rp_sum(s);
-      __syncthreads();
-      if (part == 0) w.v2[i] = s;
+      if (part == 0) vout[i] = s;
     }
     __syncthreads();
-    const double out = (tid < dim) ? w.v2[tid] : 0.0;
-    __syncthreads();
-    return out;
+    return (tid < dim) ? vout[tid] : 0.0;
   }
 
   // M^-1 v = V diag(1/lamt) V^T v   (matrices.py:1568-1575, 1623-1624)
@@ -559,9 +583,24 @@ struct SoftAbsBackendT {
       a2 = 2.0 * w.nat[tid] * wi * xi;      // (m_vi + m_iv) w_i x_i
       a3 = w.v2[tid] * wi;                  // m_ii w_i
     }
-    const double S = block_reduce4(a1, 0, w.red);
-    const double s2 = block_reduce4(a2, 0, w.red);
-    const double s3 = block_reduce4(a3, 0, w.red);
+    // three sums, one pair of barriers (a workgroup barrier of this team costs ~340 cycles)
+    double S, s2, s3;
+    {
+      double* const red3 = w.ring + 512;  // [16][3]; the ring is idle outside eigh()
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      a1 = wave_sum(a1);
+      a2 = wave_sum(a2);
+      a3 = wave_sum(a3);
+      if (lane == 0) { red3[3 * wave] = a1; red3[3 * wave + 1] = a2; red3[3 * wave + 2] = a3; }
+      __syncthreads();
+      double r1 = 0.0, r2 = 0.0, r3 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NT / 64; ++k) { r1 += red3[3 * k]; r2 += red3[3 * k + 1]; r3 += red3[3 * k + 2]; }
+      __syncthreads();
+      S = uniform_f64(r1);
+      s2 = uniform_f64(r2);
+      s3 = uniform_f64(r3);
+    }
     double out = 0.0;
     if (tid == 0) out = -0.5 * ev * S * mvv + ev * s2 - ev * s3;
     else if (tid < dim) {
@@ -606,6 +645,59 @@ struct SoftAbsBackendT {
     const double c = vt_times(p);
     if (tid < NP) w.v1[tid] = (tid < dim) ? c / w.lamt[tid] : 0.0;  // e
     __syncthreads();
+    if constexpr (kMatricesInLds) {
+      // J into w.H, A into w.W, zero beyond dim; then B = A J on the matrix cores: wave t owns the 16 x 16 tile
+      // (t / 4, t % 4) of B - sixteen v_mfma_f64_16x16x4 (A operand: lane (g, m) = A[16 I + m][4 kk + g]; B operand:
+      // lane (g, n) = J[4 kk + g][16 Jt + n]; accumulator lane 16 g + j, register r = B[16 I + 4 r + g][16 Jt + j]).
+      // md_i = sum_l B_il A_il is reduced over a tile's columns on the DPP row and over the four column tiles through
+      // LDS; m0_i = sum_l B_0l A_il needs row 0 of B only.  (The FMA loop this replaces took 31 k cycles a call.)
+      for (int el = tid; el < NP * NP; el += NT) {
+        const int k = el / NP, l = el % NP;
+        double jv = 0.0, av = 0.0;
+        if (k < dim && l < dim) {
+          double num = w.lamt[k] - w.lamt[l], den = w.lam[k] - w.lam[l];
+          if (k == l) { num += w.gsa[k]; den = 1.0; }
+          jv = num / den;                        // 0/0 -> NaN for degenerate spectra, as the reference
+          av = w.V[k * LD + l] * w.v1[l];        // A[i=k][k=l]
+        }
+        w.H[k * LD + l] = jv;
+        w.W[k * LD + l] = av;
+      }
+      __syncthreads();
+      double* const part = w.ring;        // [4][NP] column-tile partials of md (the ring is idle outside eigh())
+      double* const brow0 = w.ring + 4 * NP;  // [NP] row 0 of B
+      {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int g = lane >> 4, j = lane & 15;
+        const int I = wave >> 2, Jt = wave & 3;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double* arow = w.W + (16 * I + j) * LD + g;
+        const double* bcol = w.H + g * LD + 16 * Jt + j;
+#pragma unroll 4
+        for (int kk = 0; kk < NP / 4; ++kk)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * kk], bcol[4 * kk * LD], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * I + 4 * r + g;
+          const double s = rp_sum_n<16>(acc[r] * w.W[i * LD + 16 * Jt + j]);
+          if (j == 0) part[Jt * NP + i] = s;
+        }
+        if (I == 0 && g == 0) brow0[16 * Jt + j] = acc[0];
+      }
+      __syncthreads();
+      {
+        const int i = tid / RP, pt = tid % RP;
+        double m0 = 0.0;
+#pragma unroll
+        for (int m = 0; m < NP / RP; ++m) m0 = __builtin_fma(brow0[pt + RP * m], w.W[i * LD + pt + RP * m], m0);
+        m0 = rp_sum(m0);
+        if (pt == 0) {
+          w.v2[i] = -((part[i] + part[NP + i]) + (part[2 * NP + i] + part[3 * NP + i]));
+          w.nat[i] = -m0;
+        }
+      }
+      __syncthreads();
+    } else {
     // J into w.H, A into w.W
     for (int el = tid; el < NP * dim; el += NT) {
       const int k = el / NP, l = el % NP;
@@ -640,6 +732,7 @@ struct SoftAbsBackendT {
       if (part == 0 && i < NP) { w.v2[i] = -md; w.nat[i] = -m0; }
       __syncthreads();
     }
+    }
     const double mdf = (tid < dim) ? w.v2[tid] : 0.0;
     const double m0f = (tid < dim) ? w.nat[tid] : 0.0;
     __syncthreads();
@@ -651,7 +744,7 @@ struct SoftAbsBackendT {
   __device__ __forceinline__ double grad(double q) {
     if (tid < NP) w.nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
-    const TargetAux aux = target_prepare<true>(target, w.nat, dim, tparams, threadIdx.x & 63);
+    const TargetAux aux = target_prepare<true>(target, w.nat, dim, tparams, (int)tid & 63);
     const double g = (tid < dim) ? target_grad_elem<true>(target, aux, w.nat, tid, dim, tparams) : 0.0;
     __syncthreads();
     return g;
@@ -659,7 +752,7 @@ struct SoftAbsBackendT {
   __device__ __forceinline__ double nld_elem(double q) {
     if (tid < NP) w.nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
-    const TargetAux aux = target_prepare<true>(target, w.nat, dim, tparams, threadIdx.x & 63);
+    const TargetAux aux = target_prepare<true>(target, w.nat, dim, tparams, (int)tid & 63);
     const double e = (tid < dim) ? target_nld_elem<true>(target, aux, w.nat, tid, dim, tparams) : 0.0;
     __syncthreads();
     return e;
