@@ -60,8 +60,8 @@ struct MLds {
 
 template <int RMETRIC>
 struct MfmaBackend {
-  static constexpr bool kSolveByInverse = true;  // implicit_core.h: solve = invert + mat-vec, one construction site
-  static constexpr bool kUnifiedConstruct = false;
+  static constexpr bool kSolveByInverse = false;
+  static constexpr bool kUnifiedConstruct = true;  // implicit_core.h: one construction site, the mode at run time
   static constexpr bool kCountersInLds = false;
   d4 acc[kTiles];
   int dim, lane, target;
@@ -133,19 +133,23 @@ struct MfmaBackend {
     double av[4], bv[4];
   };
 
-  // update the tiles of tile-row/column `in` (hot == true) or all the others (hot == false); in < 0: all
-  __device__ __forceinline__ void apply(const Ops& o, const int in, const bool hot) {
+  // update the tiles of tile-row/column `in` (hot == true) or all the others (hot == false); in < 0: all.
+  // jmin: the trailing (LDL^T) sweep leaves the tile columns left of the pivot's alone.
+  __device__ __forceinline__ void apply(const Ops& o, const int in, const bool hot, const int jmin = 0) {
 #pragma unroll
     for (int I = 0; I < 4; ++I)
 #pragma unroll
       for (int J = 0; J <= I; ++J) {
         const bool is_hot = (I == in) || (J == in);
-        if (in < 0 || is_hot == hot)
+        if (J >= jmin && (in < 0 || is_hot == hot))
           acc[tix(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.av[I], o.bv[J], acc[tix(I, J)], 0, 0, 0);
       }
   }
 
   // ---- one block of the sweep (B compile-time after unrolling) ----------------------------------------
+  // TRAILING: only the tiles (I, J) with J >= I0 are updated - a blocked LDL^T (D^3/3 flops instead of D^3) that
+  // ends with tile (K, K) = -P_K^-1 and tile (I, K) = A_IK P_K^-1, the factors solve_factored() substitutes with
+  template <bool TRAILING>
   __device__ __forceinline__ void block_step(const int B, Ops& ops, double& pmin) {
     const int I0 = B >> 2, R0 = B & 3;
     const int g = lane >> 4, j = lane & 15;
@@ -154,7 +158,7 @@ struct MfmaBackend {
     // lanes holding columns K of the tiles below the diagonal tile; the other lanes store into the (dead)
     // W buffer instead of branching, which keeps the whole sweep one basic block for the scheduler.
 #pragma unroll
-    for (int J = 0; J <= I0; ++J) w.qt[((16 * J + j) << 2) + g] = acc[tix(I0, J)][R0];
+    for (int J = TRAILING ? I0 : 0; J <= I0; ++J) w.qt[((16 * J + j) << 2) + g] = acc[tix(I0, J)][R0];
     {
       double* dst = ((j >> 2) == R0) ? w.qt + (g << 2) + (j & 3) : w.wt + j;
 #pragma unroll
@@ -170,7 +174,7 @@ struct MfmaBackend {
     const d4 c3 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 3) << 2));
     d4 q = *reinterpret_cast<const d4*>(w.qt + (lane << 2));
     // the previous block's cold tiles: independent of everything below until this block's own update
-    if (B > 0) apply(ops, I0, false);
+    if (B > 0) apply(ops, I0, false, TRAILING ? (B - 1) >> 2 : 0);
     d4 wv;
     {
       // P = [A B; B^T C] with 2 x 2 blocks; c_s is column s of P
@@ -231,33 +235,95 @@ struct MfmaBackend {
       ops.av[X] = w.wt[((16 * X + j) << 2) + g];
       ops.bv[X] = w.qt[((16 * X + j) << 2) + g];
     }
-    if (B < 15) apply(ops, (B + 1) >> 2, true);
-    else apply(ops, -1, true);
+    if (B < 15) apply(ops, (B + 1) >> 2, true, TRAILING ? I0 : 0);
+    else apply(ops, -1, true, TRAILING ? I0 : 0);
     if (j == 4 * R0 + g) acc[tix(I0, I0)][R0] -= 2.0;
     wave_sync();  // the next block overwrites Qt / Wt
   }
 
+  template <bool TRAILING>
   __device__ __forceinline__ bool sweep() {
     double pmin = 1.0;  // smallest pivot seen
     Ops ops;
 #pragma unroll
-    for (int B = 0; B < 16; ++B) block_step(B, ops, pmin);
+    for (int B = 0; B < 16; ++B) block_step<TRAILING>(B, ops, pmin);
+    if constexpr (!TRAILING) {
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) acc[t] = -acc[t];
-    const double probe = acc[0][0];
+      for (int t = 0; t < kTiles; ++t) acc[t] = -acc[t];
+    }
+    // a NaN pivot poisons every entry of W and with it every tile that is still being updated: the last diagonal
+    // tile is updated by every block of both sweeps
+    const double probe = acc[tix(3, 3)][0];
     return (pmin > 0.0) && __all(probe == probe);
   }
 
-  __device__ __forceinline__ bool build_and_invert(double x) {
+  // ---- u = M^-1 b from the trailing sweep's factors (tile (K, K) = -P_K^-1, tile (I, K) = T_IK = A_IK P_K^-1) ------
+  // forward, right-looking: y_K is final when step K starts; z_K = P_K^-1 y_K and b_I -= T_IK y_K for I > K come
+  // from the tiles of tile column K through the mat-vec's row partial sums.  Backward, right-looking: u_I is final
+  // when step I starts and z_K -= T_IK^T u_I for K < I comes through the mirrored partial sums.
+  __device__ __forceinline__ double solve_factored(double b) {
+    const int g = lane >> 4, j = lane & 15;
+    w.nat[lane] = (lane < dim) ? b : 0.0;
+    wave_sync();
+#pragma unroll
+    for (int K = 0; K < 4; ++K) {
+      const double yk = w.nat[16 * K + j];
+#pragma unroll
+      for (int I = K; I < 4; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.part[(16 * I + 4 * r + g) * kPartStride + j] = acc[tix(I, K)][r] * yk;
+      wave_sync();
+      if (lane >= 16 * K) {
+        const double* src = w.part + lane * kPartStride;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) { a0 += src[k]; a1 += src[k + 1]; a2 += src[k + 2]; a3 += src[k + 3]; }
+        const double sum = (a0 + a1) + (a2 + a3);
+        w.nat[lane] = (lane < 16 * K + 16) ? -sum : w.nat[lane] - sum;  // z_K (the tile is -P^-1) | b_I - T_IK y_K
+      }
+      wave_sync();
+    }
+#pragma unroll
+    for (int I = 3; I >= 1; --I) {
+      const d4 ur = d4{w.nat[16 * I + g], w.nat[16 * I + 4 + g], w.nat[16 * I + 8 + g], w.nat[16 * I + 12 + g]};
+#pragma unroll
+      for (int K = 0; K < I; ++K) {
+        const d4 a = acc[tix(I, K)];
+        double m = a[0] * ur[0];
+        m = __builtin_fma(a[1], ur[1], m);
+        m = __builtin_fma(a[2], ur[2], m);
+        m = __builtin_fma(a[3], ur[3], m);
+        w.mpart[(K * 4 + g) * 16 + j] = m;
+      }
+      wave_sync();
+      if (lane < 16 * I) {
+        const double* m = w.mpart + (lane >> 4) * 64 + (lane & 15);
+        w.nat[lane] -= (m[0] + m[16]) + (m[32] + m[48]);
+      }
+      wave_sync();
+    }
+    const double u = (lane < dim) ? w.nat[lane] : 0.0;
+    wave_sync();
+    return u;
+  }
+
+  // implicit_core.h, kUnifiedConstruct: metric_func(x), then the explicit inverse (kept in the tiles for matvec /
+  // half_vjp_inv / dh2_dpos) or the single solve u = M(x)^-1 rhs (systems.py:1381-1399)
+  __device__ __forceinline__ bool construct(double x, bool need_inverse, double rhs, double* u) {
     bool ok = build(x);
-    ok = sweep() && ok;
+    if (need_inverse) {  // wave-uniform
+      ok = sweep<false>() && ok;
+    } else {
+      ok = sweep<true>() && ok;
+      *u = solve_factored(rhs);
+    }
     return ok;
   }
-  __device__ __forceinline__ bool build_and_solve(double x, double rhs, double* u) {
-    const bool ok = build_and_invert(x);
-    *u = matvec(rhs);
-    return ok;
+  __device__ __forceinline__ bool build_and_invert(double x) {
+    double dummy;
+    return construct(x, true, 0.0, &dummy);
   }
+  __device__ __forceinline__ bool build_and_solve(double x, double rhs, double* u) { return construct(x, false, rhs, u); }
 
   // ---- y = T v for the symmetric matrix held as lower tiles -------------------------------------------
   __device__ __forceinline__ double matvec(double v) {
@@ -450,7 +516,7 @@ __global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs 
     const long long t0 = __builtin_readcyclecounter();
     bool ok = bk.build(q);
     const long long t1 = __builtin_readcyclecounter();
-    ok = bk.sweep() && ok;
+    ok = bk.template sweep<false>() && ok;
     const long long t2 = __builtin_readcyclecounter();
     const double u = bk.matvec(p);
     const long long t3 = __builtin_readcyclecounter();
