@@ -31,6 +31,7 @@ EXTRA_FLAGS = {
     "k_implicit_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "k_implicit_mfma_team.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "k_implicit_blk16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "k_implicit_blk16la.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }
 
 

@@ -19,10 +19,13 @@ from mici_amd.runtime import DeviceBatch, default_context
 pytestmark = pytest.mark.gpu
 
 
-def _linalg(system, x, b, op):
+KERNELS = ["blk16", "blk16la"]  # k_implicit_blk16.hip and its look-ahead variant k_implicit_blk16la.hip
+
+
+def _linalg(system, x, b, op, kernel="blk16"):
     ctx = default_context()
     lib = ctx._lib
-    fn = lib.mm_debug_blk16_linalg
+    fn = lib.mm_debug_blk16_linalg if kernel == "blk16" else lib.mm_debug_blk16la_linalg
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _ffi.c_double_p, _ffi.c_int32_p, C.c_int,
                    _ffi.c_double_p]
@@ -37,22 +40,23 @@ def _linalg(system, x, b, op):
     return out, status
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("dim", [256, 255, 200, 129, 77])
-def test_rank1_metric_inverse_and_solves(dim):
+def test_rank1_metric_inverse_and_solves(dim, kernel):
     rng = np.random.default_rng(dim)
     n = 5
     om = omdl.Rank1Metric(omdl.make_spd(dim, rng))
     system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(om.base))
     x = rng.standard_normal((n, dim))
     b = rng.standard_normal((n, dim))
-    inv, st = _linalg(system, x, b, 0)
+    inv, st = _linalg(system, x, b, 0, kernel)
     assert np.all(st == 0)
     for c in range(n):
         M = om.metric_func(x[c])
         want = np.linalg.inv(M)
         assert_close(inv[c, :dim, :dim], want, 1e-11, f"explicit inverse, chain {c}")
     for op, what in ((1, "LDL^T solve"), (2, "inverse mat-vec")):
-        u, st = _linalg(system, x, b, op)
+        u, st = _linalg(system, x, b, op, kernel)
         assert np.all(st == 0)
         for c in range(n):
             want = np.linalg.solve(om.metric_func(x[c]), b[c])
@@ -60,7 +64,8 @@ def test_rank1_metric_inverse_and_solves(dim):
             assert np.all(u[c, dim:] == 0.0)
 
 
-def test_diagquad_metric_and_failure_flags():
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_diagquad_metric_and_failure_flags(kernel):
     dim, n = 100, 4
     rng = np.random.default_rng(3)
     system = systems.DenseRiemannianMetricSystem(models.Poly(dim, 1.0, 1.0 / 3.0), models.DiagQuadMetric(dim))
@@ -69,13 +74,14 @@ def test_diagquad_metric_and_failure_flags():
     x[2, 7] = np.inf   # "Array is not finite."   (matrices.py:211-215)
     x[3, 0] = np.nan
     for op in (1, 2):
-        u, st = _linalg(system, x, b, op)
+        u, st = _linalg(system, x, b, op, kernel)
         assert st.tolist() == [0, 0, 5, 5]
         for c in range(2):
             assert_close(u[c, :dim], b[c] / (1.0 + x[c] ** 2), 1e-12, f"op {op} chain {c}")
 
 
-def test_not_positive_definite_is_flagged():
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_not_positive_definite_is_flagged(kernel):
     dim, n = 96, 3
     rng = np.random.default_rng(4)
     base = omdl.make_spd(dim, rng)
@@ -83,7 +89,7 @@ def test_not_positive_definite_is_flagged():
     system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(base))
     x = 0.1 * rng.standard_normal((n, dim))
     for op in (0, 1):
-        _, st = _linalg(system, x, x, op)
+        _, st = _linalg(system, x, x, op, kernel)
         assert np.all(st == 5)
 
 
