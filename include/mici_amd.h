@@ -243,7 +243,11 @@ int mm_composition_euclid(mm_ctx* ctx, const mm_model* model, mm_state* state, d
 
 /* ImplicitLeapfrogIntegrator.step x n_steps on a Dense / SoftAbs RiemannianMetricSystem
  * (integrators.py:493-544; solvers.py:47-154; systems.py:1360-1402; matrices.py:1161-1188, 1631-1685).
- * opts == NULL selects the reference defaults. counters may be NULL. */
+ * opts == NULL selects the reference defaults. counters may be NULL.
+ * On a plain EuclideanMetricSystem (the reference runs this integrator on any System, tests/test_integrators.py:435-462)
+ * the step reduces to the explicit composition A(t) C(t) C(t) A(t) and is run as such: every chain reports status 0, the
+ * solver options other than max_iters >= 2 are not consulted, and a state whose drift |t M^-1 p| exceeds divergence_tol
+ * or is not finite - where the reference raises ConvergenceError - is integrated on instead of being frozen. */
 int mm_implicit_leapfrog(mm_ctx* ctx, const mm_model* model, mm_state* state, double step_size,
                          int32_t n_steps, const mm_fp_opts* opts, mm_counters* counters);
 
