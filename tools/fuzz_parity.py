@@ -81,7 +81,7 @@ def euclid_case(rng):
 
 
 def riemann_case(rng):
-    dim = int(rng.choice([1, 2, 5, 8, 9, 16, 31, 32, 33, 40, 63, 64, 65, 70, 75, 76, 90, 128]))
+    dim = int(rng.choice([1, 2, 5, 8, 9, 16, 31, 32, 33, 40, 63, 64, 65, 70, 75, 76, 90, 128, 200, 255, 256]))
     n = int(rng.choice([1, 2, 5, 9]))
     which = rng.choice(["rank1", "diagquad"])
     pt, ot = targets(dim, rng, ["poly", "banana"] if dim >= 2 else ["poly"])
@@ -108,7 +108,7 @@ def riemann_case(rng):
 
 
 def softabs_case(rng):
-    dim = int(rng.choice([2, 3, 5, 8, 16, 17, 33, 48, 64]))
+    dim = int(rng.choice([2, 3, 5, 8, 13, 16, 17, 33, 48, 63, 64, 65, 72, 100, 127, 128]))
     n = int(rng.choice([1, 2, 5]))
     if rng.random() < 0.5:
         w = np.linspace(0.5, 2.0, dim - 1)
@@ -129,16 +129,53 @@ def softabs_case(rng):
     return desc, integ, system, osys, q0, p0, dirs, steps, ref, 5e-8
 
 
+def constrained_case(rng):
+    """Linear-equality and sphere manifolds up to D = 64 / C = 8 (the padded lane-per-chain kernels included)."""
+    dim = int(rng.choice([2, 3, 5, 8, 9, 12, 16, 17, 24, 33, 48, 64]))
+    n = int(rng.choice([1, 3, 7]))
+    mk, metric = metric_of(dim, rng)
+    pt, ot = targets(dim, rng, ["poly"])
+    if rng.random() < 0.6 and dim >= 3:
+        c = int(rng.integers(1, min(8, dim - 1) + 1))
+        a, b = rng.standard_normal((c, dim)), rng.standard_normal(c)
+        pc, oc = models.LinearConstr(a, b), omdl.LinearConstr(a, b)
+        part = np.linalg.lstsq(a, b, rcond=None)[0]
+        null = np.linalg.svd(a)[2][c:].T
+        q0 = part + 0.5 * rng.standard_normal((n, dim - c)) @ null.T
+        what = f"linear C={c}"
+    else:
+        pc, oc = models.SphereConstr(), omdl.SphereConstr()
+        x = rng.standard_normal((n, dim))
+        q0 = x / np.linalg.norm(x, axis=1, keepdims=True)
+        what = "sphere"
+    system = systems.DenseConstrainedEuclideanMetricSystem(pt, pc, metric=metric)
+    osys = orc.ConstrainedSystem(ot, oc, mk, metric)
+    solver = int(rng.integers(0, 3))
+    proj = [solvers.solve_projection_onto_manifold_newton, solvers.solve_projection_onto_manifold_quasi_newton,
+            solvers.solve_projection_onto_manifold_newton_with_line_search][solver]
+    h, steps = float(rng.uniform(0.03, 0.15)), int(rng.integers(1, 8))
+    integ = integrators.ConstrainedLeapfrogIntegrator(system, h, projection_solver=proj)
+    p0 = np.stack([osys.project_onto_cotangent_space(osys.msqrt(z), osys.constraint.jacob_constr(q0[c]))
+                   for c, z in enumerate(rng.standard_normal((n, dim)))])
+    dirs = np.where(rng.random(n) < 0.5, 1, -1).astype(np.int8)
+    desc = f"constrained {what} D={dim} N={n} metric={mk} solver={solver} h={h:.3f} steps={steps}"
+    ref = lambda c: orc.constrained_leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, steps, proj_solver=solver)  # noqa: E731
+    return desc, integ, system, osys, q0, p0, dirs, steps, ref, 1e-9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--kinds", default="euclid,riemann,softabs,constrained",
+                    help="comma-separated case families to draw from (uniformly)")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
+    makers = {"euclid": euclid_case, "riemann": riemann_case, "softabs": softabs_case, "constrained": constrained_case}
+    kinds = [makers[k] for k in a.kinds.split(",")]
     bad = 0
     for i in range(a.cases):
-        u = rng.random()
-        make = euclid_case if u < 0.55 else (riemann_case if u < 0.9 else softabs_case)
+        make = kinds[int(rng.integers(0, len(kinds)))]
         desc, integ, system, osys, q0, p0, dirs, steps, ref, tol = make(rng)
         try:
             q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=steps)
