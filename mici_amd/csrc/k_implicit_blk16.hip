@@ -681,6 +681,14 @@ struct TeamBlk16 {
     // rows I > K left in part[16 K + j][I], publishes u_K, and leaves its own row's partials for the columns J < K.
 #pragma unroll 1
     for (int K = nblk - 1; K >= 0; --K) {
+      d4 ur = d4{0.0, 0.0, 0.0, 0.0};
+      auto col_partial = [&](const d4 a, const int J) {
+        double m = a[0] * ur[0];
+        m = __builtin_fma(a[1], ur[1], m);
+        m = __builtin_fma(a[2], ur[2], m);
+        m = __builtin_fma(a[3], ur[3], m);
+        part[(16 * J + j) * PSTR + K] = sum_over_g(m);
+      };
       if (K == ib || K == ia) {
         double u = aux[16 * K + j];
         const double* src = part + (16 * K + j) * PSTR;
@@ -694,28 +702,30 @@ struct TeamBlk16 {
         nat[16 * K + j] = u;
         lds[kOffVperm + (((K << 2) + (j & 3)) << 2) + (j >> 2)] = u;
         wave_sync();
-        const d4 ur = *reinterpret_cast<const d4*>(lds + kOffVperm + ((K * 4 + g) << 2));
-        auto col_partial = [&](const d4 a, const int J) {
-          double m = a[0] * ur[0];
-          m = __builtin_fma(a[1], ur[1], m);
-          m = __builtin_fma(a[2], ur[2], m);
-          m = __builtin_fma(a[3], ur[3], m);
-          part[(16 * J + j) * PSTR + K] = sum_over_g(m);
-        };
-        if (K == ib) {  // tile row 15-w: slots 1..15-w, column J = ib - s
-#pragma unroll
-          for (int s = 1; s < NSLOT - 1; ++s)
-            if (s <= 8 || s <= 15 - w) {
-              if (s <= ib) col_partial(acc[s], ib - s);
-            }
-        } else {  // tile row w: slots 16-w..15, column J = w + s - 16
-#pragma unroll
-          for (int s = 9; s < NSLOT - 1; ++s)
-            if (s > 15 - w) col_partial(acc[s], w + s - 16);
+        ur = *reinterpret_cast<const d4*>(lds + kOffVperm + ((K * 4 + g) << 2));
+        // before the barrier only what the NEXT step needs: the partial of this row's tile in column K - 1 (slot 1 of
+        // tile row 15-w, slot 15 of tile row w); the rest of the row follows after the barrier, while the owner of
+        // tile row K - 1 (another wave, except at K = 8 -> 7) is already at work
+        if (K == ib) {
+          if (ib >= 1) col_partial(acc[1], ib - 1);
+        } else {
+          if (ia >= 1) col_partial(acc[15], ia - 1);
         }
       }
       __syncthreads();
+      if (K == ib) {  // tile row 15-w: slots 2..15-w, column J = ib - s
+#pragma unroll
+        for (int s = 2; s < NSLOT - 1; ++s)
+          if (s <= 8 || s <= 15 - w) {
+            if (s <= ib) col_partial(acc[s], ib - s);
+          }
+      } else if (K == ia) {  // tile row w: slots 16-w..14, column J = w + s - 16
+#pragma unroll
+        for (int s = 9; s < NSLOT - 2; ++s)
+          if (s > 15 - w) col_partial(acc[s], w + s - 16);
+      }
     }
+    __syncthreads();
     const double u = (tid < dim) ? nat[tid] : 0.0;
     __syncthreads();
     return u;
