@@ -61,6 +61,8 @@ constexpr int NCLASS = 2;           // tile rows per wave
 constexpr int CS = 18;              // doubles per panel column in LDS: 16 + 2 (keeps 16-byte alignment, spreads banks)
 constexpr int PSTR = 17;            // partial sums per output element: 16 column-sum slots + the row sum
 constexpr int VLM = DPM + 8;        // flat vectors: DPM elements + a dummy cell for threads >= DPM
+constexpr int kInvWave = 7;         // the wave that inverts the pivot blocks: tile rows 8 and 7, with wave 3 (rows 12, 3)
+                                    // the SIMD with the least tile work in a trailing sweep
 
 // LDS (doubles).  The flat per-thread state comes first: its thirteen slots are then ONE address register plus a 16-bit
 // immediate offset each (DS instructions carry offsets < 64 KiB), not thirteen address registers.
@@ -451,6 +453,7 @@ struct TeamBlk16 {
     do {
       const int w = opaque_wave(wave);
       const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
+      const bool on_inv_simd = w == kInvWave || w == kInvWave - 4;  // waves w and w + 4 share a SIMD
       double* X = lds + kOffX + (I0 & 1) * (DPM * CS);
       long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
       if constexpr (PROF) c0 = __builtin_readcyclecounter();
@@ -512,7 +515,7 @@ struct TeamBlk16 {
       d4 t;
       {
         double* tbuf = lds + kOffScr + 64;  // [64 lanes][4]
-        if (w == 0) {
+        if (w == kInvWave) {
           t = load_b(X, I0, g, j);
 #pragma unroll
           for (int r = 0; r < 4; ++r) t[r] += (j == 4 * r + g) ? 1.0 : 0.0;
@@ -520,6 +523,15 @@ struct TeamBlk16 {
           if constexpr (EXPER != 1) tile_sweep(t, okb, w, g, j);
           *reinterpret_cast<d4*>(tbuf + 4 * ln) = t;
           if (ln == 0) lds[kOffScr + 5 * 64] = okb ? 0.0 : 1.0;
+        }
+        // The forward substitution step of the PREVIOUS block runs here, in the window in which the other waves would
+        // otherwise wait for the inverse (3.7 k cycles): its inputs - y_(K-1) and the factor tiles of column K-1 - are
+        // final since the previous block's updates, and the next step's y_K is needed one block later.  (At the end of
+        // the block that produced them it cost ~1.5 k cycles of every wave's critical path.)  Not on the inverting
+        // wave's SIMD: FP64 vector work there would slow the inverse down; those two waves - the ones with the least
+        // tile work in a trailing sweep - keep their step at the end of the block.
+        if constexpr (TRAILING) {
+          if (!on_inv_simd && I0 > 0) forward_substitution_step(I0 - 1, w, g, j);
         }
         __syncthreads();
         t = *reinterpret_cast<const d4*>(tbuf + 4 * ln);
@@ -594,7 +606,9 @@ struct TeamBlk16 {
             if (j == 4 * r + g) acc[s][r] -= 2.0;
         }
       }
-      if constexpr (TRAILING) forward_substitution_step(I0, w, g, j);
+      if constexpr (TRAILING) {
+        if (on_inv_simd) forward_substitution_step(I0, w, g, j);
+      }
       if constexpr (PROF) {
         const long long c5 = __builtin_readcyclecounter();
         pc[0] += c1 - c0;  // publish (includes waiting for the previous block's MFMA results)
@@ -606,6 +620,11 @@ struct TeamBlk16 {
       }
       // no barrier here: the next block publishes into the other panel buffer
     } while (++I0 < nblk);
+    if constexpr (TRAILING) {  // the last block's forward substitution step (solve() starts with a barrier)
+      const int w = opaque_wave(wave);
+      const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
+      if (!(w == kInvWave || w == kInvWave - 4)) forward_substitution_step(nblk - 1, w, g, j);
+    }
     if constexpr (PROF) {
       if (fresh_lane() == 0) {
         long long* dst = reinterpret_cast<long long*>(lds + kOffPart) + wave * 8;
