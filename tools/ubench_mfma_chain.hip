@@ -38,26 +38,34 @@ void run(int waves_per_simd, int iters) {
   long long* cyc;
   hipMalloc(&out, sizeof(double) * threads * blocks);
   hipMalloc(&cyc, sizeof(long long) * blocks * threads / 64);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
   hipLaunchKernelGGL(chain_kernel<NACC>, dim3(blocks), dim3(threads), 0, 0, out, cyc, iters);
+  hipEventRecord(e0, 0);
   hipLaunchKernelGGL(chain_kernel<NACC>, dim3(blocks), dim3(threads), 0, 0, out, cyc, iters);
+  hipEventRecord(e1, 0);
   hipDeviceSynchronize();
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
   std::vector<long long> h(blocks * threads / 64);
   hipMemcpy(h.data(), cyc, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
   double mean = 0.0;
   for (auto v : h) mean += (double)v;
   mean /= h.size();
   const double per_wave = mean / (iters * 8.0 * NACC);
-  printf("waves/SIMD %d  interleaved chains %d : %7.1f cycles per MFMA per wave, %7.1f per SIMD\n", waves_per_simd, NACC,
-         per_wave, per_wave / waves_per_simd);
+  const double flops = 2048.0 * iters * 8.0 * NACC * (threads / 64.0) * blocks;
+  printf("waves/SIMD %d  interleaved chains %d : %7.1f cycles per MFMA per wave, %7.1f per SIMD | launch %.3f ms = %.1f "
+         "TFLOP/s, counter %.2f GHz\n", waves_per_simd, NACC, per_wave, per_wave / waves_per_simd, ms,
+         flops / (ms * 1e-3) / 1e12, mean / (ms * 1e-3) / 1e9);
   hipFree(out);
   hipFree(cyc);
 }
 
 int main() {
   for (int w = 1; w <= 2; ++w) {
-    run<1>(w, 200);
-    run<2>(w, 200);
-    run<4>(w, 200);
+    run<1>(w, 20000);
+    run<4>(w, 20000);
   }
   return 0;
 }
