@@ -374,27 +374,32 @@ struct SoftAbsBackendT {
         wave_sync();
       }
     }
-    // the 64 cross pairs: slot i keeps column i of ba in registers and meets column (i + k) mod 8 of bb in round k
+    // the 64 cross pairs: slot i keeps column i of ba in registers and meets column (i + k) mod 8 of bb in round k.
+    // The bb columns stay in registers too: after a round every slot hands its column to the slot below it (lane
+    // L takes lane L + 8's registers, ds_bpermute: one crossbar trip instead of an LDS store, a wait and a load).
     const int oa = col_offset(ba * 8 + slot, sub);
     load_col(M, oa, xa);
-    bool any = false;
+    load_col(M, col_offset(bb * 8 + slot, sub), xb);
+    const int from = ((threadIdx.x + 8) & 63) << 2;  // byte address of the source lane for ds_bpermute
     for (int k = 0; k < 8; ++k) {
-      const int ob = col_offset(bb * 8 + ((slot + k) & 7), sub);
       SA_STAMP(ta);
-      load_col(M, ob, xb);
-      if (rotate_pair<GROLE>(xa, xb, ring + ((7 + k) * 8 + slot) * 2, writer, big, bad, prof)) {
-        SA_STAMP(tb);
-        store_col(M, ob, xb);
-        any = true;
-        wave_sync();
-        SA_STAMP(tc);
-        SA_STAMP_ADD(4, tb, tc);
+      rotate_pair<GROLE>(xa, xb, ring + ((7 + k) * 8 + slot) * 2, writer, big, bad, prof);
+      if (k < 7) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          const long long b = __double_as_longlong(xb[r]);
+          const int lo = __builtin_amdgcn_ds_bpermute(from, (int)(b & 0xffffffffLL));
+          const int hi = __builtin_amdgcn_ds_bpermute(from, (int)(b >> 32));
+          xb[r] = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        }
       }
-      wave_sync();
       SA_STAMP(td);
       SA_STAMP_ADD(3, ta, td);
     }
-    if (any) store_col(M, oa, xa);
+    // slot i ends with column (i + 7) mod 8 of bb
+    store_col(M, oa, xa);
+    store_col(M, col_offset(bb * 8 + ((slot + 7) & 7), sub), xb);
+    wave_sync();
   }
 
   // the two blocks of block-pair slot w in round R of the tournament of the NBLK blocks
