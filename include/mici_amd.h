@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 2
+#define MM_ABI_VERSION 3
 
 typedef struct mm_ctx mm_ctx;
 typedef struct mm_model mm_model;
@@ -160,6 +160,13 @@ typedef struct mm_counters {
   int64_t n_fp_solves;    /* fixed-point solves                         */
   int64_t n_newton_iters; /* projection-solver iterations               */
   int64_t n_constr;       /* constraint + Jacobian evaluations          */
+  int64_t n_eigh;         /* SoftAbs: eigendecompositions executed      */
+  /* Work the device actually executed for the n_metric constructions (round 3): the solve-only constructions of the
+   * position fixed points are refined from the explicit inverse at the step's start (implicit_core.h) instead of
+   * being factorised.  n_factor_full + n_factor_solve + (refined constructions) = constructions executed. */
+  int64_t n_refine;       /* preconditioned-CG product pairs (M(x) v, M(x0)^-1 v) */
+  int64_t n_factor_full;  /* full sweeps: factorisation + explicit inverse */
+  int64_t n_factor_solve; /* trailing sweeps: LDL^T factorisation + one substitution */
   int64_t reserved;
 } mm_counters;
 

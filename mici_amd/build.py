@@ -29,9 +29,7 @@ EXTRA_FLAGS = {
     # keep the MFMA accumulators (= the metric tiles) in architected VGPRs: the sweep reads them back every
     # block, and from AGPRs that is one v_accvgpr_read per dword
     "k_implicit_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-    "k_implicit_mfma_team.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "k_implicit_blk16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-    "k_implicit_blk16la.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }
 
 

@@ -639,10 +639,7 @@ int mm_launch_implicit_large(mm_ctx*, const mm_model*, mm_state*, double, int, c
                              mm_counters*);
 int mm_launch_riemann_aux_large(mm_ctx*, const mm_model*, mm_state*, int, double*, const double*);
 int mm_launch_implicit_mfma(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
-int mm_launch_implicit_mfma_team(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&,
-                                 mm_counters*);
 int mm_launch_implicit_blk16(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
-int mm_launch_implicit_blk16la(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
 
 int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
                                 const mm_fp_opts& opts, mm_counters* d_counters) {
@@ -655,17 +652,12 @@ int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, dou
   static const int force = [] {
     const char* e = getenv("MICI_AMD_IMPLICIT_KERNEL");
     if (!e) return 0;
-    return strcmp(e, "wave") == 0 ? 1 : strcmp(e, "team") == 0 ? 2 : strcmp(e, "team4") == 0 ? 3
-           : strcmp(e, "blk16la") == 0 ? 4 : 0;
+    return strcmp(e, "wave") == 0 ? 1 : strcmp(e, "team") == 0 ? 2 : 0;
   }();
   // 75 < D <= 256: team of 8 waves, metric in the CU's register file, 16-pivot blocks on the matrix cores with
-  // solve-only constructions as a blocked LDL^T (k_implicit_blk16.hip).  MICI_AMD_IMPLICIT_KERNEL=team4 selects
-  // the round-1 kernel (4-pivot blocks, explicit inverse every time: k_implicit_mfma_team.hip), =team the VALU
-  // team kernel
-  if (m->dim > 75 && m->dim <= 256 && force == 3)
-    return mm_launch_implicit_mfma_team(ctx, m, s, h, n_steps, opts, d_counters);
-  if (m->dim > 75 && m->dim <= 256 && force == 4)  // look-ahead variant (k_implicit_blk16la.hip)
-    return mm_launch_implicit_blk16la(ctx, m, s, h, n_steps, opts, d_counters);
+  // solve-only constructions as a blocked LDL^T (k_implicit_blk16.hip).  MICI_AMD_IMPLICIT_KERNEL=team selects the
+  // VALU team kernel.  (The round-1 4-pivot kernel and the look-ahead variant of round 2 lost their A/B runs and were
+  // removed in round 3; they are in the history: k_implicit_mfma_team.hip, k_implicit_blk16la.hip.)
   if (m->dim > 75 && m->dim <= 256 && force != 2)
     return mm_launch_implicit_blk16(ctx, m, s, h, n_steps, opts, d_counters);
   if (m->dim > 64 || (m->dim > 32 && force == 2))

@@ -66,8 +66,8 @@ constexpr int kInvWave = 7;         // the wave that inverts the pivot blocks: t
 
 // LDS (doubles).  The flat per-thread state comes first: its thirteen slots are then ONE address register plus a 16-bit
 // immediate offset each (DS instructions carry offsets < 64 KiB), not thirteen address registers.
-constexpr int kOffStash = 0;                               // [SL_COUNT][VLM] flat per-thread state of the step
-constexpr int kOffNat = kOffStash + SL_COUNT * VLM;        // [VLM] natural-order vector
+constexpr int kOffStash = 0;                               // [SL_COUNT_REFINE][VLM] flat per-thread state of the step
+constexpr int kOffNat = kOffStash + SL_COUNT_REFINE * VLM; // [VLM] natural-order vector
 constexpr int kOffVperm = kOffNat + VLM;                   // [DPM] the same vector as [I][g][r]: row operands as one 32-byte read
 constexpr int kOffAux = kOffVperm + DPM;                   // [VLM] second natural-order vector (z of the substitution)
 constexpr int kOffRed = kOffAux + VLM;                     // [24]  team reductions / flags / work counters
@@ -78,6 +78,13 @@ constexpr int kOffPart = kOffX + 2 * DPM * CS;             // [DPM][PSTR]
 constexpr int kOffB = kOffPart + DPM * PSTR;               // [DPM] right-hand side of a solve-only construction: the forward
                                                            // substitution runs inside the trailing sweep, in place
 constexpr int kLdsDoubles = kOffB + DPM;
+// Scratch of the refinement solves (implicit_core.h refine_solve) lives in the panel buffers: no sweep runs while one
+// is in flight.  The point x of metric_apply() in both operand orders, then RS_COUNT flat per-thread vectors.
+constexpr int kOffXnat = kOffX;                            // [VLM]
+constexpr int kOffXperm = kOffXnat + VLM;                  // [DPM]
+constexpr int kOffRs = kOffXperm + DPM;                    // [RS_COUNT][VLM]
+static_assert(kOffRs + RS_COUNT * VLM <= kOffPart, "refinement scratch must fit the panel buffers");
+static_assert((kOffXperm % 2) == 0, "16-byte alignment of the d4 accesses");
 static_assert((kOffVperm % 2) == 0 && (kOffScr % 2) == 0 && (kOffX % 2) == 0, "16-byte alignment of the d4 accesses");
 static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU");
 
@@ -183,6 +190,7 @@ struct TeamBlk16 {
   static constexpr bool kSolveByInverse = false;
   static constexpr bool kUnifiedConstruct = true;  // implicit_core.h: one construction site, mode at run time
   static constexpr bool kCountersInLds = true;     // implicit_core.h: work counters in LDS, bumped by thread 0
+  static constexpr bool kRefine = true;            // implicit_core.h: solve-only constructions refined from the held inverse
   d4 acc[NSLOT];
   int wave; // wave index, wave-uniform (phases re-materialise it through opaque_wave)
   int nblk; // number of 16-pivot blocks that contain real rows: ceil(dim / 16)
@@ -250,6 +258,34 @@ struct TeamBlk16 {
     r.n_solves = (long long)lds[kOffRed + 16 + CNT_SOLVES];
     r.n_metric = (long long)lds[kOffRed + 16 + CNT_METRIC];
     r.n_grad = (long long)lds[kOffRed + 16 + CNT_GRAD];
+    r.n_refine = (long long)lds[kOffRed + 16 + CNT_REFINE];
+    r.n_full = (long long)lds[kOffRed + 16 + CNT_FULL];
+    r.n_trail = (long long)lds[kOffRed + 16 + CNT_TRAIL];
+  }
+  static_assert(CNT_COUNT <= 8, "work counters occupy lds[kOffRed + 16 .. 23]");
+  __device__ __forceinline__ double& rslot(int i) { return lds[kOffRs + i * VLM + (tid < DPM ? tid : DPM)]; }
+
+  // two team-uniform sums over the chain's elements in one pass (two barriers)
+  __device__ __forceinline__ void sum2(double a, double b, double* sa, double* sb) {
+    const int lane = fresh_lane(), wv = opaque_wave(wave);
+    const bool act = tid < dim;
+    a = wave_sum(act ? a : 0.0);
+    b = wave_sum(act ? b : 0.0);
+    double* red = lds + kOffRed;
+    if (lane == 0) {
+      red[wv] = a;
+      red[8 + wv] = b;
+    }
+    __syncthreads();
+    double ra = red[0], rb = red[8];
+#pragma unroll
+    for (int k = 1; k < NWAVE; ++k) {
+      ra += red[k];
+      rb += red[8 + k];
+    }
+    __syncthreads();
+    *sa = uniform_f64(ra);
+    *sb = uniform_f64(rb);
   }
   __device__ __forceinline__ double& slot(int i) { return lds[kOffStash + i * VLM + (tid < DPM ? tid : DPM)]; }
 
@@ -314,6 +350,78 @@ struct TeamBlk16 {
       }
     }
     return __builtin_amdgcn_ballot_w64(chk != 0.0) != 0;
+  }
+
+  // ---- M(x) v without touching the tiles (they hold -M(x0)^-1): refine_solve's matrix-free product ---------------
+  __device__ __forceinline__ void metric_point(double x) {
+    if (tid < DPM) {
+      const double xm = tid < dim ? x : 0.0;
+      lds[kOffXnat + tid] = xm;
+      lds[kOffXperm + ((((tid >> 4) << 2) + (tid & 3)) << 2) + ((tid >> 2) & 3)] = xm;
+    }
+    // visible after metric_apply()'s publish barrier
+  }
+  // The entries of metric_func(x) are formed exactly as in build() (same loads, same arithmetic) and contracted with v
+  // like matvec() does with the tiles: every lower tile serves its own rows and, mirrored, its columns.
+  __device__ __forceinline__ double metric_apply(double v) {
+    publish_vector(v);
+    const int w = opaque_wave(wave);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
+    const double inv_d = 1.0 / (double)dim;
+    double* part = lds + kOffPart;
+    d4 rs[NCLASS];
+#pragma unroll
+    for (int c = 0; c < NCLASS; ++c) rs[c] = d4{0.0, 0.0, 0.0, 0.0};
+    const unsigned lane_off = (unsigned)(g * base_ld + j);
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int I = tile_i(s, w), J = tile_j(s, w);
+      const d4 qr = *reinterpret_cast<const d4*>(lds + kOffXperm + ((I * 4 + g) << 2));
+      d4 m;
+      if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+        const double* tile0 = base + (unsigned)((16 * I) * base_ld + 16 * J);
+        const double qs = lds[kOffXnat + 16 * J + j] * inv_d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = __builtin_fma(qr[r], qs, tile0[lane_off + (unsigned)(4 * r * base_ld)]);
+      } else {
+        m = d4{0.0, 0.0, 0.0, 0.0};
+      }
+      if (is_diag_slot(s)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool on_diag = (j == 4 * r + g);
+          if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
+            if (on_diag) m[r] = __builtin_fma(qr[r], qr[r], 1.0);
+          }
+          if (on_diag && 16 * I + 4 * r + g >= dim) m[r] = 1.0;
+        }
+      }
+      const double vc = lds[kOffNat + 16 * J + j];
+      add_row(s, w, rs, m, vc);
+      if (!is_diag_slot(s)) {
+        const d4 vr = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
+        double mm = m[0] * vr[0];
+        mm = __builtin_fma(m[1], vr[1], mm);
+        mm = __builtin_fma(m[2], vr[2], mm);
+        mm = __builtin_fma(m[3], vr[3], mm);
+        mm = sum_over_g(mm);
+        part[(16 * J + j) * PSTR + I] = mm;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCLASS; ++c) {
+      const double k = row_reduce16(rs[c], j);
+      part[(16 * row_of_class(c, w) + 4 * (j >> 2) + g) * PSTR + 16] = k;
+    }
+    __syncthreads();
+    double y = 0.0;
+    if (tid < DPM) {
+      const double* src = lds + kOffPart + tid * PSTR;
+#pragma unroll
+      for (int k = 0; k < PSTR; ++k) y += src[k];
+    }
+    __syncthreads();
+    return tid < dim ? y : 0.0;
   }
 
   // B operands of column tile J: bx[kk] = X[4 kk + g][16 J + j] (the panel is published as Q - E already)

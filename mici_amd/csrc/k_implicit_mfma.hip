@@ -41,8 +41,10 @@ constexpr int kWaves = 4;      // chains per workgroup
 constexpr int kTiles = 10;     // lower-triangular 16 x 16 tiles of a 64 x 64 matrix
 constexpr int kPartStride = 17;
 // per-wave LDS (doubles): Qt[64][4], Wt[64][4], nat[64], vperm[64], aux[64], part[64][17], mpart[3][64],
-// stash[SL_COUNT][64]
-constexpr int kMfmaWaveDoubles = 256 + 256 + 64 + 64 + 64 + 64 * kPartStride + 192 + SL_COUNT * 64;
+// stash[SL_COUNT_REFINE][64].  The refinement solves (implicit_core.h refine_solve) keep their scratch in Qt / Wt: no
+// sweep runs while one is in flight.
+constexpr int kMfmaWaveDoubles = 256 + 256 + 64 + 64 + 64 + 64 * kPartStride + 192 + SL_COUNT_REFINE * 64;
+static_assert((2 + RS_COUNT) * 64 <= 512, "refinement scratch must fit Qt + Wt");
 constexpr int kBaseDoubles = kTiles * 4 * 64;  // staged base matrix of the rank-one metric
 
 __host__ __device__ constexpr int tix(int I, int J) { return I * (I + 1) / 2 + J; }
@@ -55,7 +57,7 @@ struct MLds {
   double* aux;    // [64]
   double* part;   // [64][17] direct partial sums of the mat-vec
   double* mpart;  // [3][4][16] mirrored partial sums
-  double* stash;  // [SL_COUNT][64]
+  double* stash;  // [SL_COUNT_REFINE][64]
 };
 
 template <int RMETRIC>
@@ -63,6 +65,7 @@ struct MfmaBackend {
   static constexpr bool kSolveByInverse = false;
   static constexpr bool kUnifiedConstruct = true;  // implicit_core.h: one construction site, the mode at run time
   static constexpr bool kCountersInLds = false;
+  static constexpr bool kRefine = true;  // implicit_core.h: solve-only constructions refined from the held inverse
   d4 acc[kTiles];
   int dim, lane, target;
   MLds w;
@@ -124,6 +127,89 @@ struct MfmaBackend {
     }
     wave_sync();
     return __all(chk == 0.0);
+  }
+
+  // ---- refinement solves (implicit_core.h): M(x) v formed matrix-free, the tiles keep M(x0)^-1 ---------------------
+  // scratch in Qt / Wt: [0] x natural order, [1] x as [I][g][r], [2 ..] the solve's flat vectors
+  __device__ __forceinline__ double& rslot(int i) { return w.qt[(2 + i) * 64 + lane]; }
+  __device__ __forceinline__ void sum2(double a, double b, double* sa, double* sb) {
+    *sa = wave_sum(lane < dim ? a : 0.0);
+    *sb = wave_sum(lane < dim ? b : 0.0);
+  }
+  __device__ __forceinline__ void metric_point(double x) {
+    const double xm = (lane < dim) ? x : 0.0;
+    w.qt[lane] = xm;
+    w.qt[64 + (((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = xm;
+    wave_sync();
+  }
+  // entries exactly as build() forms them, contracted with v like matvec() contracts the tiles
+  __device__ __forceinline__ double metric_apply(double v) {
+    const int g = lane >> 4, j = lane & 15;
+    w.nat[lane] = (lane < dim) ? v : 0.0;
+    w.vperm[(((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = (lane < dim) ? v : 0.0;
+    wave_sync();
+    const double inv_d = 1.0 / (double)dim;
+    double vc[4], qc[4];
+    d4 vr[4], qr[4];
+#pragma unroll
+    for (int X = 0; X < 4; ++X) {
+      vc[X] = w.nat[16 * X + j];
+      vr[X] = *reinterpret_cast<const d4*>(w.vperm + ((X * 4 + g) << 2));
+      qc[X] = w.qt[16 * X + j] * inv_d;
+      qr[X] = *reinterpret_cast<const d4*>(w.qt + 64 + ((X * 4 + g) << 2));
+    }
+    double mir[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int I = 0; I < 4; ++I) {
+      d4 s = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int J = 0; J <= I; ++J) {
+        const int t = tix(I, J);
+        d4 m;
+        if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+          const d2 b01 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 0) * 64 + lane) * 2);
+          const d2 b23 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 1) * 64 + lane) * 2);
+          m[0] = __builtin_fma(qr[I][0], qc[J], b01[0]);
+          m[1] = __builtin_fma(qr[I][1], qc[J], b01[1]);
+          m[2] = __builtin_fma(qr[I][2], qc[J], b23[0]);
+          m[3] = __builtin_fma(qr[I][3], qc[J], b23[1]);
+        } else {
+          m = d4{0.0, 0.0, 0.0, 0.0};
+        }
+        if (I == J) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool on_diag = (j == 4 * r + g);
+            if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
+              if (on_diag) m[r] = __builtin_fma(qr[I][r], qr[I][r], 1.0);
+            }
+            if (on_diag && 16 * I + 4 * r + g >= dim) m[r] = 1.0;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mir[J] = __builtin_fma(m[r], vr[I][r], mir[J]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = __builtin_fma(m[r], vc[J], s[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w.part[(16 * I + 4 * r + g) * kPartStride + j] = s[r];
+    }
+#pragma unroll
+    for (int J = 0; J < 3; ++J) w.mpart[(J * 4 + g) * 16 + j] = mir[J];
+    wave_sync();
+    double y = 0.0;
+    {
+      const double* src = w.part + lane * kPartStride;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) y += src[k];
+      if (lane < 48) {
+        const double* mp = w.mpart + (lane >> 4) * 64 + (lane & 15);
+        y += (mp[0] + mp[16]) + (mp[32] + mp[48]);
+      }
+    }
+    wave_sync();
+    return lane < dim ? y : 0.0;
   }
 
   // operands of one block's rank-4 update.  They stay in registers after the block so that the six

@@ -848,7 +848,7 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
     add_counters(A.counters, r);
     if (A.counters) {
       atomicAdd((unsigned long long*)&A.counters->n_newton_iters, (unsigned long long)bk.n_sweeps);
-      atomicAdd((unsigned long long*)&A.counters->reserved, (unsigned long long)bk.n_eigh);
+      atomicAdd((unsigned long long*)&A.counters->n_eigh, (unsigned long long)bk.n_eigh);
     }
   }
 }

@@ -19,13 +19,13 @@ from mici_amd.runtime import DeviceBatch, default_context
 pytestmark = pytest.mark.gpu
 
 
-KERNELS = ["blk16", "blk16la"]  # k_implicit_blk16.hip and its look-ahead variant k_implicit_blk16la.hip
+KERNELS = ["blk16"]
 
 
 def _linalg(system, x, b, op, kernel="blk16"):
     ctx = default_context()
     lib = ctx._lib
-    fn = lib.mm_debug_blk16_linalg if kernel == "blk16" else lib.mm_debug_blk16la_linalg
+    fn = lib.mm_debug_blk16_linalg
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _ffi.c_double_p, _ffi.c_int32_p, C.c_int,
                    _ffi.c_double_p]
