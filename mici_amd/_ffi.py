@@ -126,37 +126,40 @@ SIGNATURES = {
     "mm_comm_wait": (C.c_int, [_VP, c_double_p]),
 }
 
-_lib = None
+_DEV_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmici_amd_dev.so")
+_libs = {}
 
 
-def lib_path():
-    return _LIB_PATH
+def lib_path(dev=False):
+    return _DEV_LIB_PATH if dev else _LIB_PATH
 
 
-def load():
-    """Load libmici_amd.so and bind every declared symbol (no GPU needed for this)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(_LIB_PATH):
+def load(dev=False):
+    """Load libmici_amd.so and bind every declared symbol (no GPU needed for this).  dev=True: the developer build
+    libmici_amd_dev.so - the same library plus the test / micro-benchmark kernels (mici_amd/build.py) - as a second,
+    independent copy: objects created through a `Context(dev=True)` stay on it."""
+    if dev in _libs:
+        return _libs[dev]
+    path = lib_path(dev)
+    if not os.path.exists(path):
         raise DeviceError(
-            f"{_LIB_PATH} is missing: build it with `python -m mici_amd.build` "
+            f"{path} is missing: build it with `python -m mici_amd.build` "
             "(hipcc, --offload-arch=gfx950). mici_amd has no CPU fallback."
         )
     try:
-        lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+        lib = C.CDLL(path, mode=C.RTLD_LOCAL if dev else C.RTLD_GLOBAL)
     except OSError as e:
-        raise DeviceError(f"cannot load {_LIB_PATH}: {e}") from e
+        raise DeviceError(f"cannot load {path}: {e}") from e
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise DeviceError(f"{_LIB_PATH} does not export {name}") from e
+            raise DeviceError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
     if lib.mm_abi_version() != ABI_VERSION:
-        raise DeviceError("libmici_amd.so ABI version mismatch; rebuild with mici_amd.build")
-    _lib = lib
+        raise DeviceError(f"{os.path.basename(path)} ABI version mismatch; rebuild with mici_amd.build")
+    _libs[dev] = lib
     return lib
 
 

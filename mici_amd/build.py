@@ -1,8 +1,12 @@
 """Build libmici_amd.so for gfx950 with hipcc (in-tree; cross-compiles without a GPU).
 
-    python -m mici_amd.build [--force] [--jobs N]
+    python -m mici_amd.build [--force] [--jobs N] [--no-dev]
 
-Each csrc/*.hip is compiled to an object (in parallel), then linked into mici_amd/lib/libmici_amd.so.
+Each csrc/*.hip is compiled to an object (in parallel), then linked into mici_amd/lib/libmici_amd.so - the product:
+it exports exactly what include/mici_amd.h declares.  The developer kernels (phase timers, the linear algebra of a
+backend on its own, micro-benchmarks: everything between `#ifdef MM_DEV_KERNELS` in csrc/) go into a second library,
+mici_amd/lib/libmici_amd_dev.so = the product objects with the few sources that have developer code recompiled with
+-DMM_DEV_KERNELS; tests/test_gpu_blk16.py and tools/ubench_*.py open it with `Context(dev=True)`.
 Objects are rebuilt only when a source or header is newer."""
 
 from __future__ import annotations
@@ -18,7 +22,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
+OBJ_DEV = os.path.join(CSRC, "_build_dev")
 LIB = os.path.join(HERE, "lib", "libmici_amd.so")
+LIB_DEV = os.path.join(HERE, "lib", "libmici_amd_dev.so")
+DEV_MACRO = "MM_DEV_KERNELS"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function", "-ffp-contract=on"]
@@ -48,26 +55,20 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force=False, jobs=None, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(
-        os.path.join(HERE, "..", "include", "*.h"))
-    hdr_time = _newest(headers)
+def _compile_and_link(sources, objdir, lib, extra, headers_time, force, jobs, verbose, reuse=None):
+    """Objects of `sources` into `objdir` (flags + extra), linked with the objects of `reuse` into `lib`."""
+    os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
-    todo = []
-    objs = []
+    todo, objs = [], []
     for src in sources:
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
-                os.path.getmtime(src), hdr_time):
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), headers_time):
             todo.append((src, obj))
 
     def compile_one(pair):
         src, obj = pair
-        cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), *DEV_FLAGS, "-c", src, "-o", obj]
+        cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), *extra, *DEV_FLAGS, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r.returncode, r.stdout + r.stderr
 
@@ -75,18 +76,38 @@ def build(force=False, jobs=None, verbose=True):
         with cf.ThreadPoolExecutor(max_workers=jobs or min(8, len(todo))) as ex:
             for src, rc, log in ex.map(compile_one, todo):
                 if verbose:
-                    print(f"[mici_amd.build] hipcc {os.path.basename(src)} -> rc={rc}")
+                    print(f"[mici_amd.build] hipcc {' '.join(extra)} {os.path.basename(src)} -> rc={rc}")
                 if rc != 0:
                     raise RuntimeError(f"hipcc failed on {src}:\n{log}")
                 if verbose and log.strip():
                     print(log)
-    if todo or force or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
-        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB, "-ldl"]
+    all_objs = objs + list(reuse or [])
+    if todo or force or not os.path.exists(lib) or os.path.getmtime(lib) < _newest(all_objs):
+        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *all_objs, "-o", lib, "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
         if verbose:
-            print(f"[mici_amd.build] linked {LIB}")
+            print(f"[mici_amd.build] linked {lib}")
+    return objs
+
+
+def build(force=False, jobs=None, verbose=True, dev=True):
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(
+        os.path.join(HERE, "..", "include", "*.h"))
+    hdr_time = _newest(headers)
+    objs = _compile_and_link(sources, OBJ, LIB, [], hdr_time, force, jobs, verbose)
+    if dev:
+        def has_dev(path):
+            with open(path, encoding="utf-8") as f:
+                return DEV_MACRO in f.read()
+        dev_sources = [s for s in sources if has_dev(s)]
+        dev_names = {os.path.basename(s)[:-4] + ".o" for s in dev_sources}
+        shared = [o for o in objs if os.path.basename(o) not in dev_names]
+        _compile_and_link(dev_sources, OBJ_DEV, LIB_DEV, ["-D" + DEV_MACRO], hdr_time, force, jobs, verbose,
+                          reuse=shared)
     return LIB
 
 
@@ -94,6 +115,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--no-dev", action="store_true", help="skip libmici_amd_dev.so (developer / test kernels)")
     a = ap.parse_args()
-    build(force=a.force, jobs=a.jobs)
+    build(force=a.force, jobs=a.jobs, dev=not a.no_dev)
     sys.exit(0)

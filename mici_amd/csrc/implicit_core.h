@@ -130,6 +130,20 @@ __device__ __forceinline__ void bump(BK& bk, ChainResult& r, const int which, co
   }
 }
 
+// Developer builds: a backend with kProf attributes its clock to the phase last announced (prof_switch returns the
+// phase it replaces, so a sub-phase can hand back to its caller's).
+enum { PH_OTHER = 0, PH_GRAD, PH_FULL, PH_TRAIL, PH_MAPPLY, PH_FAPPLY, PH_RSUM, PH_MOMENTUM, PH_COUNT };
+template <class BK, class = void>
+struct prof_trait { static constexpr bool value = false; };
+template <class BK>
+struct prof_trait<BK, decltype((void)BK::kProf)> { static constexpr bool value = BK::kProf; };
+template <class BK>
+__device__ __forceinline__ int prof(BK& bk, int phase) {
+  if constexpr (prof_trait<BK>::value) return bk.prof_switch(phase);
+  else return 0;
+}
+
+
 // momentum-space fixed point  x = base - tt * dh2_dpos(q, x)  with the metric fixed (B and B-check)
 template <class BK>
 __device__ __forceinline__ int momentum_solve(BK& bk, double base, double tt, double q,
@@ -137,13 +151,18 @@ __device__ __forceinline__ int momentum_solve(BK& bk, double base, double tt, do
   FpCtl c{0, 0};
   double x0 = base, x1 = 0.0, pt = base;
   int status = MM_ST_OK;
+  const int ph0 = prof(bk, PH_MOMENTUM);
   for (;;) {
     const double fx = base - tt * bk.dh2_dpos(pt, q);
     bump(bk, r, CNT_EVALS, 1);
     const int act = fp_feed(bk, c, x0, x1, fx, o, &pt, &status);
     if (act == FP_DONE) break;
-    if (act == FP_FAIL) return status;
+    if (act == FP_FAIL) {
+      prof(bk, ph0);
+      return status;
+    }
   }
+  prof(bk, ph0);
   *result = pt;
   return MM_ST_OK;
 }
@@ -184,11 +203,14 @@ constexpr double kRefineTol2 = 1e-28;  // (relative energy-norm error)^2
 template <class BK>
 __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, double guess, double* u_out,
                                              ChainResult& r) {
+  const int ph0 = prof(bk, PH_MAPPLY);
   bk.metric_point(x);
   bk.rslot(RS_U) = guess;
   double rv = rhs - bk.metric_apply(guess);
   bk.rslot(RS_R) = rv;
+  prof(bk, PH_FAPPLY);
   double z = bk.matvec(rv);
+  prof(bk, PH_RSUM);
   double rz, pu;
   bk.sum2(rv * z, rhs * guess, &rz, &pu);
   int pairs = 1;
@@ -197,7 +219,9 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
     bk.rslot(RS_D) = z;
 #pragma unroll 1
     for (int k = 0; k < kRefineMaxIter; ++k) {
+      prof(bk, PH_MAPPLY);
       const double q = bk.metric_apply(bk.rslot(RS_D));
+      prof(bk, PH_RSUM);
       double dq, unused;
       bk.sum2(bk.rslot(RS_D) * q, 0.0, &dq, &unused);
       if (!(dq > 0.0)) break;  // not positive definite along d, or not finite
@@ -206,7 +230,9 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
       bk.rslot(RS_U) = u;
       rv = __builtin_fma(-al, q, bk.rslot(RS_R));
       bk.rslot(RS_R) = rv;
+      prof(bk, PH_FAPPLY);
       z = bk.matvec(rv);
+      prof(bk, PH_RSUM);
       ++pairs;
       double rz2;
       bk.sum2(rv * z, rhs * u, &rz2, &pu);
@@ -220,6 +246,7 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
   }
   bump(bk, r, CNT_REFINE, pairs);
   *u_out = bk.rslot(RS_U);
+  prof(bk, ph0);
   return ok;
 }
 
@@ -254,8 +281,10 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
     // Scalar-heavy work goes HERE, where the metric registers are dead (the build below overwrites
     // every tile): the gradient at the point whose metric is about to be built for A / B-adj + A.
     if (mode == MODE_INIT || mode == MODE_BADJ) {
+      prof(bk, PH_GRAD);
       bk.slot(SL_GNEW) = bk.grad(bk.slot(SL_XQ));
       bump(bk, r, CNT_GRAD, 1);
+      prof(bk, PH_OTHER);
     }
     // INIT / BADJ need the explicit inverse (applied ~12 times: momentum solves, both A half-steps, the
     // general-VJP path); the position-space iterations use their metric for a single solve.
@@ -272,6 +301,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
     if (refined) {
       okm = true;
     } else {
+      prof(bk, need_inverse ? PH_FULL : PH_TRAIL);
       if constexpr (BK::kUnifiedConstruct) {
         // one construction site, the mode decided at run time: explicit inverse, or the single solve M(x)^-1 pw
         okm = bk.construct(bk.slot(SL_XQ), need_inverse, bk.slot(SL_PW), &u_pos);
@@ -283,6 +313,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         okm = need_inverse ? bk.build_and_invert(bk.slot(SL_XQ))
                            : bk.build_and_solve(bk.slot(SL_XQ), bk.slot(SL_PW), &u_pos);
       }
+      prof(bk, PH_OTHER);
       bump(bk, r, (need_inverse || BK::kSolveByInverse) ? CNT_FULL : CNT_TRAIL, 1);
       if constexpr (kRefine) anchor = need_inverse && okm;
     }

@@ -488,6 +488,7 @@ __global__ __launch_bounds__(64 * kWaves) void riemann_aux_kernel(ImplicitArgs A
   }
 }
 
+#ifdef MM_DEV_KERNELS
 // ---- developer micro-benchmark (not part of the ABI header): R repetitions of one primitive per wave
 template <int TS>
 __global__ __launch_bounds__(64 * kWaves) void debug_primitive_kernel(ImplicitArgs A, int variant,
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(64 * kWaves) void debug_primitive_kernel(ImplicitAr
   }
   if (lane == 0) sink[chain] = acc;
 }
+#endif  // MM_DEV_KERNELS
 
 template <int TS, int RMETRIC>
 size_t lds_bytes() {
@@ -693,6 +695,7 @@ int mm_launch_riemann_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, d
   return dispatch(ctx, m, AuxFn{ctx, a, s->n, op});
 }
 
+#ifdef MM_DEV_KERNELS
 // developer hook (tools/ubench_primitives.py): time `repeats` repetitions of one primitive per chain
 extern "C" int mm_debug_primitive_bench(mm_ctx* ctx, const mm_model* m, mm_state* s, int variant,
                                         int repeats, double* ms) {
@@ -717,3 +720,4 @@ extern "C" int mm_debug_primitive_bench(mm_ctx* ctx, const mm_model* m, mm_state
   (void)hipEventDestroy(e1);
   return MM_OK;
 }
+#endif  // MM_DEV_KERNELS

@@ -61,6 +61,7 @@ constexpr int NCLASS = 2;           // tile rows per wave
 constexpr int CS = 18;              // doubles per panel column in LDS: 16 + 2 (keeps 16-byte alignment, spreads banks)
 constexpr int PSTR = 17;            // partial sums per output element: 16 column-sum slots + the row sum
 constexpr int VLM = DPM + 8;        // flat vectors: DPM elements + a dummy cell for threads >= DPM
+__host__ __device__ constexpr int tix(int I, int J) { return I * (I + 1) / 2 + J; }  // lower tile (I, J) of the base image
 constexpr int kInvWave = 7;         // the wave that inverts the pivot blocks: tile rows 8 and 7, with wave 3 (rows 12, 3)
                                     // the SIMD with the least tile work in a trailing sweep
 
@@ -78,6 +79,8 @@ constexpr int kOffPart = kOffX + 2 * DPM * CS;             // [DPM][PSTR]
 constexpr int kOffB = kOffPart + DPM * PSTR;               // [DPM] right-hand side of a solve-only construction: the forward
                                                            // substitution runs inside the trailing sweep, in place
 constexpr int kLdsDoubles = kOffB + DPM;
+constexpr int kOffProf = kOffScr + 6 * 64 + 8;             // developer builds: [PH_COUNT + 2] phase clocks (free part of Scr)
+static_assert(PH_COUNT + 2 <= 48, "phase clocks must fit the unused part of the Scr block");
 // Scratch of the refinement solves (implicit_core.h refine_solve) lives in the panel buffers: no sweep runs while one
 // is in flight.  The point x of metric_apply() in both operand orders, then RS_COUNT flat per-thread vectors.
 constexpr int kOffXnat = kOffX;                            // [VLM]
@@ -185,12 +188,13 @@ __device__ __forceinline__ double row_reduce16(const d4 rs, const int j) {
   return kk;
 }
 
-template <int RMETRIC>
+template <int RMETRIC, bool PROFILE = false>
 struct TeamBlk16 {
   static constexpr bool kSolveByInverse = false;
   static constexpr bool kUnifiedConstruct = true;  // implicit_core.h: one construction site, mode at run time
   static constexpr bool kCountersInLds = true;     // implicit_core.h: work counters in LDS, bumped by thread 0
   static constexpr bool kRefine = true;            // implicit_core.h: solve-only constructions refined from the held inverse
+  static constexpr bool kProf = PROFILE;           // developer builds: cycles per phase of the step (prof_switch)
   d4 acc[NSLOT];
   int wave; // wave index, wave-uniform (phases re-materialise it through opaque_wave)
   int nblk; // number of 16-pivot blocks that contain real rows: ceil(dim / 16)
@@ -206,8 +210,7 @@ struct TeamBlk16 {
     }
   } tid;
   double* lds;
-  const double* base;  // rank-one metric: base matrix zero-padded, leading dimension base_ld
-  int base_ld;
+  const double* base;  // rank-one metric: the base matrix tile by tile in lane order (mm_model::d_rmetric_tiled)
   const double* tparams;
 
   // ---- slot map (wave-uniform; see the file header).  Row class of a slot: 0 = tile row 15-w (slots 0..15-w, from
@@ -263,6 +266,20 @@ struct TeamBlk16 {
     r.n_trail = (long long)lds[kOffRed + 16 + CNT_TRAIL];
   }
   static_assert(CNT_COUNT <= 8, "work counters occupy lds[kOffRed + 16 .. 23]");
+  // developer builds: the clock since the last call goes to the phase announced then; [kOffProf + PH_COUNT] = that
+  // phase, [+ PH_COUNT + 1] = the time of the call.  Thread 0 only.
+  __device__ __forceinline__ int prof_switch(int phase) {
+    int old = 0;
+    if (tid == 0) {
+      double* P = lds + kOffProf;
+      const double now = (double)__builtin_readcyclecounter();
+      old = (int)P[PH_COUNT];
+      P[old] += now - P[PH_COUNT + 1];
+      P[PH_COUNT] = (double)phase;
+      P[PH_COUNT + 1] = now;
+    }
+    return __builtin_amdgcn_readfirstlane(old);
+  }
   __device__ __forceinline__ double& rslot(int i) { return lds[kOffRs + i * VLM + (tid < DPM ? tid : DPM)]; }
 
   // two team-uniform sums over the chain's elements in one pass (two barriers)
@@ -314,18 +331,17 @@ struct TeamBlk16 {
     const double inv_d = 1.0 / (double)dim;
     double chk = 0.0;
     if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-      // base matrix (L2-resident) + q q^T / D.  Wave-uniform tile origin (scalar base) + a 32-bit lane offset shared
-      // by all tiles: the sixty-eight loads share four offset registers.
-      const unsigned lane_off = (unsigned)(g * base_ld + j);
+      // base matrix (L2-resident) + q q^T / D.  The base matrix is stored tile by tile in lane order: a lane's four
+      // entries of a tile are one 32-byte load, a tile is 2 KB contiguous (wave-uniform tile origin + one lane offset).
+      const d4* lane_base = reinterpret_cast<const d4*>(base) + ln;
 #pragma unroll
       for (int s = 0; s < NSLOT; ++s) {
         const int I = tile_i(s, w), J = tile_j(s, w);
-        const double* tile0 = base + (unsigned)((16 * I) * base_ld + 16 * J);
+        const d4 b = lane_base[(unsigned)(tix(I, J) * 64)];
         const d4 qr = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
         const double qs = lds[kOffNat + 16 * J + j] * inv_d;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[s][r] = __builtin_fma(qr[r], qs, tile0[lane_off + (unsigned)(4 * r * base_ld)]);
+        for (int r = 0; r < 4; ++r) acc[s][r] = __builtin_fma(qr[r], qs, b[r]);
       }
     } else {
 #pragma unroll
@@ -372,17 +388,27 @@ struct TeamBlk16 {
     d4 rs[NCLASS];
 #pragma unroll
     for (int c = 0; c < NCLASS; ++c) rs[c] = d4{0.0, 0.0, 0.0, 0.0};
-    const unsigned lane_off = (unsigned)(g * base_ld + j);
+    const d4* lane_base = reinterpret_cast<const d4*>(base) + ln;
+    // the base-matrix tiles kAhead slots ahead of their use: a lone load costs an L2 round trip (~1 us x 17 when each
+    // waits for the previous slot's arithmetic)
+    constexpr int kAhead = 4;
+    d4 bq[kAhead];
+    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+#pragma unroll
+      for (int a = 0; a < kAhead; ++a) bq[a] = lane_base[(unsigned)(tix(tile_i(a, w), tile_j(a, w)) * 64)];
+    }
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
       const int I = tile_i(s, w), J = tile_j(s, w);
       const d4 qr = *reinterpret_cast<const d4*>(lds + kOffXperm + ((I * 4 + g) << 2));
       d4 m;
       if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-        const double* tile0 = base + (unsigned)((16 * I) * base_ld + 16 * J);
+        const d4 b = bq[s % kAhead];
+        if (s + kAhead < NSLOT)
+          bq[s % kAhead] = lane_base[(unsigned)(tix(tile_i(s + kAhead, w), tile_j(s + kAhead, w)) * 64)];
         const double qs = lds[kOffXnat + 16 * J + j] * inv_d;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m[r] = __builtin_fma(qr[r], qs, tile0[lane_off + (unsigned)(4 * r * base_ld)]);
+        for (int r = 0; r < 4; ++r) m[r] = __builtin_fma(qr[r], qs, b[r]);
       } else {
         m = d4{0.0, 0.0, 0.0, 0.0};
       }
@@ -407,6 +433,8 @@ struct TeamBlk16 {
         mm = sum_over_g(mm);
         part[(16 * J + j) * PSTR + I] = mm;
       }
+      // keep the prefetch distance: without it the scheduler sinks every load to just before its use
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int c = 0; c < NCLASS; ++c) {
@@ -929,8 +957,8 @@ struct TeamBlk16 {
   }
 };
 
-template <int RMETRIC>
-__device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC>& bk, const ImplicitArgs& A, int base_ld, double* lds) {
+template <int RMETRIC, bool PROFILE>
+__device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC, PROFILE>& bk, const ImplicitArgs& A, double* lds) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   __builtin_assume(wv >= 0 && wv < NWAVE);
   bk.wave = wv;
@@ -940,18 +968,21 @@ __device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC>& bk, const Impli
   bk.target = A.target;
   bk.lds = lds;
   bk.base = A.rparams;
-  bk.base_ld = base_ld;
   bk.tparams = A.tparams;
   for (int i = threadIdx.x; i < DPM * PSTR; i += NTHR) lds[kOffPart + i] = 0.0;  // unused partial-sum slots stay 0
   if (threadIdx.x < 8) lds[kOffRed + 16 + threadIdx.x] = 0.0;                     // work counters
+  if constexpr (PROFILE) {
+    if (threadIdx.x < PH_COUNT + 2)
+      lds[kOffProf + threadIdx.x] = threadIdx.x == PH_COUNT + 1 ? (double)__builtin_readcyclecounter() : 0.0;
+  }
   __syncthreads();
 }
 
-template <int RMETRIC>
-__global__ __launch_bounds__(NTHR, 2) void implicit_blk16_kernel(ImplicitArgs A, int base_ld) {
+template <int RMETRIC, bool PROFILE = false>
+__global__ __launch_bounds__(NTHR, 2) void implicit_blk16_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  TeamBlk16<RMETRIC> bk;
-  init_backend(bk, A, base_ld, lds);
+  TeamBlk16<RMETRIC, PROFILE> bk;
+  init_backend(bk, A, lds);
   const int64_t chain = blockIdx.x;
   const int tid = threadIdx.x, dim = A.dim;
   const bool act = tid < dim;
@@ -972,8 +1003,13 @@ __global__ __launch_bounds__(NTHR, 2) void implicit_blk16_kernel(ImplicitArgs A,
     A.n_done[chain] = r.done;
     add_counters(A.counters, r);
   }
+  if constexpr (PROFILE) {  // out[chain][PH_COUNT]: cycles per phase of this chain's launch
+    bk.prof_switch(PH_OTHER);
+    if (tid < PH_COUNT) A.out[chain * PH_COUNT + tid] = lds[kOffProf + tid];
+  }
 }
 
+#ifdef MM_DEV_KERNELS
 // Developer / test hook: the linear algebra of the backend on its own.  Per chain, with x = pos and b = mom:
 //   op 0: out[chain][256][256] = the explicit inverse M(x)^-1 (dense, symmetric) from the full sweep
 //   op 1: out[chain][256]      = M(x)^-1 b by the trailing sweep + substitution
@@ -982,10 +1018,10 @@ __global__ __launch_bounds__(NTHR, 2) void implicit_blk16_kernel(ImplicitArgs A,
 //        6 = mat-vec, 7 = substitution - each repeated `reps` times
 // status[chain] = 0 if the metric was found positive definite and finite, else 5.
 template <int RMETRIC>
-__global__ __launch_bounds__(NTHR, 2) void blk16_debug_kernel(ImplicitArgs A, int base_ld, int op, int reps) {
+__global__ __launch_bounds__(NTHR, 2) void blk16_debug_kernel(ImplicitArgs A, int op, int reps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   TeamBlk16<RMETRIC> bk;
-  init_backend(bk, A, base_ld, lds);
+  init_backend(bk, A, lds);
   const int64_t chain = blockIdx.x;
   const int tid = threadIdx.x, dim = A.dim;
   const bool act = tid < dim;
@@ -1018,10 +1054,10 @@ __global__ __launch_bounds__(NTHR, 2) void blk16_debug_kernel(ImplicitArgs A, in
 //   8 / 9 = per-phase cycle counts of one full / trailing sweep (summed over its blocks), per wave -> out[chain][64];
 //   10..12 = as 8 with a phase removed (sweep<>'s EXPER: results are wrong, only the clock is read)
 template <int OP>
-__global__ __launch_bounds__(NTHR, 2) void blk16_bench_kernel(ImplicitArgs A, int base_ld, int reps) {
+__global__ __launch_bounds__(NTHR, 2) void blk16_bench_kernel(ImplicitArgs A, int reps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   TeamBlk16<MM_RMETRIC_RANK1> bk;
-  init_backend(bk, A, base_ld, lds);
+  init_backend(bk, A, lds);
   const int64_t chain = blockIdx.x;
   const int tid = threadIdx.x, dim = A.dim;
   const bool act = tid < dim;
@@ -1029,7 +1065,17 @@ __global__ __launch_bounds__(NTHR, 2) void blk16_bench_kernel(ImplicitArgs A, in
   const double p = act ? A.mom[chain * dim + tid] : 0.0;
   double u = 0.0;
   bool ok = true;
-  if constexpr (OP <= 7) {
+  if constexpr (OP == 15 || OP == 16) {  // 15 = metric_apply (M(x) v matrix-free), 16 = sum2 (two team sums)
+    bk.metric_point(q);
+    for (int rep = 0; rep < reps; ++rep) {
+      if constexpr (OP == 15) u = bk.metric_apply(p + u * 1e-300);
+      else {
+        double sa, sb;
+        bk.sum2(p + u * 1e-300, q, &sa, &sb);
+        u = sa + sb;
+      }
+    }
+  } else if constexpr (OP <= 7) {
     if constexpr (OP == 6) ok = bk.construct(q, true, p, &u);
     if constexpr (OP == 7) ok = bk.construct(q, false, p, &u);
     for (int rep = 0; rep < reps; ++rep) {
@@ -1072,12 +1118,14 @@ __global__ void blk16_permlane_check_kernel(double* out) {
   out[l] = (a16 != b16 ? 1.0 : 0.0) + (a32 != b32 ? 2.0 : 0.0) + (y != z ? 4.0 : 0.0);
 }
 
+#endif  // MM_DEV_KERNELS
+
 template <class K, class... Extra>
-int launch_blk16(mm_ctx* ctx, K kernel, const ImplicitArgs& a, int base_ld, Extra... extra) {
+int launch_blk16(mm_ctx* ctx, K kernel, const ImplicitArgs& a, Extra... extra) {
   const size_t lds = kLdsDoubles * sizeof(double);
   MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)a.n_chains), dim3(NTHR), lds, ctx->stream, a, base_ld, extra...);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)a.n_chains), dim3(NTHR), lds, ctx->stream, a, extra...);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }
@@ -1087,8 +1135,8 @@ int fill_args(mm_ctx* ctx, const mm_model* m, mm_state* s, ImplicitArgs& a) {
     mm_set_error(ctx, "block-16 matrix-core team kernel supports dim <= 256");
     return MM_ERR_UNSUPPORTED;
   }
-  if (m->rmetric == MM_RMETRIC_RANK1 && (m->d_rmetric_padded == nullptr || m->rmetric_pad_dim < DPM)) {
-    mm_set_error(ctx, "internal: rank-one base matrix was not padded for the team kernels");
+  if (m->rmetric == MM_RMETRIC_RANK1 && m->d_rmetric_tiled == nullptr) {
+    mm_set_error(ctx, "internal: rank-one base matrix was not tiled for the block-16 kernel");
     return MM_ERR_UNSUPPORTED;
   }
   a.pos = s->d_pos;
@@ -1102,7 +1150,7 @@ int fill_args(mm_ctx* ctx, const mm_model* m, mm_state* s, ImplicitArgs& a) {
   a.dim = s->dim;
   a.target = m->target;
   a.tparams = m->d_target_params;
-  a.rparams = m->d_rmetric_padded;
+  a.rparams = m->d_rmetric_tiled;
   return MM_OK;
 }
 
@@ -1118,15 +1166,16 @@ int mm_launch_implicit_blk16(mm_ctx* ctx, const mm_model* m, mm_state* s, double
   a.opts = opts;
   a.counters = d_counters;
   if (m->rmetric == MM_RMETRIC_RANK1)
-    return launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_RANK1>, a, m->rmetric_pad_dim);
-  return launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_DIAGQUAD>, a, 0);
+    return launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_RANK1>, a);
+  return launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_DIAGQUAD>, a);
 }
 
+#ifdef MM_DEV_KERNELS
 // developer / test hook (tests/test_gpu_blk16.py): see blk16_debug_kernel.  out is a HOST buffer of
 // N * 256 * 256 (op 0) or N * 256 (op 1, 2) doubles; status[N] (host, may be NULL) receives 0 / 5 per chain.
 extern "C" int mm_debug_blk16_linalg(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* out,
                                      int32_t* status, int reps, double* ms) {
-  if (!ctx || !m || !s || !out || op < 0 || op > 14 || m->rmetric == MM_RMETRIC_NONE ||
+  if (!ctx || !m || !s || !out || op < 0 || op > 16 || m->rmetric == MM_RMETRIC_NONE ||
       m->rmetric == MM_RMETRIC_SOFTABS)
     return MM_ERR_INVALID;
   MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -1151,16 +1200,16 @@ extern "C" int mm_debug_blk16_linalg(mm_ctx* ctx, const mm_model* m, mm_state* s
       return MM_ERR_INVALID;
     }
     switch (op) {
-#define MM_BENCH(OP) case OP: lrc = launch_blk16(ctx, blk16_bench_kernel<OP>, a, m->rmetric_pad_dim, reps); break;
+#define MM_BENCH(OP) case OP: lrc = launch_blk16(ctx, blk16_bench_kernel<OP>, a, reps); break;
       MM_BENCH(3) MM_BENCH(4) MM_BENCH(5) MM_BENCH(6) MM_BENCH(7) MM_BENCH(8) MM_BENCH(9) MM_BENCH(10) MM_BENCH(11)
-      MM_BENCH(12) MM_BENCH(14)
+      MM_BENCH(12) MM_BENCH(14) MM_BENCH(15) MM_BENCH(16)
 #undef MM_BENCH
       default: lrc = MM_ERR_INVALID; break;
     }
   } else if (m->rmetric == MM_RMETRIC_RANK1)
-    lrc = launch_blk16(ctx, blk16_debug_kernel<MM_RMETRIC_RANK1>, a, m->rmetric_pad_dim, op, reps);
+    lrc = launch_blk16(ctx, blk16_debug_kernel<MM_RMETRIC_RANK1>, a, op, reps);
   else
-    lrc = launch_blk16(ctx, blk16_debug_kernel<MM_RMETRIC_DIAGQUAD>, a, 0, op, reps);
+    lrc = launch_blk16(ctx, blk16_debug_kernel<MM_RMETRIC_DIAGQUAD>, a, op, reps);
   (void)hipEventRecord(e1, ctx->stream);
   if (lrc == MM_OK && ms) {
     float f = 0.f;
@@ -1183,3 +1232,33 @@ extern "C" int mm_debug_blk16_linalg(mm_ctx* ctx, const mm_model* m, mm_state* s
   (void)hipFree(d_out);
   return lrc;
 }
+
+// developer hook (tools/ubench_blk16.py): mm_implicit_leapfrog on the block-16 kernel with the phase clocks on;
+// out is a HOST buffer of N * 8 doubles: cycles of chain i spent in the phases PH_* of implicit_core.h
+extern "C" int mm_debug_blk16_step_profile(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                                           const mm_fp_opts* opts, double* out) {
+  if (!ctx || !m || !s || !opts || !out || m->rmetric != MM_RMETRIC_RANK1) return MM_ERR_INVALID;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ImplicitArgs a{};
+  const int rc = fill_args(ctx, m, s, a);
+  if (rc != MM_OK) return rc;
+  a.step_size = h;
+  a.n_steps = n_steps;
+  a.opts = *opts;
+  const size_t bytes = (size_t)s->n * PH_COUNT * sizeof(double);
+  double* d_out = nullptr;
+  MM_HIP_CHECK(ctx, hipMalloc(&d_out, bytes));
+  a.out = d_out;
+  int lrc = launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_RANK1, true>, a);
+  if (lrc == MM_OK) {
+    hipError_t e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      mm_set_error(ctx, std::string("mm_debug_blk16_step_profile: ") + hipGetErrorString(e));
+      lrc = MM_ERR_HIP;
+    }
+  }
+  (void)hipFree(d_out);
+  return lrc;
+}
+#endif  // MM_DEV_KERNELS

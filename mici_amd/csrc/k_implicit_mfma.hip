@@ -561,6 +561,7 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs
 }
 
 
+#ifdef MM_DEV_KERNELS
 // ---- developer profile (not part of the ABI header; tools/ubench_primitives.py): shader-clock cycles of
 // the backend's primitives, measured in-kernel with s_memtime on every wave, chain 0 reported
 __global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs A, int repeats, double* out) {
@@ -623,6 +624,8 @@ __global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs 
   if (lane == 0) out[8 + chain] = sink;
 }
 
+#endif  // MM_DEV_KERNELS
+
 }  // namespace
 
 int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
@@ -666,6 +669,7 @@ int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
   return MM_OK;
 }
 
+#ifdef MM_DEV_KERNELS
 // developer hook: cycles of {build, sweep, mat-vec, grad, norm} into out[0..4]
 extern "C" int mm_debug_mfma_profile(mm_ctx* ctx, const mm_model* m, mm_state* s, int repeats, double* out) {
   if (!ctx || !m || !s || m->dim > 64 || m->rmetric != MM_RMETRIC_RANK1) return MM_ERR_INVALID;
@@ -689,3 +693,4 @@ extern "C" int mm_debug_mfma_profile(mm_ctx* ctx, const mm_model* m, mm_state* s
   (void)hipFree(d_out);
   return MM_OK;
 }
+#endif  // MM_DEV_KERNELS

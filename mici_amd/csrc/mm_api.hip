@@ -354,6 +354,19 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
     for (int i = 0; i < D; ++i)
       for (int j = 0; j < D; ++j) pad[(size_t)i * DP + j] = d->rmetric_params[(size_t)i * D + j];
     rc = upload(ctx, pad.data(), pad.size(), &m->d_rmetric_padded);
+    if (rc == MM_OK && D > 75 && D <= 256) {
+      // k_implicit_blk16.hip: every lane's four entries of a 16 x 16 tile are 32 consecutive bytes, a tile 2 KB
+      std::vector<double> tl((size_t)136 * 256, 0.0);
+      for (int I = 0; I < 16; ++I)
+        for (int J = 0; J <= I; ++J)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * I + 4 * r + (lane >> 4), col = 16 * J + (lane & 15);
+              if (row < D && col < D)
+                tl[((size_t)(I * (I + 1) / 2 + J) * 64 + lane) * 4 + r] = d->rmetric_params[(size_t)row * D + col];
+            }
+      rc = upload(ctx, tl.data(), tl.size(), &m->d_rmetric_tiled);
+    }
   }
   if (rc == MM_OK) rc = upload(ctx, d->metric, need_m, &m->d_metric);
   if (rc == MM_OK && d->metric_kind == MM_METRIC_DIAG) {
@@ -423,6 +436,7 @@ int mm_model_destroy(mm_model* m) {
   (void)hipFree(m->d_metric_eigvec);
   (void)hipFree(m->d_rmetric_params);
   (void)hipFree(m->d_rmetric_padded);
+  (void)hipFree(m->d_rmetric_tiled);
   (void)hipFree(m->d_constr_params);
   delete m;
   return MM_OK;

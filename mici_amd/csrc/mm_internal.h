@@ -47,6 +47,8 @@ struct mm_model {
   double* d_rmetric_params = nullptr;
   double* d_rmetric_padded = nullptr;  // rank-one base matrix zero-padded for the team kernels (dim > 32)
   int rmetric_pad_dim = 0;             // its leading dimension (mm_team_padded_dim)
+  double* d_rmetric_tiled = nullptr;   // the same matrix as the block-16 kernel's lanes read it (75 < dim <= 256):
+                                       // [lower tile I (I + 1) / 2 + J][lane 16 g + j][r] = B[16 I + 4 r + g][16 J + j]
   size_t n_rmetric_params = 0;
   double* d_constr_params = nullptr;
   size_t n_constr_params = 0;

@@ -22,8 +22,9 @@ def _dptr(a):
 class Context:
     """One HIP stream on one device.  Not thread safe; distinct contexts are independent."""
 
-    def __init__(self, device=None):
-        self._lib = _ffi.load()
+    def __init__(self, device=None, dev=False):
+        # dev=True: the developer build of the library (extra test / micro-benchmark entry points, mici_amd/build.py)
+        self._lib = _ffi.load(dev=dev)
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
         count = C.c_int(0)

@@ -33,6 +33,24 @@ def test_library_exports_every_declared_symbol():
     assert lib.mm_abi_version() == _ffi.ABI_VERSION
 
 
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({ln.split()[-1] for ln in out.splitlines() if re.search(r" T mm_[a-z0-9_]+$", ln)})
+
+
+def test_product_library_exports_exactly_the_header():
+    """`nm -D libmici_amd.so | grep mm_` equals include/mici_amd.h - the developer entry points
+    (mm_debug_*) live in libmici_amd_dev.so only, which is the product plus those."""
+    names = declared_symbols()
+    assert _exported(_ffi.lib_path()) == names
+    dev = _exported(_ffi.lib_path(dev=True))
+    assert set(names) <= set(dev)
+    extra = sorted(set(dev) - set(names))
+    assert extra and all(n.startswith("mm_debug_") for n in extra), extra
+    _ffi.load(dev=True)
+
+
 def test_struct_sizes_match_header():
     # layouts as the C compiler sees them (x86-64 SysV)
     import ctypes as C

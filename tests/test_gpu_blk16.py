@@ -14,16 +14,25 @@ from conftest import assert_close
 from oracle import models as omdl
 
 from mici_amd import _ffi, models, systems
-from mici_amd.runtime import DeviceBatch, default_context
+from mici_amd.runtime import Context, DeviceBatch
 
 pytestmark = pytest.mark.gpu
 
 
 KERNELS = ["blk16"]
+_DEV_CTX = []
+
+
+def dev_context():
+    """A context on the developer build of the library (libmici_amd_dev.so: the product plus the test hooks)."""
+    if not _DEV_CTX:
+        _DEV_CTX.append(Context(dev=True))
+    return _DEV_CTX[0]
+
 
 
 def _linalg(system, x, b, op, kernel="blk16"):
-    ctx = default_context()
+    ctx = dev_context()
     lib = ctx._lib
     fn = lib.mm_debug_blk16_linalg
     fn.restype = C.c_int

@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mici_amd import _ffi, models, systems  # noqa: E402
-from mici_amd.runtime import DeviceBatch, default_context  # noqa: E402
+from mici_amd.runtime import Context, DeviceBatch  # noqa: E402
 
 dim = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
@@ -20,7 +20,7 @@ rng = np.random.default_rng(0)
 a = rng.standard_normal((dim, dim))
 base = a @ a.T / dim + np.eye(dim)
 system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(base))
-ctx = default_context()
+ctx = Context(dev=True)
 fn = ctx._lib.mm_debug_blk16_linalg
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _ffi.c_double_p, _ffi.c_int32_p, C.c_int, _ffi.c_double_p]
@@ -28,7 +28,8 @@ batch = DeviceBatch(ctx, n, dim)
 batch.upload(rng.standard_normal((n, dim)), rng.standard_normal((n, dim)), np.ones(n, dtype=np.int8))
 out = np.zeros((n, 256))
 res = {}
-names = {3: "build", 4: "build+full_sweep", 5: "build+trailing_sweep", 6: "matvec", 7: "substitution"}
+names = {3: "build", 4: "build+full_sweep", 5: "build+trailing_sweep", 6: "matvec", 7: "substitution",
+         15: "metric_apply", 16: "sum2"}
 for op, name in names.items():
     t = {}
     for r in (0, reps):
@@ -56,4 +57,24 @@ for op, name in ((8, "full sweep"), (9, "trailing sweep"), (10, "full sweep WITH
     for w in range(8):
         print(f"  {w}    " + "  ".join(f"{prof[w, k] / nb:8.0f}" for k in range(5)) + f"   | {prof[w, 6]:10.0f}")
     res[name + " profile"] = prof.tolist()
+# phase clocks of whole steps (implicit_core.h PH_*), c4 workload: h = 0.01, 10 steps
+prof_fn = ctx._lib.mm_debug_blk16_step_profile
+prof_fn.restype = C.c_int
+prof_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.POINTER(_ffi.FpOpts), _ffi.c_double_p]
+from mici_amd import integrators  # noqa: E402
+integ = integrators.ImplicitLeapfrogIntegrator(system, 0.01)
+q0 = rng.standard_normal((n, dim))
+p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+batch.upload(q0, p0, np.ones(n, dtype=np.int8))
+nsteps = 10
+ph = np.zeros((n, 8))
+opts = integ._opts()
+_ffi.check(prof_fn(ctx.handle, system.device_model(ctx).handle, batch.handle, 0.01, nsteps, C.byref(opts),
+                   ph.ctypes.data_as(_ffi.c_double_p)), ctx.handle, "mm_debug_blk16_step_profile")
+labels = ["other", "grad", "full sweep", "trailing sweep", "M(x) v", "M0^-1 r", "reductions", "momentum solves"]
+tot = ph.sum(1).mean()
+print(f"step profile (cycle-counter ticks per leapfrog step, mean over {n} chains, {nsteps} steps): total {tot / nsteps:.0f}")
+for k, lab in enumerate(labels):
+    print(f"  {lab:16s} {ph[:, k].mean() / nsteps:10.0f}  {100 * ph[:, k].mean() / tot:5.1f} %")
+res["step_profile"] = {lab: ph[:, k].mean() / nsteps for k, lab in enumerate(labels)}
 print(json.dumps(res))

@@ -7,10 +7,10 @@ import numpy as np
 
 sys.path.insert(0, ".")
 from mici_amd import models, systems  # noqa: E402
-from mici_amd.runtime import DeviceBatch, default_context  # noqa: E402
+from mici_amd.runtime import Context, DeviceBatch  # noqa: E402
 from oracle import models as omdl  # noqa: E402
 
-ctx = default_context()
+ctx = Context(dev=True)
 lib = ctx._lib
 lib.mm_debug_primitive_bench.restype = C.c_int
 lib.mm_debug_primitive_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
