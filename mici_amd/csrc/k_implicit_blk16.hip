@@ -82,12 +82,10 @@ constexpr int kLdsDoubles = kOffB + DPM;
 constexpr int kOffProf = kOffScr + 6 * 64 + 8;             // developer builds: [PH_COUNT + 2] phase clocks (free part of Scr)
 static_assert(PH_COUNT + 2 <= 48, "phase clocks must fit the unused part of the Scr block");
 // Scratch of the refinement solves (implicit_core.h refine_solve) lives in the panel buffers: no sweep runs while one
-// is in flight.  The point x of metric_apply() in both operand orders, then RS_COUNT flat per-thread vectors.
+// is in flight.  The point x of metric_apply(), then RS_COUNT flat per-thread vectors.
 constexpr int kOffXnat = kOffX;                            // [VLM]
-constexpr int kOffXperm = kOffXnat + VLM;                  // [DPM]
-constexpr int kOffRs = kOffXperm + DPM;                    // [RS_COUNT][VLM]
+constexpr int kOffRs = kOffXnat + VLM;                     // [RS_COUNT][VLM]
 static_assert(kOffRs + RS_COUNT * VLM <= kOffPart, "refinement scratch must fit the panel buffers");
-static_assert((kOffXperm % 2) == 0, "16-byte alignment of the d4 accesses");
 static_assert((kOffVperm % 2) == 0 && (kOffScr % 2) == 0 && (kOffX % 2) == 0, "16-byte alignment of the d4 accesses");
 static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU");
 
@@ -369,87 +367,75 @@ struct TeamBlk16 {
   }
 
   // ---- M(x) v without touching the tiles (they hold -M(x0)^-1): refine_solve's matrix-free product ---------------
+  // Each metric in the form that suits it (as half_vjp_inv / dh2_dpos below do for the vector-Jacobian products):
+  //   rank-one update  M(x) v = B v + x (x . v) / D   B streamed tile by tile from L2, contracted like matvec() contracts
+  //                                                    the register tiles; the dot product rides on the same barrier
+  //   diag(1 + x^2)    M(x) v = (1 + x_i^2) v_i       per thread
   __device__ __forceinline__ void metric_point(double x) {
-    if (tid < DPM) {
-      const double xm = tid < dim ? x : 0.0;
-      lds[kOffXnat + tid] = xm;
-      lds[kOffXperm + ((((tid >> 4) << 2) + (tid & 3)) << 2) + ((tid >> 2) & 3)] = xm;
-    }
-    // visible after metric_apply()'s publish barrier
+    if (tid < DPM) lds[kOffXnat + tid] = tid < dim ? x : 0.0;  // read back by the same thread only
   }
-  // The entries of metric_func(x) are formed exactly as in build() (same loads, same arithmetic) and contracted with v
-  // like matvec() does with the tiles: every lower tile serves its own rows and, mirrored, its columns.
   __device__ __forceinline__ double metric_apply(double v) {
-    publish_vector(v);
-    const int w = opaque_wave(wave);
-    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
-    const double inv_d = 1.0 / (double)dim;
-    double* part = lds + kOffPart;
-    d4 rs[NCLASS];
+    const double x = tid < DPM ? lds[kOffXnat + tid] : 0.0;
+    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
+      return tid < dim ? __builtin_fma(x * x, v, v) : 0.0;
+    } else {
+      publish_vector(v);
+      const int w = opaque_wave(wave);
+      const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
+      double* part = lds + kOffPart;
+      {
+        const double xv = wave_sum(tid < dim ? x * v : 0.0);
+        if (ln == 0) lds[kOffRed + w] = xv;
+      }
+      d4 rs[NCLASS];
 #pragma unroll
-    for (int c = 0; c < NCLASS; ++c) rs[c] = d4{0.0, 0.0, 0.0, 0.0};
-    const d4* lane_base = reinterpret_cast<const d4*>(base) + ln;
-    // the base-matrix tiles kAhead slots ahead of their use: a lone load costs an L2 round trip (~1 us x 17 when each
-    // waits for the previous slot's arithmetic)
-    constexpr int kAhead = 4;
-    d4 bq[kAhead];
-    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+      for (int c = 0; c < NCLASS; ++c) rs[c] = d4{0.0, 0.0, 0.0, 0.0};
+      const d4* lane_base = reinterpret_cast<const d4*>(base) + ln;
+      // the base-matrix tiles kAhead slots ahead of their use: a lone load costs an L2 round trip (~1 us x 17 when each
+      // waits for the previous slot's arithmetic)
+      constexpr int kAhead = 4;
+      d4 bq[kAhead];
 #pragma unroll
       for (int a = 0; a < kAhead; ++a) bq[a] = lane_base[(unsigned)(tix(tile_i(a, w), tile_j(a, w)) * 64)];
-    }
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-      const int I = tile_i(s, w), J = tile_j(s, w);
-      const d4 qr = *reinterpret_cast<const d4*>(lds + kOffXperm + ((I * 4 + g) << 2));
-      d4 m;
-      if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-        const d4 b = bq[s % kAhead];
+      for (int s = 0; s < NSLOT; ++s) {
+        const int I = tile_i(s, w), J = tile_j(s, w);
+        const d4 m = bq[s % kAhead];
         if (s + kAhead < NSLOT)
           bq[s % kAhead] = lane_base[(unsigned)(tix(tile_i(s + kAhead, w), tile_j(s + kAhead, w)) * 64)];
-        const double qs = lds[kOffXnat + 16 * J + j] * inv_d;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m[r] = __builtin_fma(qr[r], qs, b[r]);
-      } else {
-        m = d4{0.0, 0.0, 0.0, 0.0};
-      }
-      if (is_diag_slot(s)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool on_diag = (j == 4 * r + g);
-          if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
-            if (on_diag) m[r] = __builtin_fma(qr[r], qr[r], 1.0);
-          }
-          if (on_diag && 16 * I + 4 * r + g >= dim) m[r] = 1.0;
+        const double vc = lds[kOffNat + 16 * J + j];
+        add_row(s, w, rs, m, vc);
+        if (!is_diag_slot(s)) {
+          const d4 vr = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
+          double mm = m[0] * vr[0];
+          mm = __builtin_fma(m[1], vr[1], mm);
+          mm = __builtin_fma(m[2], vr[2], mm);
+          mm = __builtin_fma(m[3], vr[3], mm);
+          mm = sum_over_g(mm);
+          part[(16 * J + j) * PSTR + I] = mm;
         }
+        // keep the prefetch distance: without it the scheduler sinks every load to just before its use
+        __builtin_amdgcn_sched_barrier(0);
       }
-      const double vc = lds[kOffNat + 16 * J + j];
-      add_row(s, w, rs, m, vc);
-      if (!is_diag_slot(s)) {
-        const d4 vr = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
-        double mm = m[0] * vr[0];
-        mm = __builtin_fma(m[1], vr[1], mm);
-        mm = __builtin_fma(m[2], vr[2], mm);
-        mm = __builtin_fma(m[3], vr[3], mm);
-        mm = sum_over_g(mm);
-        part[(16 * J + j) * PSTR + I] = mm;
+#pragma unroll
+      for (int c = 0; c < NCLASS; ++c) {
+        const double k = row_reduce16(rs[c], j);
+        part[(16 * row_of_class(c, w) + 4 * (j >> 2) + g) * PSTR + 16] = k;
       }
-      // keep the prefetch distance: without it the scheduler sinks every load to just before its use
-      __builtin_amdgcn_sched_barrier(0);
-    }
+      __syncthreads();
+      double y = 0.0;
+      if (tid < DPM) {
+        const double* src = lds + kOffPart + tid * PSTR;
 #pragma unroll
-    for (int c = 0; c < NCLASS; ++c) {
-      const double k = row_reduce16(rs[c], j);
-      part[(16 * row_of_class(c, w) + 4 * (j >> 2) + g) * PSTR + 16] = k;
-    }
-    __syncthreads();
-    double y = 0.0;
-    if (tid < DPM) {
-      const double* src = lds + kOffPart + tid * PSTR;
+        for (int k = 0; k < PSTR; ++k) y += src[k];
+        double dot = lds[kOffRed];
 #pragma unroll
-      for (int k = 0; k < PSTR; ++k) y += src[k];
+        for (int k = 1; k < NWAVE; ++k) dot += lds[kOffRed + k];
+        y = __builtin_fma(x, dot / (double)dim, y);
+      }
+      __syncthreads();
+      return tid < dim ? y : 0.0;
     }
-    __syncthreads();
-    return tid < dim ? y : 0.0;
   }
 
   // B operands of column tile J: bx[kk] = X[4 kk + g][16 J + j] (the panel is published as Q - E already)

@@ -43,8 +43,8 @@ constexpr int kPartStride = 17;
 // per-wave LDS (doubles): Qt[64][4], Wt[64][4], nat[64], vperm[64], aux[64], part[64][17], mpart[3][64],
 // stash[SL_COUNT_REFINE][64].  The refinement solves (implicit_core.h refine_solve) keep their scratch in Qt / Wt: no
 // sweep runs while one is in flight.
-constexpr int kMfmaWaveDoubles = 256 + 256 + 64 + 64 + 64 + 64 * kPartStride + 192 + SL_COUNT_REFINE * 64;
-static_assert((2 + RS_COUNT) * 64 <= 512, "refinement scratch must fit Qt + Wt");
+constexpr int kMfmaWaveDoubles = 256 + 256 + 64 + 64 + 64 + 64 * kPartStride + 192 + SL_COUNT_REFINE * 64 + 16;
+static_assert((1 + RS_COUNT) * 64 <= 512, "refinement scratch must fit Qt + Wt");
 constexpr int kBaseDoubles = kTiles * 4 * 64;  // staged base matrix of the rank-one metric
 
 __host__ __device__ constexpr int tix(int I, int J) { return I * (I + 1) / 2 + J; }
@@ -58,10 +58,23 @@ struct MLds {
   double* part;   // [64][17] direct partial sums of the mat-vec
   double* mpart;  // [3][4][16] mirrored partial sums
   double* stash;  // [SL_COUNT_REFINE][64]
+  double* prof;   // [16] developer builds: phase clocks (implicit_core.h PH_*)
 };
 
-template <int RMETRIC>
+template <int RMETRIC, bool PROFILE = false>
 struct MfmaBackend {
+  static constexpr bool kProf = PROFILE;  // developer builds: cycles per phase of the step
+  __device__ __forceinline__ int prof_switch(int phase) {
+    int old = 0;
+    if (lane == 0) {
+      const double now = (double)__builtin_readcyclecounter();
+      old = (int)w.prof[PH_COUNT];
+      w.prof[old] += now - w.prof[PH_COUNT + 1];
+      w.prof[PH_COUNT] = (double)phase;
+      w.prof[PH_COUNT + 1] = now;
+    }
+    return __builtin_amdgcn_readfirstlane(old);
+  }
   static constexpr bool kSolveByInverse = false;
   static constexpr bool kUnifiedConstruct = true;  // implicit_core.h: one construction site, the mode at run time
   static constexpr bool kCountersInLds = false;
@@ -130,86 +143,69 @@ struct MfmaBackend {
   }
 
   // ---- refinement solves (implicit_core.h): M(x) v formed matrix-free, the tiles keep M(x0)^-1 ---------------------
-  // scratch in Qt / Wt: [0] x natural order, [1] x as [I][g][r], [2 ..] the solve's flat vectors
-  __device__ __forceinline__ double& rslot(int i) { return w.qt[(2 + i) * 64 + lane]; }
+  // scratch in Qt / Wt: [0] the point x, [1 ..] the solve's flat vectors
+  __device__ __forceinline__ double& rslot(int i) { return w.qt[(1 + i) * 64 + lane]; }
   __device__ __forceinline__ void sum2(double a, double b, double* sa, double* sb) {
     *sa = wave_sum(lane < dim ? a : 0.0);
     *sb = wave_sum(lane < dim ? b : 0.0);
   }
-  __device__ __forceinline__ void metric_point(double x) {
-    const double xm = (lane < dim) ? x : 0.0;
-    w.qt[lane] = xm;
-    w.qt[64 + (((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = xm;
-    wave_sync();
-  }
-  // entries exactly as build() forms them, contracted with v like matvec() contracts the tiles
+  // M(x) v in the form that suits the metric:  rank-one update  B v + x (x . v) / D  (B's tiles from LDS, contracted
+  // like matvec() contracts the register tiles);  diag(1 + x^2): per lane
+  __device__ __forceinline__ void metric_point(double x) { w.qt[lane] = (lane < dim) ? x : 0.0; }
   __device__ __forceinline__ double metric_apply(double v) {
-    const int g = lane >> 4, j = lane & 15;
-    w.nat[lane] = (lane < dim) ? v : 0.0;
-    w.vperm[(((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = (lane < dim) ? v : 0.0;
-    wave_sync();
-    const double inv_d = 1.0 / (double)dim;
-    double vc[4], qc[4];
-    d4 vr[4], qr[4];
+    const double x = w.qt[lane];
+    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
+      return lane < dim ? __builtin_fma(x * x, v, v) : 0.0;
+    } else {
+      const int g = lane >> 4, j = lane & 15;
+      w.nat[lane] = (lane < dim) ? v : 0.0;
+      w.vperm[(((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = (lane < dim) ? v : 0.0;
+      wave_sync();
+      double vc[4];
+      d4 vr[4];
 #pragma unroll
-    for (int X = 0; X < 4; ++X) {
-      vc[X] = w.nat[16 * X + j];
-      vr[X] = *reinterpret_cast<const d4*>(w.vperm + ((X * 4 + g) << 2));
-      qc[X] = w.qt[16 * X + j] * inv_d;
-      qr[X] = *reinterpret_cast<const d4*>(w.qt + 64 + ((X * 4 + g) << 2));
-    }
-    double mir[3] = {0.0, 0.0, 0.0};
+      for (int X = 0; X < 4; ++X) {
+        vc[X] = w.nat[16 * X + j];
+        vr[X] = *reinterpret_cast<const d4*>(w.vperm + ((X * 4 + g) << 2));
+      }
+      double mir[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int I = 0; I < 4; ++I) {
-      d4 s = d4{0.0, 0.0, 0.0, 0.0};
+      for (int I = 0; I < 4; ++I) {
+        d4 s = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int J = 0; J <= I; ++J) {
-        const int t = tix(I, J);
-        d4 m;
-        if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+        for (int J = 0; J <= I; ++J) {
+          const int t = tix(I, J);
           const d2 b01 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 0) * 64 + lane) * 2);
           const d2 b23 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 1) * 64 + lane) * 2);
-          m[0] = __builtin_fma(qr[I][0], qc[J], b01[0]);
-          m[1] = __builtin_fma(qr[I][1], qc[J], b01[1]);
-          m[2] = __builtin_fma(qr[I][2], qc[J], b23[0]);
-          m[3] = __builtin_fma(qr[I][3], qc[J], b23[1]);
-        } else {
-          m = d4{0.0, 0.0, 0.0, 0.0};
-        }
-        if (I == J) {
+          const d4 m = d4{b01[0], b01[1], b23[0], b23[1]};  // zero on the padding, where v is zero too
+          if (I != J) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool on_diag = (j == 4 * r + g);
-            if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
-              if (on_diag) m[r] = __builtin_fma(qr[I][r], qr[I][r], 1.0);
-            }
-            if (on_diag && 16 * I + 4 * r + g >= dim) m[r] = 1.0;
+            for (int r = 0; r < 4; ++r) mir[J] = __builtin_fma(m[r], vr[I][r], mir[J]);
           }
-        } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mir[J] = __builtin_fma(m[r], vr[I][r], mir[J]);
+          for (int r = 0; r < 4; ++r) s[r] = __builtin_fma(m[r], vc[J], s[r]);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[r] = __builtin_fma(m[r], vc[J], s[r]);
+        for (int r = 0; r < 4; ++r) w.part[(16 * I + 4 * r + g) * kPartStride + j] = s[r];
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) w.part[(16 * I + 4 * r + g) * kPartStride + j] = s[r];
-    }
+      for (int J = 0; J < 3; ++J) w.mpart[(J * 4 + g) * 16 + j] = mir[J];
+      const double dot = wave_sum(lane < dim ? x * v : 0.0);
+      wave_sync();
+      double y = 0.0;
+      {
+        const double* src = w.part + lane * kPartStride;
 #pragma unroll
-    for (int J = 0; J < 3; ++J) w.mpart[(J * 4 + g) * 16 + j] = mir[J];
-    wave_sync();
-    double y = 0.0;
-    {
-      const double* src = w.part + lane * kPartStride;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) y += src[k];
-      if (lane < 48) {
-        const double* mp = w.mpart + (lane >> 4) * 64 + (lane & 15);
-        y += (mp[0] + mp[16]) + (mp[32] + mp[48]);
+        for (int k = 0; k < 16; ++k) y += src[k];
+        if (lane < 48) {
+          const double* mp = w.mpart + (lane >> 4) * 64 + (lane & 15);
+          y += (mp[0] + mp[16]) + (mp[32] + mp[48]);
+        }
+        y = __builtin_fma(x, dot / (double)dim, y);
       }
+      wave_sync();
+      return lane < dim ? y : 0.0;
     }
-    wave_sync();
-    return lane < dim ? y : 0.0;
   }
 
   // operands of one block's rank-4 update.  They stay in registers after the block so that the six
@@ -503,7 +499,7 @@ struct MfmaBackend {
   }
 };
 
-template <int RMETRIC>
+template <int RMETRIC, bool PROFILE = false>
 __global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* base_lds = lds;
@@ -530,7 +526,7 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs
   double p = act ? A.mom[chain * dim + lane] : 0.0;
   const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
 
-  MfmaBackend<RMETRIC> bk;
+  MfmaBackend<RMETRIC, PROFILE> bk;
   bk.dim = dim;
   bk.lane = lane;
   bk.target = A.target;
@@ -542,8 +538,13 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs
   bk.w.part = wl + 704;
   bk.w.mpart = bk.w.part + 64 * kPartStride;
   bk.w.stash = bk.w.mpart + 192;
+  bk.w.prof = bk.w.stash + SL_COUNT_REFINE * 64;
   bk.base_lds = base_lds;
   bk.tparams = A.tparams;
+  if constexpr (PROFILE) {
+    if (lane < PH_COUNT + 2) bk.w.prof[lane] = lane == PH_COUNT + 1 ? (double)__builtin_readcyclecounter() : 0.0;
+    wave_sync();
+  }
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
   const ChainResult r = implicit_leapfrog_chain(bk, t, mmdev::chain_steps(A.chain_steps, chain, A.n_steps), A.opts);
@@ -557,6 +558,11 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs
     A.status[chain] = r.status;
     A.n_done[chain] = r.done;
     add_counters(A.counters, r);
+  }
+  if constexpr (PROFILE) {  // out[chain][PH_COUNT]: cycles per phase of this chain's launch
+    bk.prof_switch(PH_OTHER);
+    wave_sync();
+    if (lane < PH_COUNT) A.out[chain * PH_COUNT + lane] = bk.w.prof[lane];
   }
 }
 
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs 
   bk.tparams = A.tparams;
   double q = lane < dim ? A.pos[chain * dim + lane] : 0.0;
   double p = lane < dim ? A.mom[chain * dim + lane] : 0.0;
-  long long c[5] = {0, 0, 0, 0, 0};
+  long long c[6] = {0, 0, 0, 0, 0, 0};
   double sink = 0.0;
   for (int r = 0; r < repeats; ++r) {
     const long long t0 = __builtin_readcyclecounter();
@@ -611,6 +617,11 @@ __global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs 
     const long long t4 = __builtin_readcyclecounter();
     const double nn = bk.norm(u, MM_NORM_LINF);
     const long long t5 = __builtin_readcyclecounter();
+    bk.metric_point(q);
+    const double mv = bk.metric_apply(p);
+    const long long t6 = __builtin_readcyclecounter();
+    c[5] += t6 - t5;
+    sink += mv;
     c[0] += t1 - t0;
     c[1] += t2 - t1;
     c[2] += t3 - t2;
@@ -620,7 +631,7 @@ __global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs 
     q += 1e-12 * sink;
   }
   if (chain == 0 && lane == 0)
-    for (int i = 0; i < 5; ++i) out[i] = (double)c[i] / repeats;
+    for (int i = 0; i < 6; ++i) out[i] = (double)c[i] / repeats;
   if (lane == 0) out[8 + chain] = sink;
 }
 
@@ -670,7 +681,7 @@ int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
 }
 
 #ifdef MM_DEV_KERNELS
-// developer hook: cycles of {build, sweep, mat-vec, grad, norm} into out[0..4]
+// developer hook: cycles of {build, sweep, mat-vec, grad, norm, M(x) v} into out[0..5]
 extern "C" int mm_debug_mfma_profile(mm_ctx* ctx, const mm_model* m, mm_state* s, int repeats, double* out) {
   if (!ctx || !m || !s || m->dim > 64 || m->rmetric != MM_RMETRIC_RANK1) return MM_ERR_INVALID;
   ImplicitArgs a{};
@@ -688,9 +699,52 @@ extern "C" int mm_debug_mfma_profile(mm_ctx* ctx, const mm_model* m, mm_state* s
   MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_profile_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(mfma_profile_kernel, dim3(blocks), dim3(64 * kWaves), lds, ctx->stream, a, repeats, d_out);
-  MM_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   (void)hipFree(d_out);
+  return MM_OK;
+}
+
+// developer hook (tools/ubench_primitives.py): mm_implicit_leapfrog on this kernel with the phase clocks on; out is a
+// HOST buffer of N * 8 doubles: cycles of chain i spent in the phases PH_* of implicit_core.h
+extern "C" int mm_debug_mfma_step_profile(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                                          const mm_fp_opts* opts, double* out) {
+  if (!ctx || !m || !s || !opts || !out || m->dim > 64 || m->rmetric != MM_RMETRIC_RANK1) return MM_ERR_INVALID;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ImplicitArgs a{};
+  a.pos = s->d_pos;
+  a.mom = s->d_mom;
+  a.dir = s->d_dir;
+  a.step_scale = s->d_step_scale;
+  a.chain_steps = s->d_chain_steps;
+  a.status = s->d_status;
+  a.n_done = s->d_n_done;
+  a.n_chains = s->n;
+  a.dim = s->dim;
+  a.target = m->target;
+  a.tparams = m->d_target_params;
+  a.rparams = m->d_rmetric_params;
+  a.step_size = h;
+  a.n_steps = n_steps;
+  a.opts = *opts;
+  const size_t bytes = (size_t)s->n * PH_COUNT * sizeof(double);
+  double* d_out = nullptr;
+  MM_HIP_CHECK(ctx, hipMalloc(&d_out, bytes));
+  a.out = d_out;
+  const unsigned blocks = (unsigned)((s->n + kWaves - 1) / kWaves);
+  const size_t lds = (kBaseDoubles + kWaves * kMfmaWaveDoubles) * sizeof(double);
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(implicit_mfma_kernel<MM_RMETRIC_RANK1, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((implicit_mfma_kernel<MM_RMETRIC_RANK1, true>), dim3(blocks), dim3(64 * kWaves), lds, ctx->stream,
+                     a);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) {
+    mm_set_error(ctx, std::string("mm_debug_mfma_step_profile: ") + hipGetErrorString(e));
+    return MM_ERR_HIP;
+  }
   return MM_OK;
 }
 #endif  // MM_DEV_KERNELS

@@ -42,6 +42,27 @@ for n in (256, 1024, 4096):
     rc = lib.mm_debug_mfma_profile(ctx.handle, model.handle, batch.handle, 50, out)
     assert rc == 0, rc
     print(f"mfma backend N={n:5d}: build {out[0]:7.0f}  sweep {out[1]:7.0f}  matvec {out[2]:7.0f}  "
-          f"grad {out[3]:7.0f}  norm {out[4]:7.0f}  cycles")
+          f"grad {out[3]:7.0f}  norm {out[4]:7.0f}  M(x)v {out[5]:7.0f}  cycles")
     batch.close()
+
+# phase clocks of whole steps (implicit_core.h PH_*), c3 workload: h = 0.02, 20 steps, 1024 chains
+from mici_amd import _ffi, integrators  # noqa: E402
+prof_fn = lib.mm_debug_mfma_step_profile
+prof_fn.restype = C.c_int
+prof_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.POINTER(_ffi.FpOpts), _ffi.c_double_p]
+integ = integrators.ImplicitLeapfrogIntegrator(system, 0.02)
+n, nsteps = 1024, 20
+q0 = rng.standard_normal((n, dim))
+p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+batch = DeviceBatch(ctx, n, dim)
+batch.upload(q0, p0, np.ones(n, dtype=np.int8))
+ph = np.zeros((n, 8))
+opts = integ._opts()
+_ffi.check(prof_fn(ctx.handle, model.handle, batch.handle, 0.02, nsteps, C.byref(opts),
+                   ph.ctypes.data_as(_ffi.c_double_p)), ctx.handle, "mm_debug_mfma_step_profile")
+labels = ["other", "grad", "full sweep", "trailing sweep", "M(x) v", "M0^-1 r", "reductions", "momentum solves"]
+tot = ph.sum(1).mean()
+print(f"step profile (cycle-counter ticks per leapfrog step, mean over {n} chains, {nsteps} steps): total {tot / nsteps:.0f}")
+for k, lab in enumerate(labels):
+    print(f"  {lab:16s} {ph[:, k].mean() / nsteps:10.0f}  {100 * ph[:, k].mean() / tot:5.1f} %")
 
