@@ -89,12 +89,16 @@ def _oracle_momenta(kind, osys, q0, z):
     return _OracleMomenta(kind, osys, q0, z)
 
 
-def make_workload(config, n_chains, rng, device=True):
+def make_workload(config, n_chains, rng, device=True, chain_rng=None):
     """Synthetic inputs of SURVEY.md section 8d.  Returns dict with the device system, integrator, initial
-    state and the algorithmic work per chain-step.  The oracle twin (`make_oracle`) is only constructed by the
+    state and the algorithmic work per chain-step.  `rng` draws the MODEL (precision / base matrices: the same on
+    every rank - DESIGN section 6, model parameters are replicated) and, unless `chain_rng` is given, the chains'
+    initial states after it; ranks > 0 pass their own `chain_rng`.  The oracle twin (`make_oracle`) is only constructed by the
     cpu_baseline leg (`device=False`: its own interpreter, initial momenta through the oracle, no device objects
     touched): nothing under oracle/ is imported on the measured path."""
     from mici_amd import integrators, models, systems
+
+    crng = chain_rng if chain_rng is not None else rng  # drawn from AFTER the model, as rank 0 always did
 
     if config in ("c2", "c2i", "c2iv", "c2bcss"):
         dim, h, traj = 128, 0.05, 1000
@@ -125,8 +129,8 @@ def make_workload(config, n_chains, rng, device=True):
         else:
             integ = integrators.LeapfrogIntegrator(system, h)
             iname = "LeapfrogIntegrator"
-        q0 = rng.standard_normal((n_chains, dim))
-        z = rng.standard_normal((n_chains, dim))
+        q0 = crng.standard_normal((n_chains, dim))
+        z = crng.standard_normal((n_chains, dim))
         p0 = z if metric is None else z @ np.linalg.cholesky(metric).T
         return dict(name=f"{name}, EuclideanMetricSystem + {iname}", dim=dim, h=h,
                     coefficients=getattr(integ, "coefficients", None),
@@ -144,8 +148,8 @@ def make_workload(config, n_chains, rng, device=True):
             return orc.RiemannianSystem(omdl.Banana(dim), omdl.Rank1Metric(base))
 
         integ = integrators.ImplicitLeapfrogIntegrator(system, h)
-        q0 = rng.standard_normal((n_chains, dim))
-        z = rng.standard_normal((n_chains, dim))
+        q0 = crng.standard_normal((n_chains, dim))
+        z = crng.standard_normal((n_chains, dim))
         p0 = system.sample_momentum_batch(q0, z) if device else _oracle_momenta("riemann", make_oracle(), q0, z)
         mom = None if device else p0
         p0 = p0 if device else mom.p0
@@ -164,8 +168,8 @@ def make_workload(config, n_chains, rng, device=True):
             return orc.RiemannianSystem(omdl.Funnel(wts), None, 1.0)
 
         integ = integrators.ImplicitLeapfrogIntegrator(system, h)
-        q0 = rng.standard_normal((n_chains, dim))
-        z = rng.standard_normal((n_chains, dim))
+        q0 = crng.standard_normal((n_chains, dim))
+        z = crng.standard_normal((n_chains, dim))
         p0 = system.sample_momentum_batch(q0, z) if device else _oracle_momenta("softabs", make_oracle(), q0, z)
         mom = None if device else p0
         p0 = p0 if device else mom.p0
@@ -183,8 +187,8 @@ def make_workload(config, n_chains, rng, device=True):
             return orc.ConstrainedSystem(omdl.Torus(), omdl.TorusConstr())
 
         integ = integrators.ConstrainedLeapfrogIntegrator(system, h)
-        q0 = _torus_init(n_chains, rng)
-        z = rng.standard_normal((n_chains, dim))
+        q0 = _torus_init(n_chains, crng)
+        z = crng.standard_normal((n_chains, dim))
         p0 = system.sample_momentum_batch(q0, z) if device else _oracle_momenta("constrained", make_oracle(), q0, z)
         mom = None if device else p0
         p0 = p0 if device else mom.p0
@@ -194,6 +198,19 @@ def make_workload(config, n_chains, rng, device=True):
                     flops_per_chain_step=1500.0, bound="hbm", kind="constrained")
     raise SystemExit(f"unknown --config {config}")
 
+
+
+def _sweep_mfma_counts(dim):
+    """v_mfma_f64_16x16x4 instructions per metric factorisation of the dense-Riemannian kernels (full sweep = explicit
+    inverse, solve = trailing LDL^T sweep), counted from the kernel sources; None for the VALU kernels."""
+    if 32 < dim <= 64:      # k_implicit_mfma.hip: 16 blocks of 4 pivots, 10 lower tiles; trailing: tiles with J >= I0
+        return dict(full=160, solve=4 * (10 + 6 + 3 + 1), padded_dim=64)
+    if 75 < dim <= 256:     # k_implicit_blk16.hip: per 16-pivot block 4 MFMAs per updated tile + 64 (-W) + 4 (pivot block)
+        nblk = (dim + 15) // 16
+        full = nblk * (136 * 4 + 64 + 4)
+        solve = sum((16 - b) * (17 - b) // 2 * 4 + 64 + 4 for b in range(nblk))
+        return dict(full=full, solve=solve, padded_dim=256)
+    return None
 
 
 DEFAULT_CHAINS = {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048}  # per GPU; everything else 4096
@@ -373,8 +390,10 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
     from mici_amd.runtime import DeviceBatch
 
     n_local = chains_per_gpu or DEFAULT_CHAINS.get(config, 4096)
-    rng = np.random.default_rng(1234 + rank)
-    w = make_workload(config, n_local, rng)
+    # the model from a rank-independent stream (every rank integrates the SAME target / metric); the chains' initial
+    # states from the rank's own stream (rank 0: the continuation of the model stream, as in rounds 1-2)
+    rng = np.random.default_rng(1234)
+    w = make_workload(config, n_local, rng, chain_rng=None if rank == 0 else np.random.default_rng([1234, rank]))
     traj = traj_len or w["traj"]
     integ = w["integ"]
     batch = DeviceBatch(ctx, n_local, w["dim"])
@@ -461,8 +480,10 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
         kernel_ms = ctx.elapsed_ms(0, 1)  # K launches back to back
     done_local = float(n_local) * traj * steps if w["kind"] == "euclid" else done_acc
     total_steps = done_local
+    rank_elapsed = [elapsed]
     if rdzv is not None:
-        elapsed = rdzv.reduce_max(elapsed)
+        rank_elapsed = [float(x) for x in rdzv.allgather(repr(elapsed).encode())]
+        elapsed = max(rank_elapsed)  # == rdzv.reduce_max(elapsed): the slowest rank's clock prices the job
         total_steps = rdzv.reduce_sum(done_local)
 
     # The job's one collective, timed on its own AFTER the timed region (communicator creation included in
@@ -516,6 +537,21 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
         w["flops_per_chain_step"] = (n_m * d**3 / 3 + done_local * 2 * d**3 / 3 + (2 * n_m + 3 * n_b) * d * d) \
             / max(done_local, 1.0)
         chain_steps_per_launch = done_local / steps
+        # What the device EXECUTED for those constructions (round 3: the solve-only ones are refined from the explicit
+        # inverse at the step's start instead of being factorised, implicit_core.h): matrix-core flops of the sweeps
+        # that ran, from the kernels' MFMA counts (v_mfma_f64_16x16x4 = 2048 flop), and the vector flops of the
+        # refinement's product pairs and of the inverse mat-vecs.
+        mf = _sweep_mfma_counts(int(d))
+        if mf is not None:
+            mfma_flops = 2048.0 * (counters_acc.get("n_factor_full", 0) * mf["full"]
+                                   + counters_acc.get("n_factor_solve", 0) * mf["solve"])
+            dp = float(mf["padded_dim"])
+            valu_flops = (4.0 * counters_acc.get("n_refine", 0) + 2.0 * n_b + 6.0 * done_local) * dp * dp
+            w["executed"] = dict(mfma_flops_per_chain_step=mfma_flops / max(done_local, 1.0),
+                                 valu_flops_per_chain_step=valu_flops / max(done_local, 1.0),
+                                 refine_pairs_per_chain_step=counters_acc.get("n_refine", 0) / max(done_local, 1.0),
+                                 sweeps_per_chain_step=(counters_acc.get("n_factor_full", 0)
+                                                        + counters_acc.get("n_factor_solve", 0)) / max(done_local, 1.0))
     if w["bound"] == "mfma":
         achieved = w["flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
         roof = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
@@ -532,13 +568,22 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE /
     # WRITE_SIZE cannot be read from inside the process); null when this shape was not profiled
     default_shape = chains_per_gpu is None and traj_len is None
-    for pmc_name in (f"r02_{config}_pmc_hbm.json", "r01_c2_pmc_hbm.json" if config == "c2" else f"r01b_{config}_pmc_hbm.json"):
+    for pmc_name in (f"r03_{config}_pmc_hbm.json", f"r02_{config}_pmc_hbm.json"):
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if default_shape and os.path.exists(pmc):
             with open(pmc) as fh:
                 roof["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
             roof["traffic_source"] = f"profiles/{pmc_name} (rocprofv3 --pmc, corrected)"
             break
+    if w.get("executed"):
+        ex = w["executed"]
+        per_launch = chain_steps_per_launch / launch_s / 1e12
+        roof["mfma_executed_flops"] = ex["mfma_flops_per_chain_step"] * chain_steps_per_launch  # per launch
+        roof["mfma_busy"] = ex["mfma_flops_per_chain_step"] * per_launch / FP64_MFMA_PEAK_TF  # executed MFMA rate / peak
+        roof["executed"] = dict(ex, achieved_tflops=(ex["mfma_flops_per_chain_step"] + ex["valu_flops_per_chain_step"])
+                                * per_launch,
+                                note="flops the kernels executed; `achieved` / `frac` price the SURVEY 8d algorithmic "
+                                     "count (one factorisation per metric construction) as the contract asks")
     roof["kernel_ms_per_launch"] = kernel_ms / steps
     roof["algorithmic_flops_per_chain_step"] = w["flops_per_chain_step"]
     roof["algorithmic_bytes_per_chain_step"] = w["bytes_per_chain_step"] / (traj if w["bound"] == "hbm" else 1)
@@ -551,6 +596,7 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
     return dict(
         value=total_steps / elapsed, unit="leapfrog-steps/s", steps=steps, warmup=warmup,
         ms_per_step=elapsed / steps * 1e3, roofline=roof,
+        rank_elapsed_s=dict(min=min(rank_elapsed), max=max(rank_elapsed), per_rank=rank_elapsed),
         workload=f"{w['name']}, D={w['dim']}, {n_local} chains/GPU x {world} GPU, h={w['h']}, one pass = a trajectory "
                  f"of {traj} leapfrog steps per chain",
         baseline_config=BASELINE_CONFIG.get(config, config), chains_per_gpu=n_local, dim=w["dim"], traj_len=traj,
@@ -666,6 +712,8 @@ def main():
                 "trace_gather_ms": head["trace_gather_ms"],
             },
             "roofline": head["roofline"],
+            # wall clock of the timed region on every rank (value uses the max): a straggler shows up here
+            "rank_elapsed_s": head["rank_elapsed_s"],
         }
         if "cpu_baseline" in head:
             out["cpu_baseline"] = head["cpu_baseline"]

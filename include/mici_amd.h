@@ -227,6 +227,13 @@ int mm_state_set_step_scale(mm_state* state, const double* scale);
  * (transitions.py:355-402). */
 int mm_state_set_chain_steps(mm_state* s, const int32_t* steps);
 
+/* Sticky per-chain error word of device-resident transitions (mm_metropolis_accept / _rng): bit k of errors[i] is set
+ * when a proposal of chain i ended with status k (1..5, section "status codes") since the word was last cleared.  The
+ * reference raises LinAlgError out of the sampler for status 5 (transitions.py:292-295 catches IntegratorError only) and
+ * records the others as rejections; a transition that downloads nothing per step (stats off) reads this at its next
+ * synchronisation point instead.  errors: host [N]; clear != 0 resets the word after reading. */
+int mm_state_download_errors(mm_state* s, uint32_t* errors, int32_t clear);
+
 /* device-to-device copy of pos, mom, dir, status, n_done (same n_chains and dim): the proposal copy of
  * Integrator.step / state.copy() (integrators.py:78, states.py:263-279) without a host round trip */
 int mm_state_copy(mm_state* dst, const mm_state* src);

@@ -519,11 +519,12 @@ __global__ void metropolis_select_kernel(double* __restrict__ pos, double* __res
                                          const int32_t* __restrict__ pn_done, const double* __restrict__ h0,
                                          const double* __restrict__ h1, const double* __restrict__ u,
                                          double* __restrict__ accept_prob, int8_t* __restrict__ accepted,
-                                         int64_t n_chains, int dim) {
+                                         uint32_t* __restrict__ errors, int64_t n_chains, int dim) {
   const int lane = threadIdx.x & 63;
   const int64_t chain = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (chain >= n_chains) return;
-  const bool error = pstatus[chain] != 0;
+  const int pst = pstatus[chain];
+  const bool error = pst != 0;
   const bool moved = pn_done[chain] > 0;
   const double h_diff = h0[chain] - h1[chain];
   double prob = 0.0;
@@ -539,6 +540,9 @@ __global__ void metropolis_select_kernel(double* __restrict__ pos, double* __res
     if (!acc) dir[chain] = (int8_t)(-dir[chain]);
     accept_prob[chain] = prob;
     accepted[chain] = acc ? 1 : 0;
+    // the proposal's status is overwritten by the next transition's copy: keep what went wrong with the CHAIN
+    // (bit k = some proposal ended with status k; read and cleared by mm_state_download_errors)
+    if (error) errors[chain] |= 1u << (pst & 31);
   }
 }
 
@@ -548,7 +552,7 @@ int mm_launch_metropolis_select(mm_ctx* ctx, mm_state* s, mm_state* prop, const 
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
   hipLaunchKernelGGL(metropolis_select_kernel, dim3(blocks), dim3(64 * w), 0, ctx->stream, s->d_pos, s->d_mom,
                      s->d_dir, prop->d_pos, prop->d_mom, prop->d_status, prop->d_n_done, d_h0, d_h1, d_u, d_prob,
-                     d_acc, s->n, s->dim);
+                     d_acc, s->d_errors, s->n, s->dim);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }

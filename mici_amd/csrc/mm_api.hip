@@ -514,7 +514,8 @@ int mm_state_free(mm_state* s) {
   (void)hipFree(s->d_tr);
   (void)hipFree(s->d_mom_save);
   (void)hipFree(s->d_step_scale);
-  (void)hipFree(s->d_chain_steps);
+  (void)hipFree(s->d_chain_steps_buf);
+  (void)hipFree(s->d_errors);
   delete s;
   return MM_OK;
 }
@@ -625,12 +626,11 @@ int mm_state_copy(mm_state* dst, const mm_state* src) {
   MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_status, src->d_status, n * 4, hipMemcpyDefault, ctx->stream));
   MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_n_done, src->d_n_done, n * 4, hipMemcpyDefault, ctx->stream));
   if (src->d_chain_steps) {  // ... and the same per-chain trajectory lengths
-    if (!dst->d_chain_steps) MM_HIP_CHECK(ctx, hipMalloc(&dst->d_chain_steps, n * sizeof(int32_t)));
+    if (!dst->d_chain_steps_buf) MM_HIP_CHECK(ctx, hipMalloc(&dst->d_chain_steps_buf, n * sizeof(int32_t)));
+    dst->d_chain_steps = dst->d_chain_steps_buf;
     MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_chain_steps, src->d_chain_steps, n * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
-  } else if (dst->d_chain_steps) {
-    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(dst->d_chain_steps);
-    dst->d_chain_steps = nullptr;
+  } else {
+    dst->d_chain_steps = nullptr;  // switched off; the buffer stays for the next transition
   }
   if (src->d_step_scale) {  // the copy integrates with the same per-chain step sizes
     if (!dst->d_step_scale) MM_HIP_CHECK(ctx, hipMalloc(&dst->d_step_scale, n * sizeof(double)));
@@ -646,20 +646,34 @@ int mm_state_copy(mm_state* dst, const mm_state* src) {
 int mm_state_set_chain_steps(mm_state* s, const int32_t* steps) {
   MM_REQUIRE(nullptr, s != nullptr, "mm_state_set_chain_steps: state is NULL");
   mm_ctx* ctx = s->ctx;
-  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a process may own contexts on several GPUs
-  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  if (!steps) {
-    (void)hipFree(s->d_chain_steps);
+  if (!steps) {  // back to one common trajectory length: nothing to wait for, the buffer is kept for the next use
     s->d_chain_steps = nullptr;
     return MM_OK;
   }
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a process may own contexts on several GPUs
   if (s->n == 0) return MM_OK;
   for (int64_t i = 0; i < s->n; ++i)
     MM_REQUIRE(ctx, steps[i] >= 0, "mm_state_set_chain_steps: counts must be non-negative");
-  if (!s->d_chain_steps) MM_HIP_CHECK(ctx, hipMalloc(&s->d_chain_steps, (size_t)s->n * sizeof(int32_t)));
+  if (!s->d_chain_steps_buf) MM_HIP_CHECK(ctx, hipMalloc(&s->d_chain_steps_buf, (size_t)s->n * sizeof(int32_t)));
+  s->d_chain_steps = s->d_chain_steps_buf;
   MM_HIP_CHECK(ctx, hipMemcpyAsync(s->d_chain_steps, steps, (size_t)s->n * sizeof(int32_t), hipMemcpyHostToDevice,
                                    ctx->stream));
   MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer is only borrowed
+  return MM_OK;
+}
+
+int mm_state_download_errors(mm_state* s, uint32_t* errors, int32_t clear) {
+  MM_REQUIRE(nullptr, s != nullptr && errors != nullptr, "mm_state_download_errors: NULL argument");
+  mm_ctx* ctx = s->ctx;
+  MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (s->n == 0) return MM_OK;
+  if (!s->d_errors) {  // no device-resident transition has run on this state yet
+    for (int64_t i = 0; i < s->n; ++i) errors[i] = 0;
+    return MM_OK;
+  }
+  MM_HIP_CHECK(ctx, hipMemcpyAsync(errors, s->d_errors, (size_t)s->n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (clear) MM_HIP_CHECK(ctx, hipMemsetAsync(s->d_errors, 0, (size_t)s->n * sizeof(uint32_t), ctx->stream));
+  MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return MM_OK;
 }
 
@@ -969,6 +983,10 @@ static int metropolis_accept(mm_ctx* ctx, const mm_model* m, mm_state* s, mm_sta
     MM_HIP_CHECK(ctx, hipMalloc(&s->d_tr, 2 * n * sizeof(double) + n));
     s->tr_elems = 2 * n;
   }
+  if (!s->d_errors) {  // the sticky error word of this state's device-resident transitions
+    MM_HIP_CHECK(ctx, hipMalloc(&s->d_errors, n * sizeof(uint32_t)));
+    MM_HIP_CHECK(ctx, hipMemsetAsync(s->d_errors, 0, n * sizeof(uint32_t), ctx->stream));
+  }
   double* d_u = s->d_tr;
   double* d_prob = s->d_tr + n;
   int8_t* d_acc = reinterpret_cast<int8_t*>(s->d_tr + 2 * n);
@@ -1005,7 +1023,8 @@ int mm_rng_chain_steps(mm_state* s, uint64_t transition, int32_t lo, int32_t hi)
   MM_REQUIRE(ctx, lo >= 0 && hi > lo, "mm_rng_chain_steps: need 0 <= lo < hi");
   MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (s->n == 0) return MM_OK;
-  if (!s->d_chain_steps) MM_HIP_CHECK(ctx, hipMalloc(&s->d_chain_steps, (size_t)s->n * sizeof(int32_t)));
+  if (!s->d_chain_steps_buf) MM_HIP_CHECK(ctx, hipMalloc(&s->d_chain_steps_buf, (size_t)s->n * sizeof(int32_t)));
+  s->d_chain_steps = s->d_chain_steps_buf;
   return mm_launch_rng_steps(ctx, s->d_chain_steps, s->n, s->rng_seed, s->rng_chain_offset, transition, lo, hi);
 }
 

@@ -84,7 +84,12 @@ struct mm_state {
   double* d_mom_save = nullptr;  // previous momentum during a correlated refresh (mm_momentum_refresh)
   size_t mom_save_elems = 0;
   double* d_step_scale = nullptr;  // optional per-chain step-size factors (mm_state_set_step_scale)
-  int32_t* d_chain_steps = nullptr;  // optional per-chain step counts (mm_state_set_chain_steps)
+  int32_t* d_chain_steps = nullptr;  // optional per-chain step counts (mm_state_set_chain_steps): the ACTIVE pointer the
+                                     // kernels see - nullptr or d_chain_steps_buf
+  int32_t* d_chain_steps_buf = nullptr;  // its allocation, kept when the counts are switched off (no free + stream
+                                         // synchronisation per transition of a random-length sampler)
+  uint32_t* d_errors = nullptr;  // sticky per-chain error word of device-resident transitions: bit k set when a
+                                 // proposal of this chain ended with status k (mm_metropolis_accept*)
   bool rng_on = false;  // device-side random draws (mm_state_set_rng): Philox keyed by rng_seed, chain = offset + i
   uint64_t rng_seed = 0, rng_chain_offset = 0;
   double* d_tr = nullptr;  // transition scratch: u[N], accept_prob[N], accepted[N] (mm_metropolis_accept)

@@ -5,8 +5,10 @@ handed out through queues and traces collected through per-chain ``.npy`` memmap
 (reference samplers.py:546-565, 668-772, 104-138).  Here each rank (one process per GPU) owns a
 contiguous shard of the chains; there is no communication during integration; trace collection is
 one all-gather of the shard positions - RCCL over xGMI on device buffers (``RcclTraceGather``) or,
-for host arrays, the standard-library rendezvous of ``mici_amd.rendezvous`` (``gather_host``; a
-``torch.distributed`` group is accepted too, for callers already inside such a job).
+for host arrays, the standard-library rendezvous of ``mici_amd.rendezvous`` (``gather_host``).  Any
+object with ``world``, ``rank``, ``allgather_array(ndarray) -> stacked ndarray`` and
+``broadcast(bytes | None) -> bytes`` serves as the group - the product itself imports no torch (a
+``torch.distributed`` adapter lives with the gloo test, tests/test_distributed_cpu.py).
 
 Shards are padded to equal length (the collective needs equal counts); padding rows are dropped
 again after the gather."""
@@ -60,48 +62,33 @@ def unpad_gathered(gathered, n_chains, world_size):
     return np.concatenate(parts, axis=0)
 
 
-def _is_rendezvous(group):
-    from .rendezvous import Rendezvous
+def _check_group(group):
+    if group is None or not all(hasattr(group, a) for a in ("world", "rank", "allgather_array", "broadcast")):
+        raise TypeError("a rendezvous group is required (mici_amd.rendezvous.Rendezvous, or any object with "
+                        "world / rank / allgather_array / broadcast)")
+    return group
 
-    return isinstance(group, Rendezvous)
 
-
-def gather_host(local, n_chains, group=None):
-    """All-gather padded host shards and return the un-padded global array on every rank.  ``group`` is a
-    :class:`mici_amd.rendezvous.Rendezvous` (the product path: standard library only) or, for callers that
-    already live inside a ``torch.distributed`` job, a torch process group / ``None`` for its default group."""
+def gather_host(local, n_chains, group):
+    """All-gather padded host shards and return the un-padded global array on every rank.  ``group``: a
+    :class:`mici_amd.rendezvous.Rendezvous` or any object with the same four members (module docstring).
+    Size limit: the rendezvous ships whole shards through one socket frame each (see its docstring)."""
+    group = _check_group(group)
     local = np.ascontiguousarray(local)
-    if _is_rendezvous(group):
-        stacked = group.allgather_array(local)
-        return unpad_gathered(stacked.reshape((-1,) + local.shape[1:]), n_chains, group.world)
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    t = torch.from_numpy(local)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t, group=group)
-    return unpad_gathered(np.concatenate([o.numpy() for o in out], axis=0), n_chains, world)
+    stacked = np.asarray(group.allgather_array(local))
+    return unpad_gathered(stacked.reshape((-1,) + local.shape[1:]), n_chains, group.world)
 
 
-def exchange_unique_id(ctx, group=None):
-    """Rank 0 creates the RCCL unique id; its 128 bytes travel over the host rendezvous (or a torch group)."""
-    def make():
+def exchange_unique_id(ctx, group):
+    """Rank 0 creates the RCCL unique id; its 128 bytes travel over the host rendezvous."""
+    group = _check_group(group)
+    blob = None
+    if group.rank == 0:
         raw = (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)()
         _ffi.check(ctx._lib.mm_comm_unique_id(raw), None, "mm_comm_unique_id")
-        return bytes(raw)
-
-    if _is_rendezvous(group):
-        blob = group.broadcast(make() if group.rank == 0 else None)
-        return (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)(*blob)
-    import torch
-    import torch.distributed as dist
-
-    buf = torch.zeros(_ffi.MM_COMM_ID_BYTES, dtype=torch.uint8)
-    if dist.get_rank(group) == 0:
-        buf = torch.tensor(list(make()), dtype=torch.uint8)
-    dist.broadcast(buf, src=0, group=group)
-    return (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)(*buf.tolist())
+        blob = bytes(raw)
+    blob = group.broadcast(blob)
+    return (C.c_uint8 * _ffi.MM_COMM_ID_BYTES)(*blob)
 
 
 class RcclTraceGather:

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _ffi, solvers
 from .errors import AdaptationError, raise_for_status
-from .runtime import DeviceBatch, default_context
+from .runtime import ContextCache, DeviceBatch, default_context
 
 
 class Integrator:
@@ -33,21 +33,21 @@ class Integrator:
                              f"{type(system).__name__}")
         self.system = system
         self.step_size = step_size
-        self._one = {}  # cached single-chain DeviceBatch per context
+        self._one = ContextCache()  # single-chain DeviceBatch per context
         self.last_counters = None
 
     # pickling / deepcopy: device handles are dropped and lazily re-created; every copy has its own
     # step_size (adapters mutate it per chain, adapters.py:373) - SURVEY.md H9
     def __getstate__(self):
         d = self.__dict__.copy()
-        d["_one"] = {}
+        d["_one"] = ContextCache()
         return d
 
     def __deepcopy__(self, memo):
         import copy
         new = object.__new__(type(self))
         for k, v in self.__dict__.items():
-            new.__dict__[k] = {} if k == "_one" else (v if k == "system" else copy.deepcopy(v, memo))
+            new.__dict__[k] = ContextCache() if k == "_one" else (v if k == "system" else copy.deepcopy(v, memo))
         return new
 
     def _check_step_size(self):
@@ -91,9 +91,9 @@ class Integrator:
         self._check_step_size()
         ctx = default_context()
         pos = np.ascontiguousarray(state.pos, dtype=np.float64)
-        batch = self._one.get(id(ctx))
-        if batch is None or batch.handle is None or batch.dim != pos.shape[0]:
-            batch = self._one[id(ctx)] = DeviceBatch(ctx, 1, pos.shape[0], mapped=True)
+        batch = self._one.get(ctx)
+        if batch is None or batch.dim != pos.shape[0]:
+            batch = self._one.put(ctx, DeviceBatch(ctx, 1, pos.shape[0], mapped=True))
         batch.upload(pos[None], np.asarray(state.mom, dtype=np.float64)[None], [int(state.dir)])
         self.step_device(batch, 1, ctx)
         q, p, _, status, _ = batch.download_all()  # one transfer each way for a single state

@@ -17,77 +17,183 @@ rank 0 serves a tiny star topology on an AF_UNIX socket, every collective is one
 from __future__ import annotations
 
 import os
-import pickle
 import socket
+import stat
 import struct
 import tempfile
 import time
 
 import numpy as np
 
-_HDR = struct.Struct("!I")
+# Wire format (no pickle anywhere: a frame is never more than bytes the receiver asked for).
+#   frame      = u64 length (network order) + payload
+#   hello      = b"MICI" + u32 rank + u32 world + u32 len(tag) + tag         rank > 0 -> rank 0, once
+#   gather     = every rank sends one frame; rank 0 answers with u32 count + count x (u64 length + bytes)
+#   array      = u8 len(dtype.str) + dtype.str + u8 ndim + ndim x u64 + the C-contiguous bytes
+_HDR = struct.Struct("!Q")
+_MAX_FRAME = 1 << 40
+_MAGIC = b"MICI"
 
 
 def _send(sock, payload):
-    sock.sendall(_HDR.pack(len(payload)) + payload)
+    sock.sendall(_HDR.pack(len(payload)))
+    sock.sendall(payload)
 
 
 def _recv_exact(sock, n):
-    buf = bytearray()
-    while len(buf) < n:
-        chunk = sock.recv(n - len(buf))
-        if not chunk:
+    buf = bytearray(n)
+    view, got = memoryview(buf), 0
+    while got < n:
+        k = sock.recv_into(view[got:], min(n - got, 1 << 24))
+        if not k:
             raise ConnectionError("rendezvous peer closed the connection")
-        buf += chunk
+        got += k
     return bytes(buf)
 
 
 def _recv(sock):
     (n,) = _HDR.unpack(_recv_exact(sock, _HDR.size))
+    if n > _MAX_FRAME:
+        raise ConnectionError(f"rendezvous: implausible frame length {n}")
     return _recv_exact(sock, n)
 
 
+def _pack_parts(parts):
+    out = [struct.pack("!I", len(parts))]
+    for p in parts:
+        out.append(_HDR.pack(len(p)))
+        out.append(p)
+    return b"".join(out)
+
+
+def _unpack_parts(blob):
+    (count,) = struct.unpack_from("!I", blob, 0)
+    off, parts = 4, []
+    for _ in range(count):
+        (n,) = _HDR.unpack_from(blob, off)
+        off += _HDR.size
+        if off + n > len(blob):
+            raise ConnectionError("rendezvous: truncated gather reply")
+        parts.append(blob[off:off + n])
+        off += n
+    return parts
+
+
+def pack_array(a):
+    a = np.asarray(a)
+    if not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a)
+    if a.dtype.hasobject:
+        raise TypeError("rendezvous ships plain numeric arrays only")
+    ds = a.dtype.str.encode()
+    head = struct.pack("!B", len(ds)) + ds + struct.pack("!B", a.ndim) + struct.pack("!%dQ" % a.ndim, *a.shape)
+    return head + a.tobytes()
+
+
+def unpack_array(blob):
+    n = blob[0]
+    dtype = np.dtype(blob[1:1 + n].decode())
+    if dtype.hasobject:
+        raise TypeError("rendezvous ships plain numeric arrays only")
+    off = 1 + n
+    ndim = blob[off]
+    shape = struct.unpack_from("!%dQ" % ndim, blob, off + 1)
+    off += 1 + 8 * ndim
+    return np.frombuffer(blob, dtype=dtype, count=int(np.prod(shape, dtype=np.int64)), offset=off).reshape(shape).copy()
+
+
+def private_dir():
+    """A directory only this user can enter (0700, owned by us) under $XDG_RUNTIME_DIR or the temp dir: the socket of
+    a job lives inside it, so another user can neither pre-bind its name nor connect to it."""
+    base = os.environ.get("XDG_RUNTIME_DIR") or tempfile.gettempdir()
+    d = os.path.join(base, "mici_amd_%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError(f"rendezvous directory {d} is not a private directory of uid {os.getuid()}")
+    return d
+
+
+def job_tag():
+    """What the ranks of ONE job agree on without talking: MICI_AMD_RDZV_TAG, else what a `torch.distributed.run`
+    launch exports (MASTER_PORT + run id), else the parent pid (ranks started by hand from one shell)."""
+    t = os.environ.get("MICI_AMD_RDZV_TAG")
+    if t:
+        return t
+    return "{}_{}".format(os.environ.get("MASTER_PORT", "p%d" % os.getppid()),
+                          os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+
+
 def default_path():
-    """Socket path shared by the ranks of one job: MICI_AMD_RDZV if set, else derived from what a
-    `torch.distributed.run` launch exports (MASTER_PORT + run id), else from the parent pid."""
+    """Socket path shared by the ranks of one job: MICI_AMD_RDZV if set (spawn_ranks sets it to a fresh private
+    directory), else <private dir>/<job tag>.sock."""
     p = os.environ.get("MICI_AMD_RDZV")
     if p:
         return p
-    tag = "{}_{}".format(os.environ.get("MASTER_PORT", "p%d" % os.getppid()),
-                         os.environ.get("TORCHELASTIC_RUN_ID", "none"))
-    return os.path.join(tempfile.gettempdir(), "mici_amd_rdzv_%d_%s.sock" % (os.getuid(), tag))
+    safe = "".join(c if c.isalnum() or c in "-_." else "_" for c in job_tag())
+    return os.path.join(private_dir(), "rdzv_%s.sock" % safe)
 
 
 class Rendezvous:
-    """World of ``world_size`` processes on one node.  ``world_size == 1`` needs no socket."""
+    """World of ``world_size`` processes on one node.  ``world_size == 1`` needs no socket.
 
-    def __init__(self, rank, world_size, path=None, timeout=120.0):
+    ``timeout`` bounds how long the ranks wait for each other to ARRIVE (connect / accept / hello); collectives then
+    wait ``collective_timeout`` seconds (default: for ever - a rank may legitimately reach a barrier or a trace gather
+    long after its peers: load imbalance, a hipRTC compile, a long sampling run).  ``allgather_array`` / ``gather_host``
+    ship whole shards as single frames and rank 0 holds every part in memory at once: fine for the per-collection
+    trace shards of this path (MBs), not a transport for hundreds of GBs."""
+
+    def __init__(self, rank, world_size, path=None, timeout=120.0, collective_timeout=None, tag=None):
         self.rank, self.world = int(rank), int(world_size)
         self.timeout = float(timeout)
-        self.path = path or default_path()
+        self.collective_timeout = collective_timeout
         self._server = None
         self._peers = {}       # rank 0: rank -> socket
         self._sock = None      # rank > 0: socket to rank 0
         if self.world <= 1:
+            self.path = path
             return
+        if not 0 <= self.rank < self.world:
+            raise ValueError(f"rank {self.rank} outside world of {self.world}")
+        self.path = path or default_path()
+        self.tag = (tag if tag is not None else job_tag()).encode()
         if self.rank == 0:
             try:
                 os.unlink(self.path)
             except FileNotFoundError:
                 pass
             srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-            srv.bind(self.path)
+            old = os.umask(0o177)  # the socket itself: owner only
+            try:
+                srv.bind(self.path)
+            finally:
+                os.umask(old)
             srv.listen(self.world)
-            srv.settimeout(self.timeout)
             self._server = srv
             deadline = time.monotonic() + self.timeout
             while len(self._peers) < self.world - 1:
-                if time.monotonic() > deadline:
+                left = deadline - time.monotonic()
+                if left <= 0:
                     raise TimeoutError(f"rendezvous: only {len(self._peers) + 1} of {self.world} ranks arrived")
-                conn, _ = srv.accept()
-                conn.settimeout(self.timeout)
-                r = pickle.loads(_recv(conn))
-                self._peers[int(r)] = conn
+                srv.settimeout(left)
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                conn.settimeout(max(1.0, min(10.0, left)))
+                try:
+                    r = self._read_hello(conn)
+                except (ConnectionError, ValueError, socket.timeout, struct.error):
+                    conn.close()  # not one of this job's ranks (stale rank of another job, a stray client)
+                    continue
+                self._peers[r] = conn
+            for conn in self._peers.values():
+                conn.settimeout(self.collective_timeout)
+            for conn in self._peers.values():  # every rank learns that the world is complete and consistent
+                _send(conn, _MAGIC)
         else:
             deadline = time.monotonic() + self.timeout
             while True:
@@ -100,17 +206,41 @@ class Rendezvous:
                     if time.monotonic() > deadline:
                         raise TimeoutError(f"rendezvous: rank 0 never listened on {self.path}")
                     time.sleep(0.02)
-            s.settimeout(self.timeout)
-            _send(s, pickle.dumps(self.rank))
+            s.settimeout(max(1.0, deadline - time.monotonic()) + 5.0)
+            _send(s, _MAGIC + struct.pack("!III", self.rank, self.world, len(self.tag)) + self.tag)
+            try:
+                ack = _recv(s)
+            except (ConnectionError, socket.timeout) as e:
+                s.close()
+                raise ConnectionError(f"rendezvous: rank 0 on {self.path} did not accept rank {self.rank} of job "
+                                      f"{self.tag.decode()!r} (another job's socket, a duplicate rank, or not all "
+                                      f"ranks arrived): {e}") from e
+            if ack != _MAGIC:
+                s.close()
+                raise ConnectionError("rendezvous: unexpected acknowledgement")
+            s.settimeout(self.collective_timeout)
             self._sock = s
 
+    def _read_hello(self, conn):
+        msg = _recv(conn)
+        if len(msg) < 16 or msg[:4] != _MAGIC:
+            raise ValueError("not a rendezvous hello")
+        r, w, n = struct.unpack_from("!III", msg, 4)
+        if w != self.world or msg[16:16 + n] != self.tag or len(msg) != 16 + n:
+            raise ValueError("hello from another job")
+        if not 0 < r < self.world or r in self._peers:
+            raise ValueError("rank out of range or already present")
+        return r
+
     @classmethod
-    def from_env(cls, timeout=120.0):
-        return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), None, timeout)
+    def from_env(cls, timeout=120.0, collective_timeout=None):
+        return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), None, timeout,
+                   collective_timeout)
 
     # -- collectives (every rank must call them in the same order) ---------------------------------------
     def allgather(self, payload: bytes):
         """Every rank contributes a byte string; every rank receives the list in rank order."""
+        payload = bytes(payload)
         if self.world <= 1:
             return [payload]
         if self.rank == 0:
@@ -118,12 +248,12 @@ class Rendezvous:
             parts[0] = payload
             for r, conn in self._peers.items():
                 parts[r] = _recv(conn)
-            blob = pickle.dumps(parts)
+            blob = _pack_parts(parts)
             for conn in self._peers.values():
                 _send(conn, blob)
             return parts
         _send(self._sock, payload)
-        return pickle.loads(_recv(self._sock))
+        return _unpack_parts(_recv(self._sock))
 
     def barrier(self):
         self.allgather(b"")
@@ -133,10 +263,9 @@ class Rendezvous:
         return parts[src]
 
     def allgather_array(self, a):
-        """Stack equal-shape NumPy arrays of all ranks along a new leading axis."""
-        a = np.ascontiguousarray(a)
-        parts = self.allgather(pickle.dumps(a, protocol=pickle.HIGHEST_PROTOCOL))
-        return np.stack([pickle.loads(p) for p in parts], axis=0)
+        """Stack equal-shape numeric NumPy arrays of all ranks along a new leading axis."""
+        parts = self.allgather(pack_array(a))
+        return np.stack([unpack_array(p) for p in parts], axis=0)
 
     def reduce_max(self, x: float) -> float:
         return float(max(struct.unpack("!d", p)[0] for p in self.allgather(struct.pack("!d", float(x)))))
@@ -180,13 +309,14 @@ def spawn_ranks(argv, world_size, env_extra=None, timeout=None):
     children inherit stdout / stderr.  If one rank fails the others are terminated."""
     import subprocess
 
-    tmp = tempfile.mkdtemp(prefix="mici_amd_rdzv_")
+    tmp = tempfile.mkdtemp(prefix="mici_amd_rdzv_")  # 0700, ours: a fresh private socket directory per job
     path = os.path.join(tmp, "rdzv.sock")
+    tag = "spawn_%d_%s" % (os.getpid(), os.path.basename(tmp))
     procs = []
     for r in range(world_size):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world_size),
-                    "MICI_AMD_RDZV": path, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+                    "MICI_AMD_RDZV": path, "MICI_AMD_RDZV_TAG": tag, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         env.update(env_extra or {})
         procs.append(subprocess.Popen(argv, env=env))
     codes = [None] * world_size

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -36,6 +37,7 @@ class Context:
         _ffi.check(self._lib.mm_ctx_create(device, C.byref(h)), None, "mm_ctx_create")
         self.handle = h
         self.device = device
+        self._caches = weakref.WeakSet()  # ContextCache objects holding device objects that live on this context
 
     def sync(self):
         _ffi.check(self._lib.mm_ctx_sync(self.handle), self.handle, "mm_ctx_sync")
@@ -51,6 +53,8 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            for cache in list(getattr(self, "_caches", ())):  # device objects cached elsewhere die with their context
+                cache.evict(self)
             self._lib.mm_ctx_destroy(self.handle)
             self.handle = None
 
@@ -59,6 +63,72 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class ContextCache:
+    """Device objects (models, single-state batches, proposal batches) cached per context by a long-lived host object
+    - a system shared by every worker thread's integrator copy, say.  Thread safe, and an entry goes when its context
+    is closed (``Context.close`` evicts), so per-thread default contexts of short-lived worker threads do not pile
+    up streams, pinned staging buffers and device models behind a shared system."""
+
+    def __init__(self):
+        self._d = {}
+        self._lock = threading.Lock()
+
+    def get(self, ctx, *extra):
+        with self._lock:
+            obj = self._d.get((id(ctx),) + extra)
+        if obj is None or getattr(obj, "handle", None) is None or obj.ctx is not ctx:
+            return None
+        return obj
+
+    def put(self, ctx, obj, *extra):
+        with self._lock:
+            self._d[(id(ctx),) + extra] = obj
+        ctx._caches.add(self)
+        return obj
+
+    def evict(self, ctx):
+        with self._lock:
+            gone = [self._d.pop(k) for k in [k for k in self._d if k[0] == id(ctx)]]
+        for obj in gone:
+            _close_cached(obj)
+
+    def clear(self):
+        with self._lock:
+            gone, self._d = list(self._d.values()), {}
+        for obj in gone:
+            _close_cached(obj)
+
+    def __len__(self):
+        return len(self._d)
+
+    def __deepcopy__(self, memo):  # device handles never travel (SURVEY.md H9): a copy starts empty
+        return ContextCache()
+
+    def __reduce__(self):
+        return (ContextCache, ())
+
+
+def _close_cached(obj):
+    try:
+        if isinstance(obj, DeviceBatch):
+            obj.close(force=True)
+        else:
+            obj.close()
+    except Exception:
+        pass
+
+
+class _ThreadContexts(dict):
+    """The default contexts of one host thread; closed (and evicted from every cache) when the thread ends."""
+
+    def __del__(self):
+        for ctx in list(self.values()):
+            try:
+                ctx.close()
+            except Exception:
+                pass
 
 
 _default = threading.local()
@@ -72,7 +142,7 @@ def default_context(device=None):
     key = device if device is not None else int(os.environ.get("LOCAL_RANK", "0"))
     table = getattr(_default, "ctxs", None)
     if table is None:
-        table = _default.ctxs = {}
+        table = _default.ctxs = _ThreadContexts()
     ctx = table.get(key)
     if ctx is None or ctx.handle is None:
         ctx = table[key] = Context(key)
@@ -217,6 +287,14 @@ class DeviceBatch:
             ptr = steps.ctypes.data_as(_ffi.c_int32_p)
         _ffi.check(self._lib.mm_state_set_chain_steps(self.handle, ptr), self.ctx.handle,
                    "mm_state_set_chain_steps")
+
+    def download_errors(self, clear=True):
+        """Sticky error word of the device-resident transitions run on this batch: uint32 [N], bit k set when a
+        proposal of the chain ended with status k since the last clearing read (include/mici_amd.h)."""
+        out = np.zeros(self.n_chains, dtype=np.uint32)
+        _ffi.check(self._lib.mm_state_download_errors(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                      1 if clear else 0), self.ctx.handle, "mm_state_download_errors")
+        return out
 
     def set_rng(self, seed, chain_offset=0):
         """Device-side random draws for this batch (include/mici_amd.h, mm_state_set_rng): chain i draws the stream

@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi, models
-from .runtime import DeviceBatch, DeviceModel, default_context
+from .runtime import ContextCache, DeviceBatch, DeviceModel, default_context
 
 
 class System:
@@ -34,8 +34,8 @@ class System:
                              "grad_neg_log_dens / backend as None")
         self.target = neg_log_dens
         self.dim = neg_log_dens.dim
-        self._device = {}
-        self._one = {}  # cached single-chain DeviceBatch per context (h / dh_dmom / sample_momentum of one state)
+        self._device = ContextCache()
+        self._one = ContextCache()  # single-chain DeviceBatch per context (h / dh_dmom / sample_momentum of one state)
 
     # ---- description -> device model --------------------------------------------------------
     def _model_args(self):
@@ -43,22 +43,22 @@ class System:
 
     def device_model(self, ctx=None):
         ctx = ctx or default_context()
-        m = self._device.get(id(ctx))
-        if m is None or m.handle is None:
-            m = self._device[id(ctx)] = DeviceModel(ctx, self.dim, self.target, **self._model_args())
+        m = self._device.get(ctx)
+        if m is None:
+            m = self._device.put(ctx, DeviceModel(ctx, self.dim, self.target, **self._model_args()))
         return m
 
     def __getstate__(self):
         d = self.__dict__.copy()
-        d["_device"] = {}  # device handles are re-created lazily after unpickling
-        d["_one"] = {}
+        d["_device"] = ContextCache()  # device handles are re-created lazily after unpickling
+        d["_one"] = ContextCache()
         return d
 
     def __deepcopy__(self, memo):
         import copy
         new = object.__new__(type(self))
         for k, v in self.__dict__.items():
-            new.__dict__[k] = {} if k in ("_device", "_one") else copy.deepcopy(v, memo)
+            new.__dict__[k] = ContextCache() if k in ("_device", "_one") else copy.deepcopy(v, memo)
         return new
 
     # ---- batched quantities ---------------------------------------------------------------------
@@ -68,9 +68,9 @@ class System:
         if pos.ndim != 2 or pos.shape[1] != self.dim:
             raise ValueError(f"pos must have shape [N, {self.dim}]")
         if pos.shape[0] == 1:  # the single-state calls of mici.transitions: keep the device buffers
-            batch = self._one.get(id(ctx))
-            if batch is None or batch.handle is None:
-                batch = self._one[id(ctx)] = DeviceBatch(ctx, 1, self.dim, mapped=True)
+            batch = self._one.get(ctx)
+            if batch is None:
+                batch = self._one.put(ctx, DeviceBatch(ctx, 1, self.dim, mapped=True))
                 batch.keep = True  # close() is a no-op; the buffers go when the system does
         else:
             batch = DeviceBatch(ctx, pos.shape[0], self.dim)
@@ -166,9 +166,7 @@ class EuclideanMetricSystem(System):
                 raise ValueError("metric must be [D] (diagonal) or [D, D] (dense) for this system's dimension")
             kind = models.METRIC_DIAG if metric.ndim == 1 else models.METRIC_DENSE
         self.metric_kind, self.metric = kind, metric
-        for m in self._device.values():
-            m.close()
-        self._device = {}
+        self._device.clear()
 
 
 class GaussianEuclideanMetricSystem(EuclideanMetricSystem):

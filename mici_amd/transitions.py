@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _ffi
 from .errors import LinAlgError
-from .runtime import DeviceBatch, default_context
+from .runtime import ContextCache, DeviceBatch, default_context
 
 
 class IndependentMomentumTransition:
@@ -110,7 +110,7 @@ class MetropolisStaticIntegrationTransition:
             "step_size": (np.float64, np.nan),
             "metrop_accept_prob": (np.float64, np.nan),
         }
-        self._proposals = {}
+        self._proposals = ContextCache()
 
     @property
     def statistic_types(self):
@@ -123,7 +123,7 @@ class MetropolisStaticIntegrationTransition:
 
     def __getstate__(self):
         d = self.__dict__.copy()
-        d["_proposals"] = {}
+        d["_proposals"] = ContextCache()
         d.pop("_one", None)
         return d
 
@@ -133,16 +133,16 @@ class MetropolisStaticIntegrationTransition:
         memo[id(self)] = new
         for k, v in self.__dict__.items():
             if k == "_proposals":
-                new.__dict__[k] = {}
+                new.__dict__[k] = ContextCache()
             elif k != "_one":
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
 
     def _proposal_for(self, batch):
-        key = (id(batch.ctx), batch.n_chains, batch.dim)
-        prop = self._proposals.get(key)
-        if prop is None or prop.handle is None:
-            prop = self._proposals[key] = DeviceBatch(batch.ctx, batch.n_chains, batch.dim)
+        prop = self._proposals.get(batch.ctx, batch.n_chains, batch.dim)
+        if prop is None:
+            prop = self._proposals.put(batch.ctx, DeviceBatch(batch.ctx, batch.n_chains, batch.dim), batch.n_chains,
+                                       batch.dim)
         return prop
 
     # ---- N chains, device resident ---------------------------------------------------------------------
@@ -190,8 +190,10 @@ class MetropolisStaticIntegrationTransition:
     def sample_batch_device(self, batch, transition, ctx=None, stats=True):
         """One transition for every chain with the accept uniform drawn ON THE DEVICE (``batch.set_rng`` first):
         no per-transition upload.  ``stats=False`` also skips every download - the transition is then a pure
-        sequence of asynchronous launches (statuses stay on the device; a LinAlgError outside a solver - status 5,
-        which the reference lets propagate - is then the caller's to check via ``batch`` statistics later)."""
+        sequence of asynchronous launches.  What went wrong with a chain is not lost: the accept step ORs every failed
+        proposal's status into the batch's sticky error word on the device, and :py:meth:`check_errors` - to be called
+        at the caller's next synchronisation point, e.g. with the trace download - raises the ``LinAlgError`` the
+        reference lets propagate out of the sampler (status 5; the other statuses are rejections there too)."""
         ctx = ctx or batch.ctx
         prop = self._proposal_for(batch)
         _ffi.check(ctx._lib.mm_state_copy(prop.handle, batch.handle), ctx.handle, "mm_state_copy")
@@ -223,6 +225,16 @@ class MetropolisStaticIntegrationTransition:
             "step_size": np.full(n, self.integrator.step_size, dtype=np.float64),
             "accepted": acc.astype(bool),
         }
+
+    @staticmethod
+    def check_errors(batch, clear=True):
+        """Read (and clear) the batch's sticky error word; raise ``LinAlgError`` for chains with a status-5 proposal
+        (a LinAlgError outside a solver propagates in the reference, transitions.py:292-295); return the word."""
+        errs = batch.download_errors(clear)
+        bad = np.flatnonzero(errs & (1 << 5))
+        if bad.size:
+            raise LinAlgError(f"metric construction failed outside a solver for chain(s) {bad.tolist()}")
+        return errs
 
     # ---- one chain, the reference's contract -----------------------------------------------------------
     def sample(self, state, rng):
@@ -295,9 +307,12 @@ class MetropolisRandomIntegrationTransition(MetropolisStaticIntegrationTransitio
         lo, hi = self.n_step_range
         _ffi.check(ctx._lib.mm_rng_chain_steps(batch.handle, int(transition), int(lo), int(hi)), ctx.handle,
                    "mm_rng_chain_steps")
+        keep = self.n_step
         self.n_step = int(hi) - 1  # the launch runs to the longest possible trajectory; chains stop at their own count
         try:
             return super().sample_batch_device(batch, transition, ctx, stats)
         finally:
+            self.n_step = keep
+            # switches the per-chain counts off again; the device buffers stay allocated (no free, no synchronisation)
             batch.set_chain_steps(None)
             self._proposal_for(batch).set_chain_steps(None)

@@ -155,14 +155,30 @@ def test_transition_deepcopy_and_pickle_drop_device_batches():
     for tr in (transitions.MetropolisStaticIntegrationTransition(system, integ, 3),
                transitions.MetropolisRandomIntegrationTransition(system, integ, (1, 4))):
         # what a transition looks like after it has sampled once: cached handles that cannot be pickled
+        class FakeCtx:
+            def __init__(self):
+                self._caches = set()
+
         class FakeBatch:
             handle = C.c_void_p(1234)
-            ctx = object()
-        tr._proposals[(1, 1, 4)] = FakeBatch()
+            closed = False
+
+            def close(self, force=False):
+                self.closed = True
+
+        fake_ctx = FakeCtx()
+        fb = FakeBatch()
+        fb.ctx = fake_ctx
+        tr._proposals.put(fake_ctx, fb, 1, 4)
         tr._one = FakeBatch()
         clone = copy.deepcopy(tr)
-        assert clone._proposals == {} and not hasattr(clone, "_one")
+        assert len(clone._proposals) == 0 and not hasattr(clone, "_one")
         assert clone.integrator is not tr.integrator and clone.integrator.step_size == 0.1
         again = pickle.loads(pickle.dumps(tr))
-        assert again._proposals == {} and not hasattr(again, "_one")
+        assert len(again._proposals) == 0 and not hasattr(again, "_one")
         assert tr._one is not None  # the original keeps its cache
+        assert tr._proposals.get(fake_ctx, 1, 4) is fb
+        # an entry goes when its context is closed (Context.close evicts from every cache it is in)
+        assert tr._proposals in fake_ctx._caches
+        tr._proposals.evict(fake_ctx)
+        assert fb.closed and len(tr._proposals) == 0

@@ -106,3 +106,114 @@ def test_zero_upload_sampling_recovers_the_target():
     assert np.max(np.abs(q.mean(0))) < 5 * np.sqrt(np.max(np.diag(cov)) / n)
     assert_close(np.cov(q.T), cov, 0.15, "sample covariance")
     batch.close()
+
+
+def test_sticky_error_word_survives_stats_free_transitions():
+    """with ``stats=False`` nothing is downloaded per transition and the proposal's status is overwritten
+    by the next transition's copy - the accept step therefore ORs every failed proposal's status into the batch's
+    error word on the device.  Same seeds, one batch with statistics and one without: the word equals the OR of the
+    per-transition flags; a status-5 proposal (LinAlgError outside a solver, which the reference lets propagate)
+    is raised by ``check_errors`` at the caller's synchronisation point."""
+    from mici_amd.errors import LinAlgError
+
+    rng = np.random.default_rng(11)
+    dim, n, T = 8, 64, 5
+    system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(omdl.make_spd(dim, rng)))
+    # a solver that gives up early: a good share of the trajectories fails with ConvergenceError
+    integ = integrators.ImplicitLeapfrogIntegrator(system, 0.5, fixed_point_solver_kwargs=dict(max_iters=7))
+    tr = transitions.MetropolisStaticIntegrationTransition(system, integ, 3)
+    mom = transitions.IndependentMomentumTransition(system)
+    ctx = default_context()
+    q0 = rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+    with_stats, without = DeviceBatch(ctx, n, dim), DeviceBatch(ctx, n, dim)
+    scale = np.where(np.arange(n) % 2 == 0, 0.02, 1.0)  # even chains: a step size the early-quitting solver manages
+    for b in (with_stats, without):
+        b.upload(q0, p0, np.ones(n, dtype=np.int8))
+        b.set_rng(99, 0)
+        b.set_step_scale(scale)
+    assert not without.download_errors().any()  # nothing has run yet
+    conv = np.zeros(n, dtype=bool)
+    nonrev = np.zeros(n, dtype=bool)
+    for t in range(T):
+        mom.sample_batch_device(with_stats, t)
+        st = tr.sample_batch_device(with_stats, t)
+        conv |= st["convergence_error"]
+        nonrev |= st["non_reversible_step"]
+        mom.sample_batch_device(without, t)
+        assert tr.sample_batch_device(without, t, stats=False) is None
+    assert conv.any() and not conv.all()  # the scenario exercises both kinds of chains
+    errs = tr.check_errors(without, clear=False)
+    assert np.array_equal((errs & 0b1110) != 0, conv)
+    assert np.array_equal((errs & (1 << 4)) != 0, nonrev)
+    assert not (errs & (1 << 5)).any()
+    assert np.array_equal(without.download_errors(clear=True), errs)
+    assert not without.download_errors().any()  # cleared
+    a, b = with_stats.download(), without.download()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # status 5: a position whose metric is not finite
+    q_bad = q0.copy()
+    q_bad[3] = 1e200
+    without.upload(q_bad, p0, np.ones(n, dtype=np.int8))
+    mom_keep = p0  # keep the momenta: the refresh itself would fail on that chain
+    tr.sample_batch_device(without, T, stats=False)
+    with pytest.raises(LinAlgError, match=r"\[3\]"):
+        tr.check_errors(without)
+    assert mom_keep is p0
+    with_stats.close()
+    without.close()
+
+
+def test_random_length_device_transition_keeps_its_buffers_and_restores_n_step():
+    """the random-length transition no longer frees + re-allocates the per-chain step counts (a stream
+    synchronisation) every transition, and leaves ``n_step`` as it found it."""
+    rng = np.random.default_rng(3)
+    dim, n = 6, 128
+    system = systems.EuclideanMetricSystem(models.GaussDense(omdl.make_spd(dim, rng)))
+    integ = integrators.LeapfrogIntegrator(system, 0.2)
+    tr = transitions.MetropolisRandomIntegrationTransition(system, integ, (2, 9))
+    ctx = default_context()
+    batch = DeviceBatch(ctx, n, dim)
+    batch.upload(rng.standard_normal((n, dim)), rng.standard_normal((n, dim)), np.ones(n, dtype=np.int8))
+    batch.set_rng(5, 0)
+    before = tr.n_step
+    seen = set()
+    for t in range(4):
+        st = tr.sample_batch_device(batch, t)
+        seen |= set(st["n_step"].tolist())
+        assert tr.n_step == before
+        # the counts are switched off again: a plain integrator call advances every chain by the common length
+        q0, p0, _ = batch.download()
+        integ.step_device(batch, 3, ctx)
+        _, nd = batch.download_status()
+        assert np.all(nd == 3)
+        batch.upload(q0, p0, np.ones(n, dtype=np.int8))
+    assert seen <= set(range(2, 9)) and len(seen) > 3
+    batch.close()
+
+
+def test_worker_thread_contexts_are_closed_and_evicted_when_the_thread_ends():
+    """the default context of a worker thread (stream, pinned staging buffer) and the device model /
+    buffers a SHARED system cached for it go when the thread ends, instead of accumulating behind the system."""
+    import gc
+    import threading
+
+    from mici_amd.states import ChainState
+
+    system = systems.EuclideanMetricSystem(models.GaussIso(4))
+    integ = integrators.LeapfrogIntegrator(system, 0.1)
+    seen = []
+
+    def work():
+        s = integ.step(ChainState(pos=np.ones(4), mom=np.ones(4), dir=1))
+        seen.append((default_context(), float(s.pos[0])))
+
+    for _ in range(3):
+        th = threading.Thread(target=work)
+        th.start()
+        th.join()
+        gc.collect()
+    assert len(seen) == 3 and len({id(c) for c, _ in seen}) >= 1
+    assert all(c.handle is None for c, _ in seen)  # closed with their threads
+    assert len(system._device) == 0 and len(integ._one) == 0  # and evicted from the shared caches
+    assert len({v for _, v in seen}) == 1
