@@ -259,7 +259,8 @@ __device__ __forceinline__ CVec<C> constr_value(const ConArgs& A, const Vec<D>& 
   if constexpr (C == 1) {
     if (A.constr == MM_CONSTR_TORUS) {
       constexpr int I1 = D > 1 ? 1 : 0;
-      const double rho = sqrt(q.v[0] * q.v[0] + q.v[I1] * q.v[I1]);
+      double rho, irho;
+      mmdev::sqrt_rsqrt(q.v[0] * q.v[0] + q.v[I1] * q.v[I1], &rho, &irho);
       const double dr = rho - A.cp0;
       c.v[0] = dr * dr + q.v[D > 2 ? 2 : 0] * q.v[D > 2 ? 2 : 0] - A.cp1 * A.cp1;
     } else if (A.constr == MM_CONSTR_FIRST) {
@@ -297,8 +298,9 @@ __device__ __forceinline__ Jac<C, D> constr_jacob(const ConArgs& A, const Vec<D>
   if constexpr (C == 1) {
     if (A.constr == MM_CONSTR_TORUS) {
       constexpr int I1 = D > 1 ? 1 : 0;
-      const double rho = sqrt(q.v[0] * q.v[0] + q.v[I1] * q.v[I1]);
-      const double f = 2.0 * (rho - A.cp0) / rho;
+      double rho, irho;  // the same call as in constr_value: one evaluation serves both after inlining
+      mmdev::sqrt_rsqrt(q.v[0] * q.v[0] + q.v[I1] * q.v[I1], &rho, &irho);
+      const double f = 2.0 * (rho - A.cp0) * irho;
       j.r[0].v[0] = f * q.v[0];
       if constexpr (D > 1) j.r[0].v[1] = f * q.v[1];
       if constexpr (D > 2) j.r[0].v[2] = 2.0 * q.v[2];
@@ -376,6 +378,15 @@ __device__ __forceinline__ bool all_finite(const CMat<C>& g) {
 // triangular solves U Y = I, U X = Y^T with U = L^T (matrices.py:1183-1188), log|det| = 2 sum log|L_ii|.
 template <int C>
 __device__ __forceinline__ bool chol_inverse(const CMat<C>& g, CMat<C>* inv, double* log_abs_det) {
+  if constexpr (C == 1) {  // one constraint: L = sqrt(g), inverse (1 / L) / L, log|det| = 2 log L
+    const double d = g.m[0][0];
+    if (!(d > 0.0)) return false;
+    double l, il;
+    mmdev::sqrt_rsqrt(d, &l, &il);
+    inv->m[0][0] = il * il;
+    *log_abs_det = 2.0 * log(l);
+    return true;
+  }
   CMat<C> l;
   bool ok = true;
 #pragma unroll
@@ -510,6 +521,11 @@ __device__ __forceinline__ CVec<C> cmat_vec(const CMat<C>& m, const CVec<C>& x) 
 // solve after lu_factor's warning; the NaN/inf then trips the solver's divergence test.
 template <int C>
 __device__ __forceinline__ CVec<C> lu_solve(CMat<C> a, CVec<C> b) {
+  if constexpr (C == 1) {
+    CVec<C> x1;
+    x1.v[0] = mmdev::fdiv(b.v[0], a.m[0][0]);
+    return x1;
+  }
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     if constexpr (C > 1) {
@@ -630,17 +646,24 @@ __device__ __forceinline__ int newton_project(const ConArgs& A, const Rot<D>& ro
     const CVec<C> c = constr_value<C, D>(A, q);
     const double err = cnorm<C>(c, o.norm);
     const CMat<C> a = rows_inner<C, D>(jac, mjp, abs_t);
-    if (!all_finite<C>(a)) return MM_ST_SOLVER_LINALG;  // "Array is not finite." inside the solver
+    const bool fin = all_finite<C>(a);  // else "Array is not finite." inside the solver
     const CVec<C> x = lu_solve<C>(a, c);
     const Vec<D> dmu = rows_combine<C, D>(jac_prev, x);
     Vec<D> dpos = rows_combine<C, D>(mjp, x);
 #pragma unroll kUnrollD<D>
     for (int i = 0; i < D; ++i) dpos.v[i] = abs_t * dpos.v[i];
-    if (err > o.div_tol || err != err) return MM_ST_DIVERGED;
-    if (err < o.constr_tol && vnorm<D>(dpos, o.norm) < o.pos_tol) {
-      apply_mu<D>(A, rot, p, mu, t);
-      *jac_out = jac;
-      return MM_ST_OK;
+    // the iteration's arithmetic is straight-line; ONE data-dependent exit decides among the reference's three
+    // (in its order: not finite -> LinAlgError, diverged, converged) - every exit is an exec-mask region in a
+    // lane-per-chain kernel
+    const bool diverged = err > o.div_tol || err != err;
+    const bool converged = err < o.constr_tol && vnorm<D>(dpos, o.norm) < o.pos_tol;
+    const int code = !fin ? MM_ST_SOLVER_LINALG : (diverged ? MM_ST_DIVERGED : (converged ? MM_ST_OK : -1));
+    if (code >= 0) {
+      if (code == MM_ST_OK) {
+        apply_mu<D>(A, rot, p, mu, t);
+        *jac_out = jac;
+      }
+      return code;
     }
 #pragma unroll kUnrollD<D>
     for (int i = 0; i < D; ++i) {
@@ -753,14 +776,50 @@ __device__ __forceinline__ int project(const ConArgs& A, const Rot<D>& rot, Vec<
   return newton_project<C, D>(A, rot, q, p, jac_prev, t, jac_out, n_iters);
 }
 
+// A kernel instantiation may pin run-time selectors of the model / solver to constants (-1 = left to run time): the
+// fields of the kernel's private ConArgs copy are overwritten before everything is inlined, so every `switch` on them
+// folds away.  The general core tests ~20 wave-uniform selectors per step (target, metric kind, constraint, solver,
+// norms ...); each is a scalar compare + branch in a single wave's dependent instruction stream.
+struct SpecNone {
+  static constexpr int target = -1, metric_kind = -1, constr = -1, solver = -1, norm = -1, n_inner = -1;
+  static constexpr bool plain_steps = false;  // true: no per-chain step sizes / step counts
+};
+// BASELINE config c5 / the reference's README example: torus density on the torus, identity metric, Newton
+// projection, maximum norm, one inner step.
+struct SpecTorus {
+  static constexpr int target = MM_TARGET_TORUS, metric_kind = MM_METRIC_IDENTITY, constr = MM_CONSTR_TORUS,
+                       solver = MM_PROJ_NEWTON, norm = MM_NORM_LINF, n_inner = 1;
+  static constexpr bool plain_steps = false;
+};
+template <class SPEC>
+__device__ __forceinline__ void apply_spec(ConArgs& A) {
+  if constexpr (SPEC::target >= 0) A.target = SPEC::target;
+  if constexpr (SPEC::metric_kind >= 0) A.metric_kind = SPEC::metric_kind;
+  if constexpr (SPEC::constr >= 0) A.constr = SPEC::constr;
+  if constexpr (SPEC::solver >= 0) A.opts.solver = SPEC::solver;
+  if constexpr (SPEC::norm >= 0) {
+    A.opts.norm = SPEC::norm;
+    A.opts.rev_norm = SPEC::norm;
+  }
+  if constexpr (SPEC::n_inner >= 0) A.opts.n_inner = SPEC::n_inner;
+}
+template <class SPEC>
+inline bool spec_matches(const ConArgs& a) {
+  return (SPEC::target < 0 || a.target == SPEC::target) && (SPEC::metric_kind < 0 || a.metric_kind == SPEC::metric_kind) &&
+         (SPEC::constr < 0 || a.constr == SPEC::constr) && (SPEC::solver < 0 || a.opts.solver == SPEC::solver) &&
+         (SPEC::norm < 0 || (a.opts.norm == SPEC::norm && a.opts.rev_norm == SPEC::norm)) &&
+         (SPEC::n_inner < 0 || a.opts.n_inner == SPEC::n_inner);
+}
+
 // EXT = false is the plain dens_wrt_hausdorff=True Euclidean system (BASELINE config c5): the Gram-term and
 // Gaussian-split branches are compiled out (the flags are forced to zero before everything is inlined).
 // PAD = false: the system's dimension is the template capacity D (A.dim is forced to D so every stride and guard
 // folds away); PAD = true: A.dim <= D at run time, the extra coordinates are held at zero.
-template <int C, int D, bool EXT, bool PAD>
+template <int C, int D, bool EXT, bool PAD, class SPEC = SpecNone>
 __global__ __launch_bounds__(256) void constrained_leapfrog_kernel(ConArgs A) {
   const int64_t chain = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (chain >= A.n_chains) return;
+  apply_spec<SPEC>(A);
   if constexpr (!PAD) A.dim = D;
   if constexpr (!EXT) {
     A.ambient = 0;
@@ -917,7 +976,11 @@ int launch_cd(mm_ctx* ctx, const ConArgs& a, int which, double* h_out) {
     hipLaunchKernelGGL((project_momentum_kernel<C, D, PAD>), dim3(blocks), dim3(256), 0, ctx->stream, a);
   else if (a.ambient || a.gaussian)
     hipLaunchKernelGGL((constrained_leapfrog_kernel<C, D, true, PAD>), dim3(blocks), dim3(256), 0, ctx->stream, a);
-  else
+  else if (C == 1 && D == 3 && !PAD && spec_matches<SpecTorus>(a)) {
+    if constexpr (C == 1 && D == 3 && !PAD)
+      hipLaunchKernelGGL((constrained_leapfrog_kernel<1, 3, false, false, SpecTorus>), dim3(blocks), dim3(256), 0,
+                         ctx->stream, a);
+  } else
     hipLaunchKernelGGL((constrained_leapfrog_kernel<C, D, false, PAD>), dim3(blocks), dim3(256), 0, ctx->stream, a);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;

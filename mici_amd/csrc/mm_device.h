@@ -70,9 +70,52 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
+// ---- lean FP64 reciprocal / division / square root for well-scaled arguments ---------------------------------------
+// The compiler's IEEE expansions carry range scaling and special-case fix-ups (v_div_scale / v_div_fmas / v_div_fixup,
+// ldexp + class tests around v_rsq): 12-18 dependent instructions each, and the lane-per-chain kernels are bound by
+// exactly that - the length of one wave's dependent FP64 stream.  These versions are Newton iterations on v_rcp_f64 /
+// v_rsq_f64 with a final residual correction: results within 1 ulp for normal, non-extreme arguments; zero, infinite
+// and NaN arguments give inf / NaN as the expansions would (possibly a NaN where IEEE gives inf or 0 - every caller
+// treats both as "not finite"); subnormal arguments are NOT handled (nothing on this path produces them).
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double fdiv(double a, double b) {
+  const double r = rcp_nr(b);
+  const double q = a * r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+// s = sqrt(x) and rs = 1 / sqrt(x) from one v_rsq_f64 (Goldschmidt, two steps + a residual correction of s)
+__device__ __forceinline__ void sqrt_rsqrt(double x, double* s, double* rs) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  *s = __builtin_fma(d, h, g);
+  *rs = h + h;
+}
+__device__ __forceinline__ double fsqrt(double x) {
+  double s, rs;
+  sqrt_rsqrt(x, &s, &rs);
+  return s;
+}
+
 // max that propagates NaN (np.abs(x).max() semantics, solvers.py:25-27)
 __device__ __forceinline__ double nanmax(double a, double b) {
-  return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
+  // branch-free: v_max_f64 returns the other operand when one is a NaN, so the NaN case is patched in with one
+  // unordered compare (a + b is a NaN whenever either operand is).  The nested-ternary form compiled to three
+  // exec-mask regions per call - a norm of a D-vector sits in every solver iteration of every kernel.
+  const double m = __builtin_fmax(a, b);
+  return __builtin_isunordered(a, b) ? a + b : m;
 }
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -157,19 +200,21 @@ __device__ __forceinline__ double target_grad_elem(int target, const TargetAux& 
       // constrained kernel's per-step critical path (they were a third of its instructions).
       const double R = tp[0], r = tp[1], al = tp[2];
       const double x = q[0], y = q[1], z = q[2];
-      const double rho2 = x * x + y * y, rho = sqrt(rho2);
-      const double irho = 1.0 / rho;
+      const double rho2 = x * x + y * y;
+      double rho, irho;
+      sqrt_rsqrt(rho2, &rho, &irho);
       const double ct = x * irho, st = y * irho;            // cos theta, sin theta
       const double ct2 = ct * ct, st2 = st * st;
       const double s4 = 4.0 * st * ct * (ct2 - st2);        // sin 4 theta
       const double c4 = 1.0 - 8.0 * ct2 * st2;              // cos 4 theta
       const double u = rho - R;
-      const double iw = 1.0 / sqrt(u * u + z * z);
+      double w_, iw;
+      sqrt_rsqrt(u * u + z * z, &w_, &iw);
       const double sp = z * iw, cp = u * iw;                // sin phi, cos phi
       const double r_over_R = r / R;
       const double d1 = 1.0 + r_over_R * cp, d2 = 1.0 + al * s4 * cp;
-      const double id2 = 1.0 / d2;
-      const double dl_dphi = -r_over_R * sp / d1 + al * s4 * sp * id2;
+      const double id2 = rcp_nr(d2);
+      const double dl_dphi = -r_over_R * sp * rcp_nr(d1) + al * s4 * sp * id2;
       const double dl_dth = -4.0 * al * c4 * cp * id2;
       const double iw2 = iw * iw, irho2 = irho * irho;
       const double dphi_drho = -z * iw2, dphi_dz = u * iw2;
