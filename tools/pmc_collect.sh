@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the dominant kernel of a bench config (two PMC passes, own runs: no trace domains mixed in)
-#   bash tools/pmc_collect.sh c3 implicit_mfma_kernel ; bash tools/pmc_collect.sh c4 implicit_mfma_team_kernel
+#   bash tools/pmc_collect.sh c3 implicit_mfma_kernel ; bash tools/pmc_collect.sh c4 implicit_blk16_kernel
 cfg=$1; kern=$2
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$cfg
 mkdir -p $out

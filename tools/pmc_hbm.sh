@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the dominant kernel of a bench config from two separate rocprofv3 --pmc passes (no trace
 # domains mixed in), corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x 2).
-#   bash tools/pmc_hbm.sh c3 implicit_mfma_kernel ; bash tools/pmc_hbm.sh c4 implicit_mfma_team_kernel
+#   bash tools/pmc_hbm.sh c3 implicit_mfma_kernel ; bash tools/pmc_hbm.sh c4 implicit_blk16_kernel
 cfg=$1; kern=$2
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_hbm_$cfg
 mkdir -p $out

@@ -1,8 +1,73 @@
-set -x
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r01b
-python -m pytest tests -m gpu -q -x > gpurun_out/r01b/pytest_gpu.log 2>&1; tail -3 gpurun_out/r01b/pytest_gpu.log | grep -E "passed|failed|error"
-for c in c2 c2i c2iv c2bcss c3 c3b c4 c5; do python bench.py --config $c 2>gpurun_out/r01b/bench_$c.err | tail -1 > gpurun_out/r01b/bench_$c.json; cut -c1-130 gpurun_out/r01b/bench_$c.json; done
+#!/bin/bash
+# ONE script regenerates every measured file the bench line and DESIGN.md cite, from the binaries in the tree
+# (VERDICT r02 #5).  Run it on the GPU box; results land in gpurun_out/<round>p/ (gpurun merges that back), then
+#     bash tools/refresh_profiles.sh collect
+# on the build host copies the summaries into profiles/ with the round prefix.
+#     gpurun --timeout 1700 -- 'bash tools/refresh_profiles.sh'
+# What it produces (ROUND=r03 by default):
+#   <round>_gpu_tests.txt                 tail of `pytest -m gpu`
+#   <round>_bench_default.json            the exact default command, `python bench.py`
+#   <round>_rocprofv3_kernel_stats.csv    `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline`
+#   <round>_<cfg>_pmc_hbm.json            FETCH_SIZE / WRITE_SIZE passes (separate runs, gfx950 correction) - c2 c2i c2iv c3 c3b c4 c5
+#   <round>_<cfg>_sq_counters.json        SQ counters (two passes) - c2 c3 c3b c4 c5
+#   <round>_c4_ubench_blk16.txt, <round>_c3_ubench_mfma.txt   phase clocks of the two dense-Riemannian kernels
+#   <round>_fuzz_parity.txt               tools/fuzz_parity.py, three seeds x 80 cases
+#   <round>_c2iv_regimes.txt              c2(iv) launched five times in fresh processes: pass time vs kernel time
+ROUND=${ROUND:-r03}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+if [ "$1" = "collect" ]; then
+  src=$ROOT/gpurun_out/${ROUND}p
+  for f in $src/*; do
+    b=$(basename $f)
+    case $b in *.json|*.csv|*.txt) cp $f $ROOT/profiles/${ROUND}_$b;; esac
+  done
+  ls $ROOT/profiles/${ROUND}_* | wc -l
+  exit 0
+fi
+cd $ROOT
+O=$ROOT/gpurun_out/${ROUND}p; rm -rf $O; mkdir -p $O
+KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2iv:leapfrog_mfma_kernel c3:implicit_mfma_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel"
+
+python -m pytest tests -q -m gpu 2>&1 | tail -4 > $O/gpu_tests.txt; tail -2 $O/gpu_tests.txt
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-160 $O/bench_default.json
+
 cd /tmp && export TMPDIR=/tmp
-for c in c2 c3 c4; do rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r01b/prof_$c -o $c -- python $GRAFT_REPO_ROOT/bench.py --config $c --no-cpu-baseline --steps 5 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/r01b/prof_$c.log 2>&1; done
-ls -R $GRAFT_REPO_ROOT/gpurun_out/r01b | head -40
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o bench -- python $ROOT/bench.py --no-cpu-baseline > $O/prof_default.log 2>&1
+cd $ROOT
+f=$(find $O/prof_default -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/rocprofv3_kernel_stats.csv && head -9 $O/rocprofv3_kernel_stats.csv | cut -c1-150
+rm -rf $O/prof_default
+
+for pair in $KERNELS; do
+  cfg=${pair%%:*}; kern=${pair##*:}
+  bash tools/pmc_hbm.sh $cfg $kern > $O/pmc_hbm_$cfg.log 2>&1
+  [ -f gpurun_out/pmc_hbm_$cfg.json ] && mv gpurun_out/pmc_hbm_$cfg.json $O/${cfg}_pmc_hbm.json
+  python -c "
+import json; d=json.load(open('$O/${cfg}_pmc_hbm.json')); print('$cfg HBM traffic MB/launch %.2f over %d launches' % (d['traffic_bytes_per_launch']/1e6, len(d['FETCH_SIZE']['per_launch_values_KB'])))" 2>&1 | tail -1
+  rm -rf gpurun_out/pmc_hbm_$cfg $O/pmc_hbm_$cfg.log
+done
+for pair in $KERNELS; do
+  cfg=${pair%%:*}; kern=${pair##*:}
+  case $cfg in c2i|c2iv) continue;; esac
+  bash tools/pmc_collect.sh $cfg $kern > $O/sq_$cfg.log 2>&1
+  [ -f gpurun_out/pmc_$cfg/pmc_$cfg.json ] && mv gpurun_out/pmc_$cfg/pmc_$cfg.json $O/${cfg}_sq_counters.json && echo "$cfg SQ counters ok"
+  rm -rf gpurun_out/pmc_$cfg $O/sq_$cfg.log
+done
+
+python tools/ubench_blk16.py 2>&1 | grep -v "^{" > $O/c4_ubench_blk16.txt; tail -10 $O/c4_ubench_blk16.txt
+python tools/ubench_primitives.py > $O/c3_ubench_mfma.txt 2>&1; tail -10 $O/c3_ubench_mfma.txt
+
+for seed in 31 32 33; do
+  timeout 1200 python tools/fuzz_parity.py --seed $seed --cases 80 > $O/fuzz_$seed.log 2>&1
+  echo "seed $seed rc=$? $(tail -1 $O/fuzz_$seed.log)" >> $O/fuzz_parity.txt
+  grep "MISMATCH\|Traceback" -B2 $O/fuzz_$seed.log | head -10 >> $O/fuzz_parity.txt
+  rm -f $O/fuzz_$seed.log
+done
+cat $O/fuzz_parity.txt
+
+# c2(iv): five fresh processes - wall-clock per pass against the HIP-event kernel time of the same pass
+for i in 1 2 3 4 5; do
+  python bench.py --config c2iv --no-cpu-baseline --no-extra-configs 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.readline()); print('run $i: ms_per_pass %.3f  kernel_ms_per_launch %.3f' % (d['ms_per_step'], d['roofline']['kernel_ms_per_launch']))" >> $O/c2iv_regimes.txt
+done
+cat $O/c2iv_regimes.txt
+du -sh $O
