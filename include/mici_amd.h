@@ -78,7 +78,8 @@ typedef enum mm_constr { /* holonomic constraint, C = 1 */
   MM_CONSTR_CIRCLE = 3, /* q_0^2 + q_1^2 - 1                            */
   MM_CONSTR_LINEAR = 4, /* A q - b, C rows: params A[C*D] (row-major) then b[C]; C = n_constr_params / (D + 1) <= 8 */
   MM_CONSTR_SPHERE_PLANE = 5, /* two constraints: |q|^2 - 1 and n . q; params n[D], D >= 3 */
-  MM_CONSTR_SPHERE = 6  /* |q|^2 - 1 (the constrained system of the reference's adapter tests), D >= 2 */
+  MM_CONSTR_SPHERE = 6, /* |q|^2 - 1 (the constrained system of the reference's adapter tests), D >= 2 */
+  MM_CONSTR_USER = 100  /* user-supplied device code: mm_model_create_from_source, desc->n_constr rows, params: any */
 } mm_constr;
 
 /* Per-chain status: which reference exception the failed step would have raised (errors.py:6-35). */
@@ -113,6 +114,8 @@ typedef struct mm_model_desc {
   const double* metric;
   size_t n_metric;
   int32_t rmetric; /* position-dependent metric (Riemannian systems) */
+  int32_t n_constr; /* MM_CONSTR_USER: the number of constraint functions (1..8, < dim); ignored (may be 0) for the
+                     * built-in constraints, whose count follows from their kind.  Sits in what used to be padding. */
   const double* rmetric_params;
   size_t n_rmetric_params;
   int32_t constr;
@@ -184,16 +187,26 @@ int mm_ctx_elapsed_ms(mm_ctx* ctx, int slot_begin, int slot_end, double* ms);
 
 /* ---- model ------------------------------------------------------------------------------------------ */
 int mm_model_create(mm_ctx* ctx, const mm_model_desc* desc, mm_model** out);
-/* A model whose TARGET is user code - the reference's `neg_log_dens` / `grad_neg_log_dens` constructor arguments
- * (systems.py:107, 119) for a device: desc->target must be MM_TARGET_USER, desc->target_params any number of
- * doubles handed to the user functions, and `hip_source` HIP C++ text defining
- *     __device__ double mm_user_grad(const double* q, int i, int dim, const double* params);     // d nld / d q_i
- *     __device__ double mm_user_nld_term(const double* q, int i, int dim, const double* params); // nld = sum_i of it
- * (q: the chain's whole position vector).  The source is compiled for gfx950 with hipRTC when the model is created
- * (compile errors come back through mm_last_error) around the wave-per-chain kernels of an EuclideanMetricSystem:
- * mm_leapfrog_euclid, mm_composition_euclid, mm_hamiltonian, mm_dh_dmom, mm_sample_momentum, mm_momentum_refresh*
- * and mm_metropolis_accept* work on such a model (identity / diagonal / dense fixed metric); the Riemannian,
- * constrained and Gaussian-split system classes need more derivatives than these two functions and are refused. */
+/* A model with USER CODE in it - the reference's callable constructor arguments for a device.  `hip_source` is HIP C++
+ * text, compiled for gfx950 with hipRTC when the model is created (compile errors come back through mm_last_error):
+ *  * desc->target == MM_TARGET_USER - `neg_log_dens` / `grad_neg_log_dens` (systems.py:107, 119): the source defines
+ *        __device__ double mm_user_grad(const double* q, int i, int dim, const double* params);     // d nld / d q_i
+ *        __device__ double mm_user_nld_term(const double* q, int i, int dim, const double* params); // nld = sum_i of it
+ *    (q: the chain's whole position vector; params: desc->target_params).  On an EuclideanMetricSystem (identity /
+ *    diagonal / dense fixed metric) the wave-per-chain kernels are compiled around it: mm_leapfrog_euclid,
+ *    mm_composition_euclid, mm_hamiltonian, mm_dh_dmom, mm_sample_momentum, mm_momentum_refresh*, mm_metropolis_accept*.
+ *  * desc->constr == MM_CONSTR_USER - `constr` / `jacob_constr` of a ConstrainedEuclideanMetricSystem
+ *    (systems.py:786-792), desc->n_constr functions of the position, 1 <= n_constr <= 8, n_constr < dim <= 64:
+ *        __device__ void mm_user_constr(const double* q, int dim, const double* params, double* c);   // c[n_constr]
+ *        __device__ void mm_user_jacob(const double* q, int dim, const double* params, double* jac);  // jac[k*dim+i]
+ *    (params: desc->constr_params) and, only for dens_wrt_ambient / Gaussian-split systems (mhp_constr,
+ *    systems.py:1006-1008: out[i] = sum_{k,j} m[k*dim+j] d2 c_k / dq_j dq_i),
+ *        __device__ void mm_user_mhp_constr(const double* q, int dim, const double* params, const double* m, double* out);
+ *    The library compiles its constrained-leapfrog core (csrc/constrained_core.h: all three projection solvers,
+ *    n_inner, both density conventions) around them; mm_constrained_leapfrog, mm_hamiltonian, mm_sample_momentum,
+ *    mm_momentum_refresh* and mm_metropolis_accept* work on such a model.  Target and constraint may both be user code
+ *    (one source text defining all the functions).
+ * Riemannian systems take built-in metrics only. */
 int mm_model_create_from_source(mm_ctx* ctx, const mm_model_desc* desc, const char* hip_source, mm_model** out);
 int mm_model_destroy(mm_model* model);
 

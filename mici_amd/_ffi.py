@@ -30,6 +30,7 @@ class ModelDesc(C.Structure):
         ("metric", c_double_p),
         ("n_metric", C.c_size_t),
         ("rmetric", C.c_int32),
+        ("n_constr", C.c_int32),
         ("rmetric_params", c_double_p),
         ("n_rmetric_params", C.c_size_t),
         ("constr", C.c_int32),

@@ -4,6 +4,16 @@
 #pragma once
 #include "mm_device.h"
 
+#ifdef MM_RTC_BUILD
+// c[k] = constraint k at q;  jac[k * dim + i] = d c_k / d q_i;  out[i] = sum_{k,j} m[k * dim + j] d2 c_k / dq_j dq_i
+// (mhp_constr, systems.py:1006-1008: only systems with dens_wrt_hausdorff=False need it)
+__device__ void mm_user_constr(const double* q, int dim, const double* params, double* c);
+__device__ void mm_user_jacob(const double* q, int dim, const double* params, double* jac);
+#ifdef MM_USER_HAS_MHP
+__device__ void mm_user_mhp_constr(const double* q, int dim, const double* params, const double* m, double* out);
+#endif
+#endif
+
 namespace mmcon {
 
 // Loops over the D coordinates are fully unrolled for the exact kernels (D <= 8: every vector lives in
@@ -231,12 +241,19 @@ __device__ __forceinline__ Jac<C, D> minv_rows(const ConArgs& A, const Jac<C, D>
   return out;
 }
 
-// ---- built-in constraint functions -----------------------------------------------------------------------
+// ---- constraint functions: built in, or - in a translation unit compiled at run time around the user's source
+// (mm_rtc.hip, MM_RTC_BUILD) - the user's `constr` / `jacob_constr` (systems.py:786-792) --------------------------
 template <int C, int D>
 __device__ __forceinline__ CVec<C> constr_value(const ConArgs& A, const Vec<D>& q) {
   CVec<C> c;
 #pragma unroll
   for (int k = 0; k < C; ++k) c.v[k] = 0.0;
+#ifdef MM_RTC_BUILD
+  if (A.constr == MM_CONSTR_USER) {
+    ::mm_user_constr(q.v, A.dim, A.cparams, c.v);
+    return c;
+  }
+#endif
   if (A.constr == MM_CONSTR_LINEAR) {  // A q - b
 #pragma unroll
     for (int k = 0; k < C; ++k) {
@@ -281,6 +298,17 @@ __device__ __forceinline__ Jac<C, D> constr_jacob(const ConArgs& A, const Vec<D>
   for (int k = 0; k < C; ++k)
 #pragma unroll kUnrollD<D>
     for (int i = 0; i < D; ++i) j.r[k].v[i] = 0.0;
+#ifdef MM_RTC_BUILD
+  if (A.constr == MM_CONSTR_USER) {
+    double jj[C * D];
+    ::mm_user_jacob(q.v, A.dim, A.cparams, jj);
+#pragma unroll
+    for (int k = 0; k < C; ++k)
+#pragma unroll kUnrollD<D>
+      for (int i = 0; i < D; ++i) j.r[k].v[i] = (i < A.dim) ? jj[k * A.dim + i] : 0.0;
+    return j;
+  }
+#endif
   if (A.constr == MM_CONSTR_LINEAR) {
 #pragma unroll
     for (int k = 0; k < C; ++k)
@@ -323,6 +351,20 @@ __device__ __forceinline__ Vec<D> constr_hess_apply(const ConArgs& A, const Vec<
   Vec<D> out;
 #pragma unroll kUnrollD<D>
   for (int i = 0; i < D; ++i) out.v[i] = 0.0;
+#if defined(MM_RTC_BUILD) && defined(MM_USER_HAS_MHP)
+  if (A.constr == MM_CONSTR_USER) {
+    double mm[C * D], oo[D];
+#pragma unroll
+    for (int k = 0; k < C; ++k)
+#pragma unroll kUnrollD<D>
+      for (int i = 0; i < D; ++i)
+        if (i < A.dim) mm[k * A.dim + i] = m.r[k].v[i];
+    ::mm_user_mhp_constr(q.v, A.dim, A.cparams, mm, oo);
+#pragma unroll kUnrollD<D>
+    for (int i = 0; i < D; ++i) out.v[i] = (i < A.dim) ? oo[i] : 0.0;
+    return out;
+  }
+#endif
   if (A.constr == MM_CONSTR_LINEAR) return out;
   if constexpr (C == 2) {
 #pragma unroll kUnrollD<D>
@@ -816,7 +858,7 @@ inline bool spec_matches(const ConArgs& a) {
 // PAD = false: the system's dimension is the template capacity D (A.dim is forced to D so every stride and guard
 // folds away); PAD = true: A.dim <= D at run time, the extra coordinates are held at zero.
 template <int C, int D, bool EXT, bool PAD, class SPEC = SpecNone>
-__global__ __launch_bounds__(256) void constrained_leapfrog_kernel(ConArgs A) {
+__device__ __forceinline__ void constrained_leapfrog_body(ConArgs& A) {
   const int64_t chain = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (chain >= A.n_chains) return;
   apply_spec<SPEC>(A);
@@ -902,7 +944,7 @@ __global__ __launch_bounds__(256) void constrained_leapfrog_kernel(ConArgs A) {
 }
 
 template <int C, int D, bool PAD>
-__global__ __launch_bounds__(256) void project_momentum_kernel(ConArgs A) {
+__device__ __forceinline__ void project_momentum_body(ConArgs& A) {
   const int64_t chain = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (chain >= A.n_chains) return;
   if constexpr (!PAD) A.dim = D;
@@ -923,7 +965,7 @@ __global__ __launch_bounds__(256) void project_momentum_kernel(ConArgs A) {
 // h1's Gram term for dens_wrt_hausdorff=False: out[chain] += log_det_sqrt_gram = log|det gram| / 2
 // (systems.py:829-831, 853-856); NaN where the reference raises LinAlgError.
 template <int C, int D, bool PAD>
-__global__ __launch_bounds__(256) void add_log_det_sqrt_gram_kernel(ConArgs A, double* __restrict__ out) {
+__device__ __forceinline__ void add_log_det_sqrt_gram_body(ConArgs& A, double* __restrict__ out) {
   const int64_t chain = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (chain >= A.n_chains) return;
   if constexpr (!PAD) A.dim = D;
@@ -937,6 +979,20 @@ __global__ __launch_bounds__(256) void add_log_det_sqrt_gram_kernel(ConArgs A, d
   double v = __longlong_as_double(0x7ff8000000000000LL);
   if (gram_inverse<C>(A, gram, &inv, &ld)) v = 0.5 * ld;
   out[chain] += v;
+}
+
+#ifndef MM_RTC_BUILD  // ---- host side and the in-tree kernel instantiations --------------------------------------
+template <int C, int D, bool EXT, bool PAD, class SPEC = SpecNone>
+__global__ __launch_bounds__(256) void constrained_leapfrog_kernel(ConArgs A) {
+  constrained_leapfrog_body<C, D, EXT, PAD, SPEC>(A);
+}
+template <int C, int D, bool PAD>
+__global__ __launch_bounds__(256) void project_momentum_kernel(ConArgs A) {
+  project_momentum_body<C, D, PAD>(A);
+}
+template <int C, int D, bool PAD>
+__global__ __launch_bounds__(256) void add_log_det_sqrt_gram_kernel(ConArgs A, double* __restrict__ out) {
+  add_log_det_sqrt_gram_body<C, D, PAD>(A, out);
 }
 
 inline ConArgs make_args(const mm_model* m, mm_state* s) {
@@ -985,5 +1041,7 @@ int launch_cd(mm_ctx* ctx, const ConArgs& a, int which, double* h_out) {
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }
+
+#endif  // !MM_RTC_BUILD
 
 }  // namespace mmcon

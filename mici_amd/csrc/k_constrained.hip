@@ -52,6 +52,10 @@ int launch_c(mm_ctx* ctx, int dim, const ConArgs& a, int which, double* h_out) {
 }
 
 int launch(mm_ctx* ctx, const mm_model* m, const ConArgs& a, int which, double* h_out = nullptr) {
+  if (m->rtc_con_module) {  // user constraint / target: the core compiled around the user's source (mm_rtc.hip)
+    ConArgs copy = a;
+    return mm_rtc_launch_constrained(ctx, m, which, &copy, a.n_chains, h_out);
+  }
   if (m->target == MM_TARGET_FUNNEL) {
     mm_set_error(ctx, "constrained kernels: the funnel target needs a wave-collective gradient");
     return MM_ERR_UNSUPPORTED;

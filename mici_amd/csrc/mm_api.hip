@@ -231,17 +231,21 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
 int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
   MM_REQUIRE(nullptr, ctx != nullptr, "mm_model_create: ctx is NULL");
   MM_REQUIRE(ctx, d != nullptr && out != nullptr, "mm_model_create: NULL argument");
-  MM_REQUIRE(ctx, d->target != MM_TARGET_USER, "mm_model_create: a user target needs mm_model_create_from_source");
+  MM_REQUIRE(ctx, d->target != MM_TARGET_USER && d->constr != MM_CONSTR_USER,
+             "mm_model_create: user code (MM_TARGET_USER / MM_CONSTR_USER) needs mm_model_create_from_source");
   return model_create(ctx, d, nullptr, out);
 }
 
 int mm_model_create_from_source(mm_ctx* ctx, const mm_model_desc* d, const char* hip_source, mm_model** out) {
   MM_REQUIRE(nullptr, ctx != nullptr, "mm_model_create_from_source: ctx is NULL");
   MM_REQUIRE(ctx, d != nullptr && out != nullptr && hip_source != nullptr, "mm_model_create_from_source: NULL argument");
-  MM_REQUIRE(ctx, d->target == MM_TARGET_USER, "mm_model_create_from_source: desc->target must be MM_TARGET_USER");
-  MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE && d->constr == MM_CONSTR_NONE && !d->gaussian_split,
-             "mm_model_create_from_source: user targets are supported on EuclideanMetricSystem (identity / diagonal / "
-             "dense fixed metric) only");
+  MM_REQUIRE(ctx, d->target == MM_TARGET_USER || d->constr == MM_CONSTR_USER,
+             "mm_model_create_from_source: desc->target must be MM_TARGET_USER and / or desc->constr MM_CONSTR_USER");
+  MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE,
+             "mm_model_create_from_source: Riemannian systems take built-in targets and metrics only");
+  MM_REQUIRE(ctx, d->target != MM_TARGET_USER || !d->gaussian_split,
+             "mm_model_create_from_source: a user target is a density with respect to the Lebesgue measure (identity / "
+             "diagonal / dense fixed metric); the Gaussian-split system classes take built-in targets");
   return model_create(ctx, d, hip_source, out);
 }
 
@@ -286,6 +290,7 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
                   : d->constr == MM_CONSTR_LINEAR       ? d->n_constr_params
                   : d->constr == MM_CONSTR_SPHERE_PLANE ? (size_t)D
                   : d->constr == MM_CONSTR_SPHERE       ? 0
+                  : d->constr == MM_CONSTR_USER         ? d->n_constr_params
                                                         : (size_t)-1;
   MM_REQUIRE(ctx, need_c != (size_t)-1, "mm_model_create: unknown constraint id");
   int n_constr = d->constr == MM_CONSTR_NONE ? 0 : 1;
@@ -295,6 +300,11 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
     n_constr = (int)(need_c / (size_t)(D + 1));
     MM_REQUIRE(ctx, n_constr >= 1 && n_constr <= 8 && (n_constr < D || D == 1),
                "mm_model_create: linear constraint supports 1 <= C <= 8 rows, C < dim");
+  }
+  if (d->constr == MM_CONSTR_USER) {
+    n_constr = d->n_constr;
+    MM_REQUIRE(ctx, n_constr >= 1 && n_constr <= 8 && n_constr < D && D <= 64,
+               "mm_model_create_from_source: a user constraint needs 1 <= n_constr <= 8, n_constr < dim <= 64");
   }
   MM_REQUIRE(ctx, d->constr != MM_CONSTR_SPHERE || D >= 2, "sphere constraint needs dim >= 2");
   if (d->constr == MM_CONSTR_SPHERE_PLANE) {
@@ -415,7 +425,10 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
       }
     }
   }
-  if (rc == MM_OK && user_src) rc = mm_rtc_attach(ctx, m, user_src);
+  // user code: the Euclidean wave-per-chain kernels around a user target (h, unconstrained integrators), and for a
+  // constrained system the constrained-leapfrog core around the user constraint and / or target
+  if (rc == MM_OK && user_src && d->target == MM_TARGET_USER) rc = mm_rtc_attach(ctx, m, user_src);
+  if (rc == MM_OK && user_src && d->constr != MM_CONSTR_NONE) rc = mm_rtc_attach_constrained(ctx, m, user_src);
   if (rc != MM_OK) {
     mm_model_destroy(m);
     return rc;
@@ -854,9 +867,9 @@ int mm_constrained_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
 
 // System.h for every chain of s into d_out[N] (device): h1 + h2 of the model's system class.
 static int launch_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_out) {
-  if (m->target == MM_TARGET_USER) return mm_rtc_launch_hamiltonian(ctx, m, s, d_out);
-  int rc = (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 0, d_out, nullptr)
-                                           : mm_launch_euclid_hamiltonian(ctx, m, s, d_out);
+  int rc = (m->target == MM_TARGET_USER)     ? mm_rtc_launch_hamiltonian(ctx, m, s, d_out)
+           : (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 0, d_out, nullptr)
+                                             : mm_launch_euclid_hamiltonian(ctx, m, s, d_out);
   if (rc == MM_OK && m->dens_wrt_ambient) rc = mm_launch_constrained_add_log_det_sqrt_gram(ctx, m, s, d_out);
   return rc;
 }

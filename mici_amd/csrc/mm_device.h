@@ -3,7 +3,16 @@
 // Closed forms: SURVEY.md section 8d / Appendix A (NumPy twins in oracle/models.py).
 #pragma once
 
+#ifdef MM_RTC_BUILD
+// compiled at run time (hipRTC) around user source: no host headers, the ABI header comes from memory (mm_rtc.hip)
+#include "mici_amd.h"
+#ifdef MM_RTC_USER_TARGET
+__device__ double mm_user_grad(const double* q, int i, int dim, const double* params);
+__device__ double mm_user_nld_term(const double* q, int i, int dim, const double* params);
+#endif
+#else
 #include "mm_internal.h"
+#endif
 
 namespace mmdev {
 
@@ -190,6 +199,10 @@ __device__ __forceinline__ double target_grad_elem(int target, const TargetAux& 
       if (i < dim - 1) g -= 4.0 * q[i] * (q[i + 1] - q[i] * q[i]);
       return g;
     }
+#if defined(MM_RTC_BUILD) && defined(MM_RTC_USER_TARGET)
+    case MM_TARGET_USER:
+      return mm_user_grad(q, i, dim, tp);
+#endif
     case MM_TARGET_FUNNEL: if constexpr (TRIG) {
       if (i == 0) return q[0] / 9.0 + 0.5 * (dim - 1) - 0.5 * a.s1 * a.s0;
       return a.s1 * tp[i - 1] * q[i];

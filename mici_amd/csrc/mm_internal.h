@@ -56,6 +56,10 @@ struct mm_model {
   void* rtc_module = nullptr;
   void* rtc_integrate = nullptr;
   void* rtc_hamiltonian = nullptr;
+  void* rtc_con_module = nullptr;  // constrained system with user code: constrained_core.h compiled around it
+  void* rtc_con_step = nullptr;
+  void* rtc_con_project = nullptr;
+  void* rtc_con_logdet = nullptr;
   double h_target_params[4] = {0, 0, 0, 0};  // first few params host-side (scalars)
   double h_rmetric_params[4] = {0, 0, 0, 0};
   double h_constr_params[4] = {0, 0, 0, 0};
@@ -128,6 +132,8 @@ int mm_launch_dh_dmom(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_out
 int mm_launch_sample_momentum(mm_ctx* ctx, const mm_model* m, mm_state* s, const double* d_z);
 int mm_rtc_attach(mm_ctx* ctx, mm_model* m, const char* user_src);
 void mm_rtc_detach(mm_model* m);
+int mm_rtc_attach_constrained(mm_ctx* ctx, mm_model* m, const char* user_src);
+int mm_rtc_launch_constrained(mm_ctx* ctx, const mm_model* m, int which, void* con_args, int64_t n_chains, double* d_out);
 int mm_rtc_launch_integrate(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_comp_coefs* cf);
 int mm_rtc_launch_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_h);
 int mm_team_padded_dim(int dim);  // k_implicit_large.hip: leading dimension of the padded rank-one base matrix

@@ -16,6 +16,7 @@ TARGET_USER = 100
 METRIC_IDENTITY, METRIC_DIAG, METRIC_DENSE = 0, 1, 2
 RMETRIC_NONE, RMETRIC_RANK1, RMETRIC_DIAGQUAD, RMETRIC_SOFTABS = 0, 1, 2, 3
 CONSTR_NONE, CONSTR_TORUS, CONSTR_FIRST, CONSTR_CIRCLE, CONSTR_LINEAR, CONSTR_SPHERE_PLANE, CONSTR_SPHERE = 0, 1, 2, 3, 4, 5, 6
+CONSTR_USER = 100
 
 
 def _f64(a):
@@ -136,6 +137,30 @@ class Constraint:
     def __init__(self, cid, params=()):
         self.cid = int(cid)
         self.params = _f64(params).ravel()
+
+
+class UserConstraint(Constraint):
+    """A constraint defined by the USER as HIP device code - the device-side form of the reference's ``constr`` /
+    ``jacob_constr`` (and, for ``dens_wrt_hausdorff=False`` systems, ``mhp_constr``) constructor arguments
+    (systems.py:786-792, 1006-1008).  ``source`` must define
+
+        __device__ void mm_user_constr(const double* q, int dim, const double* params, double* c);    // c[n_constr]
+        __device__ void mm_user_jacob(const double* q, int dim, const double* params, double* jac);   // jac[k*dim + i]
+
+    and for ``dens_wrt_hausdorff=False`` / Gaussian-split systems also
+
+        __device__ void mm_user_mhp_constr(const double* q, int dim, const double* params, const double* m, double* out);
+        // out[i] = sum_{k,j} m[k*dim + j] d2 c_k / dq_j dq_i
+
+    It is compiled for gfx950 (hipRTC) together with the library's constrained-leapfrog core when the system's
+    device model is created; ``params`` are handed to all three.  1 <= n_constr <= 8, n_constr < dim <= 64."""
+
+    def __init__(self, n_constr, source, params=()):
+        super().__init__(CONSTR_USER, params)
+        if not isinstance(source, str) or "mm_user_constr" not in source or "mm_user_jacob" not in source:
+            raise ValueError("source must define mm_user_constr and mm_user_jacob (see the class docstring)")
+        self.n_constr = int(n_constr)
+        self.source = source
 
 
 class TorusConstr(Constraint):

@@ -153,7 +153,8 @@ class DeviceModel:
     """Device copy of a built-in model (target + fixed metric + Riemannian metric + constraint)."""
 
     def __init__(self, ctx, dim, target, metric_kind=0, metric=None, rmetric=0, rmetric_params=None,
-                 constr=0, constr_params=None, gaussian_split=False, dens_wrt_ambient=False):
+                 constr=0, constr_params=None, gaussian_split=False, dens_wrt_ambient=False, n_constr=0,
+                 constr_source=None):
         self.ctx = ctx
         self._lib = ctx._lib
         self._keep = []
@@ -173,11 +174,14 @@ class DeviceModel:
         d.rmetric = rmetric
         d.rmetric_params, d.n_rmetric_params = arr(rmetric_params)
         d.constr = constr
+        d.n_constr = int(n_constr)
         d.dens_wrt_ambient = int(bool(dens_wrt_ambient))
         d.constr_params, d.n_constr_params = arr(constr_params)
         h = C.c_void_p()
-        source = getattr(target, "source", None)
-        if source is not None:  # user-defined target: compiled by hipRTC inside the library
+        # user-defined target and / or constraint: ONE source text, compiled by hipRTC inside the library
+        sources = [t for t in (getattr(target, "source", None), constr_source) if t is not None]
+        source = "\n".join(sources) if sources else None
+        if source is not None:
             _ffi.check(self._lib.mm_model_create_from_source(ctx.handle, C.byref(d), source.encode(), C.byref(h)),
                        ctx.handle, "mm_model_create_from_source")
         else:

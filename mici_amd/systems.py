@@ -241,7 +241,9 @@ class DenseConstrainedEuclideanMetricSystem(EuclideanMetricSystem):
     def _model_args(self):
         args = EuclideanMetricSystem._model_args(self)
         args.update(constr=self.constraint.cid, constr_params=self.constraint.params,
-                    dens_wrt_ambient=not self.dens_wrt_hausdorff)
+                    dens_wrt_ambient=not self.dens_wrt_hausdorff,
+                    n_constr=getattr(self.constraint, "n_constr", 0),
+                    constr_source=getattr(self.constraint, "source", None))
         return args
 
 

@@ -431,6 +431,55 @@ def make_spd(dim, rng):
     return a @ a.T / dim + np.eye(dim)
 
 
+CONSTR_USER = 100
+
+
+class EllipsoidSaddleConstr:
+    """Two constraints that are NOT built into the device library (they reach it as user HIP source, tests/
+    test_gpu_user_target.py):  c_0 = sum_i a_i q_i^2 - 1,  c_1 = q_0 q_1 - q_2 + kappa q_3^3   (dim >= 4)."""
+    cid = CONSTR_USER
+    n_constr = 2
+
+    def __init__(self, a, kappa=0.3):
+        self.a = np.asarray(a, dtype=np.float64)
+        self.kappa = float(kappa)
+
+    def params(self):
+        return np.concatenate([self.a, [self.kappa]])
+
+    def constr(self, q):
+        return np.array([self.a @ (q * q) - 1.0, q[0] * q[1] - q[2] + self.kappa * q[3] ** 3])
+
+    def jacob_constr(self, q):
+        j = np.zeros((2, q.shape[0]))
+        j[0] = 2.0 * self.a * q
+        j[1, 0], j[1, 1], j[1, 2], j[1, 3] = q[1], q[0], -1.0, 3.0 * self.kappa * q[3] ** 2
+        return j
+
+    def mhp_constr(self, q):
+        def mhp(m):
+            out = 2.0 * self.a * m[0]
+            out[0] += m[1, 1]
+            out[1] += m[1, 0]
+            out[3] += 6.0 * self.kappa * q[3] * m[1, 3]
+            return out
+        return mhp
+
+    def init(self, n, rng):
+        """Points on the manifold: Gauss-Newton projection of random points."""
+        d = self.a.shape[0]
+        out = np.empty((n, d))
+        for c in range(n):
+            q = rng.standard_normal(d) / np.sqrt(self.a.sum())
+            for _ in range(100):
+                j, r = self.jacob_constr(q), self.constr(q)
+                if np.max(np.abs(r)) < 1e-14:
+                    break
+                q = q - j.T @ np.linalg.solve(j @ j.T, r)
+            out[c] = q
+        return out
+
+
 def torus_init(n, rng, R=1.0, r=0.5):
     """Initial positions on the torus from (theta, phi) ~ U(0, 2pi) (README.md:344-355)."""
     theta, phi = rng.uniform(0, 2 * np.pi, size=(2, n))
@@ -478,6 +527,9 @@ def rmetric_from_id(mid, params, dim):
 
 def constr_from_id(cid, params, dim=None):
     cid = int(cid)
+    if cid == CONSTR_USER:  # the one constraint of the fixtures that the device library only knows as user source
+        params = np.asarray(params, dtype=np.float64)
+        return EllipsoidSaddleConstr(params[:-1], params[-1])
     if cid == CONSTR_LINEAR:
         params = np.asarray(params, dtype=np.float64)
         c = params.size // (dim + 1)

@@ -19,7 +19,11 @@ pytestmark = pytest.mark.gpu
 def build(g):
     n, d = g["q0"].shape
     target = models.target_from_id(g["target"], g["target_params"], d)
-    constr = models.constr_from_id(g["constr"], g["constr_params"], g["q0"].shape[1])
+    if int(g["constr"]) == models.CONSTR_USER:  # not built in: reaches the library as HIP source (hipRTC)
+        from user_sources import ELLIPSOID_SADDLE
+        constr = models.UserConstraint(2, ELLIPSOID_SADDLE, g["constr_params"])
+    else:
+        constr = models.constr_from_id(g["constr"], g["constr_params"], g["q0"].shape[1])
     mk = int(g["metric_kind"])
     metric = None if mk == models.METRIC_IDENTITY else g["metric"]
     variant = str(g.get("variant", "hausdorff"))

@@ -130,3 +130,76 @@ def test_compile_errors_and_unsupported_systems_fail_loudly():
     with pytest.raises((DeviceError, TypeError, ValueError)):
         sysr = systems.DenseRiemannianMetricSystem(models.UserTarget(4, BANANA_SRC), models.DiagQuadMetric(4))
         integrators.ImplicitLeapfrogIntegrator(sysr, 0.1).step_batch(np.zeros((1, 4)), np.ones((1, 4)), 1, 1)
+
+
+# ---- user CONSTRAINTS (reference systems.py:786-792: `constr` / `jacob_constr` are callables) -----------
+def test_torus_constraint_as_user_source_reproduces_the_builtin():
+    """The built-in torus constraint written as user source (with the library's own sqrt / reciprocal helper, which the
+    run-time translation unit can call) goes through the SAME constrained-leapfrog core, compiled at run time: states,
+    statuses, step counts and Newton iteration counts equal the built-in kernel's."""
+    from oracle import models as omdl
+    from user_sources import TORUS_AS_USER
+
+    rng = np.random.default_rng(5)
+    n, h, steps = 512, 0.1, 30
+    q0 = omdl.torus_init(n, rng)
+    builtin = systems.DenseConstrainedEuclideanMetricSystem(models.Torus(), models.TorusConstr())
+    user = systems.DenseConstrainedEuclideanMetricSystem(models.Torus(), models.UserConstraint(1, TORUS_AS_USER, [1.0, 0.5]))
+    z = rng.standard_normal((n, 3))
+    p0 = builtin.sample_momentum_batch(q0, z)
+    assert np.array_equal(user.sample_momentum_batch(q0, z), p0)  # the cotangent projection, run-time compiled
+    ib = integrators.ConstrainedLeapfrogIntegrator(builtin, h)
+    iu = integrators.ConstrainedLeapfrogIntegrator(user, h)
+    qb, pb, sb, nb = ib.step_batch(q0, p0, 1, n_steps=steps)
+    qu, pu, su, nu = iu.step_batch(q0, p0, 1, n_steps=steps)
+    assert np.array_equal(sb, su) and np.array_equal(nb, nu)
+    assert ib.last_counters["n_newton_iters"] == iu.last_counters["n_newton_iters"]
+    # same arithmetic, but two different instantiations of the core (selectors folded at compile time there, tested
+    # at run time here): fused-multiply-add contraction may differ by an ulp per operation
+    assert_close(qu, qb, 1e-12, "positions")
+    assert_close(pu, pb, 1e-12, "momenta")
+    assert_close(user.h_batch(qu, pu), builtin.h_batch(qb, pb), 1e-12, "hamiltonian")
+
+
+def test_user_constraint_errors_fail_loudly():
+    from user_sources import ELLIPSOID_SADDLE
+
+    with pytest.raises(ValueError):
+        models.UserConstraint(1, "__device__ void f() {}")
+    broken = models.UserConstraint(2, ELLIPSOID_SADDLE.replace("c[0] = s - 1.0;", "c[0] = s - undefined_thing;"),
+                                   np.ones(6))
+    with pytest.raises(DeviceError, match="undefined_thing"):
+        systems.DenseConstrainedEuclideanMetricSystem(models.Poly(5, 0.5, 0.25), broken).device_model()
+    with pytest.raises(DeviceError, match="n_constr"):  # as many constraints as dimensions
+        systems.DenseConstrainedEuclideanMetricSystem(
+            models.Poly(2, 0.5, 0.25), models.UserConstraint(2, ELLIPSOID_SADDLE, np.ones(3))).device_model()
+
+
+def test_device_transitions_run_on_a_user_constraint():
+    """Static HMC with device draws on the user-constrained system: the chains stay on the manifold."""
+    from oracle import models as omdl
+    from user_sources import ELLIPSOID_SADDLE
+
+    rng = np.random.default_rng(8)
+    d, n = 5, 256
+    con = omdl.EllipsoidSaddleConstr(np.exp(0.3 * rng.standard_normal(d)), 0.3)
+    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(d, 0.5, 0.25),
+                                                           models.UserConstraint(2, ELLIPSOID_SADDLE, con.params()))
+    integ = integrators.ConstrainedLeapfrogIntegrator(system, 0.1)
+    tr = transitions.MetropolisStaticIntegrationTransition(system, integ, 5)
+    mom = transitions.IndependentMomentumTransition(system)
+    ctx = default_context()
+    batch = DeviceBatch(ctx, n, d)
+    q0 = con.init(n, rng)
+    batch.upload(q0, np.zeros((n, d)), np.ones(n, dtype=np.int8))
+    batch.set_rng(12, 0)
+    acc = []
+    for t in range(10):
+        mom.sample_batch_device(batch, t)
+        acc.append(tr.sample_batch_device(batch, t)["accept_stat"].mean())
+    q, p, _ = batch.download()
+    assert np.mean(acc) > 0.6
+    assert np.max(np.abs([con.constr(x) for x in q])) < 1e-8
+    assert np.max(np.abs([con.jacob_constr(x) @ y for x, y in zip(q, p)])) < 1e-8  # momenta in the cotangent space
+    assert np.max(np.abs(q - q0)) > 0.05  # and the chains moved
+    batch.close()

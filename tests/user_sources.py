@@ -1,0 +1,50 @@
+"""HIP source of the user-defined model parts the GPU tests hand to the library (compiled there with hipRTC).
+Each text is the device-side form of a NumPy twin in oracle/models.py, which the reference itself ran when the
+fixtures were recorded (tools/gen_golden.py)."""
+
+# oracle/models.py EllipsoidSaddleConstr: c_0 = sum_i a_i q_i^2 - 1, c_1 = q_0 q_1 - q_2 + kappa q_3^3; params = a[dim], kappa
+ELLIPSOID_SADDLE = r"""
+__device__ void mm_user_constr(const double* q, int dim, const double* params, double* c) {
+  double s = 0.0;
+  for (int i = 0; i < dim; ++i) s += params[i] * (q[i] * q[i]);
+  c[0] = s - 1.0;
+  c[1] = q[0] * q[1] - q[2] + params[dim] * (q[3] * q[3] * q[3]);
+}
+__device__ void mm_user_jacob(const double* q, int dim, const double* params, double* jac) {
+  for (int i = 0; i < dim; ++i) {
+    jac[i] = 2.0 * params[i] * q[i];
+    jac[dim + i] = 0.0;
+  }
+  jac[dim + 0] = q[1];
+  jac[dim + 1] = q[0];
+  jac[dim + 2] = -1.0;
+  jac[dim + 3] = 3.0 * params[dim] * (q[3] * q[3]);
+}
+#ifdef MM_USER_HAS_MHP
+__device__ void mm_user_mhp_constr(const double* q, int dim, const double* params, const double* m, double* out) {
+  for (int i = 0; i < dim; ++i) out[i] = 2.0 * params[i] * m[i];
+  out[0] += m[dim + 1];
+  out[1] += m[dim + 0];
+  out[3] += 6.0 * params[dim] * q[3] * m[dim + 3];
+}
+#endif
+"""
+
+# the built-in torus constraint (csrc/constrained_core.h constr_value / constr_jacob) written as user source with the
+# library's own arithmetic: must reproduce the built-in kernels
+TORUS_AS_USER = r"""
+__device__ void mm_user_constr(const double* q, int dim, const double* params, double* c) {
+  double rho, irho;
+  mmdev::sqrt_rsqrt(q[0] * q[0] + q[1] * q[1], &rho, &irho);
+  const double dr = rho - params[0];
+  c[0] = dr * dr + q[2] * q[2] - params[1] * params[1];
+}
+__device__ void mm_user_jacob(const double* q, int dim, const double* params, double* jac) {
+  double rho, irho;
+  mmdev::sqrt_rsqrt(q[0] * q[0] + q[1] * q[1], &rho, &irho);
+  const double f = 2.0 * (rho - params[0]) * irho;
+  jac[0] = f * q[0];
+  jac[1] = f * q[1];
+  jac[2] = 2.0 * q[2];
+}
+"""

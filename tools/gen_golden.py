@@ -1142,6 +1142,20 @@ def main():
                   else mdl.make_spd(d, r))
         add_constrained(name, mdl.Poly(d, 1.0, 0.25), mdl.LinearConstr(a, b), mk, metric, q0, h, cps, r=r, **kw)
 
+    # ---- constraints that are not built into the device library: they reach it as USER SOURCE compiled by hipRTC
+    #      (tests/test_gpu_user_target.py); here the reference and the oracle run their NumPy twin ---------------------
+    def add_user_constrained(name, d, n, mk, h, cps, **kw):
+        r = case_rng(name)
+        con = mdl.EllipsoidSaddleConstr(np.exp(0.3 * r.standard_normal(d)), 0.3)
+        metric = None if mk == mdl.METRIC_IDENTITY else (np.exp(0.2 * r.standard_normal(d)) if mk == mdl.METRIC_DIAG
+                                                         else mdl.make_spd(d, r))
+        add_constrained(name, mdl.Poly(d, 0.5, 0.25), con, mk, metric, con.init(n, r), h, cps, r=r, **kw)
+
+    add_user_constrained("constrained_user_ellipsoid_d5", 5, 6, mdl.METRIC_DENSE, 0.1, [1, 5, 20])
+    add_user_constrained("constrained_user_ellipsoid_ambient_d6", 6, 5, mdl.METRIC_DIAG, 0.08, [1, 5, 20], variant="ambient")
+    add_user_constrained("constrained_user_ellipsoid_d12_quasi", 12, 4, mdl.METRIC_IDENTITY, 0.1, [1, 5, 20], proj_solver=1)
+    add_user_constrained("constrained_user_ellipsoid_d5_fail_bigstep", 5, 6, mdl.METRIC_IDENTITY, 1.5, [1, 3])
+
     wide_linear("constrained_c4_linear_dense_d32", 32, 4, 4, mdl.METRIC_DENSE, 0.1, [1, 5, 20])
     wide_linear("constrained_c8_linear_diag_d64_quasi", 64, 8, 3, mdl.METRIC_DIAG, 0.1, [1, 5], proj_solver=1)
     wide_linear("constrained_c5_linear_ambient_d20", 20, 5, 4, mdl.METRIC_DENSE, 0.1, [1, 5, 20], variant="ambient")
