@@ -231,18 +231,22 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
 int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
   MM_REQUIRE(nullptr, ctx != nullptr, "mm_model_create: ctx is NULL");
   MM_REQUIRE(ctx, d != nullptr && out != nullptr, "mm_model_create: NULL argument");
-  MM_REQUIRE(ctx, d->target != MM_TARGET_USER && d->constr != MM_CONSTR_USER,
-             "mm_model_create: user code (MM_TARGET_USER / MM_CONSTR_USER) needs mm_model_create_from_source");
+  MM_REQUIRE(ctx, d->target != MM_TARGET_USER && d->constr != MM_CONSTR_USER && d->rmetric != MM_RMETRIC_USER,
+             "mm_model_create: user code (MM_TARGET_USER / MM_CONSTR_USER / MM_RMETRIC_USER) needs "
+             "mm_model_create_from_source");
   return model_create(ctx, d, nullptr, out);
 }
 
 int mm_model_create_from_source(mm_ctx* ctx, const mm_model_desc* d, const char* hip_source, mm_model** out) {
   MM_REQUIRE(nullptr, ctx != nullptr, "mm_model_create_from_source: ctx is NULL");
   MM_REQUIRE(ctx, d != nullptr && out != nullptr && hip_source != nullptr, "mm_model_create_from_source: NULL argument");
-  MM_REQUIRE(ctx, d->target == MM_TARGET_USER || d->constr == MM_CONSTR_USER,
-             "mm_model_create_from_source: desc->target must be MM_TARGET_USER and / or desc->constr MM_CONSTR_USER");
-  MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE,
-             "mm_model_create_from_source: Riemannian systems take built-in targets and metrics only");
+  MM_REQUIRE(ctx, d->target == MM_TARGET_USER || d->constr == MM_CONSTR_USER || d->rmetric == MM_RMETRIC_USER,
+             "mm_model_create_from_source: one of desc->target / constr / rmetric must be the _USER id");
+  MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE || d->rmetric == MM_RMETRIC_USER,
+             "mm_model_create_from_source: a user target on a Riemannian system needs a user metric too (the built-in "
+             "metrics' kernels are compiled ahead of time around the built-in targets)");
+  MM_REQUIRE(ctx, d->rmetric != MM_RMETRIC_USER || d->dim <= 32,
+             "mm_model_create_from_source: user metrics run on the wave-per-chain kernels, dim <= 32");
   MM_REQUIRE(ctx, d->target != MM_TARGET_USER || !d->gaussian_split,
              "mm_model_create_from_source: a user target is a density with respect to the Lebesgue measure (identity / "
              "diagonal / dense fixed metric); the Gaussian-split system classes take built-in targets");
@@ -277,6 +281,7 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
                   : d->rmetric == MM_RMETRIC_RANK1    ? (size_t)D * D
                   : d->rmetric == MM_RMETRIC_DIAGQUAD ? 0
                   : d->rmetric == MM_RMETRIC_SOFTABS  ? 1
+                  : d->rmetric == MM_RMETRIC_USER     ? d->n_rmetric_params
                                                       : (size_t)-1;
   MM_REQUIRE(ctx, need_r != (size_t)-1, "mm_model_create: unknown Riemannian metric id");
   MM_REQUIRE(ctx, d->n_rmetric_params == need_r && (need_r == 0 || d->rmetric_params),
@@ -427,7 +432,9 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
   }
   // user code: the Euclidean wave-per-chain kernels around a user target (h, unconstrained integrators), and for a
   // constrained system the constrained-leapfrog core around the user constraint and / or target
-  if (rc == MM_OK && user_src && d->target == MM_TARGET_USER) rc = mm_rtc_attach(ctx, m, user_src);
+  if (rc == MM_OK && user_src && d->rmetric == MM_RMETRIC_USER) rc = mm_rtc_attach_riemann(ctx, m, user_src);
+  if (rc == MM_OK && user_src && d->target == MM_TARGET_USER && d->rmetric == MM_RMETRIC_NONE)
+    rc = mm_rtc_attach(ctx, m, user_src);
   if (rc == MM_OK && user_src && d->constr != MM_CONSTR_NONE) rc = mm_rtc_attach_constrained(ctx, m, user_src);
   if (rc != MM_OK) {
     mm_model_destroy(m);
@@ -828,8 +835,9 @@ int mm_implicit_midpoint(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, 
   MM_REQUIRE(ctx, n_steps >= 0, "mm_implicit_midpoint: n_steps < 0");
   mm_fp_opts o = {1e-9, 1e10, 100, MM_NORM_LINF, MM_FP_DIRECT, MM_NORM_LINF, 2e-8};
   if (opts) o = *opts;
-  if (m->target == MM_TARGET_USER) {
-    mm_set_error(ctx, "mm_implicit_midpoint: user-defined targets run on the explicit Euclidean integrators only");
+  if (m->target == MM_TARGET_USER && m->rmetric != MM_RMETRIC_USER) {
+    mm_set_error(ctx, "mm_implicit_midpoint: on Euclidean-metric systems user-defined targets run on the explicit "
+                      "integrators only");
     return MM_ERR_UNSUPPORTED;
   }
   MM_REQUIRE(ctx, o.max_iters >= 0 && (o.norm == 0 || o.norm == 1) && (o.rev_norm == 0 || o.rev_norm == 1) &&
@@ -867,8 +875,8 @@ int mm_constrained_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
 
 // System.h for every chain of s into d_out[N] (device): h1 + h2 of the model's system class.
 static int launch_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_out) {
-  int rc = (m->target == MM_TARGET_USER)     ? mm_rtc_launch_hamiltonian(ctx, m, s, d_out)
-           : (m->rmetric != MM_RMETRIC_NONE) ? mm_launch_riemann_aux(ctx, m, s, 0, d_out, nullptr)
+  int rc = (m->rmetric != MM_RMETRIC_NONE)   ? mm_launch_riemann_aux(ctx, m, s, 0, d_out, nullptr)
+           : (m->target == MM_TARGET_USER)   ? mm_rtc_launch_hamiltonian(ctx, m, s, d_out)
                                              : mm_launch_euclid_hamiltonian(ctx, m, s, d_out);
   if (rc == MM_OK && m->dens_wrt_ambient) rc = mm_launch_constrained_add_log_det_sqrt_gram(ctx, m, s, d_out);
   return rc;

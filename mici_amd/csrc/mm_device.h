@@ -266,6 +266,10 @@ __device__ __forceinline__ double target_nld_elem(int target, const TargetAux& a
       }
       return v;
     }
+#if defined(MM_RTC_BUILD) && defined(MM_RTC_USER_TARGET)
+    case MM_TARGET_USER:
+      return mm_user_nld_term(q, i, dim, tp);
+#endif
     case MM_TARGET_FUNNEL:
       return i == 0 ? q[0] * q[0] / 18.0 + 0.5 * (dim - 1) * q[0] + 0.5 * a.s1 * a.s0 : 0.0;
     case MM_TARGET_TORUS: if constexpr (TRIG) {

@@ -60,6 +60,8 @@ struct mm_model {
   void* rtc_con_step = nullptr;
   void* rtc_con_project = nullptr;
   void* rtc_con_logdet = nullptr;
+  void* rtc_riem_module = nullptr;  // dense-Riemannian system with a user metric: implicit_wave.h compiled around it
+  void* rtc_riem_fn[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // step, midpoint, h, dh_dmom, sample_momentum
   double h_target_params[4] = {0, 0, 0, 0};  // first few params host-side (scalars)
   double h_rmetric_params[4] = {0, 0, 0, 0};
   double h_constr_params[4] = {0, 0, 0, 0};
@@ -133,6 +135,8 @@ int mm_launch_sample_momentum(mm_ctx* ctx, const mm_model* m, mm_state* s, const
 int mm_rtc_attach(mm_ctx* ctx, mm_model* m, const char* user_src);
 void mm_rtc_detach(mm_model* m);
 int mm_rtc_attach_constrained(mm_ctx* ctx, mm_model* m, const char* user_src);
+int mm_rtc_attach_riemann(mm_ctx* ctx, mm_model* m, const char* user_src);
+int mm_rtc_launch_riemann(mm_ctx* ctx, const mm_model* m, int which, void* implicit_args, int64_t n_chains);
 int mm_rtc_launch_constrained(mm_ctx* ctx, const mm_model* m, int which, void* con_args, int64_t n_chains, double* d_out);
 int mm_rtc_launch_integrate(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_comp_coefs* cf);
 int mm_rtc_launch_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_h);

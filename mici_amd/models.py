@@ -116,6 +116,27 @@ class RiemannianMetric:
         self.params = _f64(params).ravel()
 
 
+RMETRIC_USER = 100
+
+
+class UserMetric(RiemannianMetric):
+    """A position-dependent metric defined by the USER as HIP device code - the device-side form of the reference's
+    ``metric_func`` / ``vjp_metric_func`` constructor arguments (systems.py:1322-1358).  ``source`` must define
+
+        __device__ double mm_user_metric(const double* q, int i, int j, int dim, const double* params);  // M(q)_ij
+        __device__ double mm_user_vjp(const double* q, const MmMat& V, int k, int dim, const double* params);
+        // element k of vjp_metric_func(q)(V) = sum_ij V(i, j) d M_ij / d q_k for a symmetric V read as V(i, j)
+
+    and is compiled for gfx950 (hipRTC) with the library's wave-per-chain implicit kernels when the system's device
+    model is created; ``params`` are handed to both.  ``dim`` <= 32."""
+
+    def __init__(self, dim, source, params=()):
+        super().__init__(RMETRIC_USER, dim, params)
+        if not isinstance(source, str) or "mm_user_metric" not in source or "mm_user_vjp" not in source:
+            raise ValueError("source must define mm_user_metric and mm_user_vjp (see the class docstring)")
+        self.source = source
+
+
 class Rank1Metric(RiemannianMetric):
     """M(q) = B + q q^T / D."""
 

@@ -154,7 +154,7 @@ class DeviceModel:
 
     def __init__(self, ctx, dim, target, metric_kind=0, metric=None, rmetric=0, rmetric_params=None,
                  constr=0, constr_params=None, gaussian_split=False, dens_wrt_ambient=False, n_constr=0,
-                 constr_source=None):
+                 constr_source=None, rmetric_source=None):
         self.ctx = ctx
         self._lib = ctx._lib
         self._keep = []
@@ -178,8 +178,8 @@ class DeviceModel:
         d.dens_wrt_ambient = int(bool(dens_wrt_ambient))
         d.constr_params, d.n_constr_params = arr(constr_params)
         h = C.c_void_p()
-        # user-defined target and / or constraint: ONE source text, compiled by hipRTC inside the library
-        sources = [t for t in (getattr(target, "source", None), constr_source) if t is not None]
+        # user-defined target / metric / constraint: ONE source text, compiled by hipRTC inside the library
+        sources = [t for t in (getattr(target, "source", None), rmetric_source, constr_source) if t is not None]
         source = "\n".join(sources) if sources else None
         if source is not None:
             _ffi.check(self._lib.mm_model_create_from_source(ctx.handle, C.byref(d), source.encode(), C.byref(h)),

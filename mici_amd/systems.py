@@ -199,7 +199,8 @@ class DenseRiemannianMetricSystem(System):
         self.rmetric = metric_func
 
     def _model_args(self):
-        return dict(rmetric=self.rmetric.mid, rmetric_params=self.rmetric.params)
+        return dict(rmetric=self.rmetric.mid, rmetric_params=self.rmetric.params,
+                    rmetric_source=getattr(self.rmetric, "source", None))
 
 
 class SoftAbsRiemannianMetricSystem(System):

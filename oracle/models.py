@@ -276,6 +276,30 @@ class Rank1Metric:
         return lambda v: (v + v.T) @ q / self.dim
 
 
+RMETRIC_USER = 100
+
+
+class SoftPlusRank1Metric:
+    """A metric that is NOT built into the device library (it reaches it as user HIP source, tests/user_sources.py):
+    M(q) = diag(1 + softplus(q_i)) + c c^T (1 + |q|^2 / D);
+    vjp(V)_k = V_kk sigmoid(q_k) + (c^T V c) 2 q_k / D."""
+
+    mid = RMETRIC_USER
+
+    def __init__(self, c):
+        self.c = np.asarray(c, dtype=np.float64)
+        self.dim = self.c.shape[0]
+
+    def params(self):
+        return self.c.copy()
+
+    def metric_func(self, q):
+        return np.diag(1.0 + np.log1p(np.exp(q))) + np.outer(self.c, self.c) * (1.0 + q @ q / self.dim)
+
+    def vjp_metric_func(self, q):
+        return lambda v: np.diagonal(v) / (1.0 + np.exp(-q)) + (self.c @ v @ self.c) * 2.0 * q / self.dim
+
+
 class DiagQuadMetric:
     """M(q) = diag(1 + q^2) held as a dense matrix; vjp(V)_i = 2 q_i V_ii
     (dense twin of the reference's DiagonalRiemannian test system,
@@ -522,6 +546,8 @@ def rmetric_from_id(mid, params, dim):
         return DiagQuadMetric(dim)
     if mid == RMETRIC_SOFTABS:
         return None
+    if mid == RMETRIC_USER:  # the one metric of the fixtures that the device library only knows as user source
+        return SoftPlusRank1Metric(params)
     raise ValueError(f"unknown Riemannian metric id {mid}")
 
 

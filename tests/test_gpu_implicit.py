@@ -28,6 +28,9 @@ def build(g):
     mid = int(g["rmetric"])
     if mid == models.RMETRIC_SOFTABS:
         system = systems.SoftAbsRiemannianMetricSystem(target, softabs_coeff=float(g["rmetric_params"][0]))
+    elif mid == models.RMETRIC_USER:  # not built in: reaches the library as HIP source (hipRTC), tests/user_sources.py
+        from user_sources import SOFTPLUS_RANK1
+        system = systems.DenseRiemannianMetricSystem(target, models.UserMetric(d, SOFTPLUS_RANK1, g["rmetric_params"]))
     else:
         system = systems.DenseRiemannianMetricSystem(
             target, models.rmetric_from_id(mid, g["rmetric_params"], d))

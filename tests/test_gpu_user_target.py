@@ -203,3 +203,45 @@ def test_device_transitions_run_on_a_user_constraint():
     assert np.max(np.abs([con.jacob_constr(x) @ y for x, y in zip(q, p)])) < 1e-8  # momenta in the cotangent space
     assert np.max(np.abs(q - q0)) > 0.05  # and the chains moved
     batch.close()
+
+
+# ---- user METRICS (reference systems.py:1322-1358: `metric_func` / `vjp_metric_func` are callables) ------
+@pytest.mark.parametrize("dim", [5, 8, 16, 27, 32])
+def test_rank1_metric_as_user_source_reproduces_the_builtin(dim):
+    """The built-in rank-one-update metric written as user source goes through the same wave-per-chain kernels
+    (csrc/implicit_wave.h), compiled at run time: leapfrog and midpoint steps, h, dh_dmom and sample_momentum equal the
+    built-in kernels' (the vector-Jacobian products are formed differently - through the user's generic V(i, j) - so the
+    bar is rounding level, not bits), with identical statuses, step counts and fixed-point evaluation counts."""
+    from user_sources import RANK1_AS_USER
+
+    rng = np.random.default_rng(dim)
+    n = 12
+    B = omdl.make_spd(dim, rng)
+    builtin = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(B))
+    user = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.UserMetric(dim, RANK1_AS_USER, B))
+    q0 = rng.standard_normal((n, dim))
+    z = rng.standard_normal((n, dim))
+    p0 = builtin.sample_momentum_batch(q0, z)
+    assert_close(user.sample_momentum_batch(q0, z), p0, 1e-13, "sample_momentum")
+    assert_close(user.h_batch(q0, p0), builtin.h_batch(q0, p0), 1e-13, "h")
+    assert_close(user.dh_dmom_batch(q0, p0), builtin.dh_dmom_batch(q0, p0), 1e-13, "dh_dmom")
+    for cls, h, steps in ((integrators.ImplicitLeapfrogIntegrator, 0.03, 10), (integrators.ImplicitMidpointIntegrator, 0.03, 5)):
+        ib, iu = cls(builtin, h), cls(user, h)
+        qb, pb, sb, nb = ib.step_batch(q0, p0, 1, n_steps=steps)
+        qu, pu, su, nu = iu.step_batch(q0, p0, 1, n_steps=steps)
+        assert np.array_equal(sb, su) and np.array_equal(nb, nu) and np.all(sb == 0)
+        assert ib.last_counters["n_fp_evals"] == iu.last_counters["n_fp_evals"]
+        assert_close(qu, qb, 1e-11, f"{cls.__name__} positions")
+        assert_close(pu, pb, 1e-11, f"{cls.__name__} momenta")
+
+
+def test_user_metric_errors_fail_loudly():
+    from user_sources import RANK1_AS_USER
+
+    with pytest.raises(ValueError):
+        models.UserMetric(4, "__device__ double f() { return 0; }")
+    bad = models.UserMetric(4, RANK1_AS_USER.replace("return s / (double)dim;", "return s / undefined_dim;"), np.eye(4))
+    with pytest.raises(DeviceError, match="undefined_dim"):
+        systems.DenseRiemannianMetricSystem(models.Banana(4), bad).device_model()
+    with pytest.raises(DeviceError, match="dim <= 32"):
+        systems.DenseRiemannianMetricSystem(models.Banana(40), models.UserMetric(40, RANK1_AS_USER, np.eye(40))).device_model()

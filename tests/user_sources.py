@@ -48,3 +48,38 @@ __device__ void mm_user_jacob(const double* q, int dim, const double* params, do
   jac[2] = 2.0 * q[2];
 }
 """
+
+# the built-in rank-one metric M(q) = B + q q^T / D (csrc/implicit_wave.h build_metric / half_vjp_*) as user source;
+# params = B[dim*dim] row-major.  vjp(V)_k = sum_ij V_ij (delta_ik q_j + q_i delta_jk) / D = ((V + V^T) q)_k / D
+RANK1_AS_USER = r"""
+__device__ double mm_user_metric(const double* q, int i, int j, int dim, const double* params) {
+  return params[i * dim + j] + (q[i] * q[j]) * (1.0 / (double)dim);
+}
+__device__ double mm_user_vjp(const double* q, const MmMat& V, int k, int dim, const double* params) {
+  double s = 0.0;
+  for (int j = 0; j < dim; ++j) s += (V(k, j) + V(j, k)) * q[j];
+  return s / (double)dim;
+}
+"""
+
+# oracle/models.py SoftPlusDiagPlusRank1Metric (not built in): M(q) = diag(1 + log(1 + exp(q_i))) + c c^T * (1 + |q|^2 / D)
+# params = c[dim]
+SOFTPLUS_RANK1 = r"""
+__device__ double mm_user_metric(const double* q, int i, int j, int dim, const double* params) {
+  double s2 = 0.0;
+  for (int k = 0; k < dim; ++k) s2 += q[k] * q[k];
+  double v = params[i] * params[j] * (1.0 + s2 / (double)dim);
+  if (i == j) v += 1.0 + log1p(exp(q[i]));
+  return v;
+}
+__device__ double mm_user_vjp(const double* q, const MmMat& V, int k, int dim, const double* params) {
+  // d M_ij / d q_k = delta_ij delta_ik sigmoid(q_k) + c_i c_j 2 q_k / D
+  double cvc = 0.0;
+  for (int i = 0; i < dim; ++i) {
+    double r = 0.0;
+    for (int j = 0; j < dim; ++j) r += V(i, j) * params[j];
+    cvc += params[i] * r;
+  }
+  return V(k, k) / (1.0 + exp(-q[k])) + cvc * 2.0 * q[k] / (double)dim;
+}
+"""

@@ -1142,6 +1142,15 @@ def main():
                   else mdl.make_spd(d, r))
         add_constrained(name, mdl.Poly(d, 1.0, 0.25), mdl.LinearConstr(a, b), mk, metric, q0, h, cps, r=r, **kw)
 
+    # ---- a position-dependent metric that is not built into the device library (user source, hipRTC) ------------------
+    for name, d, n, hh, cps, kw in (("riemann_user_softplus_poly_d6", 6, 5, 0.08, [1, 5, 20], {}),
+                                    ("riemann_user_softplus_banana_d20", 20, 4, 0.02, [1, 5, 20], {}),
+                                    ("riemann_user_softplus_poly_d32_steffensen", 32, 3, 0.05, [1, 5], dict(fp_solver=1)),
+                                    ("riemann_user_softplus_poly_d6_fail_bigstep", 6, 5, 1.5, [1, 3], {})):
+        r = case_rng(name)
+        tgt = mdl.Banana(d) if "banana" in name else mdl.Poly(d, 1.0, 1.0 / 3.0)
+        add_riemann(name, tgt, mdl.SoftPlusRank1Metric(0.5 * r.standard_normal(d)), None, n, hh, cps, r=r, **kw)
+
     # ---- constraints that are not built into the device library: they reach it as USER SOURCE compiled by hipRTC
     #      (tests/test_gpu_user_target.py); here the reference and the oracle run their NumPy twin ---------------------
     def add_user_constrained(name, d, n, mk, h, cps, **kw):
