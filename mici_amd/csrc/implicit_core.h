@@ -17,7 +17,7 @@
 //   double metric_apply(double v)       M(x) v, matrix-free: the entries of metric_func(x) are formed as in build()
 //                                        and contracted with v on the fly - the explicit inverse the backend holds
 //                                        (from the last INIT / BADJ construction) stays where it is
-//   void   sum2(a, b, &sa, &sb)         two team-uniform sums at once
+//   void   sum2(a, b, &sa, &sb)         two team-uniform sums at once;  double sum1(a)  one
 //   double& rslot(int i)                per-thread scratch of the solve (may alias sweep buffers)
 // All control flow below is team-uniform (it depends only on norms / pivots every thread agrees on),
 // so a team iterates its own solves and stops on failure without any masking.
@@ -222,8 +222,7 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
       prof(bk, PH_MAPPLY);
       const double q = bk.metric_apply(bk.rslot(RS_D));
       prof(bk, PH_RSUM);
-      double dq, unused;
-      bk.sum2(bk.rslot(RS_D) * q, 0.0, &dq, &unused);
+      const double dq = bk.sum1(bk.rslot(RS_D) * q);
       if (!(dq > 0.0)) break;  // not positive definite along d, or not finite
       const double al = rz / dq;
       const double u = __builtin_fma(al, bk.rslot(RS_D), bk.rslot(RS_U));

@@ -366,6 +366,12 @@ struct TeamBlk16 {
     return __builtin_amdgcn_ballot_w64(chk != 0.0) != 0;
   }
 
+  __device__ __forceinline__ double sum1(double a) {  // the second sum rides on the same two barriers for free
+    double sa, sb;
+    sum2(a, 0.0, &sa, &sb);
+    return sa;
+  }
+
   // ---- M(x) v without touching the tiles (they hold -M(x0)^-1): refine_solve's matrix-free product ---------------
   // Each metric in the form that suits it (as half_vjp_inv / dh2_dpos below do for the vector-Jacobian products):
   //   rank-one update  M(x) v = B v + x (x . v) / D   B streamed tile by tile from L2, contracted like matvec() contracts

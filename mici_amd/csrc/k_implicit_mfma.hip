@@ -143,12 +143,15 @@ struct MfmaBackend {
   }
 
   // ---- refinement solves (implicit_core.h): M(x) v formed matrix-free, the tiles keep M(x0)^-1 ---------------------
-  // scratch in Qt / Wt: [0] the point x, [1 ..] the solve's flat vectors
-  __device__ __forceinline__ double& rslot(int i) { return w.qt[(1 + i) * 64 + lane]; }
+  // the solve's flat vectors (u, r, d) stay in registers: nothing else of the step is live during a refinement solve
+  // (the sweeps' operands are dead), and a lone wave pays ~100 cycles for every dependent LDS access
+  double rs_[RS_COUNT];
+  __device__ __forceinline__ double& rslot(int i) { return rs_[i]; }
   __device__ __forceinline__ void sum2(double a, double b, double* sa, double* sb) {
     *sa = wave_sum(lane < dim ? a : 0.0);
     *sb = wave_sum(lane < dim ? b : 0.0);
   }
+  __device__ __forceinline__ double sum1(double a) { return wave_sum(lane < dim ? a : 0.0); }
   // M(x) v in the form that suits the metric:  rank-one update  B v + x (x . v) / D  (B's tiles from LDS, contracted
   // like matvec() contracts the register tiles);  diag(1 + x^2): per lane
   __device__ __forceinline__ void metric_point(double x) { w.qt[lane] = (lane < dim) ? x : 0.0; }
