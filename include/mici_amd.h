@@ -69,7 +69,7 @@ typedef enum mm_rmetric { /* position-dependent metric of a RiemannianMetricSyst
   MM_RMETRIC_RANK1 = 1,    /* M(q) = B + q q^T / D, params B[D*D]; DenseRiemannianMetricSystem     */
   MM_RMETRIC_DIAGQUAD = 2, /* M(q) = diag(1 + q^2) held dense;     DenseRiemannianMetricSystem     */
   MM_RMETRIC_SOFTABS = 3,  /* SoftAbs of the target Hessian, params coeff; SoftAbsRiemannianMetricSystem */
-  MM_RMETRIC_USER = 100    /* user-supplied device code: mm_model_create_from_source, dim <= 32, params: any */
+  MM_RMETRIC_USER = 100    /* user-supplied device code: mm_model_create_from_source, dim <= 64, params: any */
 } mm_rmetric;
 
 typedef enum mm_constr { /* holonomic constraint, C = 1 */
@@ -208,7 +208,7 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* desc, mm_model** out);
  *    mm_momentum_refresh* and mm_metropolis_accept* work on such a model.  Target and constraint may both be user code
  *    (one source text defining all the functions).
  *  * desc->rmetric == MM_RMETRIC_USER - `metric_func` / `vjp_metric_func` of a DenseRiemannianMetricSystem
- *    (systems.py:1322-1358), dim <= 32 (the wave-per-chain kernels: the metric of a chain in one wave's registers):
+ *    (systems.py:1322-1358), dim <= 64 (the wave-per-chain kernels: the metric of a chain in one wave's registers):
  *        __device__ double mm_user_metric(const double* q, int i, int j, int dim, const double* params);  // M(q)_ij
  *        __device__ double mm_user_vjp(const double* q, const MmMat& V, int k, int dim, const double* params);
  *        // element k of vjp_metric_func(q)(V) = sum_ij V(i, j) d M_ij / d q_k;  V(i, j) reads the symmetric argument

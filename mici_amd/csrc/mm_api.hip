@@ -245,8 +245,8 @@ int mm_model_create_from_source(mm_ctx* ctx, const mm_model_desc* d, const char*
   MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE || d->rmetric == MM_RMETRIC_USER,
              "mm_model_create_from_source: a user target on a Riemannian system needs a user metric too (the built-in "
              "metrics' kernels are compiled ahead of time around the built-in targets)");
-  MM_REQUIRE(ctx, d->rmetric != MM_RMETRIC_USER || d->dim <= 32,
-             "mm_model_create_from_source: user metrics run on the wave-per-chain kernels, dim <= 32");
+  MM_REQUIRE(ctx, d->rmetric != MM_RMETRIC_USER || d->dim <= 64,
+             "mm_model_create_from_source: user metrics run on the wave-per-chain kernels, dim <= 64");
   MM_REQUIRE(ctx, d->target != MM_TARGET_USER || !d->gaussian_split,
              "mm_model_create_from_source: a user target is a density with respect to the Lebesgue measure (identity / "
              "diagonal / dense fixed metric); the Gaussian-split system classes take built-in targets");

@@ -128,7 +128,7 @@ class UserMetric(RiemannianMetric):
         // element k of vjp_metric_func(q)(V) = sum_ij V(i, j) d M_ij / d q_k for a symmetric V read as V(i, j)
 
     and is compiled for gfx950 (hipRTC) with the library's wave-per-chain implicit kernels when the system's device
-    model is created; ``params`` are handed to both.  ``dim`` <= 32."""
+    model is created; ``params`` are handed to both.  ``dim`` <= 64."""
 
     def __init__(self, dim, source, params=()):
         super().__init__(RMETRIC_USER, dim, params)

@@ -206,7 +206,7 @@ def test_device_transitions_run_on_a_user_constraint():
 
 
 # ---- user METRICS (reference systems.py:1322-1358: `metric_func` / `vjp_metric_func` are callables) ------
-@pytest.mark.parametrize("dim", [5, 8, 16, 27, 32])
+@pytest.mark.parametrize("dim", [5, 8, 16, 27, 32, 40, 64])
 def test_rank1_metric_as_user_source_reproduces_the_builtin(dim):
     """The built-in rank-one-update metric written as user source goes through the same wave-per-chain kernels
     (csrc/implicit_wave.h), compiled at run time: leapfrog and midpoint steps, h, dh_dmom and sample_momentum equal the
@@ -243,5 +243,5 @@ def test_user_metric_errors_fail_loudly():
     bad = models.UserMetric(4, RANK1_AS_USER.replace("return s / (double)dim;", "return s / undefined_dim;"), np.eye(4))
     with pytest.raises(DeviceError, match="undefined_dim"):
         systems.DenseRiemannianMetricSystem(models.Banana(4), bad).device_model()
-    with pytest.raises(DeviceError, match="dim <= 32"):
-        systems.DenseRiemannianMetricSystem(models.Banana(40), models.UserMetric(40, RANK1_AS_USER, np.eye(40))).device_model()
+    with pytest.raises(DeviceError, match="dim <= 64"):
+        systems.DenseRiemannianMetricSystem(models.Banana(70), models.UserMetric(70, RANK1_AS_USER, np.eye(70))).device_model()

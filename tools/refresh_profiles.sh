@@ -28,7 +28,7 @@ cd $ROOT
 O=$ROOT/gpurun_out/${ROUND}p; rm -rf $O; mkdir -p $O
 KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2iv:leapfrog_mfma_kernel c3:implicit_mfma_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel"
 
-python -m pytest tests -q -m gpu 2>&1 | tail -4 > $O/gpu_tests.txt; tail -2 $O/gpu_tests.txt
+python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -4 > $O/gpu_tests.txt; cat $O/gpu_tests.txt
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-160 $O/bench_default.json
 
 cd /tmp && export TMPDIR=/tmp
