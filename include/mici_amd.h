@@ -236,6 +236,12 @@ int mm_state_download_status(mm_state* state, int32_t* status, int32_t* n_done);
 int mm_state_download_all(mm_state* s, double* pos, double* mom, int8_t* dir, int32_t* status, int32_t* n_done);
 /* raw device pointers (zero-copy interop / RCCL): any of the outputs may be NULL */
 int mm_state_device_ptrs(mm_state* state, double** pos, double** mom, int8_t** dir);
+/* A state from mm_state_alloc_mapped lives in pinned host memory: these are HOST-addressable pointers to its pos[N*D],
+ * mom[N*D], dir[N], status[N], n_done[N] (any output may be NULL).  A caller that steps one state at a time
+ * (Integrator.step, integrators.py:63-80) writes its inputs there, launches, calls mm_ctx_sync and reads the results
+ * in place - no upload / download calls.  The memory may only be touched while no launch on it is in flight.
+ * MM_ERR_INVALID for a state that is not mapped. */
+int mm_state_mapped_ptrs(mm_state* state, double** pos, double** mom, int8_t** dir, int32_t** status, int32_t** n_done);
 
 /* Per-chain step sizes (step-size adaptation runs every chain at its own step size; the reference keeps one
  * integrator copy per chain, adapters.py:322-340, samplers.py:1124-1129): scale[N] (host) multiplies the

@@ -120,6 +120,8 @@ SIGNATURES = {
     "mm_dh_dmom": (C.c_int, [_VP, _VP, _VP, c_double_p]),
     "mm_sample_momentum": (C.c_int, [_VP, _VP, _VP, c_double_p]),
     "mm_state_download_errors": (C.c_int, [_VP, C.POINTER(C.c_uint32), C.c_int32]),
+    "mm_state_mapped_ptrs": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP),
+                                       C.POINTER(_VP)]),
     "mm_comm_unique_id": (C.c_int, [c_uint8_p]),
     "mm_comm_create": (C.c_int, [_VP, C.c_int32, C.c_int32, c_uint8_p, C.POINTER(_VP)]),
     "mm_comm_destroy": (C.c_int, [_VP]),

@@ -724,6 +724,17 @@ int mm_state_device_ptrs(mm_state* s, double** pos, double** mom, int8_t** dir) 
   return MM_OK;
 }
 
+int mm_state_mapped_ptrs(mm_state* s, double** pos, double** mom, int8_t** dir, int32_t** status, int32_t** n_done) {
+  MM_REQUIRE(nullptr, s != nullptr, "mm_state_mapped_ptrs: state is NULL");
+  MM_REQUIRE(s->ctx, s->mapped, "mm_state_mapped_ptrs: the state was not allocated with mm_state_alloc_mapped");
+  if (pos) *pos = s->d_pos;
+  if (mom) *mom = s->d_mom;
+  if (dir) *dir = s->d_dir;
+  if (status) *status = s->d_status;
+  if (n_done) *n_done = s->d_n_done;
+  return MM_OK;
+}
+
 // ---- hot path dispatch ----------------------------------------------------------------------------------
 static int check_pair(mm_ctx* ctx, const mm_model* m, mm_state* s, const char* who) {
   MM_REQUIRE(nullptr, ctx != nullptr, std::string(who) + ": ctx is NULL");

@@ -87,20 +87,33 @@ class Integrator:
         return batch.download_status()
 
     def step(self, state):
-        """Single-chain step with the reference's semantics (integrators.py:63-80)."""
+        """Single-chain step with the reference's semantics (integrators.py:63-80).  The chain's state lives in a
+        cached buffer of pinned host memory that the kernels access in place: the inputs are written through NumPy
+        views, one launch, one stream synchronisation, and the results are read back through the same views - no
+        upload / download calls (tools/host_latency.py: launch + synchronisation is 14 us of the call on the MI355X
+        box, the two transfer calls used to add 17 us)."""
         self._check_step_size()
         ctx = default_context()
-        pos = np.ascontiguousarray(state.pos, dtype=np.float64)
+        pos = state.pos
+        dim = pos.shape[0]
         batch = self._one.get(ctx)
-        if batch is None or batch.dim != pos.shape[0]:
-            batch = self._one.put(ctx, DeviceBatch(ctx, 1, pos.shape[0], mapped=True))
-        batch.upload(pos[None], np.asarray(state.mom, dtype=np.float64)[None], [int(state.dir)])
+        if batch is None or batch.dim != dim:
+            batch = self._one.put(ctx, DeviceBatch(ctx, 1, dim, mapped=True))
+        vq, vp, vd, vs, _ = batch.mapped_views()
+        d = int(state.dir)
+        if d != 1 and d != -1:
+            raise ValueError("dir entries must be +1 or -1")
+        vq[0] = pos
+        vp[0] = state.mom
+        vd[0] = d
         self.step_device(batch, 1, ctx)
-        q, p, _, status, _ = batch.download_all()  # one transfer each way for a single state
-        raise_for_status(status[0])
+        ctx.sync()
+        st = int(vs[0])
+        if st:
+            raise_for_status(st)
         new = state.copy()
-        new.pos = q[0]
-        new.mom = p[0]
+        new.pos = vq[0].copy()
+        new.mom = vp[0].copy()
         return new
 
 

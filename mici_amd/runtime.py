@@ -292,6 +292,25 @@ class DeviceBatch:
         _ffi.check(self._lib.mm_state_set_chain_steps(self.handle, ptr), self.ctx.handle,
                    "mm_state_set_chain_steps")
 
+    def mapped_views(self):
+        """NumPy views (pos[N, D], mom[N, D], dir[N], status[N], n_done[N]) ONTO the pinned host memory of a mapped
+        batch: the single-state path writes its inputs there, launches, synchronises and reads the results in place.
+        Only to be touched while no launch on the batch is in flight."""
+        v = getattr(self, "_views", None)
+        if v is None:
+            ptrs = [C.c_void_p() for _ in range(5)]
+            _ffi.check(self._lib.mm_state_mapped_ptrs(self.handle, *[C.byref(p) for p in ptrs]), self.ctx.handle,
+                       "mm_state_mapped_ptrs")
+            n, d = self.n_chains, self.dim
+
+            def view(ptr, ctype, shape):
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=shape)
+
+            v = self._views = (view(ptrs[0], C.c_double, (n, d)), view(ptrs[1], C.c_double, (n, d)),
+                               view(ptrs[2], C.c_int8, (n,)), view(ptrs[3], C.c_int32, (n,)),
+                               view(ptrs[4], C.c_int32, (n,)))
+        return v
+
     def download_errors(self, clear=True):
         """Sticky error word of the device-resident transitions run on this batch: uint32 [N], bit k set when a
         proposal of the chain ended with status k since the last clearing read (include/mici_amd.h)."""

@@ -111,22 +111,53 @@ class System:
         return mom
 
     # ---- single-state surface used by mici.transitions ----------------------------------------------
+    # One state at a time goes through a cached buffer of pinned host memory the kernels access in place: inputs are
+    # written through NumPy views, no upload call (tools/host_latency.py: the transfer calls were half of a call's time).
+    def _one_state(self, pos, mom):
+        ctx = default_context()
+        batch = self._one.get(ctx)
+        if batch is None:
+            batch = self._one.put(ctx, DeviceBatch(ctx, 1, self.dim, mapped=True))
+            batch.keep = True
+        vq, vp, _, _, _ = batch.mapped_views()
+        pos = np.asarray(pos)
+        if pos.shape != (self.dim,):
+            raise ValueError(f"pos must have shape [{self.dim}]")
+        ctx.sync()  # nothing may still be reading the buffer
+        vq[0] = pos
+        if mom is not None:
+            vp[0] = mom
+        return ctx, batch, vp
+
     def h(self, state):
-        val = self.h_batch(np.asarray(state.pos)[None], np.asarray(state.mom)[None])[0]
+        ctx, batch, _ = self._one_state(state.pos, state.mom)
+        out = np.empty(1)
+        _ffi.check(ctx._lib.mm_hamiltonian(ctx.handle, self.device_model(ctx).handle, batch.handle,
+                                           out.ctypes.data_as(_ffi.c_double_p)), ctx.handle, "mm_hamiltonian")
+        val = out[0]
         if np.isnan(val) and np.all(np.isfinite(state.pos)) and np.all(np.isfinite(state.mom)):
             from .errors import LinAlgError
             raise LinAlgError("Cholesky factorisation failed.")
         return float(val)
 
     def dh_dmom(self, state):
-        return self.dh_dmom_batch(np.asarray(state.pos)[None], np.asarray(state.mom)[None])[0]
+        ctx, batch, _ = self._one_state(state.pos, state.mom)
+        out = np.empty(self.dim)
+        _ffi.check(ctx._lib.mm_dh_dmom(ctx.handle, self.device_model(ctx).handle, batch.handle,
+                                       out.ctypes.data_as(_ffi.c_double_p)), ctx.handle, "mm_dh_dmom")
+        return out
 
     def dh2_dmom(self, state):
         return self.dh_dmom(state)
 
     def sample_momentum(self, state, rng):
-        z = rng.standard_normal(np.asarray(state.pos).shape)
-        return self.sample_momentum_batch(np.asarray(state.pos)[None], z[None])[0]
+        z = np.ascontiguousarray(rng.standard_normal(np.asarray(state.pos).shape))
+        ctx, batch, vp = self._one_state(state.pos, None)
+        vp[0] = 0.0
+        _ffi.check(ctx._lib.mm_sample_momentum(ctx.handle, self.device_model(ctx).handle, batch.handle,
+                                               z.ctypes.data_as(_ffi.c_double_p)), ctx.handle, "mm_sample_momentum")
+        ctx.sync()
+        return vp[0].copy()
 
 
 class EuclideanMetricSystem(System):

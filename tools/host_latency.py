@@ -22,3 +22,32 @@ h=sys_.h(st)
 t0=time.perf_counter()
 for _ in range(n): sys_.h(st)
 print("system.h: %.1f us" % ((time.perf_counter()-t0)/n*1e6))
+
+# ---- where the single-state step's time goes: the floor of "one kernel launch + one stream synchronisation" on this box
+from mici_amd.runtime import DeviceBatch, default_context
+ctx = default_context()
+b = DeviceBatch(ctx, 1, 32, mapped=True)
+b.upload(np.random.randn(1, 32), np.random.randn(1, 32), [1])
+for _ in range(100):
+    integ.step_device(b, 1, ctx)
+ctx.sync()
+t0 = time.perf_counter()
+for _ in range(n):
+    integ.step_device(b, 1, ctx)
+ctx.sync()
+print("launch only (asynchronous, amortised): %.1f us per call" % ((time.perf_counter() - t0) / n * 1e6))
+t0 = time.perf_counter()
+for _ in range(n):
+    integ.step_device(b, 1, ctx)
+    ctx.sync()
+print("launch + stream synchronisation (the floor of a single-state step through any kernel): %.1f us"
+      % ((time.perf_counter() - t0) / n * 1e6))
+t0 = time.perf_counter()
+for _ in range(n):
+    ctx.sync()
+print("stream synchronisation of an idle stream: %.1f us" % ((time.perf_counter() - t0) / n * 1e6))
+t0 = time.perf_counter()
+for _ in range(n):
+    b.upload(st.pos[None], st.mom[None], [1])
+    b.download_all()
+print("upload + download_all of the mapped single-state buffer (no kernel): %.1f us" % ((time.perf_counter() - t0) / n * 1e6))
