@@ -50,7 +50,19 @@ struct ImplicitArgs {
   // aux ops
   double* out;
   const double* z;
+  int no_refine;  // 1: factorise every metric construction (MICI_AMD_REFINE=0: A/B runs against section 4.3c of DESIGN.md)
 };
+
+// MICI_AMD_REFINE=0 in the environment switches the refinement of the solve-only constructions off (read once)
+#ifndef MM_RTC_BUILD
+inline int mm_refine_disabled() {
+  static const int off = [] {
+    const char* e = getenv("MICI_AMD_REFINE");
+    return (e && e[0] == '0') ? 1 : 0;
+  }();
+  return off;
+}
+#endif
 
 __device__ __forceinline__ double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
@@ -292,7 +304,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
     const bool need_inverse = mode == MODE_INIT || mode == MODE_BADJ;
     bool refined = false;
     if constexpr (kRefine) {
-      if (!need_inverse && anchor) {  // team-uniform
+      if (!need_inverse && anchor && bk.refine_on) {  // team-uniform
         refined = refine_solve(bk, bk.slot(SL_XQ), bk.slot(SL_PW), bk.slot(mode == MODE_CHK ? SL_UC : SL_UA), &u_pos, r);
         anchor = refined;  // a failed refinement is followed by the factorisation below, which overwrites the inverse
       }

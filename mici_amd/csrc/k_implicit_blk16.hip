@@ -193,6 +193,7 @@ struct TeamBlk16 {
   static constexpr bool kCountersInLds = true;     // implicit_core.h: work counters in LDS, bumped by thread 0
   static constexpr bool kRefine = true;            // implicit_core.h: solve-only constructions refined from the held inverse
   static constexpr bool kProf = PROFILE;           // developer builds: cycles per phase of the step (prof_switch)
+  bool refine_on;                                  // false: MICI_AMD_REFINE=0, every construction is factorised
   d4 acc[NSLOT];
   int wave; // wave index, wave-uniform (phases re-materialise it through opaque_wave)
   int nblk; // number of 16-pivot blocks that contain real rows: ceil(dim / 16)
@@ -961,6 +962,7 @@ __device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC, PROFILE>& bk, co
   bk.lds = lds;
   bk.base = A.rparams;
   bk.tparams = A.tparams;
+  bk.refine_on = A.no_refine == 0;
   for (int i = threadIdx.x; i < DPM * PSTR; i += NTHR) lds[kOffPart + i] = 0.0;  // unused partial-sum slots stay 0
   if (threadIdx.x < 8) lds[kOffRed + 16 + threadIdx.x] = 0.0;                     // work counters
   if constexpr (PROFILE) {
@@ -1156,6 +1158,7 @@ int mm_launch_implicit_blk16(mm_ctx* ctx, const mm_model* m, mm_state* s, double
   a.step_size = h;
   a.n_steps = n_steps;
   a.opts = opts;
+  a.no_refine = mm_refine_disabled();
   a.counters = d_counters;
   if (m->rmetric == MM_RMETRIC_RANK1)
     return launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_RANK1>, a);

@@ -79,6 +79,7 @@ struct MfmaBackend {
   static constexpr bool kUnifiedConstruct = true;  // implicit_core.h: one construction site, the mode at run time
   static constexpr bool kCountersInLds = false;
   static constexpr bool kRefine = true;  // implicit_core.h: solve-only constructions refined from the held inverse
+  bool refine_on;                        // false: MICI_AMD_REFINE=0, every construction is factorised
   d4 acc[kTiles];
   int dim, lane, target;
   MLds w;
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs
   bk.w.mpart = bk.w.part + 64 * kPartStride;
   bk.w.stash = bk.w.mpart + 192;
   bk.w.prof = bk.w.stash + SL_COUNT_REFINE * 64;
+  bk.refine_on = A.no_refine == 0;
   bk.base_lds = base_lds;
   bk.tparams = A.tparams;
   if constexpr (PROFILE) {
@@ -664,6 +666,7 @@ int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
   a.step_size = h;
   a.n_steps = n_steps;
   a.opts = opts;
+  a.no_refine = mm_refine_disabled();
   a.counters = d_counters;
   const unsigned blocks = (unsigned)((s->n + kWaves - 1) / kWaves);
   const bool r1 = m->rmetric == MM_RMETRIC_RANK1;

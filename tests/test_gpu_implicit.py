@@ -367,3 +367,58 @@ def test_softabs_long_trajectory_matches_oracle():
         assert_close(p[c], po, 1e-7, f"p chain {c}")
     h0, h1 = system.h_batch(q0, p0), system.h_batch(q, p)
     assert np.all(np.abs(h1 - h0) < 5e-2)
+
+
+_REFINE_SCRIPT = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from mici_amd import integrators, models, systems
+from oracle import models as omdl
+out = {{}}
+for dim, h, steps in ((64, 0.02, 20), (200, 0.01, 6), (64, 0.35, 4)):
+    rng = np.random.default_rng(dim + int(1000 * h))
+    system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(omdl.make_spd(dim, rng)))
+    integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+    q0 = rng.standard_normal((16, dim))
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((16, dim)))
+    q, p, st, nd = integ.step_batch(q0, p0, 1, n_steps=steps)
+    out["%d_%g" % (dim, h)] = dict(q=q.tolist(), p=p.tolist(), status=st.tolist(), n_done=nd.tolist(),
+                                   counters={{k: int(v) for k, v in integ.last_counters.items()}})
+print(json.dumps(out))
+"""
+
+
+def test_refined_solves_equal_factorised_solves():
+    """the solve-only metric constructions are refined (preconditioned CG from the explicit inverse the
+    step holds) instead of factorised.  Same inputs with MICI_AMD_REFINE=0 (every construction factorised, the round-2
+    behaviour; the switch is read once per process): identical statuses, step counts and fixed-point evaluation counts,
+    states equal to solver accuracy - on the c3 kernel (D = 64), the c4 kernel (D = 200) and at a step size large
+    enough that chains fail and refinements fall back to the factorisation."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _REFINE_SCRIPT.format(root=root)], capture_output=True, text=True,
+                           env=dict(os.environ, MICI_AMD_REFINE=mode), cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in res["1"]:
+        a, b = res["1"][key], res["0"][key]
+        assert a["status"] == b["status"] and a["n_done"] == b["n_done"], key
+        ca, cb = a["counters"], b["counters"]
+        for k in ("n_fp_evals", "n_fp_solves", "n_metric", "n_grad"):
+            assert ca[k] == cb[k], (key, k, ca[k], cb[k])
+        assert cb["n_refine"] == 0 and cb["n_factor_solve"] > 0          # switched off: trailing sweeps only
+        assert ca["n_refine"] > 0 and ca["n_factor_solve"] < cb["n_factor_solve"]
+        assert ca["n_factor_full"] == cb["n_factor_full"]
+        ok = np.array(a["status"]) == 0
+        assert_close(np.array(a["q"])[ok], np.array(b["q"])[ok], 1e-11, f"{key} positions")
+        assert_close(np.array(a["p"])[ok], np.array(b["p"])[ok], 1e-11, f"{key} momenta")
+    small = res["1"]["64_0.02"]["counters"]
+    assert small["n_factor_solve"] == 0 and np.all(np.array(res["1"]["64_0.02"]["status"]) == 0)
+    big = res["1"]["64_0.35"]
+    assert any(s != 0 for s in big["status"])  # the scenario has failing chains ...
