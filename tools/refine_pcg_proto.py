@@ -1,5 +1,9 @@
+"""Round-3 study behind DESIGN.md section 4.3c (test infrastructure: imports oracle/): how far the metric of the
+solve-only constructions of an implicit leapfrog step is from the explicit inverse the step holds, and how many
+preconditioned-CG iterations it takes to reach 1e-13 - on the c3 and c4 workloads of bench.py.  Output: profiles/r03_refine_contraction.txt."""
+import os
 import sys, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import integrators as orc, models as omdl
 import bench
 
