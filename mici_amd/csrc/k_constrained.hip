@@ -20,12 +20,18 @@
 // The state of a chain is 2*D doubles (48 B for the torus): there is no HBM roofline to speak of, the
 // kernel is FP64-VALU / transcendental bound; data-dependent Newton iteration counts are handled by
 // SIMT masking (lanes of a wave wait for their slowest chain).
+#include <cstdlib>
+#include <cstring>
+
 #include "constrained_core.h"
 
 using namespace mmcon;
 
 // capacity-16 instantiations (k_constrained_wide.hip)
 int mm_launch_constrained_wide(mm_ctx* ctx, int n_constr, const mmcon::ConArgs& a, int which, double* h_out);
+// one wave per chain, 8 < D <= 64 (k_constrained_wave.hip)
+bool mm_constrained_wave_supports(const mmcon::ConArgs& a, int n_constr);
+int mm_launch_constrained_wave(mm_ctx* ctx, int n_constr, const mmcon::ConArgs& a);
 
 namespace {
 
@@ -60,8 +66,17 @@ int launch(mm_ctx* ctx, const mm_model* m, const ConArgs& a, int which, double* 
     mm_set_error(ctx, "constrained kernels: the funnel target needs a wave-collective gradient");
     return MM_ERR_UNSUPPORTED;
   }
-  // exact register-resident kernels: D <= 8 with C <= 3; everything else up to D = 64, C = 8 runs the padded
-  // (capacity 16 or 64) instantiations of the same core, whose per-chain arrays live in scratch
+  // exact register-resident kernels: D <= 8 with C <= 3.  Beyond: the step of a plain (dens_wrt_hausdorff, no Gaussian
+  // split) system with a built-in constraint runs one wave per chain (k_constrained_wave.hip); everything else up to
+  // D = 64, C = 8 - the other system variants, the auxiliary kernels, and every size with
+  // MICI_AMD_CONSTRAINED_KERNEL=lane (A/B runs) - runs the padded (capacity 16 or 64) instantiations of the
+  // lane-per-chain core, whose per-chain arrays live in scratch
+  static const bool force_lane = [] {
+    const char* e = getenv("MICI_AMD_CONSTRAINED_KERNEL");
+    return e && strcmp(e, "lane") == 0;
+  }();
+  if (which == K_STEP && !force_lane && mm_constrained_wave_supports(a, m->n_constr))
+    return mm_launch_constrained_wave(ctx, m->n_constr, a);
   if (m->dim > 8 || m->n_constr > 3) return mm_launch_constrained_wide(ctx, m->n_constr, a, which, h_out);
   switch (m->n_constr) {
     case 1: return launch_c<1>(ctx, m->dim, a, which, h_out);

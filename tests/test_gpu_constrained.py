@@ -207,3 +207,75 @@ def test_single_state_step_raises_reference_exceptions():
         except (ConvergenceError, NonReversibleStepError) as e:
             assert isinstance(e, expect[int(g["status"][c])])
         assert n_ok == g["n_done"][c]
+
+
+_WAVE_SCRIPT = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from mici_amd import integrators, models, solvers, systems
+from oracle import models as omdl
+out = {{}}
+cases = [("sphereplane_d40_newton", 40, 0, "dense"), ("sphereplane_d33_linesearch", 33, 2, "diag"),
+         ("linear_c8_d64_quasi", 64, 1, "dense"), ("sphere_d12_newton_inner2", 12, 0, "identity")]
+for name, d, solver, mk in cases:
+    rng = np.random.default_rng(d)
+    metric = None if mk == "identity" else (np.exp(0.2 * rng.standard_normal(d)) if mk == "diag" else omdl.make_spd(d, rng))
+    if name.startswith("linear"):
+        a, b = rng.standard_normal((8, d)), rng.standard_normal(8)
+        con = models.LinearConstr(a, b)
+        x0 = np.linalg.lstsq(a, b, rcond=None)[0]
+        q0 = x0 + 0.5 * rng.standard_normal((24, d)) @ (np.eye(d) - a.T @ np.linalg.solve(a @ a.T, a)).T
+    elif name.startswith("sphereplane"):
+        nrm = rng.standard_normal(d)
+        con = models.SpherePlaneConstr(nrm)
+        x = rng.standard_normal((24, d))
+        x -= np.outer(x @ nrm, nrm) / (nrm @ nrm)
+        q0 = x / np.linalg.norm(x, axis=1, keepdims=True)
+    else:
+        con = models.SphereConstr()
+        x = rng.standard_normal((24, d))
+        q0 = x / np.linalg.norm(x, axis=1, keepdims=True)
+    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(d, 0.5, 0.25), con, metric=metric)
+    proj = [solvers.solve_projection_onto_manifold_newton, solvers.solve_projection_onto_manifold_quasi_newton,
+            solvers.solve_projection_onto_manifold_newton_with_line_search][solver]
+    integ = integrators.ConstrainedLeapfrogIntegrator(system, 0.04, projection_solver=proj,
+                                                      n_inner_step=2 if "inner2" in name else 1)
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal(q0.shape))
+    q, p, st, nd = integ.step_batch(q0, p0, np.where(np.arange(24) % 3 == 0, -1, 1), n_steps=15)
+    out[name] = dict(q=q.tolist(), p=p.tolist(), status=st.tolist(), n_done=nd.tolist(),
+                     newton=int(integ.last_counters["n_newton_iters"]))
+print(json.dumps(out))
+"""
+
+
+def test_wave_per_chain_kernel_equals_lane_per_chain_core():
+    """k_constrained_wave.hip (8 < D <= 64: one wave per chain, Jacobians and vectors in registers, sums through LDS)
+    against the lane-per-chain core (MICI_AMD_CONSTRAINED_KERNEL=lane: the padded instantiations with their arrays in
+    scratch) on the same inputs: all three projection solvers, two constraints and eight, identity / diagonal / dense
+    metric, n_inner_step = 2, both time directions - same statuses, step counts and Newton iteration counts, states to
+    rounding (the D-long sums are ordered differently)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("wave", "lane"):
+        env = dict(os.environ)
+        env.pop("MICI_AMD_CONSTRAINED_KERNEL", None)
+        if mode == "lane":
+            env["MICI_AMD_CONSTRAINED_KERNEL"] = "lane"
+        r = subprocess.run([sys.executable, "-c", _WAVE_SCRIPT.format(root=root)], capture_output=True, text=True, env=env,
+                           cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    differs = False
+    for key in res["wave"]:
+        a, b = res["wave"][key], res["lane"][key]
+        assert a["status"] == b["status"] and a["n_done"] == b["n_done"] and a["newton"] == b["newton"], key
+        assert all(s == 0 for s in a["status"]), key
+        assert_close(np.array(a["q"]), np.array(b["q"]), 1e-11, f"{key} positions")
+        assert_close(np.array(a["p"]), np.array(b["p"]), 1e-11, f"{key} momenta")
+        differs = differs or a["q"] != b["q"]
+    assert differs  # two different kernels really ran (their sums are ordered differently)

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Fill the measured tables of DESIGN.md / README.md from profiles/<round>_bench_default.json (+ the PMC files), between
+the <!-- R03_TABLE --> / <!-- R03_README_TABLE --> markers, so the documents quote what the committed record holds."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = os.environ.get("ROUND", "r03")
+
+
+def sci(x):
+    e = 0
+    while x >= 10:
+        x /= 10
+        e += 1
+    sup = str(e).translate(str.maketrans("0123456789", "⁰¹²³⁴⁵⁶⁷⁸⁹"))
+    return f"{x:.2f}·10{sup}"
+
+
+def main():
+    rec = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_bench_default.json")))
+    rows = [("c2", "c2(iii) D=128, 4096 chains, leapfrog", rec)]
+    names = {"c2i": "c2(i) iso-Gaussian", "c2iv": "c2(iv) + dense metric", "c3": "c3(a) D=64, 1024 chains",
+             "c3b": "c3(b) SoftAbs D=64", "c4": "c4 shard D=256, 1024 chains", "c5": "c5 shard, 2048 chains"}
+    for k, v in rec.get("configs", {}).items():
+        if "error" not in v:
+            rows.append((k, names.get(k, k), v))
+    out = ["| config | steps/s (1 GPU) | kernel ms per launch | roofline (algorithmic) | executed | HBM traffic per launch (PMC) |",
+           "|---|---|---|---|---|---|"]
+    for key, name, r in rows:
+        roof = r["roofline"]
+        frac = f"{roof['frac']:.3f} of {'FP64 MFMA' if roof['bound'] == 'mfma' else 'HBM'} peak ({roof['achieved']:.1f} {roof['unit']})"
+        if "fp64_valu" in roof:
+            frac += f"; FP64 VALU {roof['fp64_valu']['frac']:.2f}"
+        ex = "—"
+        if roof.get("executed"):
+            e = roof["executed"]
+            ex = (f"MFMA busy {roof['mfma_busy']:.3f}; {e['refine_pairs_per_chain_step']:.1f} CG pairs + "
+                  f"{e['sweeps_per_chain_step']:.2f} sweeps per step")
+        tr = roof.get("traffic")
+        out.append(f"| {name} | {sci(r['value'])} | {roof['kernel_ms_per_launch']:.3g} | {frac} | {ex} | "
+                   f"{'—' if tr is None else '%.1f MB' % (tr / 1e6)} |")
+    table = "\n".join(out)
+    for fn, marker in (("DESIGN.md", "R03_TABLE"), ("README.md", "R03_README_TABLE")):
+        p = os.path.join(ROOT, fn)
+        s = open(p).read()
+        block = f"<!-- {marker} -->\n{table}\n<!-- /{marker} -->"
+        if f"<!-- /{marker} -->" in s:
+            s = re.sub(rf"<!-- {marker} -->.*?<!-- /{marker} -->", lambda m: block, s, flags=re.S)
+        else:
+            s = s.replace(f"<!-- {marker} -->", block)
+        open(p, "w").write(s)
+    print(table)
+
+
+if __name__ == "__main__":
+    main()
