@@ -29,7 +29,7 @@ using namespace mmimp;
 #define MM_WAVES_PER_BLOCK 4
 #endif
 constexpr int kWaves = MM_WAVES_PER_BLOCK;  // chains per workgroup (a run-time translation unit may lower it to fit 64 KB of LDS)
-constexpr int kWaveLdsDoubles = 5 * 64 + mmimp::SL_COUNT * 64 + 8 * 64;  // scratch vectors + step state + column block
+constexpr int kWaveLdsDoubles = 5 * 64 + mmimp::SL_COUNT_REFINE * 64 + 8 * 64;  // scratch vectors + step state + column block
 
 // Per-wave LDS scratch (doubles): 5 vectors of 64.
 struct WaveLds {
@@ -378,10 +378,14 @@ struct WaveBackend {
   static constexpr bool kSolveByInverse = false;  // implicit_core.h: solve = invert + mat-vec, one construction site
   static constexpr bool kUnifiedConstruct = false;
   static constexpr bool kCountersInLds = false;
+  // implicit_core.h: solve-only constructions refined from the held inverse (built-in metrics: M(x) v has a closed form
+  // that needs no tiles; a user metric would re-evaluate its D^2 entries per product and keeps the factorisations)
+  static constexpr bool kRefine = RMETRIC != MM_RMETRIC_USER;
+  bool refine_on;
   double T[TS][TS];
   int dim, lane, target;
   WaveLds w;
-  double* stash;  // [SL_COUNT][64] flat state of the step, in LDS to keep VGPRs for the tiles
+  double* stash;  // [SL_COUNT_REFINE][64] flat state of the step, in LDS to keep VGPRs for the tiles
   double* blk;    // [8][64] one block of re-published columns for the back substitution
 
   __device__ __forceinline__ double& slot(int i) { return stash[i * 64 + lane]; }
@@ -401,6 +405,43 @@ struct WaveBackend {
     return ok;
   }
   __device__ __forceinline__ double matvec(double v) { return matvec_flat<TS>(T, v, lane, w); }
+  // ---- refinement solves (implicit_core.h refine_solve): M(x) v in the form that suits the metric ----------------------
+  double rs_[RS_COUNT], xpt_;
+  __device__ __forceinline__ double& rslot(int i) { return rs_[i]; }
+  __device__ __forceinline__ void sum2(double a, double b, double* sa, double* sb) {
+    *sa = wave_sum(lane < dim ? a : 0.0);
+    *sb = wave_sum(lane < dim ? b : 0.0);
+  }
+  __device__ __forceinline__ double sum1(double a) { return wave_sum(lane < dim ? a : 0.0); }
+  __device__ __forceinline__ void metric_point(double x) { xpt_ = (lane < dim) ? x : 0.0; }
+  __device__ __forceinline__ double metric_apply(double v) {
+    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+      // B v (the staged base matrix has this lane's TS x TS entries in matvec_flat's tile order) + x (x . v) / D
+      const int ti = lane >> 3, tj = lane & 7;
+      if (lane < Geo<TS>::DP) w.vin[Geo<TS>::pos(lane)] = (lane < dim) ? v : 0.0;
+      wave_sync();
+      double part[TS];
+      const double* bt = base_lds + lane * Geo<TS>::TSTRIDE;
+#pragma unroll
+      for (int a = 0; a < TS; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < TS; ++b) s = __builtin_fma(bt[a * TS + b], w.vin[tj * TS + b], s);
+        part[a] = group8_sum(s);
+      }
+      if (tj == 0) {
+#pragma unroll
+        for (int a = 0; a < TS; ++a) w.vout[ti * TS + a] = part[a];
+      }
+      const double dot = wave_sum(lane < dim ? xpt_ * v : 0.0);
+      wave_sync();
+      const double y = (lane < Geo<TS>::DP) ? w.vout[Geo<TS>::pos(lane)] : 0.0;
+      wave_sync();
+      return lane < dim ? __builtin_fma(xpt_, dot / (double)dim, y) : 0.0;
+    } else {  // diag(1 + x^2)
+      return lane < dim ? __builtin_fma(xpt_ * xpt_, v, v) : 0.0;
+    }
+  }
   __device__ __forceinline__ double half_vjp_inv(double q) {
     return half_vjp_tiles<TS, RMETRIC>(T, q, dim, lane, w, base_lds);
   }
@@ -437,8 +478,9 @@ __device__ __forceinline__ void implicit_leapfrog_body(const ImplicitArgs& A, do
   bk.target = A.target;
   bk.w = make_wave_lds<TS, RMETRIC>(wl);
   bk.stash = wl + 320;
-  bk.blk = wl + 320 + SL_COUNT * 64;
+  bk.blk = wl + 320 + SL_COUNT_REFINE * 64;
   bk.base_lds = (RMETRIC == MM_RMETRIC_USER) ? A.rparams : base_lds;  // a user metric reads its params directly
+  bk.refine_on = A.no_refine == 0;
   bk.tparams = A.tparams;
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
@@ -476,8 +518,9 @@ __device__ __forceinline__ void implicit_midpoint_body(const ImplicitArgs& A, do
   bk.target = A.target;
   bk.w = make_wave_lds<TS, RMETRIC>(wl);
   bk.stash = wl + 320;
-  bk.blk = wl + 320 + SL_COUNT * 64;
+  bk.blk = wl + 320 + SL_COUNT_REFINE * 64;
   bk.base_lds = (RMETRIC == MM_RMETRIC_USER) ? A.rparams : base_lds;  // a user metric reads its params directly
+  bk.refine_on = A.no_refine == 0;
   bk.tparams = A.tparams;
   bk.slot(MP_Q) = act ? A.pos[chain * dim + lane] : 0.0;
   bk.slot(MP_P) = act ? A.mom[chain * dim + lane] : 0.0;

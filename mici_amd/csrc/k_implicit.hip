@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64 * kWaves) void debug_primitive_kernel(ImplicitAr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* wl = lds + base_elems + wave * kWaveLdsDoubles;
   const WaveLds w{wl, wl + 64, wl + 128, wl + 192, wl + 256};
-  double* blk = wl + 320 + SL_COUNT * 64;
+  double* blk = wl + 320 + SL_COUNT_REFINE * 64;
   stage_base<TS, MM_RMETRIC_RANK1>(base_lds, A.rparams, A.dim);
   const int64_t chain = (int64_t)blockIdx.x * kWaves + wave;
   if (chain >= A.n_chains) return;
@@ -228,6 +228,7 @@ int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, dou
   a.n_steps = n_steps;
   a.opts = opts;
   a.counters = d_counters;
+  a.no_refine = mm_refine_disabled();
   return dispatch(ctx, m, StepFn{ctx, a, s->n});
 }
 

@@ -376,7 +376,7 @@ sys.path.insert(0, {root!r})
 from mici_amd import integrators, models, systems
 from oracle import models as omdl
 out = {{}}
-for dim, h, steps in ((64, 0.02, 20), (200, 0.01, 6), (64, 0.35, 4)):
+for dim, h, steps in ((64, 0.02, 20), (200, 0.01, 6), (64, 0.35, 4), (20, 0.05, 20), (7, 0.1, 20)):
     rng = np.random.default_rng(dim + int(1000 * h))
     system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(omdl.make_spd(dim, rng)))
     integ = integrators.ImplicitLeapfrogIntegrator(system, h)
@@ -393,8 +393,8 @@ def test_refined_solves_equal_factorised_solves():
     """the solve-only metric constructions are refined (preconditioned CG from the explicit inverse the
     step holds) instead of factorised.  Same inputs with MICI_AMD_REFINE=0 (every construction factorised, the round-2
     behaviour; the switch is read once per process): identical statuses, step counts and fixed-point evaluation counts,
-    states equal to solver accuracy - on the c3 kernel (D = 64), the c4 kernel (D = 200) and at a step size large
-    enough that chains fail and refinements fall back to the factorisation."""
+    states equal to solver accuracy - on the c3 kernel (D = 64), the c4 kernel (D = 200), the wave-per-chain VALU kernel
+    (D = 20, 7) and at a step size large enough that chains fail and refinements fall back to the factorisation."""
     import json
     import os
     import subprocess
