@@ -369,12 +369,37 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void constrained_wave_kernel(C
   }
 }
 
+// project_onto_cotangent_space of the momenta (systems.py:863-873) - what sample_momentum calls after the draw
 template <int C>
-int launch_wave(mm_ctx* ctx, const ConArgs& a) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) void project_momentum_wave_kernel(ConArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t chain = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (chain >= A.n_chains) return;
+  double* wl = lds + wave * kWaveLds;
+  const WaveCtx w{wl, wl + 64 * kRowStride, wl + 64 * kRowStride + 64, wl + 64 * kRowStride + 128, lane, A.dim};
+  const int dim = A.dim;
+  const bool in = lane < dim;
+  const double q = in ? A.pos[chain * dim + lane] : 0.0;
+  double p = in ? A.mom[chain * dim + lane] : 0.0;
+  const Col<C> jac = jacob_w<C>(A, w, q);
+  const bool ok = project_cotangent_w<C>(A, w, p, jac);
+  if (in) A.mom[chain * dim + lane] = ok ? p : __longlong_as_double(0x7ff8000000000000LL);
+}
+
+template <int C>
+int launch_wave(mm_ctx* ctx, const ConArgs& a, bool project_only) {
   const size_t lds = (size_t)kWavesPerBlock * kWaveLds * sizeof(double);
+  const unsigned blocks = (unsigned)((a.n_chains + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (project_only) {
+    MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(project_momentum_wave_kernel<C>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((project_momentum_wave_kernel<C>), dim3(blocks), dim3(64 * kWavesPerBlock), lds, ctx->stream, a);
+    MM_HIP_CHECK(ctx, hipGetLastError());
+    return MM_OK;
+  }
   MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(constrained_wave_kernel<C>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const unsigned blocks = (unsigned)((a.n_chains + kWavesPerBlock - 1) / kWavesPerBlock);
   hipLaunchKernelGGL((constrained_wave_kernel<C>), dim3(blocks), dim3(64 * kWavesPerBlock), lds, ctx->stream, a);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
@@ -393,15 +418,15 @@ bool mm_constrained_wave_supports(const mmcon::ConArgs& a, int n_constr) {
   }
 }
 
-int mm_launch_constrained_wave(mm_ctx* ctx, int n_constr, const mmcon::ConArgs& a) {
+int mm_launch_constrained_wave(mm_ctx* ctx, int n_constr, const mmcon::ConArgs& a, bool project_only) {
   switch (n_constr) {
-    case 1: return launch_wave<1>(ctx, a);
-    case 2: return launch_wave<2>(ctx, a);
-    case 3: return launch_wave<3>(ctx, a);
-    case 4: return launch_wave<4>(ctx, a);
-    case 5: return launch_wave<5>(ctx, a);
-    case 6: return launch_wave<6>(ctx, a);
-    case 7: return launch_wave<7>(ctx, a);
-    default: return launch_wave<8>(ctx, a);
+    case 1: return launch_wave<1>(ctx, a, project_only);
+    case 2: return launch_wave<2>(ctx, a, project_only);
+    case 3: return launch_wave<3>(ctx, a, project_only);
+    case 4: return launch_wave<4>(ctx, a, project_only);
+    case 5: return launch_wave<5>(ctx, a, project_only);
+    case 6: return launch_wave<6>(ctx, a, project_only);
+    case 7: return launch_wave<7>(ctx, a, project_only);
+    default: return launch_wave<8>(ctx, a, project_only);
   }
 }
