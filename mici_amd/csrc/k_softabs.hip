@@ -297,22 +297,36 @@ struct SoftAbsBackendT {
   // (c, s) must satisfy c^2 + s^2 = 1 to rounding - V stays orthogonal only then - which rules out the tempting
   // unnormalised form a - t b, b + t a with a low-precision t: it scales the two columns, the next rotation mixes a
   // scaled with an unscaled column, and the columns of G come out orthogonal without V being orthogonal.
-  template <bool GROLE>
+  // TRACK (G role, cross pairs of a block round): the squared norms na = |xa|^2, nb = |xb|^2 come in with the columns
+  // and are updated with the rotation (|a'|^2 = c^2 al - 2 c s ga + s^2 be, |b'|^2 = s^2 al + 2 c s ga + c^2 be), so a
+  // round forms ONE dot product (and one 8-lane reduction) instead of three: the dots and their reductions were half of
+  // a round's dependent chain.  The norms are recomputed from the columns at the start of every block round (eight
+  // rounds), so rounding in the recurrence cannot accumulate; it only perturbs the rotation ANGLE at the 1e-15 level -
+  // (c, s) stay normalised, and the convergence test compares ga^2 with al be at 1e-14 / 1e-30.
+  template <bool GROLE, bool TRACK = false>
   __device__ static __forceinline__ bool rotate_pair(double (&xa)[ROWS], double (&xb)[ROWS], double* cs, bool writer,
-                                                     double& big, double& bad, double* prof) {
+                                                     double& big, double& bad, double* prof, double* na = nullptr,
+                                                     double* nb = nullptr) {
     double c = 1.0, s = 0.0;
     if (GROLE) {
       SA_STAMP(t0);
       double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
       for (int j = 0; j < ROWS; ++j) {
-        al = __builtin_fma(xa[j], xa[j], al);
-        be = __builtin_fma(xb[j], xb[j], be);
+        if constexpr (!TRACK) {
+          al = __builtin_fma(xa[j], xa[j], al);
+          be = __builtin_fma(xb[j], xb[j], be);
+        }
         ga = __builtin_fma(xa[j], xb[j], ga);
       }
       SA_STAMP(t1);
-      al = group8_sum(al);
-      be = group8_sum(be);
+      if constexpr (TRACK) {
+        al = *na;
+        be = *nb;
+      } else {
+        al = group8_sum(al);
+        be = group8_sum(be);
+      }
       ga = group8_sum(ga);
       SA_STAMP(t2);
       SA_STAMP_ADD(0, t0, t1);
@@ -330,6 +344,11 @@ struct SoftAbsBackendT {
         s = ga * ri * rc;
         if (d < 0.0) s = -s;
         if (!(fabs(s) <= 1.0)) bad = 1.0;
+        if constexpr (TRACK) {
+          const double cc = c * c, ss = s * s, csg = 2.0 * c * s * ga;
+          *na = __builtin_fma(cc, al, __builtin_fma(ss, be, -csg));
+          *nb = __builtin_fma(ss, al, __builtin_fma(cc, be, csg));
+        }
       }
       SA_STAMP(t3);
       SA_STAMP_ADD(2, t2, t3);
@@ -381,17 +400,29 @@ struct SoftAbsBackendT {
     load_col(M, oa, xa);
     load_col(M, col_offset(bb * 8 + slot, sub), xb);
     const int from = ((threadIdx.x + 8) & 63) << 2;  // byte address of the source lane for ds_bpermute
+    double na = 0.0, nb = 0.0;  // G role: squared norms of the two columns, carried through the eight rounds
+    if constexpr (GROLE) {
+#pragma unroll
+      for (int j = 0; j < ROWS; ++j) {
+        na = __builtin_fma(xa[j], xa[j], na);
+        nb = __builtin_fma(xb[j], xb[j], nb);
+      }
+      na = group8_sum(na);
+      nb = group8_sum(nb);
+    }
+    auto hand_down = [&](double v) {
+      const long long b = __double_as_longlong(v);
+      const int lo = __builtin_amdgcn_ds_bpermute(from, (int)(b & 0xffffffffLL));
+      const int hi = __builtin_amdgcn_ds_bpermute(from, (int)(b >> 32));
+      return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    };
     for (int k = 0; k < 8; ++k) {
       SA_STAMP(ta);
-      rotate_pair<GROLE>(xa, xb, ring + ((7 + k) * 8 + slot) * 2, writer, big, bad, prof);
+      rotate_pair<GROLE, GROLE>(xa, xb, ring + ((7 + k) * 8 + slot) * 2, writer, big, bad, prof, &na, &nb);
       if (k < 7) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-          const long long b = __double_as_longlong(xb[r]);
-          const int lo = __builtin_amdgcn_ds_bpermute(from, (int)(b & 0xffffffffLL));
-          const int hi = __builtin_amdgcn_ds_bpermute(from, (int)(b >> 32));
-          xb[r] = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-        }
+        for (int r = 0; r < ROWS; ++r) xb[r] = hand_down(xb[r]);
+        if constexpr (GROLE) nb = hand_down(nb);  // the norm travels with its column
       }
       SA_STAMP(td);
       SA_STAMP_ADD(3, ta, td);
