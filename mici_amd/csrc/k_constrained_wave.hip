@@ -15,8 +15,9 @@
 //
 // Replaces, per chain and per step (reference /root/reference/src/mici): ConstrainedLeapfrogIntegrator._step*
 // integrators.py:929-984; solve_projection_onto_manifold_newton / _quasi_newton / _newton_with_line_search
-// solvers.py:429-469, 303-343, 561-614; ConstrainedEuclideanMetricSystem.* systems.py:786-873 (dens_wrt_hausdorff=True,
-// no Gaussian split: those variants, user constraints and the auxiliary kernels stay on the lane-per-chain path).
+// solvers.py:429-469, 303-343, 561-614; ConstrainedEuclideanMetricSystem.* systems.py:786-873, both density conventions
+// (systems.py:829-862, 1024-1031).  The Gaussian split, user constraints and the Gram log-determinant kernel stay on the
+// lane-per-chain path.
 #include "constrained_core.h"
 
 using namespace mmcon;
@@ -212,6 +213,35 @@ __device__ __forceinline__ double grad_w(const ConArgs& A, const WaveCtx& w, dou
   return g;
 }
 
+// dh1_dpos (systems.py:858-862): grad_neg_log_dens, plus for dens_wrt_hausdorff=False
+// grad_log_det_sqrt_gram = mhp_constr(inv_gram J M^-1) (systems.py:1024-1031).  false = LinAlgError.
+// The built-in constraints' Hessians are constant multiples of (part of) the identity: sum_k m[k] * H_k picks
+// 2 m[0] on the coordinates the quadratic constraint involves, nothing for the linear ones.
+template <int C>
+__device__ __forceinline__ bool dh1_dpos_w(const ConArgs& A, const WaveCtx& w, double q, double* out) {
+  double g = grad_w(A, w, q);
+  if (A.ambient) {
+    const Col<C> jac = jacob_w<C>(A, w, q);
+    const CMat<C> gram = rows_inner_w<C>(w, jac, minv_rows_w<C>(A, w, jac), 1.0);
+    CMat<C> inv;
+    double ld;
+    if (!all_finite<C>(gram) || !chol_inverse<C>(gram, &inv, &ld)) return false;
+    Col<C> m;  // column `lane` of inv_gram @ J
+#pragma unroll
+    for (int a = 0; a < C; ++a) {
+      double s = inv.m[a][0] * jac.v[0];
+#pragma unroll
+      for (int b = 1; b < C; ++b) s += inv.m[a][b] * jac.v[b];
+      m.v[a] = s;
+    }
+    const double m0 = minv1(A, w, m.v[0]);  // only row 0 meets a non-zero constraint Hessian
+    if (A.constr == MM_CONSTR_SPHERE || A.constr == MM_CONSTR_SPHERE_PLANE) g += 2.0 * m0;
+    else if (A.constr == MM_CONSTR_CIRCLE) g += w.lane < 2 ? 2.0 * m0 : 0.0;
+  }
+  *out = g;
+  return true;
+}
+
 // The three projection solvers (solvers.py:429-469, 303-343, 561-614) on the lane-distributed state.
 template <int C>
 __device__ __forceinline__ int project_w(const ConArgs& A, const WaveCtx& w, double& q, double& p, const Col<C>& jac_prev,
@@ -315,7 +345,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void constrained_wave_kernel(C
   long long n_newton = 0, n_grad = 0;
   int status = MM_ST_OK, done = 0;
 
-  double g = grad_w(A, w, q);  // cached dh1_dpos at the current position
+  double g;  // cached dh1_dpos at the current position
+  if (!dh1_dpos_w<C>(A, w, q, &g)) status = MM_ST_LINALG;
   Col<C> jac = jacob_w<C>(A, w, q);
   ++n_grad;
   const int my_steps = chain_steps(A.chain_steps, chain, A.n_steps);
@@ -334,7 +365,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void constrained_wave_kernel(C
       status = project_w<C>(A, w, qs, ps, j_prev, t_in, &j_new, &n_newton);
       if (status != MM_ST_OK) break;
       if (inn == n_inner - 1) {  // pre-evaluated dh1_dpos, integrators.py:956-969
-        gs = grad_w(A, w, qs);
+        if (!dh1_dpos_w<C>(A, w, qs, &gs)) { status = MM_ST_LINALG; break; }
         ++n_grad;
       }
       if (!project_cotangent_w<C>(A, w, ps, j_new)) { status = MM_ST_LINALG; break; }
@@ -410,7 +441,7 @@ int launch_wave(mm_ctx* ctx, const ConArgs& a, bool project_only) {
 // true if the wave-per-chain kernel covers this model (the caller falls back to the lane-per-chain path otherwise)
 bool mm_constrained_wave_supports(const mmcon::ConArgs& a, int n_constr) {
   if (a.dim <= 8 || a.dim > 64 || n_constr < 1 || n_constr > 8 || n_constr >= a.dim) return false;
-  if (a.ambient || a.gaussian) return false;
+  if (a.gaussian) return false;  // the Gaussian split's rotations stay on the lane-per-chain path
   switch (a.constr) {
     case MM_CONSTR_LINEAR: case MM_CONSTR_SPHERE: case MM_CONSTR_CIRCLE: case MM_CONSTR_FIRST: return true;
     case MM_CONSTR_SPHERE_PLANE: return n_constr == 2;

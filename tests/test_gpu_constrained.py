@@ -217,7 +217,9 @@ from mici_amd import integrators, models, solvers, systems
 from oracle import models as omdl
 out = {{}}
 cases = [("sphereplane_d40_newton", 40, 0, "dense"), ("sphereplane_d33_linesearch", 33, 2, "diag"),
-         ("linear_c8_d64_quasi", 64, 1, "dense"), ("sphere_d12_newton_inner2", 12, 0, "identity")]
+         ("linear_c8_d64_quasi", 64, 1, "dense"), ("sphere_d12_newton_inner2", 12, 0, "identity"),
+         ("sphereplane_d24_newton_ambient", 24, 0, "dense"), ("sphere_d48_linesearch_ambient", 48, 2, "diag"),
+         ("linear_c8_d20_newton_ambient", 20, 0, "dense")]
 for name, d, solver, mk in cases:
     rng = np.random.default_rng(d)
     metric = None if mk == "identity" else (np.exp(0.2 * rng.standard_normal(d)) if mk == "diag" else omdl.make_spd(d, rng))
@@ -236,7 +238,8 @@ for name, d, solver, mk in cases:
         con = models.SphereConstr()
         x = rng.standard_normal((24, d))
         q0 = x / np.linalg.norm(x, axis=1, keepdims=True)
-    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(d, 0.5, 0.25), con, metric=metric)
+    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(d, 0.5, 0.25), con, metric=metric,
+                                                           dens_wrt_hausdorff="ambient" not in name)
     proj = [solvers.solve_projection_onto_manifold_newton, solvers.solve_projection_onto_manifold_quasi_newton,
             solvers.solve_projection_onto_manifold_newton_with_line_search][solver]
     integ = integrators.ConstrainedLeapfrogIntegrator(system, 0.04, projection_solver=proj,
@@ -253,8 +256,9 @@ def test_wave_per_chain_kernel_equals_lane_per_chain_core():
     """k_constrained_wave.hip (8 < D <= 64: one wave per chain, Jacobians and vectors in registers, sums through LDS)
     against the lane-per-chain core (MICI_AMD_CONSTRAINED_KERNEL=lane: the padded instantiations with their arrays in
     scratch) on the same inputs: all three projection solvers, two constraints and eight, identity / diagonal / dense
-    metric, n_inner_step = 2, both time directions - same statuses, step counts and Newton iteration counts, states to
-    rounding (the D-long sums are ordered differently)."""
+    metric, n_inner_step = 2, both density conventions (dens_wrt_hausdorff=False adds the Gram log-determinant's
+    gradient), both time directions - same statuses, step counts and Newton iteration counts, states to rounding (the
+    D-long sums are ordered differently)."""
     import json
     import os
     import subprocess
@@ -279,3 +283,31 @@ def test_wave_per_chain_kernel_equals_lane_per_chain_core():
         assert_close(np.array(a["p"]), np.array(b["p"]), 1e-11, f"{key} momenta")
         differs = differs or a["q"] != b["q"]
     assert differs  # two different kernels really ran (their sums are ordered differently)
+
+
+@pytest.mark.parametrize("variant", ["hausdorff", "ambient"])
+def test_wave_per_chain_kernel_matches_oracle(variant):
+    """The wave-per-chain kernel against the oracle directly (D = 20, sphere and plane, dense metric), both density
+    conventions: statuses, step counts, states."""
+    rng = np.random.default_rng(41)
+    n, d, h, steps = 64, 20, 0.05, 8
+    metric = omdl.make_spd(d, rng)
+    normal = rng.standard_normal(d)
+    q0 = rng.standard_normal((n, d))
+    q0 -= np.outer(q0 @ normal, normal) / (normal @ normal)
+    q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
+    hausdorff = variant == "hausdorff"
+    osys = orc.ConstrainedSystem(omdl.Poly(d, 0.5, 0.25), omdl.SpherePlaneConstr(normal), omdl.METRIC_DENSE, metric,
+                                 dens_wrt_hausdorff=hausdorff)
+    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(d, 0.5, 0.25), models.SpherePlaneConstr(normal),
+                                                           metric=metric, dens_wrt_hausdorff=hausdorff)
+    integ = integrators.ConstrainedLeapfrogIntegrator(system, h)
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, d)))
+    dirs = np.where(rng.random(n) < 0.5, 1, -1).astype(np.int8)
+    q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=steps)
+    assert np.all(status == 0)
+    for cidx in range(0, n, 8):
+        qo, po, so, no = orc.constrained_leapfrog_steps(osys, q0[cidx], p0[cidx], dirs[cidx] * h, steps)
+        assert so == status[cidx] and no == n_done[cidx]
+        assert_close(q[cidx], qo, 1e-10, f"q chain {cidx}")
+        assert_close(p[cidx], po, 1e-10, f"p chain {cidx}")
