@@ -44,7 +44,7 @@ struct SaLds {
   double* ring; // rotation (c, s) of a block round: [2 (parity)][4 (G wave)][15 (local round)][8 (pair slot)][2]
   double* red;  // [16]
   double* cnt;  // [8] work counters of the chain (thread 0)
-  double* prof; // [8] -DMM_SOFTABS_PROF: cycle stamps inside the Jacobi rounds
+  double* prof; // [16] -DMM_SOFTABS_PROF: cycle stamps inside the Jacobi rounds [0..4], phases of the step [8..15]
   double* stash;  // [SL_COUNT][65]
 };
 constexpr int kRingDoubles = 15 * 8 * 2;  // (c, s) of the 15 local rounds x 8 pair slots of a block round
@@ -72,6 +72,19 @@ __device__ __forceinline__ double block_reduce4(double v, int kind_max, double* 
   return uniform_f64(r);
 }
 
+// maxima without NaN propagation (v_max_f64 returns the other operand): over a 16-lane DPP row, over the wave
+__device__ __forceinline__ double row_fmax(double v) {
+  v = __builtin_fmax(v, dpp_move<kDppXor1>(v));
+  v = __builtin_fmax(v, dpp_move<kDppXor2>(v));
+  v = __builtin_fmax(v, dpp_move<kDppHalfMirror>(v));
+  return __builtin_fmax(v, dpp_move<kDppMirror>(v));
+}
+__device__ __forceinline__ double wave_fmax(double v) {
+  v = row_fmax(v);
+  return __builtin_fmax(__builtin_fmax(readlane_f64(v, 0), readlane_f64(v, 16)),
+                        __builtin_fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+
 // sum over the RP (16 or 8) consecutive lanes that share an output element (one DPP row, or half of one)
 template <int RP>
 __device__ __forceinline__ double rp_sum_n(double v) {
@@ -85,6 +98,12 @@ __device__ __forceinline__ double rp_sum_n(double v) {
 #define SA_PROF_BEGIN() const long long prof_t0_ = __builtin_readcyclecounter()
 #define SA_PROF_END(slot_) \
   do { if (tid_raw == 0) w.cnt[slot_] += (double)(__builtin_readcyclecounter() - prof_t0_); } while (0)
+#define SA_PROF_END2(slot_) \
+  do { if (tid_raw == 0) w.prof[slot_] += (double)(__builtin_readcyclecounter() - prof_t0_); } while (0)
+#define SA_LAP(slot_) \
+  do { const long long now_ = __builtin_readcyclecounter(); if (tid_raw == 0) w.prof[slot_] += (double)(now_ - lap_); \
+       lap_ = now_; } while (0)
+#define SA_LAP_BEGIN() long long lap_ = __builtin_readcyclecounter()
 // -DMM_SOFTABS_PROF=2 adds stamps inside a Jacobi round of G wave 0 (lane 0 accumulates into prof[k]; scheduling
 // barriers pin their place; they cost ~15 % themselves)
 #if MM_SOFTABS_PROF >= 2
@@ -98,6 +117,9 @@ __device__ __forceinline__ double rp_sum_n(double v) {
 #else
 #define SA_PROF_BEGIN() do {} while (0)
 #define SA_PROF_END(slot_) do {} while (0)
+#define SA_PROF_END2(slot_) do {} while (0)
+#define SA_LAP(slot_) do {} while (0)
+#define SA_LAP_BEGIN() do {} while (0)
 #define SA_STAMP(var_) do {} while (0)
 #define SA_STAMP_ADD(k_, a_, b_) do {} while (0)
 #endif
@@ -118,7 +140,7 @@ struct SoftAbsBackendT {
   static constexpr int GW = NBLK / 2;     // waves rotating G (as many again replay on V)
   static constexpr int ROWS = NP / 8;     // rows per lane of a column pair
   static constexpr bool kMatricesInLds = NP == 64;
-  static constexpr int kLdsVectors = 6 * NP + 2 * GW * kRingDoubles + 16 + 8 + 8 + SL_COUNT * (NP + 1);
+  static constexpr int kLdsVectors = 6 * NP + 2 * GW * kRingDoubles + 16 + 8 + 16 + SL_COUNT * (NP + 1);
   static constexpr int kLdsDoubles = kLdsVectors + (kMatricesInLds ? MAT + 2 * MATJ : 0);
   static constexpr int kWorkDoubles = kMatricesInLds ? 0 : MAT + 2 * MATJ;  // per chain, global memory
   __device__ static __forceinline__ double rp_sum(double v) { return rp_sum_n<RP>(v); }
@@ -128,7 +150,9 @@ struct SoftAbsBackendT {
   static constexpr bool kCountersInLds = true;  // implicit_core.h: work counters in LDS, bumped by thread 0
   int dim, tid_raw, target;
   int warm = 0;  // eigendecompositions since the last cold start (0: w.V is not a usable basis)
-  int n_sweeps = 0, n_eigh = 0;  // work counters (reported as n_newton_iters / n_inverse)
+  int n_sweeps = 0, n_eigh = 0;  // work counters (reported as n_newton_iters / n_eigh)
+  int n_refined = 0;             // decompositions obtained by refine_eigh() alone (reported as n_refine)
+  bool refine_on = true;         // MICI_AMD_REFINE=0: every decomposition by Jacobi sweeps
   double coeff;
   SaLds w;
   const double* tparams;
@@ -156,13 +180,16 @@ struct SoftAbsBackendT {
   __device__ __forceinline__ double& slot(int i) { return w.stash[i * (NP + 1) + (tid < NP ? tid : NP)]; }
 
   __device__ __forceinline__ double norm(double x, int kind) {
+    SA_PROF_BEGIN();
     const double a = tid < dim ? x : 0.0;
-    if (kind == MM_NORM_LINF) return block_reduce4(fabs(a), 1, w.red);
-    return sqrt(block_reduce4(a * a, 0, w.red));
+    const double r = kind == MM_NORM_LINF ? block_reduce4(fabs(a), 1, w.red) : sqrt(block_reduce4(a * a, 0, w.red));
+    SA_PROF_END2(13);
+    return r;
   }
 
   // ---- hess_neg_log_dens(q) into w.H (systems.py:1870-1888); q flat --------------------------------
   __device__ __forceinline__ void build_hessian(double q) {
+    SA_PROF_BEGIN();
     if (tid < NP) w.nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
     const double* x = w.nat;
@@ -189,6 +216,7 @@ struct SoftAbsBackendT {
       if (warm == 0) w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
+    SA_PROF_END2(8);
   }
 
   // G = H V, written COLUMN-major (leading dimension LDJ) into w.W, rows and columns >= dim zeroed: the start of the one-sided
@@ -440,6 +468,133 @@ struct SoftAbsBackendT {
     bb = R - w; if (bb < 0) bb += NBLK - 1;
   }
 
+  // ---- eigh(H) from a nearby eigenvector basis, by matrix products (NP = 64, matrices in LDS) ----------------------
+  // Consecutive decompositions of a step are at nearby positions, so X = V_prev almost diagonalises the new Hessian A.
+  // One pass of the Ogita-Aishima refinement of an approximate eigenvector matrix
+  //     S = X^T A X,  R = I - X^T X,  lam_i = S_ii / (1 - R_ii),
+  //     E_ij = (S_ij + lam_j R_ij) / (lam_j - lam_i)  (i != j),   E_ii = R_ii / 2,   X <- X + X E
+  // squares the error (rotation AND loss of orthogonality) and is four 64^3 products on the matrix cores - wave t owns
+  // the 16 x 16 tile (t / 4, t % 4) of every product - plus five workgroup barriers: ~6 k cycles where a Jacobi sweep
+  // is 63 dependent rotation rounds, ~80 k.  c3(b): 1-4 passes per decomposition, 2.4 on average
+  // (tools/refine_eigh_proto.py replays the Hessians of a chain on the CPU).
+  // Pairs closer than kRefineGuard |A| are treated as a multiple eigenvalue (E_ij = R_ij / 2, any basis of their
+  // invariant subspace will do); that is only valid if their coupling S_ij has vanished by the time the rest has
+  // converged - otherwise, and whenever the first pass finds a rotation that is not small, the Jacobi sweeps take over:
+  //   returns 1: done (w.V, w.lam);  0: w.V is still orthonormal, continue with warm-started sweeps;
+  //          -1: w.V was updated but the passes stopped contracting - restart the sweeps from the identity.
+  // The eigenvalues are the Rayleigh quotients of the last pass' input, whose error is the square of a rotation
+  // below kRefineDone.
+  static constexpr double kRefineStart = 0.35;   // largest first-pass |E_ij| the refinement is started from
+  static constexpr double kRefineDone = 1e-7;    // a pass whose largest |E_ij| is below this is the last
+  static constexpr double kRefineGuard = 1e-6;   // relative eigenvalue gap below which a pair counts as multiple
+  static constexpr double kRefineSplit = 1e-11;  // largest |S_ij| / |A| tolerated inside such a pair at the end
+  static constexpr int kRefineMaxPass = 8;
+  __device__ __forceinline__ int refine_eigh() {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int I = wave >> 2, J = wave & 3;
+    const int ri = 16 * I + j, cj = 16 * J + j;  // row / column this lane addresses in the operand tiles
+    const bool cj_ok = cj < dim;
+    double* const X = w.V;
+    double* const Gm = w.W;       // G = A X, then E (row-major, leading dimension LD)
+    double* const part = w.ring;  // [2][16] per-wave maxima (the ring is idle outside the sweeps)
+    if (dim < NP) {  // zero beyond dim, so that the operand loads of the products need no masks
+      for (int el = tid; el < NP * NP; el += NT) {
+        const int i = el / NP, c = el % NP;
+        if (i >= dim || c >= dim) {
+          w.H[i * LD + c] = 0.0;
+          X[i * LD + c] = 0.0;
+        }
+      }
+      __syncthreads();
+    }
+    // Operand addresses of this lane.  Lane group g takes the k = 16 g + kk terms of a product (any assignment of k to
+    // the four groups is as good to the sum, as long as both operands use the same): the two groups of a 32-lane LDS
+    // access are then 16 rows of LD = 65 doubles apart - 32 banks - and neither the loads that walk down a column (16
+    // lanes on consecutive doubles) nor the ones that walk along a row (16 lanes a row apart) conflict.  A = H is
+    // symmetric and is read down its columns.
+    const double* const xcol_i = X + 16 * g * LD + ri;
+    const double* const xcol_j = X + 16 * g * LD + cj;
+    const double* const hcol_i = w.H + 16 * g * LD + ri;
+    const double* const gcol_j = Gm + 16 * g * LD + cj;
+    const double* const xrow_i = X + ri * LD + 16 * g;
+    double prev = 0.0;
+    SA_LAP_BEGIN();
+    for (int pass = 0; pass < kRefineMaxPass; ++pass) {
+      SA_LAP(4);
+      {  // G = A X
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < NP / 4; ++kk)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(hcol_i[kk * LD], xcol_j[kk * LD], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Gm[(16 * I + 4 * r + g) * LD + cj] = acc[r];
+      }
+      __syncthreads();
+      SA_LAP(0);
+      d4 s = {0.0, 0.0, 0.0, 0.0}, xx = {0.0, 0.0, 0.0, 0.0};  // tiles of X^T G and X^T X
+#pragma unroll
+      for (int kk = 0; kk < NP / 4; ++kk) {
+        const double a = xcol_i[kk * LD];
+        s = __builtin_amdgcn_mfma_f64_16x16x4f64(a, gcol_j[kk * LD], s, 0, 0, 0);
+        xx = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xcol_j[kk * LD], xx, 0, 0, 0);
+      }
+      if (I == J) {  // Rayleigh quotients from the diagonal tiles: element (4 r + g, j) of the tile is acc[r]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * r + g == j) w.lam[cj] = cj_ok ? s[r] / xx[r] : 1.0;
+      }
+      __syncthreads();
+      SA_LAP(1);
+      // E, its largest entry and the largest coupling left inside a "multiple" pair.  A NaN anywhere (a non-finite
+      // Hessian) must not be lost in the maxima: it is counted as an infinite rotation
+      const double norm_a = uniform_f64(wave_fmax(lane < dim ? fabs(w.lam[lane]) : 0.0));
+      const double lj = w.lam[cj];
+      const double inf = __longlong_as_double(0x7ff0000000000000LL);
+      double max_e = (norm_a == norm_a) ? 0.0 : inf, near_s = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + 4 * r + g;
+        const double li = w.lam[i];
+        const double rij = (i == cj ? 1.0 : 0.0) - xx[r];
+        const double gap = lj - li;
+        const bool far = fabs(gap) > kRefineGuard * norm_a;
+        double e = (i != cj && far) ? fdiv(__builtin_fma(lj, rij, s[r]), gap) : 0.5 * rij;
+        if (i >= dim || !cj_ok) e = 0.0;
+        else if (i != cj && !far) near_s = __builtin_fmax(near_s, fabs(s[r]));
+        max_e = __builtin_fmax(max_e, (e == e && s[r] == s[r]) ? fabs(e) : inf);
+        Gm[i * LD + cj] = e;  // every wave is past its reads of G: the barrier above
+      }
+      max_e = wave_fmax(max_e);
+      near_s = wave_fmax(near_s);
+      if (lane == 0) {
+        part[wave] = max_e;
+        part[16 + wave] = near_s;
+      }
+      __syncthreads();
+      max_e = uniform_f64(row_fmax(part[j]));  // the 16 lanes of a row read the 16 waves' values
+      near_s = uniform_f64(row_fmax(part[16 + j]));
+      if (pass == 0 && !(max_e < kRefineStart)) return 0;           // (NaN included) w.V untouched
+      const bool last = max_e < kRefineDone;
+      if (!last && pass > 0 && !(max_e < prev)) return -1;
+      prev = max_e;
+      SA_LAP(2);
+      d4 acc;  // X' = X + X E
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = X[(16 * I + 4 * r + g) * LD + cj];
+#pragma unroll
+      for (int kk = 0; kk < NP / 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xrow_i[kk], gcol_j[kk * LD], acc, 0, 0, 0);
+      __syncthreads();  // every wave has read the X it needs
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X[(16 * I + 4 * r + g) * LD + cj] = acc[r];
+      __syncthreads();
+      SA_LAP(3);
+      if (last) return (near_s <= kRefineSplit * norm_a) ? 1 : 0;  // 0: a split cluster the passes cannot resolve
+    }
+    return -1;
+  }
+
   __device__ __forceinline__ bool eigh() {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -450,6 +605,25 @@ struct SoftAbsBackendT {
     bool converged = false;
     ++n_eigh;
     SA_PROF_BEGIN();
+    if constexpr (kMatricesInLds) {
+      if (refine_on && warm > 0) {
+        const int rc = refine_eigh();
+        SA_PROF_END2(11);
+        if (rc > 0) {
+          ++n_refined;
+          SA_PROF_END(4);
+          return true;
+        }
+        if (rc < 0) {  // restart from the identity (the Hessian is intact: the passes only read it)
+          warm = 0;
+          for (int el = tid; el < NP * dim; el += NT) {
+            const int i = el / NP, j = el % NP;
+            if (j < dim) w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+          }
+          __syncthreads();
+        }
+      }
+    }
     times_basis();
     char* const G = reinterpret_cast<char*>(w.W);
     char* const Vt = reinterpret_cast<char*>(w.H);
@@ -528,6 +702,7 @@ struct SoftAbsBackendT {
 
   // softabs(x) = x / tanh(coeff x); grad_softabs (matrices.py:1662-1669)
   __device__ __forceinline__ bool regularise() {
+    SA_PROF_BEGIN();
     double bad = 0.0;
     if (tid < NP) {
       double lt = 1.0, gs = 0.0;
@@ -541,7 +716,9 @@ struct SoftAbsBackendT {
       w.lamt[tid] = lt;
       w.gsa[tid] = gs;
     }
-    return block_reduce4(bad, 0, w.red) == 0.0;
+    const bool ok = block_reduce4(bad, 0, w.red) == 0.0;
+    SA_PROF_END2(9);
+    return ok;
   }
 
   __device__ __forceinline__ bool build_and_invert(double x) {
@@ -595,8 +772,11 @@ struct SoftAbsBackendT {
   }
 
   __device__ __forceinline__ double matvec(double v) {
+    SA_PROF_BEGIN();
     const double c = vt_times(v);
-    return v_times(tid < dim ? (1.0 / w.lamt[tid]) * c : 0.0);
+    const double u = v_times(tid < dim ? (1.0 / w.lamt[tid]) * c : 0.0);
+    SA_PROF_END2(10);
+    return u;
   }
 
   // mtp_neg_log_dens(q)(m) given only what the built-in Tressians touch: m_ii (md) and the symmetric
@@ -778,11 +958,13 @@ struct SoftAbsBackendT {
   }
 
   __device__ __forceinline__ double grad(double q) {
+    SA_PROF_BEGIN();
     if (tid < NP) w.nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
     const TargetAux aux = target_prepare<true>(target, w.nat, dim, tparams, (int)tid & 63);
     const double g = (tid < dim) ? target_grad_elem<true>(target, aux, w.nat, tid, dim, tparams) : 0.0;
     __syncthreads();
+    SA_PROF_END2(12);
     return g;
   }
   __device__ __forceinline__ double nld_elem(double q) {
@@ -805,6 +987,7 @@ __device__ __forceinline__ void init_backend(SoftAbsBackendT<NP>& bk, const Impl
   bk.target = A.target;
   bk.coeff = uniform_f64(A.z[0]);  // softabs coefficient (device copy of the model's rmetric_params)
   bk.tparams = A.tparams;
+  bk.refine_on = A.no_refine == 0;
   double* p = lds;
   if (B::kMatricesInLds) {
     bk.w.H = p; p += B::MATJ;
@@ -824,10 +1007,10 @@ __device__ __forceinline__ void init_backend(SoftAbsBackendT<NP>& bk, const Impl
   bk.w.ring = p; p += 2 * B::GW * kRingDoubles;
   bk.w.red = p; p += 16;
   bk.w.cnt = p; p += 8;
-  bk.w.prof = p; p += 8;
+  bk.w.prof = p; p += 16;
   bk.w.stash = p;
   if (threadIdx.x < 8) bk.w.cnt[threadIdx.x] = 0.0;
-  if (threadIdx.x < 8) bk.w.prof[threadIdx.x] = 0.0;
+  if (threadIdx.x < 16) bk.w.prof[threadIdx.x] = 0.0;
 }
 
 struct SaArgs {
@@ -867,11 +1050,17 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
 #ifdef MM_SOFTABS_PROF
   if (tid == 0 && chain == 0)
     printf("softabs prof: total %lld eigh(incl basis) %.0f basis %.0f dh2_dpos %.0f half_vjp %.0f | n_eigh %d sweeps %d "
-           "evals %.0f\n", (long long)(__builtin_readcyclecounter() - prof_start), bk.w.cnt[4], bk.w.cnt[5], bk.w.cnt[6],
-           bk.w.cnt[7], bk.n_eigh, bk.n_sweeps, bk.w.cnt[CNT_EVALS]);
+           "refined %d evals %.0f\n", (long long)(__builtin_readcyclecounter() - prof_start), bk.w.cnt[4], bk.w.cnt[5], bk.w.cnt[6],
+           bk.w.cnt[7], bk.n_eigh, bk.n_sweeps, bk.n_refined, bk.w.cnt[CNT_EVALS]);
   if (tid == 0 && chain == 0)
     printf("softabs prof rounds (cross rounds of G wave 0): dots %.0f reduce %.0f params %.0f whole round %.0f "
            "store+sync %.0f\n", bk.w.prof[0], bk.w.prof[1], bk.w.prof[2], bk.w.prof[3], bk.w.prof[4]);
+  if (tid == 0 && chain == 0)
+    printf("softabs prof refine laps: G=AX %.0f S,XX %.0f E %.0f X+XE %.0f between %.0f\n", bk.w.prof[0], bk.w.prof[1],
+           bk.w.prof[2], bk.w.prof[3], bk.w.prof[4]);
+  if (tid == 0 && chain == 0)
+    printf("softabs prof phases: build_hessian %.0f regularise %.0f matvec %.0f refine_eigh %.0f grad %.0f norm %.0f\n",
+           bk.w.prof[8], bk.w.prof[9], bk.w.prof[10], bk.w.prof[11], bk.w.prof[12], bk.w.prof[13]);
 #endif
   if (tid == 0) {
     A.status[chain] = r.status;
@@ -880,6 +1069,7 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
     if (A.counters) {
       atomicAdd((unsigned long long*)&A.counters->n_newton_iters, (unsigned long long)bk.n_sweeps);
       atomicAdd((unsigned long long*)&A.counters->n_eigh, (unsigned long long)bk.n_eigh);
+      atomicAdd((unsigned long long*)&A.counters->n_refine, (unsigned long long)bk.n_refined);
     }
   }
 }
@@ -928,6 +1118,7 @@ SaArgs make_args(const mm_model* m, mm_state* s) {
   S.a.dim = s->dim;
   S.a.target = m->target;
   S.a.tparams = m->d_target_params;
+  S.a.no_refine = mm_refine_disabled();
   S.coeff = m->d_rmetric_params;
   return S;
 }
