@@ -41,10 +41,12 @@ struct SaLds {
   double* v1;   // vectors
   double* v2;
   double* nat;
+  double* qv;   // [NP] position argument of mtp_lds()
+  double* tp;   // [NP] parameters of the target (weights of the funnel, coefficients of the polynomial)
   double* ring; // rotation (c, s) of a block round: [2 (parity)][4 (G wave)][15 (local round)][8 (pair slot)][2]
-  double* red;  // [16]
+  double* red;  // [2][16]: per-wave partials of a workgroup reduction, two alternating sets
   double* cnt;  // [8] work counters of the chain (thread 0)
-  double* prof; // [16] -DMM_SOFTABS_PROF: cycle stamps inside the Jacobi rounds [0..4], phases of the step [8..15]
+  double* prof; // [24] -DMM_SOFTABS_PROF: cycle stamps inside the Jacobi rounds [0..4], phases of the step [8..15]
   double* stash;  // [SL_COUNT][65]
 };
 constexpr int kRingDoubles = 15 * 8 * 2;  // (c, s) of the 15 local rounds x 8 pair slots of a block round
@@ -60,15 +62,30 @@ __device__ __forceinline__ double uniform_f64(double v) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-__device__ __forceinline__ double block_reduce4(double v, int kind_max, double* red) {
+// Sum / NaN-propagating maximum over the workgroup, the same value in every thread.  `red` holds two sets of 16 per-wave
+// partials used alternately (`flip`, toggled by every call - all threads make the same calls): the next reduction
+// writes the other set, and the one after that is behind a barrier every reader of this one has passed, so ONE
+// workgroup barrier per reduction is enough (a barrier of this 16-wave team costs ~340 cycles).  The 16 partials are
+// read by the 16 lanes of a DPP row and combined there.
+__device__ __forceinline__ double block_reduce4(double v, int kind_max, double* red, int& flip) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* const set = red + 16 * flip;
+  flip ^= 1;
   v = kind_max ? wave_max(v) : wave_sum(v);
-  if (lane == 0) red[wave] = v;
+  if (lane == 0) set[wave] = v;
   __syncthreads();
-  double r = red[0];
-#pragma unroll
-  for (int w = 1; w < NT / 64; ++w) r = kind_max ? nanmax(r, red[w]) : r + red[w];
-  __syncthreads();
+  double r = set[lane & 15];
+  if (kind_max) {
+    r = nanmax(r, dpp_move<kDppXor1>(r));
+    r = nanmax(r, dpp_move<kDppXor2>(r));
+    r = nanmax(r, dpp_move<kDppHalfMirror>(r));
+    r = nanmax(r, dpp_move<kDppMirror>(r));
+  } else {
+    r += dpp_move<kDppXor1>(r);
+    r += dpp_move<kDppXor2>(r);
+    r += dpp_move<kDppHalfMirror>(r);
+    r += dpp_move<kDppMirror>(r);
+  }
   return uniform_f64(r);
 }
 
@@ -140,7 +157,7 @@ struct SoftAbsBackendT {
   static constexpr int GW = NBLK / 2;     // waves rotating G (as many again replay on V)
   static constexpr int ROWS = NP / 8;     // rows per lane of a column pair
   static constexpr bool kMatricesInLds = NP == 64;
-  static constexpr int kLdsVectors = 6 * NP + 2 * GW * kRingDoubles + 16 + 8 + 16 + SL_COUNT * (NP + 1);
+  static constexpr int kLdsVectors = 8 * NP + 2 * GW * kRingDoubles + 32 + 8 + 24 + SL_COUNT * (NP + 1);
   static constexpr int kLdsDoubles = kLdsVectors + (kMatricesInLds ? MAT + 2 * MATJ : 0);
   static constexpr int kWorkDoubles = kMatricesInLds ? 0 : MAT + 2 * MATJ;  // per chain, global memory
   __device__ static __forceinline__ double rp_sum(double v) { return rp_sum_n<RP>(v); }
@@ -151,6 +168,9 @@ struct SoftAbsBackendT {
   int dim, tid_raw, target;
   int warm = 0;  // eigendecompositions since the last cold start (0: w.V is not a usable basis)
   int n_sweeps = 0, n_eigh = 0;  // work counters (reported as n_newton_iters / n_eigh)
+  bool j_valid = false;          // w.H holds the J matrix of the current eigenvalues (dh2_dpos)
+  int red_flip = 0;              // which set of w.red the next workgroup reduction writes
+  int unchecked = 0;             // decompositions since refine_eigh() last measured X^T X
   int n_refined = 0;             // decompositions obtained by refine_eigh() alone (reported as n_refine)
   bool refine_on = true;         // MICI_AMD_REFINE=0: every decomposition by Jacobi sweeps
   double coeff;
@@ -182,7 +202,7 @@ struct SoftAbsBackendT {
   __device__ __forceinline__ double norm(double x, int kind) {
     SA_PROF_BEGIN();
     const double a = tid < dim ? x : 0.0;
-    const double r = kind == MM_NORM_LINF ? block_reduce4(fabs(a), 1, w.red) : sqrt(block_reduce4(a * a, 0, w.red));
+    const double r = kind == MM_NORM_LINF ? block_reduce4(fabs(a), 1, w.red, red_flip) : sqrt(block_reduce4(a * a, 0, w.red, red_flip));
     SA_PROF_END2(13);
     return r;
   }
@@ -190,30 +210,40 @@ struct SoftAbsBackendT {
   // ---- hess_neg_log_dens(q) into w.H (systems.py:1870-1888); q flat --------------------------------
   __device__ __forceinline__ void build_hessian(double q) {
     SA_PROF_BEGIN();
+    j_valid = false;
     if (tid < NP) w.nat[tid] = (tid < dim) ? q : 0.0;
     __syncthreads();
-    const double* x = w.nat;
-    double e = 0.0, s = 0.0;
-    if (target == MM_TARGET_FUNNEL) {
-      e = exp(-x[0]);
-      double acc = 0.0;
-      for (int i = 1 + ((int)tid & 63); i < dim; i += 64) acc += tparams[i - 1] * x[i] * x[i];  // (opaque lane)
-      s = wave_sum(acc);  // every wave computes the same S = sum w x^2
-    }
-    for (int el = tid; el < NP * dim; el += NT) {
+    // Both built-in Hessians are sparse (diagonal; arrowhead): the workgroup zero-fills all NP x NP entries (zero beyond
+    // dim as well: the matrix-core products read whole tiles) and, behind a barrier, thread i < dim writes the entries
+    // of row / column i.  (Every thread evaluating exp() and the branches of a dense fill kept all 16 waves' VALUs
+    // busy for ~6 k cycles a call.)
+    for (int el = tid; el < NP * NP; el += NT) {
       const int i = el / NP, j = el % NP;
-      if (j >= dim) continue;
-      double h = 0.0;
+      w.H[i * LD + j] = 0.0;
+      if (warm == 0 && i < dim && j < dim) w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (tid < NP) {  // whole waves
+      const double* x = w.nat;
+      const double* tp = w.tp;  // the target's parameters, staged in LDS by init_backend
+      const int i = tid;
       if (target == MM_TARGET_POLY) {
-        if (i == j) h = tparams[0] + 3.0 * tparams[1] * x[i] * x[i];
-      } else {  // funnel: arrowhead
-        if (i == 0 && j == 0) h = 1.0 / 9.0 + 0.5 * e * s;
-        else if (i == 0) h = -e * tparams[j - 1] * x[j];
-        else if (j == 0) h = -e * tparams[i - 1] * x[i];
-        else if (i == j) h = e * tparams[i - 1];
+        if (i < dim) w.H[i * LD + i] = tp[0] + 3.0 * tp[1] * x[i] * x[i];
+      } else {  // funnel
+        const double e = exp(-x[0]);
+        const int k = (int)tid & 63;  // every wave forms the whole S = sum w x^2 (NP = 128: two terms a lane)
+        double acc = (k >= 1 && k < dim) ? tp[k - 1] * x[k] * x[k] : 0.0;
+        if (NP > 64 && k + 64 < dim) acc += tp[k + 63] * x[k + 64] * x[k + 64];
+        const double s = wave_sum(acc);
+        if (i == 0) {
+          w.H[0] = 1.0 / 9.0 + 0.5 * e * s;
+        } else if (i < dim) {
+          const double a = -e * tp[i - 1] * x[i];
+          w.H[i] = a;
+          w.H[i * LD] = a;
+          w.H[i * LD + i] = e * tp[i - 1];
+        }
       }
-      w.H[i * LD + j] = h;
-      if (warm == 0) w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
     SA_PROF_END2(8);
@@ -489,6 +519,7 @@ struct SoftAbsBackendT {
   static constexpr double kRefineGuard = 1e-6;   // relative eigenvalue gap below which a pair counts as multiple
   static constexpr double kRefineSplit = 1e-11;  // largest |S_ij| / |A| tolerated inside such a pair at the end
   static constexpr int kRefineMaxPass = 8;
+  static constexpr int kOrthoPeriod = 8;
   __device__ __forceinline__ int refine_eigh() {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, j = lane & 15;
@@ -501,10 +532,7 @@ struct SoftAbsBackendT {
     if (dim < NP) {  // zero beyond dim, so that the operand loads of the products need no masks
       for (int el = tid; el < NP * NP; el += NT) {
         const int i = el / NP, c = el % NP;
-        if (i >= dim || c >= dim) {
-          w.H[i * LD + c] = 0.0;
-          X[i * LD + c] = 0.0;
-        }
+        if (i >= dim || c >= dim) X[i * LD + c] = 0.0;  // (build_hessian zeroes H there)
       }
       __syncthreads();
     }
@@ -519,6 +547,7 @@ struct SoftAbsBackendT {
     const double* const gcol_j = Gm + 16 * g * LD + cj;
     const double* const xrow_i = X + ri * LD + 16 * g;
     double prev = 0.0;
+    ++unchecked;
     SA_LAP_BEGIN();
     for (int pass = 0; pass < kRefineMaxPass; ++pass) {
       SA_LAP(4);
@@ -532,12 +561,25 @@ struct SoftAbsBackendT {
       }
       __syncthreads();
       SA_LAP(0);
-      d4 s = {0.0, 0.0, 0.0, 0.0}, xx = {0.0, 0.0, 0.0, 0.0};  // tiles of X^T G and X^T X
+      // tiles of X^T G and X^T X.  The first pass takes X^T X = I: X is the result of the previous decomposition,
+      // orthonormal to the square of its last rotation (< 1e-14), and a later pass repairs what the first adds to that.
+      // Decompositions that end after their first pass never measure X^T X, so every kOrthoPeriod-th of those does.
+      d4 s = {0.0, 0.0, 0.0, 0.0}, xx = {0.0, 0.0, 0.0, 0.0};
+      const bool with_xx = pass > 0 || unchecked >= kOrthoPeriod;
+      if (with_xx) {
+        unchecked = 0;
 #pragma unroll
-      for (int kk = 0; kk < NP / 4; ++kk) {
-        const double a = xcol_i[kk * LD];
-        s = __builtin_amdgcn_mfma_f64_16x16x4f64(a, gcol_j[kk * LD], s, 0, 0, 0);
-        xx = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xcol_j[kk * LD], xx, 0, 0, 0);
+        for (int kk = 0; kk < NP / 4; ++kk) {
+          const double a = xcol_i[kk * LD];
+          s = __builtin_amdgcn_mfma_f64_16x16x4f64(a, gcol_j[kk * LD], s, 0, 0, 0);
+          xx = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xcol_j[kk * LD], xx, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < NP / 4; ++kk)
+          s = __builtin_amdgcn_mfma_f64_16x16x4f64(xcol_i[kk * LD], gcol_j[kk * LD], s, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xx[r] = (16 * I + 4 * r + g == cj) ? 1.0 : 0.0;
       }
       if (I == J) {  // Rayleigh quotients from the diagonal tiles: element (4 r + g, j) of the tile is acc[r]
 #pragma unroll
@@ -660,13 +702,13 @@ struct SoftAbsBackendT {
         ++done;
         __syncthreads();
       }
-      bad = block_reduce4(bad, 0, w.red);
+      bad = block_reduce4(bad, 0, w.red, red_flip);
       if (bad != 0.0) {
         __builtin_amdgcn_s_setprio(0);
         warm = 0;
         return false;
       }
-      big = block_reduce4(big, 0, w.red);
+      big = block_reduce4(big, 0, w.red, red_flip);
       if (big == 0.0) {
         converged = true;
         break;
@@ -716,7 +758,7 @@ struct SoftAbsBackendT {
       w.lamt[tid] = lt;
       w.gsa[tid] = gs;
     }
-    const bool ok = block_reduce4(bad, 0, w.red) == 0.0;
+    const bool ok = block_reduce4(bad, 0, w.red, red_flip) == 0.0;
     SA_PROF_END2(9);
     return ok;
   }
@@ -779,57 +821,52 @@ struct SoftAbsBackendT {
     return u;
   }
 
-  // mtp_neg_log_dens(q)(m) given only what the built-in Tressians touch: m_ii (md) and the symmetric
-  // first row m_0i (m0), flat.  systems.py:1890-1920; closed forms SURVEY.md Appendix A.
-  __device__ __forceinline__ double mtp(double q, double md, double m0) {
-    if (target == MM_TARGET_POLY) return 6.0 * tparams[1] * q * md;
+  // mtp_neg_log_dens(q)(m) given only what the built-in Tressians touch: m_ii and the symmetric first row m_0i.
+  // systems.py:1890-1920; closed forms SURVEY.md Appendix A.  The arguments are in LDS - w.qv = q, w.v2 = m_ii,
+  // w.nat = m_0i, visible to every thread (the caller's barrier); the result is flat.  For NP = 64 the first wave does
+  // all of it without a barrier - so whoever writes those vectors NEXT from another wave must be behind a barrier of
+  // its own (half_vjp_inv() has one for that; dh2_dpos() and everything else reach one before they write).
+  __device__ __forceinline__ double mtp_lds() {
+    if (NP == 64 && tid >= NP) return 0.0;  // the flat result lives in the first wave, and so does all the work
+    const double qi = (tid < dim) ? w.qv[tid] : 0.0;
+    const double md = (tid < dim) ? w.v2[tid] : 0.0;
+    if (target == MM_TARGET_POLY) return 6.0 * w.tp[1] * qi * md;
     // funnel: q = (v, x)
-    if (tid < NP) {
-      w.v1[tid] = (tid < dim) ? q : 0.0;
-      w.v2[tid] = (tid < dim) ? md : 0.0;
-      w.nat[tid] = (tid < dim) ? m0 : 0.0;
-    }
-    __syncthreads();
-    const double ev = exp(-w.v1[0]);
+    const double m0 = (tid < dim) ? w.nat[tid] : 0.0;
+    const double ev = exp(-w.qv[0]);
     const double mvv = w.v2[0];
-    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (tid >= 1 && tid < dim) {
-      const double wi = tparams[tid - 1], xi = w.v1[tid];
-      a1 = wi * xi * xi;                    // S
-      a2 = 2.0 * w.nat[tid] * wi * xi;      // (m_vi + m_iv) w_i x_i
-      a3 = w.v2[tid] * wi;                  // m_ii w_i
-    }
-    // three sums, one pair of barriers (a workgroup barrier of this team costs ~340 cycles)
+    const double wi = (tid >= 1 && tid < dim) ? w.tp[tid - 1] : 0.0;
+    double a1 = wi * qi * qi;        // S
+    double a2 = 2.0 * m0 * wi * qi;  // (m_vi + m_iv) w_i x_i
+    double a3 = md * wi;             // m_ii w_i
     double S, s2, s3;
-    {
-      double* const red3 = w.ring + 512;  // [16][3]; the ring is idle outside eigh()
+    if constexpr (NP == 64) {  // one wave holds every term: no barrier
+      S = wave_sum(a1);
+      s2 = wave_sum(a2);
+      s3 = wave_sum(a3);
+    } else {
+      // three sums behind one barrier: two alternating sets of per-wave partials, as block_reduce4
+      double* const red3 = w.ring + 512 + 48 * red_flip;  // [16][3]; the ring is idle outside eigh()
+      red_flip ^= 1;
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       a1 = wave_sum(a1);
       a2 = wave_sum(a2);
       a3 = wave_sum(a3);
       if (lane == 0) { red3[3 * wave] = a1; red3[3 * wave + 1] = a2; red3[3 * wave + 2] = a3; }
       __syncthreads();
-      double r1 = 0.0, r2 = 0.0, r3 = 0.0;
-#pragma unroll
-      for (int k = 0; k < NT / 64; ++k) { r1 += red3[3 * k]; r2 += red3[3 * k + 1]; r3 += red3[3 * k + 2]; }
-      __syncthreads();
-      S = uniform_f64(r1);
-      s2 = uniform_f64(r2);
-      s3 = uniform_f64(r3);
+      const int k = lane & 15;
+      S = uniform_f64(rp_sum_n<16>(red3[3 * k]));
+      s2 = uniform_f64(rp_sum_n<16>(red3[3 * k + 1]));
+      s3 = uniform_f64(rp_sum_n<16>(red3[3 * k + 2]));
     }
-    double out = 0.0;
-    if (tid == 0) out = -0.5 * ev * S * mvv + ev * s2 - ev * s3;
-    else if (tid < dim) {
-      const double wk = tparams[tid - 1];
-      out = ev * wk * w.v1[tid] * mvv - ev * wk * (2.0 * w.nat[tid]);
-    }
-    __syncthreads();
-    return out;
+    if (tid == 0) return -0.5 * ev * S * mvv + ev * s2 - ev * s3;
+    return ev * wi * qi * mvv - ev * wi * (2.0 * m0);  // (zero beyond dim: wi = 0)
   }
 
   // 0.5 * mtp(grad_log_abs_det), grad_log_abs_det = V diag(grad_softabs(lam)/lamt) V^T  (:1671-1674)
   __device__ __forceinline__ double half_vjp_inv(double q) {
     SA_PROF_BEGIN();
+    if (tid < NP) w.qv[tid] = (tid < dim) ? q : 0.0;
     {
       const int i = tid / RP, part = tid % RP;
       double md = 0.0, m0 = 0.0;
@@ -843,13 +880,11 @@ struct SoftAbsBackendT {
       }
       md = rp_sum(md);
       m0 = rp_sum(m0);
-      if (part == 0) { w.v2[i] = md; w.v1[i] = m0; }
+      __syncthreads();  // (a previous mtp_lds() may still be reading in the first wave)
+      if (part == 0) { w.v2[i] = md; w.nat[i] = m0; }
     }
     __syncthreads();
-    const double mdf = (tid < dim) ? w.v2[tid] : 0.0;
-    const double m0f = (tid < dim) ? w.v1[tid] : 0.0;
-    __syncthreads();
-    const double out = 0.5 * mtp(q, mdf, m0f);
+    const double out = 0.5 * mtp_lds();
     SA_PROF_END(7);
     return out;
   }
@@ -858,28 +893,42 @@ struct SoftAbsBackendT {
   // e = V^T p / lamt, J_kl = (lamt_k - lamt_l)/(lam_k - lam_l), J_kk = grad_softabs(lam_k)  (:1676-1685)
   __device__ __forceinline__ double dh2_dpos(double p, double q) {
     SA_PROF_BEGIN();
+    SA_LAP_BEGIN();
+    if (tid < NP) w.qv[tid] = (tid < dim) ? q : 0.0;  // for mtp_lds(): visible long before it runs
     const double c = vt_times(p);
     if (tid < NP) w.v1[tid] = (tid < dim) ? c / w.lamt[tid] : 0.0;  // e
     __syncthreads();
+    SA_LAP(16);
     if constexpr (kMatricesInLds) {
       // J into w.H, A into w.W, zero beyond dim; then B = A J on the matrix cores: wave t owns the 16 x 16 tile
       // (t / 4, t % 4) of B - sixteen v_mfma_f64_16x16x4 (A operand: lane (g, m) = A[16 I + m][4 kk + g]; B operand:
       // lane (g, n) = J[4 kk + g][16 Jt + n]; accumulator lane 16 g + j, register r = B[16 I + 4 r + g][16 Jt + j]).
       // md_i = sum_l B_il A_il is reduced over a tile's columns on the DPP row and over the four column tiles through
       // LDS; m0_i = sum_l B_0l A_il needs row 0 of B only.  (The FMA loop this replaces took 31 k cycles a call.)
-      for (int el = tid; el < NP * NP; el += NT) {
-        const int k = el / NP, l = el % NP;
-        double jv = 0.0, av = 0.0;
-        if (k < dim && l < dim) {
-          double num = w.lamt[k] - w.lamt[l], den = w.lam[k] - w.lam[l];
-          if (k == l) { num += w.gsa[k]; den = 1.0; }
-          jv = num / den;                        // 0/0 -> NaN for degenerate spectra, as the reference
-          av = w.V[k * LD + l] * w.v1[l];        // A[i=k][k=l]
+      // (J depends on the eigenvalues only: it is built once per decomposition - the momentum fixed point calls this
+      // several times at one position - and stays in w.H until build_hessian() overwrites it)
+      if (j_valid) {
+        for (int el = tid; el < NP * NP; el += NT) {
+          const int k = el / NP, l = el % NP;
+          w.W[k * LD + l] = (k < dim && l < dim) ? w.V[k * LD + l] * w.v1[l] : 0.0;  // A[i=k][k=l]
         }
-        w.H[k * LD + l] = jv;
-        w.W[k * LD + l] = av;
+      } else {
+        for (int el = tid; el < NP * NP; el += NT) {
+          const int k = el / NP, l = el % NP;
+          double jv = 0.0, av = 0.0;
+          if (k < dim && l < dim) {
+            double num = w.lamt[k] - w.lamt[l], den = w.lam[k] - w.lam[l];
+            if (k == l) { num += w.gsa[k]; den = 1.0; }
+            jv = num / den;                        // 0/0 -> NaN for degenerate spectra, as the reference
+            av = w.V[k * LD + l] * w.v1[l];        // A[i=k][k=l]
+          }
+          w.H[k * LD + l] = jv;
+          w.W[k * LD + l] = av;
+        }
+        j_valid = true;
       }
       __syncthreads();
+      SA_LAP(17);
       double* const part = w.ring;        // [4][NP] column-tile partials of md (the ring is idle outside eigh())
       double* const brow0 = w.ring + 4 * NP;  // [NP] row 0 of B
       {
@@ -887,11 +936,12 @@ struct SoftAbsBackendT {
         const int g = lane >> 4, j = lane & 15;
         const int I = wave >> 2, Jt = wave & 3;
         d4 acc = {0.0, 0.0, 0.0, 0.0};
-        const double* arow = w.W + (16 * I + j) * LD + g;
-        const double* bcol = w.H + g * LD + 16 * Jt + j;
-#pragma unroll 4
+        // lane group g takes the terms k = 16 g + kk (refine_eigh(): no LDS bank conflicts that way)
+        const double* arow = w.W + (16 * I + j) * LD + 16 * g;
+        const double* bcol = w.H + 16 * g * LD + 16 * Jt + j;
+#pragma unroll
         for (int kk = 0; kk < NP / 4; ++kk)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * kk], bcol[4 * kk * LD], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[kk], bcol[kk * LD], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * I + 4 * r + g;
@@ -901,6 +951,7 @@ struct SoftAbsBackendT {
         if (I == 0 && g == 0) brow0[16 * Jt + j] = acc[0];
       }
       __syncthreads();
+      SA_LAP(18);
       {
         const int i = tid / RP, pt = tid % RP;
         double m0 = 0.0;
@@ -949,10 +1000,9 @@ struct SoftAbsBackendT {
       __syncthreads();
     }
     }
-    const double mdf = (tid < dim) ? w.v2[tid] : 0.0;
-    const double m0f = (tid < dim) ? w.nat[tid] : 0.0;
-    __syncthreads();
-    const double out = 0.5 * mtp(q, mdf, m0f);
+    SA_LAP(19);
+    const double out = 0.5 * mtp_lds();
+    SA_LAP(20);
     SA_PROF_END(6);
     return out;
   }
@@ -1004,13 +1054,19 @@ __device__ __forceinline__ void init_backend(SoftAbsBackendT<NP>& bk, const Impl
   bk.w.v1 = p; p += NP;
   bk.w.v2 = p; p += NP;
   bk.w.nat = p; p += NP;
+  bk.w.tp = p; p += NP;
+  bk.w.qv = p; p += NP;
   bk.w.ring = p; p += 2 * B::GW * kRingDoubles;
-  bk.w.red = p; p += 16;
+  bk.w.red = p; p += 32;
   bk.w.cnt = p; p += 8;
-  bk.w.prof = p; p += 16;
+  bk.w.prof = p; p += 24;
   bk.w.stash = p;
+  {  // (visible after the first barrier of whatever runs next)
+    const int n_tp = A.target == MM_TARGET_FUNNEL ? A.dim - 1 : 2;
+    if ((int)threadIdx.x < NP) bk.w.tp[threadIdx.x] = (int)threadIdx.x < n_tp ? A.tparams[threadIdx.x] : 0.0;
+  }
   if (threadIdx.x < 8) bk.w.cnt[threadIdx.x] = 0.0;
-  if (threadIdx.x < 16) bk.w.prof[threadIdx.x] = 0.0;
+  if (threadIdx.x < 24) bk.w.prof[threadIdx.x] = 0.0;
 }
 
 struct SaArgs {
@@ -1059,6 +1115,9 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
     printf("softabs prof refine laps: G=AX %.0f S,XX %.0f E %.0f X+XE %.0f between %.0f\n", bk.w.prof[0], bk.w.prof[1],
            bk.w.prof[2], bk.w.prof[3], bk.w.prof[4]);
   if (tid == 0 && chain == 0)
+    printf("softabs prof dh2_dpos laps: V^T p, e %.0f J, A %.0f B = A J %.0f md, m0 %.0f mtp %.0f\n", bk.w.prof[16],
+           bk.w.prof[17], bk.w.prof[18], bk.w.prof[19], bk.w.prof[20]);
+  if (tid == 0 && chain == 0)
     printf("softabs prof phases: build_hessian %.0f regularise %.0f matvec %.0f refine_eigh %.0f grad %.0f norm %.0f\n",
            bk.w.prof[8], bk.w.prof[9], bk.w.prof[10], bk.w.prof[11], bk.w.prof[12], bk.w.prof[13]);
 #endif
@@ -1092,7 +1151,7 @@ __global__ __launch_bounds__(NT) void softabs_aux_kernel(SaArgs S, double* out, 
   if (S.op == 0) {
     const double u = bk.matvec(p);
     double e = bk.nld_elem(q) + (act ? 0.5 * p * u + 0.5 * log(fabs(bk.w.lamt[tid])) : 0.0);
-    e = block_reduce4(e, 0, bk.w.red);
+    e = block_reduce4(e, 0, bk.w.red, bk.red_flip);
     if (tid == 0) out[chain] = ok ? e : nan;
   } else if (S.op == 1) {
     const double u = bk.matvec(p);

@@ -422,3 +422,81 @@ def test_refined_solves_equal_factorised_solves():
     assert small["n_factor_solve"] == 0 and np.all(np.array(res["1"]["64_0.02"]["status"]) == 0)
     big = res["1"]["64_0.35"]
     assert any(s != 0 for s in big["status"])  # the scenario has failing chains ...
+
+
+_SOFTABS_REFINE_SCRIPT = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from mici_amd import integrators, models, systems
+out = {{}}
+cases = [("funnel_w_d64", 64, np.linspace(0.5, 2.0, 63), 0.02, 12), ("funnel_w_d23", 23, np.linspace(0.7, 1.6, 22), 0.04, 12),
+         ("funnel_equal_d12", 12, np.ones(11), 0.03, 12), ("poly_d40", 40, None, 0.05, 10),
+         ("funnel_w_d64_bigstep", 64, np.linspace(0.5, 2.0, 63), 0.3, 3)]
+for name, dim, wts, h, steps in cases:
+    rng = np.random.default_rng(dim)
+    target = models.Poly(dim, 0.5, 0.25) if wts is None else models.Funnel(wts)
+    system = systems.SoftAbsRiemannianMetricSystem(target, softabs_coeff=1.0)
+    integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+    q0 = 0.6 * rng.standard_normal((12, dim))
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((12, dim)))
+    q, p, st, nd = integ.step_batch(q0, p0, 1, n_steps=steps)
+    out[name] = dict(q=q.tolist(), p=p.tolist(), status=st.tolist(), n_done=nd.tolist(),
+                     counters={{k: int(v) for k, v in integ.last_counters.items()}})
+print(json.dumps(out))
+"""
+
+
+def test_softabs_refined_decompositions_equal_jacobi_decompositions():
+    """a SoftAbs decomposition starts from the previous eigenvectors and is refined by matrix products
+    (k_softabs.hip refine_eigh), the Jacobi sweeps being the fallback.  Same inputs with MICI_AMD_REFINE=0 (every
+    decomposition by sweeps, the round-2 behaviour): identical statuses, step counts and work counters, states equal to
+    solver accuracy - weighted funnel at the c3(b) size and at a padded one, the unweighted funnel (a 10-fold eigenvalue,
+    whose coupling the refinement leaves to the sweeps whenever it has not vanished), a diagonal Hessian whose eigenvalues
+    cross, and a step size at which chains fail."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _SOFTABS_REFINE_SCRIPT.format(root=root)], capture_output=True,
+                           text=True, env=dict(os.environ, MICI_AMD_REFINE=mode), cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in res["1"]:
+        a, b = res["1"][key], res["0"][key]
+        assert a["status"] == b["status"] and a["n_done"] == b["n_done"], key
+        ca, cb = a["counters"], b["counters"]
+        for k in ("n_fp_evals", "n_fp_solves", "n_metric", "n_grad", "n_eigh"):
+            assert ca[k] == cb[k], (key, k, ca[k], cb[k])
+        assert cb["n_refine"] == 0
+        ok = np.array(a["status"]) == 0
+        assert_close(np.array(a["q"])[ok], np.array(b["q"])[ok], 1e-10, f"{key} positions")
+        assert_close(np.array(a["p"])[ok], np.array(b["p"])[ok], 1e-10, f"{key} momenta")
+    for key in ("funnel_w_d64", "funnel_w_d23", "poly_d40"):
+        ca, cb = res["1"][key]["counters"], res["0"][key]["counters"]
+        assert ca["n_refine"] > 0.9 * ca["n_eigh"], (key, ca)              # the sweeps only start a chain ...
+        assert ca["n_newton_iters"] < 0.2 * cb["n_newton_iters"], (key, ca, cb)  # ... (Jacobi sweeps are counted here)
+        assert all(s == 0 for s in res["1"][key]["status"])
+    assert any(s != 0 for s in res["1"]["funnel_w_d64_bigstep"]["status"])
+
+
+def test_softabs_refined_decompositions_match_oracle_at_c3b_size():
+    """The c3(b) configuration itself (scaled funnel, D = 64, h = 0.02) against the oracle over 15 steps."""
+    rng = np.random.default_rng(3)
+    dim, n, h, steps = 64, 3, 0.02, 15
+    w = np.linspace(0.5, 2.0, dim - 1)
+    system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(w), softabs_coeff=1.0)
+    osys = orc.RiemannianSystem(omdl.Funnel(w), None, 1.0, orc.Counters())
+    integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+    q0 = rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+    q, p, status, n_done = integ.step_batch(q0, p0, 1, n_steps=steps)
+    assert integ.last_counters["n_refine"] > 0.9 * integ.last_counters["n_eigh"]
+    for c in range(n):
+        qo, po, so, no = orc.implicit_leapfrog_steps(osys, q0[c], p0[c], h, steps)
+        assert so == status[c] and no == n_done[c]
+        assert_close(q[c], qo, 1e-9, f"q chain {c}")
+        assert_close(p[c], po, 1e-9, f"p chain {c}")
