@@ -10,10 +10,11 @@
 //       "Eigenvalues must all be positive."                       matrices.py:1529-1628
 //   the integrator step itself is implicit_core.h (integrators.py:493-544, solvers.py:47-154)
 //
-// eigh = parallel cyclic ONE-SIDED (Hestenes) Jacobi on G = H V: each round rotates D/2 disjoint column pairs
-// (round-robin schedule) of G and V, a pair per half wave, one barrier per round; sweeps repeat until the columns
-// of G are orthogonal (quadratic convergence, 7-8 sweeps cold, ~2 warm-started).  The result is used only
-// through V f(lambda) V^T products, which do not depend on eigenvalue order or eigenvector signs.
+// eigh = (D <= 64) refinement of the previous decomposition's eigenvectors by matrix products on the matrix cores
+// (refine_eigh(): Ogita-Aishima iteration, quadratic, 2.4 passes of four 64^3 products at c3(b)), falling back to a
+// parallel cyclic ONE-SIDED (Hestenes) Jacobi on G = H V when there is no nearby basis: each round rotates D/2 disjoint
+// column pairs of G and V, sweeps repeat until the columns of G are orthogonal (7-8 sweeps cold, ~2 warm-started).
+// The result is used only through V f(lambda) V^T products, which do not depend on eigenvalue order or eigenvector signs.
 // The matrix-Tressian products of the built-in targets need only the diagonal and the first row of
 // their matrix argument, so V diag(g) V^T and A J A^T are never formed in full; the latter still needs
 // the D^3 product B = A J (A = V diag(e)), done as an LDS-tiled FMA GEMM.
@@ -504,9 +505,10 @@ struct SoftAbsBackendT {
   //     S = X^T A X,  R = I - X^T X,  lam_i = S_ii / (1 - R_ii),
   //     E_ij = (S_ij + lam_j R_ij) / (lam_j - lam_i)  (i != j),   E_ii = R_ii / 2,   X <- X + X E
   // squares the error (rotation AND loss of orthogonality) and is four 64^3 products on the matrix cores - wave t owns
-  // the 16 x 16 tile (t / 4, t % 4) of every product - plus five workgroup barriers: ~6 k cycles where a Jacobi sweep
-  // is 63 dependent rotation rounds, ~80 k.  c3(b): 1-4 passes per decomposition, 2.4 on average
-  // (tools/refine_eigh_proto.py replays the Hessians of a chain on the CPU).
+  // the 16 x 16 tile (t / 4, t % 4) of every product - plus five workgroup barriers: ~21 k cycles, the products at the
+  // CU's FP64 rate (4.1 k cycles each), where a Jacobi sweep is 63 dependent rotation rounds, ~80 k.  c3(b): 1-5 passes
+  // per decomposition, 2.4 on average (profiles/r03_c3b_phases.txt; tools/refine_eigh_proto.py replays the Hessians of
+  // a chain on the CPU).
   // Pairs closer than kRefineGuard |A| are treated as a multiple eigenvalue (E_ij = R_ij / 2, any basis of their
   // invariant subspace will do); that is only valid if their coupling S_ij has vanished by the time the rest has
   // converged - otherwise, and whenever the first pass finds a rotation that is not small, the Jacobi sweeps take over:
