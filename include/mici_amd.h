@@ -168,10 +168,12 @@ typedef struct mm_counters {
   /* Work the device actually executed for the n_metric constructions (round 3): the solve-only constructions of the
    * position fixed points are refined from the explicit inverse at the step's start (implicit_core.h) instead of
    * being factorised.  n_factor_full + n_factor_solve + (refined constructions) = constructions executed. */
-  int64_t n_refine;       /* preconditioned-CG product pairs (M(x) v, M(x0)^-1 v) */
+  int64_t n_refine;       /* preconditioned-CG product pairs (M(x) v, M(x0)^-1 v); SoftAbs: decompositions obtained
+                           * by refining the previous eigenvectors (no Jacobi sweep) */
   int64_t n_factor_full;  /* full sweeps: factorisation + explicit inverse */
   int64_t n_factor_solve; /* trailing sweeps: LDL^T factorisation + one substitution */
-  int64_t reserved;
+  int64_t n_mfma_products; /* SoftAbs, D <= 64: 64^3 products run on the matrix cores (refinement passes, G = H V,
+                            * B = A J of grad_quadratic_form_inv) */
 } mm_counters;
 
 /* ---- library / context ------------------------------------------------------------------------- */

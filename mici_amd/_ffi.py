@@ -70,10 +70,10 @@ class ProjOpts(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_grad", "n_metric", "n_inverse", "n_fp_evals", "n_fp_solves", "n_newton_iters",
-        "n_constr", "n_eigh", "n_refine", "n_factor_full", "n_factor_solve", "reserved")]
+        "n_constr", "n_eigh", "n_refine", "n_factor_full", "n_factor_solve", "n_mfma_products")]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
 # every symbol include/mici_amd.h declares: name -> (restype, argtypes)

@@ -172,6 +172,7 @@ struct SoftAbsBackendT {
   bool j_valid = false;          // w.H holds the J matrix of the current eigenvalues (dh2_dpos)
   int red_flip = 0;              // which set of w.red the next workgroup reduction writes
   int unchecked = 0;             // decompositions since refine_eigh() last measured X^T X
+  int n_products = 0;            // NP^3 products run on the matrix cores (reported as n_mfma_products)
   int n_refined = 0;             // decompositions obtained by refine_eigh() alone (reported as n_refine)
   bool refine_on = true;         // MICI_AMD_REFINE=0: every decomposition by Jacobi sweeps
   double coeff;
@@ -261,6 +262,7 @@ struct SoftAbsBackendT {
       const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
       const int g = lane >> 4, j = lane & 15;
       const int I = wave >> 2, Jt = wave & 3;
+      ++n_products;
       d4 acc = {0.0, 0.0, 0.0, 0.0};
       const double* arow = w.H + (16 * I + j) * LD + g;   // H[16 I + m][4 kk + g], m = j
       const double* bcol = w.V + g * LD + 16 * Jt + j;    // V[4 kk + g][16 Jt + n], n = j
@@ -563,6 +565,7 @@ struct SoftAbsBackendT {
       }
       __syncthreads();
       SA_LAP(0);
+      n_products += 2;  // G and S
       // tiles of X^T G and X^T X.  The first pass takes X^T X = I: X is the result of the previous decomposition,
       // orthonormal to the square of its last rotation (< 1e-14), and a later pass repairs what the first adds to that.
       // Decompositions that end after their first pass never measure X^T X, so every kOrthoPeriod-th of those does.
@@ -570,6 +573,7 @@ struct SoftAbsBackendT {
       const bool with_xx = pass > 0 || unchecked >= kOrthoPeriod;
       if (with_xx) {
         unchecked = 0;
+        ++n_products;
 #pragma unroll
         for (int kk = 0; kk < NP / 4; ++kk) {
           const double a = xcol_i[kk * LD];
@@ -629,6 +633,7 @@ struct SoftAbsBackendT {
 #pragma unroll
       for (int kk = 0; kk < NP / 4; ++kk)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xrow_i[kk], gcol_j[kk * LD], acc, 0, 0, 0);
+      ++n_products;
       __syncthreads();  // every wave has read the X it needs
 #pragma unroll
       for (int r = 0; r < 4; ++r) X[(16 * I + 4 * r + g) * LD + cj] = acc[r];
@@ -938,6 +943,7 @@ struct SoftAbsBackendT {
         const int g = lane >> 4, j = lane & 15;
         const int I = wave >> 2, Jt = wave & 3;
         d4 acc = {0.0, 0.0, 0.0, 0.0};
+        ++n_products;
         // lane group g takes the terms k = 16 g + kk (refine_eigh(): no LDS bank conflicts that way)
         const double* arow = w.W + (16 * I + j) * LD + 16 * g;
         const double* bcol = w.H + 16 * g * LD + 16 * Jt + j;
@@ -1131,6 +1137,7 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
       atomicAdd((unsigned long long*)&A.counters->n_newton_iters, (unsigned long long)bk.n_sweeps);
       atomicAdd((unsigned long long*)&A.counters->n_eigh, (unsigned long long)bk.n_eigh);
       atomicAdd((unsigned long long*)&A.counters->n_refine, (unsigned long long)bk.n_refined);
+      atomicAdd((unsigned long long*)&A.counters->n_mfma_products, (unsigned long long)bk.n_products);
     }
   }
 }
