@@ -37,8 +37,13 @@ def main():
         ex = "—"
         if roof.get("executed"):
             e = roof["executed"]
-            ex = (f"MFMA busy {roof['mfma_busy']:.3f}; {e['refine_pairs_per_chain_step']:.1f} CG pairs + "
-                  f"{e['sweeps_per_chain_step']:.2f} sweeps per step")
+            if "refine_pairs_per_chain_step" in e:
+                ex = (f"MFMA busy {roof['mfma_busy']:.3f}; {e['refine_pairs_per_chain_step']:.1f} CG pairs + "
+                      f"{e['sweeps_per_chain_step']:.2f} sweeps per step")
+            else:  # SoftAbs: eigenvector refinement
+                ex = (f"MFMA busy {roof['mfma_busy']:.3f}; {e['mfma_products_per_chain_step']:.0f} 64³ products, "
+                      f"{e['refined_decompositions_per_chain_step']:.1f} refined decompositions + "
+                      f"{e['jacobi_sweeps_per_chain_step']:.2f} Jacobi sweeps per step")
         tr = roof.get("traffic")
         out.append(f"| {name} | {sci(r['value'])} | {roof['kernel_ms_per_launch']:.3g} | {frac} | {ex} | "
                    f"{'—' if tr is None else '%.1f MB' % (tr / 1e6)} |")
