@@ -172,6 +172,17 @@ struct MfmaBackend {
         vc[X] = w.nat[16 * X + j];
         vr[X] = *reinterpret_cast<const d4*>(w.vperm + ((X * 4 + g) << 2));
       }
+      // all ten tiles of the staged base matrix first: a lone wave cannot hide an LDS round trip (~130 cycles), and
+      // issued one tile ahead of its arithmetic the twenty loads were ten of them in a row (1.6 k of the call's 3.0 k
+      // cycles); the scheduling barrier keeps the compiler from sinking them back to their uses
+      d4 m[10];
+#pragma unroll
+      for (int t = 0; t < 10; ++t) {
+        const d2 b01 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 0) * 64 + lane) * 2);
+        const d2 b23 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 1) * 64 + lane) * 2);
+        m[t] = d4{b01[0], b01[1], b23[0], b23[1]};  // zero on the padding, where v is zero too
+      }
+      __builtin_amdgcn_sched_barrier(0);
       double mir[3] = {0.0, 0.0, 0.0};
 #pragma unroll
       for (int I = 0; I < 4; ++I) {
@@ -179,15 +190,12 @@ struct MfmaBackend {
 #pragma unroll
         for (int J = 0; J <= I; ++J) {
           const int t = tix(I, J);
-          const d2 b01 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 0) * 64 + lane) * 2);
-          const d2 b23 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 1) * 64 + lane) * 2);
-          const d4 m = d4{b01[0], b01[1], b23[0], b23[1]};  // zero on the padding, where v is zero too
           if (I != J) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mir[J] = __builtin_fma(m[r], vr[I][r], mir[J]);
+            for (int r = 0; r < 4; ++r) mir[J] = __builtin_fma(m[t][r], vr[I][r], mir[J]);
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[r] = __builtin_fma(m[r], vc[J], s[r]);
+          for (int r = 0; r < 4; ++r) s[r] = __builtin_fma(m[t][r], vc[J], s[r]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) w.part[(16 * I + 4 * r + g) * kPartStride + j] = s[r];
