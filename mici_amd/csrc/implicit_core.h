@@ -236,7 +236,7 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
       prof(bk, PH_RSUM);
       const double dq = bk.sum1(bk.rslot(RS_D) * q);
       if (!(dq > 0.0)) break;  // not positive definite along d, or not finite
-      const double al = rz / dq;
+      const double al = mmdev::fdiv(rz, dq);  // (lean division: the IEEE expansion is ~30 dependent instructions)
       const double u = __builtin_fma(al, bk.rslot(RS_D), bk.rslot(RS_U));
       bk.rslot(RS_U) = u;
       rv = __builtin_fma(-al, q, bk.rslot(RS_R));
@@ -251,7 +251,7 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
         ok = true;
         break;
       }
-      bk.rslot(RS_D) = __builtin_fma(rz2 / rz, bk.rslot(RS_D), z);
+      bk.rslot(RS_D) = __builtin_fma(mmdev::fdiv(rz2, rz), bk.rslot(RS_D), z);
       rz = rz2;
     }
   }

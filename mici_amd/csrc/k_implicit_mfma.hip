@@ -156,6 +156,18 @@ struct MfmaBackend {
   // M(x) v in the form that suits the metric:  rank-one update  B v + x (x . v) / D  (B's tiles from LDS, contracted
   // like matvec() contracts the register tiles);  diag(1 + x^2): per lane
   __device__ __forceinline__ void metric_point(double x) { w.qt[lane] = (lane < dim) ? x : 0.0; }
+  // sixteen partial sums of a row, pairwise: a lone wave pays every dependent add in full (a serial chain is 16 deep)
+  __device__ static __forceinline__ double sum16(const double* src) {
+    double a[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = src[k];
+#pragma unroll
+    for (int h = 8; h >= 1; h >>= 1)
+#pragma unroll
+      for (int k = 0; k < h; ++k) a[k] += a[k + h];
+    return a[0];
+  }
+
   __device__ __forceinline__ double metric_apply(double v) {
     const double x = w.qt[lane];
     if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
@@ -206,9 +218,7 @@ struct MfmaBackend {
       wave_sync();
       double y = 0.0;
       {
-        const double* src = w.part + lane * kPartStride;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) y += src[k];
+        y = sum16(w.part + lane * kPartStride);
         if (lane < 48) {
           const double* mp = w.mpart + (lane >> 4) * 64 + (lane & 15);
           y += (mp[0] + mp[16]) + (mp[32] + mp[48]);
@@ -457,9 +467,7 @@ struct MfmaBackend {
     wave_sync();
     double y = 0.0;
     {
-      const double* src = w.part + lane * kPartStride;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) y += src[k];
+      y = sum16(w.part + lane * kPartStride);
       if (lane < 48) {
         const double* m = w.mpart + (lane >> 4) * 64 + (lane & 15);
         y += (m[0] + m[16]) + (m[32] + m[48]);
