@@ -107,6 +107,9 @@ def riemann_case(rng):
     return desc, integ, system, osys, q0, p0, dirs, steps, ref, 1e-9
 
 
+STEP_FACTOR = 1  # --long: longer SoftAbs trajectories (the decompositions are refined from one another, k_softabs.hip)
+
+
 def softabs_case(rng):
     dim = int(rng.choice([2, 3, 5, 8, 13, 16, 17, 33, 48, 63, 64, 65, 72, 100, 127, 128]))
     n = int(rng.choice([1, 2, 5]))
@@ -119,7 +122,7 @@ def softabs_case(rng):
     coeff = float(rng.choice([0.5, 1.0, 2.0]))
     system = systems.SoftAbsRiemannianMetricSystem(pt, softabs_coeff=coeff)
     osys = orc.RiemannianSystem(ot, None, coeff, orc.Counters())
-    h, steps = float(rng.uniform(0.01, 0.05)), int(rng.integers(1, 4))
+    h, steps = float(rng.uniform(0.01, 0.05)), int(rng.integers(1, 4)) * STEP_FACTOR
     integ = integrators.ImplicitLeapfrogIntegrator(system, h)
     q0 = 0.5 * rng.standard_normal((n, dim))
     p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
@@ -167,9 +170,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--long", action="store_true", help="SoftAbs cases integrate four times as many steps")
     ap.add_argument("--kinds", default="euclid,riemann,softabs,constrained",
                     help="comma-separated case families to draw from (uniformly)")
     a = ap.parse_args()
+    global STEP_FACTOR
+    STEP_FACTOR = 4 if a.long else 1
     rng = np.random.default_rng(a.seed)
     makers = {"euclid": euclid_case, "riemann": riemann_case, "softabs": softabs_case, "constrained": constrained_case}
     kinds = [makers[k] for k in a.kinds.split(",")]

@@ -11,7 +11,7 @@
 #   <round>_<cfg>_pmc_hbm.json            FETCH_SIZE / WRITE_SIZE passes (separate runs, gfx950 correction) - c2 c2i c2iv c3 c3b c4 c5
 #   <round>_<cfg>_sq_counters.json        SQ counters (two passes) - c2 c3 c3b c4 c5
 #   <round>_c4_ubench_blk16.txt, <round>_c3_ubench_mfma.txt   phase clocks of the two dense-Riemannian kernels
-#   <round>_fuzz_parity.txt               tools/fuzz_parity.py, three seeds x 80 cases
+#   <round>_fuzz_parity.txt               tools/fuzz_parity.py, three seeds x 80 cases + 60 long SoftAbs cases
 #   <round>_c2iv_regimes.txt              c2(iv) launched five times in fresh processes: pass time vs kernel time
 ROUND=${ROUND:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -62,6 +62,10 @@ for seed in 31 32 33; do
   grep "MISMATCH\|Traceback" -B2 $O/fuzz_$seed.log | head -10 >> $O/fuzz_parity.txt
   rm -f $O/fuzz_$seed.log
 done
+timeout 1200 python tools/fuzz_parity.py --seed 41 --cases 60 --kinds softabs --long > $O/fuzz_41.log 2>&1
+echo "seed 41 (SoftAbs only, four times the steps) rc=$? $(tail -1 $O/fuzz_41.log)" >> $O/fuzz_parity.txt
+grep "MISMATCH\|Traceback" -B2 $O/fuzz_41.log | head -10 >> $O/fuzz_parity.txt
+rm -f $O/fuzz_41.log
 cat $O/fuzz_parity.txt
 
 # c2(iv): five fresh processes - wall-clock per pass against the HIP-event kernel time of the same pass
