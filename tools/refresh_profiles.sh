@@ -29,14 +29,6 @@ O=$ROOT/gpurun_out/${ROUND}p; rm -rf $O; mkdir -p $O
 KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2iv:leapfrog_mfma_kernel c3:implicit_mfma_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel"
 
 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -4 > $O/gpu_tests.txt; cat $O/gpu_tests.txt
-python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-160 $O/bench_default.json
-
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o bench -- python $ROOT/bench.py --no-cpu-baseline > $O/prof_default.log 2>&1
-cd $ROOT
-f=$(find $O/prof_default -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/rocprofv3_kernel_stats.csv && head -9 $O/rocprofv3_kernel_stats.csv | cut -c1-150
-rm -rf $O/prof_default
-
 for pair in $KERNELS; do
   cfg=${pair%%:*}; kern=${pair##*:}
   bash tools/pmc_hbm.sh $cfg $kern > $O/pmc_hbm_$cfg.log 2>&1
@@ -45,6 +37,16 @@ for pair in $KERNELS; do
 import json; d=json.load(open('$O/${cfg}_pmc_hbm.json')); print('$cfg HBM traffic MB/launch %.2f over %d launches' % (d['traffic_bytes_per_launch']/1e6, len(d['FETCH_SIZE']['per_launch_values_KB'])))" 2>&1 | tail -1
   rm -rf gpurun_out/pmc_hbm_$cfg $O/pmc_hbm_$cfg.log
 done
+# the bench line cites the HBM traffic of THESE passes: put them where bench.py looks (profiles/ of this tree) first
+for pair in $KERNELS; do cfg=${pair%%:*}; [ -f $O/${cfg}_pmc_hbm.json ] && cp $O/${cfg}_pmc_hbm.json $ROOT/profiles/${ROUND}_${cfg}_pmc_hbm.json; done
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-160 $O/bench_default.json
+
+export TMPDIR=/tmp; cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o bench -- python $ROOT/bench.py --no-cpu-baseline > $O/prof_default.log 2>&1
+cd $ROOT
+f=$(find $O/prof_default -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/rocprofv3_kernel_stats.csv && head -9 $O/rocprofv3_kernel_stats.csv | cut -c1-150
+rm -rf $O/prof_default
+
 for pair in $KERNELS; do
   cfg=${pair%%:*}; kern=${pair##*:}
   case $cfg in c2i|c2iv) continue;; esac
