@@ -31,7 +31,7 @@ using namespace mmcon;
 int mm_launch_constrained_wide(mm_ctx* ctx, int n_constr, const mmcon::ConArgs& a, int which, double* h_out);
 // one wave per chain, 8 < D <= 64 (k_constrained_wave.hip)
 bool mm_constrained_wave_supports(const mmcon::ConArgs& a, int n_constr);
-int mm_launch_constrained_wave(mm_ctx* ctx, int n_constr, const mmcon::ConArgs& a, bool project_only);
+int mm_launch_constrained_wave(mm_ctx* ctx, int n_constr, const mmcon::ConArgs& a, int which, double* d_out);
 
 namespace {
 
@@ -75,8 +75,8 @@ int launch(mm_ctx* ctx, const mm_model* m, const ConArgs& a, int which, double* 
     const char* e = getenv("MICI_AMD_CONSTRAINED_KERNEL");
     return e && strcmp(e, "lane") == 0;
   }();
-  if ((which == K_STEP || which == K_PROJECT) && !force_lane && mm_constrained_wave_supports(a, m->n_constr))
-    return mm_launch_constrained_wave(ctx, m->n_constr, a, which == K_PROJECT);
+  if ((which == K_STEP || which == K_PROJECT || m->dim > 64) && !force_lane && mm_constrained_wave_supports(a, m->n_constr))
+    return mm_launch_constrained_wave(ctx, m->n_constr, a, which == K_STEP ? 0 : (which == K_PROJECT ? 1 : 2), h_out);
   if (m->dim > 8 || m->n_constr > 3) return mm_launch_constrained_wide(ctx, m->n_constr, a, which, h_out);
   switch (m->n_constr) {
     case 1: return launch_c<1>(ctx, m->dim, a, which, h_out);

@@ -1,9 +1,10 @@
-// Constrained leapfrog for 8 < D <= 64 with 1 <= C <= 8 constraints: ONE WAVE PER CHAIN (round 3; VERDICT r02 "missing" #4).
+// Constrained leapfrog for D > 8 with 1 <= C <= 8 constraints: ONE WAVE PER CHAIN (round 3; VERDICT r02 "missing" #3, #4).
 //
 // The lane-per-chain core of constrained_core.h keeps every per-chain array in registers up to D = 8; beyond, its padded
 // instantiations (k_constrained_wide*.hip) run the same code with the arrays - a C x D Jacobian is up to 4 KB, several
-// copies live at once - in 5-26 KB of scratch per lane.  Here a chain belongs to a wave instead: lane i holds
-// coordinate i of every D-vector and column i of every C x D Jacobian in registers, D-long sums are wave reductions,
+// copies live at once - in 5-26 KB of scratch per lane, and stop at D = 64.  Here a chain belongs to a wave instead: lane
+// i holds coordinates i, i + 64, ... (NE of them: D <= 64 NE) of every D-vector and those columns of every C x D
+// Jacobian in registers, D-long sums are wave reductions,
 // and the C x C systems (Gram matrix + Cholesky, Newton residual Jacobian + pivoted LU: constrained_core.h's own
 // routines) are solved redundantly by every lane.  Control flow is wave-uniform - one chain, one wave - so a failed or
 // converged chain simply leaves its loops: no SIMT masking.
@@ -25,17 +26,76 @@ using namespace mmdev;
 
 namespace {
 
-constexpr int kWavesPerBlock = 4;
-constexpr int kRowStride = 65;                      // doubles per row of the transposition buffer
-constexpr int kWaveLds = 64 * kRowStride + 64 + 64 + 64;  // prod[64][65], sums[64], nat[64], vec[64]
+constexpr int kRowStride = 65;  // doubles per row of the transposition buffer
+// LDS of one wave: prod[64][65], sums[64], nat[64 NE], vec[64 NE]
+template <int NE>
+constexpr int wave_lds() { return 64 * kRowStride + 64 + 2 * 64 * NE; }
+// waves (chains) per workgroup: four while their LDS fits, two for the 16-coordinates-per-lane instantiations
+template <int NE>
+constexpr int waves_per_block() { return NE <= 4 ? 4 : 2; }
 
 struct WaveCtx {
   double* prod;  // [64][65]
   double* sums;  // [64]
-  double* nat;   // [64] a D-vector in natural order (target gradient, dense-metric products)
-  double* vec;   // [64] second natural-order vector
+  double* nat;   // [64 NE] a D-vector in natural order (target gradient, dense-metric products)
+  double* vec;   // [64 NE] second natural-order vector
   int lane, dim;
 };
+
+// a D-vector spread over the wave: element e of lane i is coordinate i + 64 e (zero beyond dim)
+template <int NE>
+struct Vec {
+  double v[NE];
+};
+template <int NE>
+__device__ __forceinline__ Vec<NE> vzero() {
+  Vec<NE> o;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) o.v[e] = 0.0;
+  return o;
+}
+// x + a y
+template <int NE>
+__device__ __forceinline__ Vec<NE> axpy(double a, const Vec<NE>& y, const Vec<NE>& x) {
+  Vec<NE> o;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) o.v[e] = __builtin_fma(a, y.v[e], x.v[e]);
+  return o;
+}
+template <int NE>
+__device__ __forceinline__ Vec<NE> scaled(double a, const Vec<NE>& x) {
+  Vec<NE> o;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) o.v[e] = a * x.v[e];
+  return o;
+}
+template <int NE>
+__device__ __forceinline__ Vec<NE> vsub(const Vec<NE>& x, const Vec<NE>& y) {
+  Vec<NE> o;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) o.v[e] = x.v[e] - y.v[e];
+  return o;
+}
+template <int NE>
+__device__ __forceinline__ Vec<NE> load_vec(const double* src, int lane, int dim) {
+  Vec<NE> o;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) o.v[e] = lane + 64 * e < dim ? src[lane + 64 * e] : 0.0;
+  return o;
+}
+template <int NE>
+__device__ __forceinline__ void store_vec(double* dst, int lane, int dim, const Vec<NE>& x) {
+#pragma unroll
+  for (int e = 0; e < NE; ++e)
+    if (lane + 64 * e < dim) dst[lane + 64 * e] = x.v[e];
+}
+// the whole vector into a natural-order LDS array (zero beyond dim), visible to the wave
+template <int NE>
+__device__ __forceinline__ void publish(double* arr, int lane, const Vec<NE>& x) {
+#pragma unroll
+  for (int e = 0; e < NE; ++e) arr[lane + 64 * e] = x.v[e];
+  wave_sync();
+}
 
 // K D-long sums at once: in  v[k] = this lane's term of sum k;  out v[k] = sum k over the wave, in every lane.
 template <int K>
@@ -67,83 +127,119 @@ __device__ __forceinline__ void reduce_many(const WaveCtx& w, double (&v)[K]) {
   wave_sync();
 }
 
-__device__ __forceinline__ double wnorm(double x, int kind) {
-  return kind == MM_NORM_LINF ? wave_max(fabs(x)) : sqrt(wave_sum(x * x));
+template <int NE>
+__device__ __forceinline__ double wnorm(const Vec<NE>& x, int kind) {
+  if (kind == MM_NORM_LINF) {
+    double m = fabs(x.v[0]);
+#pragma unroll
+    for (int e = 1; e < NE; ++e) m = nanmax(m, fabs(x.v[e]));
+    return wave_max(m);
+  }
+  double s = x.v[0] * x.v[0];
+#pragma unroll
+  for (int e = 1; e < NE; ++e) s = __builtin_fma(x.v[e], x.v[e], s);
+  return sqrt(wave_sum(s));
 }
 
-// y = M^-1 x, one coordinate per lane.  Dense: M^-1 is symmetric, so lane i walks COLUMN i (coalesced over the lanes
-// for every j) with x_j broadcast from LDS.
-__device__ __forceinline__ double minv1(const ConArgs& A, const WaveCtx& w, double x) {
+// y = M^-1 x.  Dense: M^-1 is symmetric, so a lane walks the COLUMNS of its coordinates (coalesced over the lanes for
+// every j) with x_j broadcast from LDS.
+template <int NE>
+__device__ __forceinline__ Vec<NE> minv1(const ConArgs& A, const WaveCtx& w, const Vec<NE>& x) {
   if (A.metric_kind == MM_METRIC_IDENTITY) return x;
-  if (A.metric_kind == MM_METRIC_DIAG) return w.lane < w.dim ? A.minv[w.lane] * x : 0.0;
-  w.vec[w.lane] = x;
-  wave_sync();
-  double y = 0.0;
-  if (w.lane < w.dim) {
-    const double* col = A.minv + w.lane;
-    for (int j = 0; j < w.dim; ++j) y = __builtin_fma(col[(int64_t)j * w.dim], w.vec[j], y);
+  Vec<NE> y = vzero<NE>();
+  if (A.metric_kind == MM_METRIC_DIAG) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) y.v[e] = w.lane + 64 * e < w.dim ? A.minv[w.lane + 64 * e] * x.v[e] : 0.0;
+    return y;
   }
+  publish<NE>(w.vec, w.lane, x);
+  // lanes beyond dim walk the last column (no predicate inside the loop) and drop their sums at the end
+  const double* col[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) col[e] = A.minv + (w.lane + 64 * e < w.dim ? w.lane + 64 * e : w.dim - 1);
+  for (int j = 0; j < w.dim; ++j) {
+    const double xj = w.vec[j];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      y.v[e] = __builtin_fma(*col[e], xj, y.v[e]);
+      col[e] += w.dim;  // row j + 1 = column j + 1
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < NE; ++e)
+    if (w.lane + 64 * e >= w.dim) y.v[e] = 0.0;
   wave_sync();
   return y;
 }
 
-template <int C>
-struct Col {  // column i of a C x D matrix: this lane's entry of every row
-  double v[C];
+template <int C, int NE>
+struct Col {  // this lane's columns of a C x D matrix: row k, element e
+  Vec<NE> r[C];
 };
 
-template <int C>
-__device__ __forceinline__ Col<C> minv_rows_w(const ConArgs& A, const WaveCtx& w, const Col<C>& j) {
-  Col<C> o;
+template <int C, int NE>
+__device__ __forceinline__ Col<C, NE> minv_rows_w(const ConArgs& A, const WaveCtx& w, const Col<C, NE>& j) {
+  Col<C, NE> o;
 #pragma unroll
-  for (int k = 0; k < C; ++k) o.v[k] = minv1(A, w, j.v[k]);
+  for (int k = 0; k < C; ++k) o.r[k] = minv1<NE>(A, w, j.r[k]);
   return o;
 }
 
-// column `lane` of jacob_constr(q)
-template <int C>
-__device__ __forceinline__ Col<C> jacob_w(const ConArgs& A, const WaveCtx& w, double q) {
-  Col<C> j;
-  const int i = w.lane;
-  const bool in = i < w.dim;
+// this lane's columns of jacob_constr(q)
+template <int C, int NE>
+__device__ __forceinline__ Col<C, NE> jacob_w(const ConArgs& A, const WaveCtx& w, const Vec<NE>& q) {
+  Col<C, NE> j;
 #pragma unroll
-  for (int k = 0; k < C; ++k) j.v[k] = 0.0;
-  if (A.constr == MM_CONSTR_LINEAR) {
+  for (int k = 0; k < C; ++k) j.r[k] = vzero<NE>();
 #pragma unroll
-    for (int k = 0; k < C; ++k) j.v[k] = in ? A.cparams[k * w.dim + i] : 0.0;
-  } else if (A.constr == MM_CONSTR_SPHERE) {
-    j.v[0] = 2.0 * q;
-  } else if (A.constr == MM_CONSTR_SPHERE_PLANE) {
-    j.v[0] = 2.0 * q;
-    if constexpr (C > 1) j.v[1] = in ? A.cparams[i] : 0.0;
-  } else if (A.constr == MM_CONSTR_CIRCLE) {
-    j.v[0] = i < 2 ? 2.0 * q : 0.0;
-  } else {  // MM_CONSTR_FIRST
-    j.v[0] = i == 0 ? 1.0 : 0.0;
+  for (int e = 0; e < NE; ++e) {
+    const int i = w.lane + 64 * e;
+    const bool in = i < w.dim;
+    if (A.constr == MM_CONSTR_LINEAR) {
+#pragma unroll
+      for (int k = 0; k < C; ++k) j.r[k].v[e] = in ? A.cparams[k * w.dim + i] : 0.0;
+    } else if (A.constr == MM_CONSTR_SPHERE) {
+      j.r[0].v[e] = 2.0 * q.v[e];
+    } else if (A.constr == MM_CONSTR_SPHERE_PLANE) {
+      j.r[0].v[e] = 2.0 * q.v[e];
+      if constexpr (C > 1) j.r[1].v[e] = in ? A.cparams[i] : 0.0;
+    } else if (A.constr == MM_CONSTR_CIRCLE) {
+      j.r[0].v[e] = i < 2 ? 2.0 * q.v[e] : 0.0;
+    } else {  // MM_CONSTR_FIRST
+      j.r[0].v[e] = i == 0 ? 1.0 : 0.0;
+    }
   }
   return j;
 }
 
 // constr(q)
-template <int C>
-__device__ __forceinline__ CVec<C> constr_w(const ConArgs& A, const WaveCtx& w, double q) {
+template <int C, int NE>
+__device__ __forceinline__ CVec<C> constr_w(const ConArgs& A, const WaveCtx& w, const Vec<NE>& q) {
   CVec<C> c;
-  const int i = w.lane;
-  const bool in = i < w.dim;
   double t[C];
 #pragma unroll
   for (int k = 0; k < C; ++k) t[k] = 0.0;
   if (A.constr == MM_CONSTR_LINEAR) {
 #pragma unroll
-    for (int k = 0; k < C; ++k) t[k] = in ? A.cparams[k * w.dim + i] * q : 0.0;
+    for (int e = 0; e < NE; ++e) {
+      const int i = w.lane + 64 * e;
+      if (i < w.dim) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) t[k] = __builtin_fma(A.cparams[k * w.dim + i], q.v[e], t[k]);
+      }
+    }
     reduce_many<C>(w, t);
 #pragma unroll
     for (int k = 0; k < C; ++k) c.v[k] = t[k] - A.cparams[C * w.dim + k];
     return c;
   }
   if (A.constr == MM_CONSTR_SPHERE_PLANE) {
-    t[0] = q * q;
-    if constexpr (C > 1) t[1] = in ? A.cparams[i] * q : 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int i = w.lane + 64 * e;
+      t[0] = __builtin_fma(q.v[e], q.v[e], t[0]);
+      if constexpr (C > 1) t[1] = i < w.dim ? __builtin_fma(A.cparams[i], q.v[e], t[1]) : t[1];
+    }
     reduce_many<C>(w, t);
     c.v[0] = t[0] - 1.0;
     if constexpr (C > 1) c.v[1] = t[1];
@@ -153,20 +249,32 @@ __device__ __forceinline__ CVec<C> constr_w(const ConArgs& A, const WaveCtx& w, 
   }
 #pragma unroll
   for (int k = 0; k < C; ++k) c.v[k] = 0.0;
-  if (A.constr == MM_CONSTR_SPHERE) c.v[0] = wave_sum(q * q) - 1.0;
-  else if (A.constr == MM_CONSTR_CIRCLE) c.v[0] = wave_sum(i < 2 ? q * q : 0.0) - 1.0;
-  else c.v[0] = readlane_f64(q, 0);  // MM_CONSTR_FIRST
+  if (A.constr == MM_CONSTR_SPHERE) {
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) s = __builtin_fma(q.v[e], q.v[e], s);
+    c.v[0] = wave_sum(s) - 1.0;
+  } else if (A.constr == MM_CONSTR_CIRCLE) {
+    c.v[0] = wave_sum(w.lane < 2 ? q.v[0] * q.v[0] : 0.0) - 1.0;
+  } else {
+    c.v[0] = readlane_f64(q.v[0], 0);  // MM_CONSTR_FIRST
+  }
   return c;
 }
 
 // g[a][b] = scale * sum_i x[a]_i y[b]_i
-template <int C>
-__device__ __forceinline__ CMat<C> rows_inner_w(const WaveCtx& w, const Col<C>& x, const Col<C>& y, double scale) {
+template <int C, int NE>
+__device__ __forceinline__ CMat<C> rows_inner_w(const WaveCtx& w, const Col<C, NE>& x, const Col<C, NE>& y, double scale) {
   double t[C * C];
 #pragma unroll
   for (int a = 0; a < C; ++a)
 #pragma unroll
-    for (int b = 0; b < C; ++b) t[a * C + b] = x.v[a] * y.v[b];
+    for (int b = 0; b < C; ++b) {
+      double s = x.r[a].v[0] * y.r[b].v[0];
+#pragma unroll
+      for (int e = 1; e < NE; ++e) s = __builtin_fma(x.r[a].v[e], y.r[b].v[e], s);
+      t[a * C + b] = s;
+    }
   reduce_many<C * C>(w, t);
   CMat<C> g;
 #pragma unroll
@@ -176,39 +284,61 @@ __device__ __forceinline__ CMat<C> rows_inner_w(const WaveCtx& w, const Col<C>& 
   return g;
 }
 
-template <int C>
-__device__ __forceinline__ double combine(const Col<C>& rows, const CVec<C>& x) {
-  double s = rows.v[0] * x.v[0];
+// rows^T x: this lane's coordinates of sum_b x_b rows[b]
+template <int C, int NE>
+__device__ __forceinline__ Vec<NE> combine(const Col<C, NE>& rows, const CVec<C>& x) {
+  Vec<NE> o;
 #pragma unroll
-  for (int b = 1; b < C; ++b) s += rows.v[b] * x.v[b];
-  return s;
+  for (int e = 0; e < NE; ++e) {
+    double s = rows.r[0].v[e] * x.v[0];
+#pragma unroll
+    for (int b = 1; b < C; ++b) s += rows.r[b].v[e] * x.v[b];
+    o.v[e] = s;
+  }
+  return o;
+}
+
+// rows x: the C sums sum_i rows[a]_i x_i
+template <int C, int NE>
+__device__ __forceinline__ CVec<C> rows_times(const WaveCtx& w, const Col<C, NE>& rows, const Vec<NE>& x) {
+  double t[C];
+#pragma unroll
+  for (int a = 0; a < C; ++a) {
+    double s = rows.r[a].v[0] * x.v[0];
+#pragma unroll
+    for (int e = 1; e < NE; ++e) s = __builtin_fma(rows.r[a].v[e], x.v[e], s);
+    t[a] = s;
+  }
+  reduce_many<C>(w, t);
+  CVec<C> o;
+#pragma unroll
+  for (int a = 0; a < C; ++a) o.v[a] = t[a];
+  return o;
 }
 
 // mom - J^T (J M^-1 J^T)^-1 J M^-1 mom     (systems.py:863-873)
-template <int C>
-__device__ __forceinline__ bool project_cotangent_w(const ConArgs& A, const WaveCtx& w, double& p, const Col<C>& jac) {
-  const CMat<C> gram = rows_inner_w<C>(w, jac, minv_rows_w<C>(A, w, jac), 1.0);
+template <int C, int NE>
+__device__ __forceinline__ bool project_cotangent_w(const ConArgs& A, const WaveCtx& w, Vec<NE>& p, const Col<C, NE>& jac) {
+  const CMat<C> gram = rows_inner_w<C, NE>(w, jac, minv_rows_w<C, NE>(A, w, jac), 1.0);
   CMat<C> inv;
   double ld;
   if (!all_finite<C>(gram) || !chol_inverse<C>(gram, &inv, &ld)) return false;
-  const double mp = minv1(A, w, p);
-  double t[C];
-#pragma unroll
-  for (int a = 0; a < C; ++a) t[a] = jac.v[a] * mp;
-  reduce_many<C>(w, t);
-  CVec<C> jm;
-#pragma unroll
-  for (int a = 0; a < C; ++a) jm.v[a] = t[a];
-  p -= combine<C>(jac, cmat_vec<C>(inv, jm));
+  const CVec<C> jm = rows_times<C, NE>(w, jac, minv1<NE>(A, w, p));
+  p = vsub<NE>(p, combine<C, NE>(jac, cmat_vec<C>(inv, jm)));
   return true;
 }
 
-// grad_neg_log_dens, one coordinate per lane (the position goes through LDS for targets that couple coordinates)
-__device__ __forceinline__ double grad_w(const ConArgs& A, const WaveCtx& w, double q) {
-  w.nat[w.lane] = w.lane < w.dim ? q : 0.0;
-  wave_sync();
+// grad_neg_log_dens (the position goes through LDS for targets that couple coordinates)
+template <int NE>
+__device__ __forceinline__ Vec<NE> grad_w(const ConArgs& A, const WaveCtx& w, const Vec<NE>& q) {
+  publish<NE>(w.nat, w.lane, q);
   const TargetAux aux;  // no wave-collective targets here (the funnel is rejected on the host)
-  const double g = w.lane < w.dim ? target_grad_elem(A.target, aux, w.nat, w.lane, w.dim, A.tparams) : 0.0;
+  Vec<NE> g;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int i = w.lane + 64 * e;
+    g.v[e] = i < w.dim ? target_grad_elem(A.target, aux, w.nat, i, w.dim, A.tparams) : 0.0;
+  }
   wave_sync();
   return g;
 }
@@ -217,178 +347,184 @@ __device__ __forceinline__ double grad_w(const ConArgs& A, const WaveCtx& w, dou
 // grad_log_det_sqrt_gram = mhp_constr(inv_gram J M^-1) (systems.py:1024-1031).  false = LinAlgError.
 // The built-in constraints' Hessians are constant multiples of (part of) the identity: sum_k m[k] * H_k picks
 // 2 m[0] on the coordinates the quadratic constraint involves, nothing for the linear ones.
-template <int C>
-__device__ __forceinline__ bool dh1_dpos_w(const ConArgs& A, const WaveCtx& w, double q, double* out) {
-  double g = grad_w(A, w, q);
+template <int C, int NE>
+__device__ __forceinline__ bool dh1_dpos_w(const ConArgs& A, const WaveCtx& w, const Vec<NE>& q, Vec<NE>* out) {
+  Vec<NE> g = grad_w<NE>(A, w, q);
   if (A.ambient) {
-    const Col<C> jac = jacob_w<C>(A, w, q);
-    const CMat<C> gram = rows_inner_w<C>(w, jac, minv_rows_w<C>(A, w, jac), 1.0);
+    const Col<C, NE> jac = jacob_w<C, NE>(A, w, q);
+    const CMat<C> gram = rows_inner_w<C, NE>(w, jac, minv_rows_w<C, NE>(A, w, jac), 1.0);
     CMat<C> inv;
     double ld;
     if (!all_finite<C>(gram) || !chol_inverse<C>(gram, &inv, &ld)) return false;
-    Col<C> m;  // column `lane` of inv_gram @ J
+    Vec<NE> m0;  // row 0 of inv_gram @ J: only it meets a non-zero constraint Hessian
 #pragma unroll
-    for (int a = 0; a < C; ++a) {
-      double s = inv.m[a][0] * jac.v[0];
+    for (int e = 0; e < NE; ++e) {
+      double s = inv.m[0][0] * jac.r[0].v[e];
 #pragma unroll
-      for (int b = 1; b < C; ++b) s += inv.m[a][b] * jac.v[b];
-      m.v[a] = s;
+      for (int b = 1; b < C; ++b) s += inv.m[0][b] * jac.r[b].v[e];
+      m0.v[e] = s;
     }
-    const double m0 = minv1(A, w, m.v[0]);  // only row 0 meets a non-zero constraint Hessian
-    if (A.constr == MM_CONSTR_SPHERE || A.constr == MM_CONSTR_SPHERE_PLANE) g += 2.0 * m0;
-    else if (A.constr == MM_CONSTR_CIRCLE) g += w.lane < 2 ? 2.0 * m0 : 0.0;
+    m0 = minv1<NE>(A, w, m0);
+    if (A.constr == MM_CONSTR_SPHERE || A.constr == MM_CONSTR_SPHERE_PLANE) {
+      g = axpy<NE>(2.0, m0, g);
+    } else if (A.constr == MM_CONSTR_CIRCLE) {
+      g.v[0] += w.lane < 2 ? 2.0 * m0.v[0] : 0.0;
+    }
   }
   *out = g;
   return true;
 }
 
 // The three projection solvers (solvers.py:429-469, 303-343, 561-614) on the lane-distributed state.
-template <int C>
-__device__ __forceinline__ int project_w(const ConArgs& A, const WaveCtx& w, double& q, double& p, const Col<C>& jac_prev,
-                                         double t, Col<C>* jac_out, long long* n_iters) {
+template <int C, int NE>
+__device__ __forceinline__ int project_w(const ConArgs& A, const WaveCtx& w, Vec<NE>& q, Vec<NE>& p,
+                                         const Col<C, NE>& jac_prev, double t, Col<C, NE>* jac_out, long long* n_iters) {
   const mm_proj_opts& o = A.opts;
   const double abs_t = fabs(t);
   const double sgn = (t > 0.0) ? 1.0 : ((t < 0.0) ? -1.0 : 0.0);
-  const Col<C> mjp = minv_rows_w<C>(A, w, jac_prev);
-  double mu = 0.0;
+  const Col<C, NE> mjp = minv_rows_w<C, NE>(A, w, jac_prev);
+  Vec<NE> mu = vzero<NE>();
   if (o.solver == MM_PROJ_QUASI_NEWTON) {
     CMat<C> inv;
     double ld;
-    const CMat<C> g0 = rows_inner_w<C>(w, jac_prev, mjp, abs_t);
+    const CMat<C> g0 = rows_inner_w<C, NE>(w, jac_prev, mjp, abs_t);
     if (!all_finite<C>(g0) || !chol_inverse<C>(g0, &inv, &ld)) return MM_ST_LINALG;
     for (int it = 0; it < o.max_iters; ++it) {
       *n_iters += 1;
-      const CVec<C> c = constr_w<C>(A, w, q);
+      const CVec<C> c = constr_w<C, NE>(A, w, q);
       const double err = cnorm<C>(c, o.norm);
       const CVec<C> x = cmat_vec<C>(inv, c);
-      const double dmu = combine<C>(jac_prev, x);
-      const double dpos = abs_t * combine<C>(mjp, x);
+      const Vec<NE> dmu = combine<C, NE>(jac_prev, x);
+      const Vec<NE> dpos = scaled<NE>(abs_t, combine<C, NE>(mjp, x));
       if (err > o.div_tol || err != err) return MM_ST_DIVERGED;
-      if (err < o.constr_tol && wnorm(dpos, o.norm) < o.pos_tol) {
-        p -= sgn * mu;
-        *jac_out = jacob_w<C>(A, w, q);
+      if (err < o.constr_tol && wnorm<NE>(dpos, o.norm) < o.pos_tol) {
+        p = axpy<NE>(-sgn, mu, p);
+        *jac_out = jacob_w<C, NE>(A, w, q);
         return MM_ST_OK;
       }
-      mu += dmu;
-      q -= dpos;
+      mu = axpy<NE>(1.0, dmu, mu);
+      q = vsub<NE>(q, dpos);
     }
     return MM_ST_MAX_ITERS;
   }
   if (o.solver == MM_PROJ_NEWTON_LINE_SEARCH) {
-    double dpos = 0.0, step = 0.0;
+    Vec<NE> dpos = vzero<NE>();
+    double step = 0.0;
     for (int it = 0; it < o.max_iters; ++it) {
       *n_iters += 1;
-      const Col<C> jac = jacob_w<C>(A, w, q);
-      const CVec<C> c = constr_w<C>(A, w, q);
+      const Col<C, NE> jac = jacob_w<C, NE>(A, w, q);
+      const CVec<C> c = constr_w<C, NE>(A, w, q);
       const double err = cnorm<C>(c, o.norm);
       if (it > 0 && (err > o.div_tol || err != err)) return MM_ST_DIVERGED;
-      const bool small_step = (it == 0) || wnorm(step * dpos, o.norm) < o.pos_tol;
+      const bool small_step = (it == 0) || wnorm<NE>(scaled<NE>(step, dpos), o.norm) < o.pos_tol;
       if (err < o.constr_tol && small_step) {
-        p -= sgn * mu;
+        p = axpy<NE>(-sgn, mu, p);
         *jac_out = jac;
         return MM_ST_OK;
       }
-      const CMat<C> a = rows_inner_w<C>(w, jac, mjp, abs_t);
+      const CMat<C> a = rows_inner_w<C, NE>(w, jac, mjp, abs_t);
       if (!all_finite<C>(a)) return MM_ST_SOLVER_LINALG;
       const CVec<C> x = lu_solve<C>(a, c);
-      const double dmu = combine<C>(jac_prev, x);
-      dpos = -(abs_t * combine<C>(mjp, x));
-      const double q_curr = q;
+      const Vec<NE> dmu = combine<C, NE>(jac_prev, x);
+      dpos = scaled<NE>(-1.0, scaled<NE>(abs_t, combine<C, NE>(mjp, x)));
+      const Vec<NE> q_curr = q;
       step = 1.0;
       for (int ls = 0; ls < o.max_line_search_iters; ++ls) {
-        q = q_curr + step * dpos;
-        const double new_err = cnorm<C>(constr_w<C>(A, w, q), o.norm);
+        q = axpy<NE>(step, dpos, q_curr);
+        const double new_err = cnorm<C>(constr_w<C, NE>(A, w, q), o.norm);
         if (new_err < err) break;
         step *= 0.5;
       }
-      mu += step * dmu;
+      mu = axpy<NE>(step, dmu, mu);
     }
     return MM_ST_MAX_ITERS;
   }
   for (int it = 0; it < o.max_iters; ++it) {  // Newton
     *n_iters += 1;
-    const Col<C> jac = jacob_w<C>(A, w, q);
-    const CVec<C> c = constr_w<C>(A, w, q);
+    const Col<C, NE> jac = jacob_w<C, NE>(A, w, q);
+    const CVec<C> c = constr_w<C, NE>(A, w, q);
     const double err = cnorm<C>(c, o.norm);
-    const CMat<C> a = rows_inner_w<C>(w, jac, mjp, abs_t);
+    const CMat<C> a = rows_inner_w<C, NE>(w, jac, mjp, abs_t);
     if (!all_finite<C>(a)) return MM_ST_SOLVER_LINALG;  // "Array is not finite." inside the solver
     const CVec<C> x = lu_solve<C>(a, c);
-    const double dmu = combine<C>(jac_prev, x);
-    const double dpos = abs_t * combine<C>(mjp, x);
+    const Vec<NE> dmu = combine<C, NE>(jac_prev, x);
+    const Vec<NE> dpos = scaled<NE>(abs_t, combine<C, NE>(mjp, x));
     if (err > o.div_tol || err != err) return MM_ST_DIVERGED;
-    if (err < o.constr_tol && wnorm(dpos, o.norm) < o.pos_tol) {
-      p -= sgn * mu;
+    if (err < o.constr_tol && wnorm<NE>(dpos, o.norm) < o.pos_tol) {
+      p = axpy<NE>(-sgn, mu, p);
       *jac_out = jac;
       return MM_ST_OK;
     }
-    mu += dmu;
-    q -= dpos;
+    mu = axpy<NE>(1.0, dmu, mu);
+    q = vsub<NE>(q, dpos);
   }
   return MM_ST_MAX_ITERS;
 }
 
-template <int C>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void constrained_wave_kernel(ConArgs A) {
+template <int NE>
+__device__ __forceinline__ WaveCtx make_ctx(double* lds, int wave, int lane, int dim) {
+  double* wl = lds + wave * wave_lds<NE>();
+  return WaveCtx{wl, wl + 64 * kRowStride, wl + 64 * kRowStride + 64, wl + 64 * kRowStride + 64 + 64 * NE, lane, dim};
+}
+
+template <int C, int NE>
+__global__ __launch_bounds__(64 * waves_per_block<NE>()) void constrained_wave_kernel(ConArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t chain = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const int64_t chain = (int64_t)blockIdx.x * waves_per_block<NE>() + wave;
   if (chain >= A.n_chains) return;  // no block-level barrier in this kernel
-  double* wl = lds + wave * kWaveLds;
-  const WaveCtx w{wl, wl + 64 * kRowStride, wl + 64 * kRowStride + 64, wl + 64 * kRowStride + 128, lane, A.dim};
   const int dim = A.dim;
-  const bool in = lane < dim;
-  double q = in ? A.pos[chain * dim + lane] : 0.0;
-  double p = in ? A.mom[chain * dim + lane] : 0.0;
+  const WaveCtx w = make_ctx<NE>(lds, wave, lane, dim);
+  Vec<NE> q = load_vec<NE>(A.pos + chain * dim, lane, dim);
+  Vec<NE> p = load_vec<NE>(A.mom + chain * dim, lane, dim);
   const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
   const int n_inner = A.opts.n_inner;
   const double t_in = t / n_inner;
   long long n_newton = 0, n_grad = 0;
   int status = MM_ST_OK, done = 0;
 
-  double g;  // cached dh1_dpos at the current position
-  if (!dh1_dpos_w<C>(A, w, q, &g)) status = MM_ST_LINALG;
-  Col<C> jac = jacob_w<C>(A, w, q);
+  Vec<NE> g;  // cached dh1_dpos at the current position
+  if (!dh1_dpos_w<C, NE>(A, w, q, &g)) status = MM_ST_LINALG;
+  Col<C, NE> jac = jacob_w<C, NE>(A, w, q);
   ++n_grad;
   const int my_steps = chain_steps(A.chain_steps, chain, A.n_steps);
   for (int s = 0; s < my_steps && status == MM_ST_OK; ++s) {
-    double qs = q, ps = p, gs = g;
-    Col<C> js = jac;
+    Vec<NE> qs = q, ps = p, gs = g;
+    Col<C, NE> js = jac;
     // ---- A(t/2): h1_flow then cotangent projection                    integrators.py:947-949
-    ps -= (0.5 * t) * g;
-    if (!project_cotangent_w<C>(A, w, ps, js)) { status = MM_ST_LINALG; break; }
+    ps = axpy<NE>(-0.5 * t, g, ps);
+    if (!project_cotangent_w<C, NE>(A, w, ps, js)) { status = MM_ST_LINALG; break; }
     // ---- B(t): n_inner retractions + reversibility checks              integrators.py:951-979
     for (int inn = 0; inn < n_inner && status == MM_ST_OK; ++inn) {
-      const double q_prev = qs;
-      const Col<C> j_prev = js;
-      qs += t_in * minv1(A, w, ps);
-      Col<C> j_new;
-      status = project_w<C>(A, w, qs, ps, j_prev, t_in, &j_new, &n_newton);
+      const Vec<NE> q_prev = qs;
+      const Col<C, NE> j_prev = js;
+      qs = axpy<NE>(t_in, minv1<NE>(A, w, ps), qs);
+      Col<C, NE> j_new;
+      status = project_w<C, NE>(A, w, qs, ps, j_prev, t_in, &j_new, &n_newton);
       if (status != MM_ST_OK) break;
       if (inn == n_inner - 1) {  // pre-evaluated dh1_dpos, integrators.py:956-969
-        if (!dh1_dpos_w<C>(A, w, qs, &gs)) { status = MM_ST_LINALG; break; }
+        if (!dh1_dpos_w<C, NE>(A, w, qs, &gs)) { status = MM_ST_LINALG; break; }
         ++n_grad;
       }
-      if (!project_cotangent_w<C>(A, w, ps, j_new)) { status = MM_ST_LINALG; break; }
+      if (!project_cotangent_w<C, NE>(A, w, ps, j_new)) { status = MM_ST_LINALG; break; }
       // reversibility check on a copy                                    integrators.py:971-979
-      double qb = qs, pb = ps;
-      Col<C> j_tmp;
-      qb += -t_in * minv1(A, w, pb);
-      status = project_w<C>(A, w, qb, pb, j_new, -t_in, &j_tmp, &n_newton);
+      Vec<NE> qb = qs, pb = ps;
+      Col<C, NE> j_tmp;
+      qb = axpy<NE>(-t_in, minv1<NE>(A, w, pb), qb);
+      status = project_w<C, NE>(A, w, qb, pb, j_new, -t_in, &j_tmp, &n_newton);
       if (status != MM_ST_OK) break;
-      if (wnorm(qb - q_prev, A.opts.rev_norm) > A.opts.rev_tol) { status = MM_ST_NON_REVERSIBLE; break; }
+      if (wnorm<NE>(vsub<NE>(qb, q_prev), A.opts.rev_norm) > A.opts.rev_tol) { status = MM_ST_NON_REVERSIBLE; break; }
       js = j_new;
     }
     if (status != MM_ST_OK) break;
     // ---- A(t/2)
-    ps -= (0.5 * t) * gs;
-    if (!project_cotangent_w<C>(A, w, ps, js)) { status = MM_ST_LINALG; break; }
+    ps = axpy<NE>(-0.5 * t, gs, ps);
+    if (!project_cotangent_w<C, NE>(A, w, ps, js)) { status = MM_ST_LINALG; break; }
     q = qs; p = ps; jac = js; g = gs;
     ++done;
   }
-  if (in) {
-    A.pos[chain * dim + lane] = q;
-    A.mom[chain * dim + lane] = p;
-  }
+  store_vec<NE>(A.pos + chain * dim, lane, dim, q);
+  store_vec<NE>(A.mom + chain * dim, lane, dim, p);
   if (lane == 0) {
     A.status[chain] = status;
     A.n_done[chain] = done;
@@ -400,47 +536,84 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void constrained_wave_kernel(C
   }
 }
 
-// project_onto_cotangent_space of the momenta (systems.py:863-873) - what sample_momentum calls after the draw
-template <int C>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void project_momentum_wave_kernel(ConArgs A) {
+// which == 1: project_onto_cotangent_space of the momenta (systems.py:863-873) - what sample_momentum calls after the
+// draw;  which == 2: out[chain] += log_det_sqrt_gram(pos) (systems.py:829-856), NaN where the Gram matrix is not
+// positive definite
+template <int C, int NE>
+__global__ __launch_bounds__(64 * waves_per_block<NE>()) void constrained_aux_wave_kernel(ConArgs A, int which,
+                                                                                         double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t chain = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  const int64_t chain = (int64_t)blockIdx.x * waves_per_block<NE>() + wave;
   if (chain >= A.n_chains) return;
-  double* wl = lds + wave * kWaveLds;
-  const WaveCtx w{wl, wl + 64 * kRowStride, wl + 64 * kRowStride + 64, wl + 64 * kRowStride + 128, lane, A.dim};
   const int dim = A.dim;
-  const bool in = lane < dim;
-  const double q = in ? A.pos[chain * dim + lane] : 0.0;
-  double p = in ? A.mom[chain * dim + lane] : 0.0;
-  const Col<C> jac = jacob_w<C>(A, w, q);
-  const bool ok = project_cotangent_w<C>(A, w, p, jac);
-  if (in) A.mom[chain * dim + lane] = ok ? p : __longlong_as_double(0x7ff8000000000000LL);
+  const WaveCtx w = make_ctx<NE>(lds, wave, lane, dim);
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  const Vec<NE> q = load_vec<NE>(A.pos + chain * dim, lane, dim);
+  const Col<C, NE> jac = jacob_w<C, NE>(A, w, q);
+  if (which == 1) {
+    Vec<NE> p = load_vec<NE>(A.mom + chain * dim, lane, dim);
+    const bool ok = project_cotangent_w<C, NE>(A, w, p, jac);
+    if (!ok) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) p.v[e] = nan;
+    }
+    store_vec<NE>(A.mom + chain * dim, lane, dim, p);
+    return;
+  }
+  const CMat<C> gram = rows_inner_w<C, NE>(w, jac, minv_rows_w<C, NE>(A, w, jac), 1.0);
+  CMat<C> inv;
+  double ld;
+  const bool ok = all_finite<C>(gram) && chol_inverse<C>(gram, &inv, &ld);
+  if (lane == 0) out[chain] += ok ? 0.5 * ld : nan;
 }
 
-template <int C>
-int launch_wave(mm_ctx* ctx, const ConArgs& a, bool project_only) {
-  const size_t lds = (size_t)kWavesPerBlock * kWaveLds * sizeof(double);
-  const unsigned blocks = (unsigned)((a.n_chains + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (project_only) {
-    MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(project_momentum_wave_kernel<C>),
+template <int C, int NE>
+int launch_wave(mm_ctx* ctx, const ConArgs& a, int which, double* d_out) {
+  constexpr int W = waves_per_block<NE>();
+  const size_t lds = (size_t)W * wave_lds<NE>() * sizeof(double);
+  const unsigned blocks = (unsigned)((a.n_chains + W - 1) / W);
+  if (which != 0) {
+    MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(constrained_aux_wave_kernel<C, NE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((project_momentum_wave_kernel<C>), dim3(blocks), dim3(64 * kWavesPerBlock), lds, ctx->stream, a);
+    hipLaunchKernelGGL((constrained_aux_wave_kernel<C, NE>), dim3(blocks), dim3(64 * W), lds, ctx->stream, a, which, d_out);
     MM_HIP_CHECK(ctx, hipGetLastError());
     return MM_OK;
   }
-  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(constrained_wave_kernel<C>),
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(constrained_wave_kernel<C, NE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((constrained_wave_kernel<C>), dim3(blocks), dim3(64 * kWavesPerBlock), lds, ctx->stream, a);
+  hipLaunchKernelGGL((constrained_wave_kernel<C, NE>), dim3(blocks), dim3(64 * W), lds, ctx->stream, a);
   MM_HIP_CHECK(ctx, hipGetLastError());
   return MM_OK;
 }
 
+// coordinates per lane for a model: 1 (D <= 64), 4 (D <= 256), 16 (D <= 1024, at most two constraints: the Jacobian
+// copies of a step must fit a lone wave's 512 registers), 0: not covered
+int elements_per_lane(int dim, int n_constr) {
+  if (dim <= 64) return 1;
+  if (dim <= 256) return 4;
+  if (dim <= 1024 && n_constr <= 2) return 16;
+  return 0;
+}
+
+template <int C>
+int launch_wave_c(mm_ctx* ctx, const ConArgs& a, int which, double* d_out) {
+  const int ne = elements_per_lane(a.dim, C);
+  if (ne == 1) return launch_wave<C, 1>(ctx, a, which, d_out);
+  if (ne == 4) return launch_wave<C, 4>(ctx, a, which, d_out);
+  if constexpr (C <= 2) {
+    if (ne == 16) return launch_wave<C, 16>(ctx, a, which, d_out);
+  }
+  mm_set_error(ctx, "constrained kernels: dim <= 256 with up to 8 constraints, dim <= 1024 with up to 2");
+  return MM_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
-// true if the wave-per-chain kernel covers this model (the caller falls back to the lane-per-chain path otherwise)
+// true if the wave-per-chain kernels cover this model (the caller falls back to the lane-per-chain path otherwise)
 bool mm_constrained_wave_supports(const mmcon::ConArgs& a, int n_constr) {
-  if (a.dim <= 8 || a.dim > 64 || n_constr < 1 || n_constr > 8 || n_constr >= a.dim) return false;
+  if (a.dim <= 8 || n_constr < 1 || n_constr > 8 || n_constr >= a.dim) return false;
+  if (elements_per_lane(a.dim, n_constr) == 0) return false;
   if (a.gaussian) return false;  // the Gaussian split's rotations stay on the lane-per-chain path
   switch (a.constr) {
     case MM_CONSTR_LINEAR: case MM_CONSTR_SPHERE: case MM_CONSTR_CIRCLE: case MM_CONSTR_FIRST: return true;
@@ -449,15 +622,16 @@ bool mm_constrained_wave_supports(const mmcon::ConArgs& a, int n_constr) {
   }
 }
 
-int mm_launch_constrained_wave(mm_ctx* ctx, int n_constr, const mmcon::ConArgs& a, bool project_only) {
+// which: 0 the leapfrog step, 1 cotangent projection of the momenta, 2 out += log_det_sqrt_gram
+int mm_launch_constrained_wave(mm_ctx* ctx, int n_constr, const mmcon::ConArgs& a, int which, double* d_out) {
   switch (n_constr) {
-    case 1: return launch_wave<1>(ctx, a, project_only);
-    case 2: return launch_wave<2>(ctx, a, project_only);
-    case 3: return launch_wave<3>(ctx, a, project_only);
-    case 4: return launch_wave<4>(ctx, a, project_only);
-    case 5: return launch_wave<5>(ctx, a, project_only);
-    case 6: return launch_wave<6>(ctx, a, project_only);
-    case 7: return launch_wave<7>(ctx, a, project_only);
-    default: return launch_wave<8>(ctx, a, project_only);
+    case 1: return launch_wave_c<1>(ctx, a, which, d_out);
+    case 2: return launch_wave_c<2>(ctx, a, which, d_out);
+    case 3: return launch_wave_c<3>(ctx, a, which, d_out);
+    case 4: return launch_wave_c<4>(ctx, a, which, d_out);
+    case 5: return launch_wave_c<5>(ctx, a, which, d_out);
+    case 6: return launch_wave_c<6>(ctx, a, which, d_out);
+    case 7: return launch_wave_c<7>(ctx, a, which, d_out);
+    default: return launch_wave_c<8>(ctx, a, which, d_out);
   }
 }

@@ -311,3 +311,69 @@ def test_wave_per_chain_kernel_matches_oracle(variant):
         assert so == status[cidx] and no == n_done[cidx]
         assert_close(q[cidx], qo, 1e-10, f"q chain {cidx}")
         assert_close(p[cidx], po, 1e-10, f"p chain {cidx}")
+
+
+@pytest.mark.parametrize("case", ["sphereplane_d100_dense", "linear_c8_d200_quasi", "sphere_d700_ambient_diag",
+                                  "linear_c2_d1024_linesearch", "circle_d130_identity_inner2"])
+def test_wave_per_chain_kernel_beyond_64_dimensions_matches_oracle(case):
+    """D > 64: the wave-per-chain kernels with four (D <= 256, C <= 8) or sixteen (D <= 1024, C <= 2) coordinates per
+    lane - all three projection solvers, the three metric kinds, both density conventions (h with its Gram
+    log-determinant included), n_inner_step = 2, both time directions, the momentum projection of sample_momentum."""
+    rng = np.random.default_rng(len(case))
+    n, steps, solver, n_inner, hausdorff = 12, 6, 0, 1, True
+    if case == "sphereplane_d100_dense":
+        d, h = 100, 0.03
+        metric, mk = omdl.make_spd(d, rng), omdl.METRIC_DENSE
+        normal = rng.standard_normal(d)
+        oc, pc = omdl.SpherePlaneConstr(normal), models.SpherePlaneConstr(normal)
+        q0 = rng.standard_normal((n, d))
+        q0 -= np.outer(q0 @ normal, normal) / (normal @ normal)
+        q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
+    elif case == "linear_c8_d200_quasi":
+        d, h, solver = 200, 0.05, 1
+        metric, mk = omdl.make_spd(d, rng), omdl.METRIC_DENSE
+        a, b = rng.standard_normal((8, d)), rng.standard_normal(8)
+        oc, pc = omdl.LinearConstr(a, b), models.LinearConstr(a, b)
+        null = np.linalg.svd(a)[2][8:].T
+        q0 = np.linalg.lstsq(a, b, rcond=None)[0] + 0.5 * rng.standard_normal((n, d - 8)) @ null.T
+    elif case == "sphere_d700_ambient_diag":
+        d, h, hausdorff = 700, 0.02, False
+        metric, mk = np.exp(0.2 * rng.standard_normal(d)), omdl.METRIC_DIAG
+        oc, pc = omdl.SphereConstr(), models.SphereConstr()
+        q0 = rng.standard_normal((n, d))
+        q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
+    elif case == "linear_c2_d1024_linesearch":
+        d, h, solver = 1024, 0.05, 2
+        metric, mk = None, omdl.METRIC_IDENTITY
+        a, b = rng.standard_normal((2, d)), rng.standard_normal(2)
+        oc, pc = omdl.LinearConstr(a, b), models.LinearConstr(a, b)
+        null = np.linalg.svd(a)[2][2:].T
+        q0 = np.linalg.lstsq(a, b, rcond=None)[0] + 0.3 * rng.standard_normal((n, d - 2)) @ null.T
+    else:
+        d, h, n_inner = 130, 0.05, 2
+        metric, mk = None, omdl.METRIC_IDENTITY
+        oc, pc = omdl.CircleConstr(), models.CircleConstr()
+        q0 = rng.standard_normal((n, d))
+        q0[:, :2] /= np.linalg.norm(q0[:, :2], axis=1, keepdims=True)
+    proj = [solvers.solve_projection_onto_manifold_newton, solvers.solve_projection_onto_manifold_quasi_newton,
+            solvers.solve_projection_onto_manifold_newton_with_line_search][solver]
+    osys = orc.ConstrainedSystem(omdl.Poly(d, 0.5, 0.25), oc, mk, metric, dens_wrt_hausdorff=hausdorff)
+    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(d, 0.5, 0.25), pc, metric=metric,
+                                                           dens_wrt_hausdorff=hausdorff)
+    integ = integrators.ConstrainedLeapfrogIntegrator(system, h, projection_solver=proj, n_inner_step=n_inner)
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, d)))
+    jac0 = np.stack([np.atleast_2d(oc.jacob_constr(x)) for x in q0])
+    minv_p0 = np.stack([osys.minv(x) for x in p0])
+    assert np.max(np.abs(np.einsum("ncd,nd->nc", jac0, minv_p0))) < 1e-10  # in the cotangent space
+    dirs = np.where(np.arange(n) % 3 == 0, -1, 1).astype(np.int8)
+    q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=steps)
+    assert np.all(status == 0), status
+    assert np.max(np.abs(np.stack([np.atleast_1d(oc.constr(x)) for x in q]))) < 1e-8
+    for cidx in range(0, n, 4):
+        qo, po, so, no = orc.constrained_leapfrog_steps(osys, q0[cidx], p0[cidx], dirs[cidx] * h, steps,
+                                                        proj_solver=solver, n_inner_step=n_inner)
+        assert so == status[cidx] and no == n_done[cidx]
+        assert_close(q[cidx], qo, 1e-9, f"q chain {cidx}")
+        assert_close(p[cidx], po, 1e-9, f"p chain {cidx}")
+    ho = np.array([osys.h(q[i], p[i]) for i in range(4)])
+    assert_close(system.h_batch(q[:4], p[:4]), ho, 1e-11, "h")

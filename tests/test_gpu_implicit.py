@@ -324,10 +324,19 @@ def test_unsupported_sizes_fail_loudly():
     with pytest.raises(DeviceError):  # SoftAbs: one workgroup per chain up to D = 128
         integrators.ImplicitLeapfrogIntegrator(system, 0.01).step_batch(
             rng.standard_normal((1, 129)), rng.standard_normal((1, 129)), 1, 1)
-    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(65, 1.0, 0.0), models.CircleConstr())
-    with pytest.raises(DeviceError):  # lane-per-chain kernels stop at dim 64
+    system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(1025, 1.0, 0.0), models.CircleConstr())
+    with pytest.raises(DeviceError):  # wave-per-chain kernels: 16 coordinates per lane at most
         integrators.ConstrainedLeapfrogIntegrator(system, 0.1).step_batch(
-            rng.standard_normal((1, 65)), rng.standard_normal((1, 65)), 1, 1)
+            rng.standard_normal((1, 1025)), rng.standard_normal((1, 1025)), 1, 1)
+    with pytest.raises(DeviceError):  # ... and four per lane with more than two constraints
+        integrators.ConstrainedLeapfrogIntegrator(
+            systems.DenseConstrainedEuclideanMetricSystem(
+                models.Poly(257, 1.0, 0.0), models.LinearConstr(rng.standard_normal((3, 257)), np.zeros(3))),
+            0.1).step_batch(rng.standard_normal((1, 257)), rng.standard_normal((1, 257)), 1, 1)
+    with pytest.raises(DeviceError):  # the Gaussian split stays on the lane-per-chain kernels, dim <= 64
+        integrators.ConstrainedLeapfrogIntegrator(
+            systems.GaussianDenseConstrainedEuclideanMetricSystem(models.Poly(65, 0.0, 0.25), models.SphereConstr()),
+            0.1).step_batch(rng.standard_normal((1, 65)), rng.standard_normal((1, 65)), 1, 1)
     with pytest.raises(DeviceError):  # ... and at 8 constraint functions
         integrators.ConstrainedLeapfrogIntegrator(
             systems.DenseConstrainedEuclideanMetricSystem(
