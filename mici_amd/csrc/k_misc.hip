@@ -250,6 +250,8 @@ EuclidModelView view_of(const mm_model* m) {
                          m->d_metric_chol, m->gaussian_split, m->d_metric_omega, m->d_metric_eigvec};
 }
 
+constexpr size_t kMaxGenericLds = 160 * 1024;  // a CU's LDS: D <= 6826 (5120 with the Gaussian split's fourth vector)
+
 int waves_per_block(int dim, size_t* lds_bytes, int nvec = 3) {
   int w = 4;
   while (w > 1 && (size_t)w * nvec * dim * sizeof(double) > 60 * 1024) w >>= 1;
@@ -262,10 +264,12 @@ int waves_per_block(int dim, size_t* lds_bytes, int nvec = 3) {
 int mm_launch_leapfrog_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps) {
   size_t lds;
   const int w = waves_per_block(s->dim, &lds, m->gaussian_split ? 4 : 3);
-  if (lds > 64 * 1024) {
-    mm_set_error(ctx, "mm_leapfrog_euclid: dim too large for the generic kernel's LDS tile");
+  if (lds > kMaxGenericLds) {
+    mm_set_error(ctx, "mm_leapfrog_euclid: dim too large for the generic kernel (three D-vectors of a chain in 160 KB of LDS)");
     return MM_ERR_UNSUPPORTED;
   }
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(leapfrog_generic_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
   hipLaunchKernelGGL(leapfrog_generic_kernel, dim3(blocks), dim3(64 * w), lds, ctx->stream,
                      view_of(m), s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done,
@@ -278,10 +282,12 @@ int mm_launch_composition_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, d
                                   int n_coeffs, const double* coeffs, int initial_h1) {
   size_t lds;
   const int w = waves_per_block(s->dim, &lds, m->gaussian_split ? 4 : 3);
-  if (lds > 64 * 1024) {
-    mm_set_error(ctx, "mm_composition_euclid: dim too large for the generic kernel's LDS tile");
+  if (lds > kMaxGenericLds) {
+    mm_set_error(ctx, "mm_composition_euclid: dim too large for the generic kernel (three D-vectors of a chain in 160 KB of LDS)");
     return MM_ERR_UNSUPPORTED;
   }
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(composition_generic_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   CompCoefs cf{};
   cf.m = n_coeffs;
   cf.initial_h1 = initial_h1;
@@ -561,10 +567,12 @@ template <int OP>
 static int launch_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, double* out, const double* z) {
   size_t lds;
   const int w = waves_per_block(s->dim, &lds);
-  if (lds > 64 * 1024) {
-    mm_set_error(ctx, "dim too large for the wave-per-chain auxiliary kernel");
+  if (lds > kMaxGenericLds) {
+    mm_set_error(ctx, "dim too large for the wave-per-chain auxiliary kernel (three D-vectors of a chain in 160 KB of LDS)");
     return MM_ERR_UNSUPPORTED;
   }
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(euclid_aux_kernel<OP>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
   hipLaunchKernelGGL((euclid_aux_kernel<OP>), dim3(blocks), dim3(64 * w), lds, ctx->stream,
                      view_of(m), s->d_pos, s->d_mom, s->n, out, z);

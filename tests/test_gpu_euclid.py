@@ -188,6 +188,7 @@ def test_single_state_step_matches_reference_semantics(name):
     (1, 5, "dense", "dense"),
     (200, 9, "dense", "dense"),         # D > 128 -> generic wave-per-chain kernel
     (64, 17, "banana", "diag"),
+    (5000, 3, "banana", "diag"),        # three D-vectors of a chain fill most of a CU's LDS
 ])
 def test_leapfrog_matches_oracle_and_is_reversible(dim, n, target_kind, metric_kind):
     rng = np.random.default_rng(1234)
