@@ -133,13 +133,14 @@ def softabs_case(rng):
 
 
 def constrained_case(rng):
-    """Linear-equality and sphere manifolds up to D = 64 / C = 8 (the padded lane-per-chain kernels included)."""
-    dim = int(rng.choice([2, 3, 5, 8, 9, 12, 16, 17, 24, 33, 48, 64]))
+    """Linear-equality and sphere manifolds up to D = 256 / C = 8 and D = 1024 / C <= 2 (the wave-per-chain kernels with
+    one, four and sixteen coordinates per lane), both density conventions."""
+    dim = int(rng.choice([2, 3, 5, 8, 9, 12, 16, 17, 24, 33, 48, 64, 65, 100, 130, 200, 256, 300, 700, 1024]))
     n = int(rng.choice([1, 3, 7]))
     mk, metric = metric_of(dim, rng)
     pt, ot = targets(dim, rng, ["poly"])
     if rng.random() < 0.6 and dim >= 3:
-        c = int(rng.integers(1, min(8, dim - 1) + 1))
+        c = int(rng.integers(1, min(8 if dim <= 256 else 2, dim - 1) + 1))
         a, b = rng.standard_normal((c, dim)), rng.standard_normal(c)
         pc, oc = models.LinearConstr(a, b), omdl.LinearConstr(a, b)
         part = np.linalg.lstsq(a, b, rcond=None)[0]
@@ -151,8 +152,9 @@ def constrained_case(rng):
         x = rng.standard_normal((n, dim))
         q0 = x / np.linalg.norm(x, axis=1, keepdims=True)
         what = "sphere"
-    system = systems.DenseConstrainedEuclideanMetricSystem(pt, pc, metric=metric)
-    osys = orc.ConstrainedSystem(ot, oc, mk, metric)
+    hausdorff = bool(rng.random() < 0.7)
+    system = systems.DenseConstrainedEuclideanMetricSystem(pt, pc, metric=metric, dens_wrt_hausdorff=hausdorff)
+    osys = orc.ConstrainedSystem(ot, oc, mk, metric, dens_wrt_hausdorff=hausdorff)
     solver = int(rng.integers(0, 3))
     proj = [solvers.solve_projection_onto_manifold_newton, solvers.solve_projection_onto_manifold_quasi_newton,
             solvers.solve_projection_onto_manifold_newton_with_line_search][solver]
@@ -161,7 +163,8 @@ def constrained_case(rng):
     p0 = np.stack([osys.project_onto_cotangent_space(osys.msqrt(z), osys.constraint.jacob_constr(q0[c]))
                    for c, z in enumerate(rng.standard_normal((n, dim)))])
     dirs = np.where(rng.random(n) < 0.5, 1, -1).astype(np.int8)
-    desc = f"constrained {what} D={dim} N={n} metric={mk} solver={solver} h={h:.3f} steps={steps}"
+    desc = (f"constrained {what} D={dim} N={n} metric={mk} solver={solver} hausdorff={int(hausdorff)} h={h:.3f} "
+            f"steps={steps}")
     ref = lambda c: orc.constrained_leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, steps, proj_solver=solver)  # noqa: E731
     return desc, integ, system, osys, q0, p0, dirs, steps, ref, 1e-9
 

@@ -68,6 +68,10 @@ timeout 1200 python tools/fuzz_parity.py --seed 41 --cases 60 --kinds softabs --
 echo "seed 41 (SoftAbs only, four times the steps) rc=$? $(tail -1 $O/fuzz_41.log)" >> $O/fuzz_parity.txt
 grep "MISMATCH\|Traceback" -B2 $O/fuzz_41.log | head -10 >> $O/fuzz_parity.txt
 rm -f $O/fuzz_41.log
+timeout 1200 python tools/fuzz_parity.py --seed 51 --cases 80 --kinds constrained > $O/fuzz_51.log 2>&1
+echo "seed 51 (constrained only, D up to 1024) rc=$? $(tail -1 $O/fuzz_51.log)" >> $O/fuzz_parity.txt
+grep "MISMATCH\|Traceback\|refused" -B2 $O/fuzz_51.log | head -10 >> $O/fuzz_parity.txt
+rm -f $O/fuzz_51.log
 cat $O/fuzz_parity.txt
 
 # c2(iv): five fresh processes - wall-clock per pass against the HIP-event kernel time of the same pass
