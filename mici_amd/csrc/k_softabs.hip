@@ -749,6 +749,33 @@ struct SoftAbsBackendT {
     return converged;
   }
 
+  // ---- the eigenvector basis carried from one launch to the next (NP = 64) ------------------------------------------
+  // A launch used to start every chain from the identity - seven or eight Jacobi sweeps, half a leapfrog step's time
+  // - which is what an HMC transition with a short trajectory, its two Hamiltonian evaluations and its momentum draw
+  // pay four times over.  The state keeps each chain's last basis in global memory (32 KB a chain, flagged valid only
+  // when the last decomposition converged); any ORTHONORMAL basis is a legitimate starting point, however stale: the
+  // refinement measures how far it is and hands over to the sweeps by itself.
+  static constexpr int kEigDoubles = NP * NP + 8;  // V[NP][NP], then the valid flag
+  __device__ __forceinline__ void load_basis(const double* eig) {
+    if (!refine_on || eig == nullptr) return;
+    if (uniform_f64(eig[NP * NP]) != 1.0) return;
+    for (int el = tid; el < NP * NP; el += NT) {
+      const int i = el / NP, j = el % NP;
+      if (i < dim && j < dim) w.V[i * LD + j] = eig[el];
+    }
+    warm = 1;  // (visible to the team at the barrier every caller reaches before its first decomposition)
+  }
+  __device__ __forceinline__ void store_basis(double* eig) {
+    if (!refine_on || eig == nullptr) return;
+    if (warm > 0) {
+      for (int el = tid; el < NP * NP; el += NT) {
+        const int i = el / NP, j = el % NP;
+        if (i < dim && j < dim) eig[el] = w.V[i * LD + j];
+      }
+    }
+    if (tid == 0) eig[NP * NP] = warm > 0 ? 1.0 : 0.0;
+  }
+
   // softabs(x) = x / tanh(coeff x); grad_softabs (matrices.py:1662-1669)
   __device__ __forceinline__ bool regularise() {
     SA_PROF_BEGIN();
@@ -1081,6 +1108,7 @@ struct SaArgs {
   ImplicitArgs a;
   const double* coeff;  // device pointer to softabs_coeff
   double* work;         // NP = 128: [n_chains][kWorkDoubles] matrices of the chains
+  double* eig;          // NP = 64: [n_chains][kEigDoubles] bases carried between launches, or nullptr
   int op;
 };
 
@@ -1100,6 +1128,8 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
   const double t = uniform_f64(signed_step(A.dir, A.step_scale, chain, A.step_size));
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
+  double* const eig = (NP == 64 && S.eig) ? S.eig + chain * SoftAbsBackendT<NP>::kEigDoubles : nullptr;
+  bk.load_basis(eig);
   __syncthreads();
   const int my_steps = mmdev::chain_steps(A.chain_steps, chain, A.n_steps);
 #ifdef MM_SOFTABS_PROF
@@ -1111,6 +1141,7 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
     A.pos[chain * dim + tid] = bk.slot(SL_Q);
     A.mom[chain * dim + tid] = bk.slot(SL_P);
   }
+  bk.store_basis(eig);
 #ifdef MM_SOFTABS_PROF
   if (tid == 0 && chain == 0)
     printf("softabs prof: total %lld eigh(incl basis) %.0f basis %.0f dh2_dpos %.0f half_vjp %.0f | n_eigh %d sweeps %d "
@@ -1156,7 +1187,10 @@ __global__ __launch_bounds__(NT) void softabs_aux_kernel(SaArgs S, double* out, 
   const double q = act ? A.pos[chain * dim + tid] : 0.0;
   const double p = act ? A.mom[chain * dim + tid] : 0.0;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  double* const eig = (NP == 64 && S.eig) ? S.eig + chain * SoftAbsBackendT<NP>::kEigDoubles : nullptr;
+  bk.load_basis(eig);
   const bool ok = bk.build_and_invert(q);
+  bk.store_basis(eig);
   if (S.op == 0) {
     const double u = bk.matvec(p);
     double e = bk.nld_elem(q) + (act ? 0.5 * p * u + 0.5 * log(fabs(bk.w.lamt[tid])) : 0.0);
@@ -1214,11 +1248,31 @@ int ensure_work(mm_ctx* ctx, mm_state* s, size_t doubles_per_chain, double** out
   return MM_OK;
 }
 
+// the bases the chains of a state carry between launches (NP = 64), zeroed - "no basis yet" - when (re)allocated
+int ensure_eig(mm_ctx* ctx, mm_state* s, size_t doubles_per_chain, double** out) {
+  const size_t need = (size_t)s->n * doubles_per_chain * sizeof(double);
+  if (need != s->eig_bytes) {
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (s->d_eig) (void)hipFree(s->d_eig);
+    s->d_eig = nullptr;
+    s->eig_bytes = 0;
+    MM_HIP_CHECK(ctx, hipMalloc(&s->d_eig, need));
+    s->eig_bytes = need;
+    MM_HIP_CHECK(ctx, hipMemsetAsync(s->d_eig, 0, need, ctx->stream));
+  }
+  *out = s->d_eig;
+  return MM_OK;
+}
+
 template <bool MIDPOINT, int NP>
 int launch_softabs_np(mm_ctx* ctx, mm_state* s, SaArgs S) {
   using B = SoftAbsBackendT<NP>;
   if (B::kWorkDoubles) {
     const int rc = ensure_work(ctx, s, B::kWorkDoubles, &S.work);
+    if (rc != MM_OK) return rc;
+  }
+  if (NP == 64 && !S.a.no_refine) {
+    const int rc = ensure_eig(ctx, s, B::kEigDoubles, &S.eig);
     if (rc != MM_OK) return rc;
   }
   const size_t lds = B::kLdsDoubles * sizeof(double);
@@ -1234,6 +1288,10 @@ int launch_aux_np(mm_ctx* ctx, mm_state* s, SaArgs S, double* d_out, const doubl
   using B = SoftAbsBackendT<NP>;
   if (B::kWorkDoubles) {
     const int rc = ensure_work(ctx, s, B::kWorkDoubles, &S.work);
+    if (rc != MM_OK) return rc;
+  }
+  if (NP == 64 && !S.a.no_refine) {
+    const int rc = ensure_eig(ctx, s, B::kEigDoubles, &S.eig);
     if (rc != MM_OK) return rc;
   }
   const size_t lds = B::kLdsDoubles * sizeof(double);

@@ -531,6 +531,7 @@ int mm_state_free(mm_state* s) {
   else (void)hipFree(s->d_block);
   (void)hipFree(s->d_scratch);
   (void)hipFree(s->d_work);
+  (void)hipFree(s->d_eig);
   (void)hipFree(s->d_tr);
   (void)hipFree(s->d_mom_save);
   (void)hipFree(s->d_step_scale);
@@ -651,6 +652,17 @@ int mm_state_copy(mm_state* dst, const mm_state* src) {
     MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_chain_steps, src->d_chain_steps, n * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
   } else {
     dst->d_chain_steps = nullptr;  // switched off; the buffer stays for the next transition
+  }
+  if (src->d_eig) {  // ... and the SoftAbs eigenvector bases the chains carry from launch to launch
+    if (dst->eig_bytes != src->eig_bytes) {
+      MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipFree(dst->d_eig);
+      dst->d_eig = nullptr;
+      dst->eig_bytes = 0;
+      MM_HIP_CHECK(ctx, hipMalloc(&dst->d_eig, src->eig_bytes));
+      dst->eig_bytes = src->eig_bytes;
+    }
+    MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_eig, src->d_eig, src->eig_bytes, hipMemcpyDeviceToDevice, ctx->stream));
   }
   if (src->d_step_scale) {  // the copy integrates with the same per-chain step sizes
     if (!dst->d_step_scale) MM_HIP_CHECK(ctx, hipMalloc(&dst->d_step_scale, n * sizeof(double)));

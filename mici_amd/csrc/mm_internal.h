@@ -87,6 +87,8 @@ struct mm_state {
   size_t scratch_elems = 0;
   void* d_work = nullptr;  // per-chain workspace of the large-D implicit path
   size_t work_bytes = 0;
+  double* d_eig = nullptr;  // SoftAbs, D <= 64: the eigenvectors each chain's last launch ended with (k_softabs.hip)
+  size_t eig_bytes = 0;
   double* d_mom_save = nullptr;  // previous momentum during a correlated refresh (mm_momentum_refresh)
   size_t mom_save_elems = 0;
   double* d_step_scale = nullptr;  // optional per-chain step-size factors (mm_state_set_step_scale)

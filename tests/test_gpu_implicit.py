@@ -509,3 +509,50 @@ def test_softabs_refined_decompositions_match_oracle_at_c3b_size():
         assert so == status[c] and no == n_done[c]
         assert_close(q[c], qo, 1e-9, f"q chain {c}")
         assert_close(p[c], po, 1e-9, f"p chain {c}")
+
+
+def test_softabs_eigenvectors_are_carried_from_launch_to_launch():
+    """A state keeps each chain's last eigenvector basis (k_softabs.hip load_basis / store_basis): five one-step launches
+    on one device batch equal one five-step launch to solver accuracy and run no more Jacobi sweeps than it does.  A copy of the batch (the proposal of a transition)
+    inherits the bases; uploading unrelated positions into the batch is harmless - the refinement finds the stale basis
+    too far and hands over to the sweeps."""
+    from mici_amd import _ffi
+    from mici_amd.runtime import DeviceBatch, default_context
+    rng = np.random.default_rng(23)
+    dim, n, h = 40, 6, 0.03
+    w = np.linspace(0.6, 1.8, dim - 1)
+    system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(w), softabs_coeff=1.0)
+    integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+    q0 = 0.5 * rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+    q5, p5, st5, _ = integ.step_batch(q0, p0, 1, n_steps=5)
+    assert np.all(st5 == 0)
+    sweeps5 = integ.last_counters["n_newton_iters"]  # Jacobi sweeps of the one launch: a cold start per chain + hand-overs
+    ctx = default_context()
+    batch = DeviceBatch(ctx, n, dim)
+    try:
+        batch.upload(q0, p0, 1)
+        sweeps = []
+        for _ in range(5):
+            integ.step_device(batch, 1, ctx)
+            q, p, _, status, _ = batch.download_all()
+            assert np.all(status == 0)
+            sweeps.append(integ.last_counters["n_newton_iters"])
+        assert_close(q, q5, 1e-10, "five launches, positions")
+        assert_close(p, p5, 1e-10, "five launches, momenta")
+        assert sum(sweeps) <= sweeps5 + n, (sweeps, sweeps5)  # no further cold starts (each is 7-8 sweeps a chain)
+        other = DeviceBatch(ctx, n, dim)
+        try:
+            _ffi.check(ctx._lib.mm_state_copy(other.handle, batch.handle), ctx.handle, "mm_state_copy")
+            integ.step_device(other, 1, ctx)
+            assert np.all(other.download_all()[3] == 0)
+            assert integ.last_counters["n_newton_iters"] < 4 * n  # the copy starts from the bases, not from the identity
+        finally:
+            other.close()
+        batch.upload(rng.standard_normal((n, dim)), p0, 1)  # unrelated positions under the stored bases
+        integ.step_device(batch, 2, ctx)
+        qs, ps, _, status, n_done = batch.download_all()
+        assert integ.last_counters["n_newton_iters"] >= 4 * n  # sweeps again, from the stale bases
+        assert np.all(np.isfinite(qs)) and np.all((status == 0) | (n_done < 2))
+    finally:
+        batch.close()
