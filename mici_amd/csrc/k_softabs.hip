@@ -550,22 +550,48 @@ struct SoftAbsBackendT {
     const double* const hcol_i = w.H + 16 * g * LD + ri;
     const double* const gcol_j = Gm + 16 * g * LD + cj;
     const double* const xrow_i = X + ri * LD + 16 * g;
+    // (every target this backend has a Hessian for; a dense Hessian would take the matrix-core product below)
+    const bool sparse_hessian = target == MM_TARGET_POLY || target == MM_TARGET_FUNNEL;
     double prev = 0.0;
     ++unchecked;
     SA_LAP_BEGIN();
     for (int pass = 0; pass < kRefineMaxPass; ++pass) {
       SA_LAP(4);
-      {  // G = A X
+      // G = A X.  The Hessians this backend builds (build_hessian) are diagonal or arrowhead - non-zero on the diagonal
+      // and in row / column 0 only - and A X is formed from that: G_ij = A_i0 X_0j + A_ii X_ij for i > 0 on every lane
+      // (the entries it owns in the tile layout); row 0 is a full-length dot product per column, four columns a wave.
+      // 3 D^2 multiply-adds where the dense product is a quarter of a refinement pass' matrix-core time.
+      if (sparse_hessian) {
+        const double x0 = X[cj];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * I + 4 * r + g;
+          if (i > 0) {
+            const double g_ij = w.H[i * LD] * x0;
+            Gm[i * LD + cj] = target == MM_TARGET_POLY ? w.H[i * LD + i] * X[i * LD + cj]
+                                                        : __builtin_fma(w.H[i * LD + i], X[i * LD + cj], g_ij);
+          }
+        }
+        {  // row 0, G_0c = sum_k A_0k X_kc: wave t forms columns 4 t .. 4 t + 3, sixteen lanes (four terms each) a column
+          const int c = 4 * wave + (lane >> 4), k0 = 4 * (lane & 15);
+          double a = w.H[k0] * X[k0 * LD + c];
+#pragma unroll
+          for (int t = 1; t < 4; ++t) a = __builtin_fma(w.H[k0 + t], X[(k0 + t) * LD + c], a);
+          a = rp_sum_n<16>(a);
+          if ((lane & 15) == 0) Gm[c] = a;
+        }
+        n_products += 1;  // S
+      } else {
         d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < NP / 4; ++kk)
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(hcol_i[kk * LD], xcol_j[kk * LD], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Gm[(16 * I + 4 * r + g) * LD + cj] = acc[r];
+        n_products += 2;  // G and S
       }
       __syncthreads();
       SA_LAP(0);
-      n_products += 2;  // G and S
       // tiles of X^T G and X^T X.  The first pass takes X^T X = I: X is the result of the previous decomposition,
       // orthonormal to the square of its last rotation (< 1e-14), and a later pass repairs what the first adds to that.
       // Decompositions that end after their first pass never measure X^T X, so every kOrthoPeriod-th of those does.
