@@ -547,11 +547,8 @@ struct SoftAbsBackendT {
     // symmetric and is read down its columns.
     const double* const xcol_i = X + 16 * g * LD + ri;
     const double* const xcol_j = X + 16 * g * LD + cj;
-    const double* const hcol_i = w.H + 16 * g * LD + ri;
     const double* const gcol_j = Gm + 16 * g * LD + cj;
     const double* const xrow_i = X + ri * LD + 16 * g;
-    // (every target this backend has a Hessian for; a dense Hessian would take the matrix-core product below)
-    const bool sparse_hessian = target == MM_TARGET_POLY || target == MM_TARGET_FUNNEL;
     double prev = 0.0;
     ++unchecked;
     SA_LAP_BEGIN();
@@ -560,8 +557,9 @@ struct SoftAbsBackendT {
       // G = A X.  The Hessians this backend builds (build_hessian) are diagonal or arrowhead - non-zero on the diagonal
       // and in row / column 0 only - and A X is formed from that: G_ij = A_i0 X_0j + A_ii X_ij for i > 0 on every lane
       // (the entries it owns in the tile layout); row 0 is a full-length dot product per column, four columns a wave.
-      // 3 D^2 multiply-adds where the dense product is a quarter of a refinement pass' matrix-core time.
-      if (sparse_hessian) {
+      // 3 D^2 multiply-adds where the dense product (times_basis() has it, for the sweeps) is a quarter of a refinement
+      // pass' matrix-core time.
+      {
         const double x0 = X[cj];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -581,14 +579,6 @@ struct SoftAbsBackendT {
           if ((lane & 15) == 0) Gm[c] = a;
         }
         n_products += 1;  // S
-      } else {
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < NP / 4; ++kk)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(hcol_i[kk * LD], xcol_j[kk * LD], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Gm[(16 * I + 4 * r + g) * LD + cj] = acc[r];
-        n_products += 2;  // G and S
       }
       __syncthreads();
       SA_LAP(0);
@@ -1274,6 +1264,15 @@ int ensure_work(mm_ctx* ctx, mm_state* s, size_t doubles_per_chain, double** out
   return MM_OK;
 }
 
+// MICI_AMD_EIG_CACHE=0: every launch starts its chains from the identity (A/B runs)
+bool eig_cache_disabled() {
+  static const bool off = [] {
+    const char* e = getenv("MICI_AMD_EIG_CACHE");
+    return e && e[0] == '0';
+  }();
+  return off;
+}
+
 // the bases the chains of a state carry between launches (NP = 64), zeroed - "no basis yet" - when (re)allocated
 int ensure_eig(mm_ctx* ctx, mm_state* s, size_t doubles_per_chain, double** out) {
   const size_t need = (size_t)s->n * doubles_per_chain * sizeof(double);
@@ -1297,7 +1296,7 @@ int launch_softabs_np(mm_ctx* ctx, mm_state* s, SaArgs S) {
     const int rc = ensure_work(ctx, s, B::kWorkDoubles, &S.work);
     if (rc != MM_OK) return rc;
   }
-  if (NP == 64 && !S.a.no_refine) {
+  if (NP == 64 && !S.a.no_refine && !eig_cache_disabled()) {
     const int rc = ensure_eig(ctx, s, B::kEigDoubles, &S.eig);
     if (rc != MM_OK) return rc;
   }
@@ -1316,7 +1315,7 @@ int launch_aux_np(mm_ctx* ctx, mm_state* s, SaArgs S, double* d_out, const doubl
     const int rc = ensure_work(ctx, s, B::kWorkDoubles, &S.work);
     if (rc != MM_OK) return rc;
   }
-  if (NP == 64 && !S.a.no_refine) {
+  if (NP == 64 && !S.a.no_refine && !eig_cache_disabled()) {
     const int rc = ensure_eig(ctx, s, B::kEigDoubles, &S.eig);
     if (rc != MM_OK) return rc;
   }
