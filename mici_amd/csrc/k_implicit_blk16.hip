@@ -404,16 +404,22 @@ struct TeamBlk16 {
       d4 bq[kAhead];
 #pragma unroll
       for (int a = 0; a < kAhead; ++a) bq[a] = lane_base[(unsigned)(tix(tile_i(a, w), tile_j(a, w)) * 64)];
+      double vc_next = lds[kOffNat + 16 * tile_j(0, w) + j];  // (the vector operands one slot ahead, as matvec())
+      d4 vr_next = *reinterpret_cast<const d4*>(lds + kOffVperm + ((tile_i(0, w) * 4 + g) << 2));
 #pragma unroll
       for (int s = 0; s < NSLOT; ++s) {
         const int I = tile_i(s, w), J = tile_j(s, w);
         const d4 m = bq[s % kAhead];
         if (s + kAhead < NSLOT)
           bq[s % kAhead] = lane_base[(unsigned)(tix(tile_i(s + kAhead, w), tile_j(s + kAhead, w)) * 64)];
-        const double vc = lds[kOffNat + 16 * J + j];
+        const double vc = vc_next;
+        const d4 vr = vr_next;
+        if (s + 1 < NSLOT) {
+          vc_next = lds[kOffNat + 16 * tile_j(s + 1, w) + j];
+          vr_next = *reinterpret_cast<const d4*>(lds + kOffVperm + ((tile_i(s + 1, w) * 4 + g) << 2));
+        }
         add_row(s, w, rs, m, vc);
         if (!is_diag_slot(s)) {
-          const d4 vr = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
           double mm = m[0] * vr[0];
           mm = __builtin_fma(m[1], vr[1], mm);
           mm = __builtin_fma(m[2], vr[2], mm);
@@ -422,7 +428,7 @@ struct TeamBlk16 {
           part[(16 * J + j) * PSTR + I] = mm;
         }
         // keep the prefetch distance: without it the scheduler sinks every load to just before its use
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0x206);  // arithmetic and LDS stores may cross, loads may not
       }
 #pragma unroll
       for (int c = 0; c < NCLASS; ++c) {
@@ -781,14 +787,22 @@ struct TeamBlk16 {
     d4 rs[NCLASS];
 #pragma unroll
     for (int c = 0; c < NCLASS; ++c) rs[c] = d4{0.0, 0.0, 0.0, 0.0};
+    // the vector operands of a slot are loaded one slot ahead: issued where they are used, each LDS round trip
+    // (~130 cycles for the two waves of a SIMD) stood in front of the slot's eight multiply-adds
+    double vc_next = lds[kOffNat + 16 * tile_j(0, w) + j];
+    d4 vr_next = *reinterpret_cast<const d4*>(lds + kOffVperm + ((tile_i(0, w) * 4 + g) << 2));
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
       const int I = tile_i(s, w), J = tile_j(s, w);
-      const double vc = lds[kOffNat + 16 * J + j];
+      const double vc = vc_next;
+      const d4 vr = vr_next;
+      if (s + 1 < NSLOT) {
+        vc_next = lds[kOffNat + 16 * tile_j(s + 1, w) + j];
+        vr_next = *reinterpret_cast<const d4*>(lds + kOffVperm + ((tile_i(s + 1, w) * 4 + g) << 2));
+      }
       const d4 a = acc[s];
       add_row(s, w, rs, a, vc);
       if (!is_diag_slot(s)) {  // below the diagonal: the mirrored tile's rows are this tile's columns
-        const d4 vr = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
         double m = a[0] * vr[0];
         m = __builtin_fma(a[1], vr[1], m);
         m = __builtin_fma(a[2], vr[2], m);
@@ -796,6 +810,7 @@ struct TeamBlk16 {
         m = sum_over_g(m);
         part[(16 * J + j) * PSTR + I] = m;
       }
+      __builtin_amdgcn_sched_barrier(0x206);  // arithmetic and LDS stores may cross, loads may not
     }
 #pragma unroll
     for (int c = 0; c < NCLASS; ++c) {
