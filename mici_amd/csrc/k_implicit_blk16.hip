@@ -169,6 +169,36 @@ __device__ __forceinline__ double sum_over_g(double m) {
   }
 }
 
+// Four lane-partials reduced over the four 16-lane rows of the wave AT ONCE: on return the lanes of row g hold the
+// complete sum of value number g.  One v_permlane16_swap pairs the values (the swapped registers are both results: no
+// copies), one v_permlane32_swap pairs the pairs - 9 instructions for four sums where four sum_over_g() are 48.
+__device__ __forceinline__ double swap_pair(double a, double b, bool by32) {
+  const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+  const unsigned la = (unsigned)(ba & 0xffffffffLL), ha = (unsigned)(ba >> 32);
+  const unsigned lb = (unsigned)(bb & 0xffffffffLL), hb = (unsigned)(bb >> 32);
+  if (by32) {
+    const auto l2 = __builtin_amdgcn_permlane32_swap(la, lb, false, false);
+    const auto h2 = __builtin_amdgcn_permlane32_swap(ha, hb, false, false);
+    return __longlong_as_double(((long long)h2[0] << 32) | (unsigned)l2[0]) +
+           __longlong_as_double(((long long)h2[1] << 32) | (unsigned)l2[1]);
+  }
+  const auto l2 = __builtin_amdgcn_permlane16_swap(la, lb, false, false);
+  const auto h2 = __builtin_amdgcn_permlane16_swap(ha, hb, false, false);
+  return __longlong_as_double(((long long)h2[0] << 32) | (unsigned)l2[0]) +
+         __longlong_as_double(((long long)h2[1] << 32) | (unsigned)l2[1]);
+}
+__device__ __forceinline__ double sum4_over_g(double a, double b, double c, double d) {
+  if constexpr (kUsePermlaneSwap) {
+    // rows 0, 2 of ab: a summed over the row pairs (0, 1), (2, 3); rows 1, 3: b likewise
+    const double ab = swap_pair(a, b, false), cd = swap_pair(c, d, false);
+    return swap_pair(ab, cd, true);  // row 0: a, row 1: b, row 2: c, row 3: d
+  } else {
+    const int g = (int)(threadIdx.x & 63) >> 4;
+    const double sa = sum_over_g(a), sb = sum_over_g(b), sc = sum_over_g(c), sd = sum_over_g(d);
+    return g == 0 ? sa : (g == 1 ? sb : (g == 2 ? sc : sd));
+  }
+}
+
 // rs[r] = this lane's partial of row element 4 r + g: sum over the 16 lanes of a DPP row with one transposing
 // butterfly (4 values -> 1).  All four lanes of a quad end up with the sum for register r = j >> 2, i.e. for row
 // element 4 (j >> 2) + g.
@@ -250,6 +280,19 @@ struct TeamBlk16 {
 #pragma unroll
       for (int r = 0; r < 4; ++r) rs[1][r] = __builtin_fma(a[r], vb, rs[1][r]);
     }
+  }
+
+  // The mirrored (column) partials of four consecutive below-diagonal slots s0 .. s0 + 3, reduced over the wave's four
+  // rows together (sum4_over_g): the lanes of row g then own slot s0 + g and store its sum.
+  __device__ __forceinline__ void store_mirrored4(double* part, const int s0, const int w, const int g, const int j,
+                                                  const double a, const double b, const double c, const double d) {
+    const double m = sum4_over_g(a, b, c, d);
+    const int o0 = 16 * tile_j(s0, w) * PSTR + tile_i(s0, w);
+    const int o1 = 16 * tile_j(s0 + 1, w) * PSTR + tile_i(s0 + 1, w);
+    const int o2 = 16 * tile_j(s0 + 2, w) * PSTR + tile_i(s0 + 2, w);
+    const int o3 = s0 + 3 < NSLOT - 1 ? 16 * tile_j(s0 + 3, w) * PSTR + tile_i(s0 + 3, w) : 0;
+    const int off = g == 0 ? o0 : (g == 1 ? o1 : (g == 2 ? o2 : o3));
+    if (s0 + 3 < NSLOT - 1 || g < 3) part[off + j * PSTR] = m;
   }
 
   __device__ __forceinline__ void count(const int which, const int n) {
@@ -791,9 +834,9 @@ struct TeamBlk16 {
     // (~130 cycles for the two waves of a SIMD) stood in front of the slot's eight multiply-adds
     double vc_next = lds[kOffNat + 16 * tile_j(0, w) + j];
     d4 vr_next = *reinterpret_cast<const d4*>(lds + kOffVperm + ((tile_i(0, w) * 4 + g) << 2));
+    double mir[4] = {0.0, 0.0, 0.0, 0.0};  // mirrored partials of up to four slots, reduced together
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-      const int I = tile_i(s, w), J = tile_j(s, w);
       const double vc = vc_next;
       const d4 vr = vr_next;
       if (s + 1 < NSLOT) {
@@ -807,8 +850,9 @@ struct TeamBlk16 {
         m = __builtin_fma(a[1], vr[1], m);
         m = __builtin_fma(a[2], vr[2], m);
         m = __builtin_fma(a[3], vr[3], m);
-        m = sum_over_g(m);
-        part[(16 * J + j) * PSTR + I] = m;
+        mir[(s - 1) & 3] = m;
+        if (((s - 1) & 3) == 3 || s == NSLOT - 2)
+          store_mirrored4(part, s - ((s - 1) & 3), w, g, j, mir[0], mir[1], mir[2], ((s - 1) & 3) == 3 ? mir[3] : 0.0);
       }
       __builtin_amdgcn_sched_barrier(0x206);  // arithmetic and LDS stores may cross, loads may not
     }
