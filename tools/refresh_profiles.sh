@@ -12,7 +12,7 @@
 #   <round>_<cfg>_sq_counters.json        SQ counters (two passes) - c2 c3 c3b c4 c5
 #   <round>_c4_ubench_blk16.txt, <round>_c3_ubench_mfma.txt   phase clocks of the two dense-Riemannian kernels
 #   <round>_fuzz_parity.txt               tools/fuzz_parity.py, three seeds x 80 cases + 60 long SoftAbs cases
-#   <round>_c2iv_regimes.txt              c2(iv) launched five times in fresh processes: pass time vs kernel time
+#   <round>_c2iv_regimes.txt              c2(iv) launched five times in fresh processes: pass time vs kernel time, every timed region
 ROUND=${ROUND:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 if [ "$1" = "collect" ]; then
@@ -77,7 +77,7 @@ cat $O/fuzz_parity.txt
 # c2(iv): five fresh processes - wall-clock per pass against the HIP-event kernel time of the same pass
 for i in 1 2 3 4 5; do
   python bench.py --config c2iv --no-cpu-baseline --no-extra-configs 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.readline()); print('run $i: ms_per_pass %.3f  kernel_ms_per_launch %.3f' % (d['ms_per_step'], d['roofline']['kernel_ms_per_launch']))" >> $O/c2iv_regimes.txt
+import json,sys; d=json.loads(sys.stdin.readline()); print('run $i: ms_per_pass %.3f  kernel_ms_per_launch %.3f  timed regions (ms per pass): %s' % (d['ms_per_step'], d['roofline']['kernel_ms_per_launch'], ' '.join('%.3f' % a['ms_per_step'] for a in d['roofline']['attempts'])))" >> $O/c2iv_regimes.txt
 done
 cat $O/c2iv_regimes.txt
 du -sh $O
