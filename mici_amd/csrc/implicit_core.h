@@ -261,6 +261,16 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
   return ok;
 }
 
+// Backends whose metric construction starts from the previous one's result (the SoftAbs eigenvector basis) may keep two
+// snapshots of it per step: bk.basis_save(slot) / bk.basis_restore(slot).  The step below saves the basis at q (slot 0)
+// and at q + t M(q)^-1 p (slot 1) and hands them back where its solves jump: the reversibility-check solve iterates back
+// towards q, the C-adjoint solve starts from q + t M^-1 p again - each would otherwise start from the basis of a point
+// a whole position update away.  A starting basis, nothing more: results do not depend on it beyond rounding.
+template <class BK, class = void>
+struct basis_trait { static constexpr bool value = false; };
+template <class BK>
+struct basis_trait<BK, decltype((void)BK::kBasisSlots)> { static constexpr bool value = BK::kBasisSlots; };
+
 template <class BK, class = void>
 struct refine_trait { static constexpr bool value = false; };
 template <class BK>
@@ -332,6 +342,10 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       if (!need_inverse) bk.slot(mode == MODE_CHK ? SL_UC : SL_UA) = u_pos;
     }
     bump(bk, r, CNT_METRIC, 1);  // (the C-adjoint solve's own construction at the shared point is counted when it starts)
+    if constexpr (basis_trait<BK>::value) {
+      if (okm && need_inverse) bk.basis_save(0);
+      if (okm && mode == MODE_CFIRST) bk.basis_save(1);
+    }
     if (!okm) {
       r.status = need_inverse ? MM_ST_LINALG : MM_ST_SOLVER_LINALG;
       break;
@@ -416,6 +430,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       } else {
         bk.slot(SL_XQ) = ptC;
         mode = MODE_CHK;
+        if constexpr (basis_trait<BK>::value) bk.basis_restore(0);
         continue;
       }
     } else {  // MODE_CHK or MODE_ADJ: one more evaluation of the active solve
@@ -461,6 +476,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         bk.slot(SL_SX1) = bk.slot(SL_AX1);
         bk.slot(SL_XQ) = bk.slot(SL_PTA);
         mode = MODE_ADJ;
+        if constexpr (basis_trait<BK>::value) bk.basis_restore(1);
         continue;
       }
     }

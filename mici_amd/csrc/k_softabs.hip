@@ -171,6 +171,7 @@ struct SoftAbsBackendT {
   int n_sweeps = 0, n_eigh = 0;  // work counters (reported as n_newton_iters / n_eigh)
   bool j_valid = false;          // w.H holds the J matrix of the current eigenvalues (dh2_dpos)
   int red_flip = 0;              // which set of w.red the next workgroup reduction writes
+  int snap_ok = 0;               // which of the step's two basis snapshots hold a converged basis
   int unchecked = 0;             // decompositions since refine_eigh() last measured X^T X
   int n_products = 0;            // NP^3 products run on the matrix cores (reported as n_mfma_products)
   int n_refined = 0;             // decompositions obtained by refine_eigh() alone (reported as n_refine)
@@ -771,25 +772,47 @@ struct SoftAbsBackendT {
   // pay four times over.  The state keeps each chain's last basis in global memory (32 KB a chain, flagged valid only
   // when the last decomposition converged); any ORTHONORMAL basis is a legitimate starting point, however stale: the
   // refinement measures how far it is and hands over to the sweeps by itself.
-  static constexpr int kEigDoubles = NP * NP + 8;  // V[NP][NP], then the valid flag
-  __device__ __forceinline__ void load_basis(const double* eig) {
-    if (!refine_on || eig == nullptr) return;
-    if (uniform_f64(eig[NP * NP]) != 1.0) return;
+  // per chain: [0] the basis carried between launches, flag at kEigFlag; [1], [2] the two snapshots of a step
+  static constexpr int kEigFlag = 3 * NP * NP;
+  static constexpr int kEigDoubles = 3 * NP * NP + 8;
+  static constexpr bool kBasisSlots = NP == 64;  // implicit_core.h: basis_save / basis_restore
+  double* eig_mem = nullptr;  // this chain's kEigDoubles, or nullptr (refinement or carry-over switched off)
+  __device__ __forceinline__ void copy_basis_out(double* dst) {
     for (int el = tid; el < NP * NP; el += NT) {
       const int i = el / NP, j = el % NP;
-      if (i < dim && j < dim) w.V[i * LD + j] = eig[el];
+      if (i < dim && j < dim) dst[el] = w.V[i * LD + j];
     }
+  }
+  __device__ __forceinline__ void copy_basis_in(const double* src) {
+    for (int el = tid; el < NP * NP; el += NT) {
+      const int i = el / NP, j = el % NP;
+      if (i < dim && j < dim) w.V[i * LD + j] = src[el];
+    }
+  }
+  __device__ __forceinline__ void load_basis() {
+    if (eig_mem == nullptr) return;
+    if (uniform_f64(eig_mem[kEigFlag]) != 1.0) return;
+    copy_basis_in(eig_mem);
     warm = 1;  // (visible to the team at the barrier every caller reaches before its first decomposition)
   }
-  __device__ __forceinline__ void store_basis(double* eig) {
-    if (!refine_on || eig == nullptr) return;
-    if (warm > 0) {
-      for (int el = tid; el < NP * NP; el += NT) {
-        const int i = el / NP, j = el % NP;
-        if (i < dim && j < dim) eig[el] = w.V[i * LD + j];
-      }
-    }
-    if (tid == 0) eig[NP * NP] = warm > 0 ? 1.0 : 0.0;
+  __device__ __forceinline__ void store_basis() {
+    if (eig_mem == nullptr) return;
+    if (warm > 0) copy_basis_out(eig_mem);
+    if (tid == 0) eig_mem[kEigFlag] = warm > 0 ? 1.0 : 0.0;
+  }
+  // snapshots of the current basis inside a step (implicit_core.h).  Every thread reads back only what it wrote itself
+  // (the same element loop both ways), so the global round trip needs no fence; the workgroup barrier orders w.V.
+  __device__ __forceinline__ void basis_save(const int slot) {
+    if (eig_mem == nullptr || warm == 0) return;
+    copy_basis_out(eig_mem + (1 + slot) * NP * NP);
+    snap_ok |= 1 << slot;
+  }
+  __device__ __forceinline__ void basis_restore(const int slot) {
+    if (eig_mem == nullptr || !(snap_ok & (1 << slot))) return;
+    __syncthreads();  // every reader of the current basis is done
+    copy_basis_in(eig_mem + (1 + slot) * NP * NP);
+    __syncthreads();
+    warm = warm > 0 ? warm : 1;
   }
 
   // softabs(x) = x / tanh(coeff x); grad_softabs (matrices.py:1662-1669)
@@ -1144,8 +1167,8 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
   const double t = uniform_f64(signed_step(A.dir, A.step_scale, chain, A.step_size));
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
-  double* const eig = (NP == 64 && S.eig) ? S.eig + chain * SoftAbsBackendT<NP>::kEigDoubles : nullptr;
-  bk.load_basis(eig);
+  bk.eig_mem = (NP == 64 && S.eig && bk.refine_on) ? S.eig + chain * SoftAbsBackendT<NP>::kEigDoubles : nullptr;
+  bk.load_basis();
   __syncthreads();
   const int my_steps = mmdev::chain_steps(A.chain_steps, chain, A.n_steps);
 #ifdef MM_SOFTABS_PROF
@@ -1157,7 +1180,7 @@ __global__ __launch_bounds__(NT) void softabs_leapfrog_kernel(SaArgs S) {
     A.pos[chain * dim + tid] = bk.slot(SL_Q);
     A.mom[chain * dim + tid] = bk.slot(SL_P);
   }
-  bk.store_basis(eig);
+  bk.store_basis();
 #ifdef MM_SOFTABS_PROF
   if (tid == 0 && chain == 0)
     printf("softabs prof: total %lld eigh(incl basis) %.0f basis %.0f dh2_dpos %.0f half_vjp %.0f | n_eigh %d sweeps %d "
@@ -1203,10 +1226,10 @@ __global__ __launch_bounds__(NT) void softabs_aux_kernel(SaArgs S, double* out, 
   const double q = act ? A.pos[chain * dim + tid] : 0.0;
   const double p = act ? A.mom[chain * dim + tid] : 0.0;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
-  double* const eig = (NP == 64 && S.eig) ? S.eig + chain * SoftAbsBackendT<NP>::kEigDoubles : nullptr;
-  bk.load_basis(eig);
+  bk.eig_mem = (NP == 64 && S.eig && bk.refine_on) ? S.eig + chain * SoftAbsBackendT<NP>::kEigDoubles : nullptr;
+  bk.load_basis();
   const bool ok = bk.build_and_invert(q);
-  bk.store_basis(eig);
+  bk.store_basis();
   if (S.op == 0) {
     const double u = bk.matvec(p);
     double e = bk.nld_elem(q) + (act ? 0.5 * p * u + 0.5 * log(fabs(bk.w.lamt[tid])) : 0.0);
