@@ -973,34 +973,27 @@ struct SoftAbsBackendT {
     __syncthreads();
     SA_LAP(16);
     if constexpr (kMatricesInLds) {
-      // J into w.H, A into w.W, zero beyond dim; then B = A J on the matrix cores: wave t owns the 16 x 16 tile
-      // (t / 4, t % 4) of B - sixteen v_mfma_f64_16x16x4 (A operand: lane (g, m) = A[16 I + m][4 kk + g]; B operand:
-      // lane (g, n) = J[4 kk + g][16 Jt + n]; accumulator lane 16 g + j, register r = B[16 I + 4 r + g][16 Jt + j]).
-      // md_i = sum_l B_il A_il is reduced over a tile's columns on the DPP row and over the four column tiles through
-      // LDS; m0_i = sum_l B_0l A_il needs row 0 of B only.  (The FMA loop this replaces took 31 k cycles a call.)
-      // (J depends on the eigenvalues only: it is built once per decomposition - the momentum fixed point calls this
-      // several times at one position - and stays in w.H until build_hessian() overwrites it)
-      if (j_valid) {
+      // B = A J on the matrix cores, A = V diag(e) formed in the operand (one multiply per term: A is never stored),
+      // J in w.H, zero beyond dim: wave t owns the 16 x 16 tile (t / 4, t % 4) of B - sixteen v_mfma_f64_16x16x4, lane
+      // group g taking the terms k = 16 g + kk (refine_eigh(): no LDS bank conflicts that way); accumulator lane
+      // 16 g + j, register r = B[16 I + 4 r + g][16 Jt + j].  md_i = sum_l B_il A_il is reduced over a tile's columns on
+      // the DPP row and over the four column tiles through LDS; m0_i = sum_l B_0l A_il needs row 0 of B only.
+      // J depends on the eigenvalues only: it is built once per decomposition - the momentum fixed point calls this
+      // several times at one position - and stays in w.H until build_hessian() overwrites it.
+      if (!j_valid) {
         for (int el = tid; el < NP * NP; el += NT) {
           const int k = el / NP, l = el % NP;
-          w.W[k * LD + l] = (k < dim && l < dim) ? w.V[k * LD + l] * w.v1[l] : 0.0;  // A[i=k][k=l]
-        }
-      } else {
-        for (int el = tid; el < NP * NP; el += NT) {
-          const int k = el / NP, l = el % NP;
-          double jv = 0.0, av = 0.0;
+          double jv = 0.0;
           if (k < dim && l < dim) {
             double num = w.lamt[k] - w.lamt[l], den = w.lam[k] - w.lam[l];
             if (k == l) { num += w.gsa[k]; den = 1.0; }
             jv = num / den;                        // 0/0 -> NaN for degenerate spectra, as the reference
-            av = w.V[k * LD + l] * w.v1[l];        // A[i=k][k=l]
           }
           w.H[k * LD + l] = jv;
-          w.W[k * LD + l] = av;
         }
         j_valid = true;
+        __syncthreads();
       }
-      __syncthreads();
       SA_LAP(17);
       double* const part = w.ring;        // [4][NP] column-tile partials of md (the ring is idle outside eigh())
       double* const brow0 = w.ring + 4 * NP;  // [NP] row 0 of B
@@ -1010,16 +1003,17 @@ struct SoftAbsBackendT {
         const int I = wave >> 2, Jt = wave & 3;
         d4 acc = {0.0, 0.0, 0.0, 0.0};
         ++n_products;
-        // lane group g takes the terms k = 16 g + kk (refine_eigh(): no LDS bank conflicts that way)
-        const double* arow = w.W + (16 * I + j) * LD + 16 * g;
+        const double* vrow = w.V + (16 * I + j) * LD + 16 * g;  // (w.V is zero beyond dim: init_backend, refine_eigh)
+        const double* ek = w.v1 + 16 * g;
         const double* bcol = w.H + 16 * g * LD + 16 * Jt + j;
 #pragma unroll
         for (int kk = 0; kk < NP / 4; ++kk)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[kk], bcol[kk * LD], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vrow[kk] * ek[kk], bcol[kk * LD], acc, 0, 0, 0);
+        const double el = w.v1[16 * Jt + j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * I + 4 * r + g;
-          const double s = rp_sum_n<16>(acc[r] * w.W[i * LD + 16 * Jt + j]);
+          const double s = rp_sum_n<16>(acc[r] * (w.V[i * LD + 16 * Jt + j] * el));
           if (j == 0) part[Jt * NP + i] = s;
         }
         if (I == 0 && g == 0) brow0[16 * Jt + j] = acc[0];
@@ -1030,7 +1024,10 @@ struct SoftAbsBackendT {
         const int i = tid / RP, pt = tid % RP;
         double m0 = 0.0;
 #pragma unroll
-        for (int m = 0; m < NP / RP; ++m) m0 = __builtin_fma(brow0[pt + RP * m], w.W[i * LD + pt + RP * m], m0);
+        for (int m = 0; m < NP / RP; ++m) {
+          const int l = pt + RP * m;
+          m0 = __builtin_fma(brow0[l], w.V[i * LD + l] * w.v1[l], m0);
+        }
         m0 = rp_sum(m0);
         if (pt == 0) {
           w.v2[i] = -((part[i] + part[NP + i]) + (part[2 * NP + i] + part[3 * NP + i]));
@@ -1135,6 +1132,12 @@ __device__ __forceinline__ void init_backend(SoftAbsBackendT<NP>& bk, const Impl
   bk.w.cnt = p; p += 8;
   bk.w.prof = p; p += 24;
   bk.w.stash = p;
+  if (B::kMatricesInLds && A.dim < NP) {  // w.V is read whole by the matrix-core products: zero beyond dim, once
+    for (int el = threadIdx.x; el < NP * NP; el += NT) {
+      const int i = el / NP, j = el % NP;
+      if (i >= A.dim || j >= A.dim) bk.w.V[i * B::LD + j] = 0.0;
+    }
+  }
   {  // (visible after the first barrier of whatever runs next)
     const int n_tp = A.target == MM_TARGET_FUNNEL ? A.dim - 1 : 2;
     if ((int)threadIdx.x < NP) bk.w.tp[threadIdx.x] = (int)threadIdx.x < n_tp ? A.tparams[threadIdx.x] : 0.0;
