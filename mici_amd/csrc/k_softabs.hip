@@ -205,7 +205,22 @@ struct SoftAbsBackendT {
   __device__ __forceinline__ double norm(double x, int kind) {
     SA_PROF_BEGIN();
     const double a = tid < dim ? x : 0.0;
-    const double r = kind == MM_NORM_LINF ? block_reduce4(fabs(a), 1, w.red, red_flip) : sqrt(block_reduce4(a * a, 0, w.red, red_flip));
+    double r;
+    if constexpr (NP == 64) {
+      // a flat vector lives in the first wave: it alone reduces (the other fifteen would reduce zeros on the SIMDs it
+      // shares), everybody reads its result behind the one barrier
+      double* const set = w.red + 16 * red_flip;
+      red_flip ^= 1;
+      if (tid < 64) {
+        const double v = kind == MM_NORM_LINF ? wave_max(fabs(a)) : wave_sum(a * a);
+        if (tid == 0) set[0] = v;
+      }
+      __syncthreads();
+      r = uniform_f64(set[0]);
+      if (kind != MM_NORM_LINF) r = sqrt(r);
+    } else {
+      r = kind == MM_NORM_LINF ? block_reduce4(fabs(a), 1, w.red, red_flip) : sqrt(block_reduce4(a * a, 0, w.red, red_flip));
+    }
     SA_PROF_END2(13);
     return r;
   }
@@ -831,7 +846,19 @@ struct SoftAbsBackendT {
       w.lamt[tid] = lt;
       w.gsa[tid] = gs;
     }
-    const bool ok = block_reduce4(bad, 0, w.red, red_flip) == 0.0;
+    bool ok;
+    if constexpr (NP == 64) {  // the eigenvalues live in the first wave: it alone reduces (as norm())
+      double* const set = w.red + 16 * red_flip;
+      red_flip ^= 1;
+      if (tid < 64) {
+        const double v = wave_sum(bad);
+        if (tid == 0) set[0] = v;
+      }
+      __syncthreads();
+      ok = uniform_f64(set[0]) == 0.0;
+    } else {
+      ok = block_reduce4(bad, 0, w.red, red_flip) == 0.0;
+    }
     SA_PROF_END2(9);
     return ok;
   }
