@@ -995,9 +995,18 @@ struct SoftAbsBackendT {
     SA_PROF_BEGIN();
     SA_LAP_BEGIN();
     if (tid < NP) w.qv[tid] = (tid < dim) ? q : 0.0;  // for mtp_lds(): visible long before it runs
-    const double c = vt_times(p);
-    if (tid < NP) w.v1[tid] = (tid < dim) ? c / w.lamt[tid] : 0.0;  // e
-    __syncthreads();
+    {  // e = V^T p / lamt into w.v1 (vt_times() with the division in its output stage: one barrier less)
+      double* const vin = w.ring + 1024;
+      if (tid < NP) vin[tid] = (tid < dim) ? p : 0.0;
+      __syncthreads();
+      const int k = tid / RP, part = tid % RP;
+      double s = 0.0;
+      if (k < dim)
+        for (int i = part; i < dim; i += RP) s = __builtin_fma(w.V[i * LD + k], vin[i], s);
+      s = rp_sum(s);
+      if (part == 0) w.v1[k] = (k < dim) ? s / w.lamt[k] : 0.0;
+      __syncthreads();
+    }
     SA_LAP(16);
     if constexpr (kMatricesInLds) {
       // B = A J on the matrix cores, A = V diag(e) formed in the operand (one multiply per term: A is never stored),
