@@ -163,7 +163,7 @@ struct SoftAbsBackendT {
   static constexpr int kWorkDoubles = kMatricesInLds ? 0 : MAT + 2 * MATJ;  // per chain, global memory
   __device__ static __forceinline__ double rp_sum(double v) { return rp_sum_n<RP>(v); }
 
-  static constexpr bool kSolveByInverse = false;  // implicit_core.h
+  static constexpr bool kSolveByInverse = true;   // implicit_core.h: ONE inlined copy of the construction (eigh: refinement + sweeps) instead of two
   static constexpr bool kUnifiedConstruct = false;
   static constexpr bool kCountersInLds = true;  // implicit_core.h: work counters in LDS, bumped by thread 0
   int dim, tid_raw, target;
