@@ -29,6 +29,11 @@ RCCL all-gather of positions over xGMI at trace collection - is timed once, sepa
 region of the headline config and reported as `config.trace_gather_ms`; MICI_AMD_BENCH_GATHER=rccl puts
 one gather per trajectory inside the timed region instead (overlapped with the next trajectory).
 
+MICI_AMD_SHARE_DEVICE=1 (a TEST switch, tests/test_gpu_multirank.py): the N ranks share the visible devices round-robin
+instead of refusing to oversubscribe, and the trace is gathered through the host rendezvous (RCCL refuses two ranks on one
+device) - N > 1 rank processes with their own contexts on a one-GPU box; the numbers of such a run are not a measurement.
+MICI_AMD_BENCH_DUMP_TRACE=<file.npy>: rank 0 writes the gathered positions of the headline config there.
+
 Re-timing: a single-process run whose timed region's wall clock exceeds the HIP-event kernel time of the same passes by
 more than 10 % (the device queue was descheduled mid-region: DESIGN.md section 8) times the region again, at most twice
 more, and reports the fastest attempt; `roofline.attempts` lists all of them.
@@ -111,12 +116,16 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
             target, P = models.GaussIso(dim), None
             metric = None
             flops = 8.0 * dim
+            # what leapfrog_elem_kernel executes per chain-step and coordinate for this target (grad = q): three
+            # v_fma_f64 - p -= (t/2) g, q += t p, p -= (t/2) g - i.e. 6 flops against SURVEY 8d's ~8
+            exec_flops = 6.0 * dim
             name = "c2(i) iso-Gaussian"
         else:
             P = _make_spd(dim, rng)
             target = models.GaussDense(P)
             metric = P if config == "c2iv" else None
             flops = stages * (2.0 * dim * dim * (2 if config == "c2iv" else 1) + 8.0 * dim)
+            exec_flops = None
             name = "c2(iv) dense-Gaussian + dense metric" if config == "c2iv" else \
                 "c2(iii) dense-precision Gaussian"
         system = systems.EuclideanMetricSystem(target, metric=metric)
@@ -139,7 +148,7 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
         return dict(name=f"{name}, EuclideanMetricSystem + {iname}", dim=dim, h=h,
                     coefficients=getattr(integ, "coefficients", None),
                     traj=traj, integ=integ, system=system, make_oracle=make_oracle, q0=q0, p0=p0,
-                    bytes_per_chain_step=32.0 * dim, flops_per_chain_step=flops,
+                    bytes_per_chain_step=32.0 * dim, flops_per_chain_step=flops, valu_executed_flops_per_chain_step=exec_flops,
                     bound="hbm" if config == "c2i" else "mfma", kind="euclid")
     if config in ("c3", "c4"):
         dim, h, traj = (64, 0.02, 100) if config == "c3" else (256, 0.01, 50)
@@ -387,7 +396,7 @@ def cpu_baseline(config, budget_s=16.0):
 
 # ---- one config, measured ---------------------------------------------------------------------------------------
 def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=None, traj_len=None,
-               gather_mode="off"):
+               gather_mode="off", dump_trace=False):
     """W warm-up passes, then exactly `steps` timed passes between (device sync + rank barrier) pairs.
     Returns the result dict of this config (identical on every rank)."""
     from mici_amd import _ffi
@@ -547,9 +556,24 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
             gather_note, trace_gather_ms = box.get("mode", "?"), box.get("ms")
     elif in_loop:
         gather_note = "rccl all-gather per pass, inside the timed region"
+    elif world > 1 and gather_mode == "host":
+        # MICI_AMD_SHARE_DEVICE: the same rank-major all-gather through the rendezvous socket (the test oracle of the
+        # RCCL path, SURVEY 8e "host-side alternative must give identical bytes")
+        from mici_amd import distributed as mdist
+        barrier()
+        tg = time.perf_counter()
+        pos_all = mdist.gather_host(batch.download()[0], world * n_local, rdzv)
+        barrier()
+        trace_gather_ms = (time.perf_counter() - tg) * 1e3
+        gather_note = "host gather over the rendezvous socket, outside the timed region (MICI_AMD_SHARE_DEVICE test switch)"
+    dump = os.environ.get("MICI_AMD_BENCH_DUMP_TRACE")
+    if dump and rank == 0 and dump_trace:
+        np.save(dump, pos_all if pos_all is not None else batch.download()[0])
 
     launch_s = kernel_ms / 1e3 / steps
-    chain_steps_per_launch = n_local * traj
+    # chain-steps a launch COMPLETED: explicit steps cannot fail; every other integrator counts n_done (a failed chain
+    # stops - at c5's h = 0.1 a quarter of the torus chain-steps is lost that way)
+    chain_steps_per_launch = n_local * traj if w["kind"] == "euclid" else done_local / steps
     d = float(w["dim"])
     if w["kind"] == "softabs":
         # algorithmic flops: n_eig * 9 D^3 (symmetric eigendecomposition
@@ -603,11 +627,16 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
                     frac=achieved / HBM_PEAK_GBS, traffic=None)
         if w.get("flops_per_chain_step"):  # what actually limits these kernels: FP64 vector issue
             tf = w["flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
-            roof["fp64_valu"] = dict(achieved=tf, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s", frac=tf / FP64_MFMA_PEAK_TF)
+            roof["fp64_valu"] = dict(achieved=tf, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s", frac=tf / FP64_MFMA_PEAK_TF,
+                                     chain_steps_per_launch=chain_steps_per_launch)
+            if w.get("valu_executed_flops_per_chain_step"):  # the flops the kernel's instruction stream really holds
+                ex_tf = w["valu_executed_flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
+                roof["fp64_valu"].update(executed_flops_per_chain_step=w["valu_executed_flops_per_chain_step"],
+                                         executed_achieved=ex_tf, executed_frac=ex_tf / FP64_MFMA_PEAK_TF)
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE /
     # WRITE_SIZE cannot be read from inside the process); null when this shape was not profiled
     default_shape = chains_per_gpu is None and traj_len is None
-    for pmc_name in (f"r03_{config}_pmc_hbm.json", f"r02_{config}_pmc_hbm.json"):
+    for pmc_name in (f"r04_{config}_pmc_hbm.json", f"r03_{config}_pmc_hbm.json", f"r02_{config}_pmc_hbm.json"):
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if default_shape and os.path.exists(pmc):
             with open(pmc) as fh:
@@ -628,7 +657,10 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
     roof["host_issue_ms"] = issued * 1e3  # of all passes; large values = the host, not the GPU, paced the region
     roof["attempts"] = attempts  # every timed region of this config (see the re-timing policy above)
     roof["algorithmic_flops_per_chain_step"] = w["flops_per_chain_step"]
-    roof["algorithmic_bytes_per_chain_step"] = w["bytes_per_chain_step"] / (traj if w["bound"] == "hbm" else 1)
+    # ONE unit for every entry: SURVEY 8d's 32 D bytes per chain-STEP.  An HBM-bound entry's `achieved` prices what a
+    # fused launch really has to move - the state read once and written once per LAUNCH (`..._per_chain_launch`)
+    roof["algorithmic_bytes_per_chain_step"] = w["bytes_per_chain_step"]
+    roof["algorithmic_bytes_per_chain_launch"] = w["bytes_per_chain_step"]
     if counters_acc:
         roof["work_counters"] = counters_acc
 
@@ -694,18 +726,21 @@ def main():
     n_dev = count.value if _ffi.load().mm_device_count(C.byref(count)) == 0 else 0
     if rdzv is not None:  # every rank learns the smallest count: all leave together, none waits in a collective
         n_dev = int(min(int(x) for x in rdzv.allgather(str(n_dev).encode())))
-    if n_dev < world or n_dev <= local_rank:
+    share = world > 1 and os.environ.get("MICI_AMD_SHARE_DEVICE", "") == "1"  # test switch, see the docstring
+    if (n_dev < world or n_dev <= local_rank) and not (share and n_dev >= 1):
         if rdzv is not None:
             rdzv.close()
         raise SystemExit(f"bench.py --gpus {world}: rank {rank} needs HIP device {local_rank} but only {n_dev} HIP "
                          "device(s) are visible (one process per GPU, no oversubscription, no CPU fallback)")
-    ctx = Context(local_rank)
+    ctx = Context(local_rank % n_dev if share else local_rank)
 
     gather_mode = "off"
     if world > 1:
         gather_mode = "rccl" if os.environ.get("MICI_AMD_BENCH_GATHER", "") == "rccl" else "after"
+        if share:
+            gather_mode = "host"
     head = run_config(ctx, rdzv, args.config, args.steps, args.warmup, rank, world, args.chains_per_gpu,
-                      args.traj_len, gather_mode)
+                      args.traj_len, gather_mode, dump_trace=True)
     exit_hard = head.pop("_exit_hard")
     # every GPU measurement comes first; the CPU baselines (all host cores busy) run after the last timed region
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
@@ -749,8 +784,9 @@ def main():
                 "workload": head["workload"],
                 "baseline_config": head["baseline_config"],
                 "chains_per_gpu": head["chains_per_gpu"], "dim": head["dim"], "traj_len": head["traj_len"],
-                "parallelism": f"chains sharded x{world}, one process per GPU, no collective in the timed region"
-                               if gather_mode != "rccl" else f"chains sharded x{world}, RCCL trace gather per pass",
+                "parallelism": (f"chains sharded x{world}, one process per GPU, no collective in the timed region"
+                                if gather_mode != "rccl" else f"chains sharded x{world}, RCCL trace gather per pass")
+                               + (" [MICI_AMD_SHARE_DEVICE: ranks share devices - not a measurement]" if share else ""),
                 "trace_gather": head["trace_gather"],
                 "trace_gather_ms": head["trace_gather_ms"],
             },

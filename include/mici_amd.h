@@ -28,6 +28,11 @@
 extern "C" {
 #endif
 
+/* libmici_amd.so is built with -fvisibility=hidden: what this header declares is the whole export list */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define MM_ABI_VERSION 3
 
 typedef struct mm_ctx mm_ctx;
@@ -379,6 +384,10 @@ int mm_comm_allgather_pos(mm_comm* comm, mm_state* state, double* pos_all);
  * gather only, e.g. on ranks that do not write traces). */
 int mm_comm_allgather_pos_async(mm_comm* comm, mm_state* state, int want_host);
 int mm_comm_wait(mm_comm* comm, double* pos_all);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ LIB = os.path.join(HERE, "lib", "libmici_amd.so")
 LIB_DEV = os.path.join(HERE, "lib", "libmici_amd_dev.so")
 DEV_MACRO = "MM_DEV_KERNELS"
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-function", "-ffp-contract=on"]
 
 
@@ -42,6 +42,18 @@ EXTRA_FLAGS = {
 
 # development builds (in-kernel phase timers etc.): MICI_AMD_HIPCC_FLAGS="-DMM_SOFTABS_PROF" python -m mici_amd.build --force
 DEV_FLAGS = os.environ.get("MICI_AMD_HIPCC_FLAGS", "").split()
+
+
+HEADER = os.path.join(HERE, "..", "include", "mici_amd.h")
+
+
+def exported_names(dev=False):
+    """The functions include/mici_amd.h declares (the product's whole export list); dev: + the developer hooks."""
+    import re
+    with open(HEADER, encoding="utf-8") as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", text)))
+    return names + (["mm_debug_*"] if dev else [])
 
 
 def hipcc():
@@ -82,8 +94,14 @@ def _compile_and_link(sources, objdir, lib, extra, headers_time, force, jobs, ve
                 if verbose and log.strip():
                     print(log)
     all_objs = objs + list(reuse or [])
-    if todo or force or not os.path.exists(lib) or os.path.getmtime(lib) < _newest(all_objs):
-        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *all_objs, "-o", lib, "-ldl"]
+    if todo or force or not os.path.exists(lib) or os.path.getmtime(lib) < _newest(all_objs + [HEADER]):
+        # the dynamic symbol table is exactly the export list: what include/mici_amd.h declares (+ mm_debug_* in the
+        # developer library).  -fvisibility=hidden alone leaves the kernels' host-side handles, __hip_cuid_* and weak
+        # std:: instantiations exported; a linker version script does not.
+        vmap = os.path.join(objdir, "exports.map")
+        with open(vmap, "w", encoding="utf-8") as f:
+            f.write("{\n  global:\n" + "".join(f"    {n};\n" for n in exported_names(dev=bool(extra))) + "  local: *;\n};\n")
+        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", f"-Wl,--version-script={vmap}", *all_objs, "-o", lib, "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)

@@ -226,8 +226,11 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
   double rz, pu;
   bk.sum2(rv * z, rhs * guess, &rz, &pu);
   int pairs = 1;
-  bool ok = rz <= kRefineTol2 * fabs(pu);
-  if (!ok) {
+  // r^T F r is the squared energy norm of the error only while F is positive definite: a negative (or NaN) value - an
+  // explicit inverse that came out numerically indefinite - must not read as "converged" (it would return the
+  // unrefined guess and skip the factorisation, which is what reports the reference's error)
+  bool ok = rz >= 0.0 && rz <= kRefineTol2 * fabs(pu);
+  if (!ok && rz > 0.0) {
     bk.rslot(RS_D) = z;
 #pragma unroll 1
     for (int k = 0; k < kRefineMaxIter; ++k) {
@@ -247,6 +250,7 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
       ++pairs;
       double rz2;
       bk.sum2(rv * z, rhs * u, &rz2, &pu);
+      if (!(rz2 >= 0.0)) break;  // F not positive definite along r (or NaN): refinement failure -> factorisation
       if (rz2 <= kRefineTol2 * fabs(pu)) {
         ok = true;
         break;

@@ -58,13 +58,15 @@ int launch_c(mm_ctx* ctx, int dim, const ConArgs& a, int which, double* h_out) {
 }
 
 int launch(mm_ctx* ctx, const mm_model* m, const ConArgs& a, int which, double* h_out = nullptr) {
-  if (m->rtc_con_module) {  // user constraint / target: the core compiled around the user's source (mm_rtc.hip)
-    ConArgs copy = a;
-    return mm_rtc_launch_constrained(ctx, m, which, &copy, a.n_chains, h_out);
-  }
+  // (before the run-time compiled branch: a user constraint on the built-in funnel target would run the core with an
+  // empty TargetAux - a silently wrong gradient; mm_model_create refuses the combination as well)
   if (m->target == MM_TARGET_FUNNEL) {
     mm_set_error(ctx, "constrained kernels: the funnel target needs a wave-collective gradient");
     return MM_ERR_UNSUPPORTED;
+  }
+  if (m->rtc_con_module) {  // user constraint / target: the core compiled around the user's source (mm_rtc.hip)
+    ConArgs copy = a;
+    return mm_rtc_launch_constrained(ctx, m, which, &copy, a.n_chains, h_out);
   }
   // exact register-resident kernels: D <= 8 with C <= 3.  Beyond: the step of a plain (dens_wrt_hausdorff, no Gaussian
   // split) system with a built-in constraint runs one wave per chain (k_constrained_wave.hip); everything else up to

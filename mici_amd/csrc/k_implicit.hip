@@ -259,7 +259,7 @@ int mm_launch_riemann_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, d
 
 #ifdef MM_DEV_KERNELS
 // developer hook (tools/ubench_primitives.py): time `repeats` repetitions of one primitive per chain
-extern "C" int mm_debug_primitive_bench(mm_ctx* ctx, const mm_model* m, mm_state* s, int variant,
+extern "C" __attribute__((visibility("default"))) int mm_debug_primitive_bench(mm_ctx* ctx, const mm_model* m, mm_state* s, int variant,
                                         int repeats, double* ms) {
   if (!ctx || !m || !s || m->dim > 64 || m->dim <= 32 || m->rmetric != MM_RMETRIC_RANK1) return MM_ERR_INVALID;
   ImplicitArgs a = make_args(m, s);

@@ -1227,7 +1227,7 @@ int mm_launch_implicit_blk16(mm_ctx* ctx, const mm_model* m, mm_state* s, double
 #ifdef MM_DEV_KERNELS
 // developer / test hook (tests/test_gpu_blk16.py): see blk16_debug_kernel.  out is a HOST buffer of
 // N * 256 * 256 (op 0) or N * 256 (op 1, 2) doubles; status[N] (host, may be NULL) receives 0 / 5 per chain.
-extern "C" int mm_debug_blk16_linalg(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* out,
+extern "C" __attribute__((visibility("default"))) int mm_debug_blk16_linalg(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* out,
                                      int32_t* status, int reps, double* ms) {
   if (!ctx || !m || !s || !out || op < 0 || op > 16 || m->rmetric == MM_RMETRIC_NONE ||
       m->rmetric == MM_RMETRIC_SOFTABS)
@@ -1289,7 +1289,7 @@ extern "C" int mm_debug_blk16_linalg(mm_ctx* ctx, const mm_model* m, mm_state* s
 
 // developer hook (tools/ubench_blk16.py): mm_implicit_leapfrog on the block-16 kernel with the phase clocks on;
 // out is a HOST buffer of N * 8 doubles: cycles of chain i spent in the phases PH_* of implicit_core.h
-extern "C" int mm_debug_blk16_step_profile(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+extern "C" __attribute__((visibility("default"))) int mm_debug_blk16_step_profile(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
                                            const mm_fp_opts* opts, double* out) {
   if (!ctx || !m || !s || !opts || !out || m->rmetric != MM_RMETRIC_RANK1) return MM_ERR_INVALID;
   MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));

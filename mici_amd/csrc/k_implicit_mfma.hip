@@ -704,7 +704,7 @@ int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
 
 #ifdef MM_DEV_KERNELS
 // developer hook: cycles of {build, sweep, mat-vec, grad, norm, M(x) v} into out[0..5]
-extern "C" int mm_debug_mfma_profile(mm_ctx* ctx, const mm_model* m, mm_state* s, int repeats, double* out) {
+extern "C" __attribute__((visibility("default"))) int mm_debug_mfma_profile(mm_ctx* ctx, const mm_model* m, mm_state* s, int repeats, double* out) {
   if (!ctx || !m || !s || m->dim > 64 || m->rmetric != MM_RMETRIC_RANK1) return MM_ERR_INVALID;
   ImplicitArgs a{};
   a.pos = s->d_pos;
@@ -729,7 +729,7 @@ extern "C" int mm_debug_mfma_profile(mm_ctx* ctx, const mm_model* m, mm_state* s
 
 // developer hook (tools/ubench_primitives.py): mm_implicit_leapfrog on this kernel with the phase clocks on; out is a
 // HOST buffer of N * 8 doubles: cycles of chain i spent in the phases PH_* of implicit_core.h
-extern "C" int mm_debug_mfma_step_profile(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+extern "C" __attribute__((visibility("default"))) int mm_debug_mfma_step_profile(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
                                           const mm_fp_opts* opts, double* out) {
   if (!ctx || !m || !s || !opts || !out || m->dim > 64 || m->rmetric != MM_RMETRIC_RANK1) return MM_ERR_INVALID;
   MM_HIP_CHECK(ctx, hipSetDevice(ctx->device));

@@ -327,6 +327,11 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
   MM_REQUIRE(ctx, d->target != MM_TARGET_FUNNEL || d->rmetric == MM_RMETRIC_NONE ||
                       d->rmetric == MM_RMETRIC_SOFTABS,
              "mm_model_create: the funnel target pairs with a fixed metric or the SoftAbs metric");
+  if (d->target == MM_TARGET_FUNNEL && d->constr != MM_CONSTR_NONE) {  // (built-in and user constraints alike)
+    mm_set_error(ctx, "mm_model_create: the funnel target is not available on constrained systems (its gradient is a "
+                      "wave-collective the lane-per-chain constrained core does not form)");
+    return MM_ERR_UNSUPPORTED;
+  }
   MM_REQUIRE(ctx, d->gaussian_split == 0 || d->gaussian_split == 1, "mm_model_create: gaussian_split must be 0 or 1");
   MM_REQUIRE(ctx, !d->gaussian_split || d->rmetric == MM_RMETRIC_NONE,
              "mm_model_create: the Gaussian split is defined for fixed-metric systems only");
@@ -663,6 +668,10 @@ int mm_state_copy(mm_state* dst, const mm_state* src) {
       dst->eig_bytes = src->eig_bytes;
     }
     MM_HIP_CHECK(ctx, hipMemcpyAsync(dst->d_eig, src->d_eig, src->eig_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  } else if (dst->d_eig) {
+    // the source carries no bases: the copy must not keep the ones of whatever positions it held before (zero = "no
+    // basis yet", as ensure_eig leaves a fresh buffer)
+    MM_HIP_CHECK(ctx, hipMemsetAsync(dst->d_eig, 0, dst->eig_bytes, ctx->stream));
   }
   if (src->d_step_scale) {  // the copy integrates with the same per-chain step sizes
     if (!dst->d_step_scale) MM_HIP_CHECK(ctx, hipMalloc(&dst->d_step_scale, n * sizeof(double)));

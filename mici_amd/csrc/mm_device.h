@@ -84,8 +84,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ldexp + class tests around v_rsq): 12-18 dependent instructions each, and the lane-per-chain kernels are bound by
 // exactly that - the length of one wave's dependent FP64 stream.  These versions are Newton iterations on v_rcp_f64 /
 // v_rsq_f64 with a final residual correction: results within 1 ulp for normal, non-extreme arguments; zero, infinite
-// and NaN arguments give inf / NaN as the expansions would (possibly a NaN where IEEE gives inf or 0 - every caller
-// treats both as "not finite"); subnormal arguments are NOT handled (nothing on this path produces them).
+// and NaN arguments of rcp_nr / fdiv give inf / NaN as the expansions would (possibly a NaN where IEEE gives inf or 0 -
+// every caller treats both as "not finite").  sqrt_rsqrt takes x >= 0 (sums of squares; the Gram value of one
+// constraint behind its positivity check) or NaN: sqrt(0) = 0 exactly (the torus constraint at x = y = 0 is
+// finite in the reference), with 1 / sqrt(0) a huge finite number instead of inf; x = inf gives NaN for both.
 __device__ __forceinline__ double rcp_nr(double x) {
   double r = __builtin_amdgcn_rcp(x);
   double e = __builtin_fma(-x, r, 1.0);
@@ -100,7 +102,9 @@ __device__ __forceinline__ double fdiv(double a, double b) {
 }
 // s = sqrt(x) and rs = 1 / sqrt(x) from one v_rsq_f64 (Goldschmidt, two steps + a residual correction of s)
 __device__ __forceinline__ void sqrt_rsqrt(double x, double* s, double* rs) {
-  const double y = __builtin_amdgcn_rsq(x);
+  // rsq(0) = inf would turn g = x y into NaN: clamped (one v_min_f64; every finite x > 0 has rsq(x) < 1e162), x = 0
+  // runs through the iteration as g = 0 exactly
+  const double y = __builtin_fmin(__builtin_amdgcn_rsq(x), 1e300);
   double g = x * y, h = 0.5 * y;
   double r = __builtin_fma(-h, g, 0.5);
   g = __builtin_fma(g, r, g);

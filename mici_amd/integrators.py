@@ -94,7 +94,11 @@ class Integrator:
         box, the two transfer calls used to add 17 us)."""
         self._check_step_size()
         ctx = default_context()
-        pos = state.pos
+        # (the mapped views below take whatever broadcasts: a scalar or length-1 pos / mom would fill the whole vector)
+        pos = np.asarray(state.pos, dtype=np.float64)
+        mom = np.asarray(state.mom, dtype=np.float64)
+        if pos.ndim != 1 or mom.shape != pos.shape:
+            raise ValueError("state.pos and state.mom must be vectors of the same length")
         dim = pos.shape[0]
         batch = self._one.get(ctx)
         if batch is None or batch.dim != dim:
@@ -104,7 +108,7 @@ class Integrator:
         if d != 1 and d != -1:
             raise ValueError("dir entries must be +1 or -1")
         vq[0] = pos
-        vp[0] = state.mom
+        vp[0] = mom
         vd[0] = d
         self.step_device(batch, 1, ctx)
         ctx.sync()

@@ -120,9 +120,13 @@ class System:
             batch = self._one.put(ctx, DeviceBatch(ctx, 1, self.dim, mapped=True))
             batch.keep = True
         vq, vp, _, _, _ = batch.mapped_views()
-        pos = np.asarray(pos)
+        pos = np.asarray(pos, dtype=np.float64)
         if pos.shape != (self.dim,):
             raise ValueError(f"pos must have shape [{self.dim}]")
+        if mom is not None:
+            mom = np.asarray(mom, dtype=np.float64)
+            if mom.shape != (self.dim,):  # (an assignment into the mapped view would broadcast a scalar silently)
+                raise ValueError(f"mom must have shape [{self.dim}]")
         ctx.sync()  # nothing may still be reading the buffer
         vq[0] = pos
         if mom is not None:

@@ -110,6 +110,44 @@ def test_riemannian_full_shard_matches_oracle_and_is_reversible(config, steps, t
     assert np.array_equal(q, q2) and np.array_equal(p, p2)
 
 
+@pytest.mark.parametrize("config,tol,per_group", [
+    ("c3", 1e-10, 4),    # 100 steps: 29 CG refinements per step start from the previous step's solutions
+    ("c4", 1e-10, 1),    # 50 steps
+    ("c3b", 2e-9, 1),    # 100 steps: the eigenbasis and its two snapshots live across steps
+])
+def test_riemannian_bench_length_trajectory_matches_oracle(config, tol, per_group):
+    """the trajectory bench.py times - 100 / 50 / 100 fused steps on the whole 1024-chain shard - against
+    the oracle on chains of the first and the last workgroup (+ one in between).  State that lives across steps and
+    launches (the refinement's starting guesses, the SoftAbs eigenbasis and its snapshots) only shows at this length."""
+    n = 1024
+    w, osys = _workload(config, n)
+    steps = w["traj"]
+    assert steps == {"c3": 100, "c4": 50, "c3b": 100}[config]
+    integ = w["integ"]
+    q, p, status, n_done = integ.step_batch(w["q0"], w["p0"], 1, n_steps=steps)
+    counters = dict(integ.last_counters)
+    assert np.all(status == 0), np.flatnonzero(status)[:10]
+    assert np.all(n_done == steps)
+    sample = np.unique(np.concatenate([np.arange(per_group), np.arange(n - per_group, n), [n // 2 + 1]]))
+    if len(sample) < 4:
+        sample = np.unique(np.concatenate([sample, [1]]))
+    assert len(sample) >= 4
+    for c in sample:
+        qo, po, so, no = orc.implicit_leapfrog_steps(osys, w["q0"][c], w["p0"][c], w["h"], steps)
+        assert so == 0 and no == steps
+        assert_close(q[c], qo, tol, f"{config} q chain {c} after {steps} steps")
+        assert_close(p[c], po, tol, f"{config} p chain {c} after {steps} steps")
+    assert counters["n_fp_solves"] == 4 * n * steps
+    # the same chains alone, one launch per 10 steps: carried state (bases, guesses) must not change the result
+    sub = sample[:4]
+    qs, ps = w["q0"][sub].copy(), w["p0"][sub].copy()
+    for _ in range(steps // 10):
+        qs, ps, ss, ns = integ.step_batch(qs, ps, 1, n_steps=10)
+        assert np.all(ss == 0) and np.all(ns == 10)
+    assert_close(qs, q[sub], tol, f"{config} q, {steps // 10} launches of 10 steps vs one of {steps}")
+    assert_close(ps, p[sub], tol, f"{config} p, {steps // 10} launches of 10 steps vs one of {steps}")
+
+
 def test_c5_full_shard_trajectory():
     """c5 shard: torus, 2048 chains x 1000 steps in one launch; the oracle on a sample at 100 steps (the chaotic
     torus dynamics amplify solver-level differences beyond that), residuals and status on all chains at 1000."""

@@ -173,6 +173,11 @@ def test_user_constraint_errors_fail_loudly():
     with pytest.raises(DeviceError, match="n_constr"):  # as many constraints as dimensions
         systems.DenseConstrainedEuclideanMetricSystem(
             models.Poly(2, 0.5, 0.25), models.UserConstraint(2, ELLIPSOID_SADDLE, np.ones(3))).device_model()
+    # the built-in funnel target has no gradient inside the constrained core; a user constraint (whose
+    # run-time compiled kernels were reached before the built-in refusal) must be refused too: rc = MM_ERR_UNSUPPORTED
+    for con in (models.UserConstraint(2, ELLIPSOID_SADDLE, np.ones(6)), models.SphereConstr()):
+        with pytest.raises(DeviceError, match=r"rc=-3.*funnel"):
+            systems.DenseConstrainedEuclideanMetricSystem(models.Funnel(np.linspace(0.5, 2.0, 4)), con).device_model()
 
 
 def test_device_transitions_run_on_a_user_constraint():

@@ -548,8 +548,13 @@ def main():
         add_riemann(f"riemann_diagquad_poly_d{size}", mdl.Poly(size, 1.0, 1.0 / 3.0),
                     mdl.DiagQuadMetric(size), None, 5, 0.1, [1, 5, 20])
     B256 = mdl.make_spd(256, rng)
-    add_riemann("riemann_c4_rank1_banana_d256", mdl.Banana(256), mdl.Rank1Metric(B256), None, 2,
-                0.01, [1, 3])
+    # round 4: 8 chains x 10 steps instead of 2 x 3.  The base matrix keeps its place in the shared
+    # stream; the two (2, 256) draws the round-1 case took from it are still consumed, so every later round-1 case keeps
+    # its inputs, and the new chains come from the case's own stream.
+    rng.standard_normal((2, 256))
+    rng.standard_normal((2, 256))
+    add_riemann("riemann_c4_rank1_banana_d256", mdl.Banana(256), mdl.Rank1Metric(B256), None, 8,
+                0.01, [1, 3, 10], r=case_rng("riemann_c4_rank1_banana_d256"))
     # failure paths: large steps / tiny iteration budgets
     add_riemann("riemann_fail_bigstep_d8", mdl.Poly(8, 1.0, 1.0 / 3.0), mdl.Rank1Metric(B8), None,
                 8, 1.5, [1, 4], qscale=2.0)

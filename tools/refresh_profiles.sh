@@ -4,7 +4,7 @@
 #     bash tools/refresh_profiles.sh collect
 # on the build host copies the summaries into profiles/ with the round prefix.
 #     gpurun --timeout 1700 -- 'bash tools/refresh_profiles.sh'
-# What it produces (ROUND=r03 by default):
+# What it produces (ROUND=r04 by default):
 #   <round>_gpu_tests.txt                 tail of `pytest -m gpu`
 #   <round>_bench_default.json            the exact default command, `python bench.py`
 #   <round>_rocprofv3_kernel_stats.csv    `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline`
@@ -12,8 +12,8 @@
 #   <round>_<cfg>_sq_counters.json        SQ counters (two passes) - c2 c3 c3b c4 c5
 #   <round>_c4_ubench_blk16.txt, <round>_c3_ubench_mfma.txt   phase clocks of the two dense-Riemannian kernels
 #   <round>_fuzz_parity.txt               tools/fuzz_parity.py, three seeds x 80 cases + 60 long SoftAbs cases
-#   <round>_c2iv_regimes.txt              c2(iv) launched five times in fresh processes: pass time vs kernel time, every timed region
-ROUND=${ROUND:-r03}
+#   <round>_host_latency.txt              tools/host_latency.py in three fresh processes (single-state Integrator.step, step_batch, system.h)
+ROUND=${ROUND:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 if [ "$1" = "collect" ]; then
   src=$ROOT/gpurun_out/${ROUND}p
@@ -74,10 +74,7 @@ grep "MISMATCH\|Traceback\|refused" -B2 $O/fuzz_51.log | head -10 >> $O/fuzz_par
 rm -f $O/fuzz_51.log
 cat $O/fuzz_parity.txt
 
-# c2(iv): five fresh processes - wall-clock per pass against the HIP-event kernel time of the same pass
-for i in 1 2 3 4 5; do
-  python bench.py --config c2iv --no-cpu-baseline --no-extra-configs 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.readline()); print('run $i: ms_per_pass %.3f  kernel_ms_per_launch %.3f  timed regions (ms per pass): %s' % (d['ms_per_step'], d['roofline']['kernel_ms_per_launch'], ' '.join('%.3f' % a['ms_per_step'] for a in d['roofline']['attempts'])))" >> $O/c2iv_regimes.txt
-done
-cat $O/c2iv_regimes.txt
+# host-call latency of the reference's calling pattern (one Integrator.step(state) per step), three fresh processes
+for i in 1 2 3; do python tools/host_latency.py 2>&1 | sed "s/^/run $i: /" >> $O/host_latency.txt; done
+grep "single-state" $O/host_latency.txt
 du -sh $O
