@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - leapfrog-steps/sec (all chains) of the MI355X integrator hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2iv|c2bcss|c3|c3b|c4|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2iv|c2bcss|c3|c3b|c4|c5|c3_user|c4_general]
                     [--traj-len L] [--chains-per-gpu M] [--no-extra-configs] [--no-cpu-baseline]
 
 Contract (driver): W untimed warm-up passes, then EXACTLY K timed passes bracketed by a barrier +
@@ -150,15 +150,33 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
                     traj=traj, integ=integ, system=system, make_oracle=make_oracle, q0=q0, p0=p0,
                     bytes_per_chain_step=32.0 * dim, flops_per_chain_step=flops, valu_executed_flops_per_chain_step=exec_flops,
                     bound="hbm" if config == "c2i" else "mfma", kind="euclid")
-    if config in ("c3", "c4"):
-        dim, h, traj = (64, 0.02, 100) if config == "c3" else (256, 0.01, 50)
-        base = _make_spd(dim, rng)
-        system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(base))
+    if config in ("c3", "c4", "c3_user", "c4_general"):
+        # c3_user / c4_general (VERDICT r03 #1c): the GENERAL dense-Riemannian path - the metric reaches the library as user
+        # source (mici_amd/user_examples.py), compiled around the matrix-core kernels at run time.  c3_user: a metric that
+        # is not built in (softplus diagonal + rank one, D = 64); c4_general: the c4 workload itself with its rank-one
+        # metric handed over as user source (D = 256) - M(x) v of the refinement solves from the user's entries.
+        dim, h, traj = (64, 0.02, 100) if config in ("c3", "c3_user") else (256, 0.01, 50)
+        if config == "c3_user":
+            from mici_amd import user_examples
+            cvec = 0.5 * rng.standard_normal(dim)
+            rmetric = models.UserMetric(dim, user_examples.SOFTPLUS_RANK1_FAST, cvec)
+            mname = "softplus-diagonal + rank-one metric as USER SOURCE (hipRTC, MM_USER_AUX + MM_USER_VJP_FLAT)"
+        else:
+            base = _make_spd(dim, rng)
+            if config == "c4_general":
+                from mici_amd import user_examples
+                rmetric = models.UserMetric(dim, user_examples.RANK1_AS_USER_FLAT, base)
+                mname = "rank-one-update dense metric as USER SOURCE (hipRTC, MM_USER_VJP_FLAT)"
+            else:
+                rmetric = models.Rank1Metric(base)
+                mname = "rank-one-update dense metric"
+        system = systems.DenseRiemannianMetricSystem(models.Banana(dim), rmetric)
 
         def make_oracle():
             from oracle import integrators as orc
             from oracle import models as omdl
-            return orc.RiemannianSystem(omdl.Banana(dim), omdl.Rank1Metric(base))
+            return orc.RiemannianSystem(omdl.Banana(dim), omdl.SoftPlusRank1Metric(cvec) if config == "c3_user"
+                                        else omdl.Rank1Metric(base))
 
         integ = integrators.ImplicitLeapfrogIntegrator(system, h)
         q0 = crng.standard_normal((n_chains, dim))
@@ -166,7 +184,7 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
         p0 = system.sample_momentum_batch(q0, z) if device else _oracle_momenta("riemann", make_oracle(), q0, z)
         mom = None if device else p0
         p0 = p0 if device else mom.p0
-        return dict(name=f"{config}(a) DenseRiemannianMetricSystem (rank-one-update dense metric, banana "
+        return dict(name=f"{config if '_' in config else config + '(a)'} DenseRiemannianMetricSystem ({mname}, banana "
                          "target) + ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
                     system=system, make_oracle=make_oracle, q0=q0, p0=p0, momenta=mom, bytes_per_chain_step=32.0 * dim,
                     flops_per_chain_step=None, bound="mfma", kind="riemann")
@@ -226,14 +244,16 @@ def _sweep_mfma_counts(dim):
     return None
 
 
-DEFAULT_CHAINS = {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048}  # per GPU; everything else 4096
-EXTRA_CONFIGS = ("c2i", "c2iv", "c3", "c3b", "c4", "c5")
+DEFAULT_CHAINS = {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048, "c3_user": 1024, "c4_general": 1024}  # per GPU; else 4096
+EXTRA_CONFIGS = ("c2i", "c2iv", "c3", "c3b", "c4", "c5", "c3_user", "c4_general")
 # pass counts of the extra configs are capped (a c3(b) pass is ~1 s, a c4 pass ~0.1-0.3 s)
-EXTRA_STEP_CAP = {"c3b": 5, "c4": 10}
+EXTRA_STEP_CAP = {"c3b": 5, "c4": 10, "c4_general": 10}
 BASELINE_CONFIG = {"c2": "BASELINE.json configs[1]", "c2i": "BASELINE.json configs[1] (iso-Gaussian variant, SURVEY 8d c2(i))",
                    "c2iv": "BASELINE.json configs[1] (dense-metric variant, SURVEY 8d c2(iv))",
                    "c3": "BASELINE.json configs[2] (Cholesky path)", "c3b": "BASELINE.json configs[2] (SoftAbs path)",
-                   "c4": "BASELINE.json configs[3] (per-GPU shard)", "c5": "BASELINE.json configs[4] (per-GPU shard)"}
+                   "c4": "BASELINE.json configs[3] (per-GPU shard)", "c5": "BASELINE.json configs[4] (per-GPU shard)",
+                   "c3_user": "BASELINE.json configs[2] sizes, a metric_func that is not built in (user source)",
+                   "c4_general": "BASELINE.json configs[3] (per-GPU shard), its metric_func handed over as user source"}
 
 
 # ---- CPU baseline: the oracle on this box's host cores ------------

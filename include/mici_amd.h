@@ -74,7 +74,7 @@ typedef enum mm_rmetric { /* position-dependent metric of a RiemannianMetricSyst
   MM_RMETRIC_RANK1 = 1,    /* M(q) = B + q q^T / D, params B[D*D]; DenseRiemannianMetricSystem     */
   MM_RMETRIC_DIAGQUAD = 2, /* M(q) = diag(1 + q^2) held dense;     DenseRiemannianMetricSystem     */
   MM_RMETRIC_SOFTABS = 3,  /* SoftAbs of the target Hessian, params coeff; SoftAbsRiemannianMetricSystem */
-  MM_RMETRIC_USER = 100    /* user-supplied device code: mm_model_create_from_source, dim <= 64, params: any */
+  MM_RMETRIC_USER = 100    /* user-supplied device code: mm_model_create_from_source, dim <= 279, params: any */
 } mm_rmetric;
 
 typedef enum mm_constr { /* holonomic constraint, C = 1 */
@@ -215,13 +215,20 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* desc, mm_model** out);
  *    mm_momentum_refresh* and mm_metropolis_accept* work on such a model.  Target and constraint may both be user code
  *    (one source text defining all the functions).
  *  * desc->rmetric == MM_RMETRIC_USER - `metric_func` / `vjp_metric_func` of a DenseRiemannianMetricSystem
- *    (systems.py:1322-1358), dim <= 64 (the wave-per-chain kernels: the metric of a chain in one wave's registers):
+ *    (systems.py:1322-1358, 1690-1734), dim <= 279:
  *        __device__ double mm_user_metric(const double* q, int i, int j, int dim, const double* params);  // M(q)_ij
  *        __device__ double mm_user_vjp(const double* q, const MmMat& V, int k, int dim, const double* params);
  *        // element k of vjp_metric_func(q)(V) = sum_ij V(i, j) d M_ij / d q_k;  V(i, j) reads the symmetric argument
- *    (params: desc->rmetric_params).  mm_implicit_leapfrog, mm_implicit_midpoint, mm_hamiltonian, mm_dh_dmom,
- *    mm_sample_momentum, mm_momentum_refresh* and mm_metropolis_accept* work on such a model; the target may be
- *    built in or user code as well. */
+ *    (params: desc->rmetric_params).  The text may opt into `#define MM_USER_AUX n` + mm_user_prepare (per-point
+ *    precomputation shared by all entries) and `#define MM_USER_VJP_FLAT` + mm_user_vjp_flat (the vector-Jacobian
+ *    product in team form, running on the backend's own mat-vec): csrc/user_metric.h states both protocols.  The
+ *    library compiles its dense-Riemannian backends around the text: the leapfrog step on the matrix-core kernels
+ *    (32 < dim <= 64 one wave per chain, 75 < dim <= 256 one workgroup per chain; compiled on first use) with the
+ *    solve-only metric constructions refined through M(x) v products of the user's entries, everything else on the
+ *    wave (dim <= 64) / team (dim <= 279) kernels.  mm_implicit_leapfrog, mm_implicit_midpoint, mm_hamiltonian,
+ *    mm_dh_dmom, mm_sample_momentum, mm_momentum_refresh* and mm_metropolis_accept* work on such a model; the target
+ *    may be built in or user code as well.  Compiled code objects are cached under MICI_AMD_RTC_CACHE (default
+ *    ~/.cache/mici_amd/rtc; "off" disables). */
 int mm_model_create_from_source(mm_ctx* ctx, const mm_model_desc* desc, const char* hip_source, mm_model** out);
 int mm_model_destroy(mm_model* model);
 

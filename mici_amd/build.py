@@ -67,15 +67,36 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
+def _deps_time(path, seen=None):
+    """Newest modification time of `path` and of everything it #includes with quotes, recursively (csrc/ and include/)."""
+    import re
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return 0.0
+    seen.add(path)
+    t = os.path.getmtime(path)
+    with open(path, encoding="utf-8") as f:
+        text = f.read()
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        for base in (os.path.dirname(path), CSRC, os.path.join(HERE, "..", "include")):
+            cand = os.path.join(base, inc)
+            if os.path.exists(cand):
+                t = max(t, _deps_time(cand, seen))
+                break
+    return t
+
+
 def _compile_and_link(sources, objdir, lib, extra, headers_time, force, jobs, verbose, reuse=None):
-    """Objects of `sources` into `objdir` (flags + extra), linked with the objects of `reuse` into `lib`."""
+    """Objects of `sources` into `objdir` (flags + extra), linked with the objects of `reuse` into `lib`.  An object is
+    rebuilt when its source or a header it includes (recursively) is newer, or when this script is."""
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
     todo, objs = [], []
     for src in sources:
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), headers_time):
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(_deps_time(src), headers_time):
             todo.append((src, obj))
 
     def compile_one(pair):
@@ -110,7 +131,8 @@ def _compile_and_link(sources, objdir, lib, extra, headers_time, force, jobs, ve
     return objs
 
 
-RTC_HEADERS = ["constrained_core.h", "implicit_wave.h", "implicit_core.h", "mm_device.h",
+RTC_HEADERS = ["constrained_core.h", "implicit_wave.h", "implicit_mfma.h", "implicit_blk16.h", "implicit_team.h",
+               "user_metric.h", "implicit_core.h", "mm_device.h",
                os.path.join("..", "..", "include", "mici_amd.h")]
 RTC_GEN = os.path.join(CSRC, "rtc_headers_gen.inc")
 
@@ -145,9 +167,7 @@ def build(force=False, jobs=None, verbose=True, dev=True):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     gen_rtc_headers()
     sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(
-        os.path.join(HERE, "..", "include", "*.h"))
-    hdr_time = _newest(headers)
+    hdr_time = os.path.getmtime(os.path.abspath(__file__))  # the flags live here; headers are tracked per source
     objs = _compile_and_link(sources, OBJ, LIB, [], hdr_time, force, jobs, verbose)
     if dev:
         def has_dev(path):

@@ -51,6 +51,8 @@ struct ImplicitArgs {
   double* out;
   const double* z;
   int no_refine;  // 1: factorise every metric construction (MICI_AMD_REFINE=0: A/B runs against section 4.3c of DESIGN.md)
+  double* work;   // user metrics with the dense-accessor VJP beyond the wave kernels: [n_chains][NP * NP] doubles of global
+                  // memory the held inverse is dumped to (user_metric.h), NP the backend's padded dimension
 };
 
 // MICI_AMD_REFINE=0 in the environment switches the refinement of the solve-only constructions off (read once)

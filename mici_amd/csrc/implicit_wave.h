@@ -4,21 +4,7 @@
 #pragma once
 #include "implicit_core.h"
 
-#if defined(MM_RTC_BUILD) && defined(MM_RTC_USER_METRIC)
-// A symmetric D x D matrix handed to the user's vector-Jacobian product: V(i, j).  Either an explicit matrix in LDS
-// (the inverse metric: grad_log_abs_det, matrices.py:1175-1177) or the rank-one -u u^T (grad_quadratic_form_inv,
-// matrices.py:1179-1181).
-struct MmMat {
-  const double* a;  // explicit: a[i * ld + j]; nullptr for the rank-one form
-  const double* u;
-  int ld;
-  __device__ __forceinline__ double operator()(int i, int j) const { return a ? a[i * ld + j] : -(u[i] * u[j]); }
-};
-// entry (i, j) of metric_func(q)  (symmetric; q: the chain's whole position vector, params: desc->rmetric_params)
-__device__ double mm_user_metric(const double* q, int i, int j, int dim, const double* params);
-// element k of vjp_metric_func(q)(V) = sum_ij V(i, j) d metric_ij / d q_k
-__device__ double mm_user_vjp(const double* q, const MmMat& V, int k, int dim, const double* params);
-#endif
+#include "user_metric.h"
 
 namespace mmwave {
 
@@ -38,7 +24,12 @@ struct WaveLds {
   double* vout; // mat-vec output (permuted order)
   double* nat;  // natural-order vector for target derivatives
   double* aux;  // natural-order spare (z for sample_momentum)
-  double* mat;  // user metrics only: a dense DP x DP matrix (the inverse metric as the user's VJP reads it)
+  double* mat;  // user metrics with the dense-accessor VJP only: a DP x DP matrix (the inverse as the user's VJP reads it)
+  // user metrics (user_metric.h): the point of the held inverse / of the refinement products in natural order, their aux
+  double* uq;
+  double* ux;
+  double* uaq;
+  double* uax;
 };
 
 template <int TS>
@@ -52,12 +43,27 @@ struct Geo {
 // per-wave LDS: 5 vectors of 64, the step's slots, the column block of the back substitution; a user metric adds a
 // dense DP x DP matrix
 template <int TS, int RMETRIC>
+__host__ __device__ constexpr int wave_mat_doubles() {
+  return (RMETRIC == MM_RMETRIC_USER && !mmuser::kFlatVjp) ? Geo<TS>::DP * Geo<TS>::DP : 0;
+}
+template <int TS, int RMETRIC>
 __host__ __device__ constexpr int wave_lds_doubles() {
-  return kWaveLdsDoubles + (RMETRIC == MM_RMETRIC_USER ? Geo<TS>::DP * Geo<TS>::DP : 0);
+  return kWaveLdsDoubles + wave_mat_doubles<TS, RMETRIC>() + (RMETRIC == MM_RMETRIC_USER ? mmuser::lds_doubles(64) : 0);
 }
 template <int TS, int RMETRIC>
 __device__ __forceinline__ WaveLds make_wave_lds(double* wl) {
-  return WaveLds{wl, wl + 64, wl + 128, wl + 192, wl + 256, RMETRIC == MM_RMETRIC_USER ? wl + kWaveLdsDoubles : nullptr};
+  WaveLds w{wl, wl + 64, wl + 128, wl + 192, wl + 256, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if constexpr (RMETRIC == MM_RMETRIC_USER) {
+    double* p = wl + kWaveLdsDoubles;
+    w.mat = wave_mat_doubles<TS, RMETRIC>() ? p : nullptr;
+    p += wave_mat_doubles<TS, RMETRIC>();
+    constexpr int kA = (mmuser::kAux + 1) & ~1;
+    w.uq = p;
+    w.ux = p + 64;
+    w.uaq = p + 128;
+    w.uax = p + 128 + kA;
+  }
+  return w;
 }
 
 // ---- symmetric sweep: T <- M^-1, returns false if a pivot is not > 0 (== Cholesky would fail) ------
@@ -239,7 +245,11 @@ __device__ __forceinline__ bool build_metric(double (&T)[TS][TS], double q, int 
                                              const WaveLds& w, const double* base_lds) {
   const int ti = lane >> 3, tj = lane & 7;
   if (lane < Geo<TS>::DP) w.vin[Geo<TS>::pos(lane)] = q;
-  if constexpr (RMETRIC == MM_RMETRIC_USER) w.nat[lane] = (lane < dim) ? q : 0.0;
+  if constexpr (RMETRIC == MM_RMETRIC_USER) {  // the point in natural order for the user's hooks, then its aux block
+    w.uq[lane] = (lane < dim) ? q : 0.0;
+    wave_sync();
+    mmuser::prepare(w.uq, dim, base_lds, w.uaq, lane, 64);
+  }
   wave_sync();
   double qr[TS], qc[TS];
 #pragma unroll
@@ -259,13 +269,9 @@ __device__ __forceinline__ bool build_metric(double (&T)[TS][TS], double q, int 
       if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
         v = base_lds[lane * Geo<TS>::TSTRIDE + a * TS + b] + (qr[a] * qc[b]) * inv_d;
       } else if constexpr (RMETRIC == MM_RMETRIC_USER) {
-#if defined(MM_RTC_BUILD) && defined(MM_RTC_USER_METRIC)
-        // the user's metric_func, entry by entry (w.nat holds q in natural order; base_lds is the params pointer)
+        // the user's metric_func, entry by entry (w.uq holds q in natural order; base_lds is the params pointer)
         const int i = ti + 8 * a, j = tj + 8 * b;
-        v = (i < dim && j < dim) ? ::mm_user_metric(w.nat, i, j, dim, base_lds) : 0.0;
-#else
-        v = 0.0;
-#endif
+        v = mmuser::entry_padded(w.uq, i, j, dim, base_lds, w.uaq);
       } else {  // MM_RMETRIC_DIAGQUAD: only diagonal lanes / diagonal tile entries are non-zero
         v = 0.0;
       }
@@ -296,24 +302,6 @@ __device__ __forceinline__ double half_vjp_tiles(const double (&V)[TS][TS], doub
                                                  int lane, const WaveLds& w, const double* uparams = nullptr) {
   if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
     return matvec_flat<TS>(V, q, lane, w) / (double)dim;
-  } else if constexpr (RMETRIC == MM_RMETRIC_USER) {
-#if defined(MM_RTC_BUILD) && defined(MM_RTC_USER_METRIC)
-    // the user's vjp_metric_func on the explicit matrix: the tiles go to LDS as a dense DP x DP array, lane k
-    // evaluates element k
-    const int ti = lane >> 3, tj = lane & 7;
-#pragma unroll
-    for (int a = 0; a < TS; ++a)
-#pragma unroll
-      for (int b = 0; b < TS; ++b) w.mat[(ti + 8 * a) * Geo<TS>::DP + tj + 8 * b] = V[a][b];
-    w.nat[lane] = (lane < dim) ? q : 0.0;
-    wave_sync();
-    const MmMat vm{w.mat, nullptr, Geo<TS>::DP};
-    const double r = (lane < dim) ? 0.5 * ::mm_user_vjp(w.nat, vm, lane, dim, uparams) : 0.0;
-    wave_sync();
-    return r;
-#else
-    return 0.0;
-#endif
   } else {
     return q * diag_flat<TS>(V, lane, w);
   }
@@ -326,18 +314,6 @@ __device__ __forceinline__ double half_vjp_neg_outer(double u, double q, int dim
   if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
     const double uq = wave_sum(lane < dim ? u * q : 0.0);
     return -(u * uq) / (double)dim;
-  } else if constexpr (RMETRIC == MM_RMETRIC_USER) {
-#if defined(MM_RTC_BUILD) && defined(MM_RTC_USER_METRIC)
-    w.nat[lane] = (lane < dim) ? q : 0.0;
-    w.aux[lane] = (lane < dim) ? u : 0.0;
-    wave_sync();
-    const MmMat vm{nullptr, w.aux, 0};
-    const double r = (lane < dim) ? 0.5 * ::mm_user_vjp(w.nat, vm, lane, dim, uparams) : 0.0;
-    wave_sync();
-    return r;
-#else
-    return 0.0;
-#endif
   } else {
     return -q * (u * u);
   }
@@ -378,9 +354,9 @@ struct WaveBackend {
   static constexpr bool kSolveByInverse = false;  // implicit_core.h: solve = invert + mat-vec, one construction site
   static constexpr bool kUnifiedConstruct = false;
   static constexpr bool kCountersInLds = false;
-  // implicit_core.h: solve-only constructions refined from the held inverse (built-in metrics: M(x) v has a closed form
-  // that needs no tiles; a user metric would re-evaluate its D^2 entries per product and keeps the factorisations)
-  static constexpr bool kRefine = RMETRIC != MM_RMETRIC_USER;
+  // implicit_core.h: solve-only constructions refined from the held inverse.  Built-in metrics: M(x) v has a closed form
+  // that needs no tiles; a user metric evaluates its TS x TS entries per product (cheap with MM_USER_AUX, user_metric.h)
+  static constexpr bool kRefine = true;
   bool refine_on;
   double T[TS][TS];
   int dim, lane, target;
@@ -413,9 +389,44 @@ struct WaveBackend {
     *sb = wave_sum(lane < dim ? b : 0.0);
   }
   __device__ __forceinline__ double sum1(double a) { return wave_sum(lane < dim ? a : 0.0); }
-  __device__ __forceinline__ void metric_point(double x) { xpt_ = (lane < dim) ? x : 0.0; }
+  __device__ __forceinline__ bool flat_active() const { return lane < dim; }
+  __device__ __forceinline__ double diag() { return diag_flat<TS>(T, lane, w); }
+  __device__ __forceinline__ void metric_point(double x) {
+    xpt_ = (lane < dim) ? x : 0.0;
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {  // the products' point in natural order and its aux block
+      w.ux[lane] = xpt_;
+      wave_sync();
+      mmuser::prepare(w.ux, dim, base_lds, w.uax, lane, 64);
+      wave_sync();
+    }
+  }
   __device__ __forceinline__ double metric_apply(double v) {
-    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {
+      // the user's metric_func at the point, entry by entry, contracted on the fly (matvec_flat's tile order)
+      const int ti = lane >> 3, tj = lane & 7;
+      if (lane < Geo<TS>::DP) w.vin[Geo<TS>::pos(lane)] = (lane < dim) ? v : 0.0;
+      wave_sync();
+      double part[TS];
+#pragma unroll
+      for (int a = 0; a < TS; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < TS; ++b) {
+          const int i = ti + 8 * a, j = tj + 8 * b;
+          const double m = mmuser::entry_padded(w.ux, i, j, dim, base_lds, w.uax);
+          s = __builtin_fma(m, w.vin[tj * TS + b], s);
+        }
+        part[a] = group8_sum(s);
+      }
+      if (tj == 0) {
+#pragma unroll
+        for (int a = 0; a < TS; ++a) w.vout[ti * TS + a] = part[a];
+      }
+      wave_sync();
+      const double y = (lane < Geo<TS>::DP) ? w.vout[Geo<TS>::pos(lane)] : 0.0;
+      wave_sync();
+      return lane < dim ? y : 0.0;
+    } else if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
       // B v (the staged base matrix has this lane's TS x TS entries in matvec_flat's tile order) + x (x . v) / D
       const int ti = lane >> 3, tj = lane & 7;
       if (lane < Geo<TS>::DP) w.vin[Geo<TS>::pos(lane)] = (lane < dim) ? v : 0.0;
@@ -442,13 +453,53 @@ struct WaveBackend {
       return lane < dim ? __builtin_fma(xpt_ * xpt_, v, v) : 0.0;
     }
   }
+  // 0.5 * vjp_metric_func(q)(V) of a user metric.  q is the point of the held inverse: build_metric() left it in w.uq
+  // (natural order) with its aux block in w.uaq.  OUTER: V = -u u^T, else the explicit inverse in the tiles.
+  template <bool OUTER>
+  __device__ __forceinline__ double user_half_vjp(double u) {
+    double r;
+    if constexpr (mmuser::kFlatVjp) {
+      if constexpr (OUTER) {
+        mmuser::VjpOpsOuter<WaveBackend> ops{*this, lane < dim ? u : 0.0};
+        r = mmuser::vjp_flat(ops, w.uq, lane, dim, base_lds, w.uaq);
+      } else {
+        mmuser::VjpOpsInv<WaveBackend> ops{*this};
+        r = mmuser::vjp_flat(ops, w.uq, lane, dim, base_lds, w.uaq);
+      }
+    } else {
+#if defined(MM_RTC_BUILD) && defined(MM_RTC_USER_METRIC)
+      if constexpr (OUTER) {
+        w.aux[lane] = (lane < dim) ? u : 0.0;
+        wave_sync();
+        const MmMat vm{nullptr, w.aux, 0};
+        r = (lane < dim) ? mmuser::vjp_dense(w.uq, vm, lane, dim, base_lds, w.uaq) : 0.0;
+      } else {
+        // the tiles go to LDS as a dense DP x DP array, lane k evaluates element k
+        const int ti = lane >> 3, tj = lane & 7;
+#pragma unroll
+        for (int a = 0; a < TS; ++a)
+#pragma unroll
+          for (int b = 0; b < TS; ++b) w.mat[(ti + 8 * a) * Geo<TS>::DP + tj + 8 * b] = T[a][b];
+        wave_sync();
+        const MmMat vm{w.mat, nullptr, Geo<TS>::DP};
+        r = (lane < dim) ? mmuser::vjp_dense(w.uq, vm, lane, dim, base_lds, w.uaq) : 0.0;
+      }
+      wave_sync();
+#else
+      r = 0.0;
+#endif
+    }
+    return lane < dim ? 0.5 * r : 0.0;
+  }
   __device__ __forceinline__ double half_vjp_inv(double q) {
-    return half_vjp_tiles<TS, RMETRIC>(T, q, dim, lane, w, base_lds);
+    if constexpr (RMETRIC == MM_RMETRIC_USER) return user_half_vjp<false>(0.0);
+    else return half_vjp_tiles<TS, RMETRIC>(T, q, dim, lane, w, base_lds);
   }
   // dense metric: grad_quadratic_form_inv(p) = -(M^-1 p)(M^-1 p)^T   (matrices.py:1179-1181)
   __device__ __forceinline__ double dh2_dpos(double p, double q) {
     const double u = matvec_flat<TS>(T, p, lane, w);
-    return half_vjp_neg_outer<RMETRIC>(u, q, dim, lane, w, base_lds);
+    if constexpr (RMETRIC == MM_RMETRIC_USER) return user_half_vjp<true>(u);
+    else return half_vjp_neg_outer<RMETRIC>(u, q, dim, lane, w, base_lds);
   }
   __device__ __forceinline__ double norm(double x, int kind) { return flat_norm(x, dim, lane, kind); }
   __device__ __forceinline__ double grad(double q) {

@@ -196,7 +196,8 @@ static int launch_user_metric(mm_ctx* ctx, const mm_model* m, mm_state* s, int w
   a.counters = d_counters;
   a.out = d_out;
   a.z = d_z;
-  return mm_rtc_launch_riemann(ctx, m, which, &a, s->n);
+  a.no_refine = mm_refine_disabled();
+  return mm_rtc_launch_riemann(ctx, m, s, which, &a);
 }
 
 int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,

@@ -1,592 +1,12 @@
-// Implicit leapfrog on dense-metric Riemannian systems, 32 < D <= 64, one wave per chain, with the
-// metric inverted by a BLOCKED symmetric sweep whose rank-4 updates run on the FP64 matrix cores
-// (v_mfma_f64_16x16x4_f64).  gfx950 / CDNA4.
-//
-// Why: at BASELINE c3 (1024 chains, D = 64) there is exactly one chain per SIMD.  A lone wave issues
-// about one VALU instruction per 6 cycles (tools/ubench_latency.hip), so the per-column cost of the
-// rank-1 sweep of k_implicit.hip (~105 instructions, 64 of them v_fma_f64) is an instruction-issue
-// bound, not a flop bound.  One v_mfma_f64_16x16x4 is ONE issue slot for 1024 fused multiply-adds,
-// so a rank-4 update of the whole matrix is 10 instructions instead of 256.
-//
-// Layout.  D is padded to 64 = 4 x 4 tiles of 16 x 16; only the 10 tiles on or below the diagonal are
-// stored, each in the MFMA accumulator layout: lane l = 16 g + j, register r holds entry
-// (16 I + 4 r + g, 16 J + j) of tile (I, J).  Consequently the four consecutive matrix rows
-// K = 16 I0 + 4 r0 + {0,1,2,3} are, for every tile of tile-row I0, exactly register r0 of all 64 lanes
-// -- which is precisely the B-operand layout (lane (k = g, n = j)) of the instruction.
-//
-// Blocked sweep (same algebra as BlockBackend::block_step in k_implicit_large.hip), per block K:
-//   (1) publish the panel Q = A[K, :] (4 x 64) to LDS as Qt[c][g]: tile-row I0 directly, the part right
-//       of the diagonal from the transposed tiles (I, I0), I > I0, by symmetry;
-//   (2) every lane inverts the 4 x 4 pivot block P redundantly (closed form through 2 x 2 Schur
-//       complements: two reciprocals instead of four), then lane c turns column c of the panel into
-//       column c of  W = P^-1 (Q - E),  E = identity on the K columns (this one modification yields both
-//       W_K = I - P^-1 and X_K = P - I of the uniform rank-4 form  A -= W^T X,  X = Q - E);
-//   (3) ten MFMAs: tile (I, J) += (-W)[:, tile I]^T  X[:, tile J];  then A_KK -= 2 I.
-// After 16 blocks the tiles hold -M^-1.
-//
-// Reference arithmetic replaced: DensePositiveDefiniteMatrix factorisation + explicit inverse
-// (matrices.py:1161-1188) inside ImplicitLeapfrogIntegrator._step (integrators.py:493-544); the step
-// logic itself is implicit_core.h (shared with the other backends).
-#include "implicit_core.h"
+// Host side of the matrix-core wave-per-chain dense-Riemannian kernel (32 < D <= 64; device code: implicit_mfma.h) and its
+// developer kernels.
+#include "implicit_mfma.h"
 
 namespace {
 
 using namespace mmdev;
 using namespace mmimp;
-
-typedef double d4 __attribute__((ext_vector_type(4)));
-typedef double d2 __attribute__((ext_vector_type(2)));
-
-constexpr int kWaves = 4;      // chains per workgroup
-constexpr int kTiles = 10;     // lower-triangular 16 x 16 tiles of a 64 x 64 matrix
-constexpr int kPartStride = 17;
-// per-wave LDS (doubles): Qt[64][4], Wt[64][4], nat[64], vperm[64], aux[64], part[64][17], mpart[3][64],
-// stash[SL_COUNT_REFINE][64].  The refinement solves (implicit_core.h refine_solve) keep their scratch in Qt / Wt: no
-// sweep runs while one is in flight.
-constexpr int kMfmaWaveDoubles = 256 + 256 + 64 + 64 + 64 + 64 * kPartStride + 192 + SL_COUNT_REFINE * 64 + 16;
-static_assert((1 + RS_COUNT) * 64 <= 512, "refinement scratch must fit Qt + Wt");
-constexpr int kBaseDoubles = kTiles * 4 * 64;  // staged base matrix of the rank-one metric
-
-__host__ __device__ constexpr int tix(int I, int J) { return I * (I + 1) / 2 + J; }
-
-struct MLds {
-  double* qt;     // [64][4] panel, column-major in the block index
-  double* wt;     // [64][4] -W
-  double* nat;    // [64] natural-order vector
-  double* vperm;  // [4][4][4] = [I][g][r] copy of a vector for row operands
-  double* aux;    // [64]
-  double* part;   // [64][17] direct partial sums of the mat-vec
-  double* mpart;  // [3][4][16] mirrored partial sums
-  double* stash;  // [SL_COUNT_REFINE][64]
-  double* prof;   // [16] developer builds: phase clocks (implicit_core.h PH_*)
-};
-
-template <int RMETRIC, bool PROFILE = false>
-struct MfmaBackend {
-  static constexpr bool kProf = PROFILE;  // developer builds: cycles per phase of the step
-  __device__ __forceinline__ int prof_switch(int phase) {
-    int old = 0;
-    if (lane == 0) {
-      const double now = (double)__builtin_readcyclecounter();
-      old = (int)w.prof[PH_COUNT];
-      w.prof[old] += now - w.prof[PH_COUNT + 1];
-      w.prof[PH_COUNT] = (double)phase;
-      w.prof[PH_COUNT + 1] = now;
-    }
-    return __builtin_amdgcn_readfirstlane(old);
-  }
-  static constexpr bool kSolveByInverse = false;
-  static constexpr bool kUnifiedConstruct = true;  // implicit_core.h: one construction site, the mode at run time
-  static constexpr bool kCountersInLds = false;
-  static constexpr bool kRefine = true;  // implicit_core.h: solve-only constructions refined from the held inverse
-  bool refine_on;                        // false: MICI_AMD_REFINE=0, every construction is factorised
-  d4 acc[kTiles];
-  int dim, lane, target;
-  MLds w;
-  const double* base_lds;
-  const double* tparams;
-
-  __device__ __forceinline__ double& slot(int i) { return w.stash[i * 64 + lane]; }
-
-  // ---- metric_func(x) into the tiles; false if an entry is not finite ----------------------------
-  __device__ __forceinline__ bool build(double x) {
-    const int g = lane >> 4, j = lane & 15;
-    const double xm = (lane < dim) ? x : 0.0;
-    w.nat[lane] = xm;
-    w.vperm[(((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = xm;
-    wave_sync();
-    const double inv_d = 1.0 / (double)dim;
-    double qc[4];
-    d4 qr[4];
-#pragma unroll
-    for (int X = 0; X < 4; ++X) {
-      qc[X] = w.nat[16 * X + j];
-      qr[X] = *reinterpret_cast<const d4*>(w.vperm + ((X * 4 + g) << 2));
-    }
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-#pragma unroll
-      for (int J = 0; J <= I; ++J) {
-        const int t = tix(I, J);
-        if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-          const d2 b01 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 0) * 64 + lane) * 2);
-          const d2 b23 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 1) * 64 + lane) * 2);
-          const double qs = qc[J] * inv_d;
-          acc[t][0] = __builtin_fma(qr[I][0], qs, b01[0]);
-          acc[t][1] = __builtin_fma(qr[I][1], qs, b01[1]);
-          acc[t][2] = __builtin_fma(qr[I][2], qs, b23[0]);
-          acc[t][3] = __builtin_fma(qr[I][3], qs, b23[1]);
-        } else {
-          acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-        }
-      }
-    // diagonal entries: (16 I + 4 r + g, same) <-> tile (I, I), register r, lanes with j == 4 r + g
-    double chk = 0.0;
-#pragma unroll
-    for (int I = 0; I < 4; ++I) {
-      const int t = tix(I, I);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool on_diag = (j == 4 * r + g);
-        if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
-          const double qi = qr[I][r];
-          if (on_diag) acc[t][r] = __builtin_fma(qi, qi, 1.0);
-        }
-        if (on_diag && 16 * I + 4 * r + g >= dim) acc[t][r] = 1.0;  // identity on the padding
-        // "Array is not finite." (matrices.py:211-215).  Both built-in metrics have their largest
-        // entries on the diagonal (B_ii + q_i^2 / D with B_ii > 0; 1 + q_i^2), so a non-finite entry
-        // anywhere implies a non-finite diagonal-tile entry.
-        chk = __builtin_fma(acc[t][r], 0.0, chk);
-      }
-    }
-    wave_sync();
-    return __all(chk == 0.0);
-  }
-
-  // ---- refinement solves (implicit_core.h): M(x) v formed matrix-free, the tiles keep M(x0)^-1 ---------------------
-  // the solve's flat vectors (u, r, d) stay in registers: nothing else of the step is live during a refinement solve
-  // (the sweeps' operands are dead), and a lone wave pays ~100 cycles for every dependent LDS access
-  double rs_[RS_COUNT];
-  __device__ __forceinline__ double& rslot(int i) { return rs_[i]; }
-  __device__ __forceinline__ void sum2(double a, double b, double* sa, double* sb) {
-    *sa = wave_sum(lane < dim ? a : 0.0);
-    *sb = wave_sum(lane < dim ? b : 0.0);
-  }
-  __device__ __forceinline__ double sum1(double a) { return wave_sum(lane < dim ? a : 0.0); }
-  // M(x) v in the form that suits the metric:  rank-one update  B v + x (x . v) / D  (B's tiles from LDS, contracted
-  // like matvec() contracts the register tiles);  diag(1 + x^2): per lane
-  __device__ __forceinline__ void metric_point(double x) { w.qt[lane] = (lane < dim) ? x : 0.0; }
-  // sixteen partial sums of a row, pairwise: a lone wave pays every dependent add in full (a serial chain is 16 deep)
-  __device__ static __forceinline__ double sum16(const double* src) {
-    double a[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = src[k];
-#pragma unroll
-    for (int h = 8; h >= 1; h >>= 1)
-#pragma unroll
-      for (int k = 0; k < h; ++k) a[k] += a[k + h];
-    return a[0];
-  }
-
-  __device__ __forceinline__ double metric_apply(double v) {
-    const double x = w.qt[lane];
-    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
-      return lane < dim ? __builtin_fma(x * x, v, v) : 0.0;
-    } else {
-      const int g = lane >> 4, j = lane & 15;
-      w.nat[lane] = (lane < dim) ? v : 0.0;
-      w.vperm[(((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = (lane < dim) ? v : 0.0;
-      wave_sync();
-      double vc[4];
-      d4 vr[4];
-#pragma unroll
-      for (int X = 0; X < 4; ++X) {
-        vc[X] = w.nat[16 * X + j];
-        vr[X] = *reinterpret_cast<const d4*>(w.vperm + ((X * 4 + g) << 2));
-      }
-      // all ten tiles of the staged base matrix first: a lone wave cannot hide an LDS round trip (~130 cycles), and
-      // issued one tile ahead of its arithmetic the twenty loads were ten of them in a row (1.6 k of the call's 3.0 k
-      // cycles); the scheduling barrier keeps the compiler from sinking them back to their uses
-      d4 m[10];
-#pragma unroll
-      for (int t = 0; t < 10; ++t) {
-        const d2 b01 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 0) * 64 + lane) * 2);
-        const d2 b23 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 1) * 64 + lane) * 2);
-        m[t] = d4{b01[0], b01[1], b23[0], b23[1]};  // zero on the padding, where v is zero too
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      double mir[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-      for (int I = 0; I < 4; ++I) {
-        d4 s = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int J = 0; J <= I; ++J) {
-          const int t = tix(I, J);
-          if (I != J) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mir[J] = __builtin_fma(m[t][r], vr[I][r], mir[J]);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[r] = __builtin_fma(m[t][r], vc[J], s[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w.part[(16 * I + 4 * r + g) * kPartStride + j] = s[r];
-      }
-#pragma unroll
-      for (int J = 0; J < 3; ++J) w.mpart[(J * 4 + g) * 16 + j] = mir[J];
-      const double dot = wave_sum(lane < dim ? x * v : 0.0);
-      wave_sync();
-      double y = 0.0;
-      {
-        y = sum16(w.part + lane * kPartStride);
-        if (lane < 48) {
-          const double* mp = w.mpart + (lane >> 4) * 64 + (lane & 15);
-          y += (mp[0] + mp[16]) + (mp[32] + mp[48]);
-        }
-        y = __builtin_fma(x, dot / (double)dim, y);
-      }
-      wave_sync();
-      return lane < dim ? y : 0.0;
-    }
-  }
-
-  // operands of one block's rank-4 update.  They stay in registers after the block so that the six
-  // "cold" tiles (those the NEXT block's panel does not read) are updated while the next block's scalar
-  // work (P^-1, W) is being issued: the matrix core runs asynchronously to the VALU.
-  struct Ops {
-    double av[4], bv[4];
-  };
-
-  // update the tiles of tile-row/column `in` (hot == true) or all the others (hot == false); in < 0: all.
-  // jmin: the trailing (LDL^T) sweep leaves the tile columns left of the pivot's alone.
-  __device__ __forceinline__ void apply(const Ops& o, const int in, const bool hot, const int jmin = 0) {
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-#pragma unroll
-      for (int J = 0; J <= I; ++J) {
-        const bool is_hot = (I == in) || (J == in);
-        if (J >= jmin && (in < 0 || is_hot == hot))
-          acc[tix(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.av[I], o.bv[J], acc[tix(I, J)], 0, 0, 0);
-      }
-  }
-
-  // ---- one block of the sweep (B compile-time after unrolling) ----------------------------------------
-  // TRAILING: only the tiles (I, J) with J >= I0 are updated - a blocked LDL^T (D^3/3 flops instead of D^3) that
-  // ends with tile (K, K) = -P_K^-1 and tile (I, K) = A_IK P_K^-1, the factors solve_factored() substitutes with
-  template <bool TRAILING>
-  __device__ __forceinline__ void block_step(const int B, Ops& ops, double& pmin) {
-    const int I0 = B >> 2, R0 = B & 3;
-    const int g = lane >> 4, j = lane & 15;
-    const int k0 = 16 * I0 + 4 * R0;
-    // (1) publish rows K of the matrix as Qt[c][s] = A[k0 + s][c].  The transposed part comes from the 16
-    // lanes holding columns K of the tiles below the diagonal tile; the other lanes store into the (dead)
-    // W buffer instead of branching, which keeps the whole sweep one basic block for the scheduler.
-#pragma unroll
-    for (int J = TRAILING ? I0 : 0; J <= I0; ++J) w.qt[((16 * J + j) << 2) + g] = acc[tix(I0, J)][R0];
-    {
-      double* dst = ((j >> 2) == R0) ? w.qt + (g << 2) + (j & 3) : w.wt + j;
-#pragma unroll
-      for (int I = I0 + 1; I < 4; ++I)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(16 * I + 4 * r) << 2] = acc[tix(I, I0)][r];
-    }
-    wave_sync();
-    // (2) P^-1 (uniform) and this lane's column of W
-    const d4 c0 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 0) << 2));
-    const d4 c1 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 1) << 2));
-    const d4 c2 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 2) << 2));
-    const d4 c3 = *reinterpret_cast<const d4*>(w.qt + ((k0 + 3) << 2));
-    d4 q = *reinterpret_cast<const d4*>(w.qt + (lane << 2));
-    // the previous block's cold tiles: independent of everything below until this block's own update
-    if (B > 0) apply(ops, I0, false, TRAILING ? (B - 1) >> 2 : 0);
-    d4 wv;
-    {
-      // P = [A B; B^T C] with 2 x 2 blocks; c_s is column s of P
-      const double a = c0[0], b = c0[1], e = c1[1];                    // A = [a b; b e]
-      const double b00 = c0[2], b01 = c0[3], b10 = c1[2], b11 = c1[3];  // B = P[0:2, 2:4]
-      const double h = c2[2], i2 = c2[3], jj = c3[3];                  // C = [h i2; i2 jj]
-      const double det_a = __builtin_fma(a, e, -b * b);
-      const double ida = fast_rcp(det_a);
-      const double ia00 = e * ida, ia01 = -b * ida, ia11 = a * ida;  // A^-1
-      // T = A^-1 B
-      const double t00 = __builtin_fma(ia00, b00, ia01 * b10), t01 = __builtin_fma(ia00, b01, ia01 * b11);
-      const double t10 = __builtin_fma(ia01, b00, ia11 * b10), t11 = __builtin_fma(ia01, b01, ia11 * b11);
-      // S = C - B^T T
-      const double s00 = h - __builtin_fma(b00, t00, b10 * t10);
-      const double s01 = i2 - __builtin_fma(b00, t01, b10 * t11);
-      const double s11 = jj - __builtin_fma(b01, t01, b11 * t11);
-      const double det_s = __builtin_fma(s00, s11, -s01 * s01);
-      const double ids = fast_rcp(det_s);
-      const double is00 = s11 * ids, is01 = -s01 * ids, is11 = s00 * ids;  // S^-1
-      // pivots of the sequential elimination: a, det_a / a, s00, det_s / s00  (all must be > 0)
-      // v_min_f64 drops NaNs, so a NaN pivot is caught separately at the end of the sweep: it poisons
-      // every entry of W and with it every tile
-      pmin = __builtin_fmin(__builtin_fmin(pmin, a), __builtin_fmin(det_a, __builtin_fmin(s00, det_s)));
-      // U = T S^-1;  P^-1 = [A^-1 + U T^T, -U; -U^T, S^-1]
-      const double u00 = __builtin_fma(t00, is00, t01 * is01), u01 = __builtin_fma(t00, is01, t01 * is11);
-      const double u10 = __builtin_fma(t10, is00, t11 * is01), u11 = __builtin_fma(t10, is01, t11 * is11);
-      const double p00 = ia00 + __builtin_fma(u00, t00, u01 * t01);
-      const double p01 = ia01 + __builtin_fma(u00, t10, u01 * t11);
-      const double p11 = ia11 + __builtin_fma(u10, t10, u11 * t11);
-      // this lane's column of the panel, minus the identity on the block's own columns
-      const int s = lane - k0;
-      q[0] -= (s == 0) ? 1.0 : 0.0;
-      q[1] -= (s == 1) ? 1.0 : 0.0;
-      q[2] -= (s == 2) ? 1.0 : 0.0;
-      q[3] -= (s == 3) ? 1.0 : 0.0;
-      // -W[:, c] = -P^-1 q
-      // (one multiply and three fused multiply-adds per component; the signs ride on operand modifiers)
-      wv[0] = __builtin_fma(-p00, q[0], __builtin_fma(-p01, q[1], __builtin_fma(u00, q[2], u01 * q[3])));
-      wv[1] = __builtin_fma(-p01, q[0], __builtin_fma(-p11, q[1], __builtin_fma(u10, q[2], u11 * q[3])));
-      wv[2] = __builtin_fma(u00, q[0], __builtin_fma(u10, q[1], __builtin_fma(-is00, q[2], -is01 * q[3])));
-      wv[3] = __builtin_fma(u01, q[0], __builtin_fma(u11, q[1], __builtin_fma(-is01, q[2], -is11 * q[3])));
-    }
-    *reinterpret_cast<d4*>(w.qt + (lane << 2)) = q;  // only the block's own four columns changed
-    *reinterpret_cast<d4*>(w.wt + (lane << 2)) = wv;
-    if (B > 0) {
-      // scheduling pipeline for this region: one cold MFMA per ~15 VALU instructions (an MFMA occupies the
-      // matrix core for 64 cycles, a lone wave issues a VALU instruction about every 6)
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 15, 0);
-      }
-    }
-    wave_sync();
-    // (3) rank-4 update on the matrix cores: now only the tiles the next block's panel reads
-#pragma unroll
-    for (int X = 0; X < 4; ++X) {
-      ops.av[X] = w.wt[((16 * X + j) << 2) + g];
-      ops.bv[X] = w.qt[((16 * X + j) << 2) + g];
-    }
-    if (B < 15) apply(ops, (B + 1) >> 2, true, TRAILING ? I0 : 0);
-    else apply(ops, -1, true, TRAILING ? I0 : 0);
-    if (j == 4 * R0 + g) acc[tix(I0, I0)][R0] -= 2.0;
-    wave_sync();  // the next block overwrites Qt / Wt
-  }
-
-  template <bool TRAILING>
-  __device__ __forceinline__ bool sweep() {
-    double pmin = 1.0;  // smallest pivot seen
-    Ops ops;
-#pragma unroll
-    for (int B = 0; B < 16; ++B) block_step<TRAILING>(B, ops, pmin);
-    if constexpr (!TRAILING) {
-#pragma unroll
-      for (int t = 0; t < kTiles; ++t) acc[t] = -acc[t];
-    }
-    // a NaN pivot poisons every entry of W and with it every tile that is still being updated: the last diagonal
-    // tile is updated by every block of both sweeps
-    const double probe = acc[tix(3, 3)][0];
-    return (pmin > 0.0) && __all(probe == probe);
-  }
-
-  // ---- u = M^-1 b from the trailing sweep's factors (tile (K, K) = -P_K^-1, tile (I, K) = T_IK = A_IK P_K^-1) ------
-  // forward, right-looking: y_K is final when step K starts; z_K = P_K^-1 y_K and b_I -= T_IK y_K for I > K come
-  // from the tiles of tile column K through the mat-vec's row partial sums.  Backward, right-looking: u_I is final
-  // when step I starts and z_K -= T_IK^T u_I for K < I comes through the mirrored partial sums.
-  __device__ __forceinline__ double solve_factored(double b) {
-    const int g = lane >> 4, j = lane & 15;
-    w.nat[lane] = (lane < dim) ? b : 0.0;
-    wave_sync();
-#pragma unroll
-    for (int K = 0; K < 4; ++K) {
-      const double yk = w.nat[16 * K + j];
-#pragma unroll
-      for (int I = K; I < 4; ++I)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w.part[(16 * I + 4 * r + g) * kPartStride + j] = acc[tix(I, K)][r] * yk;
-      wave_sync();
-      if (lane >= 16 * K) {
-        const double* src = w.part + lane * kPartStride;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; k += 4) { a0 += src[k]; a1 += src[k + 1]; a2 += src[k + 2]; a3 += src[k + 3]; }
-        const double sum = (a0 + a1) + (a2 + a3);
-        w.nat[lane] = (lane < 16 * K + 16) ? -sum : w.nat[lane] - sum;  // z_K (the tile is -P^-1) | b_I - T_IK y_K
-      }
-      wave_sync();
-    }
-#pragma unroll
-    for (int I = 3; I >= 1; --I) {
-      const d4 ur = d4{w.nat[16 * I + g], w.nat[16 * I + 4 + g], w.nat[16 * I + 8 + g], w.nat[16 * I + 12 + g]};
-#pragma unroll
-      for (int K = 0; K < I; ++K) {
-        const d4 a = acc[tix(I, K)];
-        double m = a[0] * ur[0];
-        m = __builtin_fma(a[1], ur[1], m);
-        m = __builtin_fma(a[2], ur[2], m);
-        m = __builtin_fma(a[3], ur[3], m);
-        w.mpart[(K * 4 + g) * 16 + j] = m;
-      }
-      wave_sync();
-      if (lane < 16 * I) {
-        const double* m = w.mpart + (lane >> 4) * 64 + (lane & 15);
-        w.nat[lane] -= (m[0] + m[16]) + (m[32] + m[48]);
-      }
-      wave_sync();
-    }
-    const double u = (lane < dim) ? w.nat[lane] : 0.0;
-    wave_sync();
-    return u;
-  }
-
-  // implicit_core.h, kUnifiedConstruct: metric_func(x), then the explicit inverse (kept in the tiles for matvec /
-  // half_vjp_inv / dh2_dpos) or the single solve u = M(x)^-1 rhs (systems.py:1381-1399)
-  __device__ __forceinline__ bool construct(double x, bool need_inverse, double rhs, double* u) {
-    bool ok = build(x);
-    if (need_inverse) {  // wave-uniform
-      ok = sweep<false>() && ok;
-    } else {
-      ok = sweep<true>() && ok;
-      *u = solve_factored(rhs);
-    }
-    return ok;
-  }
-  __device__ __forceinline__ bool build_and_invert(double x) {
-    double dummy;
-    return construct(x, true, 0.0, &dummy);
-  }
-  __device__ __forceinline__ bool build_and_solve(double x, double rhs, double* u) { return construct(x, false, rhs, u); }
-
-  // ---- y = T v for the symmetric matrix held as lower tiles -------------------------------------------
-  __device__ __forceinline__ double matvec(double v) {
-    const int g = lane >> 4, j = lane & 15;
-    w.nat[lane] = (lane < dim) ? v : 0.0;
-    w.vperm[(((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = (lane < dim) ? v : 0.0;
-    wave_sync();
-    double vc[4];
-    d4 vr[4];
-#pragma unroll
-    for (int X = 0; X < 4; ++X) {
-      vc[X] = w.nat[16 * X + j];
-      vr[X] = *reinterpret_cast<const d4*>(w.vperm + ((X * 4 + g) << 2));
-    }
-    // direct: rows of tile-row I, summed over this lane's column j of tiles J <= I
-#pragma unroll
-    for (int I = 0; I < 4; ++I) {
-      d4 s = acc[tix(I, 0)] * vc[0];
-#pragma unroll
-      for (int J = 1; J <= I; ++J) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[r] = __builtin_fma(acc[tix(I, J)][r], vc[J], s[r]);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w.part[(16 * I + 4 * r + g) * kPartStride + j] = s[r];
-    }
-    // mirrored: column 16 J + j of the tiles (I, J), I > J, against the row operand
-#pragma unroll
-    for (int J = 0; J < 3; ++J) {
-      double s = 0.0;
-#pragma unroll
-      for (int I = J + 1; I < 4; ++I)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s = __builtin_fma(acc[tix(I, J)][r], vr[I][r], s);
-      w.mpart[(J * 4 + g) * 16 + j] = s;
-    }
-    wave_sync();
-    double y = 0.0;
-    {
-      y = sum16(w.part + lane * kPartStride);
-      if (lane < 48) {
-        const double* m = w.mpart + (lane >> 4) * 64 + (lane & 15);
-        y += (m[0] + m[16]) + (m[32] + m[48]);
-      }
-    }
-    wave_sync();
-    return lane < dim ? y : 0.0;
-  }
-
-  __device__ __forceinline__ double diag() {
-    const int g = lane >> 4, j = lane & 15;
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (j == 4 * r + g) w.nat[16 * I + 4 * r + g] = acc[tix(I, I)][r];
-    wave_sync();
-    const double y = (lane < dim) ? w.nat[lane] : 0.0;
-    wave_sync();
-    return y;
-  }
-
-  // 0.5 * vjp_metric(M^-1): rank-one metric M^-1 q / D; diag-quad metric q_i (M^-1)_ii
-  __device__ __forceinline__ double half_vjp_inv(double q) {
-    if constexpr (RMETRIC == MM_RMETRIC_RANK1) return matvec(q) / (double)dim;
-    else return q * diag();
-  }
-  // dense metric: grad_quadratic_form_inv(p) = -(M^-1 p)(M^-1 p)^T   (matrices.py:1179-1181)
-  __device__ __forceinline__ double dh2_dpos(double p, double q) {
-    const double u = matvec(p);
-    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-      const double uq = wave_sum(lane < dim ? u * q : 0.0);
-      return -(u * uq) / (double)dim;
-    } else {
-      return -q * (u * u);
-    }
-  }
-  __device__ __forceinline__ double norm(double x, int kind) {
-    const double a = wave_norm_accum(0.0, lane < dim ? x : 0.0, kind);
-    return wave_norm_finish(a, kind);
-  }
-  __device__ __forceinline__ double grad(double q) {
-    w.nat[lane] = (lane < dim) ? q : 0.0;
-    wave_sync();
-    const TargetAux aux = target_prepare<false>(target, w.nat, dim, tparams, lane);
-    const double gr = (lane < dim) ? target_grad_elem<false>(target, aux, w.nat, lane, dim, tparams) : 0.0;
-    wave_sync();
-    return gr;
-  }
-};
-
-template <int RMETRIC, bool PROFILE = false>
-__global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs A) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* base_lds = lds;
-  const int base_elems = (RMETRIC == MM_RMETRIC_RANK1) ? kBaseDoubles : 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int dim = A.dim;
-  if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-    // base_lds[((t*2 + h)*64 + lane)*2 + e] = B[16 I + 4 (2h + e) + g][16 J + j], zero outside dim x dim
-    for (int idx = threadIdx.x; idx < kBaseDoubles; idx += blockDim.x) {
-      const int e = idx & 1, l = (idx >> 1) & 63, th = idx >> 7, h = th & 1, t = th >> 1;
-      int I = 0;
-      while (tix(I + 1, 0) <= t) ++I;
-      const int J = t - tix(I, 0);
-      const int row = 16 * I + 4 * (2 * h + e) + (l >> 4), col = 16 * J + (l & 15);
-      base_lds[idx] = (row < dim && col < dim) ? A.rparams[(int64_t)row * dim + col] : 0.0;
-    }
-  }
-  __syncthreads();
-  const int64_t chain = (int64_t)blockIdx.x * kWaves + wave;
-  if (chain >= A.n_chains) return;  // no block-level barrier below this point
-  double* wl = lds + base_elems + wave * kMfmaWaveDoubles;
-  const bool act = lane < dim;
-  double q = act ? A.pos[chain * dim + lane] : 0.0;
-  double p = act ? A.mom[chain * dim + lane] : 0.0;
-  const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
-
-  MfmaBackend<RMETRIC, PROFILE> bk;
-  bk.dim = dim;
-  bk.lane = lane;
-  bk.target = A.target;
-  bk.w.qt = wl;
-  bk.w.wt = wl + 256;
-  bk.w.nat = wl + 512;
-  bk.w.vperm = wl + 576;
-  bk.w.aux = wl + 640;
-  bk.w.part = wl + 704;
-  bk.w.mpart = bk.w.part + 64 * kPartStride;
-  bk.w.stash = bk.w.mpart + 192;
-  bk.w.prof = bk.w.stash + SL_COUNT_REFINE * 64;
-  bk.refine_on = A.no_refine == 0;
-  bk.base_lds = base_lds;
-  bk.tparams = A.tparams;
-  if constexpr (PROFILE) {
-    if (lane < PH_COUNT + 2) bk.w.prof[lane] = lane == PH_COUNT + 1 ? (double)__builtin_readcyclecounter() : 0.0;
-    wave_sync();
-  }
-  bk.slot(SL_Q) = q;
-  bk.slot(SL_P) = p;
-  const ChainResult r = implicit_leapfrog_chain(bk, t, mmdev::chain_steps(A.chain_steps, chain, A.n_steps), A.opts);
-  q = bk.slot(SL_Q);
-  p = bk.slot(SL_P);
-  if (act) {
-    A.pos[chain * dim + lane] = q;
-    A.mom[chain * dim + lane] = p;
-  }
-  if (lane == 0) {
-    A.status[chain] = r.status;
-    A.n_done[chain] = r.done;
-    add_counters(A.counters, r);
-  }
-  if constexpr (PROFILE) {  // out[chain][PH_COUNT]: cycles per phase of this chain's launch
-    bk.prof_switch(PH_OTHER);
-    wave_sync();
-    if (lane < PH_COUNT) A.out[chain * PH_COUNT + lane] = bk.w.prof[lane];
-  }
-}
-
+using namespace mmmfma;
 
 #ifdef MM_DEV_KERNELS
 // ---- developer profile (not part of the ABI header; tools/ubench_primitives.py): shader-clock cycles of

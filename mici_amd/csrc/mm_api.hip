@@ -44,6 +44,20 @@ void mm_set_error(const mm_ctx* ctx, const std::string& msg) {
   if (ctx) const_cast<mm_ctx*>(ctx)->last_error = msg;
 }
 
+// the per-chain global-memory workspace of a state (SoftAbs matrices beyond 64 dimensions, the dense copy of the inverse
+// metric a user's accessor-form vector-Jacobian product reads): grown on demand, kept with the state
+int mm_state_ensure_work(mm_ctx* ctx, mm_state* s, size_t bytes) {
+  if (bytes > s->work_bytes) {
+    MM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (s->d_work) (void)hipFree(s->d_work);
+    s->d_work = nullptr;
+    s->work_bytes = 0;
+    MM_HIP_CHECK(ctx, hipMalloc(&s->d_work, bytes));
+    s->work_bytes = bytes;
+  }
+  return MM_OK;
+}
+
 extern "C" {
 
 int mm_abi_version(void) { return MM_ABI_VERSION; }
@@ -245,8 +259,8 @@ int mm_model_create_from_source(mm_ctx* ctx, const mm_model_desc* d, const char*
   MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE || d->rmetric == MM_RMETRIC_USER,
              "mm_model_create_from_source: a user target on a Riemannian system needs a user metric too (the built-in "
              "metrics' kernels are compiled ahead of time around the built-in targets)");
-  MM_REQUIRE(ctx, d->rmetric != MM_RMETRIC_USER || d->dim <= 64,
-             "mm_model_create_from_source: user metrics run on the wave-per-chain kernels, dim <= 64");
+  MM_REQUIRE(ctx, d->rmetric != MM_RMETRIC_USER || d->dim <= 279,
+             "mm_model_create_from_source: user metrics run on the register-resident dense-Riemannian kernels, dim <= 279");
   MM_REQUIRE(ctx, d->target != MM_TARGET_USER || !d->gaussian_split,
              "mm_model_create_from_source: a user target is a density with respect to the Lebesgue measure (identity / "
              "diagonal / dense fixed metric); the Gaussian-split system classes take built-in targets");

@@ -60,8 +60,16 @@ struct mm_model {
   void* rtc_con_step = nullptr;
   void* rtc_con_project = nullptr;
   void* rtc_con_logdet = nullptr;
-  void* rtc_riem_module = nullptr;  // dense-Riemannian system with a user metric: implicit_wave.h compiled around it
-  void* rtc_riem_fn[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // step, midpoint, h, dh_dmom, sample_momentum
+  // dense-Riemannian system with a user metric (user_metric.h): the backends compiled around the user's source, one
+  // module per kernel family - MM_RTC_FAM_WAVE (implicit_wave.h, dim <= 64), _MFMA (implicit_mfma.h, 32 < dim <= 64,
+  // leapfrog step), _TEAM (implicit_team.h, 64 < dim <= 279), _BLK16 (implicit_blk16.h, 75 < dim <= 256, leapfrog step).
+  // The family with the auxiliary kernels is compiled when the model is created (compile errors surface there), the
+  // matrix-core step kernels on their first launch.  fn: step, midpoint, h, dh_dmom, sample_momentum.
+  void* rtc_riem_module[4] = {nullptr, nullptr, nullptr, nullptr};
+  void* rtc_riem_fn[4][5] = {};
+  std::string user_src;        // the user's text (kept for the families compiled later)
+  int user_aux = 0;            // MM_USER_AUX of the user's text (0: none)
+  bool user_flat_vjp = false;  // MM_USER_VJP_FLAT
   double h_target_params[4] = {0, 0, 0, 0};  // first few params host-side (scalars)
   double h_rmetric_params[4] = {0, 0, 0, 0};
   double h_constr_params[4] = {0, 0, 0, 0};
@@ -138,7 +146,9 @@ int mm_rtc_attach(mm_ctx* ctx, mm_model* m, const char* user_src);
 void mm_rtc_detach(mm_model* m);
 int mm_rtc_attach_constrained(mm_ctx* ctx, mm_model* m, const char* user_src);
 int mm_rtc_attach_riemann(mm_ctx* ctx, mm_model* m, const char* user_src);
-int mm_rtc_launch_riemann(mm_ctx* ctx, const mm_model* m, int which, void* implicit_args, int64_t n_chains);
+enum { MM_RTC_FAM_WAVE = 0, MM_RTC_FAM_MFMA = 1, MM_RTC_FAM_TEAM = 2, MM_RTC_FAM_BLK16 = 3 };
+int mm_rtc_launch_riemann(mm_ctx* ctx, const mm_model* m, mm_state* s, int which, void* implicit_args);
+int mm_state_ensure_work(mm_ctx* ctx, mm_state* s, size_t bytes);  // grows s->d_work (per-chain global workspace)
 int mm_rtc_launch_constrained(mm_ctx* ctx, const mm_model* m, int which, void* con_args, int64_t n_chains, double* d_out);
 int mm_rtc_launch_integrate(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_comp_coefs* cf);
 int mm_rtc_launch_hamiltonian(mm_ctx* ctx, const mm_model* m, mm_state* s, double* d_h);

@@ -127,8 +127,11 @@ class UserMetric(RiemannianMetric):
         __device__ double mm_user_vjp(const double* q, const MmMat& V, int k, int dim, const double* params);
         // element k of vjp_metric_func(q)(V) = sum_ij V(i, j) d M_ij / d q_k for a symmetric V read as V(i, j)
 
-    and is compiled for gfx950 (hipRTC) with the library's wave-per-chain implicit kernels when the system's device
-    model is created; ``params`` are handed to both.  ``dim`` <= 64."""
+    and is compiled for gfx950 (hipRTC) with the library's dense-Riemannian kernels (the auxiliary kernels when the
+    system's device model is created, the matrix-core leapfrog kernels on their first launch); ``params`` are handed to
+    both.  ``dim`` <= 279.  The text may opt into per-point precomputation (``#define MM_USER_AUX n`` +
+    ``mm_user_prepare``) and the team-form vector-Jacobian product (``#define MM_USER_VJP_FLAT`` +
+    ``mm_user_vjp_flat``): csrc/user_metric.h - both decide how fast the system runs, neither changes results."""
 
     def __init__(self, dim, source, params=()):
         super().__init__(RMETRIC_USER, dim, params)

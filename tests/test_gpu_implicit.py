@@ -22,15 +22,17 @@ SOLVER = {0: solvers.solve_fixed_point_direct, 1: solvers.solve_fixed_point_stef
 NORM = {0: solvers.maximum_norm, 1: solvers.euclidean_norm}
 
 
-def build(g):
+def build(g, fast_source=False):
     n, d = g["q0"].shape
     target = models.target_from_id(g["target"], g["target_params"], d)
     mid = int(g["rmetric"])
     if mid == models.RMETRIC_SOFTABS:
         system = systems.SoftAbsRiemannianMetricSystem(target, softabs_coeff=float(g["rmetric_params"][0]))
     elif mid == models.RMETRIC_USER:  # not built in: reaches the library as HIP source (hipRTC), tests/user_sources.py
-        from user_sources import SOFTPLUS_RANK1
-        system = systems.DenseRiemannianMetricSystem(target, models.UserMetric(d, SOFTPLUS_RANK1, g["rmetric_params"]))
+        # plain form: entry-wise metric, accessor-form VJP; fast form: per-point aux + team-form VJP (csrc/user_metric.h)
+        from user_sources import SOFTPLUS_RANK1, softplus_fast
+        system = systems.DenseRiemannianMetricSystem(
+            target, models.UserMetric(d, softplus_fast(d) if fast_source else SOFTPLUS_RANK1, g["rmetric_params"]))
     else:
         system = systems.DenseRiemannianMetricSystem(
             target, models.rmetric_from_id(mid, g["rmetric_params"], d))
@@ -43,10 +45,15 @@ def build(g):
     return system, integ
 
 
-@pytest.mark.parametrize("name", DENSE)
+@pytest.mark.parametrize("name", DENSE + [n + ":fast" for n in golden_names("riemann_user")])
 def test_implicit_leapfrog_matches_reference_fixture(name):
+    """Every dense-Riemannian / SoftAbs fixture; the user-metric ones twice: with the plain form of the user's source
+    (entry-wise metric, V(i, j) accessor - the dense copy of the inverse) and with its fast form (MM_USER_AUX +
+    MM_USER_VJP_FLAT).  32 < D <= 64 and 75 < D <= 256 run the leapfrog on the matrix-core kernels compiled around the
+    source, with the solve-only constructions refined through M(x) v products of the user's entries."""
+    name, _, variant = name.partition(":")
     g = load_golden(name)
-    system, integ = build(g)
+    system, integ = build(g, fast_source=variant == "fast")
     n = g["q0"].shape[0]
     s_max = int(g["checkpoints"].max())
     # SoftAbs: Jacobi eigh vs LAPACK differs at 1e-13 and the divided differences of

@@ -1151,7 +1151,16 @@ def main():
     for name, d, n, hh, cps, kw in (("riemann_user_softplus_poly_d6", 6, 5, 0.08, [1, 5, 20], {}),
                                     ("riemann_user_softplus_banana_d20", 20, 4, 0.02, [1, 5, 20], {}),
                                     ("riemann_user_softplus_poly_d32_steffensen", 32, 3, 0.05, [1, 5], dict(fp_solver=1)),
-                                    ("riemann_user_softplus_poly_d6_fail_bigstep", 6, 5, 1.5, [1, 3], {})):
+                                    ("riemann_user_softplus_poly_d6_fail_bigstep", 6, 5, 1.5, [1, 3], {}),
+                                    # round 4: the BASELINE Riemannian sizes (the matrix-core kernels compiled around user
+                                    # source), the team kernels' sizes in between, a failing case on the matrix cores
+                                    ("riemann_user_softplus_banana_d64", 64, 4, 0.02, [1, 5, 20], {}),
+                                    ("riemann_user_softplus_poly_d48_steffensen_l2", 48, 3, 0.04, [1, 5], dict(fp_solver=1, norm=1)),
+                                    ("riemann_user_softplus_poly_d40_fail_bigstep", 40, 5, 0.9, [1, 3], {}),
+                                    ("riemann_user_softplus_poly_d70", 70, 3, 0.03, [1, 4], {}),
+                                    ("riemann_user_softplus_banana_d100", 100, 3, 0.015, [1, 4], {}),
+                                    ("riemann_user_softplus_banana_d256", 256, 3, 0.01, [1, 3], {}),
+                                    ("riemann_user_softplus_poly_d270", 270, 2, 0.01, [1, 2], {})):
         r = case_rng(name)
         tgt = mdl.Banana(d) if "banana" in name else mdl.Poly(d, 1.0, 1.0 / 3.0)
         add_riemann(name, tgt, mdl.SoftPlusRank1Metric(0.5 * r.standard_normal(d)), None, n, hh, cps, r=r, **kw)
