@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - leapfrog-steps/sec (all chains) of the MI355X integrator hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2iv|c2bcss|c3|c3b|c4|c5|c3_user|c4_general]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2iv|c2bcss|c3|c3b|c4|c5|c3_user|c4_general|c3b_dense]
                     [--traj-len L] [--chains-per-gpu M] [--no-extra-configs] [--no-cpu-baseline]
 
 Contract (driver): W untimed warm-up passes, then EXACTLY K timed passes bracketed by a barrier +
@@ -188,15 +188,23 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
                          "target) + ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
                     system=system, make_oracle=make_oracle, q0=q0, p0=p0, momenta=mom, bytes_per_chain_step=32.0 * dim,
                     flops_per_chain_step=None, bound="mfma", kind="riemann")
-    if config == "c3b":
+    if config in ("c3b", "c3b_dense"):
+        # c3b_dense (VERDICT r03 #1c): SoftAbs on the BANANA - its tridiagonal Hessian and matrix-Tressian product reach the
+        # library as user source (mici_amd/user_examples.py BANANA_HESS): the dense path - G = A X on the matrix cores,
+        # grad_log_abs_det / grad_quadratic_form_inv formed in full - none of the arrowhead structure c3(b) leans on
         dim, h, traj = 64, 0.02, 100
         wts = np.linspace(0.5, 2.0, dim - 1)
-        system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(wts), softabs_coeff=1.0)
+        if config == "c3b_dense":
+            from mici_amd import user_examples
+            system = systems.SoftAbsRiemannianMetricSystem(
+                models.Banana(dim), softabs_coeff=1.0, hess_neg_log_dens=models.UserHessian(user_examples.BANANA_HESS))
+        else:
+            system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(wts), softabs_coeff=1.0)
 
         def make_oracle():
             from oracle import integrators as orc
             from oracle import models as omdl
-            return orc.RiemannianSystem(omdl.Funnel(wts), None, 1.0)
+            return orc.RiemannianSystem(omdl.Banana(dim) if config == "c3b_dense" else omdl.Funnel(wts), None, 1.0)
 
         integ = integrators.ImplicitLeapfrogIntegrator(system, h)
         q0 = crng.standard_normal((n_chains, dim))
@@ -204,8 +212,9 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
         p0 = system.sample_momentum_batch(q0, z) if device else _oracle_momenta("softabs", make_oracle(), q0, z)
         mom = None if device else p0
         p0 = p0 if device else mom.p0
-        return dict(name="c3(b) SoftAbsRiemannianMetricSystem (scaled funnel) + "
-                         "ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
+        return dict(name=("c3b_dense SoftAbsRiemannianMetricSystem (banana target, Hessian / MTP as USER SOURCE: dense path) + "
+                          if config == "c3b_dense" else "c3(b) SoftAbsRiemannianMetricSystem (scaled funnel) + ")
+                    + "ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
                     system=system, make_oracle=make_oracle, q0=q0, p0=p0, momenta=mom, bytes_per_chain_step=32.0 * dim,
                     flops_per_chain_step=None, bound="mfma", kind="softabs")
     if config == "c5":
@@ -244,16 +253,17 @@ def _sweep_mfma_counts(dim):
     return None
 
 
-DEFAULT_CHAINS = {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048, "c3_user": 1024, "c4_general": 1024}  # per GPU; else 4096
-EXTRA_CONFIGS = ("c2i", "c2iv", "c3", "c3b", "c4", "c5", "c3_user", "c4_general")
+DEFAULT_CHAINS = {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048, "c3_user": 1024, "c4_general": 1024, "c3b_dense": 1024}  # per GPU; else 4096
+EXTRA_CONFIGS = ("c2i", "c2iv", "c3", "c3b", "c4", "c5", "c3_user", "c4_general", "c3b_dense")
 # pass counts of the extra configs are capped (a c3(b) pass is ~1 s, a c4 pass ~0.1-0.3 s)
-EXTRA_STEP_CAP = {"c3b": 5, "c4": 10, "c4_general": 10}
+EXTRA_STEP_CAP = {"c3b": 5, "c4": 10, "c4_general": 10, "c3b_dense": 5}
 BASELINE_CONFIG = {"c2": "BASELINE.json configs[1]", "c2i": "BASELINE.json configs[1] (iso-Gaussian variant, SURVEY 8d c2(i))",
                    "c2iv": "BASELINE.json configs[1] (dense-metric variant, SURVEY 8d c2(iv))",
                    "c3": "BASELINE.json configs[2] (Cholesky path)", "c3b": "BASELINE.json configs[2] (SoftAbs path)",
                    "c4": "BASELINE.json configs[3] (per-GPU shard)", "c5": "BASELINE.json configs[4] (per-GPU shard)",
                    "c3_user": "BASELINE.json configs[2] sizes, a metric_func that is not built in (user source)",
-                   "c4_general": "BASELINE.json configs[3] (per-GPU shard), its metric_func handed over as user source"}
+                   "c4_general": "BASELINE.json configs[3] (per-GPU shard), its metric_func handed over as user source",
+                   "c3b_dense": "BASELINE.json configs[2] (SoftAbs path) on the banana target: a dense (user-source) Hessian"}
 
 
 # ---- CPU baseline: the oracle on this box's host cores ------------

@@ -74,7 +74,9 @@ typedef enum mm_rmetric { /* position-dependent metric of a RiemannianMetricSyst
   MM_RMETRIC_RANK1 = 1,    /* M(q) = B + q q^T / D, params B[D*D]; DenseRiemannianMetricSystem     */
   MM_RMETRIC_DIAGQUAD = 2, /* M(q) = diag(1 + q^2) held dense;     DenseRiemannianMetricSystem     */
   MM_RMETRIC_SOFTABS = 3,  /* SoftAbs of the target Hessian, params coeff; SoftAbsRiemannianMetricSystem */
-  MM_RMETRIC_USER = 100    /* user-supplied device code: mm_model_create_from_source, dim <= 279, params: any */
+  MM_RMETRIC_USER = 100,   /* user-supplied device code: mm_model_create_from_source, dim <= 279, params: any */
+  MM_RMETRIC_SOFTABS_USER = 101 /* SoftAbs of a USER Hessian (hess_neg_log_dens / mtp_neg_log_dens as device code, dense):
+                                   mm_model_create_from_source, dim <= 64, params coeff then the user's own */
 } mm_rmetric;
 
 typedef enum mm_constr { /* holonomic constraint, C = 1 */
@@ -228,7 +230,15 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* desc, mm_model** out);
  *    wave (dim <= 64) / team (dim <= 279) kernels.  mm_implicit_leapfrog, mm_implicit_midpoint, mm_hamiltonian,
  *    mm_dh_dmom, mm_sample_momentum, mm_momentum_refresh* and mm_metropolis_accept* work on such a model; the target
  *    may be built in or user code as well.  Compiled code objects are cached under MICI_AMD_RTC_CACHE (default
- *    ~/.cache/mici_amd/rtc; "off" disables). */
+ *    ~/.cache/mici_amd/rtc; "off" disables); `python -m mici_amd.precompile` produces them ahead of time, without a GPU.
+ *  * desc->rmetric == MM_RMETRIC_SOFTABS_USER - `hess_neg_log_dens` / `mtp_neg_log_dens` of a
+ *    SoftAbsRiemannianMetricSystem (systems.py:1737-1920), dim <= 64; rmetric_params = softabs_coeff, then the user's:
+ *        __device__ double mm_user_hess(const double* q, int i, int j, int dim, const double* params);   // H(q)_ij
+ *        __device__ double mm_user_mtp(const double* q, const MmMat& M, int k, int dim, const double* params);
+ *        // element k of mtp_neg_log_dens(q)(M) = sum_ij M(i, j) d3 nld / dq_i dq_j dq_k;  M(i, j) reads the symmetric argument
+ *    Nothing is assumed about the Hessian's structure (csrc/user_hessian.h): the eigendecompositions and the
+ *    V f(lambda) V^T arguments of the matrix-Tressian product are formed in full on the matrix cores.  The target is
+ *    built in or user code; the same entry points as for the built-in SoftAbs system work on such a model. */
 int mm_model_create_from_source(mm_ctx* ctx, const mm_model_desc* desc, const char* hip_source, mm_model** out);
 int mm_model_destroy(mm_model* model);
 

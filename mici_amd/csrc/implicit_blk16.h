@@ -230,6 +230,15 @@ __device__ __forceinline__ double row_reduce16(const d4 rs, const int j) {
   return kk;
 }
 
+// the workgroup as a team (user_metric.h mm_user_prepare)
+struct Team16 {
+  double* red;
+  int tid;
+  __device__ __forceinline__ int rank() const { return tid; }
+  __device__ __forceinline__ int size() const { return NTHR; }
+  __device__ __forceinline__ double sum(double x) const { return uniform_f64(team_reduce(x, 0, red)); }
+};
+
 template <int RMETRIC, bool PROFILE = false>
 struct TeamBlk16 {
   static constexpr bool kSolveByInverse = false;
@@ -407,7 +416,7 @@ struct TeamBlk16 {
       // user's metric_func entry by entry (zero on the padding; its diagonal is set to 1 below)
       if (tid < DPM) lds[kOffUq + tid] = lds[kOffNat + tid];
       __syncthreads();
-      mmuser::prepare(lds + kOffUq, dim, base, lds + kOffUaq, tid, NTHR);
+      mmuser::prepare(Team16{lds + kOffRed, (int)tid}, lds + kOffUq, dim, base, lds + kOffUaq);
       __syncthreads();
 #pragma unroll
       for (int s = 0; s < NSLOT; ++s) {
@@ -463,7 +472,7 @@ struct TeamBlk16 {
     if (tid < DPM) lds[kOffXnat + tid] = tid < dim ? x : 0.0;  // built-in metrics: read back by the same thread only
     if constexpr (RMETRIC == MM_RMETRIC_USER) {  // the user's hooks read the whole point: publish it, then its aux block
       __syncthreads();
-      mmuser::prepare(lds + kOffXnat, dim, base, lds + kOffUax, tid, NTHR);
+      mmuser::prepare(Team16{lds + kOffRed, (int)tid}, lds + kOffXnat, dim, base, lds + kOffUax);
       __syncthreads();
     }
   }

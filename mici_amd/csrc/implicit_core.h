@@ -232,6 +232,7 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
   // explicit inverse that came out numerically indefinite - must not read as "converged" (it would return the
   // unrefined guess and skip the factorisation, which is what reports the reference's error)
   bool ok = rz >= 0.0 && rz <= kRefineTol2 * fabs(pu);
+  if (!(fabs(pu) > 0.0)) pu = rz;  // (a zero first guess: the test becomes relative to the first residual)
   if (!ok && rz > 0.0) {
     bk.rslot(RS_D) = z;
 #pragma unroll 1
@@ -250,8 +251,9 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
       z = bk.matvec(rv);
       prof(bk, PH_RSUM);
       ++pairs;
-      double rz2;
-      bk.sum2(rv * z, rhs * u, &rz2, &pu);
+      // (the scale p^T u of the relative test stays the first guess' - the guess is good to 1e-2 or better and the test
+      // is relative: on the wave backends a team sum is ~40 dependent DPP / readlane steps, one per pair saved)
+      const double rz2 = bk.sum1(rv * z);
       if (!(rz2 >= 0.0)) break;  // F not positive definite along r (or NaN): refinement failure -> factorisation
       if (rz2 <= kRefineTol2 * fabs(pu)) {
         ok = true;

@@ -117,7 +117,7 @@ struct MfmaBackend {
     if constexpr (RMETRIC == MM_RMETRIC_USER) {  // the point in natural order for the user's hooks, then its aux block
       w.uq[lane] = xm;
       wave_sync();
-      mmuser::prepare(w.uq, dim, uparams, w.uaq, lane, 64);
+      mmuser::prepare(mmuser::WaveTeam{lane}, w.uq, dim, uparams, w.uaq);
     }
     wave_sync();
     const double inv_d = 1.0 / (double)dim;
@@ -193,13 +193,26 @@ struct MfmaBackend {
   __device__ __forceinline__ double sum1(double a) { return wave_sum(lane < dim ? a : 0.0); }
   // M(x) v in the form that suits the metric:  rank-one update  B v + x (x . v) / D  (B's tiles from LDS, contracted
   // like matvec() contracts the register tiles);  diag(1 + x^2): per lane
+  // user metric: the tiles of M(x) at the products' point, evaluated ONCE per refinement solve (its 2 - 8 products are all at
+  // that point) and kept in registers next to the inverse - dead again before anything else of the step runs
+  d4 mx_[RMETRIC == MM_RMETRIC_USER ? kTiles : 1];
   __device__ __forceinline__ void metric_point(double x) {
     w.qt[lane] = (lane < dim) ? x : 0.0;
     if constexpr (RMETRIC == MM_RMETRIC_USER) {  // the products' point in natural order and its aux block
       w.ux[lane] = (lane < dim) ? x : 0.0;
       wave_sync();
-      mmuser::prepare(w.ux, dim, uparams, w.uax, lane, 64);
+      mmuser::prepare(mmuser::WaveTeam{lane}, w.ux, dim, uparams, w.uax);
       wave_sync();
+      const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+      for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + 4 * r + g, jj = 16 * J + j;
+            mx_[tix(I, J)][r] = mmuser::entry_padded(w.ux, i, jj, dim, uparams, w.uax);
+          }
     }
   }
   // sixteen partial sums of a row, pairwise: a lone wave pays every dependent add in full (a serial chain is 16 deep)
@@ -235,16 +248,8 @@ struct MfmaBackend {
       // cycles); the scheduling barrier keeps the compiler from sinking them back to their uses
       d4 m[10];
       if constexpr (RMETRIC == MM_RMETRIC_USER) {
-        // the user's metric_func at the products' point, entry by entry (the tiles keep M(x0)^-1: nothing is stored)
 #pragma unroll
-        for (int I = 0; I < 4; ++I)
-#pragma unroll
-          for (int J = 0; J <= I; ++J)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int i = 16 * I + 4 * r + g, jj = 16 * J + j;
-              m[tix(I, J)][r] = mmuser::entry_padded(w.ux, i, jj, dim, uparams, w.uax);
-            }
+        for (int t = 0; t < 10; ++t) m[t] = mx_[t];  // the user's metric_func at the products' point: metric_point()
       } else {
 #pragma unroll
         for (int t = 0; t < 10; ++t) {

@@ -95,6 +95,16 @@ __device__ __forceinline__ double block_reduce(double v, int kind_max, double* r
   return r;
 }
 
+// the workgroup as a team (user_metric.h mm_user_prepare)
+template <class C>
+struct TeamOf {
+  double* red;
+  int tid;
+  __device__ __forceinline__ int rank() const { return tid; }
+  __device__ __forceinline__ int size() const { return C::NT; }
+  __device__ __forceinline__ double sum(double x) const { return block_reduce<C>(x, 0, red); }
+};
+
 template <class C, int RMETRIC>
 struct BlockBackend {
   static constexpr bool kSolveByInverse = true;  // implicit_core.h: solve = invert + mat-vec, one construction site
@@ -138,7 +148,7 @@ struct BlockBackend {
     if constexpr (RMETRIC == MM_RMETRIC_USER) {  // the point in natural order for the user's hooks, then its aux block
       if (tid < VL) w.uq[tid] = (tid < dim) ? x : 0.0;
       __syncthreads();
-      mmuser::prepare(w.uq, dim, base, w.uaq, tid, NT);
+      mmuser::prepare(TeamOf<C>{w.red, tid}, w.uq, dim, base, w.uaq);
     }
     __syncthreads();
     double chk = 0.0;

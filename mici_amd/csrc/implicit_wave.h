@@ -248,7 +248,7 @@ __device__ __forceinline__ bool build_metric(double (&T)[TS][TS], double q, int 
   if constexpr (RMETRIC == MM_RMETRIC_USER) {  // the point in natural order for the user's hooks, then its aux block
     w.uq[lane] = (lane < dim) ? q : 0.0;
     wave_sync();
-    mmuser::prepare(w.uq, dim, base_lds, w.uaq, lane, 64);
+    mmuser::prepare(mmuser::WaveTeam{lane}, w.uq, dim, base_lds, w.uaq);
   }
   wave_sync();
   double qr[TS], qc[TS];
@@ -396,7 +396,7 @@ struct WaveBackend {
     if constexpr (RMETRIC == MM_RMETRIC_USER) {  // the products' point in natural order and its aux block
       w.ux[lane] = xpt_;
       wave_sync();
-      mmuser::prepare(w.ux, dim, base_lds, w.uax, lane, 64);
+      mmuser::prepare(mmuser::WaveTeam{lane}, w.ux, dim, base_lds, w.uax);
       wave_sync();
     }
   }

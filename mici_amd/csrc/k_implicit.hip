@@ -204,7 +204,7 @@ int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, dou
                                 const mm_fp_opts& opts, mm_counters* d_counters) {
   if (m->rmetric == MM_RMETRIC_USER)
     return launch_user_metric(ctx, m, s, 0, h, n_steps, &opts, d_counters, nullptr, nullptr);
-  if (m->rmetric == MM_RMETRIC_SOFTABS)
+  if (m->rmetric == MM_RMETRIC_SOFTABS || m->rmetric == MM_RMETRIC_SOFTABS_USER)
     return mm_launch_softabs_leapfrog(ctx, m, s, h, n_steps, opts, d_counters);
   // D <= 32: one wave per chain, rank-1 sweep on the VALU (this file).  32 < D <= 64: one wave per chain,
   // blocked sweep on the matrix cores (k_implicit_mfma.hip).  D > 64: a team of waves shares the chain's
@@ -237,7 +237,8 @@ int mm_launch_implicit_midpoint_riemann(mm_ctx* ctx, const mm_model* m, mm_state
                                         const mm_fp_opts& opts, mm_counters* d_counters) {
   if (m->rmetric == MM_RMETRIC_USER)
     return launch_user_metric(ctx, m, s, 1, h, n_steps, &opts, d_counters, nullptr, nullptr);
-  if (m->rmetric == MM_RMETRIC_SOFTABS) return mm_launch_softabs_midpoint(ctx, m, s, h, n_steps, opts, d_counters);
+  if (m->rmetric == MM_RMETRIC_SOFTABS || m->rmetric == MM_RMETRIC_SOFTABS_USER)
+    return mm_launch_softabs_midpoint(ctx, m, s, h, n_steps, opts, d_counters);
   if (m->dim > 64) return mm_launch_implicit_midpoint_large(ctx, m, s, h, n_steps, opts, d_counters);
   ImplicitArgs a = make_args(m, s);
   a.step_size = h;
@@ -250,7 +251,8 @@ int mm_launch_implicit_midpoint_riemann(mm_ctx* ctx, const mm_model* m, mm_state
 int mm_launch_riemann_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* d_out,
                           const double* d_z) {
   if (m->rmetric == MM_RMETRIC_USER) return launch_user_metric(ctx, m, s, 2 + op, 0.0, 0, nullptr, nullptr, d_out, d_z);
-  if (m->rmetric == MM_RMETRIC_SOFTABS) return mm_launch_softabs_aux(ctx, m, s, op, d_out, d_z);
+  if (m->rmetric == MM_RMETRIC_SOFTABS || m->rmetric == MM_RMETRIC_SOFTABS_USER)
+    return mm_launch_softabs_aux(ctx, m, s, op, d_out, d_z);
   if (m->dim > 64) return mm_launch_riemann_aux_large(ctx, m, s, op, d_out, d_z);
   ImplicitArgs a = make_args(m, s);
   a.out = d_out;

@@ -245,7 +245,8 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
 int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
   MM_REQUIRE(nullptr, ctx != nullptr, "mm_model_create: ctx is NULL");
   MM_REQUIRE(ctx, d != nullptr && out != nullptr, "mm_model_create: NULL argument");
-  MM_REQUIRE(ctx, d->target != MM_TARGET_USER && d->constr != MM_CONSTR_USER && d->rmetric != MM_RMETRIC_USER,
+  MM_REQUIRE(ctx, d->target != MM_TARGET_USER && d->constr != MM_CONSTR_USER && d->rmetric != MM_RMETRIC_USER &&
+                      d->rmetric != MM_RMETRIC_SOFTABS_USER,
              "mm_model_create: user code (MM_TARGET_USER / MM_CONSTR_USER / MM_RMETRIC_USER) needs "
              "mm_model_create_from_source");
   return model_create(ctx, d, nullptr, out);
@@ -254,9 +255,12 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* d, mm_model** out) {
 int mm_model_create_from_source(mm_ctx* ctx, const mm_model_desc* d, const char* hip_source, mm_model** out) {
   MM_REQUIRE(nullptr, ctx != nullptr, "mm_model_create_from_source: ctx is NULL");
   MM_REQUIRE(ctx, d != nullptr && out != nullptr && hip_source != nullptr, "mm_model_create_from_source: NULL argument");
-  MM_REQUIRE(ctx, d->target == MM_TARGET_USER || d->constr == MM_CONSTR_USER || d->rmetric == MM_RMETRIC_USER,
+  MM_REQUIRE(ctx, d->target == MM_TARGET_USER || d->constr == MM_CONSTR_USER || d->rmetric == MM_RMETRIC_USER ||
+                      d->rmetric == MM_RMETRIC_SOFTABS_USER,
              "mm_model_create_from_source: one of desc->target / constr / rmetric must be the _USER id");
-  MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE || d->rmetric == MM_RMETRIC_USER,
+  MM_REQUIRE(ctx, d->rmetric != MM_RMETRIC_SOFTABS_USER || d->dim <= 64,
+             "mm_model_create_from_source: a SoftAbs system with a user Hessian runs on the LDS-resident kernel, dim <= 64");
+  MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE || d->rmetric == MM_RMETRIC_USER || d->rmetric == MM_RMETRIC_SOFTABS_USER,
              "mm_model_create_from_source: a user target on a Riemannian system needs a user metric too (the built-in "
              "metrics' kernels are compiled ahead of time around the built-in targets)");
   MM_REQUIRE(ctx, d->rmetric != MM_RMETRIC_USER || d->dim <= 279,
@@ -296,6 +300,7 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
                   : d->rmetric == MM_RMETRIC_DIAGQUAD ? 0
                   : d->rmetric == MM_RMETRIC_SOFTABS  ? 1
                   : d->rmetric == MM_RMETRIC_USER     ? d->n_rmetric_params
+                  : d->rmetric == MM_RMETRIC_SOFTABS_USER ? (d->n_rmetric_params >= 1 ? d->n_rmetric_params : (size_t)-1)
                                                       : (size_t)-1;
   MM_REQUIRE(ctx, need_r != (size_t)-1, "mm_model_create: unknown Riemannian metric id");
   MM_REQUIRE(ctx, d->n_rmetric_params == need_r && (need_r == 0 || d->rmetric_params),
@@ -339,7 +344,7 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
   MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE || d->target != MM_TARGET_TORUS,
              "mm_model_create: the torus target is only defined for constrained systems");
   MM_REQUIRE(ctx, d->target != MM_TARGET_FUNNEL || d->rmetric == MM_RMETRIC_NONE ||
-                      d->rmetric == MM_RMETRIC_SOFTABS,
+                      d->rmetric == MM_RMETRIC_SOFTABS || d->rmetric == MM_RMETRIC_SOFTABS_USER,
              "mm_model_create: the funnel target pairs with a fixed metric or the SoftAbs metric");
   if (d->target == MM_TARGET_FUNNEL && d->constr != MM_CONSTR_NONE) {  // (built-in and user constraints alike)
     mm_set_error(ctx, "mm_model_create: the funnel target is not available on constrained systems (its gradient is a "
@@ -353,6 +358,8 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
              "mm_model_create: dens_wrt_ambient must be 0 or 1");
   MM_REQUIRE(ctx, !d->dens_wrt_ambient || d->constr != MM_CONSTR_NONE,
              "mm_model_create: dens_wrt_ambient needs a constraint");
+  if (d->rmetric == MM_RMETRIC_SOFTABS_USER)
+    MM_REQUIRE(ctx, d->rmetric_params[0] > 0.0, "softabs_coeff must be positive");  // matrices.py:1652-1654
   if (d->rmetric == MM_RMETRIC_SOFTABS) {
     MM_REQUIRE(ctx, d->rmetric_params[0] > 0.0, "softabs_coeff must be positive");  // matrices.py:1652-1654
     MM_REQUIRE(ctx, d->target == MM_TARGET_FUNNEL || d->target == MM_TARGET_POLY,
@@ -452,6 +459,7 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
   // user code: the Euclidean wave-per-chain kernels around a user target (h, unconstrained integrators), and for a
   // constrained system the constrained-leapfrog core around the user constraint and / or target
   if (rc == MM_OK && user_src && d->rmetric == MM_RMETRIC_USER) rc = mm_rtc_attach_riemann(ctx, m, user_src);
+  if (rc == MM_OK && user_src && d->rmetric == MM_RMETRIC_SOFTABS_USER) rc = mm_rtc_attach_softabs(ctx, m, user_src);
   if (rc == MM_OK && user_src && d->target == MM_TARGET_USER && d->rmetric == MM_RMETRIC_NONE)
     rc = mm_rtc_attach(ctx, m, user_src);
   if (rc == MM_OK && user_src && d->constr != MM_CONSTR_NONE) rc = mm_rtc_attach_constrained(ctx, m, user_src);

@@ -67,6 +67,8 @@ struct mm_model {
   // matrix-core step kernels on their first launch.  fn: step, midpoint, h, dh_dmom, sample_momentum.
   void* rtc_riem_module[4] = {nullptr, nullptr, nullptr, nullptr};
   void* rtc_riem_fn[4][5] = {};
+  void* rtc_softabs_module = nullptr;  // SoftAbs system with a user Hessian: softabs.h compiled around it
+  void* rtc_softabs_fn[3] = {nullptr, nullptr, nullptr};  // leapfrog step, midpoint step, aux (h / dh_dmom / sample_momentum)
   std::string user_src;        // the user's text (kept for the families compiled later)
   int user_aux = 0;            // MM_USER_AUX of the user's text (0: none)
   bool user_flat_vjp = false;  // MM_USER_VJP_FLAT
@@ -148,6 +150,10 @@ int mm_rtc_attach_constrained(mm_ctx* ctx, mm_model* m, const char* user_src);
 int mm_rtc_attach_riemann(mm_ctx* ctx, mm_model* m, const char* user_src);
 enum { MM_RTC_FAM_WAVE = 0, MM_RTC_FAM_MFMA = 1, MM_RTC_FAM_TEAM = 2, MM_RTC_FAM_BLK16 = 3 };
 int mm_rtc_launch_riemann(mm_ctx* ctx, const mm_model* m, mm_state* s, int which, void* implicit_args);
+int mm_rtc_attach_softabs(mm_ctx* ctx, mm_model* m, const char* user_src);
+// which: 0 = leapfrog step, 1 = midpoint step (args: mmsoftabs::SaArgs), 2 = aux (SaArgs, double* out, const double* z)
+int mm_rtc_launch_softabs(mm_ctx* ctx, const mm_model* m, int which, void* sa_args, int64_t n_chains, double* d_out,
+                          const double* d_z);
 int mm_state_ensure_work(mm_ctx* ctx, mm_state* s, size_t bytes);  // grows s->d_work (per-chain global workspace)
 int mm_rtc_launch_constrained(mm_ctx* ctx, const mm_model* m, int which, void* con_args, int64_t n_chains, double* d_out);
 int mm_rtc_launch_integrate(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_comp_coefs* cf);

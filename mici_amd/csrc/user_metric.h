@@ -10,14 +10,19 @@
 //                                                            V(i, j) an accessor of the symmetric argument (MmMat)
 // and may opt into two things that decide how fast its system runs (each by a #define in the text, which the library finds
 // and hoists in front of its own headers):
-//   #define MM_USER_AUX n                                    n doubles (<= 288) of per-POINT precomputation shared by all
-//     void mm_user_prepare(q, dim, params, aux, t, nt)       entries: called once per evaluation point by every thread of
-//                                                            the chain's team (t of nt; a thread handles i = t, t + nt, ...
-//                                                            and may write any aux[.] - identical values from several
-//                                                            threads are fine); the metric / vjp hooks then take `aux`.
-//                                                            Without it an entry that needs sum_k q_k^2 recomputes it per
-//                                                            entry: D^3 work per construction, and per M(x) v product of
-//                                                            the refinement solves.
+//   #define MM_USER_AUX n                                    n doubles (<= 560) of per-POINT precomputation shared by all
+//     template <class Team>                                  entries, in LDS: called once per evaluation point by EVERY
+//     void mm_user_prepare(Team& tm, q, dim, params, aux)    thread of the chain's team - tm.rank() of tm.size(); a thread
+//                                                            handles i = rank, rank + size, ... and may write any aux[.]
+//                                                            (identical values from several threads are fine); tm.sum(x) is
+//                                                            a team collective (every thread calls it, idle ones with 0):
+//                                                            |q|^2 is one wave reduction, not a 64-step loop.  The metric /
+//                                                            vjp hooks then take `aux`.  Put there what every entry needs -
+//                                                            sums over q, transcendental functions of q_i, and (D <= 64,
+//                                                            where a lone wave cannot hide a global load) the parameters
+//                                                            themselves.  Without it an entry that needs sum_k q_k^2
+//                                                            recomputes it per entry: D^3 work per construction, and per
+//                                                            M(x) v product of the refinement solves.
 //   #define MM_USER_VJP_FLAT                                 the vector-Jacobian product in TEAM form:
 //     template <class Ops> double mm_user_vjp_flat(Ops& V, q, k, dim, params, aux)
 //                                                            called by EVERY thread of the team with its own k (k >= dim:
@@ -42,16 +47,20 @@
 // A symmetric D x D matrix handed to the user's vector-Jacobian product: V(i, j).  Either an explicit dense matrix
 // (the inverse metric: grad_log_abs_det, matrices.py:1175-1177) or the rank-one -u u^T (grad_quadratic_form_inv,
 // matrices.py:1179-1181).
+#ifndef MM_MMMAT_DEFINED
+#define MM_MMMAT_DEFINED 1
 struct MmMat {
   const double* a;  // explicit: a[i * ld + j]; nullptr for the rank-one form
   const double* u;
   int ld;
   __device__ __forceinline__ double operator()(int i, int j) const { return a ? a[i * ld + j] : -(u[i] * u[j]); }
 };
+#endif
 
 #ifdef MM_USER_AUX
-static_assert(MM_USER_AUX >= 1 && MM_USER_AUX <= 288, "MM_USER_AUX: 1 .. 288 doubles");
-__device__ void mm_user_prepare(const double* q, int dim, const double* params, double* aux, int t, int nt);
+static_assert(MM_USER_AUX >= 1 && MM_USER_AUX <= 560, "MM_USER_AUX: 1 .. 560 doubles");
+template <class Team>
+__device__ void mm_user_prepare(Team& tm, const double* q, int dim, const double* params, double* aux);
 __device__ double mm_user_metric(const double* q, int i, int j, int dim, const double* params, const double* aux);
 #else
 __device__ double mm_user_metric(const double* q, int i, int j, int dim, const double* params);
@@ -100,11 +109,12 @@ __device__ __forceinline__ double entry_padded(const double* q, int i, int j, in
   const double v = entry(q, ic, jc, dim, params, aux);
   return (i < dim && j < dim) ? v : 0.0;
 }
-// every thread of the team calls this (t of nt) BETWEEN two team synchronisations of the caller: q is published before,
-// aux is read after
-__device__ __forceinline__ void prepare(const double* q, int dim, const double* params, double* aux, int t, int nt) {
+// every thread of the team calls this BETWEEN two team synchronisations of the caller: q is published before, aux is read
+// after.  Team: rank(), size(), sum(x) (a collective of the whole team)
+template <class Team>
+__device__ __forceinline__ void prepare(Team tm, const double* q, int dim, const double* params, double* aux) {
 #ifdef MM_USER_AUX
-  ::mm_user_prepare(q, dim, params, aux, t, nt);
+  ::mm_user_prepare(tm, q, dim, params, aux);
 #endif
 }
 // element k of vjp_metric_func(q)(V) through the dense accessor
@@ -133,12 +143,21 @@ constexpr bool kFlatVjp = false;
 __host__ __device__ constexpr int lds_doubles(int) { return 0; }
 __device__ __forceinline__ double entry(const double*, int, int, int, const double*, const double*) { return 0.0; }
 __device__ __forceinline__ double entry_padded(const double*, int, int, int, const double*, const double*) { return 0.0; }
-__device__ __forceinline__ void prepare(const double*, int, const double*, double*, int, int) {}
+template <class Team>
+__device__ __forceinline__ void prepare(Team, const double*, int, const double*, double*) {}
 template <class M>
 __device__ __forceinline__ double vjp_dense(const double*, const M&, int, int, const double*, const double*) { return 0.0; }
 template <class Ops>
 __device__ __forceinline__ double vjp_flat(Ops&, const double*, int, int, const double*, const double*) { return 0.0; }
 #endif
+
+// one wave as a team (the wave-per-chain backends)
+struct WaveTeam {
+  int lane;
+  __device__ __forceinline__ int rank() const { return lane; }
+  __device__ __forceinline__ int size() const { return 64; }
+  __device__ __forceinline__ double sum(double x) const { return mmdev::wave_sum(x); }
+};
 
 // The team form of the symmetric argument of a vector-Jacobian product.  BK: a backend of implicit_core.h that also has
 // diag() (flat diagonal of the held explicit inverse), sum1() and flat_active().

@@ -140,6 +140,28 @@ class UserMetric(RiemannianMetric):
         self.source = source
 
 
+RMETRIC_SOFTABS_USER = 101
+
+
+class UserHessian:
+    """The Hessian of the target and its matrix-Tressian product defined by the USER as HIP device code - the device-side
+    form of the reference's ``hess_neg_log_dens`` / ``mtp_neg_log_dens`` constructor arguments of
+    ``SoftAbsRiemannianMetricSystem`` (systems.py:1737-1920).  ``source`` must define
+
+        __device__ double mm_user_hess(const double* q, int i, int j, int dim, const double* params);   // H(q)_ij
+        __device__ double mm_user_mtp(const double* q, const MmMat& M, int k, int dim, const double* params);
+        // element k of mtp_neg_log_dens(q)(M) = sum_ij M(i, j) d3 nld / dq_i dq_j dq_k for a symmetric M read as M(i, j)
+
+    and is compiled for gfx950 (hipRTC) with the library's SoftAbs kernels when the system's device model is created
+    (csrc/user_hessian.h).  Nothing is assumed about the Hessian's structure.  ``dim`` <= 64."""
+
+    def __init__(self, source, params=()):
+        if not isinstance(source, str) or "mm_user_hess" not in source or "mm_user_mtp" not in source:
+            raise ValueError("source must define mm_user_hess and mm_user_mtp (see the class docstring)")
+        self.source = source
+        self.params = _f64(params).ravel()
+
+
 class Rank1Metric(RiemannianMetric):
     """M(q) = B + q q^T / D."""
 

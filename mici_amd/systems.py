@@ -239,20 +239,30 @@ class DenseRiemannianMetricSystem(System):
 
 
 class SoftAbsRiemannianMetricSystem(System):
-    """SoftAbs-regularised Hessian metric (reference systems.py:1737-1920)."""
+    """SoftAbs-regularised Hessian metric (reference systems.py:1737-1920).  The built-in targets with a device Hessian
+    (funnel, poly) bring it themselves; for any other target ``hess_neg_log_dens`` takes a ``models.UserHessian`` - the
+    Hessian and its matrix-Tressian product as device code (the reference's ``hess_neg_log_dens`` / ``mtp_neg_log_dens``
+    callables), dense, dim <= 64."""
 
     _kind = "riemann"
 
     def __init__(self, neg_log_dens, *, grad_neg_log_dens=None, hess_neg_log_dens=None,
                  mtp_neg_log_dens=None, softabs_coeff=1.0, backend=None):
         super().__init__(neg_log_dens, grad_neg_log_dens, backend)
-        if hess_neg_log_dens is not None or mtp_neg_log_dens is not None:
-            raise ValueError("Hessian / MTP are supplied by the device model; leave them None")
+        if mtp_neg_log_dens is not None:
+            raise ValueError("the matrix-Tressian product comes with the device Hessian (models.UserHessian); leave it None")
+        if hess_neg_log_dens is not None and not isinstance(hess_neg_log_dens, models.UserHessian):
+            raise TypeError("hess_neg_log_dens must be a mici_amd.models.UserHessian (or None for a built-in device Hessian)")
         if softabs_coeff <= 0:
             raise ValueError("softabs_coeff must be positive.")
         self.softabs_coeff = float(softabs_coeff)
+        self.hessian = hess_neg_log_dens
 
     def _model_args(self):
+        if self.hessian is not None:
+            return dict(rmetric=models.RMETRIC_SOFTABS_USER,
+                        rmetric_params=np.concatenate([[self.softabs_coeff], self.hessian.params]),
+                        rmetric_source=self.hessian.source)
         return dict(rmetric=models.RMETRIC_SOFTABS, rmetric_params=[self.softabs_coeff])
 
 

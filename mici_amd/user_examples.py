@@ -19,31 +19,56 @@ __device__ double mm_user_vjp_flat(Ops& V, const double* q, int k, int dim, cons
 """
 
 # M(q) = diag(1 + softplus(q_i)) + c c^T (1 + |q|^2 / D), params = c[dim] (oracle/models.py SoftPlusRank1Metric - not built
-# into the device library).  |q|^2 and softplus(q_i) once per point (aux[0], aux[1 + i]); the vector-Jacobian product
-# V_kk sigmoid(q_k) + (c^T V c) 2 q_k / D through one mat-vec and one team sum.
+# into the device library).  Per point: |q|^2 by one team reduction (aux[0]), softplus(q_i) (aux[1 + i]) and the parameters
+# themselves (aux[1 + dim + i]: an entry then reads LDS only - at D <= 64 a lone wave cannot hide a global load); the
+# vector-Jacobian product V_kk sigmoid(q_k) + (c^T V c) 2 q_k / D through one mat-vec and one team sum.
 SOFTPLUS_RANK1_FAST = r"""
-#define MM_USER_AUX 66
+#define MM_USER_AUX 130
 #define MM_USER_VJP_FLAT
-__device__ void mm_user_prepare(const double* q, int dim, const double* params, double* aux, int t, int nt) {
-  if (t == 0) {
-    double s2 = 0.0;
-    for (int k = 0; k < dim; ++k) s2 += q[k] * q[k];
-    aux[0] = 1.0 + s2 / (double)dim;
+template <class Team>
+__device__ void mm_user_prepare(Team& tm, const double* q, int dim, const double* params, double* aux) {
+  double s2 = 0.0;
+  for (int i = tm.rank(); i < dim; i += tm.size()) {
+    s2 += q[i] * q[i];
+    aux[1 + i] = 1.0 + log1p(exp(q[i]));
+    aux[1 + dim + i] = params[i];
   }
-  for (int i = t; i < dim; i += nt) aux[1 + i] = 1.0 + log1p(exp(q[i]));
+  s2 = tm.sum(s2);
+  if (tm.rank() == 0) aux[0] = 1.0 + s2 / (double)dim;
 }
 __device__ double mm_user_metric(const double* q, int i, int j, int dim, const double* params, const double* aux) {
-  const double v = params[i] * params[j] * aux[0], d = aux[1 + i];  // (d loaded unconditionally: no branch, user_metric.h)
+  const double v = aux[1 + dim + i] * aux[1 + dim + j] * aux[0], d = aux[1 + i];  // (d unconditionally: no branch)
   return i == j ? v + d : v;
 }
 template <class Ops>
 __device__ double mm_user_vjp_flat(Ops& V, const double* q, int k, int dim, const double* params, const double* aux) {
   const bool on = V.active();
-  const double ck = on ? params[k] : 0.0, qk = on ? q[k] : 0.0;
+  const double ck = on ? aux[1 + dim + k] : 0.0, qk = on ? q[k] : 0.0;
   const double cvc = V.sum(ck * V.matvec(ck));
   return V.diag() / (1.0 + exp(-qk)) + cvc * 2.0 * qk / (double)dim;
 }
 """
 
 # the same metric for every size the library takes (dim <= 279: aux sized for it)
-SOFTPLUS_RANK1_FAST_WIDE = SOFTPLUS_RANK1_FAST.replace("#define MM_USER_AUX 66", "#define MM_USER_AUX 288")
+SOFTPLUS_RANK1_FAST_WIDE = SOFTPLUS_RANK1_FAST.replace("#define MM_USER_AUX 130", "#define MM_USER_AUX 560")
+
+# Hessian and matrix-Tressian product of the built-in banana target (oracle/models.py Banana.hess / .mtp) for
+# SoftAbsRiemannianMetricSystem(models.Banana(D), hess_neg_log_dens=models.UserHessian(BANANA_HESS)): a TRIDIAGONAL Hessian,
+# i.e. a dense eigenproblem with none of the structure of the built-in device Hessians (bench.py c3b_dense).
+#   H_ii = 1/10 + 2 [i > 0] + (12 q_i^2 - 4 q_{i+1}) [i < D-1],   H_{i,i+1} = -4 q_i
+#   mtp(M)_k = 24 q_k M_kk [k < D-1] - 4 M_{k-1,k-1} [k > 0] - 4 (M_{k,k+1} + M_{k+1,k}) [k < D-1]
+BANANA_HESS = r"""
+__device__ double mm_user_hess(const double* q, int i, int j, int dim, const double* params) {
+  const int lo = i < j ? i : j, hi = i < j ? j : i, nx = lo + 1 < dim ? lo + 1 : lo;   // clamped: reads stay inside q
+  const double ql = q[lo], qn = q[nx];
+  const double diag = 0.1 + (lo > 0 ? 2.0 : 0.0) + (lo < dim - 1 ? 12.0 * ql * ql - 4.0 * qn : 0.0);
+  const double off = hi == lo + 1 ? -4.0 * ql : 0.0;
+  return hi == lo ? diag : off;
+}
+__device__ double mm_user_mtp(const double* q, const MmMat& M, int k, int dim, const double* params) {
+  const int kp = k + 1 < dim ? k + 1 : k, km = k > 0 ? k - 1 : 0;   // clamped: every read is inside the matrix
+  const double a = 24.0 * q[k] * M(k, k) - 4.0 * (M(k, kp) + M(kp, k));
+  const double b = -4.0 * M(km, km);
+  return (k < dim - 1 ? a : 0.0) + (k > 0 ? b : 0.0);
+}
+"""

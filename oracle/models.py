@@ -153,6 +153,31 @@ class Banana(Target):
         g[:-1] -= 4.0 * q[:-1] * r
         return g
 
+    # SoftAbs system on the banana (BASELINE c3 "banana/funnel"; systems.py:1870-1920): a TRIDIAGONAL Hessian, i.e. a
+    # dense eigenproblem with none of the arrowhead / diagonal structure of the other built-in Hessians - it reaches
+    # the device as user source (tests/user_sources.py BANANA_HESS).
+    #   H_ii = 1/10 + 2 [i > 0] + (12 q_i^2 - 4 q_{i+1}) [i < D-1],   H_{i,i+1} = -4 q_i
+    #   T_iii = 24 q_i [i < D-1],   T_{i,i,i+1} (and permutations) = -4
+    def hess(self, q):
+        d = q.shape[0]
+        h = np.zeros((d, d))
+        idx = np.arange(d)
+        h[idx, idx] = 0.1
+        h[idx[1:], idx[1:]] += 2.0
+        h[idx[:-1], idx[:-1]] += 12.0 * q[:-1] ** 2 - 4.0 * q[1:]
+        h[idx[:-1], idx[1:]] = -4.0 * q[:-1]
+        h[idx[1:], idx[:-1]] = -4.0 * q[:-1]
+        return h
+
+    def mtp(self, q):
+        def vjp(m):
+            dg = np.diagonal(m)
+            out = np.zeros_like(q)
+            out[:-1] += 24.0 * q[:-1] * dg[:-1] - 4.0 * (np.diagonal(m, 1) + np.diagonal(m, -1))
+            out[1:] += -4.0 * dg[:-1]
+            return out
+        return vjp
+
 
 class Funnel(Target):
     """Scaled funnel, q = (v, x_1..x_n): l = v^2/18 + n v/2 + exp(-v)/2 * sum(w x^2)."""

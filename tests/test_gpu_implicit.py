@@ -22,12 +22,22 @@ SOLVER = {0: solvers.solve_fixed_point_direct, 1: solvers.solve_fixed_point_stef
 NORM = {0: solvers.maximum_norm, 1: solvers.euclidean_norm}
 
 
+def softabs_system(target, coeff):
+    """SoftAbs system of a fixture: the funnel / poly targets bring their device Hessian, any other target's Hessian and
+    matrix-Tressian product reach the library as user source (round 4: the banana's tridiagonal Hessian - dense path)."""
+    hess = None
+    if target.tid == models.TARGET_BANANA:
+        from user_sources import BANANA_HESS
+        hess = models.UserHessian(BANANA_HESS)
+    return systems.SoftAbsRiemannianMetricSystem(target, softabs_coeff=coeff, hess_neg_log_dens=hess)
+
+
 def build(g, fast_source=False):
     n, d = g["q0"].shape
     target = models.target_from_id(g["target"], g["target_params"], d)
     mid = int(g["rmetric"])
     if mid == models.RMETRIC_SOFTABS:
-        system = systems.SoftAbsRiemannianMetricSystem(target, softabs_coeff=float(g["rmetric_params"][0]))
+        system = softabs_system(target, float(g["rmetric_params"][0]))
     elif mid == models.RMETRIC_USER:  # not built in: reaches the library as HIP source (hipRTC), tests/user_sources.py
         # plain form: entry-wise metric, accessor-form VJP; fast form: per-point aux + team-form VJP (csrc/user_metric.h)
         from user_sources import SOFTPLUS_RANK1, softplus_fast
@@ -282,7 +292,7 @@ def test_implicit_midpoint_matches_reference_fixture(name):
         mk = int(g["metric_kind"])
         system = systems.EuclideanMetricSystem(target, metric=None if mk == models.METRIC_IDENTITY else g["metric"])
     elif str(g["system"]) == "softabs":
-        system = systems.SoftAbsRiemannianMetricSystem(target, softabs_coeff=float(g["rmetric_params"][0]))
+        system = softabs_system(target, float(g["rmetric_params"][0]))
     else:
         system = systems.DenseRiemannianMetricSystem(target, models.rmetric_from_id(g["rmetric"], g["rmetric_params"], d))
     norm = {0: solvers.maximum_norm, 1: solvers.euclidean_norm}[int(g["norm"])]

@@ -400,3 +400,86 @@ def test_user_metric_beyond_64_dimensions_matches_oracle(dim):
                 assert so == 0 and no == steps
                 assert_close(q[k], qo, 1e-10, f"{cls.__name__} q chain {k}")
                 assert_close(p[k], po, 1e-10, f"{cls.__name__} p chain {k}")
+
+
+# ---- round 4 (VERDICT r03 #1b): user HESSIANS - SoftAbsRiemannianMetricSystem with hess_neg_log_dens / mtp_neg_log_dens as
+#      device code (systems.py:1737-1920), the dense SoftAbs path (csrc/softabs.h USERH, csrc/user_hessian.h) --------------
+def test_user_hessian_errors_fail_loudly():
+    from user_sources import BANANA_HESS
+
+    with pytest.raises(ValueError):
+        models.UserHessian("__device__ double f() { return 0; }")
+    with pytest.raises(TypeError):
+        systems.SoftAbsRiemannianMetricSystem(models.Banana(5), hess_neg_log_dens=lambda q: q)
+    bad = models.UserHessian(BANANA_HESS.replace("return hi == lo ? diag : off;", "return hi == lo ? diag : undefined_off;"))
+    with pytest.raises(DeviceError, match="undefined_off"):
+        systems.SoftAbsRiemannianMetricSystem(models.Banana(5), hess_neg_log_dens=bad).device_model()
+    with pytest.raises(DeviceError, match="dim <= 64"):
+        systems.SoftAbsRiemannianMetricSystem(models.Banana(70), hess_neg_log_dens=models.UserHessian(BANANA_HESS)).device_model()
+    with pytest.raises(DeviceError, match="Hessian"):  # the banana has no built-in device Hessian
+        systems.SoftAbsRiemannianMetricSystem(models.Banana(5)).device_model()
+
+
+@pytest.mark.parametrize("dim", [7, 33, 64])
+def test_builtin_funnel_hessian_as_user_source_matches_the_builtin(dim):
+    """The scaled funnel's Hessian and matrix-Tressian product as user source run the DENSE SoftAbs path (matrix-core
+    G = A X, grad_log_abs_det / grad_quadratic_form_inv formed in full); the built-in path exploits the arrowhead structure
+    and never forms them.  Same statuses, step counts and fixed-point evaluation counts; states to 2e-9 (eigenvector
+    bases differ, and the divided differences of grad_quadratic_form_inv amplify that)."""
+    from user_sources import FUNNEL_HESS
+
+    rng = np.random.default_rng(dim)
+    n = 6
+    w = np.linspace(0.5, 2.0, dim - 1)
+    builtin = systems.SoftAbsRiemannianMetricSystem(models.Funnel(w), softabs_coeff=1.0)
+    user = systems.SoftAbsRiemannianMetricSystem(models.Funnel(w), softabs_coeff=1.0,
+                                                 hess_neg_log_dens=models.UserHessian(FUNNEL_HESS, w))
+    q0 = 0.7 * rng.standard_normal((n, dim))
+    z = rng.standard_normal((n, dim))
+    p0 = builtin.sample_momentum_batch(q0, z)
+    assert_close(user.sample_momentum_batch(q0, z), p0, 1e-10, "sample_momentum")
+    assert_close(user.h_batch(q0, p0), builtin.h_batch(q0, p0), 1e-10, "h")
+    assert_close(user.dh_dmom_batch(q0, p0), builtin.dh_dmom_batch(q0, p0), 1e-10, "dh_dmom")
+    for cls, h, steps in ((integrators.ImplicitLeapfrogIntegrator, 0.02, 6), (integrators.ImplicitMidpointIntegrator, 0.02, 3)):
+        ib, iu = cls(builtin, h), cls(user, h)
+        qb, pb, sb, nb = ib.step_batch(q0, p0, 1, n_steps=steps)
+        qu, pu, su, nu = iu.step_batch(q0, p0, 1, n_steps=steps)
+        assert np.array_equal(sb, su) and np.array_equal(nb, nu) and np.all(sb == 0)
+        assert ib.last_counters["n_fp_evals"] == iu.last_counters["n_fp_evals"]
+        assert_close(qu, qb, 2e-9, f"{cls.__name__} positions")
+        assert_close(pu, pb, 2e-9, f"{cls.__name__} momenta")
+
+
+@pytest.mark.parametrize("dim", [9, 40, 64])
+def test_user_hessian_softabs_on_the_banana_matches_oracle(dim):
+    """SoftAbs on the banana (BASELINE c3 "banana/funnel"): a tridiagonal Hessian that is not built in.  h, dh_dmom,
+    sample_momentum, leapfrog and midpoint steps against the oracle; a launch of 12 steps equals 3 launches of 4 (the
+    eigenbasis carried between launches is only a starting point)."""
+    from user_sources import BANANA_HESS
+
+    rng = np.random.default_rng(100 + dim)
+    n = 5
+    system = systems.SoftAbsRiemannianMetricSystem(models.Banana(dim), softabs_coeff=1.0,
+                                                   hess_neg_log_dens=models.UserHessian(BANANA_HESS))
+    osys = orc.RiemannianSystem(omdl.Banana(dim), None, 1.0)
+    q0 = rng.standard_normal((n, dim))
+    z = rng.standard_normal((n, dim))
+    p0 = np.stack([osys.sample_momentum(orc._State(q0[k], None), z[k]) for k in range(n)])
+    assert_close(system.sample_momentum_batch(q0, z), p0, 1e-10, "sample_momentum")
+    assert_close(system.h_batch(q0, p0), [osys.h(orc._State(q0[k], p0[k])) for k in range(n)], 1e-10, "h")
+    assert_close(system.dh_dmom_batch(q0, p0), [osys.dh2_dmom(orc._State(q0[k], p0[k])) for k in range(n)], 1e-10, "dh_dmom")
+    for cls, ofn, h, steps in ((integrators.ImplicitLeapfrogIntegrator, orc.implicit_leapfrog_steps, 0.02, 12),
+                               (integrators.ImplicitMidpointIntegrator, orc.implicit_midpoint_steps, 0.02, 4)):
+        integ = cls(system, h)
+        q, p, st, nd = integ.step_batch(q0, p0, 1, n_steps=steps)
+        for k in range(n):
+            qo, po, so, no = ofn(osys, q0[k], p0[k], h, steps)
+            assert so == st[k] and no == nd[k]
+            assert_close(q[k], qo, 2e-9, f"{cls.__name__} q chain {k}")
+            assert_close(p[k], po, 2e-9, f"{cls.__name__} p chain {k}")
+        if cls is integrators.ImplicitLeapfrogIntegrator and np.all(st == 0):
+            qs, ps = q0, p0
+            for _ in range(3):
+                qs, ps, ss, _ = integ.step_batch(qs, ps, 1, n_steps=4)
+                assert np.all(ss == 0)
+            assert_close(qs, q, 2e-9, "3 launches of 4 steps vs one of 12")

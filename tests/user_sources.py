@@ -87,10 +87,40 @@ __device__ double mm_user_vjp(const double* q, const MmMat& V, int k, int dim, c
 # ---- round 4: the two opt-ins of csrc/user_metric.h (MM_USER_AUX, MM_USER_VJP_FLAT).  The texts live with the package
 # (mici_amd/user_examples.py: bench.py measures them as c3_user / c4_general): RANK1_AS_USER_FLAT must reproduce the built-in
 # kernels bit for bit; SOFTPLUS_RANK1_FAST is oracle/models.py SoftPlusRank1Metric with both opt-ins.
-from mici_amd.user_examples import RANK1_AS_USER_FLAT, SOFTPLUS_RANK1_FAST, SOFTPLUS_RANK1_FAST_WIDE  # noqa: E402,F401
+from mici_amd.user_examples import (BANANA_HESS, RANK1_AS_USER_FLAT, SOFTPLUS_RANK1_FAST,  # noqa: E402,F401
+                                    SOFTPLUS_RANK1_FAST_WIDE)
 
 SOFTPLUS_RANK1_FAST_256 = SOFTPLUS_RANK1_FAST_WIDE
 
 
 def softplus_fast(dim):
     return SOFTPLUS_RANK1_FAST if dim <= 64 else SOFTPLUS_RANK1_FAST_WIDE
+
+# the built-in scaled-funnel Hessian / matrix-Tressian product (csrc/softabs.h build_hessian / mtp_lds)
+# as user source: goes through the DENSE SoftAbs path and must agree with the built-in arrowhead path.  params = w[dim - 1]
+FUNNEL_HESS = r"""
+__device__ double mm_user_hess(const double* q, int i, int j, int dim, const double* params) {
+  const double e = exp(-q[0]);
+  double S = 0.0;
+  for (int k = 1; k < dim; ++k) S += params[k - 1] * q[k] * q[k];
+  const int lo = i < j ? i : j, hi = i < j ? j : i, h1 = hi > 0 ? hi : 1;
+  const double wh = params[h1 - 1], xh = q[h1];
+  const double vv = 1.0 / 9.0 + 0.5 * e * S, vi = -e * wh * xh, ii = e * wh;
+  return hi == 0 ? vv : (lo == 0 ? vi : (lo == hi ? ii : 0.0));
+}
+__device__ double mm_user_mtp(const double* q, const MmMat& M, int k, int dim, const double* params) {
+  const double e = exp(-q[0]), mvv = M(0, 0);
+  if (k == 0) {
+    double S = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int i = 1; i < dim; ++i) {
+      const double w = params[i - 1];
+      S += w * q[i] * q[i];
+      s2 += (M(0, i) + M(i, 0)) * w * q[i];
+      s3 += M(i, i) * w;
+    }
+    return -0.5 * e * S * mvv + e * s2 - e * s3;
+  }
+  const double w = params[k - 1];
+  return e * w * q[k] * mvv - e * w * (M(0, k) + M(k, 0));
+}
+"""

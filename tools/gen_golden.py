@@ -945,11 +945,12 @@ def main():
     add_midpoint_riemann("midpoint_riemann_rank1_banana_d100", mdl.Banana(100), mdl.Rank1Metric(mdl.make_spd(100, rng)),
                          3, 0.01, [1, 3])
 
-    def add_midpoint_softabs(name, target, coeff, n, h, cps, qscale=0.5, **kw):
-        q0 = qscale * rng.standard_normal((n, target.dim))
+    def add_midpoint_softabs(name, target, coeff, n, h, cps, qscale=0.5, r=None, **kw):
+        r = rng if r is None else r
+        q0 = qscale * r.standard_normal((n, target.dim))
         osys = orc.RiemannianSystem(target, None, coeff)
         p0 = np.stack([osys.sample_momentum(orc._State(q0[c], None), zz)
-                       for c, zz in enumerate(rng.standard_normal((n, target.dim)))])
+                       for c, zz in enumerate(r.standard_normal((n, target.dim)))])
 
         def make():
             rsys = mici.systems.SoftAbsRiemannianMetricSystem(
@@ -1186,6 +1187,15 @@ def main():
     wide_linear("constrained_c6_linear_gauss_d24", 24, 6, 4, mdl.METRIC_DENSE, 0.2, [1, 5, 20], variant="gaussian")
 
     # ---- SoftAbs systems beyond D = 64 (round 2: the NP = 128 instantiation of k_softabs.hip) ------------------------
+    # round 4: SoftAbs on the banana - a tridiagonal Hessian that is NOT built into the device library: it reaches it as
+    # user source (mici_amd/user_examples.py BANANA_HESS; hess_neg_log_dens / mtp_neg_log_dens, systems.py:1870-1920)
+    for nm, d, n, hh, cps, kw in (("softabs_user_banana_d9", 9, 5, 0.05, [1, 5, 20], {}),
+                                  ("softabs_user_banana_d40_steffensen", 40, 3, 0.03, [1, 5], dict(fp_solver=1)),
+                                  ("softabs_user_banana_d64", 64, 4, 0.02, [1, 5, 20], {}),
+                                  ("softabs_user_banana_d9_fail_bigstep", 9, 6, 0.7, [1, 3], dict(qscale=1.5))):
+        add_riemann(nm, mdl.Banana(d), None, 1.0, n, hh, cps, r=case_rng(nm), **kw)
+    add_midpoint_softabs("midpoint_softabs_user_banana_d16", mdl.Banana(16), 1.0, 3, 0.03, [1, 4],
+                         r=case_rng("midpoint_softabs_user_banana_d16"))
     add_riemann("softabs_funnel_d100", mdl.Funnel(np.linspace(0.5, 2.0, 99)), None, 1.0, 3, 0.02, [1, 4],
                 r=case_rng("softabs_funnel_d100"))
     add_riemann("softabs_poly_d72", mdl.Poly(72, 1.0, 1.0 / 3.0), None, 1.5, 3, 0.05, [1, 5],

@@ -16,8 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("MICI_AMD_RTC_CACHE", "off")
+os.environ.setdefault("MICI_AMD_RTC_SEED", "off")
 
-FAMS = {"wave": 0, "mfma": 1, "team": 2, "blk16": 3}
+FAMS = {"wave": 0, "mfma": 1, "team": 2, "blk16": 3, "softabs": 4}
 
 
 def resources(path):
