@@ -195,6 +195,7 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
         dim, h, traj = 64, 0.02, 100
         wts = np.linspace(0.5, 2.0, dim - 1)
         if config == "c3b_dense":
+            h = 0.01  # (at 0.02 half of the banana chains meet a ConvergenceError within 100 steps - in the reference too)
             from mici_amd import user_examples
             system = systems.SoftAbsRiemannianMetricSystem(
                 models.Banana(dim), softabs_coeff=1.0, hess_neg_log_dens=models.UserHessian(user_examples.BANANA_HESS))

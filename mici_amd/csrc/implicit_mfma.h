@@ -48,12 +48,15 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 constexpr int kWaves = MM_MFMA_WAVES_PER_BLOCK;  // chains per workgroup
 constexpr int kTiles = 10;     // lower-triangular 16 x 16 tiles of a 64 x 64 matrix
 constexpr int kPartStride = 17;
+constexpr int kRowPitch = 18;   // doubles per row of the tile -> row conversion buffer (16 columns + 2: 16-byte aligned rows,
+                                // conflict-free for the row owners' 16-byte reads)
+constexpr int kBasePitch = 66;  // doubles per row of the staged base matrix (64 + 2: the same two properties)
 // per-wave LDS (doubles): Qt[64][4], Wt[64][4], nat[64], vperm[64], aux[64], part[64][17], mpart[3][64],
 // stash[SL_COUNT_REFINE][64].  The refinement solves (implicit_core.h refine_solve) keep their scratch in Qt / Wt: no
 // sweep runs while one is in flight.
-constexpr int kMfmaWaveDoubles = 256 + 256 + 64 + 64 + 64 + 64 * kPartStride + 192 + SL_COUNT_REFINE * 64 + 16;
+constexpr int kMfmaWaveDoubles = 256 + 256 + 64 + 64 + 64 + 64 * kRowPitch + 192 + SL_COUNT_REFINE * 64 + 16;
 static_assert((1 + RS_COUNT) * 64 <= 512, "refinement scratch must fit Qt + Wt");
-constexpr int kBaseDoubles = kTiles * 4 * 64;  // staged base matrix of the rank-one metric
+constexpr int kBaseDoubles = 64 * kBasePitch;  // staged base matrix of the rank-one metric: full rows, zero padded
 
 __host__ __device__ constexpr int tix(int I, int J) { return I * (I + 1) / 2 + J; }
 
@@ -63,7 +66,7 @@ struct MLds {
   double* nat;    // [64] natural-order vector
   double* vperm;  // [4][4][4] = [I][g][r] copy of a vector for row operands
   double* aux;    // [64]
-  double* part;   // [64][17] direct partial sums of the mat-vec
+  double* part;   // [64][18] the tile -> row conversion buffer; [64][17] partial sums of the factored solve
   double* mpart;  // [3][4][16] mirrored partial sums
   double* stash;  // [SL_COUNT_REFINE][64]
   double* prof;   // [16] developer builds: phase clocks (implicit_core.h PH_*)
@@ -134,18 +137,18 @@ struct MfmaBackend {
       for (int J = 0; J <= I; ++J) {
         const int t = tix(I, J);
         if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-          const d2 b01 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 0) * 64 + lane) * 2);
-          const d2 b23 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 1) * 64 + lane) * 2);
+          const double* bt = base_lds + (16 * I + g) * kBasePitch + 16 * J + j;  // B[16 I + 4 r + g][16 J + j]
           const double qs = qc[J] * inv_d;
-          acc[t][0] = __builtin_fma(qr[I][0], qs, b01[0]);
-          acc[t][1] = __builtin_fma(qr[I][1], qs, b01[1]);
-          acc[t][2] = __builtin_fma(qr[I][2], qs, b23[0]);
-          acc[t][3] = __builtin_fma(qr[I][3], qs, b23[1]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fma(qr[I][r], qs, bt[4 * r * kBasePitch]);
         } else if constexpr (RMETRIC == MM_RMETRIC_USER) {
-          // the user's metric_func, entry by entry (zero on the padding; its diagonal is set to 1 below)
+          // the user's metric_func, entry by entry (zero on the padding; its diagonal is set to 1 below); the lane index
+          // laundered so that the entries' addresses are computed here, not hoisted out of the step loop
+          int og = g, oj = j;
+          asm volatile("" : "+v"(og), "+v"(oj));
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int i = 16 * I + 4 * r + g, jj = 16 * J + j;
+            const int i = 16 * I + 4 * r + og, jj = 16 * J + oj;
             acc[t][r] = mmuser::entry_padded(w.uq, i, jj, dim, uparams, w.uaq);
           }
         } else {
@@ -193,104 +196,109 @@ struct MfmaBackend {
   __device__ __forceinline__ double sum1(double a) { return wave_sum(lane < dim ? a : 0.0); }
   // M(x) v in the form that suits the metric:  rank-one update  B v + x (x . v) / D  (B's tiles from LDS, contracted
   // like matvec() contracts the register tiles);  diag(1 + x^2): per lane
-  // user metric: the tiles of M(x) at the products' point, evaluated ONCE per refinement solve (its 2 - 8 products are all at
-  // that point) and kept in registers next to the inverse - dead again before anything else of the step runs
-  d4 mx_[RMETRIC == MM_RMETRIC_USER ? kTiles : 1];
+  // ---- products in ROW form (round 4) -------------------------------------------------------------------------------
+  // A step applies the held inverse ~40 times (29 refinement pairs, the momentum solves, the half steps) and sweeps it
+  // once.  In the tile layout of the sweep a mat-vec is 64 multiply-adds a lane wrapped in two LDS round trips - operands
+  // out, 19 partial sums per lane back through LDS and a summation tree (1.4 k cycles, a fifth of them arithmetic).  After
+  // the sweep the inverse is therefore re-laid out ONCE, lane i taking row i (tiles_to_rows: 64 LDS stores and 32 16-byte
+  // loads a lane); a product is then the vector broadcast from LDS (sixteen 16-byte reads of one address) against 64
+  // registers: no partial sums, no reduction, the result already flat.  M(x) v of the refinement solves takes row i of
+  // the staged base matrix the same way (rank-one metric), or of the user's metric evaluated once per solve.
+  double fr_[64];  // row `lane` of M(x0)^-1 (the padding is the identity: zero off the diagonal)
+  double fd_;      // its diagonal entry
+  double mxr_[RMETRIC == MM_RMETRIC_USER ? 64 : 1];  // user metric: row `lane` of M(x) at the products' point
+
+  __device__ __forceinline__ void tiles_to_rows() {
+    const int g = lane >> 4, j = lane & 15;
+    double* buf = w.part;  // [64][kRowPitch]: one chunk of sixteen columns at a time
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int I = c; I < 4; ++I)  // tile (I, c): rows 16 I + 4 r + g, column 16 c + j
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf[(16 * I + 4 * r + g) * kRowPitch + j] = acc[tix(I, c)][r];
+#pragma unroll
+      for (int J = 0; J < c; ++J)  // tile (c, J) by symmetry: row 16 J + j, column 16 c + 4 r + g
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf[(16 * J + j) * kRowPitch + 4 * r + g] = acc[tix(c, J)][r];
+      wave_sync();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const d2 x = *reinterpret_cast<const d2*>(buf + lane * kRowPitch + 2 * k);
+        fr_[16 * c + 2 * k] = x[0];
+        fr_[16 * c + 2 * k + 1] = x[1];
+      }
+      if ((lane >> 4) == c) fd_ = buf[lane * kRowPitch + (lane & 15)];
+      wave_sync();
+    }
+  }
+
+  // y_lane = sum_j row[j] v_j with v broadcast from LDS (w.nat, zero beyond dim); four independent accumulators
+  __device__ __forceinline__ double row_dot(const double (&row)[64], double v) {
+    w.nat[lane] = (lane < dim) ? v : 0.0;
+    wave_sync();
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const d4 vv = *reinterpret_cast<const d4*>(w.nat + 4 * k);
+      y0 = __builtin_fma(row[4 * k], vv[0], y0);
+      y1 = __builtin_fma(row[4 * k + 1], vv[1], y1);
+      y2 = __builtin_fma(row[4 * k + 2], vv[2], y2);
+      y3 = __builtin_fma(row[4 * k + 3], vv[3], y3);
+    }
+    wave_sync();  // (the next product overwrites w.nat)
+    return (y0 + y1) + (y2 + y3);
+  }
+
   __device__ __forceinline__ void metric_point(double x) {
     w.qt[lane] = (lane < dim) ? x : 0.0;
-    if constexpr (RMETRIC == MM_RMETRIC_USER) {  // the products' point in natural order and its aux block
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {
+      // the products' point in natural order, its aux block, then row `lane` of the user's metric_func there - ONCE per
+      // refinement solve (its 2 - 8 products are all at that point), dead again before anything else of the step runs
       w.ux[lane] = (lane < dim) ? x : 0.0;
       wave_sync();
       mmuser::prepare(mmuser::WaveTeam{lane}, w.ux, dim, uparams, w.uax);
       wave_sync();
-      const int g = lane >> 4, j = lane & 15;
+      // (the lane index laundered: everything the entries' addresses derive from is loop invariant, and hoisted out of the
+      // step loop 64 of them - 128 registers - lived across the whole kernel in scratch)
+      int ol = lane;
+      asm volatile("" : "+v"(ol));
 #pragma unroll
-      for (int I = 0; I < 4; ++I)
-#pragma unroll
-        for (int J = 0; J <= I; ++J)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * I + 4 * r + g, jj = 16 * J + j;
-            mx_[tix(I, J)][r] = mmuser::entry_padded(w.ux, i, jj, dim, uparams, w.uax);
-          }
+      for (int jj = 0; jj < 64; ++jj) {
+        mxr_[jj] = mmuser::entry_padded(w.ux, ol, jj, dim, uparams, w.uax);
+        // eight entries at a time: left alone the scheduler hoists all 64 entries' operand loads to the top
+        if ((jj & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
     }
-  }
-  // sixteen partial sums of a row, pairwise: a lone wave pays every dependent add in full (a serial chain is 16 deep)
-  __device__ static __forceinline__ double sum16(const double* src) {
-    double a[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = src[k];
-#pragma unroll
-    for (int h = 8; h >= 1; h >>= 1)
-#pragma unroll
-      for (int k = 0; k < h; ++k) a[k] += a[k + h];
-    return a[0];
   }
 
   __device__ __forceinline__ double metric_apply(double v) {
     const double x = w.qt[lane];
     if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
       return lane < dim ? __builtin_fma(x * x, v, v) : 0.0;
+    } else if constexpr (RMETRIC == MM_RMETRIC_USER) {
+      const double y = row_dot(mxr_, v);
+      return lane < dim ? y : 0.0;
     } else {
-      const int g = lane >> 4, j = lane & 15;
+      // rank-one update: B v from row `lane` of the staged base matrix (16-byte reads, conflict-free at a pitch of 66
+      // doubles; zero on the padding) + x (x . v) / D
       w.nat[lane] = (lane < dim) ? v : 0.0;
-      w.vperm[(((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = (lane < dim) ? v : 0.0;
       wave_sync();
-      double vc[4];
-      d4 vr[4];
+      const double* brow = base_lds + lane * kBasePitch;
+      double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
 #pragma unroll
-      for (int X = 0; X < 4; ++X) {
-        vc[X] = w.nat[16 * X + j];
-        vr[X] = *reinterpret_cast<const d4*>(w.vperm + ((X * 4 + g) << 2));
+      for (int k = 0; k < 16; ++k) {
+        const d4 vv = *reinterpret_cast<const d4*>(w.nat + 4 * k);
+        const d2 b01 = *reinterpret_cast<const d2*>(brow + 4 * k);
+        const d2 b23 = *reinterpret_cast<const d2*>(brow + 4 * k + 2);
+        y0 = __builtin_fma(b01[0], vv[0], y0);
+        y1 = __builtin_fma(b01[1], vv[1], y1);
+        y2 = __builtin_fma(b23[0], vv[2], y2);
+        y3 = __builtin_fma(b23[1], vv[3], y3);
       }
-      // all ten tiles of the staged base matrix first: a lone wave cannot hide an LDS round trip (~130 cycles), and
-      // issued one tile ahead of its arithmetic the twenty loads were ten of them in a row (1.6 k of the call's 3.0 k
-      // cycles); the scheduling barrier keeps the compiler from sinking them back to their uses
-      d4 m[10];
-      if constexpr (RMETRIC == MM_RMETRIC_USER) {
-#pragma unroll
-        for (int t = 0; t < 10; ++t) m[t] = mx_[t];  // the user's metric_func at the products' point: metric_point()
-      } else {
-#pragma unroll
-        for (int t = 0; t < 10; ++t) {
-          const d2 b01 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 0) * 64 + lane) * 2);
-          const d2 b23 = *reinterpret_cast<const d2*>(base_lds + ((t * 2 + 1) * 64 + lane) * 2);
-          m[t] = d4{b01[0], b01[1], b23[0], b23[1]};  // zero on the padding, where v is zero too
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      double mir[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-      for (int I = 0; I < 4; ++I) {
-        d4 s = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int J = 0; J <= I; ++J) {
-          const int t = tix(I, J);
-          if (I != J) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mir[J] = __builtin_fma(m[t][r], vr[I][r], mir[J]);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[r] = __builtin_fma(m[t][r], vc[J], s[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w.part[(16 * I + 4 * r + g) * kPartStride + j] = s[r];
-      }
-#pragma unroll
-      for (int J = 0; J < 3; ++J) w.mpart[(J * 4 + g) * 16 + j] = mir[J];
-      double dot = 0.0;
-      if constexpr (RMETRIC == MM_RMETRIC_RANK1) dot = wave_sum(lane < dim ? x * v : 0.0);
+      const double dot = wave_sum(lane < dim ? x * v : 0.0);
       wave_sync();
-      double y = 0.0;
-      {
-        y = sum16(w.part + lane * kPartStride);
-        if (lane < 48) {
-          const double* mp = w.mpart + (lane >> 4) * 64 + (lane & 15);
-          y += (mp[0] + mp[16]) + (mp[32] + mp[48]);
-        }
-        if constexpr (RMETRIC == MM_RMETRIC_RANK1) y = __builtin_fma(x, dot / (double)dim, y);
-      }
-      wave_sync();
+      const double y = __builtin_fma(x, dot / (double)dim, (y0 + y1) + (y2 + y3));
       return lane < dim ? y : 0.0;
     }
   }
@@ -479,9 +487,20 @@ struct MfmaBackend {
   // implicit_core.h, kUnifiedConstruct: metric_func(x), then the explicit inverse (kept in the tiles for matvec /
   // half_vjp_inv / dh2_dpos) or the single solve u = M(x)^-1 rhs (systems.py:1381-1399)
   __device__ __forceinline__ bool construct(double x, bool need_inverse, double rhs, double* u) {
+    // every construction ends the life of the inverse held so far (a solve-only construction overwrites the tiles it would
+    // be rebuilt from; nothing applies it before the next construction with need_inverse - implicit_core.h drops the
+    // anchor).  Saying so keeps its 128 registers from being carried across the sweeps.
+#pragma unroll
+    for (int k = 0; k < 64; ++k) fr_[k] = 0.0;
+    fd_ = 0.0;
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {  // (and a refinement solve's row of M(x) is dead between solves)
+#pragma unroll
+      for (int k = 0; k < 64; ++k) mxr_[k] = 0.0;
+    }
     bool ok = build(x);
     if (need_inverse) {  // wave-uniform
       ok = sweep<false>() && ok;
+      tiles_to_rows();  // the inverse is APPLIED in row form (above); the tiles are dead until the next construction
     } else {
       ok = sweep<true>() && ok;
       *u = solve_factored(rhs);
@@ -494,66 +513,13 @@ struct MfmaBackend {
   }
   __device__ __forceinline__ bool build_and_solve(double x, double rhs, double* u) { return construct(x, false, rhs, u); }
 
-  // ---- y = T v for the symmetric matrix held as lower tiles -------------------------------------------
+  // ---- y = M(x0)^-1 v with the inverse in row form ------------------------------------------------------------------
   __device__ __forceinline__ double matvec(double v) {
-    const int g = lane >> 4, j = lane & 15;
-    w.nat[lane] = (lane < dim) ? v : 0.0;
-    w.vperm[(((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = (lane < dim) ? v : 0.0;
-    wave_sync();
-    double vc[4];
-    d4 vr[4];
-#pragma unroll
-    for (int X = 0; X < 4; ++X) {
-      vc[X] = w.nat[16 * X + j];
-      vr[X] = *reinterpret_cast<const d4*>(w.vperm + ((X * 4 + g) << 2));
-    }
-    // direct: rows of tile-row I, summed over this lane's column j of tiles J <= I
-#pragma unroll
-    for (int I = 0; I < 4; ++I) {
-      d4 s = acc[tix(I, 0)] * vc[0];
-#pragma unroll
-      for (int J = 1; J <= I; ++J) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[r] = __builtin_fma(acc[tix(I, J)][r], vc[J], s[r]);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w.part[(16 * I + 4 * r + g) * kPartStride + j] = s[r];
-    }
-    // mirrored: column 16 J + j of the tiles (I, J), I > J, against the row operand
-#pragma unroll
-    for (int J = 0; J < 3; ++J) {
-      double s = 0.0;
-#pragma unroll
-      for (int I = J + 1; I < 4; ++I)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s = __builtin_fma(acc[tix(I, J)][r], vr[I][r], s);
-      w.mpart[(J * 4 + g) * 16 + j] = s;
-    }
-    wave_sync();
-    double y = 0.0;
-    {
-      y = sum16(w.part + lane * kPartStride);
-      if (lane < 48) {
-        const double* m = w.mpart + (lane >> 4) * 64 + (lane & 15);
-        y += (m[0] + m[16]) + (m[32] + m[48]);
-      }
-    }
-    wave_sync();
+    const double y = row_dot(fr_, v);
     return lane < dim ? y : 0.0;
   }
 
-  __device__ __forceinline__ double diag() {
-    const int g = lane >> 4, j = lane & 15;
-#pragma unroll
-    for (int I = 0; I < 4; ++I)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (j == 4 * r + g) w.nat[16 * I + 4 * r + g] = acc[tix(I, I)][r];
-    wave_sync();
-    const double y = (lane < dim) ? w.nat[lane] : 0.0;
-    wave_sync();
-    return y;
-  }
+  __device__ __forceinline__ double diag() { return lane < dim ? fd_ : 0.0; }
 
   // 0.5 * vjp_metric_func(q)(V) of a user metric.  q is the point of the held inverse: build() left it in w.uq (natural
   // order) with its aux block in w.uaq.  OUTER: V = -u u^T, else the explicit inverse in the tiles - handed to the user's
@@ -578,18 +544,8 @@ struct MfmaBackend {
         r = (lane < dim) ? mmuser::vjp_dense(w.uq, vm, lane, dim, uparams, w.uaq) : 0.0;
         wave_sync();
       } else {
-        const int g = lane >> 4, j = lane & 15;
 #pragma unroll
-        for (int I = 0; I < 4; ++I)
-#pragma unroll
-          for (int J = 0; J <= I; ++J)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              const int i = 16 * I + 4 * rr + g, jj = 16 * J + j;
-              const double v = acc[tix(I, J)][rr];
-              work[i * 64 + jj] = v;
-              work[jj * 64 + i] = v;
-            }
+        for (int jj = 0; jj < 64; ++jj) work[lane * 64 + jj] = fr_[jj];  // lane i owns row i of the inverse
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the wave's own stores, read back by its other lanes
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const MmMat vm{work, nullptr, 64};
@@ -641,13 +597,9 @@ __device__ __forceinline__ void implicit_mfma_body(const ImplicitArgs& A, double
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dim = A.dim;
   if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-    // base_lds[((t*2 + h)*64 + lane)*2 + e] = B[16 I + 4 (2h + e) + g][16 J + j], zero outside dim x dim
+    // base_lds[row * kBasePitch + col] = B[row][col], zero outside dim x dim
     for (int idx = threadIdx.x; idx < kBaseDoubles; idx += blockDim.x) {
-      const int e = idx & 1, l = (idx >> 1) & 63, th = idx >> 7, h = th & 1, t = th >> 1;
-      int I = 0;
-      while (tix(I + 1, 0) <= t) ++I;
-      const int J = t - tix(I, 0);
-      const int row = 16 * I + 4 * (2 * h + e) + (l >> 4), col = 16 * J + (l & 15);
+      const int row = idx / kBasePitch, col = idx - row * kBasePitch;
       base_lds[idx] = (row < dim && col < dim) ? A.rparams[(int64_t)row * dim + col] : 0.0;
     }
   }
@@ -670,7 +622,7 @@ __device__ __forceinline__ void implicit_mfma_body(const ImplicitArgs& A, double
   bk.w.vperm = wl + 576;
   bk.w.aux = wl + 640;
   bk.w.part = wl + 704;
-  bk.w.mpart = bk.w.part + 64 * kPartStride;
+  bk.w.mpart = bk.w.part + 64 * kRowPitch;
   bk.w.stash = bk.w.mpart + 192;
   bk.w.prof = bk.w.stash + SL_COUNT_REFINE * 64;
   bk.refine_on = A.no_refine == 0;

@@ -17,11 +17,7 @@ __global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int dim = A.dim;
   for (int idx = threadIdx.x; idx < kBaseDoubles; idx += blockDim.x) {
-    const int e = idx & 1, l = (idx >> 1) & 63, th = idx >> 7, h = th & 1, t = th >> 1;
-    int I = 0;
-    while (tix(I + 1, 0) <= t) ++I;
-    const int J = t - tix(I, 0);
-    const int row = 16 * I + 4 * (2 * h + e) + (l >> 4), col = 16 * J + (l & 15);
+    const int row = idx / kBasePitch, col = idx - row * kBasePitch;
     base_lds[idx] = (row < dim && col < dim) ? A.rparams[(int64_t)row * dim + col] : 0.0;
   }
   __syncthreads();
@@ -38,7 +34,7 @@ __global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs 
   bk.w.vperm = wl + 576;
   bk.w.aux = wl + 640;
   bk.w.part = wl + 704;
-  bk.w.mpart = bk.w.part + 64 * kPartStride;
+  bk.w.mpart = bk.w.part + 64 * kRowPitch;
   bk.w.stash = bk.w.mpart + 192;
   bk.base_lds = base_lds;
   bk.tparams = A.tparams;
@@ -51,6 +47,7 @@ __global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs 
     bool ok = bk.build(q);
     const long long t1 = __builtin_readcyclecounter();
     ok = bk.template sweep<false>() && ok;
+    bk.tiles_to_rows();  // (timed with the sweep: the inverse is applied in row form)
     const long long t2 = __builtin_readcyclecounter();
     const double u = bk.matvec(p);
     const long long t3 = __builtin_readcyclecounter();

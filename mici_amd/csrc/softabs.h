@@ -738,7 +738,7 @@ struct SoftAbsBackendT {
         }
       }
     }
-    snap_ok = 0;  // the sweeps use the whole (c, s) ring: the snapshots that start in its tail are gone
+    snap_ok &= ~2;  // the sweeps use the whole (c, s) ring: snapshot 1, which starts in its tail, is gone
     times_basis();
     char* const G = reinterpret_cast<char*>(w.W);
     char* const Vt = reinterpret_cast<char*>(w.H);
@@ -856,16 +856,19 @@ struct SoftAbsBackendT {
   // snapshot is a starting basis, nothing more: rounded to 6e-8 it is still orthonormal to 1e-7, far inside what the
   // refinement starts from - but no longer to the square of a finished rotation, so the decomposition that starts from a
   // restored snapshot measures X^T X in its first pass instead of taking it for the identity (`unchecked`).
+  // slot 1 (the basis at q + t M^-1 p) starts in the ring's tail; slot 0 (the basis at q) is the LAST 16 KB of the
+  // region, clear of the ring: a fallback to the Jacobi sweeps only costs the step snapshot 1
+  __device__ __forceinline__ float* snap_slot(const int slot) const { return w.snap + (slot == 0 ? NP * NP : 0); }
   __device__ __forceinline__ void basis_save(const int slot) {
     if (!refine_on || warm == 0) return;
-    float* const dst = w.snap + slot * NP * NP;
+    float* const dst = snap_slot(slot);
     for (int el = tid; el < NP * NP; el += NT) dst[el] = (float)w.V[(el / NP) * LD + el % NP];  // (zero beyond dim)
     snap_ok |= 1 << slot;
   }
   __device__ __forceinline__ void basis_restore(const int slot) {
     if (!(snap_ok & (1 << slot))) return;
     __syncthreads();  // every reader of the current basis is done
-    const float* const src = w.snap + slot * NP * NP;
+    const float* const src = snap_slot(slot);
     for (int el = tid; el < NP * NP; el += NT) w.V[(el / NP) * LD + el % NP] = (double)src[el];
     __syncthreads();
     warm = warm > 0 ? warm : 1;

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Fill the measured tables of DESIGN.md / README.md from profiles/<round>_bench_default.json (+ the PMC files), between
-the <!-- R03_TABLE --> / <!-- R03_README_TABLE --> markers, so the documents quote what the committed record holds."""
+the <!-- R04_TABLE --> / <!-- R04_README_TABLE --> markers (ROUND=r04), so the documents quote what the committed record holds."""
 import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r03")
+ROUND = os.environ.get("ROUND", "r04")
 
 
 def sci(x):
@@ -23,7 +23,9 @@ def main():
     rec = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_bench_default.json")))
     rows = [("c2", "c2(iii) D=128, 4096 chains, leapfrog", rec)]
     names = {"c2i": "c2(i) iso-Gaussian", "c2iv": "c2(iv) + dense metric", "c3": "c3(a) D=64, 1024 chains",
-             "c3b": "c3(b) SoftAbs D=64", "c4": "c4 shard D=256, 1024 chains", "c5": "c5 shard, 2048 chains"}
+             "c3b": "c3(b) SoftAbs D=64", "c4": "c4 shard D=256, 1024 chains", "c5": "c5 shard, 2048 chains",
+             "c3_user": "c3_user D=64: softplus + rank-one metric as user source", "c4_general": "c4_general D=256: the c4 metric as user source",
+             "c3b_dense": "c3b_dense D=64: SoftAbs on the banana, Hessian as user source (h = 0.01)"}
     for k, v in rec.get("configs", {}).items():
         if "error" not in v:
             rows.append((k, names.get(k, k), v))
@@ -48,7 +50,7 @@ def main():
         out.append(f"| {name} | {sci(r['value'])} | {roof['kernel_ms_per_launch']:.3g} | {frac} | {ex} | "
                    f"{'—' if tr is None else '%.1f MB' % (tr / 1e6)} |")
     table = "\n".join(out)
-    for fn, marker in (("DESIGN.md", "R03_TABLE"), ("README.md", "R03_README_TABLE")):
+    for fn, marker in (("DESIGN.md", f"{ROUND.upper()}_TABLE"), ("README.md", f"{ROUND.upper()}_README_TABLE")):
         p = os.path.join(ROOT, fn)
         s = open(p).read()
         block = f"<!-- {marker} -->\n{table}\n<!-- /{marker} -->"

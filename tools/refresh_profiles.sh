@@ -9,7 +9,8 @@
 #   <round>_bench_default.json            the exact default command, `python bench.py`
 #   <round>_rocprofv3_kernel_stats.csv    `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline`
 #   <round>_<cfg>_pmc_hbm.json            FETCH_SIZE / WRITE_SIZE passes (separate runs, gfx950 correction) - c2 c2i c2iv c3 c3b c4 c5
-#   <round>_<cfg>_sq_counters.json        SQ counters (two passes) - c2 c3 c3b c4 c5
+#                                         and the user-source configs c3_user c4_general c3b_dense (kernels mm_rtc_*)
+#   <round>_<cfg>_sq_counters.json        SQ counters (two passes) - c2 c3 c3b c4 c5 c3_user c4_general c3b_dense
 #   <round>_c4_ubench_blk16.txt, <round>_c3_ubench_mfma.txt   phase clocks of the two dense-Riemannian kernels
 #   <round>_fuzz_parity.txt               tools/fuzz_parity.py, three seeds x 80 cases + 60 long SoftAbs cases
 #   <round>_host_latency.txt              tools/host_latency.py in three fresh processes (single-state Integrator.step, step_batch, system.h)
@@ -26,7 +27,7 @@ if [ "$1" = "collect" ]; then
 fi
 cd $ROOT
 O=$ROOT/gpurun_out/${ROUND}p; rm -rf $O; mkdir -p $O
-KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2iv:leapfrog_mfma_kernel c3:implicit_mfma_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel"
+KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2iv:leapfrog_mfma_kernel c3:implicit_mfma_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel c3_user:mm_rtc_riem_step c4_general:mm_rtc_riem_step c3b_dense:mm_rtc_softabs_step"
 
 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -4 > $O/gpu_tests.txt; cat $O/gpu_tests.txt
 for pair in $KERNELS; do
