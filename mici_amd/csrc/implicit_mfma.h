@@ -206,7 +206,12 @@ struct MfmaBackend {
   // the staged base matrix the same way (rank-one metric), or of the user's metric evaluated once per solve.
   double fr_[64];  // row `lane` of M(x0)^-1 (the padding is the identity: zero off the diagonal)
   double fd_;      // its diagonal entry
-  double mxr_[RMETRIC == MM_RMETRIC_USER ? 64 : 1];  // user metric: row `lane` of M(x) at the products' point
+  // rank-one metric: row `lane` of the base matrix, fetched from the staged copy after every sweep and dead again at the
+  // next construction (like fr_: the sweeps need the registers) - M(x) v then reads nothing but the broadcast vector
+  double br_[RMETRIC == MM_RMETRIC_RANK1 ? 64 : 1];
+  // user metric: the ten lower tiles of M(x) at the products' point (tile layout of the sweep: 40 entries a lane, the
+  // symmetric half - a row would be 64, and its evaluation, once per refinement solve, is what a user metric pays for)
+  d4 mx_[RMETRIC == MM_RMETRIC_USER ? kTiles : 1];
 
   __device__ __forceinline__ void tiles_to_rows() {
     const int g = lane >> 4, j = lane & 15;
@@ -231,6 +236,15 @@ struct MfmaBackend {
       if ((lane >> 4) == c) fd_ = buf[lane * kRowPitch + (lane & 15)];
       wave_sync();
     }
+    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+      const double* brow = base_lds + lane * kBasePitch;  // 16-byte reads, conflict-free at a pitch of 66 doubles
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const d2 b = *reinterpret_cast<const d2*>(brow + 2 * k);
+        br_[2 * k] = b[0];
+        br_[2 * k + 1] = b[1];
+      }
+    }
   }
 
   // y_lane = sum_j row[j] v_j with v broadcast from LDS (w.nat, zero beyond dim); four independent accumulators
@@ -253,23 +267,79 @@ struct MfmaBackend {
   __device__ __forceinline__ void metric_point(double x) {
     w.qt[lane] = (lane < dim) ? x : 0.0;
     if constexpr (RMETRIC == MM_RMETRIC_USER) {
-      // the products' point in natural order, its aux block, then row `lane` of the user's metric_func there - ONCE per
+      // the products' point in natural order, its aux block, then the tiles of the user's metric_func there - ONCE per
       // refinement solve (its 2 - 8 products are all at that point), dead again before anything else of the step runs
       w.ux[lane] = (lane < dim) ? x : 0.0;
       wave_sync();
       mmuser::prepare(mmuser::WaveTeam{lane}, w.ux, dim, uparams, w.uax);
       wave_sync();
       // (the lane index laundered: everything the entries' addresses derive from is loop invariant, and hoisted out of the
-      // step loop 64 of them - 128 registers - lived across the whole kernel in scratch)
-      int ol = lane;
-      asm volatile("" : "+v"(ol));
+      // step loop they lived in scratch for the whole kernel)
+      int og = lane >> 4, oj = lane & 15;
+      asm volatile("" : "+v"(og), "+v"(oj));
 #pragma unroll
-      for (int jj = 0; jj < 64; ++jj) {
-        mxr_[jj] = mmuser::entry_padded(w.ux, ol, jj, dim, uparams, w.uax);
-        // eight entries at a time: left alone the scheduler hoists all 64 entries' operand loads to the top
-        if ((jj & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-      }
+      for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            mx_[tix(I, J)][r] = mmuser::entry_padded(w.ux, 16 * I + 4 * r + og, 16 * J + oj, dim, uparams, w.uax);
     }
+  }
+
+  // sixteen partial sums of a row, pairwise: a lone wave pays every dependent add in full (a serial chain is 16 deep)
+  __device__ static __forceinline__ double sum16(const double* src) {
+    double a[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = src[k];
+#pragma unroll
+    for (int h = 8; h >= 1; h >>= 1)
+#pragma unroll
+      for (int k = 0; k < h; ++k) a[k] += a[k + h];
+    return a[0];
+  }
+
+  // y = T v for a symmetric matrix held as lower tiles in the sweep's layout (the user metric's M(x)): operands out
+  // through LDS, 19 partial sums a lane back through LDS
+  __device__ __forceinline__ double tile_matvec(const d4 (&m)[kTiles], double v) {
+    const int g = lane >> 4, j = lane & 15;
+    w.nat[lane] = (lane < dim) ? v : 0.0;
+    w.vperm[(((lane >> 4) * 4 + (lane & 3)) << 2) + ((lane >> 2) & 3)] = (lane < dim) ? v : 0.0;
+    wave_sync();
+    double vc[4];
+    d4 vr[4];
+#pragma unroll
+    for (int X = 0; X < 4; ++X) {
+      vc[X] = w.nat[16 * X + j];
+      vr[X] = *reinterpret_cast<const d4*>(w.vperm + ((X * 4 + g) << 2));
+    }
+    double mir[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int I = 0; I < 4; ++I) {
+      d4 sr = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int J = 0; J <= I; ++J) {
+        const int t = tix(I, J);
+        if (I != J) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mir[J] = __builtin_fma(m[t][r], vr[I][r], mir[J]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sr[r] = __builtin_fma(m[t][r], vc[J], sr[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w.part[(16 * I + 4 * r + g) * kPartStride + j] = sr[r];
+    }
+#pragma unroll
+    for (int J = 0; J < 3; ++J) w.mpart[(J * 4 + g) * 16 + j] = mir[J];
+    wave_sync();
+    double y = sum16(w.part + lane * kPartStride);
+    if (lane < 48) {
+      const double* mp = w.mpart + (lane >> 4) * 64 + (lane & 15);
+      y += (mp[0] + mp[16]) + (mp[32] + mp[48]);
+    }
+    wave_sync();
+    return lane < dim ? y : 0.0;
   }
 
   __device__ __forceinline__ double metric_apply(double v) {
@@ -277,28 +347,12 @@ struct MfmaBackend {
     if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
       return lane < dim ? __builtin_fma(x * x, v, v) : 0.0;
     } else if constexpr (RMETRIC == MM_RMETRIC_USER) {
-      const double y = row_dot(mxr_, v);
-      return lane < dim ? y : 0.0;
+      return tile_matvec(mx_, v);
     } else {
-      // rank-one update: B v from row `lane` of the staged base matrix (16-byte reads, conflict-free at a pitch of 66
-      // doubles; zero on the padding) + x (x . v) / D
-      w.nat[lane] = (lane < dim) ? v : 0.0;
-      wave_sync();
-      const double* brow = base_lds + lane * kBasePitch;
-      double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const d4 vv = *reinterpret_cast<const d4*>(w.nat + 4 * k);
-        const d2 b01 = *reinterpret_cast<const d2*>(brow + 4 * k);
-        const d2 b23 = *reinterpret_cast<const d2*>(brow + 4 * k + 2);
-        y0 = __builtin_fma(b01[0], vv[0], y0);
-        y1 = __builtin_fma(b01[1], vv[1], y1);
-        y2 = __builtin_fma(b23[0], vv[2], y2);
-        y3 = __builtin_fma(b23[1], vv[3], y3);
-      }
+      // rank-one update: B v from row `lane` of the base matrix (in registers since the last sweep) + x (x . v) / D
+      const double bv = row_dot(br_, v);
       const double dot = wave_sum(lane < dim ? x * v : 0.0);
-      wave_sync();
-      const double y = __builtin_fma(x, dot / (double)dim, (y0 + y1) + (y2 + y3));
+      const double y = __builtin_fma(x, dot / (double)dim, bv);
       return lane < dim ? y : 0.0;
     }
   }
@@ -329,6 +383,10 @@ struct MfmaBackend {
   template <bool TRAILING>
   __device__ __forceinline__ void block_step(const int B, Ops& ops, double& pmin) {
     const int I0 = B >> 2, R0 = B & 3;
+    // (the lane index laundered per block: the LDS addresses derived from it are a few instructions to recompute, and
+    // kept live across the whole kernel - with the row-form inverse next to them - they ended up in scratch)
+    int lane = this->lane;
+    asm volatile("" : "+v"(lane));
     const int g = lane >> 4, j = lane & 15;
     const int k0 = 16 * I0 + 4 * R0;
     // (1) publish rows K of the matrix as Qt[c][s] = A[k0 + s][c].  The transposed part comes from the 16
@@ -493,9 +551,13 @@ struct MfmaBackend {
 #pragma unroll
     for (int k = 0; k < 64; ++k) fr_[k] = 0.0;
     fd_ = 0.0;
-    if constexpr (RMETRIC == MM_RMETRIC_USER) {  // (and a refinement solve's row of M(x) is dead between solves)
+    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
 #pragma unroll
-      for (int k = 0; k < 64; ++k) mxr_[k] = 0.0;
+      for (int k = 0; k < 64; ++k) br_[k] = 0.0;
+    }
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {  // (and a refinement solve's tiles of M(x) are dead between solves)
+#pragma unroll
+      for (int t = 0; t < kTiles; ++t) mx_[t] = d4{0.0, 0.0, 0.0, 0.0};
     }
     bool ok = build(x);
     if (need_inverse) {  // wave-uniform
