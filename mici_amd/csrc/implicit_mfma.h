@@ -206,9 +206,7 @@ struct MfmaBackend {
   // the staged base matrix the same way (rank-one metric), or of the user's metric evaluated once per solve.
   double fr_[64];  // row `lane` of M(x0)^-1 (the padding is the identity: zero off the diagonal)
   double fd_;      // its diagonal entry
-  // rank-one metric: row `lane` of the base matrix, fetched from the staged copy after every sweep and dead again at the
-  // next construction (like fr_: the sweeps need the registers) - M(x) v then reads nothing but the broadcast vector
-  double br_[RMETRIC == MM_RMETRIC_RANK1 ? 64 : 1];
+
   // user metric: the ten lower tiles of M(x) at the products' point (tile layout of the sweep: 40 entries a lane, the
   // symmetric half - a row would be 64, and its evaluation, once per refinement solve, is what a user metric pays for)
   d4 mx_[RMETRIC == MM_RMETRIC_USER ? kTiles : 1];
@@ -235,15 +233,6 @@ struct MfmaBackend {
       }
       if ((lane >> 4) == c) fd_ = buf[lane * kRowPitch + (lane & 15)];
       wave_sync();
-    }
-    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-      const double* brow = base_lds + lane * kBasePitch;  // 16-byte reads, conflict-free at a pitch of 66 doubles
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        const d2 b = *reinterpret_cast<const d2*>(brow + 2 * k);
-        br_[2 * k] = b[0];
-        br_[2 * k + 1] = b[1];
-      }
     }
   }
 
@@ -349,10 +338,27 @@ struct MfmaBackend {
     } else if constexpr (RMETRIC == MM_RMETRIC_USER) {
       return tile_matvec(mx_, v);
     } else {
-      // rank-one update: B v from row `lane` of the base matrix (in registers since the last sweep) + x (x . v) / D
-      const double bv = row_dot(br_, v);
+      // rank-one update: B v from row `lane` of the staged base matrix (16-byte reads, conflict-free at a pitch of 66
+      // doubles; zero on the padding) + x (x . v) / D.  (The row in registers between sweeps - 128 more next to the
+      // inverse's 128 - was measured and loses: beyond 256 architected registers the allocator parks operands in
+      // accumulation registers, and every multiply-add then pays two v_accvgpr_read: c3 1.09e7 against 1.19e7.)
+      w.nat[lane] = (lane < dim) ? v : 0.0;
+      wave_sync();
+      const double* brow = base_lds + lane * kBasePitch;
+      double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const d4 vv = *reinterpret_cast<const d4*>(w.nat + 4 * k);
+        const d2 b01 = *reinterpret_cast<const d2*>(brow + 4 * k);
+        const d2 b23 = *reinterpret_cast<const d2*>(brow + 4 * k + 2);
+        y0 = __builtin_fma(b01[0], vv[0], y0);
+        y1 = __builtin_fma(b01[1], vv[1], y1);
+        y2 = __builtin_fma(b23[0], vv[2], y2);
+        y3 = __builtin_fma(b23[1], vv[3], y3);
+      }
       const double dot = wave_sum(lane < dim ? x * v : 0.0);
-      const double y = __builtin_fma(x, dot / (double)dim, bv);
+      wave_sync();
+      const double y = __builtin_fma(x, dot / (double)dim, (y0 + y1) + (y2 + y3));
       return lane < dim ? y : 0.0;
     }
   }
@@ -551,10 +557,6 @@ struct MfmaBackend {
 #pragma unroll
     for (int k = 0; k < 64; ++k) fr_[k] = 0.0;
     fd_ = 0.0;
-    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-#pragma unroll
-      for (int k = 0; k < 64; ++k) br_[k] = 0.0;
-    }
     if constexpr (RMETRIC == MM_RMETRIC_USER) {  // (and a refinement solve's tiles of M(x) are dead between solves)
 #pragma unroll
       for (int t = 0; t < kTiles; ++t) mx_[t] = d4{0.0, 0.0, 0.0, 0.0};
