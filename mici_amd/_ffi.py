@@ -8,7 +8,8 @@ import os
 
 from .errors import DeviceError
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmici_amd.so")
+# MICI_AMD_LIB: another build of the library (A/B runs of kernel variants, tools/ab_build.py)
+_LIB_PATH = os.environ.get("MICI_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmici_amd.so")
 
 MM_COMM_ID_BYTES = 128
 ABI_VERSION = 3

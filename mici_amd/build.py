@@ -102,7 +102,11 @@ def _compile_and_link(sources, objdir, lib, extra, headers_time, force, jobs, ve
     def compile_one(pair):
         src, obj = pair
         cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), *extra, *DEV_FLAGS, "-c", src, "-o", obj]
+        import time
+        t0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode == 0:  # stamped with the time the compile STARTED: a header edited while it ran rebuilds it next time
+            os.utime(obj, (t0, t0))
         return src, r.returncode, r.stdout + r.stderr
 
     if todo:

@@ -73,45 +73,13 @@ __device__ __forceinline__ double group8_sum(double v) {
   return v;
 }
 
-// gfx950 has VALU row swaps: v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of
-// its second, v_permlane32_swap the upper half of the first with the lower half of the second; fed the same value twice,
-// the two results are (x[l], x[l ^ 16]) - resp. (x[l], x[l ^ 32]) - in some order, so combining them is the xor-16 / xor-32
-// butterfly step of a cross-row reduction: two swaps and one operation per step, the result in every lane, where the
-// readlane form was eight v_readlane (each with its SALU hazard) and three operations.  Semantics verified on the MI355X
-// by tests/test_gpu_blk16.py::test_permlane_swap_semantics.
-// a value every lane of the wave agrees on, moved to scalar registers
-__device__ __forceinline__ double wave_uniform(double v) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL));
-  const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-__device__ __forceinline__ void permlane_swap_pair(double m, bool by32, double* x0, double* x1) {
-  const long long b = __double_as_longlong(m);
-  const unsigned lo = (unsigned)(b & 0xffffffffLL), hi = (unsigned)(b >> 32);
-  if (by32) {
-    const auto l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    *x0 = __longlong_as_double(((long long)h2[0] << 32) | (unsigned)l2[0]);
-    *x1 = __longlong_as_double(((long long)h2[1] << 32) | (unsigned)l2[1]);
-  } else {
-    const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    *x0 = __longlong_as_double(((long long)h2[0] << 32) | (unsigned)l2[0]);
-    *x1 = __longlong_as_double(((long long)h2[1] << 32) | (unsigned)l2[1]);
-  }
-}
-
+// (Round 4 measured the cross-row part on gfx950's v_permlane16_swap / v_permlane32_swap - two swaps and one add per
+// butterfly step, the result read back with v_readfirstlane to keep the callers' control flow scalar - against the four
+// v_readlane pairs below: c3(a) 1.250e7 against 1.263e7 steps/s.  The readlane form stays.)
 __device__ __forceinline__ double wave_sum(double v) {
   v = group8_sum(v);
   v += dpp_move<kDppMirror>(v);  // every lane of a 16-lane row now holds the row sum
-  double a, b;
-  permlane_swap_pair(v, false, &a, &b);
-  v = a + b;
-  permlane_swap_pair(v, true, &a, &b);
-  // a + b is commutative bit for bit: every lane holds the same value - moved to scalar registers, so that the control
-  // flow the callers hang on it (solver convergence tests, CG breakdown tests) stays scalar
-  return wave_uniform(a + b);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 // ---- lean FP64 reciprocal / division / square root for well-scaled arguments ---------------------------------------
@@ -171,11 +139,8 @@ __device__ __forceinline__ double wave_max(double v) {
   v = nanmax(v, dpp_move<kDppXor2>(v));
   v = nanmax(v, dpp_move<kDppHalfMirror>(v));
   v = nanmax(v, dpp_move<kDppMirror>(v));
-  double a, b;
-  permlane_swap_pair(v, false, &a, &b);
-  v = nanmax(a, b);
-  permlane_swap_pair(v, true, &a, &b);
-  return wave_uniform(nanmax(a, b));
+  return nanmax(nanmax(readlane_f64(v, 0), readlane_f64(v, 16)),
+                nanmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 
 // broadcast from a wave-uniform source lane (v_readlane, no LDS crossbar)
