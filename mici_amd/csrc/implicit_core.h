@@ -323,7 +323,10 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
     bool refined = false;
     if constexpr (kRefine) {
       if (!need_inverse && anchor && bk.refine_on) {  // team-uniform
-        refined = refine_solve(bk, bk.slot(SL_XQ), bk.slot(SL_PW), bk.slot(mode == MODE_CHK ? SL_UC : SL_UA), &u_pos, r);
+        // (both guesses read, one selected - and written back by a uniform branch below: no slot is indexed by a run-time
+        // value, so a backend may keep its slots in registers)
+        const double g_chk = bk.slot(SL_UC), g_adj = bk.slot(SL_UA);
+        refined = refine_solve(bk, bk.slot(SL_XQ), bk.slot(SL_PW), mode == MODE_CHK ? g_chk : g_adj, &u_pos, r);
         anchor = refined;  // a failed refinement is followed by the factorisation below, which overwrites the inverse
       }
     }
@@ -347,7 +350,10 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       if constexpr (kRefine) anchor = need_inverse && okm;
     }
     if constexpr (kRefine) {
-      if (!need_inverse) bk.slot(mode == MODE_CHK ? SL_UC : SL_UA) = u_pos;
+      if (!need_inverse) {
+        if (mode == MODE_CHK) bk.slot(SL_UC) = u_pos;
+        else bk.slot(SL_UA) = u_pos;
+      }
     }
     bump(bk, r, CNT_METRIC, 1);  // (the C-adjoint solve's own construction at the shared point is counted when it starts)
     if constexpr (basis_trait<BK>::value) {

@@ -108,6 +108,8 @@ struct MfmaBackend {
   const double* uparams;  // user metric: its params (global memory)
   double* work;           // user metric with the dense-accessor VJP: this chain's 64 x 64 doubles of global memory
 
+  // (the step's slots in registers instead of LDS - there is room since round 4 - were measured and lose: 1.17e7 against
+  // 1.24e7 steps/s on c3)
   __device__ __forceinline__ double& slot(int i) { return w.stash[i * 64 + lane]; }
   __device__ __forceinline__ bool flat_active() const { return lane < dim; }
 
@@ -236,21 +238,30 @@ struct MfmaBackend {
     }
   }
 
-  // y_lane = sum_j row[j] v_j with v broadcast from LDS (w.nat, zero beyond dim); four independent accumulators
+  // independent accumulator chains of a row product: four for the held inverse (registers x broadcast vector), two for
+  // M(x) v (whose 32 row loads, not the multiply-adds, pace it) - measured on c3 (tools/ab_build.py grid, steps/s):
+  // F4/M4 1.25e7, F4/M2 1.316e7, F4/M1 1.314e7, F8/M2 1.308e7, F2/M2 1.23e7, F16/M4 1.23e7
+  static constexpr int kAcc = 4;
+  static constexpr int kAccM = 2;
+  // y_lane = sum_j row[j] v_j with v broadcast from LDS (w.nat, zero beyond dim)
   __device__ __forceinline__ double row_dot(const double (&row)[64], double v) {
     w.nat[lane] = (lane < dim) ? v : 0.0;
     wave_sync();
-    double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+    double y[kAcc];
+#pragma unroll
+    for (int a = 0; a < kAcc; ++a) y[a] = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const d4 vv = *reinterpret_cast<const d4*>(w.nat + 4 * k);
-      y0 = __builtin_fma(row[4 * k], vv[0], y0);
-      y1 = __builtin_fma(row[4 * k + 1], vv[1], y1);
-      y2 = __builtin_fma(row[4 * k + 2], vv[2], y2);
-      y3 = __builtin_fma(row[4 * k + 3], vv[3], y3);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[(4 * k + e) % kAcc] = __builtin_fma(row[4 * k + e], vv[e], y[(4 * k + e) % kAcc]);
     }
     wave_sync();  // (the next product overwrites w.nat)
-    return (y0 + y1) + (y2 + y3);
+#pragma unroll
+    for (int h = kAcc / 2; h >= 1; h >>= 1)
+#pragma unroll
+      for (int a = 0; a < h; ++a) y[a] += y[a + h];
+    return y[0];
   }
 
   __device__ __forceinline__ void metric_point(double x) {
@@ -345,20 +356,26 @@ struct MfmaBackend {
       w.nat[lane] = (lane < dim) ? v : 0.0;
       wave_sync();
       const double* brow = base_lds + lane * kBasePitch;
-      double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+      double ya[kAccM];
+#pragma unroll
+      for (int a = 0; a < kAccM; ++a) ya[a] = 0.0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const d4 vv = *reinterpret_cast<const d4*>(w.nat + 4 * k);
         const d2 b01 = *reinterpret_cast<const d2*>(brow + 4 * k);
         const d2 b23 = *reinterpret_cast<const d2*>(brow + 4 * k + 2);
-        y0 = __builtin_fma(b01[0], vv[0], y0);
-        y1 = __builtin_fma(b01[1], vv[1], y1);
-        y2 = __builtin_fma(b23[0], vv[2], y2);
-        y3 = __builtin_fma(b23[1], vv[3], y3);
+        ya[(4 * k) % kAccM] = __builtin_fma(b01[0], vv[0], ya[(4 * k) % kAccM]);
+        ya[(4 * k + 1) % kAccM] = __builtin_fma(b01[1], vv[1], ya[(4 * k + 1) % kAccM]);
+        ya[(4 * k + 2) % kAccM] = __builtin_fma(b23[0], vv[2], ya[(4 * k + 2) % kAccM]);
+        ya[(4 * k + 3) % kAccM] = __builtin_fma(b23[1], vv[3], ya[(4 * k + 3) % kAccM]);
       }
       const double dot = wave_sum(lane < dim ? x * v : 0.0);
       wave_sync();
-      const double y = __builtin_fma(x, dot / (double)dim, (y0 + y1) + (y2 + y3));
+#pragma unroll
+      for (int h = kAccM / 2; h >= 1; h >>= 1)
+#pragma unroll
+        for (int a = 0; a < h; ++a) ya[a] += ya[a + h];
+      const double y = __builtin_fma(x, dot / (double)dim, ya[0]);
       return lane < dim ? y : 0.0;
     }
   }
