@@ -212,31 +212,35 @@ struct MfmaBackend {
   // user metric: the ten lower tiles of M(x) at the products' point (tile layout of the sweep: 40 entries a lane, the
   // symmetric half - a row would be 64, and its evaluation, once per refinement solve, is what a user metric pays for)
   d4 mx_[RMETRIC == MM_RMETRIC_USER ? kTiles : 1];
+  // (converted to a row per refinement solve - tiles_to_row, then the reduction-free row product - it loses: 80 + 128
+  // more registers next to the inverse's row spill; c3_user 4.16e6 against 4.57e6 steps/s)
 
-  __device__ __forceinline__ void tiles_to_rows() {
+  // lower tiles of a symmetric matrix (the sweep's layout) -> row `lane` of the full matrix, sixteen columns at a time
+  __device__ __forceinline__ void tiles_to_row(const d4 (&t)[kTiles], double (&row)[64], double* diag_out) {
     const int g = lane >> 4, j = lane & 15;
-    double* buf = w.part;  // [64][kRowPitch]: one chunk of sixteen columns at a time
+    double* buf = w.part;  // [64][kRowPitch]
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
       for (int I = c; I < 4; ++I)  // tile (I, c): rows 16 I + 4 r + g, column 16 c + j
 #pragma unroll
-        for (int r = 0; r < 4; ++r) buf[(16 * I + 4 * r + g) * kRowPitch + j] = acc[tix(I, c)][r];
+        for (int r = 0; r < 4; ++r) buf[(16 * I + 4 * r + g) * kRowPitch + j] = t[tix(I, c)][r];
 #pragma unroll
       for (int J = 0; J < c; ++J)  // tile (c, J) by symmetry: row 16 J + j, column 16 c + 4 r + g
 #pragma unroll
-        for (int r = 0; r < 4; ++r) buf[(16 * J + j) * kRowPitch + 4 * r + g] = acc[tix(c, J)][r];
+        for (int r = 0; r < 4; ++r) buf[(16 * J + j) * kRowPitch + 4 * r + g] = t[tix(c, J)][r];
       wave_sync();
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const d2 x = *reinterpret_cast<const d2*>(buf + lane * kRowPitch + 2 * k);
-        fr_[16 * c + 2 * k] = x[0];
-        fr_[16 * c + 2 * k + 1] = x[1];
+        row[16 * c + 2 * k] = x[0];
+        row[16 * c + 2 * k + 1] = x[1];
       }
-      if ((lane >> 4) == c) fd_ = buf[lane * kRowPitch + (lane & 15)];
+      if (diag_out && (lane >> 4) == c) *diag_out = buf[lane * kRowPitch + (lane & 15)];
       wave_sync();
     }
   }
+  __device__ __forceinline__ void tiles_to_rows() { tiles_to_row(acc, fr_, &fd_); }
 
   // independent accumulator chains of a row product: four for the held inverse (registers x broadcast vector), two for
   // M(x) v (whose 32 row loads, not the multiply-adds, pace it) - measured on c3 (tools/ab_build.py grid, steps/s):
