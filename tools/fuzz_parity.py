@@ -132,6 +132,53 @@ def softabs_case(rng):
     return desc, integ, system, osys, q0, p0, dirs, steps, ref, 5e-8
 
 
+def riemann_user_case(rng):
+    """A metric the library does not have, as USER source (run-time compiled kernels, csrc/user_metric.h): the softplus +
+    rank-one metric of oracle/models.py at ANY dim up to the ceiling."""
+    from mici_amd import user_examples
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import user_sources
+    dim = int(rng.integers(2, 280))
+    n = int(rng.choice([1, 3, 9]))
+    form = rng.choice(["plain", "fast"])
+    src = user_sources.SOFTPLUS_RANK1 if form == "plain" else user_sources.softplus_fast(dim)
+    c = 0.3 * rng.standard_normal(dim)
+    pt, ot = targets(dim, rng, ["poly", "banana"])
+    system = systems.DenseRiemannianMetricSystem(pt, models.UserMetric(dim, src, c))
+    osys = orc.RiemannianSystem(ot, omdl.SoftPlusRank1Metric(c), None, orc.Counters())
+    h, steps = float(rng.uniform(0.01, 0.05)), int(rng.integers(1, 4))
+    if isinstance(ot, omdl.Banana):
+        h *= 0.4
+    midpoint = rng.random() < 0.3
+    integ = (integrators.ImplicitMidpointIntegrator if midpoint else integrators.ImplicitLeapfrogIntegrator)(system, h)
+    q0 = 0.7 * rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+    dirs = np.where(rng.random(n) < 0.5, 1, -1).astype(np.int8)
+    desc = f"riemann_user softplus:{form} D={dim} N={n} {type(ot).__name__} {'midpoint' if midpoint else 'leapfrog'} h={h:.3f} steps={steps}"
+    stepper = orc.implicit_midpoint_steps if midpoint else orc.implicit_leapfrog_steps
+    ref = lambda cc: stepper(osys, q0[cc], p0[cc], dirs[cc] * h, steps)  # noqa: E731
+    return desc, integ, system, osys, q0, p0, dirs, steps, ref, 1e-9
+
+
+def softabs_user_case(rng):
+    """SoftAbs with the Hessian / MTP as USER source (the dense path of csrc/softabs.h): the banana's tridiagonal Hessian."""
+    from mici_amd import user_examples
+    dim = int(rng.integers(2, 65))
+    n = int(rng.choice([1, 2, 5]))
+    coeff = float(rng.choice([0.5, 1.0, 2.0]))
+    system = systems.SoftAbsRiemannianMetricSystem(
+        models.Banana(dim), softabs_coeff=coeff, hess_neg_log_dens=models.UserHessian(user_examples.BANANA_HESS))
+    osys = orc.RiemannianSystem(omdl.Banana(dim), None, coeff, orc.Counters())
+    h, steps = float(rng.uniform(0.004, 0.012)), int(rng.integers(1, 4)) * STEP_FACTOR
+    integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+    q0 = 0.5 * rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+    dirs = np.where(rng.random(n) < 0.5, 1, -1).astype(np.int8)
+    desc = f"softabs_user banana D={dim} N={n} coeff={coeff} h={h:.4f} steps={steps}"
+    ref = lambda c: orc.implicit_leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, steps)  # noqa: E731
+    return desc, integ, system, osys, q0, p0, dirs, steps, ref, 5e-8
+
+
 def constrained_case(rng):
     """Linear-equality and sphere manifolds up to D = 256 / C = 8 and D = 1024 / C <= 2 (the wave-per-chain kernels with
     one, four and sixteen coordinates per lane), both density conventions."""
@@ -180,7 +227,8 @@ def main():
     global STEP_FACTOR
     STEP_FACTOR = 4 if a.long else 1
     rng = np.random.default_rng(a.seed)
-    makers = {"euclid": euclid_case, "riemann": riemann_case, "softabs": softabs_case, "constrained": constrained_case}
+    makers = {"euclid": euclid_case, "riemann": riemann_case, "softabs": softabs_case, "constrained": constrained_case,
+              "riemann_user": riemann_user_case, "softabs_user": softabs_user_case}
     kinds = [makers[k] for k in a.kinds.split(",")]
     bad = 0
     for i in range(a.cases):

@@ -12,7 +12,7 @@
 #                                         and the user-source configs c3_user c4_general c3b_dense (kernels mm_rtc_*)
 #   <round>_<cfg>_sq_counters.json        SQ counters (two passes) - c2 c3 c3b c4 c5 c3_user c4_general c3b_dense
 #   <round>_c4_ubench_blk16.txt, <round>_c3_ubench_mfma.txt   phase clocks of the two dense-Riemannian kernels
-#   <round>_fuzz_parity.txt               tools/fuzz_parity.py, three seeds x 80 cases + 60 long SoftAbs cases
+#   <round>_fuzz_parity.txt               tools/fuzz_parity.py, three seeds x 80 cases + 60 long SoftAbs cases + constrained + user-source kinds
 #   <round>_host_latency.txt              tools/host_latency.py in three fresh processes (single-state Integrator.step, step_batch, system.h)
 ROUND=${ROUND:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -73,6 +73,15 @@ timeout 1200 python tools/fuzz_parity.py --seed 51 --cases 80 --kinds constraine
 echo "seed 51 (constrained only, D up to 1024) rc=$? $(tail -1 $O/fuzz_51.log)" >> $O/fuzz_parity.txt
 grep "MISMATCH\|Traceback\|refused" -B2 $O/fuzz_51.log | head -10 >> $O/fuzz_parity.txt
 rm -f $O/fuzz_51.log
+# user-source kinds (run-time compiled kernels: a translation unit per kernel family and source text, not per dim)
+timeout 1500 python tools/fuzz_parity.py --seed 61 --cases 40 --kinds riemann_user > $O/fuzz_61.log 2>&1
+echo "seed 61 (user metric, any D <= 279) rc=$? $(tail -1 $O/fuzz_61.log)" >> $O/fuzz_parity.txt
+grep "MISMATCH\|Traceback\|refused" -B2 $O/fuzz_61.log | head -10 >> $O/fuzz_parity.txt
+grep "^\[" $O/fuzz_61.log | cut -c1-110 >> $O/fuzz_parity.txt
+timeout 1500 python tools/fuzz_parity.py --seed 62 --cases 40 --kinds softabs_user > $O/fuzz_62.log 2>&1
+echo "seed 62 (user Hessian, D <= 64) rc=$? $(tail -1 $O/fuzz_62.log)" >> $O/fuzz_parity.txt
+grep "MISMATCH\|Traceback\|refused" -B2 $O/fuzz_62.log | head -10 >> $O/fuzz_parity.txt
+rm -f $O/fuzz_61.log $O/fuzz_62.log
 cat $O/fuzz_parity.txt
 
 # host-call latency of the reference's calling pattern (one Integrator.step(state) per step), three fresh processes
