@@ -238,6 +238,7 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
 #pragma unroll 1
     for (int k = 0; k < kRefineMaxIter; ++k) {
       prof(bk, PH_MAPPLY);
+      const double irz = mmdev::rcp_nr(rz);  // 1 / (r^T F r) for the direction update, in the shadow of the product below
       const double q = bk.metric_apply(bk.rslot(RS_D));
       prof(bk, PH_RSUM);
       const double dq = bk.sum1(bk.rslot(RS_D) * q);
@@ -254,12 +255,11 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
       // (the scale p^T u of the relative test stays the first guess' - the guess is good to 1e-2 or better and the test
       // is relative: on the wave backends a team sum is ~40 dependent DPP / readlane steps, one per pair saved)
       const double rz2 = bk.sum1(rv * z);
-      if (!(rz2 >= 0.0)) break;  // F not positive definite along r (or NaN): refinement failure -> factorisation
-      if (rz2 <= kRefineTol2 * fabs(pu)) {
-        ok = true;
+      if (!(rz2 > kRefineTol2 * fabs(pu))) {  // converged - or F not positive definite along r / NaN: refinement failure,
+        ok = rz2 >= 0.0;                      // the factorisation takes over
         break;
       }
-      bk.rslot(RS_D) = __builtin_fma(mmdev::fdiv(rz2, rz), bk.rslot(RS_D), z);
+      bk.rslot(RS_D) = __builtin_fma(rz2 * irz, bk.rslot(RS_D), z);
       rz = rz2;
     }
   }

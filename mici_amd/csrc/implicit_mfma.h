@@ -356,7 +356,8 @@ struct MfmaBackend {
       // rank-one update: B v from row `lane` of the staged base matrix (16-byte reads, conflict-free at a pitch of 66
       // doubles; zero on the padding) + x (x . v) / D.  (The row in registers between sweeps - 128 more next to the
       // inverse's 128 - was measured and loses: beyond 256 architected registers the allocator parks operands in
-      // accumulation registers, and every multiply-add then pays two v_accvgpr_read: c3 1.09e7 against 1.19e7.)
+      // accumulation registers, and every multiply-add then pays two v_accvgpr_read: c3 1.09e7 against 1.19e7.  Its leading
+      // 16 / 32 / 48 columns only: 1.29 / 1.30 / 1.12e7 against 1.32e7.)
       w.nat[lane] = (lane < dim) ? v : 0.0;
       wave_sync();
       const double* brow = base_lds + lane * kBasePitch;
