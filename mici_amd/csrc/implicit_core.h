@@ -211,7 +211,13 @@ enum {
 // non-positive curvature, a NaN - falls back to the factorisation of M(x_k), which reports the reference's errors
 // ("Cholesky factorisation failed", "Array is not finite") and drops the anchor for the rest of the step.
 enum { RS_U = 0, RS_R, RS_D, RS_COUNT };
-constexpr int kRefineMaxIter = 8;
+// (12 pairs cost about what the factorisation they avoid costs; with 8, one solve in thirty of c3_user - a metric whose
+// perturbation has full rank - ran out of iterations and took the factorised path: 4.6 against 5.5e6 steps/s.
+// MICI_AMD_RTC_FLAGS=-DMM_REFINE_MAX_ITER=n varies it in the run-time compiled kernels.)
+#ifndef MM_REFINE_MAX_ITER
+#define MM_REFINE_MAX_ITER 12
+#endif
+constexpr int kRefineMaxIter = MM_REFINE_MAX_ITER;
 constexpr double kRefineTol2 = 1e-28;  // (relative energy-norm error)^2
 
 template <class BK>
