@@ -557,11 +557,19 @@ struct SoftAbsBackendT {
   //          -1: w.V was updated but the passes stopped contracting - restart the sweeps from the identity.
   // The eigenvalues are the Rayleigh quotients of the last pass' input, whose error is the square of a rotation
   // below kRefineDone.
-  static constexpr double kRefineStart = 0.35;   // largest first-pass |E_ij| the refinement is started from
+#ifndef MM_SA_REFINE_START  // (A/B runs: tools/ab_build.py, MICI_AMD_RTC_FLAGS)
+#define MM_SA_REFINE_START 1.0
+#endif
+#ifndef MM_SA_REFINE_MAX_PASS
+#define MM_SA_REFINE_MAX_PASS 8
+#endif
+  // largest first-pass |E_ij| the refinement is started from.  Measured (steps/s; Jacobi sweeps per step), c3(b) / c3b_dense:
+  // 0.35: 5.69e5 (0.31) / 2.94e5 (4.6);  0.7: 5.76e5 / 3.09e5;  1.0: 5.82e5 (0.16) / 3.11e5 (2.7);  2.0: 5.81e5 / 3.02e5;  4.0: - / 2.97e5
+  static constexpr double kRefineStart = MM_SA_REFINE_START;
   static constexpr double kRefineDone = 1e-7;    // a pass whose largest |E_ij| is below this is the last
   static constexpr double kRefineGuard = 1e-6;   // relative eigenvalue gap below which a pair counts as multiple
   static constexpr double kRefineSplit = 1e-11;  // largest |S_ij| / |A| tolerated inside such a pair at the end
-  static constexpr int kRefineMaxPass = 8;
+  static constexpr int kRefineMaxPass = MM_SA_REFINE_MAX_PASS;
   static constexpr int kOrthoPeriod = 8;
   __device__ __forceinline__ int refine_eigh() {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
