@@ -92,7 +92,7 @@ def riemann_case(rng):
         pm, om = models.DiagQuadMetric(dim), omdl.DiagQuadMetric(dim)
     system = systems.DenseRiemannianMetricSystem(pt, pm)
     osys = orc.RiemannianSystem(ot, om, None, orc.Counters())
-    h, steps = float(rng.uniform(0.01, 0.06)), int(rng.integers(1, 5))
+    h, steps = H_FACTOR * float(rng.uniform(0.01, 0.06)), int(rng.integers(1, 5))
     if isinstance(ot, omdl.Banana):
         h *= 0.4
     solver = int(rng.integers(0, 2))
@@ -107,6 +107,7 @@ def riemann_case(rng):
     return desc, integ, system, osys, q0, p0, dirs, steps, ref, 1e-9
 
 
+H_FACTOR = 1.0  # --stress: step sizes this much larger (fixed points that diverge / run out of iterations: the statuses must agree)
 STEP_FACTOR = 1  # --long: longer SoftAbs trajectories (the decompositions are refined from one another, k_softabs.hip)
 
 
@@ -122,7 +123,7 @@ def softabs_case(rng):
     coeff = float(rng.choice([0.5, 1.0, 2.0]))
     system = systems.SoftAbsRiemannianMetricSystem(pt, softabs_coeff=coeff)
     osys = orc.RiemannianSystem(ot, None, coeff, orc.Counters())
-    h, steps = float(rng.uniform(0.01, 0.05)), int(rng.integers(1, 4)) * STEP_FACTOR
+    h, steps = H_FACTOR * float(rng.uniform(0.01, 0.05)), int(rng.integers(1, 4)) * STEP_FACTOR
     integ = integrators.ImplicitLeapfrogIntegrator(system, h)
     q0 = 0.5 * rng.standard_normal((n, dim))
     p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
@@ -146,7 +147,7 @@ def riemann_user_case(rng):
     pt, ot = targets(dim, rng, ["poly", "banana"])
     system = systems.DenseRiemannianMetricSystem(pt, models.UserMetric(dim, src, c))
     osys = orc.RiemannianSystem(ot, omdl.SoftPlusRank1Metric(c), None, orc.Counters())
-    h, steps = float(rng.uniform(0.01, 0.05)), int(rng.integers(1, 4))
+    h, steps = H_FACTOR * float(rng.uniform(0.01, 0.05)), int(rng.integers(1, 4))
     if isinstance(ot, omdl.Banana):
         h *= 0.4
     midpoint = rng.random() < 0.3
@@ -169,7 +170,7 @@ def softabs_user_case(rng):
     system = systems.SoftAbsRiemannianMetricSystem(
         models.Banana(dim), softabs_coeff=coeff, hess_neg_log_dens=models.UserHessian(user_examples.BANANA_HESS))
     osys = orc.RiemannianSystem(omdl.Banana(dim), None, coeff, orc.Counters())
-    h, steps = float(rng.uniform(0.004, 0.012)), int(rng.integers(1, 4)) * STEP_FACTOR
+    h, steps = H_FACTOR * float(rng.uniform(0.004, 0.012)), int(rng.integers(1, 4)) * STEP_FACTOR
     integ = integrators.ImplicitLeapfrogIntegrator(system, h)
     q0 = 0.5 * rng.standard_normal((n, dim))
     p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
@@ -221,19 +222,25 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--long", action="store_true", help="SoftAbs cases integrate four times as many steps")
+    ap.add_argument("--stress", type=float, default=1.0, help="multiply the Riemannian step sizes (failing solves)")
+    ap.add_argument("--only", type=int, default=-1, help="run this case of the sequence only (the draws of the others are still made)")
     ap.add_argument("--kinds", default="euclid,riemann,softabs,constrained",
                     help="comma-separated case families to draw from (uniformly)")
     a = ap.parse_args()
-    global STEP_FACTOR
+    global STEP_FACTOR, H_FACTOR
+    H_FACTOR = a.stress
     STEP_FACTOR = 4 if a.long else 1
     rng = np.random.default_rng(a.seed)
     makers = {"euclid": euclid_case, "riemann": riemann_case, "softabs": softabs_case, "constrained": constrained_case,
               "riemann_user": riemann_user_case, "softabs_user": softabs_user_case}
     kinds = [makers[k] for k in a.kinds.split(",")]
-    bad = 0
+    bad = n_failed = 0
     for i in range(a.cases):
         make = kinds[int(rng.integers(0, len(kinds)))]
         desc, integ, system, osys, q0, p0, dirs, steps, ref, tol = make(rng)
+        if a.only >= 0 and i != a.only:
+            rng.integers(0, len(q0))  # (the draw of the compared chain below)
+            continue
         try:
             q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=steps)
         except Exception as e:  # unsupported sizes must fail loudly, never silently
@@ -246,9 +253,11 @@ def main():
                 ok = False
                 err = np.max(np.abs(np.nan_to_num(q[c]) - np.nan_to_num(qo)))
                 print(f"    chain {c}: status {status[c]} vs {so}, n_done {n_done[c]} vs {no}, max |dq| = {err:.2e}")
-        print(f"[{i}] {desc}: {'ok' if ok else 'MISMATCH'}")
+        failed = int(np.count_nonzero(status))
+        n_failed += failed > 0
+        print(f"[{i}] {desc}: {'ok' if ok else 'MISMATCH'}" + (f" ({failed} of {len(status)} chains stopped early: {sorted(set(status[status != 0].tolist()))})" if failed else ""))
         bad += not ok
-    print(f"{a.cases} cases, {bad} mismatches")
+    print(f"{a.cases} cases, {bad} mismatches" + (f" ({n_failed} cases with chains that stopped early, statuses equal)" if n_failed else ""))
     sys.exit(1 if bad else 0)
 
 
