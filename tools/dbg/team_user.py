@@ -1,3 +1,5 @@
+"""One implicit step of a user metric at the given dims (default 128 270) on the run-time compiled team / block-16 kernels against
+the oracle, for each form of the source (plain, aux + dense VJP, aux + flat VJP).  python tools/dbg/team_user.py [dims...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, 'tests')
