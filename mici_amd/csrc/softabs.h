@@ -736,6 +736,9 @@ struct SoftAbsBackendT {
           SA_PROF_END(4);
           return true;
         }
+#ifdef MM_SA_DBG_COUNT  // (debug, tools/dbg/sa_handover.sh: 1000 in the sweep counter per warm hand-over (=1) / per restart (=2))
+        n_sweeps += ((rc < 0) == (MM_SA_DBG_COUNT == 2)) ? 1000 : 0;
+#endif
         if (rc < 0) {  // restart from the identity (the Hessian is intact: the passes only read it)
           warm = 0;
           for (int el = tid; el < NP * dim; el += NT) {
