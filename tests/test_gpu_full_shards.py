@@ -75,6 +75,10 @@ def test_c2iv_dense_metric_full_trajectory_matches_oracle():
     ("c3", 4, 1e-10, 4),     # c3(a): D=64, 1024 chains, one wave per chain
     ("c4", 2, 1e-10, 2),     # c4 shard: D=256, 1024 chains, one workgroup (a whole CU) per chain: 4 waves of CUs
     ("c3b", 2, 2e-9, 2),     # c3(b): SoftAbs D=64, 1024 chains, one 1024-thread workgroup per chain
+    # round 4, the general path (user source, run-time compiled kernels) at the same shard sizes
+    ("c3_user", 4, 1e-10, 4),     # softplus + rank-one metric on the matrix-core wave kernel
+    ("c4_general", 2, 1e-10, 2),  # the c4 metric as user source on the block-16 kernel
+    ("c3b_dense", 2, 2e-9, 2),    # SoftAbs on the banana, Hessian / MTP as user source (dense path)
 ])
 def test_riemannian_full_shard_matches_oracle_and_is_reversible(config, steps, tol, per_group):
     n = 1024
@@ -114,6 +118,9 @@ def test_riemannian_full_shard_matches_oracle_and_is_reversible(config, steps, t
     ("c3", 1e-10, 4),    # 100 steps: 29 CG refinements per step start from the previous step's solutions
     ("c4", 1e-10, 1),    # 50 steps
     ("c3b", 2e-9, 1),    # 100 steps: the eigenbasis and its two snapshots live across steps
+    ("c3_user", 1e-10, 2),     # round 4: the same, through the run-time compiled kernels of user source
+    ("c4_general", 1e-10, 1),
+    ("c3b_dense", 2e-9, 1),    # (h = 0.01; a few chains of the shard meet a ConvergenceError - in the oracle too)
 ])
 def test_riemannian_bench_length_trajectory_matches_oracle(config, tol, per_group):
     """the trajectory bench.py times - 100 / 50 / 100 fused steps on the whole 1024-chain shard - against
@@ -122,24 +129,30 @@ def test_riemannian_bench_length_trajectory_matches_oracle(config, tol, per_grou
     n = 1024
     w, osys = _workload(config, n)
     steps = w["traj"]
-    assert steps == {"c3": 100, "c4": 50, "c3b": 100}[config]
+    assert steps == {"c3": 100, "c4": 50, "c3b": 100, "c3_user": 100, "c4_general": 50, "c3b_dense": 100}[config]
     integ = w["integ"]
     q, p, status, n_done = integ.step_batch(w["q0"], w["p0"], 1, n_steps=steps)
     counters = dict(integ.last_counters)
-    assert np.all(status == 0), np.flatnonzero(status)[:10]
-    assert np.all(n_done == steps)
+    may_fail = config == "c3b_dense"
+    if may_fail:
+        assert np.count_nonzero(status) < 0.1 * n and np.all((n_done == steps) == (status == 0))
+    else:
+        assert np.all(status == 0), np.flatnonzero(status)[:10]
+        assert np.all(n_done == steps)
     sample = np.unique(np.concatenate([np.arange(per_group), np.arange(n - per_group, n), [n // 2 + 1]]))
     if len(sample) < 4:
         sample = np.unique(np.concatenate([sample, [1]]))
     assert len(sample) >= 4
     for c in sample:
         qo, po, so, no = orc.implicit_leapfrog_steps(osys, w["q0"][c], w["p0"][c], w["h"], steps)
-        assert so == 0 and no == steps
+        assert so == status[c] and no == n_done[c], (c, so, status[c], no, n_done[c])
+        assert may_fail or so == 0
         assert_close(q[c], qo, tol, f"{config} q chain {c} after {steps} steps")
         assert_close(p[c], po, tol, f"{config} p chain {c} after {steps} steps")
-    assert counters["n_fp_solves"] == 4 * n * steps
+    if not may_fail:
+        assert counters["n_fp_solves"] == 4 * n * steps
     # the same chains alone, one launch per 10 steps: carried state (bases, guesses) must not change the result
-    sub = sample[:4]
+    sub = sample[status[sample] == 0][:4]
     qs, ps = w["q0"][sub].copy(), w["p0"][sub].copy()
     for _ in range(steps // 10):
         qs, ps, ss, ns = integ.step_batch(qs, ps, 1, n_steps=10)
