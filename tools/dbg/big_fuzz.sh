@@ -4,7 +4,7 @@ run() { timeout 1500 python tools/fuzz_parity.py --seed $1 --cases $2 --kinds $3
 run 71 150 riemann_user &
 run 72 200 softabs_user &
 wait
-run 73 200 riemann &
+run 73 300 riemann &
 run 74 120 softabs --long &
 wait
 run 75 200 euclid,constrained

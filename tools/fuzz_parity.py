@@ -81,7 +81,7 @@ def euclid_case(rng):
 
 
 def riemann_case(rng):
-    dim = int(rng.choice([1, 2, 5, 8, 9, 16, 31, 32, 33, 40, 63, 64, 65, 70, 75, 76, 90, 128, 200, 255, 256]))
+    dim = int(rng.choice([1, 2, 5, 8, 9, 16, 31, 32, 33, 40, 63, 64, 65, 70, 75, 76, 90, 128, 200, 255, 256, 257, 270, 279]))
     n = int(rng.choice([1, 2, 5, 9]))
     which = rng.choice(["rank1", "diagquad"])
     pt, ot = targets(dim, rng, ["poly", "banana"] if dim >= 2 else ["poly"])
