@@ -712,6 +712,9 @@ struct SoftAbsBackendT {
       for (int r = 0; r < 4; ++r) X[(16 * I + 4 * r + g) * LD + cj] = acc[r];
       __syncthreads();
       SA_LAP(3);
+#if defined(MM_SA_DBG_COUNT) && MM_SA_DBG_COUNT == 3  // (debug: 1000 in the sweep counter per split cluster)
+      if (last && !(near_s <= kRefineSplit * norm_a)) n_sweeps += 1000;
+#endif
       if (last) return (near_s <= kRefineSplit * norm_a) ? 1 : 0;  // 0: a split cluster the passes cannot resolve
     }
     return -1;
@@ -737,7 +740,7 @@ struct SoftAbsBackendT {
           return true;
         }
 #ifdef MM_SA_DBG_COUNT  // (debug, tools/dbg/sa_handover.sh: 1000 in the sweep counter per warm hand-over (=1) / per restart (=2))
-        n_sweeps += ((rc < 0) == (MM_SA_DBG_COUNT == 2)) ? 1000 : 0;
+        n_sweeps += (MM_SA_DBG_COUNT < 3 && (rc < 0) == (MM_SA_DBG_COUNT == 2)) ? 1000 : 0;
 #endif
         if (rc < 0) {  // restart from the identity (the Hessian is intact: the passes only read it)
           warm = 0;
