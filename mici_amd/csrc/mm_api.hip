@@ -474,6 +474,7 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
 int mm_model_destroy(mm_model* m) {
   if (!m) return MM_OK;
   (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);  // nothing of this model's run-time compiled modules may still be in flight
   mm_rtc_detach(m);
   (void)hipFree(m->d_target_params);
   (void)hipFree(m->d_metric);
