@@ -206,6 +206,9 @@ struct MfmaBackend {
   // loads a lane); a product is then the vector broadcast from LDS (sixteen 16-byte reads of one address) against 64
   // registers: no partial sums, no reduction, the result already flat.  M(x) v of the refinement solves takes row i of
   // the staged base matrix the same way (rank-one metric), or of the user's metric evaluated once per solve.
+  // 1 / D of the rank-one metric's q q^T / D: multiplied with, not divided by - the IEEE division's ~30 dependent
+  // instructions sat on the critical path of every M(x) v and every momentum iteration
+  double inv_dim_;
   double fr_[64];  // row `lane` of M(x0)^-1 (the padding is the identity: zero off the diagonal)
   double fd_;      // its diagonal entry
 
@@ -380,7 +383,7 @@ struct MfmaBackend {
       for (int h = kAccM / 2; h >= 1; h >>= 1)
 #pragma unroll
         for (int a = 0; a < h; ++a) ya[a] += ya[a + h];
-      const double y = __builtin_fma(x, dot / (double)dim, ya[0]);
+      const double y = __builtin_fma(x, dot * inv_dim_, ya[0]);
       return lane < dim ? y : 0.0;
     }
   }
@@ -647,7 +650,7 @@ struct MfmaBackend {
   // 0.5 * vjp_metric(M^-1): rank-one metric M^-1 q / D; diag-quad metric q_i (M^-1)_ii
   __device__ __forceinline__ double half_vjp_inv(double q) {
     if constexpr (RMETRIC == MM_RMETRIC_USER) return user_half_vjp<false>(0.0);
-    else if constexpr (RMETRIC == MM_RMETRIC_RANK1) return matvec(q) / (double)dim;
+    else if constexpr (RMETRIC == MM_RMETRIC_RANK1) return matvec(q) * inv_dim_;
     else return q * diag();
   }
   // dense metric: grad_quadratic_form_inv(p) = -(M^-1 p)(M^-1 p)^T   (matrices.py:1179-1181)
@@ -657,7 +660,7 @@ struct MfmaBackend {
       return user_half_vjp<true>(u);
     } else if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
       const double uq = wave_sum(lane < dim ? u * q : 0.0);
-      return -(u * uq) / (double)dim;
+      return -(u * uq) * inv_dim_;
     } else {
       return -q * (u * u);
     }
@@ -700,6 +703,7 @@ __device__ __forceinline__ void implicit_mfma_body(const ImplicitArgs& A, double
 
   MfmaBackend<RMETRIC, PROFILE> bk;
   bk.dim = dim;
+  bk.inv_dim_ = 1.0 / (double)dim;
   bk.lane = lane;
   bk.target = A.target;
   bk.w.qt = wl;

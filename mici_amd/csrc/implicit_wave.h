@@ -301,7 +301,7 @@ template <int TS, int RMETRIC>
 __device__ __forceinline__ double half_vjp_tiles(const double (&V)[TS][TS], double q, int dim,
                                                  int lane, const WaveLds& w, const double* uparams = nullptr) {
   if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
-    return matvec_flat<TS>(V, q, lane, w) / (double)dim;
+    return matvec_flat<TS>(V, q, lane, w) * (1.0 / (double)dim);
   } else {
     return q * diag_flat<TS>(V, lane, w);
   }
@@ -313,7 +313,7 @@ __device__ __forceinline__ double half_vjp_neg_outer(double u, double q, int dim
                                                      const double* uparams = nullptr) {
   if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
     const double uq = wave_sum(lane < dim ? u * q : 0.0);
-    return -(u * uq) / (double)dim;
+    return -(u * uq) * (1.0 / (double)dim);
   } else {
     return -q * (u * u);
   }
@@ -448,7 +448,7 @@ struct WaveBackend {
       wave_sync();
       const double y = (lane < Geo<TS>::DP) ? w.vout[Geo<TS>::pos(lane)] : 0.0;
       wave_sync();
-      return lane < dim ? __builtin_fma(xpt_, dot / (double)dim, y) : 0.0;
+      return lane < dim ? __builtin_fma(xpt_, dot * (1.0 / (double)dim), y) : 0.0;
     } else {  // diag(1 + x^2)
       return lane < dim ? __builtin_fma(xpt_ * xpt_, v, v) : 0.0;
     }

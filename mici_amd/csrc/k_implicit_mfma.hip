@@ -26,6 +26,7 @@ __global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs 
   double* wl = lds + kBaseDoubles + wave * kMfmaWaveDoubles;
   MfmaBackend<MM_RMETRIC_RANK1> bk;
   bk.dim = dim;
+  bk.inv_dim_ = 1.0 / (double)dim;
   bk.lane = lane;
   bk.target = A.target;
   bk.w.qt = wl;

@@ -14,7 +14,7 @@ __device__ double mm_user_metric(const double* q, int i, int j, int dim, const d
 }
 template <class Ops>
 __device__ double mm_user_vjp_flat(Ops& V, const double* q, int k, int dim, const double* params, const double* aux) {
-  return 2.0 * (V.matvec(V.active() ? q[k] : 0.0) / (double)dim);
+  return 2.0 * (V.matvec(V.active() ? q[k] : 0.0) * (1.0 / (double)dim));
 }
 """
 
