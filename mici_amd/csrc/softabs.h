@@ -661,9 +661,16 @@ struct SoftAbsBackendT {
         for (int r = 0; r < 4; ++r) xx[r] = (16 * I + 4 * r + g == cj) ? 1.0 : 0.0;
       }
       if (I == J) {  // Rayleigh quotients from the diagonal tiles: element (4 r + g, j) of the tile is acc[r]
+        // (the lane's one diagonal element selected first: four predicated IEEE divisions - ~30 dependent instructions each -
+        // stood between the products and the barrier of every pass)
+        double sn = 0.0, xn = 1.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (4 * r + g == j) w.lam[cj] = cj_ok ? s[r] / xx[r] : 1.0;
+          if (4 * r + g == j) {
+            sn = s[r];
+            xn = xx[r];
+          }
+        if ((j & 3) == g) w.lam[cj] = cj_ok ? fdiv(sn, xn) : 1.0;
       }
       __syncthreads();
       SA_LAP(1);
@@ -978,7 +985,7 @@ struct SoftAbsBackendT {
   __device__ __forceinline__ double matvec(double v) {
     SA_PROF_BEGIN();
     const double c = vt_times(v);
-    const double u = v_times(tid < dim ? (1.0 / w.lamt[tid]) * c : 0.0);
+    const double u = v_times(tid < dim ? mmdev::rcp_nr(w.lamt[tid]) * c : 0.0);
     SA_PROF_END2(10);
     return u;
   }
@@ -1065,7 +1072,7 @@ struct SoftAbsBackendT {
       double md = 0.0, m0 = 0.0;
       if (i < dim) {
         for (int k = part; k < dim; k += RP) {
-          const double g = w.gsa[k] / w.lamt[k];
+          const double g = fdiv(w.gsa[k], w.lamt[k]);
           const double vik = w.V[i * LD + k];
           md = __builtin_fma(vik * vik, g, md);
           m0 = __builtin_fma(w.V[k] * vik, g, m0);  // V[0][k] V[i][k] g_k
@@ -1097,7 +1104,7 @@ struct SoftAbsBackendT {
       if (k < dim)
         for (int i = part; i < dim; i += RP) s = __builtin_fma(w.V[i * LD + k], vin[i], s);
       s = rp_sum(s);
-      if (part == 0) w.v1[k] = (k < dim) ? s / w.lamt[k] : 0.0;
+      if (part == 0) w.v1[k] = (k < dim) ? fdiv(s, w.lamt[k]) : 0.0;
       __syncthreads();
     }
     SA_LAP(16);
@@ -1116,7 +1123,7 @@ struct SoftAbsBackendT {
           if (k < dim && l < dim) {
             double num = w.lamt[k] - w.lamt[l], den = w.lam[k] - w.lam[l];
             if (k == l) { num += w.gsa[k]; den = 1.0; }
-            jv = num / den;                        // 0/0 -> NaN for degenerate spectra, as the reference
+            jv = fdiv(num, den);                   // 0/0 -> NaN for degenerate spectra, as the reference
           }
           w.H[k * LD + l] = jv;
         }
