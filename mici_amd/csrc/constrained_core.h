@@ -430,6 +430,7 @@ __device__ __forceinline__ bool chol_inverse(const CMat<C>& g, CMat<C>* inv, dou
     return true;
   }
   CMat<C> l;
+  double ril[C];
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < C; ++j) {
@@ -437,14 +438,17 @@ __device__ __forceinline__ bool chol_inverse(const CMat<C>& g, CMat<C>* inv, dou
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= l.m[j][k] * l.m[j][k];
     ok = ok && (d > 0.0);
-    const double ljj = sqrt(d);
+    // L_jj and 1 / L_jj from one v_rsq_f64 (mm_device.h): every division by a diagonal entry below is a multiplication -
+    // the IEEE expansion is ~30 dependent instructions, and a lane runs C (C + 1) of them per Gram matrix
+    double ljj;
+    mmdev::sqrt_rsqrt(d > 0.0 ? d : 1.0, &ljj, &ril[j]);
     l.m[j][j] = ljj;
 #pragma unroll
     for (int i = j + 1; i < C; ++i) {
       double s = g.m[i][j];
 #pragma unroll
       for (int k = 0; k < j; ++k) s -= l.m[i][k] * l.m[j][k];
-      l.m[i][j] = s / ljj;
+      l.m[i][j] = s * ril[j];
     }
   }
   if (!ok) return false;
@@ -457,7 +461,7 @@ __device__ __forceinline__ bool chol_inverse(const CMat<C>& g, CMat<C>* inv, dou
       double s = (i == c) ? 1.0 : 0.0;
 #pragma unroll
       for (int k = i + 1; k < C; ++k) s -= l.m[k][i] * y.m[k][c];
-      y.m[i][c] = s / l.m[i][i];
+      y.m[i][c] = s * ril[i];
     }
   // X = U^-1 Y^T
 #pragma unroll
@@ -467,7 +471,7 @@ __device__ __forceinline__ bool chol_inverse(const CMat<C>& g, CMat<C>* inv, dou
       double s = y.m[c][i];
 #pragma unroll
       for (int k = i + 1; k < C; ++k) s -= l.m[k][i] * inv->m[k][c];
-      inv->m[i][c] = s / l.m[i][i];
+      inv->m[i][c] = s * ril[i];
     }
   double ld = 0.0;
 #pragma unroll
@@ -568,6 +572,7 @@ __device__ __forceinline__ CVec<C> lu_solve(CMat<C> a, CVec<C> b) {
     x1.v[0] = mmdev::fdiv(b.v[0], a.m[0][0]);
     return x1;
   }
+  double rp[C];  // reciprocals of the pivots: the divisions of the elimination and of the back substitution as products
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     if constexpr (C > 1) {
@@ -596,9 +601,10 @@ __device__ __forceinline__ CVec<C> lu_solve(CMat<C> a, CVec<C> b) {
         }
       }
     }
+    rp[k] = mmdev::rcp_nr(a.m[k][k]);  // (a zero pivot: NaN where the division gives inf - "not finite" either way)
 #pragma unroll
     for (int i = k + 1; i < C; ++i) {
-      const double f = a.m[i][k] / a.m[k][k];
+      const double f = a.m[i][k] * rp[k];
 #pragma unroll
       for (int j = k + 1; j < C; ++j) a.m[i][j] -= f * a.m[k][j];
       b.v[i] -= f * b.v[k];
@@ -610,7 +616,7 @@ __device__ __forceinline__ CVec<C> lu_solve(CMat<C> a, CVec<C> b) {
     double s = b.v[i];
 #pragma unroll
     for (int j = i + 1; j < C; ++j) s -= a.m[i][j] * x.v[j];
-    x.v[i] = s / a.m[i][i];
+    x.v[i] = s * rp[i];
   }
   return x;
 }
