@@ -231,7 +231,7 @@ __device__ __forceinline__ double target_grad_elem(int target, const TargetAux& 
       double w_, iw;
       sqrt_rsqrt(u * u + z * z, &w_, &iw);
       const double sp = z * iw, cp = u * iw;                // sin phi, cos phi
-      const double r_over_R = r / R;
+      const double r_over_R = r * rcp_nr(R);               // (two parameters: not worth an IEEE division per gradient)
       const double d1 = 1.0 + r_over_R * cp, d2 = 1.0 + al * s4 * cp;
       const double id2 = rcp_nr(d2);
       const double dl_dphi = -r_over_R * sp * rcp_nr(d1) + al * s4 * sp * id2;
