@@ -22,3 +22,10 @@ def test_every_environment_switch_is_documented():
     assert len(names) >= 15, names
     missing = sorted(n for n in names if n not in doc)
     assert not missing, f"INTEGRATION.md has no row for {missing}"
+
+
+def test_fixture_count_quoted_in_the_documents():
+    n = len(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+    for name in ("README.md", "DESIGN.md"):
+        text = open(os.path.join(ROOT, name)).read()
+        assert f"{n} fixtures" in text or f"{n} cases" in text, f"{name} does not quote the {n} fixtures of tests/golden/"
