@@ -14,10 +14,12 @@ inputs resident in HBM when the timed region starts; failed chains count only co
 
 Headline (N=1) workload = BASELINE.json configs[1] (c2): EuclideanMetricSystem, dense-precision
 Gaussian target, D=128, 4096 chains per GPU, identity metric, explicit leapfrog h=0.05, L=1000.
-The same JSON line carries a `configs` object with the other BASELINE configs measured in the same
-process by the same procedure (c2(i), c2(iv), c3(a), c3(b), the c4 per-GPU shard, the c5 per-GPU shard):
-value, ms_per_step, roofline and (N=1) cpu_baseline each.  Their pass counts are capped so that the
-default run stays within a few minutes (`steps` is reported per entry).
+The other BASELINE configs are measured in the same process by the same procedure (c2(i), c2(iv), c3(a), c3(b), the c4
+per-GPU shard, the c5 per-GPU shard, the three user-source configs): their full records (value, ms_per_step, roofline,
+work counters and, at N=1, cpu_baseline each) go to the SIDECAR file `bench_configs.json` next to this script; the one
+stdout line stays under 4 KB (`compact_result`: the headline whole, five scalars per extra config) because the driver's
+capture lost the 22 KB line of round 4.  Their pass counts are capped so that the default run stays within a few minutes
+(`steps` is reported per entry in the sidecar).
 
 Multi-GPU: one process per GPU.  Launched under `python -m torch.distributed.run` the ranks come from
 RANK / LOCAL_RANK / WORLD_SIZE; started plainly as `python bench.py --gpus N` the script starts the N
@@ -667,7 +669,7 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE /
     # WRITE_SIZE cannot be read from inside the process); null when this shape was not profiled
     default_shape = chains_per_gpu is None and traj_len is None
-    for pmc_name in (f"r04_{config}_pmc_hbm.json", f"r03_{config}_pmc_hbm.json", f"r02_{config}_pmc_hbm.json"):
+    for pmc_name in (f"r05_{config}_pmc_hbm.json", f"r04_{config}_pmc_hbm.json", f"r03_{config}_pmc_hbm.json", f"r02_{config}_pmc_hbm.json"):
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if default_shape and os.path.exists(pmc):
             with open(pmc) as fh:
@@ -707,6 +709,87 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
                  f"of {traj} leapfrog steps per chain",
         baseline_config=BASELINE_CONFIG.get(config, config), chains_per_gpu=n_local, dim=w["dim"], traj_len=traj,
         trace_gather=gather_note, trace_gather_ms=trace_gather_ms, _exit_hard=exit_hard)
+
+
+# ---- the result line ---------------------------------------------------------------------------------------------
+HEADLINE_MAX_BYTES = 4096  # the driver's capture lost a 22 KB line in round 4 (BENCH_r04.json: parsed null)
+_ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_per_launch", "mfma_busy",
+              "algorithmic_flops_per_chain_step", "algorithmic_bytes_per_chain_step", "algorithmic_bytes_per_chain_launch")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "single_chain_1core")
+
+
+def _sig(x, digits=6):
+    """Floats to `digits` significant figures (the line is read by a parser, not compared bit for bit)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_result(full, sidecar=None):
+    """The LAST stdout line: the headline only - metric, value, unit, n_gpus, steps, warmup, ms_per_step, dtype,
+    config{workload, ...}, roofline{bound, achieved, peak, unit, frac, traffic, kernel_ms_per_launch, algorithmic_*},
+    cpu_baseline{value, unit, cores, kind, sample} - plus five scalars per extra config (`configs.<name>` = value,
+    ms_per_step, roofline frac, kernel ms per launch, CPU-baseline value).  Everything else is in the sidecar."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data")}
+    cfg = dict(full["config"])
+    cfg["workload"] = cfg["workload"][:200]
+    cfg["parallelism"] = cfg["parallelism"][:120]
+    out["config"] = cfg
+    out["roofline"] = {k: full["roofline"][k] for k in _ROOF_KEYS if k in full["roofline"]}
+    if "cpu_baseline" in full:
+        cb = {k: full["cpu_baseline"][k] for k in _CPU_KEYS if k in full["cpu_baseline"]}
+        if isinstance(cb.get("sample"), str):
+            cb["sample"] = cb["sample"][:200]
+        out["cpu_baseline"] = cb
+    if full.get("configs"):
+        brief = {}
+        for name, res in full["configs"].items():
+            if "error" in res:
+                brief[name] = {"error": res["error"][:80]}
+                continue
+            brief[name] = {"value": res["value"], "ms_per_step": res["ms_per_step"],
+                           "frac": res["roofline"]["frac"], "kernel_ms": res["roofline"]["kernel_ms_per_launch"],
+                           "cpu": (res.get("cpu_baseline") or {}).get("value")}
+        out["configs"] = brief
+    if sidecar:
+        out["detail"] = sidecar
+    out = _sig(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > HEADLINE_MAX_BYTES:  # never again: drop the per-config scalars before the headline suffers
+        out.pop("configs", None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) <= HEADLINE_MAX_BYTES, len(line)
+    return line
+
+
+def emit_result(full):
+    """Full detail -> sidecar file `bench_configs.json` (next to bench.py; MICI_AMD_BENCH_SIDECAR overrides, also copied
+    under gpurun_out/ when that directory exists); one short `# name: ...` line per extra config on stderr; the compact
+    headline is the ONLY line of stdout."""
+    side = os.environ.get("MICI_AMD_BENCH_SIDECAR", os.path.join(ROOT, "bench_configs.json"))
+    written = None
+    try:
+        with open(side, "w") as fh:
+            json.dump(full, fh, indent=1)
+        written = os.path.relpath(side, ROOT) if side.startswith(ROOT) else side
+        scratch = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(scratch) and "MICI_AMD_BENCH_SIDECAR" not in os.environ:
+            with open(os.path.join(scratch, "bench_configs.json"), "w") as fh:
+                json.dump(full, fh, indent=1)
+    except OSError:
+        pass
+    for name, res in (full.get("configs") or {}).items():  # one short line per extra config, before the headline
+        if "error" in res:
+            print(f"# {name}: {res['error']}", file=sys.stderr, flush=True)
+        else:
+            print(f"# {name}: {res['value']:.4g} steps/s, {res['ms_per_step']:.4g} ms/pass, roofline "
+                  f"{res['roofline']['frac']:.3f} ({res['roofline']['bound']})", file=sys.stderr, flush=True)
+    print(compact_result(full, written), flush=True)
 
 
 def main():
@@ -820,6 +903,7 @@ def main():
                                + (" [MICI_AMD_SHARE_DEVICE: ranks share devices - not a measurement]" if share else ""),
                 "trace_gather": head["trace_gather"],
                 "trace_gather_ms": head["trace_gather_ms"],
+                "n_ranks_seen": head.get("n_ranks_seen", world),
             },
             "roofline": head["roofline"],
             # wall clock of the timed region on every rank (value uses the max): a straggler shows up here
@@ -829,7 +913,7 @@ def main():
             out["cpu_baseline"] = head["cpu_baseline"]
         if configs:
             out["configs"] = configs
-        print(json.dumps(out), flush=True)
+        emit_result(out)
 
     if exit_hard:  # a collective is wedged in the helper thread: the result line is out, leave without cleanup
         sys.stdout.flush()
