@@ -53,6 +53,8 @@ struct ImplicitArgs {
   int no_refine;  // 1: factorise every metric construction (MICI_AMD_REFINE=0: A/B runs against section 4.3c of DESIGN.md)
   double* work;   // user metrics with the dense-accessor VJP beyond the wave kernels: [n_chains][NP * NP] doubles of global
                   // memory the held inverse is dumped to (user_metric.h), NP the backend's padded dimension
+  int no_dual;    // 1: the two position solves of a step one after the other, as in rounds 1-4 (MICI_AMD_DUAL=0: A/B runs
+                  // against the lock-step form)
 };
 
 // MICI_AMD_REFINE=0 in the environment switches the refinement of the solve-only constructions off (read once)
@@ -60,6 +62,14 @@ struct ImplicitArgs {
 inline int mm_refine_disabled() {
   static const int off = [] {
     const char* e = getenv("MICI_AMD_REFINE");
+    return (e && e[0] == '0') ? 1 : 0;
+  }();
+  return off;
+}
+// MICI_AMD_DUAL=0: the reversibility-check solve and the C-adjoint solve of a step run one after the other (read once)
+inline int mm_dual_disabled() {
+  static const int off = [] {
+    const char* e = getenv("MICI_AMD_DUAL");
     return (e && e[0] == '0') ? 1 : 0;
   }();
   return off;
@@ -85,26 +95,30 @@ enum { FP_CONT = 0, FP_DONE = 1, FP_FAIL = 2 };
 
 // fx = f(point last requested).  FP_CONT: evaluate f at *out next; FP_DONE: *out is the solution;
 // FP_FAIL: *status says why (diverged / max_iters).
-template <class BK>
-__device__ __forceinline__ int fp_feed(BK& bk, FpCtl& c, double& x0, double& x1, double fx,
-                                       const mm_fp_opts& o, double* out, int* status) {
-  double x;
+// In two halves so that two solves advancing in lock step (implicit_leapfrog_chain, kDual backends) can take their two
+// convergence norms through ONE team reduction: fp_pre forms the new iterate *x (false: a Steffensen half step that was
+// only staged - *out is the next point, no test follows), fp_post applies the tests to err = |x - x0|.
+__device__ __forceinline__ bool fp_pre(FpCtl& c, double& x0, double& x1, double fx, const mm_fp_opts& o, double* x,
+                                       double* out) {
   if (o.solver == MM_FP_DIRECT) {
-    x = fx;
-  } else {
-    if (c.stage == 0) {
-      x1 = fx;
-      c.stage = 1;
-      *out = fx;
-      return FP_CONT;
-    }
-    const double a0 = x0, a1 = x1;
-    double denom = fx - 2.0 * a1 + a0;
-    if (fabs(denom) == 0.0) denom = 2.220446049250313e-16;  // np.finfo(float64).eps
-    x = a0 - (a1 - a0) * (a1 - a0) / denom;
-    c.stage = 0;
+    *x = fx;
+    return true;
   }
-  const double err = bk.norm(x - x0, o.norm);
+  if (c.stage == 0) {
+    x1 = fx;
+    c.stage = 1;
+    *out = fx;
+    return false;
+  }
+  const double a0 = x0, a1 = x1;
+  double denom = fx - 2.0 * a1 + a0;
+  if (fabs(denom) == 0.0) denom = 2.220446049250313e-16;  // np.finfo(float64).eps
+  *x = a0 - (a1 - a0) * (a1 - a0) / denom;
+  c.stage = 0;
+  return true;
+}
+__device__ __forceinline__ int fp_post(FpCtl& c, double& x0, double x, double err, const mm_fp_opts& o, double* out,
+                                       int* status) {
   if (err > o.div_tol || err != err) {
     *status = MM_ST_DIVERGED;
     return FP_FAIL;
@@ -117,6 +131,14 @@ __device__ __forceinline__ int fp_feed(BK& bk, FpCtl& c, double& x0, double& x1,
     return FP_FAIL;
   }
   return FP_CONT;
+}
+template <class BK>
+__device__ __forceinline__ int fp_feed(BK& bk, FpCtl& c, double& x0, double& x1, double fx,
+                                       const mm_fp_opts& o, double* out, int* status) {
+  double x;
+  if (!fp_pre(c, x0, x1, fx, o, &x, out)) return FP_CONT;
+  const double err = bk.norm(x - x0, o.norm);
+  return fp_post(c, x0, x, err, o, out, status);
 }
 
 struct ChainResult {
@@ -220,6 +242,42 @@ enum { RS_U = 0, RS_R, RS_D, RS_COUNT };
 constexpr int kRefineMaxIter = MM_REFINE_MAX_ITER;
 constexpr double kRefineTol2 = 1e-28;  // (relative energy-norm error)^2
 
+// CG iterations k, k + 1, ... of the system whose state (u, r, d) sits in rslot(S * RS_COUNT + RS_*), at the point last
+// published with metric_point(); rz = r^T F r on entry.  true: converged.
+template <class BK, int S>
+__device__ __forceinline__ bool refine_iterate(BK& bk, double rz, const double pu, int k, int& pairs) {
+  constexpr int B0 = S * RS_COUNT;
+  bool ok = false;
+#pragma unroll 1
+  for (; k < kRefineMaxIter; ++k) {
+    prof(bk, PH_MAPPLY);
+    const double irz = mmdev::rcp_nr(rz);  // 1 / (r^T F r) for the direction update, in the shadow of the product below
+    const double q = bk.metric_apply(bk.rslot(B0 + RS_D));
+    prof(bk, PH_RSUM);
+    const double dq = bk.sum1(bk.rslot(B0 + RS_D) * q);
+    if (!(dq > 0.0)) break;  // not positive definite along d, or not finite
+    const double al = mmdev::fdiv(rz, dq);  // (lean division: the IEEE expansion is ~30 dependent instructions)
+    const double u = __builtin_fma(al, bk.rslot(B0 + RS_D), bk.rslot(B0 + RS_U));
+    bk.rslot(B0 + RS_U) = u;
+    const double rv = __builtin_fma(-al, q, bk.rslot(B0 + RS_R));
+    bk.rslot(B0 + RS_R) = rv;
+    prof(bk, PH_FAPPLY);
+    const double z = bk.matvec(rv);
+    prof(bk, PH_RSUM);
+    ++pairs;
+    // (the scale p^T u of the relative test stays the first guess' - the guess is good to 1e-2 or better and the test
+    // is relative: on the wave backends a team sum is ~40 dependent DPP / readlane steps, one per pair saved)
+    const double rz2 = bk.sum1(rv * z);
+    if (!(rz2 > kRefineTol2 * fabs(pu))) {  // converged - or F not positive definite along r / NaN: refinement failure,
+      ok = rz2 >= 0.0;                      // the factorisation takes over
+      break;
+    }
+    bk.rslot(B0 + RS_D) = __builtin_fma(rz2 * irz, bk.rslot(B0 + RS_D), z);
+    rz = rz2;
+  }
+  return ok;
+}
+
 template <class BK>
 __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, double guess, double* u_out,
                                              ChainResult& r) {
@@ -241,38 +299,115 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
   if (!(fabs(pu) > 0.0)) pu = rz;  // (a zero first guess: the test becomes relative to the first residual)
   if (!ok && rz > 0.0) {
     bk.rslot(RS_D) = z;
-#pragma unroll 1
-    for (int k = 0; k < kRefineMaxIter; ++k) {
-      prof(bk, PH_MAPPLY);
-      const double irz = mmdev::rcp_nr(rz);  // 1 / (r^T F r) for the direction update, in the shadow of the product below
-      const double q = bk.metric_apply(bk.rslot(RS_D));
-      prof(bk, PH_RSUM);
-      const double dq = bk.sum1(bk.rslot(RS_D) * q);
-      if (!(dq > 0.0)) break;  // not positive definite along d, or not finite
-      const double al = mmdev::fdiv(rz, dq);  // (lean division: the IEEE expansion is ~30 dependent instructions)
-      const double u = __builtin_fma(al, bk.rslot(RS_D), bk.rslot(RS_U));
-      bk.rslot(RS_U) = u;
-      rv = __builtin_fma(-al, q, bk.rslot(RS_R));
-      bk.rslot(RS_R) = rv;
-      prof(bk, PH_FAPPLY);
-      z = bk.matvec(rv);
-      prof(bk, PH_RSUM);
-      ++pairs;
-      // (the scale p^T u of the relative test stays the first guess' - the guess is good to 1e-2 or better and the test
-      // is relative: on the wave backends a team sum is ~40 dependent DPP / readlane steps, one per pair saved)
-      const double rz2 = bk.sum1(rv * z);
-      if (!(rz2 > kRefineTol2 * fabs(pu))) {  // converged - or F not positive definite along r / NaN: refinement failure,
-        ok = rz2 >= 0.0;                      // the factorisation takes over
-        break;
-      }
-      bk.rslot(RS_D) = __builtin_fma(rz2 * irz, bk.rslot(RS_D), z);
-      rz = rz2;
-    }
+    ok = refine_iterate<BK, 0>(bk, rz, pu, 0, pairs);
   }
   bump(bk, r, CNT_REFINE, pairs);
   *u_out = bk.rslot(RS_U);
   prof(bk, ph0);
   return ok;
+}
+
+// ---- two refinement solves in lock step (round 5) ------------------------------------------------------------------------
+// The reversibility-check solve of C and the C-adjoint solve (integrators.py:521-536) start from the same point and
+// iterate x = qw -/+ t M(x)^-1 p independently of each other; the reference runs one to its end, then the other.  A
+// backend with kDual advances both together: the two systems M(x_C) u_C = p, M(x_A) u_A = p share every pass over the
+// base matrix (M(x) v: ONE read of the staged / streamed tiles serves both vectors) and over the held inverse, their team
+// sums travel through the same dependent chains, and a lone wave has two independent instruction streams to fill its
+// issue slots with.  Each system runs exactly the arithmetic of refine_solve() - the same operations in the same order -
+// so its iterates are bit for bit those of the sequential form (MICI_AMD_DUAL=0), and a system that has converged (or
+// failed) simply stops being updated; once only one is left the loop hands over to the single-system iteration.
+// System 1's state lives in rslot(RS_COUNT + RS_*).
+template <class BK>
+__device__ __forceinline__ void refine_solve2(BK& bk, double xC, double xA, double rhs, double gC, double gA,
+                                              double* uC, double* uA, bool* okC_out, bool* okA_out, ChainResult& r) {
+  constexpr int A0 = RS_COUNT;
+  const int ph0 = prof(bk, PH_MAPPLY);
+  bk.metric_point2(xC, xA);
+  bk.rslot(RS_U) = gC;
+  bk.rslot(A0 + RS_U) = gA;
+  double rzC = 0.0, rzA = 0.0, puC = 0.0, puA = 0.0;
+  int pairsC = 0, pairsA = 0;
+  bool okC = false, okA = false, liveC = true, liveA = true;
+  // ONE loop with ONE site of each product, the residual's set-up folded in as its first trip (k = -1: the products'
+  // operand is the guess instead of the direction).  One loop for both systems, until neither is live: a system that
+  // has converged (or failed) rides along with a zero step - its vectors stay what they are.  (Every further inlined
+  // copy of the products - a prologue, single-system tails - is another region the inverse's row must stay in registers
+  // across, and the allocator answers with accumulation registers for the row: c3 8.9e6 instead of 1.35e7 steps/s.)
+#pragma unroll 1
+  for (int k = -1; (liveC || liveA) && k < kRefineMaxIter; ++k) {
+    const bool first = k < 0;  // team-uniform
+    prof(bk, PH_MAPPLY);
+    const double irzC = mmdev::rcp_nr(rzC), irzA = mmdev::rcp_nr(rzA);  // (unused on the first trip)
+    double qC, qA;
+    // (both read, one selected: no slot is indexed by a run-time value, so a backend may keep its slots in registers)
+    const double vinC = first ? bk.rslot(RS_U) : bk.rslot(RS_D), vinA = first ? bk.rslot(A0 + RS_U) : bk.rslot(A0 + RS_D);
+    bk.metric_apply2(vinC, vinA, &qC, &qA);
+    prof(bk, PH_RSUM);
+    double rvC, rvA;
+    if (first) {
+      rvC = rhs - qC;
+      rvA = rhs - qA;
+    } else {
+      double dqC, dqA;
+      bk.sum2x(vinC * qC, vinA * qA, &dqC, &dqA);
+      if (!(dqC > 0.0)) liveC = false;  // not positive definite along d, or not finite: this system's refinement has
+      if (!(dqA > 0.0)) liveA = false;  // failed (ok stays false)
+      const double alC = liveC ? mmdev::fdiv(rzC, dqC) : 0.0, alA = liveA ? mmdev::fdiv(rzA, dqA) : 0.0;
+      bk.rslot(RS_U) = __builtin_fma(alC, vinC, bk.rslot(RS_U));
+      bk.rslot(A0 + RS_U) = __builtin_fma(alA, vinA, bk.rslot(A0 + RS_U));
+      rvC = __builtin_fma(-alC, qC, bk.rslot(RS_R));
+      rvA = __builtin_fma(-alA, qA, bk.rslot(A0 + RS_R));
+    }
+    bk.rslot(RS_R) = rvC;
+    bk.rslot(A0 + RS_R) = rvA;
+    prof(bk, PH_FAPPLY);
+    double zC, zA;
+    bk.matvec2(rvC, rvA, &zC, &zA);
+    prof(bk, PH_RSUM);
+    pairsC += liveC ? 1 : 0;
+    pairsA += liveA ? 1 : 0;
+    double rz2C, rz2A;
+    if (first) {
+      bk.sum4(rvC * zC, rhs * gC, rvA * zA, rhs * gA, &rz2C, &puC, &rz2A, &puA);
+      // r^T F r is the squared energy norm of the error only while F is positive definite (see refine_solve)
+      okC = rz2C >= 0.0 && rz2C <= kRefineTol2 * fabs(puC);
+      okA = rz2A >= 0.0 && rz2A <= kRefineTol2 * fabs(puA);
+      if (!(fabs(puC) > 0.0)) puC = rz2C;
+      if (!(fabs(puA) > 0.0)) puA = rz2A;
+      liveC = !okC && rz2C > 0.0;
+      liveA = !okA && rz2A > 0.0;
+      bk.rslot(RS_D) = zC;
+      bk.rslot(A0 + RS_D) = zA;
+      rzC = rz2C;
+      rzA = rz2A;
+    } else {
+      bk.sum2x(rvC * zC, rvA * zA, &rz2C, &rz2A);
+      if (liveC) {
+        if (!(rz2C > kRefineTol2 * fabs(puC))) {  // converged - or F not positive definite along r / NaN (refine_iterate)
+          okC = rz2C >= 0.0;
+          liveC = false;
+        } else {
+          bk.rslot(RS_D) = __builtin_fma(rz2C * irzC, bk.rslot(RS_D), zC);
+          rzC = rz2C;
+        }
+      }
+      if (liveA) {
+        if (!(rz2A > kRefineTol2 * fabs(puA))) {
+          okA = rz2A >= 0.0;
+          liveA = false;
+        } else {
+          bk.rslot(A0 + RS_D) = __builtin_fma(rz2A * irzA, bk.rslot(A0 + RS_D), zA);
+          rzA = rz2A;
+        }
+      }
+    }
+  }
+  bump(bk, r, CNT_REFINE, pairsC + pairsA);
+  *uC = bk.rslot(RS_U);
+  *uA = bk.rslot(A0 + RS_U);
+  *okC_out = okC;
+  *okA_out = okA;
+  prof(bk, ph0);
 }
 
 // Backends whose metric construction starts from the previous one's result (the SoftAbs eigenvector basis) may keep two
@@ -284,6 +419,11 @@ template <class BK, class = void>
 struct basis_trait { static constexpr bool value = false; };
 template <class BK>
 struct basis_trait<BK, decltype((void)BK::kBasisSlots)> { static constexpr bool value = BK::kBasisSlots; };
+
+template <class BK, class = void>
+struct dual_trait { static constexpr bool value = false; };
+template <class BK>
+struct dual_trait<BK, decltype((void)BK::kDual)> { static constexpr bool value = BK::kDual; };
 
 template <class BK, class = void>
 struct refine_trait { static constexpr bool value = false; };
@@ -298,7 +438,13 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
                                                                const mm_fp_opts& o) {
   ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0, 0, 0, 0};
   constexpr bool kRefine = refine_trait<BK>::value;
+  constexpr bool kDual = kRefine && dual_trait<BK>::value;
   bool anchor = false;  // kRefine: the backend holds the explicit inverse at the step's starting position
+  // kDual: the C-adjoint solve advances together with the reversibility-check solve while both are in flight
+  // (refine_solve2).  Its evaluations are COUNTED when the reference would have made them - after the check has passed
+  // (pendA) - so that a step that fails its check reports the reference's counts.
+  bool dual_ok = false;
+  int pendA = 0;
   // One loop, one metric-construction site.  `mode` says why the metric at slot(SL_XQ) is being built:
   //   INIT   cold start at the initial position (LinAlgError outside a solver on failure)
   //   CFIRST first evaluation shared by the C reversibility check and the C-adjoint solve (both start
@@ -321,6 +467,68 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       bump(bk, r, CNT_GRAD, 1);
       prof(bk, PH_OTHER);
     }
+    bool chk_done = false, adj_done = false;
+    double q_back = 0.0;
+    bool skip_refine = false;
+    if constexpr (kDual) {
+      if (mode == MODE_CHK && dual_ok && anchor && actA == FP_CONT) {  // team-uniform
+        // ---- both position solves in flight: one more evaluation of each, the two solves M(x)^-1 p in lock step ----
+        // The C-adjoint solve's state stays in its parked form (SL_AX0 / SL_AX1 / SL_PTA, iterA, stageA, actA): whenever
+        // the lock step ends - the check converges, a refinement fails, the adjoint solve converges or fails first - the
+        // sequential code below carries on from exactly there.
+        double uC, uA;
+        bool okC, okA;
+#ifdef MM_DUAL_SEQ_EXPERIMENT
+        okC = refine_solve(bk, bk.slot(SL_XQ), bk.slot(SL_PW), bk.slot(SL_UC), &uC, r);
+        okA = refine_solve(bk, bk.slot(SL_PTA), bk.slot(SL_PW), bk.slot(SL_UA), &uA, r);
+#else
+        refine_solve2(bk, bk.slot(SL_XQ), bk.slot(SL_PTA), bk.slot(SL_PW), bk.slot(SL_UC), bk.slot(SL_UA), &uC, &uA,
+                      &okC, &okA, r);
+#endif
+        if (!okA) dual_ok = false;  // the adjoint solve's evaluation is repeated (and factorised) when its turn comes
+        if (!okC) {
+          skip_refine = true;       // the check's refinement failed: factorise at its point (below), as refine_solve would
+          dual_ok = false;
+        } else {
+          bk.slot(SL_UC) = uC;
+          bump(bk, r, CNT_METRIC, 1);
+          bump(bk, r, CNT_EVALS, 1);
+          const double qw = bk.slot(SL_QW);
+          double xC, xA = 0.0, ptC, ptA = 0.0;
+          int stC = MM_ST_OK;
+          FpCtl cA{iterA, stageA};
+          const bool testC = fp_pre(cS, bk.slot(SL_SX0), bk.slot(SL_SX1), qw - t * uC, o, &xC, &ptC);
+          bool testA = false;
+          if (okA) {
+            bk.slot(SL_UA) = uA;
+            ++pendA;
+            testA = fp_pre(cA, bk.slot(SL_AX0), bk.slot(SL_AX1), qw + t * uA, o, &xA, &ptA);
+          }
+          double eC = 0.0, eA = 0.0;
+          if (testC && testA) bk.norm2(xC - bk.slot(SL_SX0), xA - bk.slot(SL_AX0), o.norm, &eC, &eA);
+          else if (testC) eC = bk.norm(xC - bk.slot(SL_SX0), o.norm);
+          else if (testA) eA = bk.norm(xA - bk.slot(SL_AX0), o.norm);
+          if (okA) {
+            actA = testA ? fp_post(cA, bk.slot(SL_AX0), xA, eA, o, &ptA, &stA) : FP_CONT;
+            bk.slot(SL_PTA) = ptA;
+            iterA = cA.iter;
+            stageA = cA.stage;
+          }
+          const int aC = testC ? fp_post(cS, bk.slot(SL_SX0), xC, eC, o, &ptC, &stC) : FP_CONT;
+          if (aC == FP_FAIL) {
+            r.status = stC;
+            break;
+          }
+          if (aC == FP_CONT) {
+            bk.slot(SL_XQ) = ptC;
+            continue;
+          }
+          chk_done = true;
+          q_back = ptC;
+        }
+      }
+    }
+    if (!chk_done) {
     // INIT / BADJ need the explicit inverse (applied ~12 times: momentum solves, both A half-steps, the
     // general-VJP path); the position-space iterations use their metric for a single solve.
     double u_pos = 0.0;
@@ -328,7 +536,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
     const bool need_inverse = mode == MODE_INIT || mode == MODE_BADJ;
     bool refined = false;
     if constexpr (kRefine) {
-      if (!need_inverse && anchor && bk.refine_on) {  // team-uniform
+      if (!need_inverse && anchor && bk.refine_on && !skip_refine) {  // team-uniform
         // (both guesses read, one selected - and written back by a uniform branch below: no slot is indexed by a run-time
         // value, so a backend may keep its slots in registers)
         const double g_chk = bk.slot(SL_UC), g_adj = bk.slot(SL_UA);
@@ -418,9 +626,11 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
     // position-space solves: f(x) = qw -/+ t M(x)^-1 p with M(xq)^-1 now held by the backend
     const double u = u_pos;
     const double qw = bk.slot(SL_QW);
-    bool chk_done = false, adj_done = false;
-    double q_back = 0.0;
     if (mode == MODE_CFIRST) {
+      if constexpr (kDual) {
+        dual_ok = refined && !bk.dual_off;  // (a factorised first evaluation: no anchor, nothing to advance together)
+        pendA = 0;
+      }
       // the reference runs the reversibility-check solve to its end before the C-adjoint solve starts: the latter's
       // first evaluation (shared with the former's here) is counted only once it would have happened
       bump(bk, r, CNT_SOLVES, 1);
@@ -475,6 +685,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         bk.slot(SL_PTA) = pt;
       }
     }
+    }  // (!chk_done: the lock-step evaluation above did not finish the check)
     if (chk_done) {
       if (bk.norm(q_back - bk.slot(SL_QINIT), o.rev_norm) > o.rev_tol) {
         r.status = MM_ST_NON_REVERSIBLE;  // integrators.py:523-528
@@ -484,6 +695,12 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       bump(bk, r, CNT_SOLVES, 1);
       bump(bk, r, CNT_EVALS, 1);
       bump(bk, r, CNT_METRIC, 1);
+      if constexpr (kDual) {  // the evaluations the adjoint solve made alongside the check
+        if (pendA > 0) {
+          bump(bk, r, CNT_EVALS, pendA);
+          bump(bk, r, CNT_METRIC, pendA);
+        }
+      }
       if (actA == FP_FAIL) {
         r.status = stA;
         break;

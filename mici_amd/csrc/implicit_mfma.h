@@ -42,6 +42,19 @@ using namespace mmimp;
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+#ifndef MM_MFMA_KERNEL_ATTR
+#define MM_MFMA_KERNEL_ATTR
+#endif
+// Lock-step position solves (implicit_core.h refine_solve2) on this kernel: OFF.  Measured in round 5 (tools/dbg/r05_ab_c3.sh):
+// the state machine and the paired products are correct (tests/test_gpu_implicit.py green with them on), and in a binary
+// where both forms pay the same register penalty the lock step is 12 % faster (9.97e6 against 8.87e6 steps/s) - but with
+// 128 registers of inverse row live across the solve, every form of the paired products tried (fully unrolled, hand
+// pipelined, a real loop, the second system's vectors in LDS, one inlined product site) makes the allocator move the row
+// into accumulation registers (1.2-1.7 k v_accvgpr_read in the kernel against 120) and the kernel falls from 1.35e7 to
+// 1.0e7.  -DMM_MFMA_DUAL=1 builds it (tools/ab_build.py k_implicit_mfma dual -DMM_MFMA_DUAL=1).
+#ifndef MM_MFMA_DUAL
+#define MM_MFMA_DUAL 0
+#endif
 #ifndef MM_MFMA_WAVES_PER_BLOCK
 #define MM_MFMA_WAVES_PER_BLOCK 4
 #endif
@@ -100,6 +113,10 @@ struct MfmaBackend {
   static constexpr bool kCountersInLds = false;
   static constexpr bool kRefine = true;  // implicit_core.h: solve-only constructions refined from the held inverse
   bool refine_on;                        // false: MICI_AMD_REFINE=0, every construction is factorised
+  // implicit_core.h refine_solve2: the two position solves of a step in lock step (round 5).  Built-in metrics; a user
+  // metric's M(x) is forty registers of entries per point, two points do not fit next to the inverse's row.
+  static constexpr bool kDual = MM_MFMA_DUAL && RMETRIC != MM_RMETRIC_USER;
+  bool dual_off;                         // true: MICI_AMD_DUAL=0, one solve after the other
   d4 acc[kTiles];
   int dim, lane, target;
   MLds w;
@@ -189,11 +206,33 @@ struct MfmaBackend {
   // ---- refinement solves (implicit_core.h): M(x) v formed matrix-free, the tiles keep M(x0)^-1 ---------------------
   // the solve's flat vectors (u, r, d) stay in registers: nothing else of the step is live during a refinement solve
   // (the sweeps' operands are dead), and a lone wave pays ~100 cycles for every dependent LDS access
+#ifndef MM_DUAL_RS_LDS
+#define MM_DUAL_RS_LDS 1
+#endif
+#if MM_DUAL_RS_LDS
+  // the second system of a lock-step pair keeps its three vectors in LDS (the dead W buffer of the sweeps): with them in
+  // registers next to the inverse's row the allocator moves the row to accumulation registers
   double rs_[RS_COUNT];
+  __device__ __forceinline__ double& rslot(int i) { return i < RS_COUNT ? rs_[i] : w.wt[(i - RS_COUNT) * 64 + lane]; }
+#else
+  double rs_[2 * RS_COUNT];  // (the second system of a lock-step pair in [RS_COUNT ..])
   __device__ __forceinline__ double& rslot(int i) { return rs_[i]; }
+#endif
   __device__ __forceinline__ void sum2(double a, double b, double* sa, double* sb) {
     *sa = wave_sum(lane < dim ? a : 0.0);
     *sb = wave_sum(lane < dim ? b : 0.0);
+  }
+  // sums of the lock-step pair: independent dependent chains, interleaved by the scheduler
+  __device__ __forceinline__ void sum2x(double a, double b, double* sa, double* sb) { sum2(a, b, sa, sb); }
+  __device__ __forceinline__ void sum4(double a, double b, double c, double d, double* sa, double* sb, double* sc,
+                                       double* sd) {
+    sum2(a, b, sa, sb);
+    sum2(c, d, sc, sd);
+  }
+  __device__ __forceinline__ void norm2(double a, double b, int kind, double* na, double* nb) {
+    const double xa = wave_norm_accum(0.0, lane < dim ? a : 0.0, kind), xb = wave_norm_accum(0.0, lane < dim ? b : 0.0, kind);
+    *na = wave_norm_finish(xa, kind);
+    *nb = wave_norm_finish(xb, kind);
   }
   __device__ __forceinline__ double sum1(double a) { return wave_sum(lane < dim ? a : 0.0); }
   // M(x) v in the form that suits the metric:  rank-one update  B v + x (x . v) / D  (B's tiles from LDS, contracted
@@ -250,6 +289,7 @@ struct MfmaBackend {
   // F4/M4 1.25e7, F4/M2 1.316e7, F4/M1 1.314e7, F8/M2 1.308e7, F2/M2 1.23e7, F16/M4 1.23e7
   static constexpr int kAcc = 4;
   static constexpr int kAccM = 2;
+  static_assert(kAccM == 1 || kAccM == 2 || kAccM == 4, "metric_apply2 assigns column 4 k + e to chain e % kAccM");
   // y_lane = sum_j row[j] v_j with v broadcast from LDS (w.nat, zero beyond dim)
   __device__ __forceinline__ double row_dot(const double (&row)[64], double v) {
     w.nat[lane] = (lane < dim) ? v : 0.0;
@@ -269,6 +309,148 @@ struct MfmaBackend {
 #pragma unroll
       for (int a = 0; a < h; ++a) y[a] += y[a + h];
     return y[0];
+  }
+
+  // two products against the same row: the row's 64 registers are read once per pair of multiply-adds' issue slots, the
+  // two accumulator sets are independent chains (each system's sum in the order row_dot() forms it: bit-equal results).
+  // The broadcast reads of the two vectors are software-pipelined by hand, kDualGroup columns-of-four at a time with the
+  // next group's loads issued before the current group's arithmetic: left alone the scheduler hoists all 32 16-byte
+  // loads (256 registers) above the arithmetic and the allocator parks the inverse's row in accumulation registers - two
+  // v_accvgpr_read per multiply-add (1.7 k of them in the kernel against 120).
+#ifndef MM_DUAL_GROUP
+#define MM_DUAL_GROUP 2
+#endif
+#ifndef MM_DUAL_ROWDOT2
+#define MM_DUAL_ROWDOT2 0
+#endif
+  static constexpr int kDualGroup = MM_DUAL_GROUP;  // 16 / kDualGroup groups
+  __device__ __forceinline__ void row_dot2(const double (&row)[64], double v0, double v1, double* y0, double* y1) {
+    w.nat[lane] = (lane < dim) ? v0 : 0.0;
+    w.aux[lane] = (lane < dim) ? v1 : 0.0;
+    wave_sync();
+    double ya[kAcc], yb[kAcc];
+#pragma unroll
+    for (int a = 0; a < kAcc; ++a) ya[a] = yb[a] = 0.0;
+    d4 va[2][kDualGroup], vb[2][kDualGroup];
+#pragma unroll
+    for (int i = 0; i < kDualGroup; ++i) {
+      va[0][i] = *reinterpret_cast<const d4*>(w.nat + 4 * i);
+      vb[0][i] = *reinterpret_cast<const d4*>(w.aux + 4 * i);
+    }
+#pragma unroll
+    for (int gk = 0; gk < 16 / kDualGroup; ++gk) {
+      const int cur = gk & 1, nxt = cur ^ 1;
+      if (gk + 1 < 16 / kDualGroup) {
+#pragma unroll
+        for (int i = 0; i < kDualGroup; ++i) {
+          va[nxt][i] = *reinterpret_cast<const d4*>(w.nat + 4 * ((gk + 1) * kDualGroup + i));
+          vb[nxt][i] = *reinterpret_cast<const d4*>(w.aux + 4 * ((gk + 1) * kDualGroup + i));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < kDualGroup; ++i) {
+        const int k = gk * kDualGroup + i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ya[(4 * k + e) % kAcc] = __builtin_fma(row[4 * k + e], va[cur][i][e], ya[(4 * k + e) % kAcc]);
+          yb[(4 * k + e) % kAcc] = __builtin_fma(row[4 * k + e], vb[cur][i][e], yb[(4 * k + e) % kAcc]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_sync();
+#pragma unroll
+    for (int h = kAcc / 2; h >= 1; h >>= 1)
+#pragma unroll
+      for (int a = 0; a < h; ++a) {
+        ya[a] += ya[a + h];
+        yb[a] += yb[a + h];
+      }
+    *y0 = ya[0];
+    *y1 = yb[0];
+  }
+  __device__ __forceinline__ void matvec2(double v0, double v1, double* y0, double* y1) {
+#if MM_DUAL_ROWDOT2
+    double a, b;
+    row_dot2(fr_, v0, v1, &a, &b);
+#else
+    // the held inverse's row is in registers: nothing to share between the two products but the exchange points, and a
+    // row product already runs kAcc independent chains.  ONE inlined product in a two-trip loop, operands and results
+    // through LDS: a second inlined copy is what tips the allocator (see refine_solve2)
+    w.wt[192 + lane] = v0;
+    w.vperm[lane] = v1;
+    double a = 0.0, b = 0.0;
+#pragma unroll 1
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const double v = sidx == 0 ? w.wt[192 + lane] : w.vperm[lane];
+      const double y = row_dot(fr_, v);
+      if (sidx == 0) a = y;
+      else b = y;
+    }
+#endif
+    *y0 = lane < dim ? a : 0.0;
+    *y1 = lane < dim ? b : 0.0;
+  }
+
+  // the points of a lock-step pair: system 0's where metric_point() puts it, system 1's behind it
+  __device__ __forceinline__ void metric_point2(double x0, double x1) {
+    w.qt[lane] = (lane < dim) ? x0 : 0.0;
+    w.qt[64 + lane] = (lane < dim) ? x1 : 0.0;
+  }
+  // M(x0) v0 and M(x1) v1: ONE pass over the staged base matrix' row (the LDS volume that paces metric_apply) for both
+  __device__ __forceinline__ void metric_apply2(double v0, double v1, double* y0, double* y1) {
+    const double x0 = w.qt[lane], x1 = w.qt[64 + lane];
+    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
+      *y0 = lane < dim ? __builtin_fma(x0 * x0, v0, v0) : 0.0;
+      *y1 = lane < dim ? __builtin_fma(x1 * x1, v1, v1) : 0.0;
+    } else if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+      w.nat[lane] = (lane < dim) ? v0 : 0.0;
+      w.aux[lane] = (lane < dim) ? v1 : 0.0;
+      wave_sync();
+      const double* brow = base_lds + lane * kBasePitch;
+      double ya[kAccM], yb[kAccM];
+#pragma unroll
+      for (int a = 0; a < kAccM; ++a) ya[a] = yb[a] = 0.0;
+      // A REAL loop (kDualUnroll columns-of-four a trip): fully unrolled, the scheduler hoists all 64 loads above the
+      // arithmetic - next to the inverse's row (128 registers, live across this product) they land in accumulation
+      // registers and come back through 240 v_accvgpr_read.  Nothing here indexes a register array, so nothing needs
+      // the unrolling.
+#ifndef MM_DUAL_UNROLL
+#define MM_DUAL_UNROLL 2
+#endif
+#pragma unroll MM_DUAL_UNROLL
+      for (int k = 0; k < 16; ++k) {
+        const d4 xa = *reinterpret_cast<const d4*>(w.nat + 4 * k);
+        const d4 xb = *reinterpret_cast<const d4*>(w.aux + 4 * k);
+        const d2 b01 = *reinterpret_cast<const d2*>(brow + 4 * k);
+        const d2 b23 = *reinterpret_cast<const d2*>(brow + 4 * k + 2);
+        // (4 k, 4 k + 2 -> chain 0, 4 k + 1, 4 k + 3 -> chain 1: metric_apply()'s assignment for kAccM = 2)
+        ya[0] = __builtin_fma(b01[0], xa[0], ya[0]);
+        yb[0] = __builtin_fma(b01[0], xb[0], yb[0]);
+        ya[1 % kAccM] = __builtin_fma(b01[1], xa[1], ya[1 % kAccM]);
+        yb[1 % kAccM] = __builtin_fma(b01[1], xb[1], yb[1 % kAccM]);
+        ya[2 % kAccM] = __builtin_fma(b23[0], xa[2], ya[2 % kAccM]);
+        yb[2 % kAccM] = __builtin_fma(b23[0], xb[2], yb[2 % kAccM]);
+        ya[3 % kAccM] = __builtin_fma(b23[1], xa[3], ya[3 % kAccM]);
+        yb[3 % kAccM] = __builtin_fma(b23[1], xb[3], yb[3 % kAccM]);
+      }
+      const double dot0 = wave_sum(lane < dim ? x0 * v0 : 0.0);
+      const double dot1 = wave_sum(lane < dim ? x1 * v1 : 0.0);
+      wave_sync();
+#pragma unroll
+      for (int h = kAccM / 2; h >= 1; h >>= 1)
+#pragma unroll
+        for (int a = 0; a < h; ++a) {
+          ya[a] += ya[a + h];
+          yb[a] += yb[a + h];
+        }
+      const double r0 = __builtin_fma(x0, dot0 * inv_dim_, ya[0]), r1 = __builtin_fma(x1, dot1 * inv_dim_, yb[0]);
+      *y0 = lane < dim ? r0 : 0.0;
+      *y1 = lane < dim ? r1 : 0.0;
+    } else {
+      *y0 = *y1 = 0.0;  // (user metrics: kDual is false)
+    }
   }
 
   __device__ __forceinline__ void metric_point(double x) {
@@ -716,6 +898,7 @@ __device__ __forceinline__ void implicit_mfma_body(const ImplicitArgs& A, double
   bk.w.stash = bk.w.mpart + 192;
   bk.w.prof = bk.w.stash + SL_COUNT_REFINE * 64;
   bk.refine_on = A.no_refine == 0;
+  bk.dual_off = A.no_dual != 0;
   bk.base_lds = base_lds;
   bk.tparams = A.tparams;
   bk.uparams = A.rparams;
@@ -757,7 +940,7 @@ __device__ __forceinline__ void implicit_mfma_body(const ImplicitArgs& A, double
 
 #ifndef MM_RTC_BUILD  // the in-tree instantiations (a run-time translation unit defines an extern "C" wrapper instead)
 template <int RMETRIC, bool PROFILE = false>
-__global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs A) {
+__global__ __launch_bounds__(64 * kWaves) MM_MFMA_KERNEL_ATTR void implicit_mfma_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   implicit_mfma_body<RMETRIC, PROFILE>(A, lds);
 }

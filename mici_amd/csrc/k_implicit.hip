@@ -197,6 +197,7 @@ static int launch_user_metric(mm_ctx* ctx, const mm_model* m, mm_state* s, int w
   a.out = d_out;
   a.z = d_z;
   a.no_refine = mm_refine_disabled();
+  a.no_dual = mm_dual_disabled();
   return mm_rtc_launch_riemann(ctx, m, s, which, &a);
 }
 
@@ -230,6 +231,7 @@ int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, dou
   a.opts = opts;
   a.counters = d_counters;
   a.no_refine = mm_refine_disabled();
+  a.no_dual = mm_dual_disabled();
   return dispatch(ctx, m, StepFn{ctx, a, s->n});
 }
 

@@ -164,6 +164,7 @@ int mm_launch_implicit_blk16(mm_ctx* ctx, const mm_model* m, mm_state* s, double
   a.n_steps = n_steps;
   a.opts = opts;
   a.no_refine = mm_refine_disabled();
+  a.no_dual = mm_dual_disabled();
   a.counters = d_counters;
   if (m->rmetric == MM_RMETRIC_RANK1)
     return launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_RANK1>, a);

@@ -100,6 +100,7 @@ static int launch_large(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, i
   a.opts = opts;
   a.counters = d_counters;
   a.no_refine = mm_refine_disabled();
+  a.no_dual = mm_dual_disabled();
   const int v = team_variant(m->dim);
   return v == 0   ? launch_step<CfgMid>(ctx, m, a, midpoint)
          : v == 1 ? launch_step<CfgSmall>(ctx, m, a, midpoint)

@@ -101,6 +101,7 @@ int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
   a.n_steps = n_steps;
   a.opts = opts;
   a.no_refine = mm_refine_disabled();
+  a.no_dual = mm_dual_disabled();
   a.counters = d_counters;
   const unsigned blocks = (unsigned)((s->n + kWaves - 1) / kWaves);
   const bool r1 = m->rmetric == MM_RMETRIC_RANK1;
