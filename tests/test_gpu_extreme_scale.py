@@ -1,0 +1,63 @@
+"""States scaled by 1e+-150 / 1e+-80 through every integrator, against fixtures recorded from the
+imported reference (tools/gen_golden.py `extreme_*`: chain c has its position multiplied by QS[c], its momentum by PS[c]).
+
+What must hold at these scales: the STATUS a chain ends with (0, ConvergenceError, LinAlgError, ...) and its completed
+steps are the reference's, whatever overflowed on the way - the lean division / square root of mm_device.h give NaN in
+places where IEEE gives inf or 0, and the solvers' tests (`err > div_tol or isnan(err)`, `!(pivot > 0)`) must not care;
+a chain that completes agrees with the reference RELATIVE to its own scale (1e-9 of the chain's largest component: a
+chain of size 1e-150 must not pass on an absolute tolerance); a chain that stops keeps its input state bit for bit."""
+
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+NAMES = golden_names("extreme")
+
+
+def _relative(a, b):
+    """max |a - b| per chain, relative to the chain's largest reference component (inf / NaN patterns must be equal)."""
+    assert np.array_equal(np.isfinite(a), np.isfinite(b)), "finite pattern differs"
+    a, b = np.where(np.isfinite(b), a, 0.0), np.where(np.isfinite(b), b, 0.0)
+    scale = np.max(np.abs(b), axis=1)
+    return np.max(np.abs(a - b), axis=1) / np.where(scale > 0, scale, 1.0)
+
+
+def _integrator(name, g):
+    if name.startswith(("extreme_riemann", "extreme_softabs")):
+        from test_gpu_implicit import build
+        return build(g)
+    if name.startswith("extreme_constrained"):
+        from test_gpu_constrained import build
+        return build(g)
+    from test_gpu_euclid import system_from_golden
+    from mici_amd import integrators
+    system = system_from_golden(g)
+    return system, integrators.LeapfrogIntegrator(system, float(g["step_size"]))
+
+
+def test_the_extreme_fixtures_exist():
+    assert len(NAMES) >= 9 and any("softabs" in n for n in NAMES) and any("constrained" in n for n in NAMES)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_status_codes_and_states_at_extreme_scale(name):
+    g = load_golden(name)
+    _, integ = _integrator(name, g)
+    s_max = int(g["checkpoints"].max())
+    tol = 2e-8 if "softabs" in name else 1e-9
+    for k, s in enumerate(int(s) for s in g["checkpoints"]):
+        q, p, status, n_done = integ.step_batch(g["q0"], g["p0"], g["dir"], n_steps=s)
+        if s == s_max:
+            assert np.array_equal(status, g["status"]), (name, status, g["status"])
+            assert np.array_equal(n_done, g["n_done"]), (name, n_done, g["n_done"])
+        done = n_done == s  # (a chain that fails later than this checkpoint has completed it)
+        ref_done = np.minimum(g["n_done"], s) == s
+        assert np.array_equal(done, ref_done), (name, s, n_done, g["n_done"])
+        if done.any():
+            eq, ep = _relative(q[done], g["q_out"][k][done]), _relative(p[done], g["p_out"][k][done])
+            assert max(eq.max(), ep.max()) <= tol, (name, s, eq, ep)
+        frozen = n_done == 0  # stopped in its first step: the input state, bit for bit
+        assert np.array_equal(q[frozen], g["q0"][frozen]) and np.array_equal(p[frozen], g["p0"][frozen]), name

@@ -11,7 +11,7 @@ from oracle import integrators as orc
 from oracle import models as mdl
 
 
-@pytest.mark.parametrize("name", golden_names("euclid"))
+@pytest.mark.parametrize("name", golden_names("euclid") + golden_names("extreme_euclid"))
 def test_euclid_leapfrog(name):
     g = load_golden(name)
     n, d = g["q0"].shape
@@ -248,7 +248,7 @@ def _riemann_kwargs(g):
     )
 
 
-RIEMANN = [n for n in golden_names() if n.startswith(("riemann", "softabs"))]
+RIEMANN = [n for n in golden_names() if n.startswith(("riemann", "softabs", "extreme_riemann", "extreme_softabs"))]
 
 
 @pytest.mark.parametrize("name", RIEMANN)
@@ -284,7 +284,7 @@ def test_implicit_leapfrog(name):
         assert counters.get("fp_iters", 0) == int(g["count_fp_iters"])
 
 
-@pytest.mark.parametrize("name", golden_names("constrained"))
+@pytest.mark.parametrize("name", golden_names("constrained") + golden_names("extreme_constrained"))
 def test_constrained_leapfrog(name):
     g = load_golden(name)
     n, d = g["q0"].shape

@@ -217,6 +217,47 @@ def constrained_case(rng):
     return desc, integ, system, osys, q0, p0, dirs, steps, ref, 1e-9
 
 
+MAKERS = None
+
+
+def run_cases(seed, cases, kinds, stress=1.0, long=False, only=-1, out=print):
+    """The sweep as a function (tests/test_gpu_fuzz_slice.py runs fixed-seed slices of it under `pytest -m gpu`).
+    Returns (list of mismatching case records, number of cases with chains that stopped early)."""
+    global STEP_FACTOR, H_FACTOR, MAKERS
+    H_FACTOR = stress
+    STEP_FACTOR = 4 if long else 1
+    rng = np.random.default_rng(seed)
+    MAKERS = {"euclid": euclid_case, "riemann": riemann_case, "softabs": softabs_case, "constrained": constrained_case,
+              "riemann_user": riemann_user_case, "softabs_user": softabs_user_case}
+    makers = [MAKERS[k] for k in kinds.split(",")]
+    bad, n_failed = [], 0
+    for i in range(cases):
+        make = makers[int(rng.integers(0, len(makers)))]
+        desc, integ, system, osys, q0, p0, dirs, steps, ref, tol = make(rng)
+        if only >= 0 and i != only:
+            rng.integers(0, len(q0))  # (the draw of the compared chain below)
+            continue
+        try:
+            q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=steps)
+        except Exception as e:  # unsupported sizes must fail loudly, never silently
+            out(f"[{i}] {desc}: device refused ({type(e).__name__}: {str(e)[:80]})")
+            continue
+        ok, detail = True, []
+        for c in sorted(set([0, len(q0) - 1, int(rng.integers(0, len(q0)))])):
+            qo, po, so, no = ref(c)
+            if so != status[c] or no != n_done[c] or not close(q[c], qo, tol) or not close(p[c], po, tol):
+                ok = False
+                err = np.max(np.abs(np.nan_to_num(q[c]) - np.nan_to_num(qo)))
+                detail.append(dict(chain=c, status=(int(status[c]), int(so)), n_done=(int(n_done[c]), int(no)), err=float(err)))
+                out(f"    chain {c}: status {status[c]} vs {so}, n_done {n_done[c]} vs {no}, max |dq| = {err:.2e}")
+        failed = int(np.count_nonzero(status))
+        n_failed += failed > 0
+        out(f"[{i}] {desc}: {'ok' if ok else 'MISMATCH'}" + (f" ({failed} of {len(status)} chains stopped early: {sorted(set(status[status != 0].tolist()))})" if failed else ""))
+        if not ok:
+            bad.append(dict(case=i, desc=desc, chains=detail))
+    return bad, n_failed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=0)
@@ -227,37 +268,8 @@ def main():
     ap.add_argument("--kinds", default="euclid,riemann,softabs,constrained",
                     help="comma-separated case families to draw from (uniformly)")
     a = ap.parse_args()
-    global STEP_FACTOR, H_FACTOR
-    H_FACTOR = a.stress
-    STEP_FACTOR = 4 if a.long else 1
-    rng = np.random.default_rng(a.seed)
-    makers = {"euclid": euclid_case, "riemann": riemann_case, "softabs": softabs_case, "constrained": constrained_case,
-              "riemann_user": riemann_user_case, "softabs_user": softabs_user_case}
-    kinds = [makers[k] for k in a.kinds.split(",")]
-    bad = n_failed = 0
-    for i in range(a.cases):
-        make = kinds[int(rng.integers(0, len(kinds)))]
-        desc, integ, system, osys, q0, p0, dirs, steps, ref, tol = make(rng)
-        if a.only >= 0 and i != a.only:
-            rng.integers(0, len(q0))  # (the draw of the compared chain below)
-            continue
-        try:
-            q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=steps)
-        except Exception as e:  # unsupported sizes must fail loudly, never silently
-            print(f"[{i}] {desc}: device refused ({type(e).__name__}: {str(e)[:80]})")
-            continue
-        ok = True
-        for c in sorted(set([0, len(q0) - 1, int(rng.integers(0, len(q0)))])):
-            qo, po, so, no = ref(c)
-            if so != status[c] or no != n_done[c] or not close(q[c], qo, tol) or not close(p[c], po, tol):
-                ok = False
-                err = np.max(np.abs(np.nan_to_num(q[c]) - np.nan_to_num(qo)))
-                print(f"    chain {c}: status {status[c]} vs {so}, n_done {n_done[c]} vs {no}, max |dq| = {err:.2e}")
-        failed = int(np.count_nonzero(status))
-        n_failed += failed > 0
-        print(f"[{i}] {desc}: {'ok' if ok else 'MISMATCH'}" + (f" ({failed} of {len(status)} chains stopped early: {sorted(set(status[status != 0].tolist()))})" if failed else ""))
-        bad += not ok
-    print(f"{a.cases} cases, {bad} mismatches" + (f" ({n_failed} cases with chains that stopped early, statuses equal)" if n_failed else ""))
+    bad, n_failed = run_cases(a.seed, a.cases, a.kinds, a.stress, a.long, a.only)
+    print(f"{a.cases} cases, {len(bad)} mismatches" + (f" ({n_failed} cases with chains that stopped early, statuses equal)" if n_failed else ""))
     sys.exit(1 if bad else 0)
 
 

@@ -1216,6 +1216,61 @@ def main():
     wide_sphere_plane("constrained_c2_sphereplane_diag_d33_linesearch", 33, 4, mdl.METRIC_DIAG, 0.05, [1, 5, 20],
                       proj_solver=2)
 
+    # ---- round 5: states scaled by 1e+-150 / 1e+-80.  The kernels replace IEEE division and square root
+    # by lean Newton forms on their critical paths (mm_device.h rcp_nr / fdiv / sqrt_rsqrt) and test divergence as
+    # `err > 1e10 or NaN` (solvers.py:80-84): at these scales the status a chain ends with - diverged, out of iterations,
+    # LinAlgError inside or outside a solver, not reversible - must still be the reference's, whatever became inf or NaN on
+    # the way.  Chain c of every case: positions x QS[c], momenta x PS[c].
+    QS = np.array([1e150, 1e-150, 1e80, 1.0, 1e150, 1e-150, 1e-80, 1.0])
+    PS = np.array([1.0, 1.0, 1e80, 1e150, 1e-150, 1e-150, 1e80, 1e-150])
+
+    def extreme_states(name, d, n=8):
+        r = case_rng(name)
+        return r.standard_normal((n, d)) * QS[:n, None], r.standard_normal((n, d)) * PS[:n, None]
+
+    def add_extreme_riemann(name, target, rmetric, coeff, h, cps, **kw):
+        q0, p0 = extreme_states(name, target.dim)
+        cases[name] = lambda: riemann_case(name, target, rmetric, coeff, q0, p0, dirs_for(len(q0)), h, cps, **kw)
+
+    with np.errstate(all="ignore"):
+        add_extreme_riemann("extreme_riemann_rank1_poly_d8", mdl.Poly(8, 1.0, 1.0 / 3.0), mdl.Rank1Metric(B8), None, 0.1, [1, 3])
+        add_extreme_riemann("extreme_riemann_diagquad_poly_d5_steffensen", mdl.Poly(5, 1.0, 1.0 / 3.0), mdl.DiagQuadMetric(5),
+                            None, 0.1, [1, 3], fp_solver=1)
+        add_extreme_riemann("extreme_riemann_rank1_banana_d40", mdl.Banana(40),
+                            mdl.Rank1Metric(mdl.make_spd(40, case_rng("extreme_base40"))), None, 0.02, [1, 3])
+        add_extreme_riemann("extreme_riemann_rank1_banana_d100", mdl.Banana(100),
+                            mdl.Rank1Metric(mdl.make_spd(100, case_rng("extreme_base100"))), None, 0.02, [1, 2])
+        add_extreme_riemann("extreme_softabs_poly_d9", mdl.Poly(9, 1.0, 1.0 / 3.0), None, 1.0, 0.05, [1, 3])
+
+    def add_extreme_euclid(name, target, mk, metric, h, cps):
+        q0, p0 = extreme_states(name, target.dim)
+        cases[name] = lambda: euclid_case(name, target, mk, metric, q0, p0, dirs_for(len(q0)), h, cps)
+
+    Px = mdl.make_spd(16, case_rng("extreme_prec16"))
+    add_extreme_euclid("extreme_euclid_dense_d16", mdl.GaussDense(Px), mdl.METRIC_DENSE,
+                       mdl.make_spd(16, case_rng("extreme_metric16")), 0.1, [1, 5, 20])
+
+    def add_extreme_constrained(name, target, constraint, mk, metric, q0, h, cps, **kw):
+        # positions stay ON the manifold; the momenta are scaled and projected onto the cotangent space
+        r = case_rng(name)
+        n, d = q0.shape
+        osys = orc.ConstrainedSystem(target, constraint, mk, metric)
+        scale = np.array([1e150, 1e-150, 1e80, 1.0, 1e10, 1e-80, 1e40, 1e-300])[:n, None]
+        p0 = project_momentum(osys, q0, np.stack([osys.msqrt(zz) for zz in r.standard_normal((n, d))])) * scale
+        cases[name] = lambda: constrained_case(name, target, constraint, mk, metric, q0, p0, dirs_for(n), h, cps, **kw)
+
+    add_extreme_constrained("extreme_constrained_torus", mdl.Torus(), mdl.TorusConstr(), mdl.METRIC_IDENTITY, None,
+                            mdl.torus_init(8, case_rng("extreme_torus_q")), 0.1, [1, 3])
+    add_extreme_constrained("extreme_constrained_torus_quasi", mdl.Torus(), mdl.TorusConstr(), mdl.METRIC_IDENTITY, None,
+                            mdl.torus_init(8, case_rng("extreme_torus_q2")), 0.1, [1, 3], proj_solver=1)
+    rr = case_rng("extreme_sphereplane")
+    nrm = rr.standard_normal(40)
+    xs = rr.standard_normal((8, 40))
+    xs -= np.outer(xs @ nrm, nrm) / (nrm @ nrm)
+    add_extreme_constrained("extreme_constrained_sphereplane_d40", mdl.Poly(40, 0.5, 0.25), mdl.SpherePlaneConstr(nrm),
+                            mdl.METRIC_DIAG, np.exp(0.2 * rr.standard_normal(40)),
+                            xs / np.linalg.norm(xs, axis=1, keepdims=True), 0.05, [1, 3])
+
     all_counts = {}
     n_ok, bad = 0, []
     for name, fn in cases.items():
