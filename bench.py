@@ -447,6 +447,7 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
 
     comm = None
     pos_all = None
+    ranks_seen = [None]  # ranks of the RCCL communicator, once one exists (None: no communicator was formed)
     in_loop = world > 1 and gather_mode == "rccl"
     want_host = 1 if rank == 0 else 0  # only the trace-writing rank needs the gathered array on the host
 
@@ -457,6 +458,11 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
         raw = mdist.exchange_unique_id(ctx, rdzv)
         h = C.c_void_p()
         _ffi.check(ctx._lib.mm_comm_create(ctx.handle, world, rank, raw, C.byref(h)), ctx.handle, "mm_comm_create")
+        nr, rr = C.c_int32(0), C.c_int32(0)  # what the communicator ITSELF says it spans (ncclCommCount / ncclCommUserRank)
+        _ffi.check(ctx._lib.mm_comm_count(h, C.byref(nr), C.byref(rr)), ctx.handle, "mm_comm_count")
+        if rr.value != rank:
+            raise RuntimeError(f"RCCL communicator reports rank {rr.value}, launcher says {rank}")
+        ranks_seen[0] = int(nr.value)
         return h, np.empty((world * n_local, w["dim"]))
 
     if in_loop:
@@ -708,7 +714,10 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
         workload=f"{w['name']}, D={w['dim']}, {n_local} chains/GPU x {world} GPU, h={w['h']}, one pass = a trajectory "
                  f"of {traj} leapfrog steps per chain",
         baseline_config=BASELINE_CONFIG.get(config, config), chains_per_gpu=n_local, dim=w["dim"], traj_len=traj,
-        trace_gather=gather_note, trace_gather_ms=trace_gather_ms, _exit_hard=exit_hard)
+        trace_gather=gather_note, trace_gather_ms=trace_gather_ms, _exit_hard=exit_hard,
+        # ranks that took part: the RCCL communicator's own count where one was formed, else the rendezvous' (world)
+        n_ranks_seen=ranks_seen[0] if ranks_seen[0] is not None else (len(rank_elapsed) if rdzv is not None else 1),
+        chains_total=n_local * world)
 
 
 # ---- the result line ---------------------------------------------------------------------------------------------
@@ -753,8 +762,13 @@ def compact_result(full, sidecar=None):
                 brief[name] = {"error": res["error"][:80]}
                 continue
             brief[name] = {"value": res["value"], "ms_per_step": res["ms_per_step"],
-                           "frac": res["roofline"]["frac"], "kernel_ms": res["roofline"]["kernel_ms_per_launch"],
-                           "cpu": (res.get("cpu_baseline") or {}).get("value")}
+                           "frac": res["roofline"]["frac"], "kernel_ms": res["roofline"]["kernel_ms_per_launch"]}
+            # the fifth scalar: at N = 1 the CPU baseline, at N > 1 (no CPU leg) the chains the whole job integrated - c4 at
+            # N = 8 is BASELINE configs[3]'s 8192 chains, c5 its 16384
+            if full.get("n_gpus", 1) > 1:
+                brief[name]["chains"] = res.get("chains_total")
+            else:
+                brief[name]["cpu"] = (res.get("cpu_baseline") or {}).get("value")
         out["configs"] = brief
     if sidecar:
         out["detail"] = sidecar
@@ -871,7 +885,7 @@ def main():
                 configs[cfg] = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
                 continue
             res.pop("_exit_hard")
-            for key in ("trace_gather", "trace_gather_ms"):
+            for key in ("trace_gather", "trace_gather_ms", "n_ranks_seen"):
                 res.pop(key)
             configs[cfg] = res
     if want_cpu:
@@ -904,6 +918,7 @@ def main():
                 "trace_gather": head["trace_gather"],
                 "trace_gather_ms": head["trace_gather_ms"],
                 "n_ranks_seen": head.get("n_ranks_seen", world),
+                "chains_total": head.get("chains_total"),
             },
             "roofline": head["roofline"],
             # wall clock of the timed region on every rank (value uses the max): a straggler shows up here

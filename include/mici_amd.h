@@ -391,6 +391,10 @@ int mm_comm_unique_id(uint8_t id[MM_COMM_ID_BYTES]); /* rank 0 creates, host sid
 int mm_comm_create(mm_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t id[MM_COMM_ID_BYTES],
                    mm_comm** out);
 int mm_comm_destroy(mm_comm* comm);
+/* Ranks the communicator spans and this process' rank in it as RCCL reports them (ncclCommCount / ncclCommUserRank);
+ * either output may be NULL.  The reference's counterpart is the number of worker processes its pool really started
+ * (samplers.py:668-772); bench.py prints it as `config.n_ranks_seen`. */
+int mm_comm_count(mm_comm* comm, int32_t* n_ranks, int32_t* rank);
 /* Gather every rank's pos shard ([n_local][D], equal n_local on all ranks) into host buffer
  * pos_all[n_ranks*n_local][D] on every rank (rank-major = global chain order). */
 int mm_comm_allgather_pos(mm_comm* comm, mm_state* state, double* pos_all);

@@ -129,6 +129,7 @@ SIGNATURES = {
     "mm_comm_allgather_pos": (C.c_int, [_VP, _VP, c_double_p]),
     "mm_comm_allgather_pos_async": (C.c_int, [_VP, _VP, C.c_int]),
     "mm_comm_wait": (C.c_int, [_VP, c_double_p]),
+    "mm_comm_count": (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
 _DEV_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmici_amd_dev.so")

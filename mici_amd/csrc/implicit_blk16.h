@@ -504,7 +504,6 @@ struct TeamBlk16 {
       }
       double vc_next = lds[kOffNat + 16 * tile_j(0, w) + j];  // (the vector operands one slot ahead, as matvec())
       d4 vr_next = *reinterpret_cast<const d4*>(lds + kOffVperm + ((tile_i(0, w) * 4 + g) << 2));
-      double mir[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int s = 0; s < NSLOT; ++s) {
         const int I = tile_i(s, w), J = tile_j(s, w);
@@ -532,11 +531,11 @@ struct TeamBlk16 {
           mm = __builtin_fma(m[1], vr[1], mm);
           mm = __builtin_fma(m[2], vr[2], mm);
           mm = __builtin_fma(m[3], vr[3], mm);
-          // the mirrored partials of four slots reduced over the wave's rows together, as matvec() does (round 5: one
-          // sum_over_g per slot was 12 instructions x 15 slots of this product's ~650)
-          mir[(s - 1) & 3] = mm;
-          if (((s - 1) & 3) == 3 || s == NSLOT - 2)
-            store_mirrored4(part, s - ((s - 1) & 3), w, g, j, mir[0], mir[1], mir[2], ((s - 1) & 3) == 3 ? mir[3] : 0.0);
+          // (round 5: the four-slots-at-a-time reduction matvec() uses - store_mirrored4, 9 instructions for four sums
+          // instead of 48 - was tried here: next to the four prefetched base tiles its four pending partials push the
+          // kernel over its 256 registers, 392 spilled values, c4 7.0e5 -> 3.0e5 steps/s)
+          mm = sum_over_g(mm);
+          part[(16 * J + j) * PSTR + I] = mm;
         }
         // keep the prefetch distance: without it the scheduler sinks every load to just before its use
         __builtin_amdgcn_sched_barrier(0x206);  // arithmetic and LDS stores may cross, loads may not

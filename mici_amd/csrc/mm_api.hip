@@ -1145,6 +1145,8 @@ struct RcclApi {
   int (*CommDestroy)(mm_nccl_comm) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, mm_nccl_comm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(const mm_nccl_comm, int*) = nullptr;     // (optional: mm_comm_count falls back to what it was created with)
+  int (*CommUserRank)(const mm_nccl_comm, int*) = nullptr;
 };
 static RcclApi g_rccl;
 static std::mutex g_rccl_mu;
@@ -1164,6 +1166,8 @@ static int rccl_load(const mm_ctx* ctx) {
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
   g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(lib, "ncclCommCount");
+  g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(lib, "ncclCommUserRank");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) {
     mm_set_error(ctx, "librccl is missing a required ncclXxx symbol");
     return MM_ERR_RCCL;
@@ -1234,6 +1238,23 @@ int mm_comm_create(mm_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t id[
     return MM_ERR_HIP;
   }
   *out = c;
+  return MM_OK;
+}
+
+// Ranks the communicator spans and this process' rank in it, as RCCL itself reports them (ncclCommCount /
+// ncclCommUserRank): what a launcher prints as "ranks seen" - not what it asked for.
+int mm_comm_count(mm_comm* c, int32_t* n_ranks, int32_t* rank) {
+  MM_REQUIRE(nullptr, c != nullptr, "mm_comm_count: comm is NULL");
+  mm_ctx* ctx = c->ctx;
+  int n = c->n_ranks, r = c->rank;
+  if (g_rccl.CommCount && g_rccl.CommUserRank) {
+    int e = g_rccl.CommCount(c->comm, &n);
+    if (e != 0) return rccl_fail(ctx, "ncclCommCount", e);
+    e = g_rccl.CommUserRank(c->comm, &r);
+    if (e != 0) return rccl_fail(ctx, "ncclCommUserRank", e);
+  }
+  if (n_ranks) *n_ranks = n;
+  if (rank) *rank = r;
   return MM_OK;
 }
 

@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 
 #include "../../include/mici_amd.h"
@@ -69,6 +70,7 @@ struct mm_model {
   void* rtc_riem_fn[4][5] = {};
   void* rtc_softabs_module = nullptr;  // SoftAbs system with a user Hessian: softabs.h compiled around it
   void* rtc_softabs_fn[3] = {nullptr, nullptr, nullptr};  // leapfrog step, midpoint step, aux (h / dh_dmom / sample_momentum)
+  std::mutex rtc_mu;           // serialises the attachment of further kernel families (mm_rtc.hip riem_compile_family)
   std::string user_src;        // the user's text (kept for the families compiled later)
   int user_aux = 0;            // MM_USER_AUX of the user's text (0: none)
   bool user_flat_vjp = false;  // MM_USER_VJP_FLAT

@@ -932,9 +932,41 @@ struct SoftAbsBackendT {
     return ok;
   }
 
+  // The Jacobi sweeps and the refinement square and multiply the matrix' entries (column norms, Rayleigh quotients):
+  // with |H_ij| beyond 1e150 - a state scaled by 1e75 on a quartic target - those overflow where LAPACK's eigh, which
+  // scales its input, succeeds and the reference carries on to a diverging fixed-point solve (ConvergenceError, not
+  // LinAlgError: tests/test_gpu_extreme_scale.py).  A Hessian whose largest entry lies outside [1e-100, 1e100] is
+  // therefore decomposed as 2^-e H (an exact scaling; the eigenvectors are those of H) and the eigenvalues scaled back.
+  // The factor goes to LDS (the spare work-counter cell): a register live across eigh() is one more spilled value.
+  __device__ __forceinline__ void rescale_hessian() {
+    double m = 0.0;
+    for (int el = tid; el < NP * NP; el += NT) m = __builtin_fmax(m, fabs(w.H[(el / NP) * LD + el % NP]));
+    m = block_reduce4(m, 1, w.red, red_flip);
+    const bool scale = (m > 1e100 || (m < 1e-100 && m > 0.0)) && m < 1.7e308;  // (not: in range, all zero, not finite)
+    if (!scale) {
+      if (tid == 0) w.cnt[7] = 1.0;
+      return;
+    }
+    const int e = ilogb(m);
+    const double down_a = ldexp(1.0, -(e / 2)), down_b = ldexp(1.0, -(e - e / 2));  // (2^-e itself can be subnormal)
+    for (int el = tid; el < NP * NP; el += NT) {
+      double& h = w.H[(el / NP) * LD + el % NP];
+      h = (h * down_a) * down_b;
+    }
+    if (tid == 0) w.cnt[7] = ldexp(1.0, e);
+    __syncthreads();
+  }
+  static_assert(CNT_COUNT <= 7, "w.cnt[7] holds the Hessian's scale factor");
+
   __device__ __forceinline__ bool build_and_invert(double x) {
     build_hessian(x);
+    rescale_hessian();
     if (!eigh()) return false;
+    const double hs = uniform_f64(w.cnt[7]);  // (written before eigh()'s barriers)
+    if (hs != 1.0) {  // team-uniform
+      if (tid < dim) w.lam[tid] *= hs;
+      __syncthreads();
+    }
     return regularise();
   }
 

@@ -103,6 +103,12 @@ class RcclTraceGather:
         self.handle = h
         self._out = None
 
+    def ranks_seen(self):
+        """(n_ranks, rank) as the RCCL communicator itself reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = C.c_int32(0), C.c_int32(0)
+        _ffi.check(self.ctx._lib.mm_comm_count(self.handle, C.byref(n), C.byref(r)), self.ctx.handle, "mm_comm_count")
+        return int(n.value), int(r.value)
+
     def gather(self, batch):
         shape = (self.world * batch.n_chains, batch.dim)
         if self._out is None or self._out.shape != shape:

@@ -63,6 +63,15 @@ def default_jobs():
         for dim in dims:
             for fam in families_of(dim):
                 jobs.append((name, src, dim, fam, 0))
+    # a user TARGET joined with a user metric / Hessian (tests/test_gpu_user_target.py: the text the package hands over is
+    # target source + "\n" + metric source, mici_amd/runtime.py DeviceModel)
+    if "user_sources" in sys.modules:
+        us = sys.modules["user_sources"]
+        for msrc, dims in ((us.RANK1_AS_USER, (20, 70, 200)), (ue.RANK1_AS_USER_FLAT, (48, 100))):
+            for dim in dims:
+                for fam in families_of(dim):
+                    jobs.append(("BANANA_SRC+RANK1", us.BANANA_SRC + "\n" + msrc, dim, fam, 100))
+        jobs.append(("BANANA_SRC+BANANA_HESS", us.BANANA_SRC + "\n" + ue.BANANA_HESS, 64, "softabs", 100))
     # user Hessians of SoftAbs systems (one translation unit per text, whatever the dimension)
     jobs.append(("BANANA_HESS", ue.BANANA_HESS, 64, "softabs", 0))
     if "user_sources" in sys.modules:

@@ -17,10 +17,11 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def _run(seed, cases, kinds, stress=1.0, only=-1):
+def _run(seed, cases, kinds, stress=1.0, only=-1, sensitivity=False):
     import fuzz_parity
     lines = []
-    bad, n_failed = fuzz_parity.run_cases(seed, cases, kinds, stress=stress, only=only, out=lines.append)
+    bad, n_failed = fuzz_parity.run_cases(seed, cases, kinds, stress=stress, only=only, out=lines.append,
+                                          sensitivity=sensitivity)
     return bad, n_failed, lines
 
 
@@ -35,15 +36,22 @@ def test_mixed_slice(seed, cases, kinds):
     assert sum("ok" in ln for ln in lines) >= cases * 0.9  # (a refused size prints "device refused": must stay rare)
 
 
-@pytest.mark.parametrize("seed,cases,kinds,stress", [
-    (511, 20, "riemann", 10.0),
-    (512, 12, "softabs", 8.0),
-    (513, 8, "riemann_user", 10.0),
+@pytest.mark.parametrize("seed,cases,kinds,stress,expect_stops", [
+    (511, 20, "riemann", 10.0, True),
+    (512, 12, "softabs", 8.0, True),
+    (513, 8, "riemann_user", 10.0, False),  # (profiles/r04_stress_fuzz.txt: one case in sixty stops early at this stress)
 ])
-def test_stress_slice_statuses_equal(seed, cases, kinds, stress):
-    bad, n_failed, lines = _run(seed, cases, kinds, stress=stress)
-    assert not bad, "\n".join(lines[-40:])
-    assert n_failed > 0, "the stress slice is there for chains that stop early"
+def test_stress_slice_statuses_equal(seed, cases, kinds, stress, expect_stops):
+    """At 4-10 times the step size many solves do not converge, and where an iteration wanders for its whole budget its
+    outcome (which step it gives up in, or whether it converges after all) can flip with the last bit of the input - in the
+    oracle itself.  A chain whose outcome differs is therefore first put to the oracle with its inputs moved by parts in
+    1e16 (fuzz_parity.oracle_is_sensitive); only an outcome the oracle does NOT reach that way is a mismatch, and at
+    most two cases of a slice may need that excuse."""
+    bad, n_failed, lines = _run(seed, cases, kinds, stress=stress, sensitivity=True)
+    real = [b for b in bad if not b.get("sensitive")]
+    assert not real, "\n".join(lines[-40:])
+    assert len(bad) <= 2, "\n".join(lines[-40:])
+    assert n_failed > 0 or not expect_stops, "the stress slice is there for chains that stop early"
 
 
 def test_the_documented_last_bit_case_resolves_either_way():

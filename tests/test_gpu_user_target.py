@@ -4,6 +4,8 @@ brings HIP device code.  Checked: a built-in target re-expressed as user source 
 target that is NOT built in matches the oracle driven by its NumPy twin; compile errors and unsupported system
 classes fail loudly."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -17,22 +19,7 @@ from mici_amd.runtime import DeviceBatch, default_context
 
 pytestmark = pytest.mark.gpu
 
-BANANA_SRC = """
-__device__ double mm_user_grad(const double* q, int i, int dim, const double* params) {
-  double g = -(1.0 - q[i]) / 10.0;
-  if (i > 0) g += 2.0 * (q[i] - q[i - 1] * q[i - 1]);
-  if (i < dim - 1) g -= 4.0 * q[i] * (q[i + 1] - q[i] * q[i]);
-  return g;
-}
-__device__ double mm_user_nld_term(const double* q, int i, int dim, const double* params) {
-  double v = (1.0 - q[i]) * (1.0 - q[i]) / 20.0;
-  if (i < dim - 1) {
-    const double r = q[i + 1] - q[i] * q[i];
-    v += r * r;
-  }
-  return v;
-}
-"""
+from user_sources import BANANA_SRC  # noqa: E402  (the built-in banana target as user source; also precompiled)
 
 # l(q) = sum_i [ log(1 + exp(-a_i q_i)) + b q_i^2 / 2 ] + c (sum_i q_i)^2 / 2 : not separable, not built in
 LOGISTIC_SRC = """
@@ -511,3 +498,98 @@ def test_user_hessian_softabs_on_the_banana_matches_oracle(dim):
                 qs, ps, ss, _ = integ.step_batch(qs, ps, 1, n_steps=4)
                 assert np.all(ss == 0)
             assert_close(qs, q, 2e-9, "3 launches of 4 steps vs one of 12")
+
+
+# ---- a user TARGET together with a user METRIC / HESSIAN: the only way to run a user target on a Riemannian
+# system; MM_RTC_USER_TARGET inside the translation units of implicit_mfma.h / implicit_blk16.h / implicit_team.h / softabs.h
+@pytest.mark.parametrize("dim,flat", [(20, False), (48, True), (70, False), (100, True), (200, False)])
+def test_user_target_with_user_metric_matches_the_builtin_pair(dim, flat):
+    """The banana target AND the rank-one metric both as user source (one joined text) against the built-in pair, on every
+    kernel family a dimension dispatches to: wave (D = 20), matrix-core wave (48), team (70), block-16 (100, 200).  Same
+    statuses, step counts and fixed-point evaluation counts; states to rounding level (the user forms build the metric
+    entry by entry and contract V(i, j) generically); h / dh_dmom / sample_momentum likewise."""
+    from user_sources import RANK1_AS_USER, RANK1_AS_USER_FLAT
+
+    rng = np.random.default_rng(900 + dim)
+    n = 6
+    B = omdl.make_spd(dim, rng)
+    builtin = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(B))
+    user = systems.DenseRiemannianMetricSystem(models.UserTarget(dim, BANANA_SRC),
+                                               models.UserMetric(dim, RANK1_AS_USER_FLAT if flat else RANK1_AS_USER, B))
+    q0 = rng.standard_normal((n, dim))
+    z = rng.standard_normal((n, dim))
+    p0 = builtin.sample_momentum_batch(q0, z)
+    assert_close(user.sample_momentum_batch(q0, z), p0, 1e-12, "sample_momentum")
+    assert_close(user.h_batch(q0, p0), builtin.h_batch(q0, p0), 1e-12, "h")
+    assert_close(user.dh_dmom_batch(q0, p0), builtin.dh_dmom_batch(q0, p0), 1e-12, "dh_dmom")
+    h, steps = (0.03, 6) if dim <= 64 else (0.01, 3)
+    ib, iu = integrators.ImplicitLeapfrogIntegrator(builtin, h), integrators.ImplicitLeapfrogIntegrator(user, h)
+    qb, pb, sb, nb = ib.step_batch(q0, p0, 1, n_steps=steps)
+    qu, pu, su, nu = iu.step_batch(q0, p0, 1, n_steps=steps)
+    assert np.array_equal(sb, su) and np.array_equal(nb, nu) and np.all(sb == 0)
+    assert ib.last_counters["n_fp_evals"] == iu.last_counters["n_fp_evals"]
+    assert_close(qu, qb, 1e-10, "positions")
+    assert_close(pu, pb, 1e-10, "momenta")
+    osys = orc.RiemannianSystem(omdl.Banana(dim), omdl.Rank1Metric(B))
+    qo, po, so, no = orc.implicit_leapfrog_steps(osys, q0[0], p0[0], h, steps)
+    assert so == 0 and no == steps
+    assert_close(qu[0], qo, 1e-10, "positions vs oracle")
+
+
+@pytest.mark.parametrize("dim", [12, 48])
+def test_user_target_with_user_hessian_matches_the_builtin_target(dim):
+    """SoftAbs: the banana target as user source + its Hessian / matrix-Tressian product as user source (softabs.h compiled
+    with MM_RTC_USER_TARGET and MM_RTC_USER_HESSIAN) against the built-in banana target with the same user Hessian."""
+    from user_sources import BANANA_HESS
+
+    rng = np.random.default_rng(950 + dim)
+    n, h, steps = 4, 0.02, 6
+    builtin = systems.SoftAbsRiemannianMetricSystem(models.Banana(dim), softabs_coeff=1.0,
+                                                    hess_neg_log_dens=models.UserHessian(BANANA_HESS))
+    user = systems.SoftAbsRiemannianMetricSystem(models.UserTarget(dim, BANANA_SRC), softabs_coeff=1.0,
+                                                 hess_neg_log_dens=models.UserHessian(BANANA_HESS))
+    q0 = rng.standard_normal((n, dim))
+    z = rng.standard_normal((n, dim))
+    p0 = builtin.sample_momentum_batch(q0, z)
+    assert_close(user.sample_momentum_batch(q0, z), p0, 1e-12, "sample_momentum")
+    assert_close(user.h_batch(q0, p0), builtin.h_batch(q0, p0), 1e-11, "h")
+    ib, iu = integrators.ImplicitLeapfrogIntegrator(builtin, h), integrators.ImplicitLeapfrogIntegrator(user, h)
+    qb, pb, sb, nb = ib.step_batch(q0, p0, 1, n_steps=steps)
+    qu, pu, su, nu = iu.step_batch(q0, p0, 1, n_steps=steps)
+    assert np.array_equal(sb, su) and np.array_equal(nb, nu)
+    assert ib.last_counters["n_fp_evals"] == iu.last_counters["n_fp_evals"]
+    assert_close(qu, qb, 2e-9, "positions")
+    assert_close(pu, pb, 2e-9, "momenta")
+
+
+def test_code_object_that_does_not_load_is_recompiled(tmp_path):
+    """a cache file that passes the ELF check but that the runtime refuses (truncated here; stale after a
+    toolchain change in the field) used to fail every later model creation.  Now: the file is erased, the text compiled
+    once more, the load retried - in the same call."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    cache = tmp_path / "cache"
+    prog = (
+        "import numpy as np, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from mici_amd import integrators, models, systems\n"
+        "from user_sources import RANK1_AS_USER\n"
+        "rng = np.random.default_rng(3); B = np.eye(6) * 2.0\n"
+        "s = systems.DenseRiemannianMetricSystem(models.Banana(6), models.UserMetric(6, RANK1_AS_USER, B))\n"
+        "q0 = rng.standard_normal((3, 6)); p0 = s.sample_momentum_batch(q0, rng.standard_normal((3, 6)))\n"
+        "q, p, st, nd = integrators.ImplicitLeapfrogIntegrator(s, 0.02).step_batch(q0, p0, 1, n_steps=2)\n"
+        "assert np.all(st == 0); print(repr(float(q.sum())))\n" % (ROOT, os.path.join(ROOT, "tests")))
+    env = dict(os.environ, MICI_AMD_RTC_SEED="off", MICI_AMD_RTC_CACHE=str(cache))
+    first = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
+    assert first.returncode == 0, first.stderr[-2000:]
+    files = sorted(f for f in os.listdir(cache) if f.endswith(".hsaco"))
+    assert files
+    good = {f: (cache / f).read_bytes() for f in files}
+    for f in files:
+        (cache / f).write_bytes(good[f][: len(good[f]) // 2])  # an ELF header, half an image
+    second = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
+    assert second.returncode == 0, second.stderr[-2000:]
+    assert second.stdout.strip() == first.stdout.strip()
+    for f in files:
+        assert (cache / f).read_bytes() == good[f], f"{f} was not restored"

@@ -124,3 +124,23 @@ __device__ double mm_user_mtp(const double* q, const MmMat& M, int k, int dim, c
   return e * w * q[k] * mvv - e * w * (M(0, k) + M(k, 0));
 }
 """
+
+
+# the built-in banana target (mm_device.h MM_TARGET_BANANA) as user source: tests/test_gpu_user_target.py
+BANANA_SRC = """
+__device__ double mm_user_grad(const double* q, int i, int dim, const double* params) {
+  double g = -(1.0 - q[i]) / 10.0;
+  if (i > 0) g += 2.0 * (q[i] - q[i - 1] * q[i - 1]);
+  if (i < dim - 1) g -= 4.0 * q[i] * (q[i + 1] - q[i] * q[i]);
+  return g;
+}
+__device__ double mm_user_nld_term(const double* q, int i, int dim, const double* params) {
+  double v = (1.0 - q[i]) * (1.0 - q[i]) / 20.0;
+  if (i < dim - 1) {
+    const double r = q[i + 1] - q[i] * q[i];
+    v += r * r;
+  }
+  return v;
+}
+"""
+
