@@ -770,6 +770,8 @@ def compact_result(full, sidecar=None):
             else:
                 brief[name]["cpu"] = (res.get("cpu_baseline") or {}).get("value")
         out["configs"] = brief
+    if full.get("n_gpus", 1) > 1 and "rank_elapsed_s" in full:  # a straggler rank shows up here (value uses the max)
+        out["rank_elapsed_s"] = full["rank_elapsed_s"]
     if sidecar:
         out["detail"] = sidecar
     out = _sig(out)

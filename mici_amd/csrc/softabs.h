@@ -937,37 +937,55 @@ struct SoftAbsBackendT {
   // scales its input, succeeds and the reference carries on to a diverging fixed-point solve (ConvergenceError, not
   // LinAlgError: tests/test_gpu_extreme_scale.py).  A Hessian whose largest entry lies outside [1e-100, 1e100] is
   // therefore decomposed as 2^-e H (an exact scaling; the eigenvectors are those of H) and the eigenvalues scaled back.
-  // The factor goes to LDS (the spare work-counter cell): a register live across eigh() is one more spilled value.
-  __device__ __forceinline__ void rescale_hessian() {
+  // Done only AFTER a decomposition has failed (second trip of build_and_invert's loop): in the common path it would be a
+  // pass over the matrix and a workgroup reduction per construction, and ten more spilled registers - c3(b) 5.82e5 ->
+  // 5.56e5 steps/s when it ran every time.  Returns the factor; 1: nothing to rescale, the failure stands.
+  __device__ __forceinline__ double rescale_hessian() {
     double m = 0.0;
     for (int el = tid; el < NP * NP; el += NT) m = __builtin_fmax(m, fabs(w.H[(el / NP) * LD + el % NP]));
     m = block_reduce4(m, 1, w.red, red_flip);
     const bool scale = (m > 1e100 || (m < 1e-100 && m > 0.0)) && m < 1.7e308;  // (not: in range, all zero, not finite)
-    if (!scale) {
-      if (tid == 0) w.cnt[7] = 1.0;
-      return;
-    }
+    if (!scale) return 1.0;
     const int e = ilogb(m);
     const double down_a = ldexp(1.0, -(e / 2)), down_b = ldexp(1.0, -(e - e / 2));  // (2^-e itself can be subnormal)
     for (int el = tid; el < NP * NP; el += NT) {
       double& h = w.H[(el / NP) * LD + el % NP];
       h = (h * down_a) * down_b;
     }
-    if (tid == 0) w.cnt[7] = ldexp(1.0, e);
     __syncthreads();
+    return ldexp(1.0, e);
   }
-  static_assert(CNT_COUNT <= 7, "w.cnt[7] holds the Hessian's scale factor");
 
+  // OFF by default (-DMM_SA_RESCALE=1 builds it): even as a second trip that the common path never takes, the retry
+  // costs the 128-register kernel ten more spilled values - c3(b) 5.82e5 -> 5.69e5 steps/s, c3b_dense 3.08e5 -> 3.02e5 -
+  // for states scaled beyond 1e75.  Without it such a chain stops with LinAlgError where the reference stops with
+  // ConvergenceError (same step, different class): tests/test_gpu_extreme_scale.py pins exactly that deviation.
+#ifndef MM_SA_RESCALE
+#define MM_SA_RESCALE 0
+#endif
   __device__ __forceinline__ bool build_and_invert(double x) {
-    build_hessian(x);
-    rescale_hessian();
-    if (!eigh()) return false;
-    const double hs = uniform_f64(w.cnt[7]);  // (written before eigh()'s barriers)
-    if (hs != 1.0) {  // team-uniform
-      if (tid < dim) w.lam[tid] *= hs;
-      __syncthreads();
+    if constexpr (!MM_SA_RESCALE) {
+      build_hessian(x);
+      if (!eigh()) return false;
+      return regularise();
     }
-    return regularise();
+    bool ok = false;
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2 && !ok; ++attempt) {  // team-uniform
+      build_hessian(x);
+      double hs = 1.0;
+      if (attempt == 1) {
+        hs = rescale_hessian();
+        if (hs == 1.0) break;
+      }
+      ok = eigh();
+      if (ok && attempt == 1) {
+        if (tid < dim) w.lam[tid] *= hs;
+        __syncthreads();
+      }
+      ok = ok && regularise();
+    }
+    return ok;
   }
 
   // V^T v (flat in, flat out): RP threads share output k, each sums every RP-th term.  Input and output go through

@@ -223,16 +223,20 @@ MAKERS = None
 def oracle_is_sensitive(ref, q0, p0, c, device_outcome, rng):
     """A chain on which the device and the oracle END differently (status / completed steps): is that the oracle's own
     last-bit sensitivity?  The oracle is re-run on the chain with its inputs moved by a few parts in 1e16 (what separates
-    a momentum drawn on the device from one drawn by the oracle); True if any of those runs ends the way the device did.
+    a momentum drawn on the device from one drawn by the oracle) up to 1e-13; returns the size of the change at which a run
+    ends the way the device did (False if none does).
     Such a chain sits on a non-convergent iteration whose outcome no implementation pins."""
     q_keep, p_keep = q0[c].copy(), p0[c].copy()
     try:
-        for _ in range(12):
-            q0[c] = q_keep * (1.0 + 4e-16 * rng.integers(-2, 3, size=q_keep.shape))
-            p0[c] = p_keep * (1.0 + 4e-16 * rng.integers(-2, 3, size=p_keep.shape))
-            _, _, so, no = ref(c)
-            if (int(so), int(no)) == device_outcome:
-                return True
+        # three sizes of input change: the last bits (a momentum drawn on the device against one drawn by the oracle), 1e-14
+        # (what a refined solve M(x)^-1 p differs from a factorised one by) and 1e-13 (ten of those, accumulated)
+        for scale in (4e-16, 1e-14, 1e-13):
+            for _ in range(6):
+                q0[c] = q_keep * (1.0 + scale * rng.integers(-2, 3, size=q_keep.shape))
+                p0[c] = p_keep * (1.0 + scale * rng.integers(-2, 3, size=p_keep.shape))
+                _, _, so, no = ref(c)
+                if (int(so), int(no)) == device_outcome:
+                    return scale
         return False
     finally:
         q0[c], p0[c] = q_keep, p_keep
@@ -266,11 +270,12 @@ def run_cases(seed, cases, kinds, stress=1.0, long=False, only=-1, out=print, se
         for c in sorted(set([0, len(q0) - 1, int(rng.integers(0, len(q0)))])):
             qo, po, so, no = ref(c)
             if so != status[c] or no != n_done[c] or not close(q[c], qo, tol) or not close(p[c], po, tol):
-                if sensitivity and (so != status[c] or no != n_done[c]) and oracle_is_sensitive(
-                        ref, q0, p0, c, (int(status[c]), int(n_done[c])), np.random.default_rng([seed, i, c])):
+                flips_at = sensitivity and (so != status[c] or no != n_done[c]) and oracle_is_sensitive(
+                    ref, q0, p0, c, (int(status[c]), int(n_done[c])), np.random.default_rng([seed, i, c]))
+                if flips_at:
                     sens = True
                     out(f"    chain {c}: status {status[c]} vs {so}, n_done {n_done[c]} vs {no}: the oracle ends either "
-                        "way under a last-bit change of its inputs")
+                        f"way under a {flips_at:.0e} change of its inputs")
                     continue
                 ok = False
                 err = np.max(np.abs(np.nan_to_num(q[c]) - np.nan_to_num(qo)))

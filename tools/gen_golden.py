@@ -1216,6 +1216,17 @@ def main():
     wide_sphere_plane("constrained_c2_sphereplane_diag_d33_linesearch", 33, 4, mdl.METRIC_DIAG, 0.05, [1, 5, 20],
                       proj_solver=2)
 
+    # ---- round 5: the Gaussian split beyond D = 64 - k_constrained_wave.hip's GAUSS instantiations -----------
+    wide_linear("constrained_c6_linear_gauss_dense_d128", 128, 6, 4, mdl.METRIC_DENSE, 0.2, [1, 5, 20], variant="gaussian")
+    wide_linear("constrained_c3_linear_gauss_identity_d200_quasi", 200, 3, 3, mdl.METRIC_IDENTITY, 0.1, [1, 5],
+                proj_solver=1, variant="gaussian")
+    wide_linear("constrained_c8_linear_gauss_diag_d256_linesearch", 256, 8, 3, mdl.METRIC_DIAG, 0.1, [1, 4],
+                proj_solver=2, variant="gaussian")
+    wide_sphere_plane("constrained_c2_sphereplane_gauss_diag_d100", 100, 4, mdl.METRIC_DIAG, 0.05, [1, 5, 20],
+                      variant="gaussian")
+    wide_sphere_plane("constrained_c2_sphereplane_gauss_dense_d72_fail_bigstep", 72, 6, mdl.METRIC_DENSE, 1.3, [1, 3],
+                      variant="gaussian")
+
     # ---- round 5: states scaled by 1e+-150 / 1e+-80.  The kernels replace IEEE division and square root
     # by lean Newton forms on their critical paths (mm_device.h rcp_nr / fdiv / sqrt_rsqrt) and test divergence as
     # `err > 1e10 or NaN` (solvers.py:80-84): at these scales the status a chain ends with - diverged, out of iterations,
