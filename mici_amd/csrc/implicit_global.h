@@ -1,0 +1,446 @@
+// Device code of the GLOBAL-MEMORY tier of the dense-Riemannian kernels: 279 < D <= 1024 (round 5).
+//
+// Every other backend keeps a chain's D x D metric on chip - in the registers of a wave (D <= 64), of a CU (D <= 279) - and
+// that is where the size limit of rounds 1-4 came from.  The reference factorises any D (DensePositiveDefiniteMatrix,
+// matrices.py:1117-1216; DenseRiemannianMetricSystem, systems.py:1690-1734).  Here the matrix lives in HBM: one
+// 1024-thread workgroup per chain (one flat vector element per thread, as implicit_core.h wants it), a DP x DP row-major
+// workspace per chain (DP = D rounded up to 64), and
+//   * the explicit inverse by a BLOCKED symmetric sweep, eight pivots per pass over the matrix (the algebra of
+//     implicit_mfma.h's block step, any block size: panel Q = A[K, :], X = Q - E, W = P^-1 X, A -= W^T X, A_KK -= 2 I; after
+//     the last block A = -M^-1, the pivots of the in-block eliminations are the Cholesky pivots squared: positive
+//     definiteness and log det) - D / 8 passes of 2 x 8 DP^2 bytes of HBM traffic;
+//   * every product (M^-1 v of the held inverse, M(x) v of the refinement solves - the solve-only constructions are
+//     refined from the held inverse as on every other backend, implicit_core.h refine_solve) as a COLUMN walk: thread i
+//     accumulates sum_j A[j][i] v_j, the loads of a wave are 512 consecutive bytes for every j, v_j is an LDS broadcast -
+//     one pass over the matrix per product (the rank-one metric's base matrix is shared by all chains: L2 / MALL resident);
+//   * sample_momentum's Cholesky factor (the reference's metric.sqrt @ z, matrices.py:1161-1178) by a blocked
+//     right-looking factorisation on the same panel machinery, stored transposed so that L z is a column walk too.
+// A step costs one sweep and ~60 products, all HBM-bound: this tier is about REACH (any D the reference takes, up to the
+// 1024 threads of a workgroup), not about the roofline; DESIGN.md section 4.4b has the measured rates.
+// Built-in metrics (rank-one update, diag(1 + q^2)); the leapfrog step and the three auxiliary operations.
+#pragma once
+#include "implicit_core.h"
+
+namespace mmglob {
+
+using namespace mmdev;
+using namespace mmimp;
+
+constexpr int NT = 1024;      // threads per chain = largest D
+constexpr int NB = 8;         // pivots per block
+constexpr int DPMAX = 1024;
+// LDS (doubles): the two panels, one natural-order vector, the pivot block and its inverse, two sets of reduction partials
+constexpr int kOffX = 0;                       // [NB][DPMAX]  X = Q - E
+constexpr int kOffW = kOffX + NB * DPMAX;      // [NB][DPMAX]  W = P^-1 X
+constexpr int kOffNat = kOffW + NB * DPMAX;    // [DPMAX + 8]
+constexpr int kOffPb = kOffNat + DPMAX + 8;    // [NB * NB] pivot block, inverted in place
+constexpr int kOffFlag = kOffPb + NB * NB;     // [8] flags / log det of the block
+constexpr int kOffRed = kOffFlag + 8;          // [2][16]
+constexpr int kLdsDoubles = kOffRed + 32;
+static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU");
+
+__host__ __device__ constexpr int padded_dim(int dim) { return (dim + 63) & ~63; }
+
+template <int RMETRIC>
+struct GlobalBackend {
+  static constexpr bool kSolveByInverse = true;   // implicit_core.h: a factorised solve = invert + product
+  static constexpr bool kUnifiedConstruct = false;
+  static constexpr bool kCountersInLds = false;
+  static constexpr bool kRefine = true;           // solve-only constructions refined from the held inverse
+  bool refine_on;
+  int dim, dp, tid, target, flip;
+  double inv_dim_;
+  double* lds;
+  double* A;            // this chain's DP x DP workspace (row-major, leading dimension dp)
+  const double* base;   // rank-one metric: base matrix [dim][dim]
+  const double* tparams;
+  double st_[SL_COUNT_REFINE];  // the step's flat per-thread state: registers (every index is a compile-time constant)
+  double rs_[RS_COUNT];
+  double xpt_;                  // this thread's coordinate of the refinement products' point
+  __device__ __forceinline__ double& slot(int i) { return st_[i]; }
+  __device__ __forceinline__ double& rslot(int i) { return rs_[i]; }
+  __device__ __forceinline__ bool flat_active() const { return tid < dim; }
+
+  // ---- workgroup reductions: one barrier each (two sets of partials used alternately, as softabs.h block_reduce4) ------
+  __device__ __forceinline__ double reduce(double v, bool use_max) {
+    const int lane = tid & 63, wave = tid >> 6;
+    double* const set = lds + kOffRed + 16 * flip;
+    flip ^= 1;
+    v = use_max ? wave_max(v) : wave_sum(v);
+    if (lane == 0) set[wave] = v;
+    __syncthreads();
+    double r = set[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) r = use_max ? nanmax(r, set[w]) : r + set[w];
+    return r;
+  }
+  __device__ __forceinline__ double sum1(double a) { return reduce(tid < dim ? a : 0.0, false); }
+  __device__ __forceinline__ void sum2(double a, double b, double* sa, double* sb) {
+    *sa = sum1(a);
+    *sb = sum1(b);
+  }
+  __device__ __forceinline__ double norm(double x, int kind) {
+    const double a = tid < dim ? x : 0.0;
+    if (kind == MM_NORM_LINF) return reduce(fabs(a), true);
+    return sqrt(reduce(a * a, false));
+  }
+
+  // natural-order copy of a flat vector (zero beyond dim), visible to the workgroup
+  __device__ __forceinline__ void publish(double v) {
+    __syncthreads();  // (readers of the previous contents are done)
+    lds[kOffNat + tid] = tid < dim ? v : 0.0;
+    __syncthreads();
+  }
+
+  // y_i = sum_{j < n} Mat[j * ld + i] nat_j : a column walk (coalesced over the threads for every j, nat_j broadcast)
+  __device__ __forceinline__ double column_walk(const double* __restrict__ mat, int ld, int n) const {
+    if (tid >= dim) return 0.0;
+    const double* col = mat + tid;
+    const double* nat = lds + kOffNat;
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+      y0 = __builtin_fma(col[(size_t)j * ld], nat[j], y0);
+      y1 = __builtin_fma(col[(size_t)(j + 1) * ld], nat[j + 1], y1);
+      y2 = __builtin_fma(col[(size_t)(j + 2) * ld], nat[j + 2], y2);
+      y3 = __builtin_fma(col[(size_t)(j + 3) * ld], nat[j + 3], y3);
+    }
+    for (; j < n; ++j) y0 = __builtin_fma(col[(size_t)j * ld], nat[j], y0);
+    return (y0 + y1) + (y2 + y3);
+  }
+
+  // ---- metric_func(x) into the workspace (identity on the padding); false: an entry is not finite -------------------
+  __device__ __forceinline__ bool build(double x) {
+    publish(x);
+    const double* nat = lds + kOffNat;
+    const int tx = tid & 31, ty = tid >> 5;
+    double chk = 0.0;
+    for (int i = ty; i < dp; i += 32) {
+      const double xi = nat[i] * inv_dim_;
+      for (int j = tx; j < dp; j += 32) {
+        double v = (i == j) ? 1.0 : 0.0;
+        if (i < dim && j < dim) {
+          if constexpr (RMETRIC == MM_RMETRIC_RANK1) v = __builtin_fma(xi, nat[j], base[(size_t)i * dim + j]);
+          else v = (i == j) ? __builtin_fma(nat[i], nat[i], 1.0) : 0.0;
+        }
+        A[(size_t)i * dp + j] = v;
+        chk = __builtin_fma(v, 0.0, chk);  // "Array is not finite." (matrices.py:211-215): every entry is looked at
+      }
+    }
+    const double bad = reduce(chk != 0.0 ? 1.0 : 0.0, false);  // (chk is NaN for a non-finite entry; its barrier publishes A)
+    return bad == 0.0;
+  }
+
+  // A[i][j] -= sum_k Wp[k][i] Xp[k][j] over the whole matrix: thread (tx, ty) owns the elements (ty + 32 a, tx + 32 b),
+  // 2 x 2 of them at a time (the panels' sixteen + sixteen operands of a 2 x 2 tile come from LDS once)
+  __device__ __forceinline__ void rank_update(const double* __restrict__ Wp, const double* __restrict__ Xp) {
+    const int tx = tid & 31, ty = tid >> 5;
+    for (int a = 0; a < dp / 32; a += 2) {
+      const int i0 = ty + 32 * a, i1 = i0 + 32;
+      double w0[NB], w1[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        w0[k] = Wp[k * DPMAX + i0];
+        w1[k] = Wp[k * DPMAX + i1];
+      }
+      for (int b = 0; b < dp / 32; b += 2) {
+        const int j0 = tx + 32 * b, j1 = j0 + 32;
+        double* p00 = A + (size_t)i0 * dp + j0;
+        double* p10 = A + (size_t)i1 * dp + j0;
+        double a00 = p00[0], a01 = p00[32], a10 = p10[0], a11 = p10[32];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          const double x0 = Xp[k * DPMAX + j0], x1 = Xp[k * DPMAX + j1];
+          a00 = __builtin_fma(-w0[k], x0, a00);
+          a01 = __builtin_fma(-w0[k], x1, a01);
+          a10 = __builtin_fma(-w1[k], x0, a10);
+          a11 = __builtin_fma(-w1[k], x1, a11);
+        }
+        p00[0] = a00;
+        p00[32] = a01;
+        p10[0] = a10;
+        p10[32] = a11;
+      }
+    }
+  }
+
+  // the NB x NB pivot block in LDS (pb), by the first wave: in-place Gauss-Jordan inverse (no pivoting: the block is a
+  // Schur complement of a positive-definite matrix), its pivots = the Cholesky pivots squared.  flag[0] = 1 unless all
+  // pivots are positive and finite, flag[1] = sum of their logarithms.
+  __device__ __forceinline__ void invert_pivot_block() {
+    double* pb = lds + kOffPb;
+    double* flag = lds + kOffFlag;
+    if (tid < 64) {
+      const int r = tid >> 3, c = tid & 7;
+      double bad = 0.0, ld = 0.0;
+#pragma unroll 1
+      for (int k = 0; k < NB; ++k) {
+        const double piv = pb[k * NB + k], prk = pb[r * NB + k], pkc = pb[k * NB + c], prc = pb[r * NB + c];
+        wave_sync();
+        if (!(piv > 0.0) || !(piv < 1.7e308)) bad = 1.0;
+        ld += log(piv);
+        const double d = 1.0 / piv;
+        double v;
+        if (r == k && c == k) v = d;
+        else if (r == k) v = prc * d;
+        else if (c == k) v = -prc * d;
+        else v = __builtin_fma(-prk * d, pkc, prc);
+        pb[r * NB + c] = v;
+        wave_sync();
+      }
+      if (tid == 0) {
+        flag[0] = bad;
+        flag[1] = ld;
+      }
+    }
+  }
+
+  // ---- explicit inverse of the matrix build() left in the workspace: A <- -M^-1 ------------------------------------------
+  __device__ __forceinline__ bool invert(double* logdet) {
+    double* Xp = lds + kOffX;
+    double* Wp = lds + kOffW;
+    double* pb = lds + kOffPb;
+    const double* flag = lds + kOffFlag;
+    bool ok = true;
+    double ld = 0.0;
+    const int nblk = (dim + NB - 1) / NB;  // (the padding beyond is the identity, decoupled from the rest)
+    for (int blk = 0; blk < nblk; ++blk) {
+      const int k0 = blk * NB;
+      // (1) the panel: rows k0 .. k0 + NB - 1 of A (coalesced), X = Q - E, and the pivot block
+      if (tid < dp) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          const double v = A[(size_t)(k0 + k) * dp + tid];
+          Xp[k * DPMAX + tid] = (tid == k0 + k) ? v - 1.0 : v;
+          if (tid >= k0 && tid < k0 + NB) pb[k * NB + (tid - k0)] = v;
+        }
+      }
+      __syncthreads();
+      // (2) P^-1 (first wave), (3) W = P^-1 X column by column
+      invert_pivot_block();
+      __syncthreads();
+      if (flag[0] != 0.0) ok = false;  // (uniform: every thread reads the same cell)
+      ld += flag[1];
+      if (tid < dp) {
+        double x[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) x[k] = Xp[k * DPMAX + tid];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          double s = pb[k * NB] * x[0];
+#pragma unroll
+          for (int l = 1; l < NB; ++l) s = __builtin_fma(pb[k * NB + l], x[l], s);
+          Wp[k * DPMAX + tid] = s;
+        }
+      }
+      __syncthreads();
+      // (4) A -= W^T X everywhere, then A_KK -= 2 I
+      rank_update(Wp, Xp);
+      __syncthreads();
+      if (tid < NB) A[(size_t)(k0 + tid) * dp + k0 + tid] -= 2.0;
+      __syncthreads();
+    }
+    if (logdet) *logdet = ld;
+    // a NaN pivot poisons W and with it the whole matrix; a non-positive one is caught by the flag
+    return ok && (ld == ld);
+  }
+
+  __device__ __forceinline__ bool build_and_invert(double x) {
+    const bool fin = build(x);
+    return invert(nullptr) && fin;
+  }
+
+  // ---- y = M(x0)^-1 v (the workspace holds -M^-1) -----------------------------------------------------------------------
+  __device__ __forceinline__ double matvec(double v) {
+    publish(v);
+    return -column_walk(A, dp, dim);
+  }
+  // ---- refinement products: M(x) v matrix-free ---------------------------------------------------------------------------
+  __device__ __forceinline__ void metric_point(double x) { xpt_ = tid < dim ? x : 0.0; }
+  __device__ __forceinline__ double metric_apply(double v) {
+    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
+      return tid < dim ? __builtin_fma(xpt_ * xpt_, v, v) : 0.0;
+    } else {
+      publish(v);
+      const double y = column_walk(base, dim, dim);  // B v (B symmetric)
+      const double dot = sum1(xpt_ * v);
+      return tid < dim ? __builtin_fma(xpt_, dot * inv_dim_, y) : 0.0;
+    }
+  }
+
+  // 0.5 * vjp_metric(M^-1): rank-one metric M^-1 q / D; diag-quad metric q_i (M^-1)_ii
+  __device__ __forceinline__ double half_vjp_inv(double q) {
+    if constexpr (RMETRIC == MM_RMETRIC_RANK1) return matvec(q) * inv_dim_;
+    else return tid < dim ? -q * A[(size_t)tid * dp + tid] : 0.0;
+  }
+  // dense metric: grad_quadratic_form_inv(p) = -(M^-1 p)(M^-1 p)^T   (matrices.py:1179-1181)
+  __device__ __forceinline__ double dh2_dpos(double p, double q) {
+    const double u = matvec(p);
+    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+      const double uq = sum1(u * q);
+      return -(u * uq) * inv_dim_;
+    } else {
+      return -q * (u * u);
+    }
+  }
+  __device__ __forceinline__ double grad(double q) {
+    publish(q);
+    const TargetAux aux = target_prepare<false>(target, lds + kOffNat, dim, tparams, tid & 63);
+    return tid < dim ? target_grad_elem<false>(target, aux, lds + kOffNat, tid, dim, tparams) : 0.0;
+  }
+  __device__ __forceinline__ double neg_log_dens_elem(double q) {
+    publish(q);
+    const TargetAux aux = target_prepare<false>(target, lds + kOffNat, dim, tparams, tid & 63);
+    return tid < dim ? target_nld_elem<false>(target, aux, lds + kOffNat, tid, dim, tparams) : 0.0;
+  }
+
+  // ---- Cholesky factor of the matrix build() left in the workspace, stored TRANSPOSED: row k of A holds L[:, k] from the
+  // diagonal on (blocked, right-looking: the trailing update is rank_update with W = X = the panel of L) --------------------
+  __device__ __forceinline__ bool cholesky_transposed() {
+    double* Xp = lds + kOffX;
+    double* pb = lds + kOffPb;
+    const double* flag = lds + kOffFlag;
+    bool ok = true;
+    const int nblk = (dim + NB - 1) / NB;
+    for (int blk = 0; blk < nblk; ++blk) {
+      const int k0 = blk * NB;
+      if (tid >= k0 && tid < k0 + NB) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) pb[k * NB + (tid - k0)] = A[(size_t)(k0 + k) * dp + tid];
+      }
+      __syncthreads();
+      if (tid == 0) {  // the 8 x 8 block's own Cholesky factor, in place (lower triangle of pb), sequentially
+        double bad = 0.0;
+        for (int j = 0; j < NB; ++j) {
+          double d = pb[j * NB + j];
+          for (int m = 0; m < j; ++m) d -= pb[j * NB + m] * pb[j * NB + m];
+          if (!(d > 0.0) || !(d < 1.7e308)) bad = 1.0;
+          const double l = sqrt(d);
+          pb[j * NB + j] = l;
+          for (int i = j + 1; i < NB; ++i) {
+            double s = pb[i * NB + j];
+            for (int m = 0; m < j; ++m) s -= pb[i * NB + m] * pb[j * NB + m];
+            pb[i * NB + j] = s / l;
+          }
+        }
+        lds[kOffFlag] = bad;
+      }
+      __syncthreads();
+      if (flag[0] != 0.0) ok = false;
+      // column j of the panel: y = Lkk^-1 A[K, j] (forward substitution) = L[j][K]^T for j beyond the block; inside the
+      // block the factor itself.  Zero left of the block (so that the full-range trailing update leaves those parts alone).
+      if (tid < dp) {
+        double y[NB];
+        if (tid >= k0 + NB) {
+#pragma unroll
+          for (int k = 0; k < NB; ++k) {
+            double s = A[(size_t)(k0 + k) * dp + tid];
+#pragma unroll
+            for (int m = 0; m < NB; ++m)
+              if (m < k) s -= pb[k * NB + m] * y[m];
+            y[k] = s / pb[k * NB + k];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NB; ++k) y[k] = (tid >= k0 && tid - k0 >= k) ? pb[(tid - k0) * NB + k] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          Xp[k * DPMAX + tid] = tid >= k0 + NB ? y[k] : 0.0;
+          if (tid >= k0) A[(size_t)(k0 + k) * dp + tid] = y[k];  // row k0 + k of A <- L[:, k0 + k]
+        }
+      }
+      __syncthreads();
+      rank_update(Xp, Xp);  // trailing A[i][j] -= sum_k L[i][k] L[j][k] (zero panel entries elsewhere)
+      __syncthreads();
+    }
+    return ok;
+  }
+};
+
+template <int RMETRIC>
+__device__ __forceinline__ void init_backend(GlobalBackend<RMETRIC>& bk, const ImplicitArgs& A, double* lds) {
+  bk.dim = A.dim;
+  bk.dp = padded_dim(A.dim);
+  bk.tid = threadIdx.x;
+  bk.target = A.target;
+  bk.flip = 0;
+  bk.inv_dim_ = 1.0 / (double)A.dim;
+  bk.lds = lds;
+  bk.A = A.work + (size_t)blockIdx.x * bk.dp * bk.dp;
+  bk.base = A.rparams;
+  bk.tparams = A.tparams;
+  bk.refine_on = A.no_refine == 0;
+  bk.xpt_ = 0.0;
+}
+
+template <int RMETRIC>
+__device__ __forceinline__ void implicit_global_body(const ImplicitArgs& A, double* lds) {
+  GlobalBackend<RMETRIC> bk;
+  init_backend(bk, A, lds);
+  const int64_t chain = blockIdx.x;
+  const int tid = threadIdx.x, dim = A.dim;
+  const bool act = tid < dim;
+  bk.slot(SL_Q) = act ? A.pos[chain * dim + tid] : 0.0;
+  bk.slot(SL_P) = act ? A.mom[chain * dim + tid] : 0.0;
+  const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
+  const ChainResult r = implicit_leapfrog_chain(bk, t, mmdev::chain_steps(A.chain_steps, chain, A.n_steps), A.opts);
+  if (act) {
+    A.pos[chain * dim + tid] = bk.slot(SL_Q);
+    A.mom[chain * dim + tid] = bk.slot(SL_P);
+  }
+  if (tid == 0) {
+    A.status[chain] = r.status;
+    A.n_done[chain] = r.done;
+    add_counters(A.counters, r);
+  }
+}
+
+// OP 0: h = nld + log det M / 2 + p^T M^-1 p / 2;  1: dh_dmom = M^-1 p;  2: sample_momentum: mom <- L z   (systems.py:1375-1402)
+template <int RMETRIC, int OP>
+__device__ __forceinline__ void riemann_aux_global_body(const ImplicitArgs& A, double* lds) {
+  GlobalBackend<RMETRIC> bk;
+  init_backend(bk, A, lds);
+  const int64_t chain = blockIdx.x;
+  const int tid = threadIdx.x, dim = A.dim;
+  const bool act = tid < dim;
+  const double q = act ? A.pos[chain * dim + tid] : 0.0;
+  const double p = act ? A.mom[chain * dim + tid] : 0.0;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  bool ok = bk.build(q);
+  if constexpr (OP == 0) {
+    double logdet;
+    ok = bk.invert(&logdet) && ok;
+    const double u = bk.matvec(p);
+    const double e = bk.neg_log_dens_elem(q) + (act ? 0.5 * p * u : 0.0);
+    const double h = bk.reduce(e, false) + 0.5 * logdet;
+    if (tid == 0) A.out[chain] = ok ? h : nan;
+  } else if constexpr (OP == 1) {
+    ok = bk.invert(nullptr) && ok;
+    const double u = bk.matvec(p);
+    if (act) A.out[chain * dim + tid] = ok ? u : nan;
+  } else {
+    ok = bk.cholesky_transposed() && ok;
+    bk.publish(act ? A.z[chain * dim + tid] : 0.0);
+    // (L z)_i = sum_{k <= i} L[i][k] z_k = sum_{k <= i} A[k][i] z_k: the column walk stops at the diagonal
+    double y = 0.0;
+    if (act) {
+      const double* nat = lds + kOffNat;
+      for (int k = 0; k <= tid; ++k) y = __builtin_fma(bk.A[(size_t)k * bk.dp + tid], nat[k], y);
+    }
+    if (act) A.mom[chain * dim + tid] = ok ? y : nan;
+  }
+}
+
+template <int RMETRIC>
+__global__ __launch_bounds__(NT) void implicit_global_kernel(ImplicitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  implicit_global_body<RMETRIC>(A, lds);
+}
+template <int RMETRIC, int OP>
+__global__ __launch_bounds__(NT) void riemann_aux_global_kernel(ImplicitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  riemann_aux_global_body<RMETRIC, OP>(A, lds);
+}
+
+}  // namespace mmglob

@@ -185,6 +185,9 @@ int mm_launch_implicit_large(mm_ctx*, const mm_model*, mm_state*, double, int, c
 int mm_launch_riemann_aux_large(mm_ctx*, const mm_model*, mm_state*, int, double*, const double*);
 int mm_launch_implicit_mfma(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
 int mm_launch_implicit_blk16(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
+// 279 < D <= 1024: the chain's metric in HBM (k_implicit_global.hip)
+int mm_launch_implicit_global(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
+int mm_launch_riemann_aux_global(mm_ctx*, const mm_model*, mm_state*, int, double*, const double*);
 
 // a user metric: the same kernels, compiled at run time around the user's source (mm_rtc.hip)
 static int launch_user_metric(mm_ctx* ctx, const mm_model* m, mm_state* s, int which, double h, int n_steps,
@@ -220,6 +223,7 @@ int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, dou
   // solve-only constructions as a blocked LDL^T (k_implicit_blk16.hip).  MICI_AMD_IMPLICIT_KERNEL=team selects the
   // VALU team kernel.  (The round-1 4-pivot kernel and the look-ahead variant of round 2 lost their A/B runs and were
   // removed in round 3; they are in the history: k_implicit_mfma_team.hip, k_implicit_blk16la.hip.)
+  if (m->dim > 279) return mm_launch_implicit_global(ctx, m, s, h, n_steps, opts, d_counters);
   if (m->dim > 75 && m->dim <= 256 && force != 2)
     return mm_launch_implicit_blk16(ctx, m, s, h, n_steps, opts, d_counters);
   if (m->dim > 64 || (m->dim > 32 && force == 2))
@@ -255,6 +259,7 @@ int mm_launch_riemann_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, d
   if (m->rmetric == MM_RMETRIC_USER) return launch_user_metric(ctx, m, s, 2 + op, 0.0, 0, nullptr, nullptr, d_out, d_z);
   if (m->rmetric == MM_RMETRIC_SOFTABS || m->rmetric == MM_RMETRIC_SOFTABS_USER)
     return mm_launch_softabs_aux(ctx, m, s, op, d_out, d_z);
+  if (m->dim > 279) return mm_launch_riemann_aux_global(ctx, m, s, op, d_out, d_z);
   if (m->dim > 64) return mm_launch_riemann_aux_large(ctx, m, s, op, d_out, d_z);
   ImplicitArgs a = make_args(m, s);
   a.out = d_out;

@@ -1,0 +1,80 @@
+// Host side of the global-memory tier of the dense-Riemannian kernels, 279 < D <= 1024 (device code: implicit_global.h).
+#include "implicit_global.h"
+
+namespace {
+
+using namespace mmimp;
+using namespace mmglob;
+
+int fill_args(mm_ctx* ctx, const mm_model* m, mm_state* s, ImplicitArgs& a) {
+  if (m->dim > DPMAX) {
+    mm_set_error(ctx, "dense-Riemannian kernels support dim <= 1024 (one flat vector element per thread of a workgroup)");
+    return MM_ERR_UNSUPPORTED;
+  }
+  if (m->rmetric != MM_RMETRIC_RANK1 && m->rmetric != MM_RMETRIC_DIAGQUAD) {
+    mm_set_error(ctx, "dense-Riemannian kernels beyond dim 279: built-in metrics only");
+    return MM_ERR_UNSUPPORTED;
+  }
+  a = ImplicitArgs{};
+  a.pos = s->d_pos;
+  a.mom = s->d_mom;
+  a.dir = s->d_dir;
+  a.step_scale = s->d_step_scale;
+  a.chain_steps = s->d_chain_steps;
+  a.status = s->d_status;
+  a.n_done = s->d_n_done;
+  a.n_chains = s->n;
+  a.dim = s->dim;
+  a.target = m->target;
+  a.tparams = m->d_target_params;
+  a.rparams = m->d_rmetric_params;  // rank-one metric: the base matrix [dim][dim], read as it is
+  const size_t dp = (size_t)padded_dim(m->dim);
+  const int rc = mm_state_ensure_work(ctx, s, (size_t)s->n * dp * dp * sizeof(double));  // the chains' matrices, in HBM
+  if (rc != MM_OK) return rc;
+  a.work = static_cast<double*>(s->d_work);
+  return MM_OK;
+}
+
+template <class K>
+int launch(mm_ctx* ctx, K kernel, const ImplicitArgs& a) {
+  if (a.n_chains == 0) return MM_OK;
+  const size_t lds = kLdsDoubles * sizeof(double);
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)a.n_chains), dim3(NT), lds, ctx->stream, a);
+  MM_HIP_CHECK(ctx, hipGetLastError());
+  return MM_OK;
+}
+
+}  // namespace
+
+int mm_launch_implicit_global(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_fp_opts& opts,
+                              mm_counters* d_counters) {
+  ImplicitArgs a;
+  const int rc = fill_args(ctx, m, s, a);
+  if (rc != MM_OK) return rc;
+  a.step_size = h;
+  a.n_steps = n_steps;
+  a.opts = opts;
+  a.counters = d_counters;
+  a.no_refine = mm_refine_disabled();
+  return m->rmetric == MM_RMETRIC_RANK1 ? launch(ctx, implicit_global_kernel<MM_RMETRIC_RANK1>, a)
+                                        : launch(ctx, implicit_global_kernel<MM_RMETRIC_DIAGQUAD>, a);
+}
+
+int mm_launch_riemann_aux_global(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* d_out, const double* d_z) {
+  ImplicitArgs a;
+  const int rc = fill_args(ctx, m, s, a);
+  if (rc != MM_OK) return rc;
+  a.out = d_out;
+  a.z = d_z;
+  const bool r1 = m->rmetric == MM_RMETRIC_RANK1;
+  if (op == 0)
+    return r1 ? launch(ctx, riemann_aux_global_kernel<MM_RMETRIC_RANK1, 0>, a)
+              : launch(ctx, riemann_aux_global_kernel<MM_RMETRIC_DIAGQUAD, 0>, a);
+  if (op == 1)
+    return r1 ? launch(ctx, riemann_aux_global_kernel<MM_RMETRIC_RANK1, 1>, a)
+              : launch(ctx, riemann_aux_global_kernel<MM_RMETRIC_DIAGQUAD, 1>, a);
+  return r1 ? launch(ctx, riemann_aux_global_kernel<MM_RMETRIC_RANK1, 2>, a)
+            : launch(ctx, riemann_aux_global_kernel<MM_RMETRIC_DIAGQUAD, 2>, a);
+}

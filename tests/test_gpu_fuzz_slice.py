@@ -49,8 +49,18 @@ def test_stress_slice_statuses_equal(seed, cases, kinds, stress, expect_stops):
     most two cases of a slice may need that excuse."""
     bad, n_failed, lines = _run(seed, cases, kinds, stress=stress, sensitivity=True)
     real = [b for b in bad if not b.get("sensitive")]
-    assert not real, "\n".join(lines[-40:])
-    assert len(bad) <= 2, "\n".join(lines[-40:])
+    # One more class is known and allowed ONCE per slice (tools/dbg/r05_case17.py, gpurun_out/r05_case17.txt in DESIGN.md
+    # section 2): a Steffensen iteration that wanders for its whole budget of 100 iterations in one implementation and
+    # slips under the tolerance in the other - the oracle's outcome is stable under INPUT changes up to 1e-12 there, yet
+    # the device, with every construction factorised (MICI_AMD_REFINE=0) as with the refined solves, converges: what
+    # differs is the rounding of M^-1 p itself (blocked sweep against LAPACK's Cholesky), which no input perturbation
+    # emulates.  Such a chain ends with MAX_ITERS (2) or not at all on both sides, one step apart.
+    def max_iters_class(rec):
+        return all(set(ch["status"]) <= {0, 2} and abs(ch["n_done"][0] - ch["n_done"][1]) <= 1 and 2 in ch["status"]
+                   for ch in rec["chains"] if ch["status"][0] != ch["status"][1] or ch["n_done"][0] != ch["n_done"][1])
+    other = [b for b in real if not max_iters_class(b)]
+    assert not other, "\n".join(lines[-40:])
+    assert len(real) <= 1 and len(bad) <= 2, "\n".join(lines[-40:])
     assert n_failed > 0 or not expect_stops, "the stress slice is there for chains that stop early"
 
 

@@ -332,7 +332,7 @@ def test_implicit_midpoint_unsupported_systems_fail_loudly():
 def test_unsupported_sizes_fail_loudly():
     from mici_amd.errors import DeviceError
     rng = np.random.default_rng(0)
-    big = 280
+    big = 1025  # (round 5: 279 < D <= 1024 runs on the global-memory tier; one flat element per thread of a workgroup)
     system = systems.DenseRiemannianMetricSystem(models.Banana(big), models.Rank1Metric(np.eye(big)))
     with pytest.raises(DeviceError):
         integrators.ImplicitLeapfrogIntegrator(system, 0.01).step_batch(
@@ -350,10 +350,10 @@ def test_unsupported_sizes_fail_loudly():
             systems.DenseConstrainedEuclideanMetricSystem(
                 models.Poly(257, 1.0, 0.0), models.LinearConstr(rng.standard_normal((3, 257)), np.zeros(3))),
             0.1).step_batch(rng.standard_normal((1, 257)), rng.standard_normal((1, 257)), 1, 1)
-    with pytest.raises(DeviceError):  # the Gaussian split stays on the lane-per-chain kernels, dim <= 64
+    with pytest.raises(DeviceError):  # the Gaussian split: lane per chain to dim 64, wave per chain to 256 (round 5)
         integrators.ConstrainedLeapfrogIntegrator(
-            systems.GaussianDenseConstrainedEuclideanMetricSystem(models.Poly(65, 0.0, 0.25), models.SphereConstr()),
-            0.1).step_batch(rng.standard_normal((1, 65)), rng.standard_normal((1, 65)), 1, 1)
+            systems.GaussianDenseConstrainedEuclideanMetricSystem(models.Poly(257, 0.0, 0.25), models.SphereConstr()),
+            0.1).step_batch(rng.standard_normal((1, 257)), rng.standard_normal((1, 257)), 1, 1)
     with pytest.raises(DeviceError):  # ... and at 8 constraint functions
         integrators.ConstrainedLeapfrogIntegrator(
             systems.DenseConstrainedEuclideanMetricSystem(

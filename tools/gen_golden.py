@@ -1216,6 +1216,18 @@ def main():
     wide_sphere_plane("constrained_c2_sphereplane_diag_d33_linesearch", 33, 4, mdl.METRIC_DIAG, 0.05, [1, 5, 20],
                       proj_solver=2)
 
+    # ---- round 5: dense Riemannian metrics beyond D = 279 - the global-memory tier (implicit_global.h) ------
+    for nm, tgt, rm, n, hh, cps, kw in (
+            ("riemann_global_rank1_banana_d300", mdl.Banana(300), "rank1", 3, 0.01, [1, 3], {}),
+            ("riemann_global_rank1_banana_d512", mdl.Banana(512), "rank1", 2, 0.008, [1, 2], {}),
+            ("riemann_global_diagquad_poly_d320_steffensen", mdl.Poly(320, 1.0, 1.0 / 3.0), "diag", 3, 0.05, [1, 3],
+             dict(fp_solver=1)),
+            ("riemann_global_rank1_poly_d281_fail_bigstep", mdl.Poly(281, 1.0, 1.0 / 3.0), "rank1", 4, 1.2, [1, 2],
+             dict(qscale=2.0))):
+        rr_ = case_rng(nm)
+        metric_ = mdl.Rank1Metric(mdl.make_spd(tgt.dim, rr_)) if rm == "rank1" else mdl.DiagQuadMetric(tgt.dim)
+        add_riemann(nm, tgt, metric_, None, n, hh, cps, r=rr_, **kw)
+
     # ---- round 5: the Gaussian split beyond D = 64 - k_constrained_wave.hip's GAUSS instantiations -----------
     wide_linear("constrained_c6_linear_gauss_dense_d128", 128, 6, 4, mdl.METRIC_DENSE, 0.2, [1, 5, 20], variant="gaussian")
     wide_linear("constrained_c3_linear_gauss_identity_d200_quasi", 200, 3, 3, mdl.METRIC_IDENTITY, 0.1, [1, 5],
