@@ -45,13 +45,12 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #ifndef MM_MFMA_KERNEL_ATTR
 #define MM_MFMA_KERNEL_ATTR
 #endif
-// Lock-step position solves (implicit_core.h refine_solve2) on this kernel: OFF.  Measured in round 5 (tools/dbg/r05_ab_c3.sh):
-// the state machine and the paired products are correct (tests/test_gpu_implicit.py green with them on), and in a binary
-// where both forms pay the same register penalty the lock step is 12 % faster (9.97e6 against 8.87e6 steps/s) - but with
-// 128 registers of inverse row live across the solve, every form of the paired products tried (fully unrolled, hand
-// pipelined, a real loop, the second system's vectors in LDS, one inlined product site) makes the allocator move the row
-// into accumulation registers (1.2-1.7 k v_accvgpr_read in the kernel against 120) and the kernel falls from 1.35e7 to
-// 1.0e7.  -DMM_MFMA_DUAL=1 builds it (tools/ab_build.py k_implicit_mfma dual -DMM_MFMA_DUAL=1).
+// Lock-step position solves (implicit_core.h refine_solve2) on this kernel: OFF.  Measured in round 5
+// (profiles/r05_ab_c3_dual.txt): the state machine and the paired products are correct (tests/test_gpu_implicit.py green with
+// them on), but with 128 registers of inverse row live across the solve most forms of the paired products make the
+// allocator move the row into accumulation registers (1.2-1.7 k v_accvgpr_read in the kernel against 120: 1.35e7 -> 1.0e7
+// steps/s), and the one form whose allocation survives (-DMM_MFMA_DUAL=1 -DMM_DUAL_UNROLL=4: the second system's vectors in
+// LDS, F r as two passes) runs at 1.257e7 with the lock step on against 1.325e7 off.  DESIGN.md section 4.3d.
 #ifndef MM_MFMA_DUAL
 #define MM_MFMA_DUAL 0
 #endif
@@ -417,7 +416,7 @@ struct MfmaBackend {
       // registers and come back through 240 v_accvgpr_read.  Nothing here indexes a register array, so nothing needs
       // the unrolling.
 #ifndef MM_DUAL_UNROLL
-#define MM_DUAL_UNROLL 2
+#define MM_DUAL_UNROLL 4
 #endif
 #pragma unroll MM_DUAL_UNROLL
       for (int k = 0; k < 16; ++k) {

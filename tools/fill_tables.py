@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""Fill the measured tables of DESIGN.md / README.md from profiles/<round>_bench_default.json (+ the PMC files), between
-the <!-- R04_TABLE --> / <!-- R04_README_TABLE --> markers (ROUND=r04), so the documents quote what the committed record holds."""
+"""Fill the measured tables of DESIGN.md / README.md from profiles/<round>_bench_configs.json (the full record bench.py
+writes beside its compact stdout line; rounds 1-4: <round>_bench_default.json) + the PMC files, between the
+<!-- R05_TABLE --> / <!-- R05_README_TABLE --> markers (ROUND=r05), so the documents quote what the committed record holds."""
 import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r04")
+ROUND = os.environ.get("ROUND", "r05")
 
 
 def sci(x):
@@ -20,7 +21,9 @@ def sci(x):
 
 
 def main():
-    rec = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_bench_default.json")))
+    # round 5: the stdout line is the compact headline; the full per-config record is the sidecar, committed beside it
+    side = os.path.join(ROOT, "profiles", f"{ROUND}_bench_configs.json")
+    rec = json.load(open(side if os.path.exists(side) else os.path.join(ROOT, "profiles", f"{ROUND}_bench_default.json")))
     rows = [("c2", "c2(iii) D=128, 4096 chains, leapfrog", rec)]
     names = {"c2i": "c2(i) iso-Gaussian", "c2iv": "c2(iv) + dense metric", "c3": "c3(a) D=64, 1024 chains",
              "c3b": "c3(b) SoftAbs D=64", "c4": "c4 shard D=256, 1024 chains", "c5": "c5 shard, 2048 chains",

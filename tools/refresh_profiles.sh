@@ -4,9 +4,10 @@
 #     bash tools/refresh_profiles.sh collect
 # on the build host copies the summaries into profiles/ with the round prefix.
 #     gpurun --timeout 1700 -- 'bash tools/refresh_profiles.sh'
-# What it produces (ROUND=r04 by default):
+# What it produces (ROUND=r05 by default; SKIP_TESTS=1 leaves the pytest run out, SHORT_FUZZ=1 runs 30-case fuzz seeds):
 #   <round>_gpu_tests.txt                 tail of `pytest -m gpu`
-#   <round>_bench_default.json            the exact default command, `python bench.py`
+#   <round>_bench_default.json            the exact default command, `python bench.py`: its ONE compact stdout line
+#   <round>_bench_configs.json            ... and the full per-config record it writes beside it (the sidecar)
 #   <round>_rocprofv3_kernel_stats.csv    `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline`
 #   <round>_<cfg>_pmc_hbm.json            FETCH_SIZE / WRITE_SIZE passes (separate runs, gfx950 correction) - c2 c2i c2iv c3 c3b c4 c5
 #                                         and the user-source configs c3_user c4_general c3b_dense (kernels mm_rtc_*)
@@ -14,7 +15,7 @@
 #   <round>_c4_ubench_blk16.txt, <round>_c3_ubench_mfma.txt   phase clocks of the two dense-Riemannian kernels
 #   <round>_fuzz_parity.txt               tools/fuzz_parity.py, three seeds x 80 cases + 60 long SoftAbs cases + constrained + user-source kinds
 #   <round>_host_latency.txt              tools/host_latency.py in three fresh processes (single-state Integrator.step, step_batch, system.h)
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 if [ "$1" = "collect" ]; then
   src=$ROOT/gpurun_out/${ROUND}p
@@ -29,7 +30,10 @@ cd $ROOT
 O=$ROOT/gpurun_out/${ROUND}p; rm -rf $O; mkdir -p $O
 KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2iv:leapfrog_mfma_kernel c3:implicit_mfma_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel c3_user:mm_rtc_riem_step c4_general:mm_rtc_riem_step c3b_dense:mm_rtc_softabs_step"
 
-python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -4 > $O/gpu_tests.txt; cat $O/gpu_tests.txt
+if [ -z "$SKIP_TESTS" ]; then
+  python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -4 > $O/gpu_tests.txt; cat $O/gpu_tests.txt
+fi
+NF=80; [ -n "$SHORT_FUZZ" ] && NF=30
 for pair in $KERNELS; do
   cfg=${pair%%:*}; kern=${pair##*:}
   bash tools/pmc_hbm.sh $cfg $kern > $O/pmc_hbm_$cfg.log 2>&1
@@ -40,7 +44,8 @@ import json; d=json.load(open('$O/${cfg}_pmc_hbm.json')); print('$cfg HBM traffi
 done
 # the bench line cites the HBM traffic of THESE passes: put them where bench.py looks (profiles/ of this tree) first
 for pair in $KERNELS; do cfg=${pair%%:*}; [ -f $O/${cfg}_pmc_hbm.json ] && cp $O/${cfg}_pmc_hbm.json $ROOT/profiles/${ROUND}_${cfg}_pmc_hbm.json; done
-python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-160 $O/bench_default.json
+MICI_AMD_BENCH_SIDECAR=$O/bench_configs.json python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-160 $O/bench_default.json
+wc -c $O/bench_default.json $O/bench_configs.json
 
 export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o bench -- python $ROOT/bench.py --no-cpu-baseline > $O/prof_default.log 2>&1
@@ -60,7 +65,7 @@ python tools/ubench_blk16.py 2>&1 | grep -v "^{" > $O/c4_ubench_blk16.txt; tail 
 python tools/ubench_primitives.py > $O/c3_ubench_mfma.txt 2>&1; tail -10 $O/c3_ubench_mfma.txt
 
 for seed in 31 32 33; do
-  timeout 1200 python tools/fuzz_parity.py --seed $seed --cases 80 > $O/fuzz_$seed.log 2>&1
+  timeout 1200 python tools/fuzz_parity.py --seed $seed --cases $NF > $O/fuzz_$seed.log 2>&1
   echo "seed $seed rc=$? $(tail -1 $O/fuzz_$seed.log)" >> $O/fuzz_parity.txt
   grep "MISMATCH\|Traceback" -B2 $O/fuzz_$seed.log | head -10 >> $O/fuzz_parity.txt
   rm -f $O/fuzz_$seed.log
