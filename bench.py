@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - leapfrog-steps/sec (all chains) of the MI355X integrator hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2iv|c2bcss|c3|c3b|c4|c5|c3_user|c4_general|c3b_dense]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2iv|c2bcss|c3|c3b|c4|c5|c3_user|c4_general|c3b_dense|c4_d512]
                     [--traj-len L] [--chains-per-gpu M] [--no-extra-configs] [--no-cpu-baseline]
 
 Contract (driver): W untimed warm-up passes, then EXACTLY K timed passes bracketed by a barrier +
@@ -152,12 +152,15 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
                     traj=traj, integ=integ, system=system, make_oracle=make_oracle, q0=q0, p0=p0,
                     bytes_per_chain_step=32.0 * dim, flops_per_chain_step=flops, valu_executed_flops_per_chain_step=exec_flops,
                     bound="hbm" if config == "c2i" else "mfma", kind="euclid")
-    if config in ("c3", "c4", "c3_user", "c4_general"):
+    if config in ("c3", "c4", "c3_user", "c4_general", "c4_d512"):
         # c3_user / c4_general (VERDICT r03 #1c): the GENERAL dense-Riemannian path - the metric reaches the library as user
         # source (mici_amd/user_examples.py), compiled around the matrix-core kernels at run time.  c3_user: a metric that
         # is not built in (softplus diagonal + rank one, D = 64); c4_general: the c4 workload itself with its rank-one
         # metric handed over as user source (D = 256) - M(x) v of the refinement solves from the user's entries.
-        dim, h, traj = (64, 0.02, 100) if config in ("c3", "c3_user") else (256, 0.01, 50)
+        # c4_d512 (round 5): the c4 workload at twice the dimension - beyond what a CU's registers hold, on the global-memory
+        # tier (csrc/implicit_global.h: the chain's metric in HBM, blocked sweep, column-walk products)
+        dim, h, traj = (64, 0.02, 100) if config in ("c3", "c3_user") else ((512, 0.008, 5) if config == "c4_d512"
+                                                                              else (256, 0.01, 50))
         if config == "c3_user":
             from mici_amd import user_examples
             cvec = 0.5 * rng.standard_normal(dim)
@@ -248,6 +251,8 @@ def _sweep_mfma_counts(dim):
     inverse, solve = trailing LDL^T sweep), counted from the kernel sources; None for the VALU kernels."""
     if 32 < dim <= 64:      # k_implicit_mfma.hip: 16 blocks of 4 pivots, 10 lower tiles; trailing: tiles with J >= I0
         return dict(full=160, solve=4 * (10 + 6 + 3 + 1), padded_dim=64)
+    if dim > 279:           # implicit_global.h: VALU sweep and column walks, no matrix-core instructions
+        return None
     if 75 < dim <= 256:     # k_implicit_blk16.hip: per 16-pivot block 4 MFMAs per updated tile + 64 (-W) + 4 (pivot block)
         nblk = (dim + 15) // 16
         full = nblk * (136 * 4 + 64 + 4)
@@ -256,17 +261,19 @@ def _sweep_mfma_counts(dim):
     return None
 
 
-DEFAULT_CHAINS = {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048, "c3_user": 1024, "c4_general": 1024, "c3b_dense": 1024}  # per GPU; else 4096
-EXTRA_CONFIGS = ("c2i", "c2iv", "c3", "c3b", "c4", "c5", "c3_user", "c4_general", "c3b_dense")
+DEFAULT_CHAINS = {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048, "c3_user": 1024, "c4_general": 1024, "c3b_dense": 1024,
+                  "c4_d512": 256}  # per GPU; else 4096
+EXTRA_CONFIGS = ("c2i", "c2iv", "c3", "c3b", "c4", "c5", "c3_user", "c4_general", "c3b_dense", "c4_d512")
 # pass counts of the extra configs are capped (a c3(b) pass is ~1 s, a c4 pass ~0.1-0.3 s)
-EXTRA_STEP_CAP = {"c3b": 5, "c4": 10, "c4_general": 10, "c3b_dense": 5}
+EXTRA_STEP_CAP = {"c3b": 5, "c4": 10, "c4_general": 10, "c3b_dense": 5, "c4_d512": 3}
 BASELINE_CONFIG = {"c2": "BASELINE.json configs[1]", "c2i": "BASELINE.json configs[1] (iso-Gaussian variant, SURVEY 8d c2(i))",
                    "c2iv": "BASELINE.json configs[1] (dense-metric variant, SURVEY 8d c2(iv))",
                    "c3": "BASELINE.json configs[2] (Cholesky path)", "c3b": "BASELINE.json configs[2] (SoftAbs path)",
                    "c4": "BASELINE.json configs[3] (per-GPU shard)", "c5": "BASELINE.json configs[4] (per-GPU shard)",
                    "c3_user": "BASELINE.json configs[2] sizes, a metric_func that is not built in (user source)",
                    "c4_general": "BASELINE.json configs[3] (per-GPU shard), its metric_func handed over as user source",
-                   "c3b_dense": "BASELINE.json configs[2] (SoftAbs path) on the banana target: a dense (user-source) Hessian"}
+                   "c3b_dense": "BASELINE.json configs[2] (SoftAbs path) on the banana target: a dense (user-source) Hessian",
+                   "c4_d512": "BASELINE.json configs[3] at twice the dimension (D = 512: the global-memory tier)"}
 
 
 # ---- CPU baseline: the oracle on this box's host cores ------------

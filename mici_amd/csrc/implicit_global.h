@@ -5,10 +5,10 @@
 // matrices.py:1117-1216; DenseRiemannianMetricSystem, systems.py:1690-1734).  Here the matrix lives in HBM: one
 // 1024-thread workgroup per chain (one flat vector element per thread, as implicit_core.h wants it), a DP x DP row-major
 // workspace per chain (DP = D rounded up to 64), and
-//   * the explicit inverse by a BLOCKED symmetric sweep, eight pivots per pass over the matrix (the algebra of
+//   * the explicit inverse by a BLOCKED symmetric sweep, sixteen (D <= 512) or eight pivots per pass over the matrix (the algebra of
 //     implicit_mfma.h's block step, any block size: panel Q = A[K, :], X = Q - E, W = P^-1 X, A -= W^T X, A_KK -= 2 I; after
 //     the last block A = -M^-1, the pivots of the in-block eliminations are the Cholesky pivots squared: positive
-//     definiteness and log det) - D / 8 passes of 2 x 8 DP^2 bytes of HBM traffic;
+//     definiteness and log det) - D / NB passes of 2 x 8 DP^2 bytes of HBM traffic;
 //   * every product (M^-1 v of the held inverse, M(x) v of the refinement solves - the solve-only constructions are
 //     refined from the held inverse as on every other backend, implicit_core.h refine_solve) as a COLUMN walk: thread i
 //     accumulates sum_j A[j][i] v_j, the loads of a wave are 512 consecutive bytes for every j, v_j is an LDS broadcast -
@@ -17,7 +17,7 @@
 //     right-looking factorisation on the same panel machinery, stored transposed so that L z is a column walk too.
 // A step costs one sweep and ~60 products, all HBM-bound: this tier is about REACH (any D the reference takes, up to the
 // 1024 threads of a workgroup), not about the roofline; DESIGN.md section 4.4b has the measured rates.
-// Built-in metrics (rank-one update, diag(1 + q^2)); the leapfrog step and the three auxiliary operations.
+// Built-in metrics (rank-one update, diag(1 + q^2)); the leapfrog and implicit-midpoint steps and the three auxiliary operations.
 #pragma once
 #include "implicit_core.h"
 
@@ -27,22 +27,25 @@ using namespace mmdev;
 using namespace mmimp;
 
 constexpr int NT = 1024;      // threads per chain = largest D
-constexpr int NB = 8;         // pivots per block
 constexpr int DPMAX = 1024;
-// LDS (doubles): the two panels, one natural-order vector, the pivot block and its inverse, two sets of reduction partials
-constexpr int kOffX = 0;                       // [NB][DPMAX]  X = Q - E
-constexpr int kOffW = kOffX + NB * DPMAX;      // [NB][DPMAX]  W = P^-1 X
-constexpr int kOffNat = kOffW + NB * DPMAX;    // [DPMAX + 8]
-constexpr int kOffPb = kOffNat + DPMAX + 8;    // [NB * NB] pivot block, inverted in place
-constexpr int kOffFlag = kOffPb + NB * NB;     // [8] flags / log det of the block
+// Pivots per block of the sweep: the two panels (2 x NB x DP doubles) must fit a CU's LDS - 16 pivots up to DP = 512 (half the
+// passes over the matrix), 8 beyond.  LDS (doubles): one natural-order vector, the pivot block and its inverse, flags, two sets
+// of reduction partials, then the two panels with a pitch of DP.
+constexpr int kPanelDoubles = 2 * 8 * DPMAX;   // = 2 * 16 * 512
+constexpr int kOffNat = 0;                     // [DPMAX + 8]
+constexpr int kOffPb = kOffNat + DPMAX + 8;    // [16 * 16] pivot block, inverted in place
+constexpr int kOffFlag = kOffPb + 256;         // [8] flags / log det of the block
 constexpr int kOffRed = kOffFlag + 8;          // [2][16]
-constexpr int kLdsDoubles = kOffRed + 32;
+constexpr int kOffX = kOffRed + 32;            // [NB][pitch]  X = Q - E
+constexpr int kLdsDoubles = kOffX + kPanelDoubles;
 static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU");
 
 __host__ __device__ constexpr int padded_dim(int dim) { return (dim + 63) & ~63; }
 
-template <int RMETRIC>
+template <int RMETRIC, int NB>
 struct GlobalBackend {
+  static constexpr int PITCH = kPanelDoubles / (2 * NB);  // panel row pitch: 1024 (NB = 8), 512 (NB = 16)
+  static constexpr int kOffW = kOffX + NB * PITCH;
   static constexpr bool kSolveByInverse = true;   // implicit_core.h: a factorised solve = invert + product
   static constexpr bool kUnifiedConstruct = false;
   static constexpr bool kCountersInLds = false;
@@ -140,8 +143,8 @@ struct GlobalBackend {
       double w0[NB], w1[NB];
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
-        w0[k] = Wp[k * DPMAX + i0];
-        w1[k] = Wp[k * DPMAX + i1];
+        w0[k] = Wp[k * PITCH + i0];
+        w1[k] = Wp[k * PITCH + i1];
       }
       for (int b = 0; b < dp / 32; b += 2) {
         const int j0 = tx + 32 * b, j1 = j0 + 32;
@@ -150,7 +153,7 @@ struct GlobalBackend {
         double a00 = p00[0], a01 = p00[32], a10 = p10[0], a11 = p10[32];
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-          const double x0 = Xp[k * DPMAX + j0], x1 = Xp[k * DPMAX + j1];
+          const double x0 = Xp[k * PITCH + j0], x1 = Xp[k * PITCH + j1];
           a00 = __builtin_fma(-w0[k], x0, a00);
           a01 = __builtin_fma(-w0[k], x1, a01);
           a10 = __builtin_fma(-w1[k], x0, a10);
@@ -170,22 +173,34 @@ struct GlobalBackend {
   __device__ __forceinline__ void invert_pivot_block() {
     double* pb = lds + kOffPb;
     double* flag = lds + kOffFlag;
+    constexpr int EPL = NB * NB / 64;  // elements per lane of the first wave
     if (tid < 64) {
-      const int r = tid >> 3, c = tid & 7;
       double bad = 0.0, ld = 0.0;
 #pragma unroll 1
       for (int k = 0; k < NB; ++k) {
-        const double piv = pb[k * NB + k], prk = pb[r * NB + k], pkc = pb[k * NB + c], prc = pb[r * NB + c];
+        const double piv = pb[k * NB + k];
+        double prk[EPL], pkc[EPL], prc[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const int idx = tid + 64 * e, r = idx / NB, c = idx % NB;
+          prk[e] = pb[r * NB + k];
+          pkc[e] = pb[k * NB + c];
+          prc[e] = pb[idx];
+        }
         wave_sync();
         if (!(piv > 0.0) || !(piv < 1.7e308)) bad = 1.0;
         ld += log(piv);
         const double d = 1.0 / piv;
-        double v;
-        if (r == k && c == k) v = d;
-        else if (r == k) v = prc * d;
-        else if (c == k) v = -prc * d;
-        else v = __builtin_fma(-prk * d, pkc, prc);
-        pb[r * NB + c] = v;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const int idx = tid + 64 * e, r = idx / NB, c = idx % NB;
+          double v;
+          if (r == k && c == k) v = d;
+          else if (r == k) v = prc[e] * d;
+          else if (c == k) v = -prc[e] * d;
+          else v = __builtin_fma(-prk[e] * d, pkc[e], prc[e]);
+          pb[idx] = v;
+        }
         wave_sync();
       }
       if (tid == 0) {
@@ -203,6 +218,7 @@ struct GlobalBackend {
     const double* flag = lds + kOffFlag;
     bool ok = true;
     double ld = 0.0;
+    static_assert(NB == 8 || NB == 16, "pivot-block inversion: NB * NB a multiple of 64");
     const int nblk = (dim + NB - 1) / NB;  // (the padding beyond is the identity, decoupled from the rest)
     for (int blk = 0; blk < nblk; ++blk) {
       const int k0 = blk * NB;
@@ -211,7 +227,7 @@ struct GlobalBackend {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
           const double v = A[(size_t)(k0 + k) * dp + tid];
-          Xp[k * DPMAX + tid] = (tid == k0 + k) ? v - 1.0 : v;
+          Xp[k * PITCH + tid] = (tid == k0 + k) ? v - 1.0 : v;
           if (tid >= k0 && tid < k0 + NB) pb[k * NB + (tid - k0)] = v;
         }
       }
@@ -224,13 +240,13 @@ struct GlobalBackend {
       if (tid < dp) {
         double x[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) x[k] = Xp[k * DPMAX + tid];
+        for (int k = 0; k < NB; ++k) x[k] = Xp[k * PITCH + tid];
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
           double s = pb[k * NB] * x[0];
 #pragma unroll
           for (int l = 1; l < NB; ++l) s = __builtin_fma(pb[k * NB + l], x[l], s);
-          Wp[k * DPMAX + tid] = s;
+          Wp[k * PITCH + tid] = s;
         }
       }
       __syncthreads();
@@ -346,7 +362,7 @@ struct GlobalBackend {
         }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-          Xp[k * DPMAX + tid] = tid >= k0 + NB ? y[k] : 0.0;
+          Xp[k * PITCH + tid] = tid >= k0 + NB ? y[k] : 0.0;
           if (tid >= k0) A[(size_t)(k0 + k) * dp + tid] = y[k];  // row k0 + k of A <- L[:, k0 + k]
         }
       }
@@ -358,8 +374,8 @@ struct GlobalBackend {
   }
 };
 
-template <int RMETRIC>
-__device__ __forceinline__ void init_backend(GlobalBackend<RMETRIC>& bk, const ImplicitArgs& A, double* lds) {
+template <int RMETRIC, int NB>
+__device__ __forceinline__ void init_backend(GlobalBackend<RMETRIC, NB>& bk, const ImplicitArgs& A, double* lds) {
   bk.dim = A.dim;
   bk.dp = padded_dim(A.dim);
   bk.tid = threadIdx.x;
@@ -374,9 +390,10 @@ __device__ __forceinline__ void init_backend(GlobalBackend<RMETRIC>& bk, const I
   bk.xpt_ = 0.0;
 }
 
-template <int RMETRIC>
+// MIDPOINT: ImplicitMidpointIntegrator (integrators.py:547-681) on the same backend (a full sweep per function evaluation)
+template <int RMETRIC, int NB, bool MIDPOINT>
 __device__ __forceinline__ void implicit_global_body(const ImplicitArgs& A, double* lds) {
-  GlobalBackend<RMETRIC> bk;
+  GlobalBackend<RMETRIC, NB> bk;
   init_backend(bk, A, lds);
   const int64_t chain = blockIdx.x;
   const int tid = threadIdx.x, dim = A.dim;
@@ -384,7 +401,9 @@ __device__ __forceinline__ void implicit_global_body(const ImplicitArgs& A, doub
   bk.slot(SL_Q) = act ? A.pos[chain * dim + tid] : 0.0;
   bk.slot(SL_P) = act ? A.mom[chain * dim + tid] : 0.0;
   const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
-  const ChainResult r = implicit_leapfrog_chain(bk, t, mmdev::chain_steps(A.chain_steps, chain, A.n_steps), A.opts);
+  const int my_steps = mmdev::chain_steps(A.chain_steps, chain, A.n_steps);
+  const ChainResult r = MIDPOINT ? implicit_midpoint_chain(bk, t, my_steps, A.opts)
+                                 : implicit_leapfrog_chain(bk, t, my_steps, A.opts);
   if (act) {
     A.pos[chain * dim + tid] = bk.slot(SL_Q);
     A.mom[chain * dim + tid] = bk.slot(SL_P);
@@ -397,9 +416,9 @@ __device__ __forceinline__ void implicit_global_body(const ImplicitArgs& A, doub
 }
 
 // OP 0: h = nld + log det M / 2 + p^T M^-1 p / 2;  1: dh_dmom = M^-1 p;  2: sample_momentum: mom <- L z   (systems.py:1375-1402)
-template <int RMETRIC, int OP>
+template <int RMETRIC, int NB, int OP>
 __device__ __forceinline__ void riemann_aux_global_body(const ImplicitArgs& A, double* lds) {
-  GlobalBackend<RMETRIC> bk;
+  GlobalBackend<RMETRIC, NB> bk;
   init_backend(bk, A, lds);
   const int64_t chain = blockIdx.x;
   const int tid = threadIdx.x, dim = A.dim;
@@ -432,15 +451,15 @@ __device__ __forceinline__ void riemann_aux_global_body(const ImplicitArgs& A, d
   }
 }
 
-template <int RMETRIC>
+template <int RMETRIC, int NB, bool MIDPOINT>
 __global__ __launch_bounds__(NT) void implicit_global_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  implicit_global_body<RMETRIC>(A, lds);
+  implicit_global_body<RMETRIC, NB, MIDPOINT>(A, lds);
 }
-template <int RMETRIC, int OP>
+template <int RMETRIC, int NB, int OP>
 __global__ __launch_bounds__(NT) void riemann_aux_global_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  riemann_aux_global_body<RMETRIC, OP>(A, lds);
+  riemann_aux_global_body<RMETRIC, NB, OP>(A, lds);
 }
 
 }  // namespace mmglob

@@ -188,6 +188,7 @@ int mm_launch_implicit_blk16(mm_ctx*, const mm_model*, mm_state*, double, int, c
 // 279 < D <= 1024: the chain's metric in HBM (k_implicit_global.hip)
 int mm_launch_implicit_global(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
 int mm_launch_riemann_aux_global(mm_ctx*, const mm_model*, mm_state*, int, double*, const double*);
+int mm_launch_implicit_midpoint_global(mm_ctx*, const mm_model*, mm_state*, double, int, const mm_fp_opts&, mm_counters*);
 
 // a user metric: the same kernels, compiled at run time around the user's source (mm_rtc.hip)
 static int launch_user_metric(mm_ctx* ctx, const mm_model* m, mm_state* s, int which, double h, int n_steps,
@@ -245,6 +246,7 @@ int mm_launch_implicit_midpoint_riemann(mm_ctx* ctx, const mm_model* m, mm_state
     return launch_user_metric(ctx, m, s, 1, h, n_steps, &opts, d_counters, nullptr, nullptr);
   if (m->rmetric == MM_RMETRIC_SOFTABS || m->rmetric == MM_RMETRIC_SOFTABS_USER)
     return mm_launch_softabs_midpoint(ctx, m, s, h, n_steps, opts, d_counters);
+  if (m->dim > 279) return mm_launch_implicit_midpoint_global(ctx, m, s, h, n_steps, opts, d_counters);
   if (m->dim > 64) return mm_launch_implicit_midpoint_large(ctx, m, s, h, n_steps, opts, d_counters);
   ImplicitArgs a = make_args(m, s);
   a.step_size = h;

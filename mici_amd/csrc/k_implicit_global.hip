@@ -48,8 +48,16 @@ int launch(mm_ctx* ctx, K kernel, const ImplicitArgs& a) {
 
 }  // namespace
 
-int mm_launch_implicit_global(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_fp_opts& opts,
-                              mm_counters* d_counters) {
+// NB = 16 pivots per pass while the two panels fit the LDS (padded dimension <= 512), 8 beyond
+#define MM_GLOB_DISPATCH(KERNEL, ...)                                                              \
+  (padded_dim(m->dim) <= 512                                                                       \
+       ? (m->rmetric == MM_RMETRIC_RANK1 ? launch(ctx, KERNEL<MM_RMETRIC_RANK1, 16, __VA_ARGS__>, a)    \
+                                         : launch(ctx, KERNEL<MM_RMETRIC_DIAGQUAD, 16, __VA_ARGS__>, a)) \
+       : (m->rmetric == MM_RMETRIC_RANK1 ? launch(ctx, KERNEL<MM_RMETRIC_RANK1, 8, __VA_ARGS__>, a)     \
+                                         : launch(ctx, KERNEL<MM_RMETRIC_DIAGQUAD, 8, __VA_ARGS__>, a)))
+
+static int launch_step(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_fp_opts& opts,
+                       mm_counters* d_counters, bool midpoint) {
   ImplicitArgs a;
   const int rc = fill_args(ctx, m, s, a);
   if (rc != MM_OK) return rc;
@@ -58,8 +66,17 @@ int mm_launch_implicit_global(mm_ctx* ctx, const mm_model* m, mm_state* s, doubl
   a.opts = opts;
   a.counters = d_counters;
   a.no_refine = mm_refine_disabled();
-  return m->rmetric == MM_RMETRIC_RANK1 ? launch(ctx, implicit_global_kernel<MM_RMETRIC_RANK1>, a)
-                                        : launch(ctx, implicit_global_kernel<MM_RMETRIC_DIAGQUAD>, a);
+  if (midpoint) return MM_GLOB_DISPATCH(implicit_global_kernel, true);
+  return MM_GLOB_DISPATCH(implicit_global_kernel, false);
+}
+
+int mm_launch_implicit_global(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_fp_opts& opts,
+                              mm_counters* d_counters) {
+  return launch_step(ctx, m, s, h, n_steps, opts, d_counters, false);
+}
+int mm_launch_implicit_midpoint_global(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
+                                       const mm_fp_opts& opts, mm_counters* d_counters) {
+  return launch_step(ctx, m, s, h, n_steps, opts, d_counters, true);
 }
 
 int mm_launch_riemann_aux_global(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* d_out, const double* d_z) {
@@ -68,13 +85,7 @@ int mm_launch_riemann_aux_global(mm_ctx* ctx, const mm_model* m, mm_state* s, in
   if (rc != MM_OK) return rc;
   a.out = d_out;
   a.z = d_z;
-  const bool r1 = m->rmetric == MM_RMETRIC_RANK1;
-  if (op == 0)
-    return r1 ? launch(ctx, riemann_aux_global_kernel<MM_RMETRIC_RANK1, 0>, a)
-              : launch(ctx, riemann_aux_global_kernel<MM_RMETRIC_DIAGQUAD, 0>, a);
-  if (op == 1)
-    return r1 ? launch(ctx, riemann_aux_global_kernel<MM_RMETRIC_RANK1, 1>, a)
-              : launch(ctx, riemann_aux_global_kernel<MM_RMETRIC_DIAGQUAD, 1>, a);
-  return r1 ? launch(ctx, riemann_aux_global_kernel<MM_RMETRIC_RANK1, 2>, a)
-            : launch(ctx, riemann_aux_global_kernel<MM_RMETRIC_DIAGQUAD, 2>, a);
+  if (op == 0) return MM_GLOB_DISPATCH(riemann_aux_global_kernel, 0);
+  if (op == 1) return MM_GLOB_DISPATCH(riemann_aux_global_kernel, 1);
+  return MM_GLOB_DISPATCH(riemann_aux_global_kernel, 2);
 }

@@ -109,3 +109,20 @@ def test_global_tier_reports_the_reference_errors():
     big = systems.DenseRiemannianMetricSystem(models.Banana(1025), models.Rank1Metric(np.eye(1025)))
     with pytest.raises(DeviceError):
         integrators.ImplicitLeapfrogIntegrator(big, 0.01).step_batch(np.zeros((1, 1025)), np.ones((1, 1025)), 1, 1)
+
+
+def test_global_tier_implicit_midpoint_matches_oracle():
+    """ImplicitMidpointIntegrator (integrators.py:547-681) beyond D = 279: the same backend, a full sweep per evaluation."""
+    rng = np.random.default_rng(77)
+    dim, n, h, steps = 300, 2, 0.02, 2
+    system, osys = _pair("rank1", dim, rng)
+    q0 = rng.standard_normal((n, dim))
+    p0 = np.stack([osys.sample_momentum(orc._State(q0[c], None), z) for c, z in enumerate(rng.standard_normal((n, dim)))])
+    integ = integrators.ImplicitMidpointIntegrator(system, h)
+    q, p, st, nd = integ.step_batch(q0, p0, 1, n_steps=steps)
+    assert np.all(st == 0) and np.all(nd == steps)
+    for c in range(n):
+        qo, po, so, no = orc.implicit_midpoint_steps(osys, q0[c], p0[c], h, steps)
+        assert so == 0 and no == steps
+        assert_close(q[c], qo, 1e-9, f"q chain {c}")
+        assert_close(p[c], po, 1e-9, f"p chain {c}")
