@@ -1,6 +1,6 @@
 """The VALU team kernels (64 < D <= 75, 256 < D <= 279) with / without the refinement of the solve-only constructions
 (MICI_AMD_REFINE=0 in a second process): steps/s, executed counts, and the difference of the results."""
-import sys, os, time, subprocess
+import sys, os, time, subprocess, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mici_amd import integrators, models, systems, user_examples  # noqa: E402
@@ -24,11 +24,12 @@ for dim, n, steps in ((70, 512, 10), (270, 256, 5)):
 if out:
     np.savez(out, **res)
 else:
-    np.savez('/tmp/team_refine_on.npz', **res)
+    TMP = tempfile.mkdtemp()  # scratch of this invocation (no fixed /tmp names)
+    np.savez(os.path.join(TMP, 'team_refine_on.npz'), **res)
     env = dict(os.environ, MICI_AMD_REFINE='0')
     print("MICI_AMD_REFINE=0:")
-    subprocess.run([sys.executable, __file__, '/tmp/team_refine_off.npz'], env=env, check=True)
-    a, b = np.load('/tmp/team_refine_on.npz'), np.load('/tmp/team_refine_off.npz')
+    subprocess.run([sys.executable, __file__, os.path.join(TMP, 'team_refine_off.npz')], env=env, check=True)
+    a, b = np.load(os.path.join(TMP, 'team_refine_on.npz')), np.load(os.path.join(TMP, 'team_refine_off.npz'))
     for k in a.files:
         x, y = a[k], b[k]
         print(k, 'max |diff| of states / statuses / counts %.2e' % np.max(np.abs(x - y) / np.maximum(1.0, np.abs(y))))
