@@ -320,10 +320,10 @@ def test_implicit_midpoint_matches_reference_fixture(name):
 
 def test_implicit_midpoint_unsupported_systems_fail_loudly():
     from mici_amd.errors import DeviceError
-    system = systems.DenseRiemannianMetricSystem(models.Banana(280), models.Rank1Metric(np.eye(280)))
+    system = systems.DenseRiemannianMetricSystem(models.Banana(1025), models.Rank1Metric(np.eye(1025)))
     integ = integrators.ImplicitMidpointIntegrator(system, 0.01)
-    with pytest.raises(DeviceError):  # the register-resident metric stops at dim 279
-        integ.step_batch(np.zeros((1, 280)), np.ones((1, 280)), 1, n_steps=1)
+    with pytest.raises(DeviceError):  # one flat element per thread of a workgroup: dim <= 1024 (round 5: the global-memory tier)
+        integ.step_batch(np.zeros((1, 1025)), np.ones((1, 1025)), 1, n_steps=1)
     with pytest.raises(ValueError):
         integrators.ImplicitMidpointIntegrator(
             systems.DenseConstrainedEuclideanMetricSystem(models.Torus(), models.TorusConstr()), 0.1)
