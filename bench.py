@@ -661,6 +661,21 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
                                  refine_pairs_per_chain_step=counters_acc.get("n_refine", 0) / max(done_local, 1.0),
                                  sweeps_per_chain_step=(counters_acc.get("n_factor_full", 0)
                                                         + counters_acc.get("n_factor_solve", 0)) / max(done_local, 1.0))
+    hbm_model = None
+    if w["kind"] == "riemann" and d > 279:
+        # the global-memory tier (csrc/implicit_global.h) is HBM-bound: what its launch has to move, from the work counters -
+        # a sweep is ceil(D / NB) passes reading and writing the DP x DP workspace (+ one write to build it), every product
+        # with the held inverse one read of it (the rank-one base matrix is shared by all chains: L2 / MALL, not counted)
+        dp = float((int(d) + 63) & ~63)
+        nb = 16.0 if dp <= 512 else 8.0
+        sweeps = counters_acc.get("n_factor_full", 0)
+        n_m = counters_acc.get("n_metric", 0)
+        n_b = max(counters_acc.get("n_fp_evals", 0) - n_m, 0)
+        products = counters_acc.get("n_refine", 0) + n_b + 4.0 * done_local  # F r per CG pair, momentum evaluations, A / C
+        bytes_total = 8.0 * dp * dp * (sweeps * (2.0 * np.ceil(d / nb) + 1.0) + products)
+        hbm_model = dict(bytes_per_launch=bytes_total / steps, achieved_GBs=bytes_total / steps / launch_s / 1e9,
+                         frac_of_hbm_peak=bytes_total / steps / launch_s / 1e9 / HBM_PEAK_GBS,
+                         note="modelled traffic of the HBM-resident metric: sweeps x (2 ceil(D / NB) + 1) + products, x 8 DP^2 bytes")
     if w["bound"] == "mfma":
         achieved = w["flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
         roof = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
@@ -699,6 +714,8 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
                                 note="flops the kernels executed; `achieved` / `frac` price the SURVEY 8d algorithmic "
                                      "count (one factorisation / one eigendecomposition per metric construction) as the "
                                      "contract asks")
+    if hbm_model is not None:
+        roof["hbm_model"] = hbm_model
     roof["kernel_ms_per_launch"] = kernel_ms / steps
     roof["host_issue_ms"] = issued * 1e3  # of all passes; large values = the host, not the GPU, paced the region
     roof["attempts"] = attempts  # every timed region of this config (see the re-timing policy above)

@@ -28,7 +28,8 @@ def main():
     names = {"c2i": "c2(i) iso-Gaussian", "c2iv": "c2(iv) + dense metric", "c3": "c3(a) D=64, 1024 chains",
              "c3b": "c3(b) SoftAbs D=64", "c4": "c4 shard D=256, 1024 chains", "c5": "c5 shard, 2048 chains",
              "c3_user": "c3_user D=64: softplus + rank-one metric as user source", "c4_general": "c4_general D=256: the c4 metric as user source",
-             "c3b_dense": "c3b_dense D=64: SoftAbs on the banana, Hessian as user source (h = 0.01)"}
+             "c3b_dense": "c3b_dense D=64: SoftAbs on the banana, Hessian as user source (h = 0.01)",
+             "c4_d512": "c4_d512 D=512, 256 chains: the c4 workload on the global-memory tier"}
     for k, v in rec.get("configs", {}).items():
         if "error" not in v:
             rows.append((k, names.get(k, k), v))
@@ -40,6 +41,9 @@ def main():
         if "fp64_valu" in roof:
             frac += f"; FP64 VALU {roof['fp64_valu']['frac']:.2f}"
         ex = "—"
+        if roof.get("hbm_model"):
+            hm = roof["hbm_model"]
+            ex = f"HBM-bound: modelled {hm['bytes_per_launch'] / 1e9:.0f} GB per launch = {hm['achieved_GBs'] / 1e3:.2f} TB/s ({hm['frac_of_hbm_peak']:.2f} of peak)"
         if roof.get("executed"):
             e = roof["executed"]
             if "refine_pairs_per_chain_step" in e:

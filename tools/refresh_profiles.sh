@@ -28,7 +28,7 @@ if [ "$1" = "collect" ]; then
 fi
 cd $ROOT
 O=$ROOT/gpurun_out/${ROUND}p; rm -rf $O; mkdir -p $O
-KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2iv:leapfrog_mfma_kernel c3:implicit_mfma_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel c3_user:mm_rtc_riem_step c4_general:mm_rtc_riem_step c3b_dense:mm_rtc_softabs_step"
+KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2iv:leapfrog_mfma_kernel c3:implicit_mfma_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel c3_user:mm_rtc_riem_step c4_general:mm_rtc_riem_step c3b_dense:mm_rtc_softabs_step c4_d512:implicit_global_kernel"
 
 if [ -z "$SKIP_TESTS" ]; then
   python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -4 > $O/gpu_tests.txt; cat $O/gpu_tests.txt
@@ -55,7 +55,7 @@ rm -rf $O/prof_default
 
 for pair in $KERNELS; do
   cfg=${pair%%:*}; kern=${pair##*:}
-  case $cfg in c2i|c2iv) continue;; esac
+  case $cfg in c2i|c2iv|c4_d512) continue;; esac
   bash tools/pmc_collect.sh $cfg $kern > $O/sq_$cfg.log 2>&1
   [ -f gpurun_out/pmc_$cfg/pmc_$cfg.json ] && mv gpurun_out/pmc_$cfg/pmc_$cfg.json $O/${cfg}_sq_counters.json && echo "$cfg SQ counters ok"
   rm -rf gpurun_out/pmc_$cfg $O/sq_$cfg.log
