@@ -136,6 +136,7 @@ def _compile_and_link(sources, objdir, lib, extra, headers_time, force, jobs, ve
 
 
 RTC_HEADERS = ["constrained_core.h", "implicit_wave.h", "implicit_mfma.h", "implicit_blk16.h", "implicit_team.h",
+               "implicit_global.h",
                "softabs.h", "user_metric.h", "user_hessian.h", "implicit_core.h", "mm_device.h",
                os.path.join("..", "..", "include", "mici_amd.h")]
 RTC_GEN = os.path.join(CSRC, "rtc_headers_gen.inc")

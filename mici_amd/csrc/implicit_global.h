@@ -7,8 +7,8 @@
 // workspace per chain (DP = D rounded up to 64), and
 //   * the explicit inverse by a BLOCKED symmetric sweep, sixteen (D <= 512) or eight pivots per pass over the matrix (the algebra of
 //     implicit_mfma.h's block step, any block size: panel Q = A[K, :], X = Q - E, W = P^-1 X, A -= W^T X, A_KK -= 2 I; after
-//     the last block A = -M^-1, the pivots of the in-block eliminations are the Cholesky pivots squared: positive
-//     definiteness and log det) - D / NB passes of 2 x 8 DP^2 bytes of HBM traffic;
+//     the last block A = -M^-1 - negated in one more pass - the pivots of the in-block eliminations are the Cholesky pivots
+//     squared: positive definiteness and log det) - D / NB passes of 2 x 8 DP^2 bytes of HBM traffic;
 //   * every product (M^-1 v of the held inverse, M(x) v of the refinement solves - the solve-only constructions are
 //     refined from the held inverse as on every other backend, implicit_core.h refine_solve) as a COLUMN walk: thread i
 //     accumulates sum_j A[j][i] v_j, the loads of a wave are 512 consecutive bytes for every j, v_j is an LDS broadcast -
@@ -17,9 +17,11 @@
 //     right-looking factorisation on the same panel machinery, stored transposed so that L z is a column walk too.
 // A step costs one sweep and ~60 products, all HBM-bound: this tier is about REACH (any D the reference takes, up to the
 // 1024 threads of a workgroup), not about the roofline; DESIGN.md section 4.4b has the measured rates.
-// Built-in metrics (rank-one update, diag(1 + q^2)); the leapfrog and implicit-midpoint steps and the three auxiliary operations.
+// Built-in metrics (rank-one update, diag(1 + q^2)) and - compiled at run time around the user's source, mm_rtc.hip - user
+// metrics; the leapfrog and implicit-midpoint steps and the three auxiliary operations.
 #pragma once
 #include "implicit_core.h"
+#include "user_metric.h"
 
 namespace mmglob {
 
@@ -39,8 +41,29 @@ constexpr int kOffRed = kOffFlag + 8;          // [2][16]
 constexpr int kOffX = kOffRed + 32;            // [NB][pitch]  X = Q - E
 constexpr int kLdsDoubles = kOffX + kPanelDoubles;
 static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU");
+// a user metric (user_metric.h) adds the point of the HELD inverse in natural order and its aux block (they outlive the
+// sweep: the vector-Jacobian products read them); the refinement products' point and aux block sit in the X panel, which is
+// idle whenever a product runs
+constexpr int kUserAux = (mmuser::kAux + 1) & ~1;
+constexpr int kOffUq = kLdsDoubles;            // [DPMAX]
+constexpr int kOffUaq = kOffUq + DPMAX;        // [kUserAux]
+constexpr int kUserLdsDoubles = kOffUaq + kUserAux;
+constexpr int kOffUx = kOffX;                  // [DPMAX]   (aliases the X panel)
+constexpr int kOffUax = kOffX + DPMAX;         // [kUserAux]
+static_assert(kUserLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU (user metric)");
+static_assert(DPMAX + kUserAux <= kPanelDoubles / 2, "the products' point and aux block must fit the X panel");
+template <int RMETRIC>
+__host__ __device__ constexpr int global_lds_doubles() { return RMETRIC == MM_RMETRIC_USER ? kUserLdsDoubles : kLdsDoubles; }
 
 __host__ __device__ constexpr int padded_dim(int dim) { return (dim + 63) & ~63; }
+
+template <class BK>
+struct TeamOfGlobal {  // the workgroup as a team (user_metric.h mm_user_prepare)
+  BK& bk;
+  __device__ __forceinline__ int rank() const { return bk.tid; }
+  __device__ __forceinline__ int size() const { return NT; }
+  __device__ __forceinline__ double sum(double x) const { return bk.reduce(x, false); }
+};
 
 template <int RMETRIC, int NB>
 struct GlobalBackend {
@@ -55,7 +78,7 @@ struct GlobalBackend {
   double inv_dim_;
   double* lds;
   double* A;            // this chain's DP x DP workspace (row-major, leading dimension dp)
-  const double* base;   // rank-one metric: base matrix [dim][dim]
+  const double* base;   // rank-one metric: base matrix [dim][dim]; user metric: its params
   const double* tparams;
   double st_[SL_COUNT_REFINE];  // the step's flat per-thread state: registers (every index is a compile-time constant)
   double rs_[RS_COUNT];
@@ -116,6 +139,12 @@ struct GlobalBackend {
   __device__ __forceinline__ bool build(double x) {
     publish(x);
     const double* nat = lds + kOffNat;
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {  // the point in natural order for the user's hooks, then its aux block
+      lds[kOffUq + tid] = nat[tid];
+      __syncthreads();
+      mmuser::prepare(TeamOfGlobal<GlobalBackend>{*this}, lds + kOffUq, dim, base, lds + kOffUaq);
+      __syncthreads();
+    }
     const int tx = tid & 31, ty = tid >> 5;
     double chk = 0.0;
     for (int i = ty; i < dp; i += 32) {
@@ -124,6 +153,7 @@ struct GlobalBackend {
         double v = (i == j) ? 1.0 : 0.0;
         if (i < dim && j < dim) {
           if constexpr (RMETRIC == MM_RMETRIC_RANK1) v = __builtin_fma(xi, nat[j], base[(size_t)i * dim + j]);
+          else if constexpr (RMETRIC == MM_RMETRIC_USER) v = mmuser::entry(lds + kOffUq, i, j, dim, base, lds + kOffUaq);
           else v = (i == j) ? __builtin_fma(nat[i], nat[i], 1.0) : 0.0;
         }
         A[(size_t)i * dp + j] = v;
@@ -256,6 +286,14 @@ struct GlobalBackend {
       if (tid < NB) A[(size_t)(k0 + tid) * dp + k0 + tid] -= 2.0;
       __syncthreads();
     }
+    // A = -M^-1: one more pass turns the sign (1 / (D / NB) of the sweep's traffic), so that the workspace IS the explicit
+    // inverse - what a user's vector-Jacobian product reads through its dense accessor V(i, j)
+    {
+      const int tx = tid & 31, ty = tid >> 5;
+      for (int i = ty; i < dp; i += 32)
+        for (int j = tx; j < dp; j += 32) A[(size_t)i * dp + j] = -A[(size_t)i * dp + j];
+    }
+    __syncthreads();
     if (logdet) *logdet = ld;
     // a NaN pivot poisons W and with it the whole matrix; a non-positive one is caught by the flag
     return ok && (ld == ld);
@@ -266,16 +304,39 @@ struct GlobalBackend {
     return invert(nullptr) && fin;
   }
 
-  // ---- y = M(x0)^-1 v (the workspace holds -M^-1) -----------------------------------------------------------------------
+  // ---- y = M(x0)^-1 v -------------------------------------------------------------------------------------------------------
   __device__ __forceinline__ double matvec(double v) {
     publish(v);
-    return -column_walk(A, dp, dim);
+    return column_walk(A, dp, dim);
   }
+  __device__ __forceinline__ double diag() const { return tid < dim ? A[(size_t)tid * dp + tid] : 0.0; }
   // ---- refinement products: M(x) v matrix-free ---------------------------------------------------------------------------
-  __device__ __forceinline__ void metric_point(double x) { xpt_ = tid < dim ? x : 0.0; }
+  __device__ __forceinline__ void metric_point(double x) {
+    xpt_ = tid < dim ? x : 0.0;
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {  // the products' point in natural order + its aux block, in the idle X panel
+      __syncthreads();
+      lds[kOffUx + tid] = xpt_;
+      __syncthreads();
+      mmuser::prepare(TeamOfGlobal<GlobalBackend>{*this}, lds + kOffUx, dim, base, lds + kOffUax);
+      __syncthreads();
+    }
+  }
   __device__ __forceinline__ double metric_apply(double v) {
     if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
       return tid < dim ? __builtin_fma(xpt_ * xpt_, v, v) : 0.0;
+    } else if constexpr (RMETRIC == MM_RMETRIC_USER) {
+      // (M(x) v)_i = sum_j M_ij(x) v_j with the user's entries evaluated on the fly (M symmetric: entry (j, i))
+      publish(v);
+      if (tid >= dim) return 0.0;
+      const double* nat = lds + kOffNat;
+      double y0 = 0.0, y1 = 0.0;
+      int j = 0;
+      for (; j + 2 <= dim; j += 2) {
+        y0 = __builtin_fma(mmuser::entry(lds + kOffUx, j, tid, dim, base, lds + kOffUax), nat[j], y0);
+        y1 = __builtin_fma(mmuser::entry(lds + kOffUx, j + 1, tid, dim, base, lds + kOffUax), nat[j + 1], y1);
+      }
+      if (j < dim) y0 = __builtin_fma(mmuser::entry(lds + kOffUx, j, tid, dim, base, lds + kOffUax), nat[j], y0);
+      return y0 + y1;
     } else {
       publish(v);
       const double y = column_walk(base, dim, dim);  // B v (B symmetric)
@@ -284,15 +345,49 @@ struct GlobalBackend {
     }
   }
 
+  // 0.5 * vjp_metric_func(q)(V) of a user metric; q is the point of the held inverse (build() left it at kOffUq with its aux
+  // block).  OUTER: V = -u u^T, else the explicit inverse - handed to the user's team-form hook (MM_USER_VJP_FLAT) or read
+  // through the dense accessor straight from the workspace.
+  template <bool OUTER>
+  __device__ __forceinline__ double user_half_vjp(double u) {
+    double r = 0.0;
+    const double* uq = lds + kOffUq;
+    const double* uaq = lds + kOffUaq;
+    if constexpr (mmuser::kFlatVjp) {
+      if constexpr (OUTER) {
+        mmuser::VjpOpsOuter<GlobalBackend> ops{*this, tid < dim ? u : 0.0};
+        r = mmuser::vjp_flat(ops, uq, tid, dim, base, uaq);
+      } else {
+        mmuser::VjpOpsInv<GlobalBackend> ops{*this};
+        r = mmuser::vjp_flat(ops, uq, tid, dim, base, uaq);
+      }
+    } else {
+#if defined(MM_RTC_BUILD) && defined(MM_RTC_USER_METRIC)
+      if constexpr (OUTER) {
+        publish(u);
+        const MmMat vm{nullptr, lds + kOffNat, 0};
+        r = (tid < dim) ? mmuser::vjp_dense(uq, vm, tid, dim, base, uaq) : 0.0;
+      } else {
+        const MmMat vm{A, nullptr, dp};
+        r = (tid < dim) ? mmuser::vjp_dense(uq, vm, tid, dim, base, uaq) : 0.0;
+      }
+#endif
+    }
+    return tid < dim ? 0.5 * r : 0.0;
+  }
+
   // 0.5 * vjp_metric(M^-1): rank-one metric M^-1 q / D; diag-quad metric q_i (M^-1)_ii
   __device__ __forceinline__ double half_vjp_inv(double q) {
-    if constexpr (RMETRIC == MM_RMETRIC_RANK1) return matvec(q) * inv_dim_;
-    else return tid < dim ? -q * A[(size_t)tid * dp + tid] : 0.0;
+    if constexpr (RMETRIC == MM_RMETRIC_USER) return user_half_vjp<false>(0.0);
+    else if constexpr (RMETRIC == MM_RMETRIC_RANK1) return matvec(q) * inv_dim_;
+    else return tid < dim ? q * A[(size_t)tid * dp + tid] : 0.0;
   }
   // dense metric: grad_quadratic_form_inv(p) = -(M^-1 p)(M^-1 p)^T   (matrices.py:1179-1181)
   __device__ __forceinline__ double dh2_dpos(double p, double q) {
     const double u = matvec(p);
-    if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {
+      return user_half_vjp<true>(u);
+    } else if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
       const double uq = sum1(u * q);
       return -(u * uq) * inv_dim_;
     } else {
@@ -451,6 +546,7 @@ __device__ __forceinline__ void riemann_aux_global_body(const ImplicitArgs& A, d
   }
 }
 
+#ifndef MM_RTC_BUILD  // the in-tree instantiations (a run-time translation unit defines extern "C" wrappers instead)
 template <int RMETRIC, int NB, bool MIDPOINT>
 __global__ __launch_bounds__(NT) void implicit_global_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -461,5 +557,7 @@ __global__ __launch_bounds__(NT) void riemann_aux_global_kernel(ImplicitArgs A) 
   extern __shared__ __attribute__((aligned(16))) double lds[];
   riemann_aux_global_body<RMETRIC, NB, OP>(A, lds);
 }
+
+#endif
 
 }  // namespace mmglob

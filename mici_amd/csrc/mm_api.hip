@@ -263,8 +263,9 @@ int mm_model_create_from_source(mm_ctx* ctx, const mm_model_desc* d, const char*
   MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE || d->rmetric == MM_RMETRIC_USER || d->rmetric == MM_RMETRIC_SOFTABS_USER,
              "mm_model_create_from_source: a user target on a Riemannian system needs a user metric too (the built-in "
              "metrics' kernels are compiled ahead of time around the built-in targets)");
-  MM_REQUIRE(ctx, d->rmetric != MM_RMETRIC_USER || d->dim <= 279,
-             "mm_model_create_from_source: user metrics run on the register-resident dense-Riemannian kernels, dim <= 279");
+  MM_REQUIRE(ctx, d->rmetric != MM_RMETRIC_USER || d->dim <= 1024,
+             "mm_model_create_from_source: user metrics run on the dense-Riemannian kernels, dim <= 1024 (register-resident to "
+             "279, the global-memory tier beyond)");
   MM_REQUIRE(ctx, d->target != MM_TARGET_USER || !d->gaussian_split,
              "mm_model_create_from_source: a user target is a density with respect to the Lebesgue measure (identity / "
              "diagonal / dense fixed metric); the Gaussian-split system classes take built-in targets");

@@ -66,8 +66,8 @@ struct mm_model {
   // leapfrog step), _TEAM (implicit_team.h, 64 < dim <= 279), _BLK16 (implicit_blk16.h, 75 < dim <= 256, leapfrog step).
   // The family with the auxiliary kernels is compiled when the model is created (compile errors surface there), the
   // matrix-core step kernels on their first launch.  fn: step, midpoint, h, dh_dmom, sample_momentum.
-  void* rtc_riem_module[4] = {nullptr, nullptr, nullptr, nullptr};
-  void* rtc_riem_fn[4][5] = {};
+  void* rtc_riem_module[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* rtc_riem_fn[5][5] = {};
   void* rtc_softabs_module = nullptr;  // SoftAbs system with a user Hessian: softabs.h compiled around it
   void* rtc_softabs_fn[3] = {nullptr, nullptr, nullptr};  // leapfrog step, midpoint step, aux (h / dh_dmom / sample_momentum)
   std::mutex rtc_mu;           // serialises the attachment of further kernel families (mm_rtc.hip riem_compile_family)
@@ -150,7 +150,8 @@ int mm_rtc_attach(mm_ctx* ctx, mm_model* m, const char* user_src);
 void mm_rtc_detach(mm_model* m);
 int mm_rtc_attach_constrained(mm_ctx* ctx, mm_model* m, const char* user_src);
 int mm_rtc_attach_riemann(mm_ctx* ctx, mm_model* m, const char* user_src);
-enum { MM_RTC_FAM_WAVE = 0, MM_RTC_FAM_MFMA = 1, MM_RTC_FAM_TEAM = 2, MM_RTC_FAM_BLK16 = 3 };
+enum { MM_RTC_FAM_WAVE = 0, MM_RTC_FAM_MFMA = 1, MM_RTC_FAM_TEAM = 2, MM_RTC_FAM_BLK16 = 3, MM_RTC_FAM_GLOBAL = 4,
+       MM_RTC_FAM_COUNT = 5 };  // _GLOBAL (implicit_global.h, 279 < dim <= 1024: every kernel of the model)
 int mm_rtc_launch_riemann(mm_ctx* ctx, const mm_model* m, mm_state* s, int which, void* implicit_args);
 int mm_rtc_attach_softabs(mm_ctx* ctx, mm_model* m, const char* user_src);
 // which: 0 = leapfrog step, 1 = midpoint step (args: mmsoftabs::SaArgs), 2 = aux (SaArgs, double* out, const double* z)

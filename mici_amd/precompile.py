@@ -21,14 +21,16 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SEED_DIR = os.path.join(HERE, "lib", "rtc_cache")
-FAMILIES = {"wave": 0, "mfma": 1, "team": 2, "blk16": 3, "softabs": 4}
-TEST_DIMS = (4, 5, 6, 8, 16, 20, 27, 32, 40, 48, 64, 70, 100, 128, 130, 200, 256, 270)
+FAMILIES = {"wave": 0, "mfma": 1, "team": 2, "blk16": 3, "softabs": 4, "global": 5}
+TEST_DIMS = (4, 5, 6, 8, 16, 20, 27, 32, 40, 48, 64, 70, 100, 128, 130, 200, 256, 270, 300, 600)
 
 
 def families_of(dim):
     """The kernel families mm_rtc_launch_riemann uses for a user metric of this size."""
     if dim <= 64:
         return ["wave"] + (["mfma"] if dim > 32 else [])
+    if dim > 279:
+        return ["global"]  # the global-memory tier: one family, every kernel of the model
     return ["team"] + (["blk16"] if 75 < dim <= 256 else [])
 
 
@@ -51,7 +53,8 @@ def default_jobs():
     from . import user_examples as ue
     sources = {"RANK1_AS_USER_FLAT": (ue.RANK1_AS_USER_FLAT, TEST_DIMS),
                "SOFTPLUS_RANK1_FAST": (ue.SOFTPLUS_RANK1_FAST, tuple(d for d in TEST_DIMS if d <= 64)),
-               "SOFTPLUS_RANK1_FAST_WIDE": (ue.SOFTPLUS_RANK1_FAST_WIDE, tuple(d for d in TEST_DIMS if d > 64))}
+               # (its aux block is 2 D + 2 doubles of the 560 a source may ask for: D <= 279)
+               "SOFTPLUS_RANK1_FAST_WIDE": (ue.SOFTPLUS_RANK1_FAST_WIDE, tuple(d for d in TEST_DIMS if 64 < d <= 279))}
     tests = os.path.join(HERE, "..", "tests")
     if os.path.exists(os.path.join(tests, "user_sources.py")):  # the plain-form sources of the GPU tests
         sys.path.insert(0, tests)
@@ -77,7 +80,7 @@ def default_jobs():
     if "user_sources" in sys.modules:
         jobs.append(("FUNNEL_HESS", sys.modules["user_sources"].FUNNEL_HESS, 64, "softabs", 0))
     # slowest first: the matrix-core wave kernel, then the wave kernel at its largest tile size
-    order = {"mfma": 0, "softabs": 0, "wave": 1, "blk16": 2, "team": 3}
+    order = {"mfma": 0, "softabs": 0, "wave": 1, "blk16": 2, "team": 3, "global": 3}
     jobs.sort(key=lambda j: (order[j[3]], -j[2]))
     return jobs
 

@@ -126,3 +126,38 @@ def test_global_tier_implicit_midpoint_matches_oracle():
         assert so == 0 and no == steps
         assert_close(q[c], qo, 1e-9, f"q chain {c}")
         assert_close(p[c], po, 1e-9, f"p chain {c}")
+
+
+# ---- user metrics beyond D = 279: the same tier compiled at run time around the user's source (MM_RTC_FAM_GLOBAL) ------------
+@pytest.mark.parametrize("dim,flat", [(300, False), (600, True)])
+def test_user_metric_on_the_global_tier_matches_the_builtin_and_the_oracle(dim, flat):
+    """The built-in rank-one metric written as user source (plain: entry-wise metric + V(i, j) accessor reading the
+    workspace itself; flat: the team-form VJP on the tier's column-walk product) against the built-in kernels of the same
+    tier and the oracle: h / dh_dmom / sample_momentum, leapfrog steps with identical statuses and evaluation counts."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from user_sources import RANK1_AS_USER, RANK1_AS_USER_FLAT
+
+    rng = np.random.default_rng(8000 + dim)
+    n, h, steps = 2, 0.01, 2
+    B = omdl.make_spd(dim, rng)
+    builtin = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(B))
+    user = systems.DenseRiemannianMetricSystem(models.Banana(dim),
+                                               models.UserMetric(dim, RANK1_AS_USER_FLAT if flat else RANK1_AS_USER, B))
+    q0 = rng.standard_normal((n, dim))
+    z = rng.standard_normal((n, dim))
+    p0 = builtin.sample_momentum_batch(q0, z)
+    assert_close(user.sample_momentum_batch(q0, z), p0, 1e-12, "sample_momentum")
+    assert_close(user.h_batch(q0, p0), builtin.h_batch(q0, p0), 1e-12, "h")
+    assert_close(user.dh_dmom_batch(q0, p0), builtin.dh_dmom_batch(q0, p0), 1e-12, "dh_dmom")
+    ib, iu = integrators.ImplicitLeapfrogIntegrator(builtin, h), integrators.ImplicitLeapfrogIntegrator(user, h)
+    qb, pb, sb, nb = ib.step_batch(q0, p0, 1, n_steps=steps)
+    qu, pu, su, nu = iu.step_batch(q0, p0, 1, n_steps=steps)
+    assert np.array_equal(sb, su) and np.array_equal(nb, nu) and np.all(sb == 0)
+    assert ib.last_counters["n_fp_evals"] == iu.last_counters["n_fp_evals"]
+    assert_close(qu, qb, 1e-10, "positions")
+    assert_close(pu, pb, 1e-10, "momenta")
+    osys = orc.RiemannianSystem(omdl.Banana(dim), omdl.Rank1Metric(B))
+    qo, po, so, no = orc.implicit_leapfrog_steps(osys, q0[0], p0[0], h, steps)
+    assert so == 0 and no == steps
+    assert_close(qu[0], qo, 1e-10, "positions vs oracle")
+    assert_close(pu[0], po, 1e-10, "momenta vs oracle")

@@ -55,7 +55,11 @@ def build(g, fast_source=False):
     return system, integ
 
 
-@pytest.mark.parametrize("name", DENSE + [n + ":fast" for n in golden_names("riemann_user")])
+def _has_fast_form(name):  # (the fast form's aux block is 2 D + 2 doubles of the 560 a source may ask for: D <= 279)
+    return load_golden(name)["q0"].shape[1] <= 279
+
+
+@pytest.mark.parametrize("name", DENSE + [n + ":fast" for n in golden_names("riemann_user") if _has_fast_form(n)])
 def test_implicit_leapfrog_matches_reference_fixture(name):
     """Every dense-Riemannian / SoftAbs fixture; the user-metric ones twice: with the plain form of the user's source
     (entry-wise metric, V(i, j) accessor - the dense copy of the inverse) and with its fast form (MM_USER_AUX +

@@ -1161,7 +1161,10 @@ def main():
                                     ("riemann_user_softplus_poly_d70", 70, 3, 0.03, [1, 4], {}),
                                     ("riemann_user_softplus_banana_d100", 100, 3, 0.015, [1, 4], {}),
                                     ("riemann_user_softplus_banana_d256", 256, 3, 0.01, [1, 3], {}),
-                                    ("riemann_user_softplus_poly_d270", 270, 2, 0.01, [1, 2], {})):
+                                    ("riemann_user_softplus_poly_d270", 270, 2, 0.01, [1, 2], {}),
+                                    # round 5: beyond what a CU's registers hold - the global-memory tier compiled around
+                                    # the user's source (plain form: the aux opt-in is 560 doubles at most, 2 D + 2 here)
+                                    ("riemann_user_softplus_banana_d320", 320, 2, 0.01, [1, 2], {})):
         r = case_rng(name)
         tgt = mdl.Banana(d) if "banana" in name else mdl.Poly(d, 1.0, 1.0 / 3.0)
         add_riemann(name, tgt, mdl.SoftPlusRank1Metric(0.5 * r.standard_normal(d)), None, n, hh, cps, r=r, **kw)
