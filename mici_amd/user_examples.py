@@ -49,7 +49,7 @@ __device__ double mm_user_vjp_flat(Ops& V, const double* q, int k, int dim, cons
 }
 """
 
-# the same metric for every size the library takes (dim <= 279: aux sized for it)
+# the same metric for every size its aux block (2 D + 2 of at most 560 doubles) allows: dim <= 279
 SOFTPLUS_RANK1_FAST_WIDE = SOFTPLUS_RANK1_FAST.replace("#define MM_USER_AUX 130", "#define MM_USER_AUX 560")
 
 # Hessian and matrix-Tressian product of the built-in banana target (oracle/models.py Banana.hess / .mtp) for

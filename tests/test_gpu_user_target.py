@@ -235,8 +235,8 @@ def test_user_metric_errors_fail_loudly():
     bad = models.UserMetric(4, RANK1_AS_USER.replace("return s / (double)dim;", "return s / undefined_dim;"), np.eye(4))
     with pytest.raises(DeviceError, match="undefined_dim"):
         systems.DenseRiemannianMetricSystem(models.Banana(4), bad).device_model()
-    with pytest.raises(DeviceError, match="dim <= 279"):
-        systems.DenseRiemannianMetricSystem(models.Banana(300), models.UserMetric(300, RANK1_AS_USER, np.eye(300))).device_model()
+    with pytest.raises(DeviceError, match="dim <= 1024"):  # (round 5: 279 < dim <= 1024 runs on the global-memory tier)
+        systems.DenseRiemannianMetricSystem(models.Banana(1025), models.UserMetric(1025, RANK1_AS_USER, np.eye(1025))).device_model()
     with pytest.raises(DeviceError, match="MM_USER_AUX"):  # the opt-in macros are parsed from the text
         systems.DenseRiemannianMetricSystem(
             models.Banana(4), models.UserMetric(4, "#define MM_USER_AUX 100000\n" + RANK1_AS_USER, np.eye(4))).device_model()
