@@ -301,9 +301,9 @@ int mm_launch_composition_generic(mm_ctx* ctx, const mm_model* m, mm_state* s, d
 }
 
 // ImplicitMidpointIntegrator (integrators.py:547-681) on a Euclidean-metric system, one wave per chain.
-// LDS per wave: 11 vectors of dim doubles.  dh_dmom = M^-1 p, dh_dpos = grad(q).
+// LDS per wave: 13 vectors of dim doubles (dim <= 1024: 104 KB).  dh_dmom = M^-1 p, dh_dpos = grad(q).
 struct MidpointLds {
-  double *q, *p, *xiq, *xip, *x0q, *x0p, *x1q, *x1p, *ptq, *ptp, *tmp;
+  double *q, *p, *xiq, *xip, *x0q, *x0p, *x1q, *x1p, *ptq, *ptp, *tmp, *q1, *p1;
 };
 
 __device__ __forceinline__ double pair_norm_lds(const double* aq, const double* bq, const double* ap,
@@ -388,9 +388,9 @@ __global__ void midpoint_euclid_kernel(EuclidModelView m, double* __restrict__ p
   const int dim = m.dim;
   const int64_t chain = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
   if (chain >= n_chains) return;
-  double* b = lds + (size_t)wave * 11 * dim;
-  const MidpointLds L{b,           b + dim,     b + 2 * dim, b + 3 * dim, b + 4 * dim, b + 5 * dim,
-                      b + 6 * dim, b + 7 * dim, b + 8 * dim, b + 9 * dim, b + 10 * dim};
+  double* b = lds + (size_t)wave * 13 * dim;
+  const MidpointLds L{b,           b + dim,     b + 2 * dim, b + 3 * dim, b + 4 * dim,  b + 5 * dim, b + 6 * dim,
+                      b + 7 * dim, b + 8 * dim, b + 9 * dim, b + 10 * dim, b + 11 * dim, b + 12 * dim};
   for (int i = lane; i < dim; i += 64) {
     L.q[i] = pos[chain * dim + i];
     L.p[i] = mom[chain * dim + i];
@@ -423,21 +423,20 @@ __global__ void midpoint_euclid_kernel(EuclidModelView m, double* __restrict__ p
       }
       wave_sync();
     }
-    // reversibility check: A(-t/2) from the new state must return to (q1, p1), kept in registers across
-    // the solve (dim <= 128: a lane holds at most two elements)
-    double q1r[2], p1r[2];
-    for (int k = 0, i = lane; i < dim; i += 64, ++k) {
-      q1r[k] = L.ptq[i];
-      p1r[k] = L.ptp[i];
+    // reversibility check: A(-t/2) from the new state must return to (q1, p1), kept across the solve in two LDS vectors
+    // of their own (round 5: they were two registers a lane, which is where the dim <= 128 limit came from)
+    for (int i = lane; i < dim; i += 64) {
+      L.q1[i] = L.ptq[i];
+      L.p1[i] = L.ptp[i];
     }
     ++n_solves;
     st = midpoint_solve(m, L, -half, o, lane, &n_evals);
     if (st != MM_ST_OK) break;
     {
       double acc = 0.0;
-      for (int k = 0, i = lane; i < dim; i += 64, ++k) {
-        acc = wave_norm_accum(acc, L.ptq[i] - q1r[k], o.rev_norm);
-        acc = wave_norm_accum(acc, L.ptp[i] - p1r[k], o.rev_norm);
+      for (int i = lane; i < dim; i += 64) {
+        acc = wave_norm_accum(acc, L.ptq[i] - L.q1[i], o.rev_norm);
+        acc = wave_norm_accum(acc, L.ptp[i] - L.p1[i], o.rev_norm);
       }
       const double rev = wave_norm_finish(acc, o.rev_norm);
       if (rev > o.rev_tol) {
@@ -470,14 +469,16 @@ __global__ void midpoint_euclid_kernel(EuclidModelView m, double* __restrict__ p
 
 int mm_launch_implicit_midpoint_euclid(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
                                        const mm_fp_opts& opts, mm_counters* d_counters) {
-  if (s->dim > 128) {
-    mm_set_error(ctx, "mm_implicit_midpoint: Euclidean systems are supported for dim <= 128");
+  if (s->dim > 1024) {
+    mm_set_error(ctx, "mm_implicit_midpoint: Euclidean systems are supported for dim <= 1024 (13 vectors of a chain in LDS)");
     return MM_ERR_UNSUPPORTED;
   }
-  const size_t per_wave = (size_t)11 * s->dim * sizeof(double);
-  int w = (int)(60 * 1024 / per_wave);
+  const size_t per_wave = (size_t)13 * s->dim * sizeof(double);
+  int w = (int)(150 * 1024 / per_wave);
   w = w > 4 ? 4 : (w < 1 ? 1 : w);
   const unsigned blocks = (unsigned)((s->n + w - 1) / w);
+  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(midpoint_euclid_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(w * per_wave)));
   hipLaunchKernelGGL(midpoint_euclid_kernel, dim3(blocks), dim3(64 * w), w * per_wave, ctx->stream, view_of(m),
                      s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done, s->n, h,
                      n_steps, opts,

@@ -241,7 +241,7 @@ class ImplicitLeapfrogIntegrator(Integrator):
 class ImplicitMidpointIntegrator(ImplicitLeapfrogIntegrator):
     """Implicit midpoint integrator for general Hamiltonians (reference integrators.py:547-681): implicit
     Euler half step (fixed point in the concatenated (pos, mom) vector), explicit Euler half step,
-    reversibility check.  Device support: Euclidean-metric systems (dim <= 128), dense-Riemannian systems
+    reversibility check.  Device support: Euclidean-metric systems (dim <= 1024), dense-Riemannian systems
     (dim <= 1024: built-in metrics beyond 279) and SoftAbs systems (dim <= 64).  Same constructor arguments and solver options as :py:class:`ImplicitLeapfrogIntegrator`."""
 
     _needs = None  # euclid or riemann

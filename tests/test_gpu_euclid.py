@@ -264,3 +264,31 @@ def test_nonfinite_state_propagates_like_reference():
     q, p, st, nd = integ.step_batch(q0, p0, 1, n_steps=2)
     assert np.all(np.isfinite(q[0])) and np.all(np.isfinite(q[2]))
     assert np.isnan(q[1]).any()
+
+
+@pytest.mark.parametrize("dim,metric_kind", [(129, "dense"), (300, "diag"), (1024, "identity")])
+def test_implicit_midpoint_on_euclidean_systems_beyond_128_dimensions(dim, metric_kind):
+    """ImplicitMidpointIntegrator (integrators.py:547-681) on Euclidean systems: rounds 1-4 stopped at D = 128 (the check's
+    reference state lived in two registers a lane); round 5 keeps it in LDS: D <= 1024."""
+    from mici_amd.errors import DeviceError
+    rng = np.random.default_rng(4000 + dim)
+    n, h, steps = 5, 0.05, 3
+    metric = {"identity": None, "diag": np.exp(0.2 * rng.standard_normal(dim)), "dense": omdl.make_spd(dim, rng)}[metric_kind]
+    mk = {"identity": omdl.METRIC_IDENTITY, "diag": omdl.METRIC_DIAG, "dense": omdl.METRIC_DENSE}[metric_kind]
+    system = systems.EuclideanMetricSystem(models.Poly(dim, 1.0, 0.3), metric=metric)
+    osys = orc.EuclidSystem(omdl.Poly(dim, 1.0, 0.3), mk, metric)
+    q0 = 0.5 * rng.standard_normal((n, dim))
+    p0 = np.stack([osys.msqrt(z) for z in rng.standard_normal((n, dim))])
+    dirs = np.where(np.arange(n) % 2 == 0, 1, -1).astype(np.int8)
+    integ = integrators.ImplicitMidpointIntegrator(system, h)
+    q, p, st, nd = integ.step_batch(q0, p0, dirs, n_steps=steps)
+    for c in range(n):
+        qo, po, so, no = orc.implicit_midpoint_steps(osys, q0[c], p0[c], dirs[c] * h, steps)
+        assert so == st[c] and no == nd[c]
+        assert_close(q[c], qo, 1e-10, f"q chain {c}")
+        assert_close(p[c], po, 1e-10, f"p chain {c}")
+    assert np.all(st == 0)
+    if dim == 1024:
+        big = systems.EuclideanMetricSystem(models.Poly(1025, 1.0, 0.3))
+        with pytest.raises(DeviceError):
+            integrators.ImplicitMidpointIntegrator(big, h).step_batch(np.zeros((1, 1025)), np.ones((1, 1025)), 1, 1)
