@@ -478,13 +478,8 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         // sequential code below carries on from exactly there.
         double uC, uA;
         bool okC, okA;
-#ifdef MM_DUAL_SEQ_EXPERIMENT
-        okC = refine_solve(bk, bk.slot(SL_XQ), bk.slot(SL_PW), bk.slot(SL_UC), &uC, r);
-        okA = refine_solve(bk, bk.slot(SL_PTA), bk.slot(SL_PW), bk.slot(SL_UA), &uA, r);
-#else
         refine_solve2(bk, bk.slot(SL_XQ), bk.slot(SL_PTA), bk.slot(SL_PW), bk.slot(SL_UC), bk.slot(SL_UA), &uC, &uA,
                       &okC, &okA, r);
-#endif
         if (!okA) dual_ok = false;  // the adjoint solve's evaluation is repeated (and factorised) when its turn comes
         if (!okC) {
           skip_refine = true;       // the check's refinement failed: factorise at its point (below), as refine_solve would

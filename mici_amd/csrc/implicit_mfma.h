@@ -42,9 +42,6 @@ using namespace mmimp;
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-#ifndef MM_MFMA_KERNEL_ATTR
-#define MM_MFMA_KERNEL_ATTR
-#endif
 // Lock-step position solves (implicit_core.h refine_solve2) on this kernel: OFF.  Measured in round 5
 // (profiles/r05_ab_c3_dual.txt): the state machine and the paired products are correct (tests/test_gpu_implicit.py green with
 // them on), but with 128 registers of inverse row live across the solve most forms of the paired products make the
@@ -310,70 +307,7 @@ struct MfmaBackend {
     return y[0];
   }
 
-  // two products against the same row: the row's 64 registers are read once per pair of multiply-adds' issue slots, the
-  // two accumulator sets are independent chains (each system's sum in the order row_dot() forms it: bit-equal results).
-  // The broadcast reads of the two vectors are software-pipelined by hand, kDualGroup columns-of-four at a time with the
-  // next group's loads issued before the current group's arithmetic: left alone the scheduler hoists all 32 16-byte
-  // loads (256 registers) above the arithmetic and the allocator parks the inverse's row in accumulation registers - two
-  // v_accvgpr_read per multiply-add (1.7 k of them in the kernel against 120).
-#ifndef MM_DUAL_GROUP
-#define MM_DUAL_GROUP 2
-#endif
-#ifndef MM_DUAL_ROWDOT2
-#define MM_DUAL_ROWDOT2 0
-#endif
-  static constexpr int kDualGroup = MM_DUAL_GROUP;  // 16 / kDualGroup groups
-  __device__ __forceinline__ void row_dot2(const double (&row)[64], double v0, double v1, double* y0, double* y1) {
-    w.nat[lane] = (lane < dim) ? v0 : 0.0;
-    w.aux[lane] = (lane < dim) ? v1 : 0.0;
-    wave_sync();
-    double ya[kAcc], yb[kAcc];
-#pragma unroll
-    for (int a = 0; a < kAcc; ++a) ya[a] = yb[a] = 0.0;
-    d4 va[2][kDualGroup], vb[2][kDualGroup];
-#pragma unroll
-    for (int i = 0; i < kDualGroup; ++i) {
-      va[0][i] = *reinterpret_cast<const d4*>(w.nat + 4 * i);
-      vb[0][i] = *reinterpret_cast<const d4*>(w.aux + 4 * i);
-    }
-#pragma unroll
-    for (int gk = 0; gk < 16 / kDualGroup; ++gk) {
-      const int cur = gk & 1, nxt = cur ^ 1;
-      if (gk + 1 < 16 / kDualGroup) {
-#pragma unroll
-        for (int i = 0; i < kDualGroup; ++i) {
-          va[nxt][i] = *reinterpret_cast<const d4*>(w.nat + 4 * ((gk + 1) * kDualGroup + i));
-          vb[nxt][i] = *reinterpret_cast<const d4*>(w.aux + 4 * ((gk + 1) * kDualGroup + i));
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < kDualGroup; ++i) {
-        const int k = gk * kDualGroup + i;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ya[(4 * k + e) % kAcc] = __builtin_fma(row[4 * k + e], va[cur][i][e], ya[(4 * k + e) % kAcc]);
-          yb[(4 * k + e) % kAcc] = __builtin_fma(row[4 * k + e], vb[cur][i][e], yb[(4 * k + e) % kAcc]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    wave_sync();
-#pragma unroll
-    for (int h = kAcc / 2; h >= 1; h >>= 1)
-#pragma unroll
-      for (int a = 0; a < h; ++a) {
-        ya[a] += ya[a + h];
-        yb[a] += yb[a + h];
-      }
-    *y0 = ya[0];
-    *y1 = yb[0];
-  }
   __device__ __forceinline__ void matvec2(double v0, double v1, double* y0, double* y1) {
-#if MM_DUAL_ROWDOT2
-    double a, b;
-    row_dot2(fr_, v0, v1, &a, &b);
-#else
     // the held inverse's row is in registers: nothing to share between the two products but the exchange points, and a
     // row product already runs kAcc independent chains.  ONE inlined product in a two-trip loop, operands and results
     // through LDS: a second inlined copy is what tips the allocator (see refine_solve2)
@@ -387,7 +321,6 @@ struct MfmaBackend {
       if (sidx == 0) a = y;
       else b = y;
     }
-#endif
     *y0 = lane < dim ? a : 0.0;
     *y1 = lane < dim ? b : 0.0;
   }
@@ -939,7 +872,7 @@ __device__ __forceinline__ void implicit_mfma_body(const ImplicitArgs& A, double
 
 #ifndef MM_RTC_BUILD  // the in-tree instantiations (a run-time translation unit defines an extern "C" wrapper instead)
 template <int RMETRIC, bool PROFILE = false>
-__global__ __launch_bounds__(64 * kWaves) MM_MFMA_KERNEL_ATTR void implicit_mfma_kernel(ImplicitArgs A) {
+__global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   implicit_mfma_body<RMETRIC, PROFILE>(A, lds);
 }
