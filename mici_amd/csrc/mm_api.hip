@@ -328,8 +328,8 @@ static int model_create(mm_ctx* ctx, const mm_model_desc* d, const char* user_sr
   }
   if (d->constr == MM_CONSTR_USER) {
     n_constr = d->n_constr;
-    MM_REQUIRE(ctx, n_constr >= 1 && n_constr <= 8 && n_constr < D && D <= 64,
-               "mm_model_create_from_source: a user constraint needs 1 <= n_constr <= 8, n_constr < dim <= 64");
+    MM_REQUIRE(ctx, n_constr >= 1 && n_constr <= 8 && n_constr < D && D <= 256,
+               "mm_model_create_from_source: a user constraint needs 1 <= n_constr <= 8, n_constr < dim <= 256");
   }
   MM_REQUIRE(ctx, d->constr != MM_CONSTR_SPHERE || D >= 2, "sphere constraint needs dim >= 2");
   if (d->constr == MM_CONSTR_SPHERE_PLANE) {

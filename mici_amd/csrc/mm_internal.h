@@ -61,6 +61,7 @@ struct mm_model {
   void* rtc_con_step = nullptr;
   void* rtc_con_project = nullptr;
   void* rtc_con_logdet = nullptr;
+  int rtc_con_waves = 0;  // 0: the lane-per-chain core (256 chains a workgroup); else the wave-per-chain kernels, chains a workgroup
   // dense-Riemannian system with a user metric (user_metric.h): the backends compiled around the user's source, one
   // module per kernel family - MM_RTC_FAM_WAVE (implicit_wave.h, dim <= 64), _MFMA (implicit_mfma.h, 32 < dim <= 64,
   // leapfrog step), _TEAM (implicit_team.h, 64 < dim <= 279), _BLK16 (implicit_blk16.h, 75 < dim <= 256, leapfrog step).

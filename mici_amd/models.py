@@ -199,7 +199,9 @@ class UserConstraint(Constraint):
         // out[i] = sum_{k,j} m[k*dim + j] d2 c_k / dq_j dq_i
 
     It is compiled for gfx950 (hipRTC) together with the library's constrained-leapfrog core when the system's
-    device model is created; ``params`` are handed to all three.  1 <= n_constr <= 8, n_constr < dim <= 64."""
+    device model is created; ``params`` are handed to all three.  1 <= n_constr <= 8, n_constr < dim <= 256 (up to 64
+    on the lane-per-chain core, beyond on the wave-per-chain kernels: ``jacob_constr`` / ``mhp_constr`` are then run by one
+    lane of the chain's wave on arrays in LDS)."""
 
     def __init__(self, n_constr, source, params=()):
         super().__init__(CONSTR_USER, params)

@@ -1182,6 +1182,12 @@ def main():
     add_user_constrained("constrained_user_ellipsoid_ambient_d6", 6, 5, mdl.METRIC_DIAG, 0.08, [1, 5, 20], variant="ambient")
     add_user_constrained("constrained_user_ellipsoid_d12_quasi", 12, 4, mdl.METRIC_IDENTITY, 0.1, [1, 5, 20], proj_solver=1)
     add_user_constrained("constrained_user_ellipsoid_d5_fail_bigstep", 5, 6, mdl.METRIC_IDENTITY, 1.5, [1, 3])
+    # round 5: user constraints beyond D = 64 - the wave-per-chain kernels compiled around the user's source
+    add_user_constrained("constrained_user_ellipsoid_dense_d100", 100, 3, mdl.METRIC_DENSE, 0.02, [1, 5, 20])
+    add_user_constrained("constrained_user_ellipsoid_ambient_d128_quasi", 128, 3, mdl.METRIC_DIAG, 0.02, [1, 5],
+                         variant="ambient", proj_solver=1)
+    add_user_constrained("constrained_user_ellipsoid_gauss_d72", 72, 3, mdl.METRIC_DENSE, 0.03, [1, 5, 20], variant="gaussian")
+    add_user_constrained("constrained_user_ellipsoid_d256_linesearch", 256, 2, mdl.METRIC_IDENTITY, 0.02, [1, 4], proj_solver=2)
 
     wide_linear("constrained_c4_linear_dense_d32", 32, 4, 4, mdl.METRIC_DENSE, 0.1, [1, 5, 20])
     wide_linear("constrained_c8_linear_diag_d64_quasi", 64, 8, 3, mdl.METRIC_DIAG, 0.1, [1, 5], proj_solver=1)
