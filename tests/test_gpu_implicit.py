@@ -70,9 +70,10 @@ def test_implicit_leapfrog_matches_reference_fixture(name):
     system, integ = build(g, fast_source=variant == "fast")
     n = g["q0"].shape[0]
     s_max = int(g["checkpoints"].max())
-    # SoftAbs: Jacobi eigh vs LAPACK differs at 1e-13 and the divided differences of
-    # grad_quadratic_form_inv amplify that; the oracle itself is pinned to the reference at 1e-9 there
-    tol = 2e-9 if name.startswith("softabs") else 1e-10
+    # 1e-10 with identical iteration counts - the contract's tolerance - for every fixture, SoftAbs included (rounds 1-4
+    # allowed those 2e-9: Jacobi eigh against LAPACK, amplified by the divided differences of grad_quadratic_form_inv; the
+    # measured worst over the SoftAbs fixtures is 1.9e-13, tools/dbg/r05_softabs_fixture_err.py - VERDICT r04 weak #8)
+    tol = 1e-10
     for k, s in enumerate(int(s) for s in g["checkpoints"]):
         q, p, status, n_done = integ.step_batch(g["q0"], g["p0"], g["dir"], n_steps=s)
         assert_close(q, g["q_out"][k], tol, f"{name} q@{s}")
@@ -393,8 +394,10 @@ def test_softabs_long_trajectory_matches_oracle():
     for c in range(n):
         qo, po, so, no = orc.implicit_leapfrog_steps(osys, q0[c], p0[c], h, steps)
         assert so == status[c] and no == n_done[c]
-        assert_close(q[c], qo, 1e-7, f"q chain {c}")
-        assert_close(p[c], po, 1e-7, f"p chain {c}")
+        # (1e-7 until round 4; the measured error after 40 steps is 2.8e-14, tools/dbg/r05_softabs_err.py, and the oracle's own
+        # response to a 1e-13 change of the inputs 6e-13: nothing here needs more than the contract's 1e-10)
+        assert_close(q[c], qo, 1e-10, f"q chain {c}")
+        assert_close(p[c], po, 1e-10, f"p chain {c}")
     h0, h1 = system.h_batch(q0, p0), system.h_batch(q, p)
     assert np.all(np.abs(h1 - h0) < 5e-2)
 
