@@ -78,8 +78,8 @@ def _compare(pool, config, n, w, sel, dirs, steps, q, p, status, n_done, qo, po,
 @pytest.mark.parametrize("config,tol,max_sensitive", [
     ("c3", 1e-10, 16),
     ("c3_user", 1e-10, 16),
-    ("c3b", 2e-9, 32),
-    ("c3b_dense", 2e-9, 32),
+    ("c3b", 1e-10, 32),  # (measured on the box: 99 % 2.6e-13, worst 2.1e-12)
+    ("c3b_dense", 2e-9, 32),  # (71 of 1024 chains stop early in both; measured 99 % 2.4e-11, worst 3.7e-10)
 ])
 def test_every_chain_of_the_d64_shards_at_bench_length(pool, config, tol, max_sensitive):
     n = 1024
