@@ -318,8 +318,8 @@ int mm_implicit_leapfrog(mm_ctx* ctx, const mm_model* model, mm_state* state, do
 
 /* ImplicitMidpointIntegrator.step x n_steps (integrators.py:547-681): implicit Euler half step solved as a
  * fixed point in the concatenated (pos, mom) vector (solvers.py:47-154), explicit Euler half step, and the
- * reversibility check.  Euclidean-metric systems (dim <= 128) and dense-Riemannian systems (dim <= 64);
- * opts / counters as for mm_implicit_leapfrog. */
+ * reversibility check.  Euclidean-metric systems and dense-Riemannian systems (dim <= 1024), SoftAbs systems
+ * (dim <= 256; user Hessians 64); opts / counters as for mm_implicit_leapfrog. */
 int mm_implicit_midpoint(mm_ctx* ctx, const mm_model* model, mm_state* state, double step_size,
                          int32_t n_steps, const mm_fp_opts* opts, mm_counters* counters);
 

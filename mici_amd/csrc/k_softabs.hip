@@ -26,14 +26,14 @@ SaArgs make_args(const mm_model* m, mm_state* s) {
 }
 
 int check_dim(mm_ctx* ctx, const mm_model* m) {
-  if (m->dim > 128) {
-    mm_set_error(ctx, "SoftAbs kernels support dim <= 128 (one workgroup per chain; matrices in LDS up to 64)");
+  if (m->dim > 256) {
+    mm_set_error(ctx, "SoftAbs kernels support dim <= 256 (one workgroup per chain; matrices in LDS up to 64)");
     return MM_ERR_UNSUPPORTED;
   }
   return MM_OK;
 }
 
-// the global-memory matrices of the NP = 128 kernels: grown on demand, kept with the state
+// the global-memory matrices of the NP = 128 / 256 kernels: grown on demand, kept with the state
 int ensure_work(mm_ctx* ctx, mm_state* s, size_t doubles_per_chain, double** out) {
   const size_t need = (size_t)s->n * doubles_per_chain * sizeof(double);
   if (need > s->work_bytes) {
@@ -57,7 +57,7 @@ bool eig_cache_disabled() {
   return off;
 }
 
-// the bases the chains of a state carry between launches (NP = 64), zeroed - "no basis yet" - when (re)allocated
+// the bases the chains of a state carry between launches, zeroed - "no basis yet" - when (re)allocated
 int ensure_eig(mm_ctx* ctx, mm_state* s, size_t doubles_per_chain, double** out) {
   const size_t need = (size_t)s->n * doubles_per_chain * sizeof(double);
   if (need != s->eig_bytes) {
@@ -80,7 +80,7 @@ int launch_softabs_np(mm_ctx* ctx, mm_state* s, SaArgs S) {
     const int rc = ensure_work(ctx, s, B::kWorkDoubles, &S.work);
     if (rc != MM_OK) return rc;
   }
-  if (NP == 64 && !S.a.no_refine && !eig_cache_disabled()) {
+  if (!S.a.no_refine && !eig_cache_disabled()) {
     const int rc = ensure_eig(ctx, s, B::kEigDoubles, &S.eig);
     if (rc != MM_OK) return rc;
   }
@@ -99,7 +99,7 @@ int launch_aux_np(mm_ctx* ctx, mm_state* s, SaArgs S, double* d_out, const doubl
     const int rc = ensure_work(ctx, s, B::kWorkDoubles, &S.work);
     if (rc != MM_OK) return rc;
   }
-  if (NP == 64 && !S.a.no_refine && !eig_cache_disabled()) {
+  if (!S.a.no_refine && !eig_cache_disabled()) {
     const int rc = ensure_eig(ctx, s, B::kEigDoubles, &S.eig);
     if (rc != MM_OK) return rc;
   }
@@ -134,7 +134,8 @@ static int launch_softabs(mm_ctx* ctx, const mm_model* m, mm_state* s, double h,
   S.a.opts = opts;
   S.a.counters = d_counters;
   if (m->rmetric == MM_RMETRIC_SOFTABS_USER) return launch_user(ctx, m, s, S, MIDPOINT ? 1 : 0, nullptr, nullptr);
-  return m->dim <= 64 ? launch_softabs_np<MIDPOINT, 64>(ctx, s, S) : launch_softabs_np<MIDPOINT, 128>(ctx, s, S);
+  if (m->dim <= 64) return launch_softabs_np<MIDPOINT, 64>(ctx, s, S);
+  return m->dim <= 128 ? launch_softabs_np<MIDPOINT, 128>(ctx, s, S) : launch_softabs_np<MIDPOINT, 256>(ctx, s, S);
 }
 
 int mm_launch_softabs_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
@@ -155,5 +156,6 @@ int mm_launch_softabs_aux(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, d
   SaArgs S = make_args(m, s);
   S.op = op;
   if (m->rmetric == MM_RMETRIC_SOFTABS_USER) return launch_user(ctx, m, s, S, 2, d_out, d_z);
-  return m->dim <= 64 ? launch_aux_np<64>(ctx, s, S, d_out, d_z) : launch_aux_np<128>(ctx, s, S, d_out, d_z);
+  if (m->dim <= 64) return launch_aux_np<64>(ctx, s, S, d_out, d_z);
+  return m->dim <= 128 ? launch_aux_np<128>(ctx, s, S, d_out, d_z) : launch_aux_np<256>(ctx, s, S, d_out, d_z);
 }

@@ -55,6 +55,12 @@ struct SaLds {
   double* prof; // [24] -DMM_SOFTABS_PROF: cycle stamps inside the Jacobi rounds [0..4], phases of the step [8..15]
   double* stash;  // [SL_COUNT][65]
   float* snap;    // NP = 64: [2][NP][NP] the step's two basis snapshots, in single precision (see basis_save)
+  double* S;      // NP > 64 (global workspace): X^T A X of a refinement pass
+  double* R;      // NP > 64: X^T X of a refinement pass
+  double* X2;     // NP > 64: the refined basis of a pass (swapped with V at its end)
+  double* Vt;     // NP > 64: V^T, kept beside V (row-major, LD): the operand a product walks ALONG the rows of V is read
+  double* X2t;    //          down the columns of V^T instead - 16 lanes on one 128-byte run, not on 16 cache lines
+  double* snapg;  // NP > 64: [2][NP][NP] the step's two basis snapshots (double precision: the workspace has the room)
 };
 constexpr int kRingDoubles = 15 * 8 * 2;  // (c, s) of the 15 local rounds x 8 pair slots of a block round
 
@@ -112,7 +118,11 @@ __device__ __forceinline__ double wave_fmax(double v) {
 // sum over the RP (16 or 8) consecutive lanes that share an output element (one DPP row, or half of one)
 template <int RP>
 __device__ __forceinline__ double rp_sum_n(double v) {
-  static_assert(RP == 16 || RP == 8, "rp_sum reduces a DPP row or half of one");
+  static_assert(RP == 16 || RP == 8 || RP == 4, "rp_sum reduces a DPP row, half of one or a quad");
+  if constexpr (RP == 4) {
+    v += dpp_move<kDppXor1>(v);
+    return v + dpp_move<kDppXor2>(v);
+  }
   v = group8_sum(v);
   return RP == 16 ? v + dpp_move<kDppMirror>(v) : v;
 }
@@ -150,12 +160,15 @@ __device__ __forceinline__ double rp_sum_n(double v) {
 
 // NP: the padded size of the problem, 64 (matrices in LDS: the BASELINE c3(b) configuration) or 128 (the same code
 // with the three matrices in a per-chain global-memory workspace, for 64 < D <= 128: coverage of the reference's
-// sizes, an order of magnitude slower per flop)
+// sizes, an order of magnitude slower per flop) or 256 (round 5, 128 < D <= 256: the same workspace layout, but a column
+// pair no longer fits the registers of eight lanes at four waves per SIMD - the Jacobi rounds stream the columns from
+// memory, block_round_mem(), and every wave rotates G and then V of its block pair: there are 16 block pairs a round and
+// 16 waves.  1.6 MB of matrices per chain: with more chains in flight than fit the L2 the sweeps are HBM-bound)
 // USERH: the Hessian and the matrix-Tressian product are the user's (user_hessian.h) - nothing is known about their
 // structure: dense Hessian, G = A X as a matrix-core product, grad_log_abs_det / grad_quadratic_form_inv formed in full
 template <int NP, bool USERH = false>
 struct SoftAbsBackendT {
-  static_assert(NP == 64 || NP == 128, "SoftAbs backend sizes");
+  static_assert(NP == 64 || NP == 128 || NP == 256, "SoftAbs backend sizes");
   static_assert(!USERH || NP == 64, "user Hessians run on the LDS-resident backend (dim <= 64)");
   static constexpr int BS = NP / TPD;     // output block side per thread in the NP x NP products
   static constexpr int RP = NT / NP;      // threads per output element of the row-wise reductions
@@ -167,7 +180,12 @@ struct SoftAbsBackendT {
   static constexpr int GW = NBLK / 2;     // waves rotating G (as many again replay on V)
   static constexpr int ROWS = NP / 8;     // rows per lane of a column pair
   static constexpr bool kMatricesInLds = NP == 64;
-  static constexpr int kLdsVectors = 8 * NP + 2 * GW * kRingDoubles + 32 + 8 + 24 + SL_COUNT * (NP + 1);
+  // NP = 256: GW = 16 is every wave of the team - each rotates G and then V of its block pair (one ring set, no replay)
+  static constexpr bool kBothRoles = 2 * GW > NT / 64;
+  static constexpr int kRingSets = kBothRoles ? 1 : 2;
+  static constexpr int kLdsVectors = 8 * NP + kRingSets * GW * kRingDoubles + 32 + 8 + 24 + SL_COUNT * (NP + 1);
+  static_assert(kRingSets * GW * kRingDoubles >= (kMatricesInLds ? 1024 + 2 * NP : 2048 + NP),
+                "vt_times() / mtp_lds() / dh2_dpos() scratch inside the ring");
   // NP = 64: the two single-precision snapshots of the eigenbasis (2 x 16 KB) start in the ring's tail - the ring is the
   // last of the vectors, its first kRingScratch doubles are scratch of the phases outside the Jacobi sweeps (dh2_dpos,
   // vt_times, refine_eigh), the rest is only touched by the sweeps, which invalidate the snapshots - and run on behind it
@@ -177,7 +195,7 @@ struct SoftAbsBackendT {
   static_assert(NP != 64 || (2 * GW * kRingDoubles >= kRingScratch && kSnapExtra > 0), "ring / snapshot layout");
   static constexpr int kLdsDoubles = kLdsVectors + (kMatricesInLds ? MAT + 2 * MATJ : 0) + kSnapExtra;
   static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU");
-  static constexpr int kWorkDoubles = kMatricesInLds ? 0 : MAT + 2 * MATJ;  // per chain, global memory
+  static constexpr int kWorkDoubles = kMatricesInLds ? 0 : 6 * MAT + 2 * MATJ + 2 * NP * NP;  // per chain, global memory (H, W, V; S, R, X2, Vt, X2t; snapshots)
   __device__ static __forceinline__ double rp_sum(double v) { return rp_sum_n<RP>(v); }
 
   static constexpr bool kSolveByInverse = true;   // implicit_core.h: ONE inlined copy of the construction (eigh: refinement + sweeps) instead of two
@@ -256,7 +274,10 @@ struct SoftAbsBackendT {
     for (int el = tid; el < NP * NP; el += NT) {
       const int i = el / NP, j = el % NP;
       w.H[i * LD + j] = 0.0;
-      if (warm == 0 && i < dim && j < dim) w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+      if (warm == 0 && i < dim && j < dim) {
+        w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+        if constexpr (!kMatricesInLds) w.Vt[i * LD + j] = (i == j) ? 1.0 : 0.0;
+      }
     }
     __syncthreads();
     if constexpr (USERH) {  // the user's hess_neg_log_dens, entry by entry (four per thread), zero beyond dim
@@ -272,9 +293,11 @@ struct SoftAbsBackendT {
         if (i < dim) w.H[i * LD + i] = tp[0] + 3.0 * tp[1] * x[i] * x[i];
       } else {  // funnel
         const double e = exp(-x[0]);
-        const int k = (int)tid & 63;  // every wave forms the whole S = sum w x^2 (NP = 128: two terms a lane)
+        const int k = (int)tid & 63;  // every wave forms the whole S = sum w x^2 (NP / 64 terms a lane)
         double acc = (k >= 1 && k < dim) ? tp[k - 1] * x[k] * x[k] : 0.0;
-        if (NP > 64 && k + 64 < dim) acc += tp[k + 63] * x[k + 64] * x[k + 64];
+#pragma unroll
+        for (int t = 64; t < NP; t += 64)
+          if (k + t < dim) acc += tp[k + t - 1] * x[k + t] * x[k + t];
         const double s = wave_sum(acc);
         if (i == 0) {
           w.H[0] = 1.0 / 9.0 + 0.5 * e * s;
@@ -319,26 +342,33 @@ struct SoftAbsBackendT {
       return;
     }
     const int ti = tid % TPD, bj = (tid / TPD) * BS;
-    double acc[BS][BS];
+    constexpr int BA = BS < 4 ? BS : 4;  // rows of the thread's block done at a time (NP = 256: 8 x 8 accumulators would spill)
+#pragma unroll 1
+    for (int a0 = 0; a0 < BS; a0 += BA) {
+      double acc[BA][BS];
 #pragma unroll
-    for (int a = 0; a < BS; ++a)
+      for (int a = 0; a < BA; ++a)
 #pragma unroll
-      for (int b = 0; b < BS; ++b) acc[a][b] = 0.0;
-    for (int k = 0; k < dim; ++k) {
-      double hv[BS], vv[BS];
+        for (int b = 0; b < BS; ++b) acc[a][b] = 0.0;
+      for (int k = 0; k < dim; ++k) {
+        double hv[BA], vv[BS];
 #pragma unroll
-      for (int a = 0; a < BS; ++a) hv[a] = w.H[(ti + TPD * a) * LD + k];
+        for (int a = 0; a < BA; ++a) hv[a] = w.H[(ti + TPD * (a0 + a)) * LD + k];
 #pragma unroll
-      for (int b = 0; b < BS; ++b) vv[b] = w.V[k * LD + bj + b];
+        for (int b = 0; b < BS; ++b) vv[b] = w.V[k * LD + bj + b];
 #pragma unroll
-      for (int a = 0; a < BS; ++a)
+        for (int a = 0; a < BA; ++a)
 #pragma unroll
-        for (int b = 0; b < BS; ++b) acc[a][b] = __builtin_fma(hv[a], vv[b], acc[a][b]);
+          for (int b = 0; b < BS; ++b) acc[a][b] = __builtin_fma(hv[a], vv[b], acc[a][b]);
+      }
+#pragma unroll
+      for (int a = 0; a < BA; ++a)
+#pragma unroll
+        for (int b = 0; b < BS; ++b) {
+          const int row = ti + TPD * (a0 + a);
+          w.W[(bj + b) * LDJ + row] = (row < dim && bj + b < dim) ? acc[a][b] : 0.0;
+        }
     }
-#pragma unroll
-    for (int a = 0; a < BS; ++a)
-#pragma unroll
-      for (int b = 0; b < BS; ++b) w.W[(bj + b) * LDJ + ti + TPD * a] = (ti + TPD * a < dim && bj + b < dim) ? acc[a][b] : 0.0;
     __syncthreads();
   }
 
@@ -531,6 +561,77 @@ struct SoftAbsBackendT {
     store_col(M, oa, xa);
     store_col(M, col_offset(bb * 8 + ((slot + 7) & 7), sub), xb);
     wave_sync();
+  }
+
+  // NP = 256: the same block round with the columns left in memory.  A column pair is 2 x 32 doubles per lane of its
+  // eight - the whole register budget of a wave at four per SIMD - so a pair's rotation is two passes over its columns:
+  // the three dot products, then the rotation.  Same pairing, same order and the same ring layout as block_round().
+  template <bool GROLE>
+  __device__ static __forceinline__ void pair_mem(char* M, int ca, int cb, int sub, double* cs, bool writer, double& big,
+                                                  double& bad) {
+    char* const pa = M + col_offset(ca, sub);
+    char* const pb = M + col_offset(cb, sub);
+    double c = 1.0, s = 0.0;
+    if (GROLE) {
+      double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < ROWS; ++j) {
+        const double a = *reinterpret_cast<const double*>(pa + 64 * j), b = *reinterpret_cast<const double*>(pb + 64 * j);
+        al = __builtin_fma(a, a, al);
+        be = __builtin_fma(b, b, be);
+        ga = __builtin_fma(a, b, ga);
+      }
+      al = group8_sum(al);
+      be = group8_sum(be);
+      ga = group8_sum(ga);
+      const double ab = al * be, gg = ga * ga;
+      if (!(ab <= 1.7e308) || !(gg <= 1.7e308)) bad = 1.0;  // NaN or overflow
+      if (gg > 1e-14 * ab) big = 1.0;
+      if (gg > 1e-30 * ab) {  // (rotate_pair(): the same angle, the same normalised (c, s))
+        const double d = be - al;
+        const double ri = rsqrt_newton(__builtin_fma(d, d, 4.0 * gg));
+        const double c2 = __builtin_fma(0.5 * fabs(d), ri, 0.5);
+        const double rc = rsqrt_newton(c2);
+        c = c2 * rc;
+        s = ga * ri * rc;
+        if (d < 0.0) s = -s;
+        if (!(fabs(s) <= 1.0)) bad = 1.0;
+      }
+      if (writer) { cs[0] = c; cs[1] = s; }
+    } else {
+      c = cs[0];
+      s = cs[1];
+    }
+    if (s != 0.0) {
+#pragma unroll 8
+      for (int j = 0; j < ROWS; ++j) {
+        const double a = *reinterpret_cast<const double*>(pa + 64 * j), b = *reinterpret_cast<const double*>(pb + 64 * j);
+        *reinterpret_cast<double*>(pa + 64 * j) = __builtin_fma(c, a, -(s * b));
+        *reinterpret_cast<double*>(pb + 64 * j) = __builtin_fma(s, a, c * b);
+      }
+    }
+    wave_sync();
+  }
+  template <bool GROLE>
+  __device__ static __forceinline__ void block_round_mem(char* M, double* ring, int ba, int bb, bool intra, int slot,
+                                                         int sub, double& big, double& bad) {
+    const bool writer = sub == 0;
+    if (intra) {
+      const int u = slot & 3, base = (slot < 4 ? ba : bb) * 8;
+#pragma unroll 1
+      for (int r = 0; r < 7; ++r) {
+        int p, q;
+        if (u == 0) { p = 7; q = r; }
+        else {
+          p = r + u; if (p >= 7) p -= 7;
+          q = r - u; if (q < 0) q += 7;
+        }
+        pair_mem<GROLE>(M, base + p, base + q, sub, ring + (r * 8 + slot) * 2, writer, big, bad);
+      }
+    }
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k)
+      pair_mem<GROLE>(M, ba * 8 + slot, bb * 8 + ((slot + k) & 7), sub, ring + ((7 + k) * 8 + slot) * 2, writer, big, bad);
   }
 
   // the two blocks of block-pair slot w in round R of the tournament of the NBLK blocks
@@ -730,6 +831,138 @@ struct SoftAbsBackendT {
     return -1;
   }
 
+  // ---- the same refinement with the matrices in the global workspace (NP = 128, 256; round 5) --------------------------
+  // Until round 5 every decomposition beyond D = 64 was warm-started Jacobi sweeps - 2.6 a decomposition, each
+  // NP (NP - 1) / 2 column rotations over memory: 33 ms a decomposition at D = 256.  The refinement pass is three
+  // products on the matrix cores - the (NP / 16)^2 tiles dealt to the 16 waves, operands straight from memory (every
+  // lane's operand loads are 128-byte runs of a row or a column; the L1 / L2 hold a chain's matrices) - around the same
+  // element-wise E.  S, R and the refined basis have buffers of their own in the workspace: a wave owns several tiles, so
+  // nothing is updated in place; the basis pointers are swapped at the end of a pass.  Same thresholds, same return
+  // values as refine_eigh().
+  // Four adjacent 16 x 16 tiles of a product at once: acc[u] += sum_k a[k] (x scale[k]) b[k][16 u + .], both operands walked
+  // down columns (leading dimension LD), lane group g taking the terms k = (NP / 4) g + kk.  One a-operand load feeds four
+  // matrix-core instructions with independent accumulators; with single tiles a wave had two loads per instruction in
+  // flight eight at a time, and a pass was load-latency bound (1.6 ms a decomposition at D = 256).
+  template <bool SCALED>
+  __device__ static __forceinline__ void quad_tiles(const double* a0, const double* b0, const double* scale, d4 (&acc)[4]) {
+#pragma unroll 4
+    for (int kk = 0; kk < NP / 4; ++kk) {
+      double a = a0[kk * LD];
+      if constexpr (SCALED) a *= scale[kk];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0[kk * LD + 16 * u], acc[u], 0, 0, 0);
+    }
+  }
+
+  __device__ __forceinline__ int refine_eigh_global() {
+    constexpr int T = NP / 16, KQ = NP / 4, QR = T / 4, NQ = T * QR, NW = NT / 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    double* const Gm = w.W;  // G = A X, then E (row-major, leading dimension LD)
+    double prev = 0.0;
+    ++unchecked;
+    for (int pass = 0; pass < kRefineMaxPass; ++pass) {
+      double* const X = w.V;
+      // G = A X from the structure of the built-in Hessians (diagonal; arrowhead), as refine_eigh()
+      for (int el = tid; el < NP * NP; el += NT) {
+        const int i = el / NP, c = el % NP;
+        if (i == 0 && target != MM_TARGET_POLY) continue;
+        const double d = w.H[i * LD + i] * X[i * LD + c];
+        Gm[i * LD + c] = target == MM_TARGET_POLY ? d : __builtin_fma(w.H[i * LD], X[c], d);
+      }
+      if (target != MM_TARGET_POLY) {  // row 0: G_0c = sum_k A_0k X_kc, RP lanes a column
+        const int c = tid / RP, part = tid % RP;
+        double a = 0.0;
+        for (int k = part; k < dim; k += RP) a = __builtin_fma(w.H[k], X[k * LD + c], a);
+        a = rp_sum(a);
+        if (part == 0) Gm[c] = a;
+      }
+      ++n_products;
+      __syncthreads();
+      const bool with_xx = pass > 0 || unchecked >= kOrthoPeriod;
+      if (with_xx) {
+        unchecked = 0;
+        ++n_products;
+      }
+#pragma unroll 1
+      for (int qd = wave; qd < NQ; qd += NW) {  // tiles of S = X^T G and of X^T X, four in a row at a time
+        const int I = qd / QR, J0 = 4 * (qd % QR);
+        const double* const xi = X + KQ * g * LD + 16 * I + j;
+        {
+          d4 sv[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+          quad_tiles<false>(xi, Gm + KQ * g * LD + 16 * J0 + j, nullptr, sv);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w.S[(16 * I + 4 * r + g) * LD + 16 * (J0 + u) + j] = sv[u][r];
+        }
+        d4 xx[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        if (with_xx) quad_tiles<false>(xi, X + KQ * g * LD + 16 * J0 + j, nullptr, xx);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + 4 * r + g, c = 16 * (J0 + u) + j;
+            w.R[i * LD + c] = with_xx ? xx[u][r] : (i == c ? 1.0 : 0.0);
+          }
+      }
+      __syncthreads();
+      if (tid < NP) w.lam[tid] = tid < dim ? fdiv(w.S[tid * LD + tid], w.R[tid * LD + tid]) : 1.0;
+      const double norm_a = block_reduce4(tid < dim ? fabs(w.lam[tid]) : 0.0, 1, w.red, red_flip);  // (w.lam visible behind its barrier)
+      const double inf = __longlong_as_double(0x7ff0000000000000LL);
+      double max_e = (norm_a == norm_a) ? 0.0 : inf, near_s = 0.0;
+      for (int el = tid; el < NP * NP; el += NT) {
+        const int i = el / NP, c = el % NP;
+        const double sij = w.S[i * LD + c];
+        const double li = w.lam[i], lj = w.lam[c];
+        const double rij = (i == c ? 1.0 : 0.0) - w.R[i * LD + c];
+        const double gap = lj - li;
+        const bool far = fabs(gap) > kRefineGuard * norm_a;
+        double e = (i != c && far) ? fdiv(__builtin_fma(lj, rij, sij), gap) : 0.5 * rij;
+        if (i >= dim || c >= dim) e = 0.0;
+        else if (i != c && !far) near_s = __builtin_fmax(near_s, fabs(sij));
+        max_e = __builtin_fmax(max_e, (e == e && sij == sij) ? fabs(e) : inf);
+        Gm[i * LD + c] = e;
+      }
+      max_e = block_reduce4(max_e, 1, w.red, red_flip);
+      near_s = block_reduce4(near_s, 1, w.red, red_flip);
+      if (pass == 0 && !(max_e < kRefineStart)) return 0;           // (NaN included) w.V untouched
+      const bool last = max_e < kRefineDone;
+      if (!last && pass > 0 && !(max_e < prev)) return -1;
+      prev = max_e;
+      ++n_products;
+#pragma unroll 1
+      for (int qd = wave; qd < NQ; qd += NW) {  // X' = X + X E into the other basis buffer (and its transpose)
+        const int I = qd / QR, J0 = 4 * (qd % QR);
+        d4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[u][r] = X[(16 * I + 4 * r + g) * LD + 16 * (J0 + u) + j];
+        // X[16 I + j][k] = X^T[k][16 I + j]: the a operand down a column of the transpose
+        quad_tiles<false>(w.Vt + KQ * g * LD + 16 * I + j, Gm + KQ * g * LD + 16 * J0 + j, nullptr, acc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            w.X2[(16 * I + 4 * r + g) * LD + 16 * (J0 + u) + j] = acc[u][r];
+            w.X2t[(16 * (J0 + u) + j) * LD + 16 * I + 4 * r + g] = acc[u][r];
+          }
+      }
+      __syncthreads();
+      {
+        double* const old = w.V;
+        w.V = w.X2;
+        w.X2 = old;
+        double* const oldt = w.Vt;
+        w.Vt = w.X2t;
+        w.X2t = oldt;
+      }
+      if (last) return (near_s <= kRefineSplit * norm_a) ? 1 : 0;  // 0: a split cluster the passes cannot resolve
+    }
+    return -1;
+  }
+
   __device__ __forceinline__ bool eigh() {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -740,9 +973,11 @@ struct SoftAbsBackendT {
     bool converged = false;
     ++n_eigh;
     SA_PROF_BEGIN();
-    if constexpr (kMatricesInLds) {
+    {
       if (refine_on && warm > 0) {
-        const int rc = refine_eigh();
+        int rc;
+        if constexpr (kMatricesInLds) rc = refine_eigh();
+        else rc = refine_eigh_global();
         SA_PROF_END2(11);
         if (rc > 0) {
           ++n_refined;
@@ -756,13 +991,16 @@ struct SoftAbsBackendT {
           warm = 0;
           for (int el = tid; el < NP * dim; el += NT) {
             const int i = el / NP, j = el % NP;
-            if (j < dim) w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+            if (j < dim) {
+              w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+              if constexpr (!kMatricesInLds) w.Vt[i * LD + j] = (i == j) ? 1.0 : 0.0;
+            }
           }
           __syncthreads();
         }
       }
     }
-    snap_ok &= ~2;  // the sweeps use the whole (c, s) ring: snapshot 1, which starts in its tail, is gone
+    if constexpr (kMatricesInLds) snap_ok &= ~2;  // the sweeps use the whole (c, s) ring: snapshot 1, which starts in its tail, is gone
     times_basis();
     char* const G = reinterpret_cast<char*>(w.W);
     char* const Vt = reinterpret_cast<char*>(w.H);
@@ -772,7 +1010,7 @@ struct SoftAbsBackendT {
     }
     __syncthreads();
     SA_PROF_END(5);
-    if (role == 0) __builtin_amdgcn_s_setprio(3);  // the G waves' dependent chain is the critical path of a round
+    if (!kBothRoles && role == 0) __builtin_amdgcn_s_setprio(3);  // the G waves' dependent chain is the critical path of a round
     int done = 0;  // block rounds the G role has done; the V role is one behind
     int Rprev = 0;
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
@@ -780,7 +1018,12 @@ struct SoftAbsBackendT {
       ++n_sweeps;
       for (int R = 0; R < NBLK - 1; ++R) {
         int ba, bb;
-        if (role == 0) {
+        if constexpr (kBothRoles) {
+          double b0 = 0.0, b1 = 0.0;
+          blocks_of(wave, R, ba, bb);
+          block_round_mem<true>(G, w.ring + wave * kRingDoubles, ba, bb, R == 0, slot, sub, big, bad);
+          block_round_mem<false>(Vt, w.ring + wave * kRingDoubles, ba, bb, R == 0, slot, sub, b0, b1);
+        } else if (role == 0) {
           blocks_of(bw, R, ba, bb);
 #ifdef MM_SOFTABS_PROF
           double* const prof = tid_raw == 0 ? w.prof : nullptr;
@@ -812,12 +1055,14 @@ struct SoftAbsBackendT {
       }
     }
     __builtin_amdgcn_s_setprio(0);
-    if (role == 1) {
-      int ba, bb;
-      double b0 = 0.0, b1 = 0.0;
-      blocks_of(bw, Rprev, ba, bb);
-      block_round<false>(Vt, w.ring + (((done - 1) & 1) * GW + bw) * kRingDoubles, ba, bb, Rprev == 0, slot, sub, b0, b1,
-                         nullptr);
+    if constexpr (!kBothRoles) {
+      if (role == 1) {
+        int ba, bb;
+        double b0 = 0.0, b1 = 0.0;
+        blocks_of(bw, Rprev, ba, bb);
+        block_round<false>(Vt, w.ring + (((done - 1) & 1) * GW + bw) * kRingDoubles, ba, bb, Rprev == 0, slot, sub, b0,
+                           b1, nullptr);
+      }
     }
     __syncthreads();
     {  // lam_i = g_i . v_i, RP lanes per column
@@ -831,7 +1076,10 @@ struct SoftAbsBackendT {
     }
     for (int e = tid; e < NP * NP; e += NT) {
       const int i = e % NP, j = e / NP;
-      if (i < dim && j < dim) w.V[i * LD + j] = w.H[j * LDJ + i];
+      if (i < dim && j < dim) {
+        w.V[i * LD + j] = w.H[j * LDJ + i];
+        if constexpr (!kMatricesInLds) w.Vt[j * LD + i] = w.H[j * LDJ + i];
+      }
     }
     __syncthreads();
     warm = converged ? (warm + 1) % kWarmPeriod : 0;
@@ -839,7 +1087,7 @@ struct SoftAbsBackendT {
     return converged;
   }
 
-  // ---- the eigenvector basis carried from one launch to the next (NP = 64) ------------------------------------------
+  // ---- the eigenvector basis carried from one launch to the next (NP = 64; round 5: every NP) -------------------------
   // A launch used to start every chain from the identity - seven or eight Jacobi sweeps, half a leapfrog step's time
   // - which is what an HMC transition with a short trajectory, its two Hamiltonian evaluations and its momentum draw
   // pay four times over.  The state keeps each chain's last basis in global memory (32 KB a chain, flagged valid only
@@ -849,7 +1097,7 @@ struct SoftAbsBackendT {
   // snapshots there as well: 128 KB written and read back per chain and step, 10 GB of HBM traffic per c3(b) launch.)
   static constexpr int kEigFlag = NP * NP;
   static constexpr int kEigDoubles = NP * NP + 8;
-  static constexpr bool kBasisSlots = NP == 64;  // implicit_core.h: basis_save / basis_restore
+  static constexpr bool kBasisSlots = true;  // implicit_core.h: basis_save / basis_restore
   double* eig_mem = nullptr;  // this chain's kEigDoubles, or nullptr (refinement or carry-over switched off)
   __device__ __forceinline__ void copy_basis_out(double* dst) {
     for (int el = tid; el < NP * NP; el += NT) {
@@ -860,7 +1108,10 @@ struct SoftAbsBackendT {
   __device__ __forceinline__ void copy_basis_in(const double* src) {
     for (int el = tid; el < NP * NP; el += NT) {
       const int i = el / NP, j = el % NP;
-      if (i < dim && j < dim) w.V[i * LD + j] = src[el];
+      if (i < dim && j < dim) {
+        w.V[i * LD + j] = src[el];
+        if constexpr (!kMatricesInLds) w.Vt[j * LD + i] = src[el];
+      }
     }
   }
   __device__ __forceinline__ void load_basis() {
@@ -885,6 +1136,12 @@ struct SoftAbsBackendT {
   __device__ __forceinline__ float* snap_slot(const int slot) const { return w.snap + (slot == 0 ? NP * NP : 0); }
   __device__ __forceinline__ void basis_save(const int slot) {
     if (!refine_on || warm == 0) return;
+    if constexpr (!kMatricesInLds) {  // round 5: the workspace tiers keep theirs in the workspace, in double precision
+      double* const dst = w.snapg + slot * NP * NP;
+      for (int el = tid; el < NP * NP; el += NT) dst[el] = w.V[(el / NP) * LD + el % NP];
+      snap_ok |= 1 << slot;
+      return;
+    }
     float* const dst = snap_slot(slot);
     for (int el = tid; el < NP * NP; el += NT) dst[el] = (float)w.V[(el / NP) * LD + el % NP];  // (zero beyond dim)
     snap_ok |= 1 << slot;
@@ -892,6 +1149,17 @@ struct SoftAbsBackendT {
   __device__ __forceinline__ void basis_restore(const int slot) {
     if (!(snap_ok & (1 << slot))) return;
     __syncthreads();  // every reader of the current basis is done
+    if constexpr (!kMatricesInLds) {
+      const double* const src = w.snapg + slot * NP * NP;
+      for (int el = tid; el < NP * NP; el += NT) {
+        const double v = src[el];
+        w.V[(el / NP) * LD + el % NP] = v;
+        w.Vt[(el % NP) * LD + el / NP] = v;
+      }
+      __syncthreads();
+      warm = warm > 0 ? warm : 1;
+      return;  // (an exact copy of a converged basis: nothing to re-measure)
+    }
     const float* const src = snap_slot(slot);
     for (int el = tid; el < NP * NP; el += NT) w.V[(el / NP) * LD + el % NP] = (double)src[el];
     __syncthreads();
@@ -1245,40 +1513,71 @@ struct SoftAbsBackendT {
       }
       __syncthreads();
     } else {
-    // J into w.H, A into w.W
-    for (int el = tid; el < NP * dim; el += NT) {
-      const int k = el / NP, l = el % NP;
-      if (l >= dim) continue;
-      double num = w.lamt[k] - w.lamt[l], den = w.lam[k] - w.lam[l];
-      if (k == l) { num += w.gsa[k]; den = 1.0; }
-      w.H[k * LD + l] = num / den;                 // 0/0 -> NaN for degenerate spectra, as the reference
-      w.W[k * LD + l] = w.V[k * LD + l] * w.v1[l]; // A[i=k][k=l]
-    }
-    __syncthreads();
-    // md_i = sum_kl A_ik J_kl A_il ; m0_i = sum_kl A_0k J_kl A_il : thread i accumulates over l of
-    // (sum_k A_ik J_kl) A_il.  Work split: RP threads per row i (each every RP-th l).
-    double md = 0.0, m0 = 0.0;
-    {
-      const int i = tid / RP, part = tid % RP;
-      if (i < dim) {
-        for (int l = part; l < dim; l += RP) {
-          double bi = 0.0, b0 = 0.0;
-          for (int k = 0; k < dim; ++k) {
-            const double jkl = w.H[k * LD + l];
-            bi = __builtin_fma(w.W[i * LD + k], jkl, bi);
-            b0 = __builtin_fma(w.W[k], jkl, b0);  // A[0][k]
+      // the same product with the matrices in the workspace (round 5; until then a VALU triple loop whose lanes walked
+      // along rows of A sixteen cache lines at a time: 6 ms a call at D = 256, half of a step).  J is built once per
+      // decomposition into w.H; tile (I, Jt) of B = A J on the matrix cores, A_ik = V_ik e_k read down the columns of V^T;
+      // a wave owns one row of tiles (NP = 128: half of one), so md_i = sum_l B_il A_il accumulates in its registers.
+      if (!j_valid) {
+        for (int el = tid; el < NP * NP; el += NT) {
+          const int k = el / NP, l = el % NP;
+          double jv = 0.0;
+          if (k < dim && l < dim) {
+            double num = w.lamt[k] - w.lamt[l], den = w.lam[k] - w.lam[l];
+            if (k == l) { num += w.gsa[k]; den = 1.0; }
+            jv = num / den;                          // 0/0 -> NaN for degenerate spectra, as the reference
           }
-          const double ail = w.W[i * LD + l];
-          md = __builtin_fma(bi, ail, md);
-          m0 = __builtin_fma(b0, ail, m0);
+          w.H[k * LD + l] = jv;
+        }
+        j_valid = true;
+        __syncthreads();
+      }
+      constexpr int T = NP / 16, KQ = NP / 4, QR = T / 4, NW = NT / 64, WPR = NW / T;  // WPR waves share a row of tiles
+      static_assert(NW % T == 0 && WPR >= 1 && WPR <= 4 && QR % WPR == 0, "tile rows of the dh2_dpos product");
+      double* const part = w.ring;           // [WPR][NP] partial md (the ring is idle outside eigh())
+      double* const brow0 = w.ring + 2048;   // [NP] row 0 of B
+      {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int g = lane >> 4, j = lane & 15;
+        const int I = wave % T, jt0 = wave / T;
+        const double* const vt_i = w.Vt + KQ * g * LD + 16 * I + j;
+        const double* const ek = w.v1 + KQ * g;
+        double mdacc[4] = {0.0, 0.0, 0.0, 0.0};
+        ++n_products;
+#pragma unroll 1
+        for (int qd = jt0; qd < QR; qd += WPR) {  // four tiles of the row at a time (quad_tiles)
+          const int J0 = 4 * qd;
+          d4 acc[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+          quad_tiles<true>(vt_i, w.H + KQ * g * LD + 16 * J0 + j, ek, acc);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int l = 16 * (J0 + u) + j;
+            const double el = w.v1[l];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              mdacc[r] += rp_sum_n<16>(acc[u][r] * (w.V[(16 * I + 4 * r + g) * LD + l] * el));
+            if (I == 0 && g == 0) brow0[l] = acc[u][0];
+          }
+        }
+        if (j == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[jt0 * NP + 16 * I + 4 * r + g] = mdacc[r];
         }
       }
-      md = rp_sum(md);
-      m0 = rp_sum(m0);
       __syncthreads();
-      if (part == 0 && i < NP) { w.v2[i] = -md; w.nat[i] = -m0; }
+      {
+        const int i = tid / RP, pt = tid % RP;
+        double m0 = 0.0;
+        for (int l = pt; l < dim; l += RP) m0 = __builtin_fma(brow0[l], w.V[i * LD + l] * w.v1[l], m0);
+        m0 = rp_sum(m0);
+        if (pt == 0) {
+          double md = part[i];
+#pragma unroll
+          for (int a = 1; a < WPR; ++a) md += part[a * NP + i];
+          w.v2[i] = -md;
+          w.nat[i] = -m0;
+        }
+      }
       __syncthreads();
-    }
     }
     SA_LAP(19);
     const double out = 0.5 * mtp_lds();
@@ -1328,6 +1627,24 @@ __device__ __forceinline__ void init_backend(SoftAbsBackendT<NP, USERH>& bk, con
     bk.w.H = work;
     bk.w.W = work + B::MATJ;
     bk.w.V = work + 2 * B::MATJ;
+    bk.w.S = bk.w.V + B::MAT;
+    bk.w.R = bk.w.S + B::MAT;
+    bk.w.X2 = bk.w.R + B::MAT;
+    bk.w.Vt = bk.w.X2 + B::MAT;
+    bk.w.X2t = bk.w.Vt + B::MAT;
+    bk.w.snapg = bk.w.X2t + B::MAT;
+    // the basis buffers are read whole by the matrix-core products: zero beyond dim, once (nothing writes there later)
+    if (A.dim < NP) {
+      for (int el = threadIdx.x; el < NP * NP; el += NT) {
+        const int i = el / NP, j = el % NP;
+        if (i >= A.dim || j >= A.dim) {
+          bk.w.V[i * B::LD + j] = 0.0;
+          bk.w.X2[i * B::LD + j] = 0.0;
+          bk.w.Vt[i * B::LD + j] = 0.0;
+          bk.w.X2t[i * B::LD + j] = 0.0;
+        }
+      }
+    }
   }
   bk.w.lam = p; p += NP;
   bk.w.lamt = p; p += NP;
@@ -1361,7 +1678,7 @@ struct SaArgs {
   ImplicitArgs a;
   const double* coeff;  // device pointer to softabs_coeff
   double* work;         // NP = 128: [n_chains][kWorkDoubles] matrices of the chains
-  double* eig;          // NP = 64: [n_chains][kEigDoubles] bases carried between launches, or nullptr
+  double* eig;          // [n_chains][kEigDoubles] bases carried between launches, or nullptr
   int op;
 };
 
@@ -1380,7 +1697,7 @@ __device__ __forceinline__ void softabs_leapfrog_body(const SaArgs& S, double* l
   const double t = uniform_f64(signed_step(A.dir, A.step_scale, chain, A.step_size));
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;
-  bk.eig_mem = (NP == 64 && S.eig && bk.refine_on) ? S.eig + chain * SoftAbsBackendT<NP, USERH>::kEigDoubles : nullptr;
+  bk.eig_mem = (S.eig && bk.refine_on) ? S.eig + chain * SoftAbsBackendT<NP, USERH>::kEigDoubles : nullptr;
   bk.load_basis();
   __syncthreads();
   const int my_steps = mmdev::chain_steps(A.chain_steps, chain, A.n_steps);
@@ -1438,7 +1755,7 @@ __device__ __forceinline__ void softabs_aux_body(const SaArgs& S, double* out, c
   const double q = act ? A.pos[chain * dim + tid] : 0.0;
   const double p = act ? A.mom[chain * dim + tid] : 0.0;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
-  bk.eig_mem = (NP == 64 && S.eig && bk.refine_on) ? S.eig + chain * SoftAbsBackendT<NP, USERH>::kEigDoubles : nullptr;
+  bk.eig_mem = (S.eig && bk.refine_on) ? S.eig + chain * SoftAbsBackendT<NP, USERH>::kEigDoubles : nullptr;
   bk.load_basis();
   const bool ok = bk.build_and_invert(q);
   bk.store_basis();

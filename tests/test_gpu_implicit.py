@@ -228,6 +228,69 @@ def test_softabs_full_size_matches_oracle():
     assert_close(qb, q0, 1e-6, "reversed q")
 
 
+@pytest.mark.parametrize("target,dim,n,steps", [("funnel", 65, 2, 2), ("funnel", 128, 2, 2), ("funnel", 129, 2, 2),
+                                                ("poly", 200, 2, 2), ("funnel", 255, 1, 2), ("funnel", 256, 2, 2),
+                                                ("poly", 256, 1, 3)])
+def test_softabs_beyond_the_lds_tier_matches_oracle(target, dim, n, steps):
+    """SoftAbs systems with the three matrices in a per-chain HBM workspace: 64 < D <= 128 (rounds 1-4) and, round 5
+    (VERDICT r04 #7), 128 < D <= 256 - Jacobi sweeps whose column pairs are streamed from memory (softabs.h
+    block_round_mem).  State, momentum draw, Hamiltonian and dh_dmom against the oracle, then time reversal."""
+    rng = np.random.default_rng(1000 + dim)
+    if target == "funnel":
+        w = np.linspace(0.5, 2.0, dim - 1)
+        ot, dt = omdl.Funnel(w), models.Funnel(w)
+    else:
+        ot, dt = omdl.Poly(dim, 1.0, 1.0 / 3.0), models.Poly(dim, 1.0, 1.0 / 3.0)
+    h = 0.02
+    osys = orc.RiemannianSystem(ot, None, 1.0)
+    system = systems.SoftAbsRiemannianMetricSystem(dt, softabs_coeff=1.0)
+    integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+    q0 = 0.5 * rng.standard_normal((n, dim))
+    z = rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, z)
+    dirs = np.where(np.arange(n) % 2 == 0, 1, -1)
+    q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=steps)
+    assert np.all(status == 0) and np.all(n_done == steps)
+    for c in range(n):
+        assert_close(p0[c], osys.sample_momentum(orc._State(q0[c], None), z[c]), 1e-11, "sample_momentum")
+        qo, po, so, no = orc.implicit_leapfrog_steps(osys, q0[c], p0[c], dirs[c] * h, steps)
+        assert so == 0 and no == steps
+        assert_close(q[c], qo, 1e-10, f"q chain {c}")
+        assert_close(p[c], po, 1e-10, f"p chain {c}")
+        st = orc._State(q[c], p[c])
+        assert_close(system.h_batch(q[c:c + 1], p[c:c + 1])[0], osys.h(st), 1e-10, "h")
+        assert_close(system.dh_dmom_batch(q[c:c + 1], p[c:c + 1])[0], osys.dh2_dmom(st), 1e-10, "dh_dmom")
+    qb, pb, sb, _ = integ.step_batch(q, p, -dirs, n_steps=steps)
+    assert np.all(sb == 0)
+    assert_close(qb, q0, 1e-6, "reversed q")
+    assert_close(pb, p0, 1e-6, "reversed p")
+
+
+@pytest.mark.parametrize("target,dim", [("funnel", 100), ("poly", 200), ("funnel", 256)])
+def test_softabs_midpoint_beyond_the_lds_tier_matches_oracle(target, dim):
+    """ImplicitMidpointIntegrator (integrators.py:547-681) on the SoftAbs workspace tiers, 64 < D <= 256."""
+    rng = np.random.default_rng(2000 + dim)
+    if target == "funnel":
+        w = np.linspace(0.5, 2.0, dim - 1)
+        ot, dt = omdl.Funnel(w), models.Funnel(w)
+    else:
+        ot, dt = omdl.Poly(dim, 1.0, 1.0 / 3.0), models.Poly(dim, 1.0, 1.0 / 3.0)
+    n, h, steps = 2, 0.02, 2
+    osys = orc.RiemannianSystem(ot, None, 1.0)
+    system = systems.SoftAbsRiemannianMetricSystem(dt, softabs_coeff=1.0)
+    integ = integrators.ImplicitMidpointIntegrator(system, h)
+    q0 = 0.5 * rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+    dirs = np.array([1, -1])
+    q, p, status, n_done = integ.step_batch(q0, p0, dirs, n_steps=steps)
+    assert np.all(status == 0) and np.all(n_done == steps)
+    for c in range(n):
+        qo, po, so, no = orc.implicit_midpoint_steps(osys, q0[c], p0[c], dirs[c] * h, steps)
+        assert so == 0 and no == steps
+        assert_close(q[c], qo, 1e-10, f"q chain {c}")
+        assert_close(p[c], po, 1e-10, f"p chain {c}")
+
+
 @pytest.mark.parametrize("dim,n,steps", [(65, 3, 2), (75, 2, 2), (76, 2, 2), (100, 2, 2), (128, 2, 2),
                                          (255, 1, 1), (256, 2, 1), (257, 1, 1), (279, 1, 1)])
 def test_large_kernel_boundaries_match_oracle(dim, n, steps):
@@ -342,10 +405,10 @@ def test_unsupported_sizes_fail_loudly():
     with pytest.raises(DeviceError):
         integrators.ImplicitLeapfrogIntegrator(system, 0.01).step_batch(
             rng.standard_normal((1, big)), rng.standard_normal((1, big)), 1, 1)
-    system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(np.linspace(0.5, 2, 128)))
-    with pytest.raises(DeviceError):  # SoftAbs: one workgroup per chain up to D = 128
+    system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(np.linspace(0.5, 2, 256)))
+    with pytest.raises(DeviceError):  # SoftAbs: one workgroup per chain up to D = 256 (round 5)
         integrators.ImplicitLeapfrogIntegrator(system, 0.01).step_batch(
-            rng.standard_normal((1, 129)), rng.standard_normal((1, 129)), 1, 1)
+            rng.standard_normal((1, 257)), rng.standard_normal((1, 257)), 1, 1)
     system = systems.DenseConstrainedEuclideanMetricSystem(models.Poly(1025, 1.0, 0.0), models.CircleConstr())
     with pytest.raises(DeviceError):  # wave-per-chain kernels: 16 coordinates per lane at most
         integrators.ConstrainedLeapfrogIntegrator(system, 0.1).step_batch(
@@ -541,15 +604,16 @@ def test_softabs_refined_decompositions_match_oracle_at_c3b_size():
         assert_close(p[c], po, 1e-9, f"p chain {c}")
 
 
-def test_softabs_eigenvectors_are_carried_from_launch_to_launch():
+@pytest.mark.parametrize("dim,n", [(40, 6), (100, 3), (160, 2)])
+def test_softabs_eigenvectors_are_carried_from_launch_to_launch(dim, n):
     """A state keeps each chain's last eigenvector basis (k_softabs.hip load_basis / store_basis): five one-step launches
     on one device batch equal one five-step launch to solver accuracy and run no more Jacobi sweeps than it does.  A copy of the batch (the proposal of a transition)
     inherits the bases; uploading unrelated positions into the batch is harmless - the refinement finds the stale basis
-    too far and hands over to the sweeps."""
+    too far and hands over to the sweeps.  (Round 5: the workspace tiers, 64 < D <= 256, refine and carry their bases too.)"""
     from mici_amd import _ffi
     from mici_amd.runtime import DeviceBatch, default_context
     rng = np.random.default_rng(23)
-    dim, n, h = 40, 6, 0.03
+    h = 0.03
     w = np.linspace(0.6, 1.8, dim - 1)
     system = systems.SoftAbsRiemannianMetricSystem(models.Funnel(w), softabs_coeff=1.0)
     integ = integrators.ImplicitLeapfrogIntegrator(system, h)

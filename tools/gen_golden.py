@@ -1211,6 +1211,11 @@ def main():
                 r=case_rng("softabs_poly_d72"))
     add_riemann("softabs_funnel_d128", mdl.Funnel(np.linspace(0.5, 2.0, 127)), None, 1.0, 2, 0.02, [1, 3],
                 qscale=0.7, r=case_rng("softabs_funnel_d128"))
+    # round 5: 128 < D <= 256 (the NP = 256 instantiation: Jacobi sweeps over columns streamed from memory)
+    add_riemann("softabs_poly_d160", mdl.Poly(160, 1.0, 1.0 / 3.0), None, 1.5, 2, 0.05, [1, 3],
+                r=case_rng("softabs_poly_d160"))
+    add_riemann("softabs_funnel_d256", mdl.Funnel(np.linspace(0.5, 2.0, 255)), None, 1.0, 2, 0.02, [1, 3],
+                qscale=0.7, r=case_rng("softabs_funnel_d256"))
 
     def wide_sphere_plane(name, d, n, mk, h, cps, **kw):
         r = case_rng(name)
