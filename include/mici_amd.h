@@ -76,7 +76,7 @@ typedef enum mm_rmetric { /* position-dependent metric of a RiemannianMetricSyst
   MM_RMETRIC_SOFTABS = 3,  /* SoftAbs of the target Hessian, params coeff; SoftAbsRiemannianMetricSystem */
   MM_RMETRIC_USER = 100,   /* user-supplied device code: mm_model_create_from_source, dim <= 279, params: any */
   MM_RMETRIC_SOFTABS_USER = 101 /* SoftAbs of a USER Hessian (hess_neg_log_dens / mtp_neg_log_dens as device code, dense):
-                                   mm_model_create_from_source, dim <= 64, params coeff then the user's own */
+                                   mm_model_create_from_source, dim <= 256, params coeff then the user's own */
 } mm_rmetric;
 
 typedef enum mm_constr { /* holonomic constraint, C = 1 */
@@ -206,18 +206,19 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* desc, mm_model** out);
  *    diagonal / dense fixed metric) the wave-per-chain kernels are compiled around it: mm_leapfrog_euclid,
  *    mm_composition_euclid, mm_hamiltonian, mm_dh_dmom, mm_sample_momentum, mm_momentum_refresh*, mm_metropolis_accept*.
  *  * desc->constr == MM_CONSTR_USER - `constr` / `jacob_constr` of a ConstrainedEuclideanMetricSystem
- *    (systems.py:786-792), desc->n_constr functions of the position, 1 <= n_constr <= 8, n_constr < dim <= 64:
+ *    (systems.py:786-792), desc->n_constr functions of the position, 1 <= n_constr <= 8, n_constr < dim <= 256:
  *        __device__ void mm_user_constr(const double* q, int dim, const double* params, double* c);   // c[n_constr]
  *        __device__ void mm_user_jacob(const double* q, int dim, const double* params, double* jac);  // jac[k*dim+i]
  *    (params: desc->constr_params) and, only for dens_wrt_ambient / Gaussian-split systems (mhp_constr,
  *    systems.py:1006-1008: out[i] = sum_{k,j} m[k*dim+j] d2 c_k / dq_j dq_i),
  *        __device__ void mm_user_mhp_constr(const double* q, int dim, const double* params, const double* m, double* out);
- *    The library compiles its constrained-leapfrog core (csrc/constrained_core.h: all three projection solvers,
- *    n_inner, both density conventions) around them; mm_constrained_leapfrog, mm_hamiltonian, mm_sample_momentum,
+ *    The library compiles its constrained-leapfrog core (csrc/constrained_core.h, lane per chain, dim <= 64;
+ *    csrc/constrained_wave.h, wave per chain, beyond: all three projection solvers, n_inner, both density
+ *    conventions) around them; mm_constrained_leapfrog, mm_hamiltonian, mm_sample_momentum,
  *    mm_momentum_refresh* and mm_metropolis_accept* work on such a model.  Target and constraint may both be user code
  *    (one source text defining all the functions).
  *  * desc->rmetric == MM_RMETRIC_USER - `metric_func` / `vjp_metric_func` of a DenseRiemannianMetricSystem
- *    (systems.py:1322-1358, 1690-1734), dim <= 279:
+ *    (systems.py:1322-1358, 1690-1734), dim <= 1024:
  *        __device__ double mm_user_metric(const double* q, int i, int j, int dim, const double* params);  // M(q)_ij
  *        __device__ double mm_user_vjp(const double* q, const MmMat& V, int k, int dim, const double* params);
  *        // element k of vjp_metric_func(q)(V) = sum_ij V(i, j) d M_ij / d q_k;  V(i, j) reads the symmetric argument
@@ -227,12 +228,13 @@ int mm_model_create(mm_ctx* ctx, const mm_model_desc* desc, mm_model** out);
  *    library compiles its dense-Riemannian backends around the text: the leapfrog step on the matrix-core kernels
  *    (32 < dim <= 64 one wave per chain, 75 < dim <= 256 one workgroup per chain; compiled on first use) with the
  *    solve-only metric constructions refined through M(x) v products of the user's entries, everything else on the
- *    wave (dim <= 64) / team (dim <= 279) kernels.  mm_implicit_leapfrog, mm_implicit_midpoint, mm_hamiltonian,
+ *    wave (dim <= 64) / team (dim <= 279) kernels; 279 < dim <= 1024 on the global-memory tier
+ *    (csrc/implicit_global.h: the chain's metric in HBM).  mm_implicit_leapfrog, mm_implicit_midpoint, mm_hamiltonian,
  *    mm_dh_dmom, mm_sample_momentum, mm_momentum_refresh* and mm_metropolis_accept* work on such a model; the target
  *    may be built in or user code as well.  Compiled code objects are cached under MICI_AMD_RTC_CACHE (default
  *    ~/.cache/mici_amd/rtc; "off" disables); `python -m mici_amd.precompile` produces them ahead of time, without a GPU.
  *  * desc->rmetric == MM_RMETRIC_SOFTABS_USER - `hess_neg_log_dens` / `mtp_neg_log_dens` of a
- *    SoftAbsRiemannianMetricSystem (systems.py:1737-1920), dim <= 64; rmetric_params = softabs_coeff, then the user's:
+ *    SoftAbsRiemannianMetricSystem (systems.py:1737-1920), dim <= 256; rmetric_params = softabs_coeff, then the user's:
  *        __device__ double mm_user_hess(const double* q, int i, int j, int dim, const double* params);   // H(q)_ij
  *        __device__ double mm_user_mtp(const double* q, const MmMat& M, int k, int dim, const double* params);
  *        // element k of mtp_neg_log_dens(q)(M) = sum_ij M(i, j) d3 nld / dq_i dq_j dq_k;  M(i, j) reads the symmetric argument
@@ -319,7 +321,7 @@ int mm_implicit_leapfrog(mm_ctx* ctx, const mm_model* model, mm_state* state, do
 /* ImplicitMidpointIntegrator.step x n_steps (integrators.py:547-681): implicit Euler half step solved as a
  * fixed point in the concatenated (pos, mom) vector (solvers.py:47-154), explicit Euler half step, and the
  * reversibility check.  Euclidean-metric systems and dense-Riemannian systems (dim <= 1024), SoftAbs systems
- * (dim <= 256; user Hessians 64); opts / counters as for mm_implicit_leapfrog. */
+ * (dim <= 256, user Hessians included); opts / counters as for mm_implicit_leapfrog. */
 int mm_implicit_midpoint(mm_ctx* ctx, const mm_model* model, mm_state* state, double step_size,
                          int32_t n_steps, const mm_fp_opts* opts, mm_counters* counters);
 

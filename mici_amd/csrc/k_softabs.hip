@@ -111,13 +111,25 @@ int launch_aux_np(mm_ctx* ctx, mm_state* s, SaArgs S, double* d_out, const doubl
   return MM_OK;
 }
 
-// a user Hessian: the same kernels, compiled at run time around the user's source (mm_rtc.hip); NP = 64, USERH
-int launch_user(mm_ctx* ctx, const mm_model* m, mm_state* s, SaArgs S, int which, double* d_out, const double* d_z) {
+// a user Hessian: the same kernels, compiled at run time around the user's source (mm_rtc.hip) for the padded size of the
+// model's dim (softabs_source(): MM_SA_NP), USERH
+template <int NP>
+int launch_user_np(mm_ctx* ctx, const mm_model* m, mm_state* s, SaArgs S, int which, double* d_out, const double* d_z) {
+  using B = SoftAbsBackendT<NP, true>;
+  if (B::kWorkDoubles) {
+    const int rc = ensure_work(ctx, s, B::kWorkDoubles, &S.work);
+    if (rc != MM_OK) return rc;
+  }
   if (!S.a.no_refine && !eig_cache_disabled()) {
-    const int rc = ensure_eig(ctx, s, SoftAbsBackendT<64, true>::kEigDoubles, &S.eig);
+    const int rc = ensure_eig(ctx, s, B::kEigDoubles, &S.eig);
     if (rc != MM_OK) return rc;
   }
   return mm_rtc_launch_softabs(ctx, m, which, &S, s->n, d_out, d_z);
+}
+int launch_user(mm_ctx* ctx, const mm_model* m, mm_state* s, SaArgs S, int which, double* d_out, const double* d_z) {
+  if (m->dim <= 64) return launch_user_np<64>(ctx, m, s, S, which, d_out, d_z);
+  return m->dim <= 128 ? launch_user_np<128>(ctx, m, s, S, which, d_out, d_z)
+                       : launch_user_np<256>(ctx, m, s, S, which, d_out, d_z);
 }
 
 }  // namespace

@@ -258,8 +258,8 @@ int mm_model_create_from_source(mm_ctx* ctx, const mm_model_desc* d, const char*
   MM_REQUIRE(ctx, d->target == MM_TARGET_USER || d->constr == MM_CONSTR_USER || d->rmetric == MM_RMETRIC_USER ||
                       d->rmetric == MM_RMETRIC_SOFTABS_USER,
              "mm_model_create_from_source: one of desc->target / constr / rmetric must be the _USER id");
-  MM_REQUIRE(ctx, d->rmetric != MM_RMETRIC_SOFTABS_USER || d->dim <= 64,
-             "mm_model_create_from_source: a SoftAbs system with a user Hessian runs on the LDS-resident kernel, dim <= 64");
+  MM_REQUIRE(ctx, d->rmetric != MM_RMETRIC_SOFTABS_USER || d->dim <= 256,
+             "mm_model_create_from_source: a SoftAbs system with a user Hessian runs one workgroup per chain, dim <= 256");
   MM_REQUIRE(ctx, d->rmetric == MM_RMETRIC_NONE || d->rmetric == MM_RMETRIC_USER || d->rmetric == MM_RMETRIC_SOFTABS_USER,
              "mm_model_create_from_source: a user target on a Riemannian system needs a user metric too (the built-in "
              "metrics' kernels are compiled ahead of time around the built-in targets)");

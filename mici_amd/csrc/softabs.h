@@ -164,12 +164,11 @@ __device__ __forceinline__ double rp_sum_n(double v) {
 // pair no longer fits the registers of eight lanes at four waves per SIMD - the Jacobi rounds stream the columns from
 // memory, block_round_mem(), and every wave rotates G and then V of its block pair: there are 16 block pairs a round and
 // 16 waves.  1.6 MB of matrices per chain: with more chains in flight than fit the L2 the sweeps are HBM-bound)
-// USERH: the Hessian and the matrix-Tressian product are the user's (user_hessian.h) - nothing is known about their
+// USERH: the Hessian and the matrix-Tressian product are the user's (user_hessian.h; any NP since round 5) - nothing is known about their
 // structure: dense Hessian, G = A X as a matrix-core product, grad_log_abs_det / grad_quadratic_form_inv formed in full
 template <int NP, bool USERH = false>
 struct SoftAbsBackendT {
   static_assert(NP == 64 || NP == 128 || NP == 256, "SoftAbs backend sizes");
-  static_assert(!USERH || NP == 64, "user Hessians run on the LDS-resident backend (dim <= 64)");
   static constexpr int BS = NP / TPD;     // output block side per thread in the NP x NP products
   static constexpr int RP = NT / NP;      // threads per output element of the row-wise reductions
   static constexpr int LD = NP + 1;       // leading dimension of the row-major matrices (LDS: conflict-free columns)
@@ -863,6 +862,20 @@ struct SoftAbsBackendT {
     ++unchecked;
     for (int pass = 0; pass < kRefineMaxPass; ++pass) {
       double* const X = w.V;
+      if constexpr (USERH) {
+        // a dense Hessian: G = A X as a tiled product, A symmetric and read down its columns
+#pragma unroll 1
+        for (int qd = wave; qd < NQ; qd += NW) {
+          const int I = qd / QR, J0 = 4 * (qd % QR);
+          d4 ax[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+          quad_tiles<false>(w.H + KQ * g * LD + 16 * I + j, X + KQ * g * LD + 16 * J0 + j, nullptr, ax);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Gm[(16 * I + 4 * r + g) * LD + 16 * (J0 + u) + j] = ax[u][r];
+        }
+        ++n_products;
+      } else {
       // G = A X from the structure of the built-in Hessians (diagonal; arrowhead), as refine_eigh()
       for (int el = tid; el < NP * NP; el += NT) {
         const int i = el / NP, c = el % NP;
@@ -876,6 +889,7 @@ struct SoftAbsBackendT {
         for (int k = part; k < dim; k += RP) a = __builtin_fma(w.H[k], X[k * LD + c], a);
         a = rp_sum(a);
         if (part == 0) Gm[c] = a;
+      }
       }
       ++n_products;
       __syncthreads();
@@ -1353,18 +1367,40 @@ struct SoftAbsBackendT {
   // 0.5 * mtp(grad_log_abs_det), grad_log_abs_det = V diag(grad_softabs(lam)/lamt) V^T  (:1671-1674)
   // the user's matrix-Tressian product of the symmetric matrix the team has just formed in w.W (row-major, leading
   // dimension LD, zero beyond dim): element k on thread k - the first wave
-  __device__ __forceinline__ double user_mtp_w() {
-    __syncthreads();  // w.W complete, w.qv visible
+  __device__ __forceinline__ double user_mtp_of(const double* m) {
+    __syncthreads();  // the matrix complete, w.qv visible
     double out = 0.0;
-    if (tid < dim) out = mmuserh::mtp(w.qv, w.W, LD, tid, dim, hparams);
-    __syncthreads();  // (the next writer of w.W / w.qv is behind this)
+    if (tid < dim) out = mmuserh::mtp(w.qv, m, LD, tid, dim, hparams);
+    __syncthreads();  // (the next writer of the matrix / w.qv is behind this)
     return out;
   }
+  __device__ __forceinline__ double user_mtp_w() { return user_mtp_of(w.W); }
 
   __device__ __forceinline__ double half_vjp_inv(double q) {
     SA_PROF_BEGIN();
     if (tid < NP) w.qv[tid] = (tid < dim) ? q : 0.0;
-    if constexpr (USERH) {
+    if constexpr (USERH && !kMatricesInLds) {
+      // the same matrix from the workspace: tile (I, J) = sum_k V^T[k][i] (g_k) V^T[k][j], both operands down columns of V^T
+      constexpr int T = NP / 16, KQ = NP / 4, QR = T / 4, NQ = T * QR, NW = NT / 64;
+      const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+      const int g = lane >> 4, j = lane & 15;
+      if (tid < NP) w.v2[tid] = (tid < dim) ? w.gsa[tid] / w.lamt[tid] : 0.0;  // (w.v2: only mtp_lds() uses it otherwise)
+      __syncthreads();
+      ++n_products;
+#pragma unroll 1
+      for (int qd = wave; qd < NQ; qd += NW) {
+        const int I = qd / QR, J0 = 4 * (qd % QR);
+        d4 acc[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        quad_tiles<true>(w.Vt + KQ * g * LD + 16 * I + j, w.Vt + KQ * g * LD + 16 * J0 + j, w.v2 + KQ * g, acc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w.W[(16 * I + 4 * r + g) * LD + 16 * (J0 + u) + j] = acc[u][r];
+      }
+      const double out = 0.5 * user_mtp_w();
+      SA_PROF_END(7);
+      return out;
+    } else if constexpr (USERH) {
       // grad_log_abs_det = V diag(softabs'(lam) / softabs(lam)) V^T in full: tile (I, Jt) = sum_k V_ik g_k V_jk on the
       // matrix cores (both operands walk along rows of V: conflict-free at LD = 65), into w.W
       const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1533,6 +1569,39 @@ struct SoftAbsBackendT {
       }
       constexpr int T = NP / 16, KQ = NP / 4, QR = T / 4, NW = NT / 64, WPR = NW / T;  // WPR waves share a row of tiles
       static_assert(NW % T == 0 && WPR >= 1 && WPR <= 4 && QR % WPR == 0, "tile rows of the dh2_dpos product");
+      if constexpr (USERH) {
+        // grad_quadratic_form_inv = -(B A^T) in full, B = A J: B^T into w.W (stored transposed, so that the second
+        // product reads it down its columns), then tile (I, J) of B A^T = sum_k B^T[k][i] e_k V^T[k][j] into w.S
+        constexpr int NQ = T * QR;
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int g = lane >> 4, j = lane & 15;
+        const double* const ek = w.v1 + KQ * g;
+        n_products += 2;
+#pragma unroll 1
+        for (int qd = wave; qd < NQ; qd += NW) {
+          const int I = qd / QR, J0 = 4 * (qd % QR);
+          d4 acc[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+          quad_tiles<true>(w.Vt + KQ * g * LD + 16 * I + j, w.H + KQ * g * LD + 16 * J0 + j, ek, acc);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w.W[(16 * (J0 + u) + j) * LD + 16 * I + 4 * r + g] = acc[u][r];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int qd = wave; qd < NQ; qd += NW) {
+          const int I = qd / QR, J0 = 4 * (qd % QR);
+          d4 acc[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+          quad_tiles<true>(w.W + KQ * g * LD + 16 * I + j, w.Vt + KQ * g * LD + 16 * J0 + j, ek, acc);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w.S[(16 * I + 4 * r + g) * LD + 16 * (J0 + u) + j] = -acc[u][r];
+        }
+        const double out = 0.5 * user_mtp_of(w.S);
+        SA_PROF_END(6);
+        return out;
+      }
       double* const part = w.ring;           // [WPR][NP] partial md (the ring is idle outside eigh())
       double* const brow0 = w.ring + 2048;   // [NP] row 0 of B
       {

@@ -13,7 +13,8 @@
 //                                                 grad_log_abs_det = V diag(softabs'(lam) / softabs(lam)) V^T and
 //                                                 grad_quadratic_form_inv = -(A J A^T)  (matrices.py:1671-1685)
 // The target itself is a built-in one or user code as well (mm_user_grad / mm_user_nld_term, mm_device.h).
-// dim <= 64.  As for user metrics: no control flow in mm_user_hess where a select will do.
+// dim <= 256 (round 5; beyond 64 the matrices - M included - live in the chain's workspace in HBM, not in LDS).  As for user
+// metrics: no control flow in mm_user_hess where a select will do.
 #pragma once
 #include "mm_device.h"
 

@@ -153,7 +153,8 @@ class UserHessian:
         // element k of mtp_neg_log_dens(q)(M) = sum_ij M(i, j) d3 nld / dq_i dq_j dq_k for a symmetric M read as M(i, j)
 
     and is compiled for gfx950 (hipRTC) with the library's SoftAbs kernels when the system's device model is created
-    (csrc/user_hessian.h).  Nothing is assumed about the Hessian's structure.  ``dim`` <= 64."""
+    (csrc/user_hessian.h).  Nothing is assumed about the Hessian's structure.  ``dim`` <= 256 (the kernels are compiled
+    for the padded size of the system's dimension: 64, 128 or 256)."""
 
     def __init__(self, source, params=()):
         if not isinstance(source, str) or "mm_user_hess" not in source or "mm_user_mtp" not in source:

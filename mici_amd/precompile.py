@@ -75,10 +75,11 @@ def default_jobs():
                 for fam in families_of(dim):
                     jobs.append(("BANANA_SRC+RANK1", us.BANANA_SRC + "\n" + msrc, dim, fam, 100))
         jobs.append(("BANANA_SRC+BANANA_HESS", us.BANANA_SRC + "\n" + ue.BANANA_HESS, 64, "softabs", 100))
-    # user Hessians of SoftAbs systems (one translation unit per text, whatever the dimension)
-    jobs.append(("BANANA_HESS", ue.BANANA_HESS, 64, "softabs", 0))
-    if "user_sources" in sys.modules:
-        jobs.append(("FUNNEL_HESS", sys.modules["user_sources"].FUNNEL_HESS, 64, "softabs", 0))
+    # user Hessians of SoftAbs systems (one translation unit per text and padded size: dim <= 64, <= 128, <= 256)
+    for dim in (64, 128, 256):
+        jobs.append(("BANANA_HESS", ue.BANANA_HESS, dim, "softabs", 0))
+        if "user_sources" in sys.modules:
+            jobs.append(("FUNNEL_HESS", sys.modules["user_sources"].FUNNEL_HESS, dim, "softabs", 0))
     # slowest first: the matrix-core wave kernel, then the wave kernel at its largest tile size
     order = {"mfma": 0, "softabs": 0, "wave": 1, "blk16": 2, "team": 3, "global": 3}
     jobs.sort(key=lambda j: (order[j[3]], -j[2]))

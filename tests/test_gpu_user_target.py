@@ -429,8 +429,8 @@ def test_user_hessian_errors_fail_loudly():
     bad = models.UserHessian(BANANA_HESS.replace("return hi == lo ? diag : off;", "return hi == lo ? diag : undefined_off;"))
     with pytest.raises(DeviceError, match="undefined_off"):
         systems.SoftAbsRiemannianMetricSystem(models.Banana(5), hess_neg_log_dens=bad).device_model()
-    with pytest.raises(DeviceError, match="dim <= 64"):
-        systems.SoftAbsRiemannianMetricSystem(models.Banana(70), hess_neg_log_dens=models.UserHessian(BANANA_HESS)).device_model()
+    with pytest.raises(DeviceError, match="dim <= 256"):
+        systems.SoftAbsRiemannianMetricSystem(models.Banana(257), hess_neg_log_dens=models.UserHessian(BANANA_HESS)).device_model()
     with pytest.raises(DeviceError, match="Hessian"):  # the banana has no built-in device Hessian
         systems.SoftAbsRiemannianMetricSystem(models.Banana(5)).device_model()
 
@@ -498,6 +498,50 @@ def test_user_hessian_softabs_on_the_banana_matches_oracle(dim):
                 qs, ps, ss, _ = integ.step_batch(qs, ps, 1, n_steps=4)
                 assert np.all(ss == 0)
             assert_close(qs, q, 2e-9, "3 launches of 4 steps vs one of 12")
+
+
+@pytest.mark.parametrize("dim", [100, 200])
+def test_user_hessians_beyond_the_lds_tier(dim):
+    """Round 5: user Hessians on the workspace tiers of the SoftAbs kernels (64 < D <= 256: softabs.h USERH with
+    refine_eigh_global(), the dense G = A X, grad_log_abs_det and grad_quadratic_form_inv as tiled products from the
+    chain's workspace).  The banana's Hessian against the oracle (h, dh_dmom, sample_momentum, leapfrog and midpoint
+    steps), and the funnel's Hessian as user source against the built-in arrowhead path of the same size."""
+    from user_sources import BANANA_HESS, FUNNEL_HESS
+
+    rng = np.random.default_rng(300 + dim)
+    n = 3
+    system = systems.SoftAbsRiemannianMetricSystem(models.Banana(dim), softabs_coeff=1.0,
+                                                   hess_neg_log_dens=models.UserHessian(BANANA_HESS))
+    osys = orc.RiemannianSystem(omdl.Banana(dim), None, 1.0)
+    q0 = 0.7 * rng.standard_normal((n, dim))
+    z = rng.standard_normal((n, dim))
+    p0 = np.stack([osys.sample_momentum(orc._State(q0[k], None), z[k]) for k in range(n)])
+    assert_close(system.sample_momentum_batch(q0, z), p0, 1e-10, "sample_momentum")
+    assert_close(system.h_batch(q0, p0), [osys.h(orc._State(q0[k], p0[k])) for k in range(n)], 1e-10, "h")
+    assert_close(system.dh_dmom_batch(q0, p0), [osys.dh2_dmom(orc._State(q0[k], p0[k])) for k in range(n)], 1e-10, "dh_dmom")
+    for cls, ofn, h, steps in ((integrators.ImplicitLeapfrogIntegrator, orc.implicit_leapfrog_steps, 0.02, 4),
+                               (integrators.ImplicitMidpointIntegrator, orc.implicit_midpoint_steps, 0.02, 2)):
+        integ = cls(system, h)
+        q, p, st, nd = integ.step_batch(q0, p0, 1, n_steps=steps)
+        for k in range(n):
+            qo, po, so, no = ofn(osys, q0[k], p0[k], h, steps)
+            assert so == st[k] and no == nd[k]
+            assert_close(q[k], qo, 2e-9, f"{cls.__name__} q chain {k}")
+            assert_close(p[k], po, 2e-9, f"{cls.__name__} p chain {k}")
+    w = np.linspace(0.5, 2.0, dim - 1)
+    builtin = systems.SoftAbsRiemannianMetricSystem(models.Funnel(w), softabs_coeff=1.0)
+    user = systems.SoftAbsRiemannianMetricSystem(models.Funnel(w), softabs_coeff=1.0,
+                                                 hess_neg_log_dens=models.UserHessian(FUNNEL_HESS, w))
+    q0 = 0.5 * rng.standard_normal((n, dim))
+    p0 = builtin.sample_momentum_batch(q0, z)
+    assert_close(user.sample_momentum_batch(q0, z), p0, 1e-10, "sample_momentum (funnel as user source)")
+    ib, iu = integrators.ImplicitLeapfrogIntegrator(builtin, 0.02), integrators.ImplicitLeapfrogIntegrator(user, 0.02)
+    qb, pb, sb, nb = ib.step_batch(q0, p0, 1, n_steps=3)
+    qu, pu, su, nu = iu.step_batch(q0, p0, 1, n_steps=3)
+    assert np.array_equal(sb, su) and np.array_equal(nb, nu) and np.all(sb == 0)
+    assert ib.last_counters["n_fp_evals"] == iu.last_counters["n_fp_evals"]
+    assert_close(qu, qb, 2e-9, "funnel as user source, positions")
+    assert_close(pu, pb, 2e-9, "funnel as user source, momenta")
 
 
 # ---- a user TARGET together with a user METRIC / HESSIAN (ADVICE r04): the only way to run a user target on a Riemannian

@@ -1201,7 +1201,10 @@ def main():
     for nm, d, n, hh, cps, kw in (("softabs_user_banana_d9", 9, 5, 0.05, [1, 5, 20], {}),
                                   ("softabs_user_banana_d40_steffensen", 40, 3, 0.03, [1, 5], dict(fp_solver=1)),
                                   ("softabs_user_banana_d64", 64, 4, 0.02, [1, 5, 20], {}),
-                                  ("softabs_user_banana_d9_fail_bigstep", 9, 6, 0.7, [1, 3], dict(qscale=1.5))):
+                                  ("softabs_user_banana_d9_fail_bigstep", 9, 6, 0.7, [1, 3], dict(qscale=1.5)),
+                                  # round 5: user Hessians on the workspace tiers (64 < D <= 256)
+                                  ("softabs_user_banana_d100", 100, 2, 0.02, [1, 3], dict(qscale=0.7)),
+                                  ("softabs_user_banana_d200", 200, 2, 0.02, [1, 3], dict(qscale=0.7))):
         add_riemann(nm, mdl.Banana(d), None, 1.0, n, hh, cps, r=case_rng(nm), **kw)
     add_midpoint_softabs("midpoint_softabs_user_banana_d16", mdl.Banana(16), 1.0, 3, 0.03, [1, 4],
                          r=case_rng("midpoint_softabs_user_banana_d16"))
