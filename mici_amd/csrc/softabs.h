@@ -1,8 +1,9 @@
 // Device code of the SoftAbs kernels (k_softabs.hip instantiates it for the built-in targets' Hessians; mm_rtc.hip compiles it
 // at run time around a USER Hessian / matrix-Tressian product, user_hessian.h).
 //
-// Implicit leapfrog on SoftAbsRiemannianMetricSystem (D <= 64): one 1024-thread workgroup per chain,
-// the Hessian / eigenvectors / work matrices in LDS.  gfx950 / CDNA4.
+// Implicit leapfrog on SoftAbsRiemannianMetricSystem (D <= 256): one 1024-thread workgroup per chain, the Hessian /
+// eigenvectors / work matrices in LDS for D <= 64 (the BASELINE c3(b) configuration), in a per-chain workspace in HBM for
+// 64 < D <= 256 (SoftAbsBackendT<NP>: NP = 64 / 128 / 256).  gfx950 / CDNA4.
 //
 // Replaces, per chain and per step (reference /root/reference/src/mici):
 //   SoftAbsRiemannianMetricSystem (metric = SoftAbs-regularised Hessian, vjp = matrix-Tressian
@@ -13,14 +14,15 @@
 //       "Eigenvalues must all be positive."                       matrices.py:1529-1628
 //   the integrator step itself is implicit_core.h (integrators.py:493-544, solvers.py:47-154)
 //
-// eigh = (D <= 64) refinement of the previous decomposition's eigenvectors by matrix products on the matrix cores
-// (refine_eigh(): Ogita-Aishima iteration, quadratic, 2.4 passes of four 64^3 products at c3(b)), falling back to a
+// eigh = refinement of the previous decomposition's eigenvectors by matrix products on the matrix cores (refine_eigh():
+// Ogita-Aishima iteration, quadratic, 2.4 passes of four 64^3 products at c3(b); refine_eigh_global(): the same pass as
+// tiled products from the workspace), falling back to a
 // parallel cyclic ONE-SIDED (Hestenes) Jacobi on G = H V when there is no nearby basis: each round rotates D/2 disjoint
 // column pairs of G and V, sweeps repeat until the columns of G are orthogonal (7-8 sweeps cold, ~2 warm-started).
 // The result is used only through V f(lambda) V^T products, which do not depend on eigenvalue order or eigenvector signs.
 // The matrix-Tressian products of the built-in targets need only the diagonal and the first row of
 // their matrix argument, so V diag(g) V^T and A J A^T are never formed in full; the latter still needs
-// the D^3 product B = A J (A = V diag(e)), done as an LDS-tiled FMA GEMM.
+// the D^3 product B = A J (A = V diag(e)), on the matrix cores.  A USER Hessian gets both in full.
 #pragma once
 #include "implicit_core.h"
 #include "user_hessian.h"
