@@ -1208,6 +1208,11 @@ def main():
         add_riemann(nm, mdl.Banana(d), None, 1.0, n, hh, cps, r=case_rng(nm), **kw)
     add_midpoint_softabs("midpoint_softabs_user_banana_d16", mdl.Banana(16), 1.0, 3, 0.03, [1, 4],
                          r=case_rng("midpoint_softabs_user_banana_d16"))
+    # round 5: the implicit midpoint rule on the SoftAbs workspace tiers (64 < D <= 256), built-in and user Hessian
+    add_midpoint_softabs("midpoint_softabs_funnel_d100", mdl.Funnel(np.linspace(0.5, 2.0, 99)), 1.0, 2, 0.02, [1, 3],
+                         r=case_rng("midpoint_softabs_funnel_d100"))
+    add_midpoint_softabs("midpoint_softabs_user_banana_d160", mdl.Banana(160), 1.0, 2, 0.02, [1, 3], qscale=0.7,
+                         r=case_rng("midpoint_softabs_user_banana_d160"))
     add_riemann("softabs_funnel_d100", mdl.Funnel(np.linspace(0.5, 2.0, 99)), None, 1.0, 3, 0.02, [1, 4],
                 r=case_rng("softabs_funnel_d100"))
     add_riemann("softabs_poly_d72", mdl.Poly(72, 1.0, 1.0 / 3.0), None, 1.5, 3, 0.05, [1, 5],
