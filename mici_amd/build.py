@@ -37,6 +37,7 @@ EXTRA_FLAGS = {
     # block, and from AGPRs that is one v_accvgpr_read per dword
     "k_implicit_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "k_implicit_blk16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "k_implicit_pair.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }
 
 

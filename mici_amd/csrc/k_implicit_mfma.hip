@@ -78,6 +78,9 @@ __global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs 
 
 }  // namespace
 
+// k_implicit_pair.hip
+int mm_launch_implicit_pair(mm_ctx* ctx, const mm_model* m, mm_state* s, const mmimp::ImplicitArgs& a);
+
 int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps,
                             const mm_fp_opts& opts, mm_counters* d_counters) {
   if (m->dim > 64) {
@@ -103,8 +106,12 @@ int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
   a.no_refine = mm_refine_disabled();
   a.no_dual = mm_dual_disabled();
   a.counters = d_counters;
-  const unsigned blocks = (unsigned)((s->n + kWaves - 1) / kWaves);
   const bool r1 = m->rmetric == MM_RMETRIC_RANK1;
+  // round 6: MICI_AMD_PAIR=1 selects the two-waves-per-chain kernel (implicit_pair.h: built, parity-green, and measured -
+  // it loses 21 % on c3, profiles/r06_ab_c3_pair.txt - so the one-wave kernel stays the default)
+  static const bool pair_on = [] { const char* e = getenv("MICI_AMD_PAIR"); return e && e[0] == '1'; }();
+  if (pair_on) return mm_launch_implicit_pair(ctx, m, s, a);
+  const unsigned blocks = (unsigned)((s->n + kWaves - 1) / kWaves);
   const size_t lds = ((r1 ? kBaseDoubles : 0) + kWaves * kMfmaWaveDoubles) * sizeof(double);
   if (r1) {
     MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(implicit_mfma_kernel<MM_RMETRIC_RANK1>),
