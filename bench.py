@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - leapfrog-steps/sec (all chains) of the MI355X integrator hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2iv|c2bcss|c3|c3b|c4|c5|c3_user|c4_general|c3b_dense|c4_d512]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2i_stream|c2iv|c2bcss|c3|c3b|c4|c5|c3_user|c4_general|c3b_dense|c4_d512]
                     [--traj-len L] [--chains-per-gpu M] [--no-extra-configs] [--no-cpu-baseline]
 
 Contract (driver): W untimed warm-up passes, then EXACTLY K timed passes bracketed by a barrier +
@@ -111,17 +111,22 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
 
     crng = chain_rng if chain_rng is not None else rng  # drawn from AFTER the model, as rank 0 always did
 
-    if config in ("c2", "c2i", "c2iv", "c2bcss"):
+    if config in ("c2", "c2i", "c2iv", "c2bcss", "c2i_stream"):
         dim, h, traj = 128, 0.05, 1000
+        if config == "c2i_stream":
+            # the HBM-bound regime north_star names ("coalesced HBM loads of the per-chain (q, p) state"): ONE leapfrog step per
+            # launch, so a launch is one read and one write of the state - 32 D bytes per chain-step, 4.3 GB at 2^20 chains -
+            # and nothing else (integrators.py:170-173, systems.py:143-152, 362-363)
+            traj = 1
         stages = 3 if config == "c2bcss" else 1  # gradient evaluations per integrator step
-        if config == "c2i":
+        if config in ("c2i", "c2i_stream"):
             target, P = models.GaussIso(dim), None
             metric = None
             flops = 8.0 * dim
             # what leapfrog_elem_kernel executes per chain-step and coordinate for this target (grad = q): three
             # v_fma_f64 - p -= (t/2) g, q += t p, p -= (t/2) g - i.e. 6 flops against SURVEY 8d's ~8
             exec_flops = 6.0 * dim
-            name = "c2(i) iso-Gaussian"
+            name = "c2(i) iso-Gaussian" if config == "c2i" else "c2(i) iso-Gaussian, streaming regime (one step per launch)"
         else:
             P = _make_spd(dim, rng)
             target = models.GaussDense(P)
@@ -151,7 +156,7 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
                     coefficients=getattr(integ, "coefficients", None),
                     traj=traj, integ=integ, system=system, make_oracle=make_oracle, q0=q0, p0=p0,
                     bytes_per_chain_step=32.0 * dim, flops_per_chain_step=flops, valu_executed_flops_per_chain_step=exec_flops,
-                    bound="hbm" if config == "c2i" else "mfma", kind="euclid")
+                    bound="hbm" if config in ("c2i", "c2i_stream") else "mfma", kind="euclid")
     if config in ("c3", "c4", "c3_user", "c4_general", "c4_d512"):
         # c3_user / c4_general (VERDICT r03 #1c): the GENERAL dense-Riemannian path - the metric reaches the library as user
         # source (mici_amd/user_examples.py), compiled around the matrix-core kernels at run time.  c3_user: a metric that
@@ -262,11 +267,14 @@ def _sweep_mfma_counts(dim):
 
 
 DEFAULT_CHAINS = {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048, "c3_user": 1024, "c4_general": 1024, "c3b_dense": 1024,
-                  "c4_d512": 256}  # per GPU; else 4096
-EXTRA_CONFIGS = ("c2i", "c2iv", "c3", "c3b", "c4", "c5", "c3_user", "c4_general", "c3b_dense", "c4_d512")
+                  "c4_d512": 256, "c2i_stream": 1 << 20}  # per GPU; else 4096
+CPU_CHAINS = {"c2i_stream": 1 << 16}  # chains of the cpu_baseline sample where the device shard would not fit a host's pool
+EXTRA_CONFIGS = ("c2i", "c2i_stream", "c2iv", "c3", "c3b", "c4", "c5", "c3_user", "c4_general", "c3b_dense", "c4_d512")
 # pass counts of the extra configs are capped (a c3(b) pass is ~1 s, a c4 pass ~0.1-0.3 s)
 EXTRA_STEP_CAP = {"c3b": 5, "c4": 10, "c4_general": 10, "c3b_dense": 5, "c4_d512": 3}
 BASELINE_CONFIG = {"c2": "BASELINE.json configs[1]", "c2i": "BASELINE.json configs[1] (iso-Gaussian variant, SURVEY 8d c2(i))",
+                   "c2i_stream": "BASELINE.json configs[1] sizes (iso-Gaussian, D = 128) with n_steps = 1 and 2^20 chains: the "
+                                 "HBM-bound regime of the (q, p) state loads north_star names",
                    "c2iv": "BASELINE.json configs[1] (dense-metric variant, SURVEY 8d c2(iv))",
                    "c3": "BASELINE.json configs[2] (Cholesky path)", "c3b": "BASELINE.json configs[2] (SoftAbs path)",
                    "c4": "BASELINE.json configs[3] (per-GPU shard)", "c5": "BASELINE.json configs[4] (per-GPU shard)",
@@ -339,7 +347,7 @@ def cpu_baseline_measure(config, budget_s):
     from oracle import integrators as orc
 
     cores = _host_cores()
-    n = DEFAULT_CHAINS.get(config, 4096)
+    n = CPU_CHAINS.get(config, DEFAULT_CHAINS.get(config, 4096))
     w = make_workload(config, n, np.random.default_rng(1234), device=False)
     osys = w["make_oracle"]()
     coefs = w.get("coefficients")
@@ -697,7 +705,7 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE /
     # WRITE_SIZE cannot be read from inside the process); null when this shape was not profiled
     default_shape = chains_per_gpu is None and traj_len is None
-    for pmc_name in (f"r05_{config}_pmc_hbm.json", f"r04_{config}_pmc_hbm.json", f"r03_{config}_pmc_hbm.json", f"r02_{config}_pmc_hbm.json"):
+    for pmc_name in (f"r06_{config}_pmc_hbm.json", f"r05_{config}_pmc_hbm.json", f"r04_{config}_pmc_hbm.json", f"r03_{config}_pmc_hbm.json", f"r02_{config}_pmc_hbm.json"):
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if default_shape and os.path.exists(pmc):
             with open(pmc) as fh:

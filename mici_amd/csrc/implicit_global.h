@@ -197,6 +197,67 @@ struct GlobalBackend {
     }
   }
 
+  // ---- the sweep's block update on the MATRIX CORES, lower triangle only (round 6) ---------------------------------------------
+  // A is symmetric and the sweep keeps it so: only the 16 x 16 tiles (I, J) with I >= J are read and written - half the HBM
+  // traffic of a pass - as  tile += (-W)[:, tile I]^T X[:, tile J],  NB / 4 v_mfma_f64_16x16x4_f64 a tile with both operands
+  // straight from the LDS panels in the instruction's own layouts (A operand: lane (i = l % 16, k = l / 16) <- Wn[k][16 I + i];
+  // B operand: lane (k = l / 16, j = l % 16) <- X[k][16 J + j]; accumulator: lane 16 g + j, register r <-> tile entry
+  // (4 r + g, j), i.e. four 128-byte row segments a load).  A wave owns tile rows I and nt - 1 - I (nt + 1 tiles: every wave the
+  // same work), keeps the row's W operands in registers and streams the tiles kTJ at a time (kTJ x 2 KB in flight a wave).
+  // The NEXT block's panel is rows K' of the matrix, all columns: their part right of the diagonal block is the transpose of
+  // tile column jn = K' / 16 below the diagonal, so those tiles are ALSO stored transposed into the upper triangle (one tile
+  // column a block: 1 / nt of the traffic).  Everything else of the upper triangle is stale until invert()'s last pass mirrors
+  // the finished lower triangle.
+  static constexpr int kTJ = 4;
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  __device__ __forceinline__ void rank_update_mfma(const double* __restrict__ Wn, const double* __restrict__ Xp, const int nt,
+                                                   const int jn) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    constexpr int KS = NB / 4;
+    const int npair = (nt + 1) / 2;
+    for (int pr = wave; pr < npair; pr += NT / 64) {
+#pragma unroll 1
+      for (int side = 0; side < 2; ++side) {
+        const int I = side == 0 ? pr : nt - 1 - pr;
+        if (side == 1 && I == pr) break;  // (odd nt: the middle row once)
+        double a[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = Wn[(4 * s + g) * PITCH + 16 * I + j];
+        double* const arow = A + (size_t)(16 * I + g) * dp + j;  // entry (16 I + 4 r + g, 16 J + j) at arow[4 r dp + 16 J]
+#pragma unroll 1
+        for (int J0 = 0; J0 <= I; J0 += kTJ) {
+          d4 c[kTJ];
+#pragma unroll
+          for (int u = 0; u < kTJ; ++u)
+            if (J0 + u <= I) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) c[u][r] = arow[(size_t)(4 * r) * dp + 16 * (J0 + u)];
+            }
+#pragma unroll
+          for (int u = 0; u < kTJ; ++u)
+            if (J0 + u <= I) {
+#pragma unroll
+              for (int s = 0; s < KS; ++s) {
+                const double b = Xp[(4 * s + g) * PITCH + 16 * (J0 + u) + j];
+                c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, c[u], 0, 0, 0);
+              }
+            }
+#pragma unroll
+          for (int u = 0; u < kTJ; ++u)
+            if (J0 + u <= I) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) arow[(size_t)(4 * r) * dp + 16 * (J0 + u)] = c[u][r];
+              if (J0 + u == jn && I > jn) {  // (wave-uniform) the next panel's rows, right of their diagonal block
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[(size_t)(16 * jn + j) * dp + 16 * I + 4 * r + g] = c[u][r];
+              }
+            }
+        }
+      }
+    }
+  }
+
   // the NB x NB pivot block in LDS (pb), by the first wave: in-place Gauss-Jordan inverse (no pivoting: the block is a
   // Schur complement of a positive-definite matrix), its pivots = the Cholesky pivots squared.  flag[0] = 1 unless all
   // pivots are positive and finite, flag[1] = sum of their logarithms.
@@ -250,6 +311,7 @@ struct GlobalBackend {
     double ld = 0.0;
     static_assert(NB == 8 || NB == 16, "pivot-block inversion: NB * NB a multiple of 64");
     const int nblk = (dim + NB - 1) / NB;  // (the padding beyond is the identity, decoupled from the rest)
+    const int nt = (dim + 15) >> 4;        // 16 x 16 tiles a side that hold anything but that identity
     for (int blk = 0; blk < nblk; ++blk) {
       const int k0 = blk * NB;
       // (1) the panel: rows k0 .. k0 + NB - 1 of A (coalesced), X = Q - E, and the pivot block
@@ -276,22 +338,39 @@ struct GlobalBackend {
           double s = pb[k * NB] * x[0];
 #pragma unroll
           for (int l = 1; l < NB; ++l) s = __builtin_fma(pb[k * NB + l], x[l], s);
-          Wp[k * PITCH + tid] = s;
+          Wp[k * PITCH + tid] = -s;  // (-W: the matrix cores accumulate)
         }
       }
       __syncthreads();
-      // (4) A -= W^T X everywhere, then A_KK -= 2 I
-      rank_update(Wp, Xp);
+      // (4) A -= W^T X on the lower-triangle tiles (matrix cores), then A_KK -= 2 I
+      rank_update_mfma(Wp, Xp, nt, (k0 + NB) >> 4);
       __syncthreads();
       if (tid < NB) A[(size_t)(k0 + tid) * dp + k0 + tid] -= 2.0;
       __syncthreads();
     }
-    // A = -M^-1: one more pass turns the sign (1 / (D / NB) of the sweep's traffic), so that the workspace IS the explicit
-    // inverse - what a user's vector-Jacobian product reads through its dense accessor V(i, j)
+    // A = -M^-1 in the lower triangle: one more pass turns the sign and mirrors it into the upper triangle (1 / (D / NB) of the
+    // sweep's traffic), so that the workspace IS the explicit inverse - what the products' column walks and a user's
+    // vector-Jacobian product (through its dense accessor V(i, j)) read
     {
-      const int tx = tid & 31, ty = tid >> 5;
-      for (int i = ty; i < dp; i += 32)
-        for (int j = tx; j < dp; j += 32) A[(size_t)i * dp + j] = -A[(size_t)i * dp + j];
+      const int lane = tid & 63, wave = tid >> 6;
+      const int g = lane >> 4, j = lane & 15;
+      const int ntiles = nt * (nt + 1) / 2;
+      for (int t = wave; t < ntiles; t += NT / 64) {
+        // tile number t -> (I, J), I >= J: I = floor((sqrt(8 t + 1) - 1) / 2), fixed up in integers
+        int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        while (I * (I + 1) / 2 > t) --I;
+        const int J = t - I * (I + 1) / 2;
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = -A[(size_t)(16 * I + 4 * r + g) * dp + 16 * J + j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[(size_t)(16 * I + 4 * r + g) * dp + 16 * J + j] = v[r];
+        if (I != J) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) A[(size_t)(16 * J + j) * dp + 16 * I + 4 * r + g] = v[r];
+        }
+      }
     }
     __syncthreads();
     if (logdet) *logdet = ld;

@@ -146,7 +146,7 @@ def _rdzv_worker(rank, world, path, n, dim, steps, h, out_dir):
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), q=q_all, p=p_all)
 
 
-@pytest.mark.parametrize("world,n", [(2, 10), (3, 7)])
+@pytest.mark.parametrize("world,n", [(2, 10), (3, 7), (8, 37)])  # (8: the node run of SURVEY 8e - VERDICT r05 #5 / #8)
 def test_socket_rendezvous_sharded_run_matches_single_process(tmp_path, world, n):
     import multiprocessing as mp
 

@@ -131,3 +131,45 @@ def test_share_switch_is_needed_on_a_one_gpu_box(tmp_path):
                           "--no-cpu-baseline", "--no-extra-configs"], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert "only 1 HIP device" in out.stderr
+
+
+@pytest.mark.parametrize("config,n_local,traj", [("c4", 16, 2), ("c5", 64, 5)])
+def test_eight_ranks_on_one_device_rehearse_the_node_run(tmp_path, config, n_local, traj):
+    """the 8-GPU launch of the driver, rehearsed on the hardware there is - `bench.py --gpus 8` starts eight
+    rank processes (here sharing the visible device(s), MICI_AMD_SHARE_DEVICE=1), they meet over the rendezvous socket, every
+    rank times its own shard, the trace is gathered rank-major.  Checked: eight processes took part (eight wall clocks, the
+    rendezvous' own count), the chain total is 8 x the shard, the gathered trace equals the eight shards recomputed in this
+    process bit for bit, the stdout line stays under 4 KB at N = 8, and the whole launch takes under two minutes.  Role in
+    the reference: samplers.py:546-565 (per-chain RNG streams), :668-772 (worker processes and their trace collection).
+    No scaling figure is read from this."""
+    import time
+    world, steps, warmup = 8, 2, 1
+    t0 = time.perf_counter()
+    dump = os.path.join(str(tmp_path), f"trace_{config}_{world}.npy")
+    env = dict(os.environ, MICI_AMD_BENCH_DUMP_TRACE=dump, HSA_ENABLE_IPC_MODE_LEGACY="0", MICI_AMD_SHARE_DEVICE="1",
+               MICI_AMD_BENCH_SIDECAR=os.path.join(str(tmp_path), "bench_configs.json"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--config", config, "--steps", str(steps),
+           "--warmup", str(warmup), "--chains-per-gpu", str(n_local), "--traj-len", str(traj), "--no-cpu-baseline",
+           "--no-extra-configs"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    wall = time.perf_counter() - t0
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints the one line, the other seven print nothing
+    assert len(lines[0].encode()) < 4096, len(lines[0].encode())
+    line = json.loads(lines[0])
+    with open(env["MICI_AMD_BENCH_SIDECAR"]) as fh:
+        full = json.load(fh)
+    assert line["n_gpus"] == world and line["steps"] == steps and line["scaling"] == "weak"
+    assert len(full["rank_elapsed_s"]["per_rank"]) == world  # eight rank processes reported their clocks
+    assert full["rank_elapsed_s"]["max"] == max(full["rank_elapsed_s"]["per_rank"])
+    assert line["config"]["n_ranks_seen"] == world
+    assert line["config"]["chains_total"] == world * n_local
+    assert "host gather" in line["config"]["trace_gather"]
+    gathered = np.load(dump)
+    expect = _single_process_shards(config, world, n_local, traj, steps)
+    assert gathered.shape == expect.shape == (world * n_local, expect.shape[1])
+    assert np.array_equal(gathered, expect), "gathered trace differs from the eight shards recomputed in-process"
+    assert wall < 120.0, f"8-rank launch took {wall:.0f} s"
