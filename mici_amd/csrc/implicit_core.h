@@ -242,6 +242,19 @@ enum { RS_U = 0, RS_R, RS_D, RS_COUNT };
 constexpr int kRefineMaxIter = MM_REFINE_MAX_ITER;
 constexpr double kRefineTol2 = 1e-28;  // (relative energy-norm error)^2
 
+// A backend may apply a cheaper form of the held inverse as the PRECONDITIONER of the refinement solves: bk.precond(r) instead
+// of bk.matvec(r) for z = F r (the global-memory tier's FP32 copy: half the HBM bytes of the pass).  Any symmetric
+// positive-definite F preconditions CG to the same solution.
+template <class BK, class = void>
+struct precond_trait { static constexpr bool value = false; };
+template <class BK>
+struct precond_trait<BK, decltype((void)&BK::precond)> { static constexpr bool value = true; };
+template <class BK>
+__device__ __forceinline__ double apply_precond(BK& bk, double r) {
+  if constexpr (precond_trait<BK>::value) return bk.precond(r);
+  else return bk.matvec(r);
+}
+
 // CG iterations k, k + 1, ... of the system whose state (u, r, d) sits in rslot(S * RS_COUNT + RS_*), at the point last
 // published with metric_point(); rz = r^T F r on entry.  true: converged.
 template <class BK, int S>
@@ -262,7 +275,7 @@ __device__ __forceinline__ bool refine_iterate(BK& bk, double rz, const double p
     const double rv = __builtin_fma(-al, q, bk.rslot(B0 + RS_R));
     bk.rslot(B0 + RS_R) = rv;
     prof(bk, PH_FAPPLY);
-    const double z = bk.matvec(rv);
+    const double z = apply_precond(bk, rv);
     prof(bk, PH_RSUM);
     ++pairs;
     // (the scale p^T u of the relative test stays the first guess' - the guess is good to 1e-2 or better and the test
@@ -287,7 +300,7 @@ __device__ __forceinline__ bool refine_solve(BK& bk, double x, double rhs, doubl
   double rv = rhs - bk.metric_apply(guess);
   bk.rslot(RS_R) = rv;
   prof(bk, PH_FAPPLY);
-  double z = bk.matvec(rv);
+  double z = apply_precond(bk, rv);
   prof(bk, PH_RSUM);
   double rz, pu;
   bk.sum2(rv * z, rhs * guess, &rz, &pu);

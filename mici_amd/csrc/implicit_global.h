@@ -78,6 +78,12 @@ struct GlobalBackend {
   double inv_dim_;
   double* lds;
   double* A;            // this chain's DP x DP workspace (row-major, leading dimension dp)
+  // Round 6: the held inverse a second time in FP32, scaled by a power of two so that its largest (a diagonal) entry is ~1:
+  // the PRECONDITIONER of the refinement solves (implicit_core.h refine_solve: z = F r) - half the bytes of the pass that a
+  // CG pair spends most of its time in.  CG converges to the same 1e-14 with any symmetric positive-definite F; everything
+  // that needs M(x0)^-1 itself (the momentum solves, the A / C sub-steps, the vector-Jacobian products) reads the FP64 matrix.
+  float* Af;
+  double pscale_;       // F = pscale_ * Af
   const double* base;   // rank-one metric: base matrix [dim][dim]; user metric: its params
   const double* tparams;
   double st_[SL_COUNT_REFINE];  // the step's flat per-thread state: registers (every index is a compile-time constant)
@@ -118,21 +124,45 @@ struct GlobalBackend {
     __syncthreads();
   }
 
-  // y_i = sum_{j < n} Mat[j * ld + i] nat_j : a column walk (coalesced over the threads for every j, nat_j broadcast)
-  __device__ __forceinline__ double column_walk(const double* __restrict__ mat, int ld, int n) const {
-    if (tid >= dim) return 0.0;
-    const double* col = mat + tid;
-    const double* nat = lds + kOffNat;
-    double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
-    int j = 0;
-    for (; j + 4 <= n; j += 4) {
-      y0 = __builtin_fma(col[(size_t)j * ld], nat[j], y0);
-      y1 = __builtin_fma(col[(size_t)(j + 1) * ld], nat[j + 1], y1);
-      y2 = __builtin_fma(col[(size_t)(j + 2) * ld], nat[j + 2], y2);
-      y3 = __builtin_fma(col[(size_t)(j + 3) * ld], nat[j + 3], y3);
+  // y_i = sum_{j < n} Mat[j * ld + i] nat_j : a column walk (coalesced over the threads for every j, nat_j broadcast).
+  // Round 6: a product is a chain of dependent HBM round trips per thread - with four loads in flight on 512 of the 1024
+  // threads a 2 MB pass took 180 us (11 GB/s a CU).  Now kWalk = 8 loads in flight a thread, and while the workgroup has two
+  // threads a column (2 D <= 1024) the rows are split between them, the two partial sums meeting in the idle W panel.
+  static constexpr int kWalk = 8;
+  template <class T>
+  __device__ __forceinline__ double column_walk(const T* __restrict__ mat, int ld, int n) {
+    const bool two = 2 * dim <= NT;  // (team-uniform)
+    const int h = (two && tid >= NT / 2) ? 1 : 0;
+    const int c = tid - h * (NT / 2);
+    const int nh = two ? ((n + 1) >> 1) : n;
+    const int j0 = h * nh, j1 = (j0 + nh < n) ? j0 + nh : n;
+    double y[kWalk];
+#pragma unroll
+    for (int e = 0; e < kWalk; ++e) y[e] = 0.0;
+    if (c < dim) {
+      const T* col = mat + c;
+      const double* nat = lds + kOffNat;
+      int j = j0;
+      for (; j + kWalk <= j1; j += kWalk) {
+        T a[kWalk];
+#pragma unroll
+        for (int e = 0; e < kWalk; ++e) a[e] = col[(size_t)(j + e) * ld];
+#pragma unroll
+        for (int e = 0; e < kWalk; ++e) y[e] = __builtin_fma((double)a[e], nat[j + e], y[e]);
+      }
+      for (; j < j1; ++j) y[0] = __builtin_fma((double)col[(size_t)j * ld], nat[j], y[0]);
     }
-    for (; j < n; ++j) y0 = __builtin_fma(col[(size_t)j * ld], nat[j], y0);
-    return (y0 + y1) + (y2 + y3);
+#pragma unroll
+    for (int hh = kWalk / 2; hh >= 1; hh >>= 1)
+#pragma unroll
+      for (int e = 0; e < hh; ++e) y[e] += y[e + hh];
+    if (!two) return c < dim ? y[0] : 0.0;
+    double* part = lds + kOffW;  // [2][NT / 2]  (no sweep is in flight while a product runs)
+    part[tid] = y[0];
+    __syncthreads();
+    const double r = tid < dim ? part[tid] + part[NT / 2 + tid] : 0.0;
+    __syncthreads();  // (the next product rewrites the partials)
+    return r;
   }
 
   // ---- metric_func(x) into the workspace (identity on the padding); false: an entry is not finite -------------------
@@ -350,8 +380,14 @@ struct GlobalBackend {
     }
     // A = -M^-1 in the lower triangle: one more pass turns the sign and mirrors it into the upper triangle (1 / (D / NB) of the
     // sweep's traffic), so that the workspace IS the explicit inverse - what the products' column walks and a user's
-    // vector-Jacobian product (through its dense accessor V(i, j)) read
+    // vector-Jacobian product (through its dense accessor V(i, j)) read - and writes the scaled FP32 copy next to it
     {
+      // the largest entry of a positive-definite matrix is on its diagonal: its binary exponent scales the FP32 copy
+      const double dmax = reduce(tid < dim ? fabs(A[(size_t)tid * dp + tid]) : 0.0, true);
+      int ex = 0;
+      if (dmax > 0.0 && dmax < 1.7e308) (void)frexp(dmax, &ex);
+      const double sdown = ldexp(1.0, -ex);
+      pscale_ = ldexp(1.0, ex);
       const int lane = tid & 63, wave = tid >> 6;
       const int g = lane >> 4, j = lane & 15;
       const int ntiles = nt * (nt + 1) / 2;
@@ -365,10 +401,16 @@ struct GlobalBackend {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = -A[(size_t)(16 * I + 4 * r + g) * dp + 16 * J + j];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) A[(size_t)(16 * I + 4 * r + g) * dp + 16 * J + j] = v[r];
+        for (int r = 0; r < 4; ++r) {
+          A[(size_t)(16 * I + 4 * r + g) * dp + 16 * J + j] = v[r];
+          Af[(size_t)(16 * I + 4 * r + g) * dp + 16 * J + j] = (float)(v[r] * sdown);
+        }
         if (I != J) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) A[(size_t)(16 * J + j) * dp + 16 * I + 4 * r + g] = v[r];
+          for (int r = 0; r < 4; ++r) {
+            A[(size_t)(16 * J + j) * dp + 16 * I + 4 * r + g] = v[r];
+            Af[(size_t)(16 * J + j) * dp + 16 * I + 4 * r + g] = (float)(v[r] * sdown);
+          }
         }
       }
     }
@@ -387,6 +429,11 @@ struct GlobalBackend {
   __device__ __forceinline__ double matvec(double v) {
     publish(v);
     return column_walk(A, dp, dim);
+  }
+  // z = F r of the refinement solves (implicit_core.h precond_trait): the scaled FP32 copy
+  __device__ __forceinline__ double precond(double v) {
+    publish(v);
+    return pscale_ * column_walk(Af, dp, dim);
   }
   __device__ __forceinline__ double diag() const { return tid < dim ? A[(size_t)tid * dp + tid] : 0.0; }
   // ---- refinement products: M(x) v matrix-free ---------------------------------------------------------------------------
@@ -558,6 +605,9 @@ __device__ __forceinline__ void init_backend(GlobalBackend<RMETRIC, NB>& bk, con
   bk.inv_dim_ = 1.0 / (double)A.dim;
   bk.lds = lds;
   bk.A = A.work + (size_t)blockIdx.x * bk.dp * bk.dp;
+  // (the FP32 copies behind the n_chains FP64 matrices: the hosts size the workspace at 12 bytes an entry)
+  bk.Af = reinterpret_cast<float*>(A.work + (size_t)A.n_chains * bk.dp * bk.dp) + (size_t)blockIdx.x * bk.dp * bk.dp;
+  bk.pscale_ = 1.0;
   bk.base = A.rparams;
   bk.tparams = A.tparams;
   bk.refine_on = A.no_refine == 0;

@@ -29,7 +29,8 @@ int fill_args(mm_ctx* ctx, const mm_model* m, mm_state* s, ImplicitArgs& a) {
   a.tparams = m->d_target_params;
   a.rparams = m->d_rmetric_params;  // rank-one metric: the base matrix [dim][dim], read as it is
   const size_t dp = (size_t)padded_dim(m->dim);
-  const int rc = mm_state_ensure_work(ctx, s, (size_t)s->n * dp * dp * sizeof(double));  // the chains' matrices, in HBM
+  // the chains' matrices, in HBM: FP64, and the FP32 copy of the held inverse behind them (implicit_global.h precond)
+  const int rc = mm_state_ensure_work(ctx, s, (size_t)s->n * dp * dp * (sizeof(double) + sizeof(float)));
   if (rc != MM_OK) return rc;
   a.work = static_cast<double*>(s->d_work);
   return MM_OK;
