@@ -30,15 +30,18 @@ using namespace mmimp;
 
 constexpr int NT = 1024;      // threads per chain = largest D
 constexpr int DPMAX = 1024;
-// Pivots per block of the sweep: the two panels (2 x NB x DP doubles) must fit a CU's LDS - 16 pivots up to DP = 512 (half the
-// passes over the matrix), 8 beyond.  LDS (doubles): one natural-order vector, the pivot block and its inverse, flags, two sets
-// of reduction partials, then the two panels with a pitch of DP.
-constexpr int kPanelDoubles = 2 * 8 * DPMAX;   // = 2 * 16 * 512
+// Pivots per block of the sweep: the panel X (NB x DP doubles) must fit a CU's LDS - 32 pivots up to DP = 512, 16 beyond
+// (round 6: the second panel W = P^-1 X is no longer stored - a wave forms the W operands of its tile row on the matrix
+// cores from X and the inverted pivot block - so the one panel that is left can hold twice the pivots: half the passes over
+// the matrix).  LDS (doubles): one natural-order vector, the pivot block and its inverse, flags, two sets of reduction
+// partials, then the panel with a pitch of DP.
+constexpr int kPanelDoubles = 16 * DPMAX;      // = 32 * 512
 constexpr int kOffNat = 0;                     // [DPMAX + 8]
-constexpr int kOffPb = kOffNat + DPMAX + 8;    // [16 * 16] pivot block, inverted in place
-constexpr int kOffFlag = kOffPb + 256;         // [8] flags / log det of the block
+constexpr int kOffPb = kOffNat + DPMAX + 8;    // [32 * 32] pivot block, inverted in place
+constexpr int kOffFlag = kOffPb + 1024;        // [8] flags / log det of the block
 constexpr int kOffRed = kOffFlag + 8;          // [2][16]
-constexpr int kOffX = kOffRed + 32;            // [NB][pitch]  X = Q - E
+constexpr int kOffRC = kOffRed + 32;           // [2][2][32] pivot row / column of the pivot-block inversion, double-buffered
+constexpr int kOffX = kOffRC + 128;            // [NB][pitch]  X = Q - E
 constexpr int kLdsDoubles = kOffX + kPanelDoubles;
 static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU");
 // a user metric (user_metric.h) adds the point of the HELD inverse in natural order and its aux block (they outlive the
@@ -67,8 +70,9 @@ struct TeamOfGlobal {  // the workgroup as a team (user_metric.h mm_user_prepare
 
 template <int RMETRIC, int NB>
 struct GlobalBackend {
-  static constexpr int PITCH = kPanelDoubles / (2 * NB);  // panel row pitch: 1024 (NB = 8), 512 (NB = 16)
-  static constexpr int kOffW = kOffX + NB * PITCH;
+  static constexpr int PITCH = kPanelDoubles / NB;  // panel row pitch: 1024 (NB = 16), 512 (NB = 32)
+  static constexpr int kOffPart = kOffX + kPanelDoubles / 2;  // [NT] partial sums of the products (the panel is idle then)
+  static constexpr int CB = NB > 16 ? 16 : NB;               // pivots per block of the Cholesky factorisation (sample_momentum)
   static constexpr bool kSolveByInverse = true;   // implicit_core.h: a factorised solve = invert + product
   static constexpr bool kUnifiedConstruct = false;
   static constexpr bool kCountersInLds = false;
@@ -157,7 +161,7 @@ struct GlobalBackend {
 #pragma unroll
       for (int e = 0; e < hh; ++e) y[e] += y[e + hh];
     if (!two) return c < dim ? y[0] : 0.0;
-    double* part = lds + kOffW;  // [2][NT / 2]  (no sweep is in flight while a product runs)
+    double* part = lds + kOffPart;  // [2][NT / 2]  (no sweep is in flight while a product runs)
     part[tid] = y[0];
     __syncthreads();
     const double r = tid < dim ? part[tid] + part[NT / 2 + tid] : 0.0;
@@ -196,13 +200,14 @@ struct GlobalBackend {
 
   // A[i][j] -= sum_k Wp[k][i] Xp[k][j] over the whole matrix: thread (tx, ty) owns the elements (ty + 32 a, tx + 32 b),
   // 2 x 2 of them at a time (the panels' sixteen + sixteen operands of a 2 x 2 tile come from LDS once)
+  template <int KB>
   __device__ __forceinline__ void rank_update(const double* __restrict__ Wp, const double* __restrict__ Xp) {
     const int tx = tid & 31, ty = tid >> 5;
     for (int a = 0; a < dp / 32; a += 2) {
       const int i0 = ty + 32 * a, i1 = i0 + 32;
-      double w0[NB], w1[NB];
+      double w0[KB], w1[KB];
 #pragma unroll
-      for (int k = 0; k < NB; ++k) {
+      for (int k = 0; k < KB; ++k) {
         w0[k] = Wp[k * PITCH + i0];
         w1[k] = Wp[k * PITCH + i1];
       }
@@ -212,7 +217,7 @@ struct GlobalBackend {
         double* p10 = A + (size_t)i1 * dp + j0;
         double a00 = p00[0], a01 = p00[32], a10 = p10[0], a11 = p10[32];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
+        for (int k = 0; k < KB; ++k) {
           const double x0 = Xp[k * PITCH + j0], x1 = Xp[k * PITCH + j1];
           a00 = __builtin_fma(-w0[k], x0, a00);
           a01 = __builtin_fma(-w0[k], x1, a01);
@@ -229,22 +234,26 @@ struct GlobalBackend {
 
   // ---- the sweep's block update on the MATRIX CORES, lower triangle only (round 6) ---------------------------------------------
   // A is symmetric and the sweep keeps it so: only the 16 x 16 tiles (I, J) with I >= J are read and written - half the HBM
-  // traffic of a pass - as  tile += (-W)[:, tile I]^T X[:, tile J],  NB / 4 v_mfma_f64_16x16x4_f64 a tile with both operands
-  // straight from the LDS panels in the instruction's own layouts (A operand: lane (i = l % 16, k = l / 16) <- Wn[k][16 I + i];
-  // B operand: lane (k = l / 16, j = l % 16) <- X[k][16 J + j]; accumulator: lane 16 g + j, register r <-> tile entry
-  // (4 r + g, j), i.e. four 128-byte row segments a load).  A wave owns tile rows I and nt - 1 - I (nt + 1 tiles: every wave the
-  // same work), keeps the row's W operands in registers and streams the tiles kTJ at a time (kTJ x 2 KB in flight a wave).
+  // traffic of a pass - as  tile += (-W)[:, tile I]^T X[:, tile J],  NB / 4 v_mfma_f64_16x16x4_f64 a tile.  Operand layouts of
+  // the instruction: A operand lane (i = l % 16, k = l / 16); B operand lane (k = l / 16, j = l % 16); accumulator lane
+  // 16 g + j, register r <-> tile entry (4 r + g, j), i.e. four 128-byte row segments a global load.
+  // A wave owns tile rows I and nt - 1 - I (nt + 1 tiles: every wave the same work).  For a tile row it first forms its W
+  // operands ITSELF:  W[:, tile I] = P^-1 X[:, tile I]  is NB / 16 accumulator tiles of (NB / 4) instructions (A operand: the
+  // symmetric P^-1 from LDS, B operand: X from LDS) - and register r of accumulator tile t, negated, IS the A operand of
+  // k-step 4 t + r of the update (entry (4 r + g, j) of W's tile = W[16 t + 4 r + g][16 I + j] on lane 16 g + j: the layout the
+  // instruction wants for W^T).  No W panel in LDS, no pass of the workgroup to compute it, no barrier for it.
+  // Then the row's tiles stream kTJ at a time (kTJ x 2 KB in flight a wave), B operands from the X panel.
   // The NEXT block's panel is rows K' of the matrix, all columns: their part right of the diagonal block is the transpose of
-  // tile column jn = K' / 16 below the diagonal, so those tiles are ALSO stored transposed into the upper triangle (one tile
-  // column a block: 1 / nt of the traffic).  Everything else of the upper triangle is stale until invert()'s last pass mirrors
-  // the finished lower triangle.
-  static constexpr int kTJ = 4;
+  // the tile columns [jn0, jn1) below the diagonal, so those tiles are ALSO stored transposed into the upper triangle (NB / 16
+  // tile columns a block).  Everything else of the upper triangle is stale until invert()'s last pass mirrors the finished
+  // lower triangle.
+  static constexpr int kTJ = 2;
   typedef double d4 __attribute__((ext_vector_type(4)));
-  __device__ __forceinline__ void rank_update_mfma(const double* __restrict__ Wn, const double* __restrict__ Xp, const int nt,
-                                                   const int jn) {
-    const int lane = tid & 63, wave = tid >> 6;
+  __device__ __forceinline__ void rank_update_mfma(const double* __restrict__ Xp, const double* __restrict__ pinv, const int nt,
+                                                   const int jn0, const int jn1) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the tile loops branch on it)
     const int g = lane >> 4, j = lane & 15;
-    constexpr int KS = NB / 4;
+    constexpr int KS = NB / 4, KT = NB / 16;
     const int npair = (nt + 1) / 2;
     for (int pr = wave; pr < npair; pr += NT / 64) {
 #pragma unroll 1
@@ -252,17 +261,38 @@ struct GlobalBackend {
         const int I = side == 0 ? pr : nt - 1 - pr;
         if (side == 1 && I == pr) break;  // (odd nt: the middle row once)
         double a[KS];
+        {
+          d4 wt[KT];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) a[s] = Wn[(4 * s + g) * PITCH + 16 * I + j];
+          for (int t = 0; t < KT; ++t) wt[t] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            const double xb = Xp[(4 * s + g) * PITCH + 16 * I + j];
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+              wt[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pinv[(16 * t + j) * NB + 4 * s + g], xb, wt[t], 0, 0, 0);
+          }
+#pragma unroll
+          for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[4 * t + r] = -wt[t][r];
+        }
         double* const arow = A + (size_t)(16 * I + g) * dp + j;  // entry (16 I + 4 r + g, 16 J + j) at arow[4 r dp + 16 J]
+        // the row's tiles kTJ at a time, the NEXT chunk's loads issued before this chunk's instructions and stores
+        d4 c[kTJ], cn[kTJ];
+#pragma unroll
+        for (int u = 0; u < kTJ; ++u)
+          if (u <= I) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[u][r] = arow[(size_t)(4 * r) * dp + 16 * u];
+          }
 #pragma unroll 1
         for (int J0 = 0; J0 <= I; J0 += kTJ) {
-          d4 c[kTJ];
 #pragma unroll
           for (int u = 0; u < kTJ; ++u)
-            if (J0 + u <= I) {
+            if (J0 + kTJ + u <= I) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) c[u][r] = arow[(size_t)(4 * r) * dp + 16 * (J0 + u)];
+              for (int r = 0; r < 4; ++r) cn[u][r] = arow[(size_t)(4 * r) * dp + 16 * (J0 + kTJ + u)];
             }
 #pragma unroll
           for (int u = 0; u < kTJ; ++u)
@@ -276,57 +306,61 @@ struct GlobalBackend {
 #pragma unroll
           for (int u = 0; u < kTJ; ++u)
             if (J0 + u <= I) {
+              const int J = J0 + u;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) arow[(size_t)(4 * r) * dp + 16 * (J0 + u)] = c[u][r];
-              if (J0 + u == jn && I > jn) {  // (wave-uniform) the next panel's rows, right of their diagonal block
+              for (int r = 0; r < 4; ++r) arow[(size_t)(4 * r) * dp + 16 * J] = c[u][r];
+              if (J >= jn0 && J < jn1 && I > J) {  // (wave-uniform) the next panel's rows, right of their diagonal tile
 #pragma unroll
-                for (int r = 0; r < 4; ++r) A[(size_t)(16 * jn + j) * dp + 16 * I + 4 * r + g] = c[u][r];
+                for (int r = 0; r < 4; ++r) A[(size_t)(16 * J + j) * dp + 16 * I + 4 * r + g] = c[u][r];
               }
             }
+#pragma unroll
+          for (int u = 0; u < kTJ; ++u) c[u] = cn[u];
         }
       }
     }
   }
 
-  // the NB x NB pivot block in LDS (pb), by the first wave: in-place Gauss-Jordan inverse (no pivoting: the block is a
-  // Schur complement of a positive-definite matrix), its pivots = the Cholesky pivots squared.  flag[0] = 1 unless all
-  // pivots are positive and finite, flag[1] = sum of their logarithms.
+  // the NB x NB pivot block in LDS (pb): in-place Gauss-Jordan inverse (no pivoting: the block is a Schur complement of a
+  // positive-definite matrix), its pivots = the Cholesky pivots squared.  flag[0] = 1 unless all pivots are positive and
+  // finite, flag[1] = sum of their logarithms.  Round 6: by the WHOLE workgroup, one element a thread held in a register across
+  // the NB elimination steps - a step publishes only the current pivot row and column (64 doubles, double-buffered: one
+  // barrier a step); one wave walking 16 elements a lane through LDS took 27 % of a sweep.  Called by every thread.
   __device__ __forceinline__ void invert_pivot_block() {
     double* pb = lds + kOffPb;
     double* flag = lds + kOffFlag;
-    constexpr int EPL = NB * NB / 64;  // elements per lane of the first wave
-    if (tid < 64) {
-      double bad = 0.0, ld = 0.0;
+    double* rc = lds + kOffRC;
+    const bool act = tid < NB * NB;
+    const int r = tid / NB, c = tid % NB;
+    double p = act ? pb[tid] : 0.0;
+    double mypiv = 1.0;
+    bool bad = false;
 #pragma unroll 1
-      for (int k = 0; k < NB; ++k) {
-        const double piv = pb[k * NB + k];
-        double prk[EPL], pkc[EPL], prc[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          const int idx = tid + 64 * e, r = idx / NB, c = idx % NB;
-          prk[e] = pb[r * NB + k];
-          pkc[e] = pb[k * NB + c];
-          prc[e] = pb[idx];
-        }
-        wave_sync();
-        if (!(piv > 0.0) || !(piv < 1.7e308)) bad = 1.0;
-        ld += log(piv);
-        const double d = 1.0 / piv;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          const int idx = tid + 64 * e, r = idx / NB, c = idx % NB;
-          double v;
-          if (r == k && c == k) v = d;
-          else if (r == k) v = prc[e] * d;
-          else if (c == k) v = -prc[e] * d;
-          else v = __builtin_fma(-prk[e] * d, pkc[e], prc[e]);
-          pb[idx] = v;
-        }
-        wave_sync();
+    for (int k = 0; k < NB; ++k) {
+      double* b = rc + (k & 1) * 64;
+      if (act && r == k) b[c] = p;
+      if (act && c == k) b[32 + r] = p;
+      __syncthreads();
+      const double piv = b[k];
+      if (!(piv > 0.0) || !(piv < 1.7e308)) bad = true;
+      if (tid == k) mypiv = piv;
+      const double d = 1.0 / piv;
+      if (act) {
+        const double pkc = b[c], prk = b[32 + r];
+        double v;
+        if (r == k && c == k) v = d;
+        else if (r == k) v = p * d;
+        else if (c == k) v = -p * d;
+        else v = __builtin_fma(-prk * d, pkc, p);
+        p = v;
       }
+    }
+    if (act) pb[tid] = p;
+    if (tid < 64) {  // (threads 0 .. NB - 1 hold the pivots)
+      const double l = wave_sum(tid < NB ? log(mypiv) : 0.0);
       if (tid == 0) {
-        flag[0] = bad;
-        flag[1] = ld;
+        flag[0] = bad ? 1.0 : 0.0;
+        flag[1] = l;
       }
     }
   }
@@ -334,49 +368,49 @@ struct GlobalBackend {
   // ---- explicit inverse of the matrix build() left in the workspace: A <- -M^-1 ------------------------------------------
   __device__ __forceinline__ bool invert(double* logdet) {
     double* Xp = lds + kOffX;
-    double* Wp = lds + kOffW;
     double* pb = lds + kOffPb;
     const double* flag = lds + kOffFlag;
     bool ok = true;
     double ld = 0.0;
-    static_assert(NB == 8 || NB == 16, "pivot-block inversion: NB * NB a multiple of 64");
+    static_assert(NB == 16 || NB == 32, "pivot block: whole 16 x 16 tiles");
     const int nblk = (dim + NB - 1) / NB;  // (the padding beyond is the identity, decoupled from the rest)
     const int nt = (dim + 15) >> 4;        // 16 x 16 tiles a side that hold anything but that identity
+#ifdef MM_GLOB_PROF
+    long long pc[5] = {0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter();
+#define MM_GP(i) { const long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - pt; pt = now_; }
+#else
+#define MM_GP(i)
+#endif
     for (int blk = 0; blk < nblk; ++blk) {
       const int k0 = blk * NB;
       // (1) the panel: rows k0 .. k0 + NB - 1 of A (coalesced), X = Q - E, and the pivot block
-      if (tid < dp) {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-          const double v = A[(size_t)(k0 + k) * dp + tid];
-          Xp[k * PITCH + tid] = (tid == k0 + k) ? v - 1.0 : v;
-          if (tid >= k0 && tid < k0 + NB) pb[k * NB + (tid - k0)] = v;
+      {
+        const int nrep = NT / dp;  // threads a column: 1 (DP > 512), 2, 3 (DP = 320) - each takes every nrep-th row
+        if (tid < nrep * dp) {
+          const int h = tid / dp, col = tid - h * dp;
+#pragma unroll 8
+          for (int k = h; k < NB; k += nrep) {
+            const double v = A[(size_t)(k0 + k) * dp + col];
+            Xp[k * PITCH + col] = (col == k0 + k) ? v - 1.0 : v;
+            if (col >= k0 && col < k0 + NB) pb[k * NB + (col - k0)] = v;
+          }
         }
       }
       __syncthreads();
-      // (2) P^-1 (first wave), (3) W = P^-1 X column by column
+      MM_GP(0)
+      // (2) P^-1 (first wave)
       invert_pivot_block();
       __syncthreads();
+      MM_GP(1)
       if (flag[0] != 0.0) ok = false;  // (uniform: every thread reads the same cell)
       ld += flag[1];
-      if (tid < dp) {
-        double x[NB];
-#pragma unroll
-        for (int k = 0; k < NB; ++k) x[k] = Xp[k * PITCH + tid];
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-          double s = pb[k * NB] * x[0];
-#pragma unroll
-          for (int l = 1; l < NB; ++l) s = __builtin_fma(pb[k * NB + l], x[l], s);
-          Wp[k * PITCH + tid] = -s;  // (-W: the matrix cores accumulate)
-        }
-      }
+      // (3) A -= (P^-1 X)^T X on the lower-triangle tiles (matrix cores; the W operands formed per tile row), then A_KK -= 2 I
+      rank_update_mfma(Xp, pb, nt, (k0 + NB) >> 4, (k0 + 2 * NB) >> 4);
       __syncthreads();
-      // (4) A -= W^T X on the lower-triangle tiles (matrix cores), then A_KK -= 2 I
-      rank_update_mfma(Wp, Xp, nt, (k0 + NB) >> 4);
-      __syncthreads();
+      MM_GP(2)
       if (tid < NB) A[(size_t)(k0 + tid) * dp + k0 + tid] -= 2.0;
       __syncthreads();
+      MM_GP(3)
     }
     // A = -M^-1 in the lower triangle: one more pass turns the sign and mirrors it into the upper triangle (1 / (D / NB) of the
     // sweep's traffic), so that the workspace IS the explicit inverse - what the products' column walks and a user's
@@ -415,6 +449,12 @@ struct GlobalBackend {
       }
     }
     __syncthreads();
+    MM_GP(4)
+#ifdef MM_GLOB_PROF
+    if (tid == 0 && blockIdx.x == 0)
+      printf("invert: panel %lld  pivot %lld  update %lld  diag %lld  mirror %lld cycles (%d blocks)\n", pc[0], pc[1], pc[2], pc[3],
+             pc[4], nblk);
+#endif
     if (logdet) *logdet = ld;
     // a NaN pivot poisons W and with it the whole matrix; a non-positive one is caught by the flag
     return ok && (ld == ld);
@@ -538,26 +578,26 @@ struct GlobalBackend {
     double* pb = lds + kOffPb;
     const double* flag = lds + kOffFlag;
     bool ok = true;
-    const int nblk = (dim + NB - 1) / NB;
+    const int nblk = (dim + CB - 1) / CB;
     for (int blk = 0; blk < nblk; ++blk) {
-      const int k0 = blk * NB;
-      if (tid >= k0 && tid < k0 + NB) {
+      const int k0 = blk * CB;
+      if (tid >= k0 && tid < k0 + CB) {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) pb[k * NB + (tid - k0)] = A[(size_t)(k0 + k) * dp + tid];
+        for (int k = 0; k < CB; ++k) pb[k * CB + (tid - k0)] = A[(size_t)(k0 + k) * dp + tid];
       }
       __syncthreads();
-      if (tid == 0) {  // the 8 x 8 block's own Cholesky factor, in place (lower triangle of pb), sequentially
+      if (tid == 0) {  // the CB x CB block's own Cholesky factor, in place (lower triangle of pb), sequentially
         double bad = 0.0;
-        for (int j = 0; j < NB; ++j) {
-          double d = pb[j * NB + j];
-          for (int m = 0; m < j; ++m) d -= pb[j * NB + m] * pb[j * NB + m];
+        for (int j = 0; j < CB; ++j) {
+          double d = pb[j * CB + j];
+          for (int m = 0; m < j; ++m) d -= pb[j * CB + m] * pb[j * CB + m];
           if (!(d > 0.0) || !(d < 1.7e308)) bad = 1.0;
           const double l = sqrt(d);
-          pb[j * NB + j] = l;
-          for (int i = j + 1; i < NB; ++i) {
-            double s = pb[i * NB + j];
-            for (int m = 0; m < j; ++m) s -= pb[i * NB + m] * pb[j * NB + m];
-            pb[i * NB + j] = s / l;
+          pb[j * CB + j] = l;
+          for (int i = j + 1; i < CB; ++i) {
+            double s = pb[i * CB + j];
+            for (int m = 0; m < j; ++m) s -= pb[i * CB + m] * pb[j * CB + m];
+            pb[i * CB + j] = s / l;
           }
         }
         lds[kOffFlag] = bad;
@@ -567,28 +607,28 @@ struct GlobalBackend {
       // column j of the panel: y = Lkk^-1 A[K, j] (forward substitution) = L[j][K]^T for j beyond the block; inside the
       // block the factor itself.  Zero left of the block (so that the full-range trailing update leaves those parts alone).
       if (tid < dp) {
-        double y[NB];
-        if (tid >= k0 + NB) {
+        double y[CB];
+        if (tid >= k0 + CB) {
 #pragma unroll
-          for (int k = 0; k < NB; ++k) {
+          for (int k = 0; k < CB; ++k) {
             double s = A[(size_t)(k0 + k) * dp + tid];
 #pragma unroll
-            for (int m = 0; m < NB; ++m)
-              if (m < k) s -= pb[k * NB + m] * y[m];
-            y[k] = s / pb[k * NB + k];
+            for (int m = 0; m < CB; ++m)
+              if (m < k) s -= pb[k * CB + m] * y[m];
+            y[k] = s / pb[k * CB + k];
           }
         } else {
 #pragma unroll
-          for (int k = 0; k < NB; ++k) y[k] = (tid >= k0 && tid - k0 >= k) ? pb[(tid - k0) * NB + k] : 0.0;
+          for (int k = 0; k < CB; ++k) y[k] = (tid >= k0 && tid - k0 >= k) ? pb[(tid - k0) * CB + k] : 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-          Xp[k * PITCH + tid] = tid >= k0 + NB ? y[k] : 0.0;
+        for (int k = 0; k < CB; ++k) {
+          Xp[k * PITCH + tid] = tid >= k0 + CB ? y[k] : 0.0;
           if (tid >= k0) A[(size_t)(k0 + k) * dp + tid] = y[k];  // row k0 + k of A <- L[:, k0 + k]
         }
       }
       __syncthreads();
-      rank_update(Xp, Xp);  // trailing A[i][j] -= sum_k L[i][k] L[j][k] (zero panel entries elsewhere)
+      rank_update<CB>(Xp, Xp);  // trailing A[i][j] -= sum_k L[i][k] L[j][k] (zero panel entries elsewhere)
       __syncthreads();
     }
     return ok;

@@ -49,13 +49,13 @@ int launch(mm_ctx* ctx, K kernel, const ImplicitArgs& a) {
 
 }  // namespace
 
-// NB = 16 pivots per pass while the two panels fit the LDS (padded dimension <= 512), 8 beyond
+// NB = 32 pivots per pass while the panel fits the LDS (padded dimension <= 512), 16 beyond
 #define MM_GLOB_DISPATCH(KERNEL, ...)                                                              \
   (padded_dim(m->dim) <= 512                                                                       \
-       ? (m->rmetric == MM_RMETRIC_RANK1 ? launch(ctx, KERNEL<MM_RMETRIC_RANK1, 16, __VA_ARGS__>, a)    \
-                                         : launch(ctx, KERNEL<MM_RMETRIC_DIAGQUAD, 16, __VA_ARGS__>, a)) \
-       : (m->rmetric == MM_RMETRIC_RANK1 ? launch(ctx, KERNEL<MM_RMETRIC_RANK1, 8, __VA_ARGS__>, a)     \
-                                         : launch(ctx, KERNEL<MM_RMETRIC_DIAGQUAD, 8, __VA_ARGS__>, a)))
+       ? (m->rmetric == MM_RMETRIC_RANK1 ? launch(ctx, KERNEL<MM_RMETRIC_RANK1, 32, __VA_ARGS__>, a)    \
+                                         : launch(ctx, KERNEL<MM_RMETRIC_DIAGQUAD, 32, __VA_ARGS__>, a)) \
+       : (m->rmetric == MM_RMETRIC_RANK1 ? launch(ctx, KERNEL<MM_RMETRIC_RANK1, 16, __VA_ARGS__>, a)     \
+                                         : launch(ctx, KERNEL<MM_RMETRIC_DIAGQUAD, 16, __VA_ARGS__>, a)))
 
 static int launch_step(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_fp_opts& opts,
                        mm_counters* d_counters, bool midpoint) {

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_global_tier.py tests/test_gpu_implicit.py -x -q -m gpu -k "global" 2>&1 | tail -5
+MICI_AMD_LIB=mici_amd/lib/ab_globprof.so timeout 300 python tools/time_global.py 2>&1 | grep -v "^$" | head -5
+timeout 500 python tools/time_global.py 2>&1 | tail -3
+timeout 600 python bench.py --config c4_d512 --no-extra-configs --no-cpu-baseline --steps 5 --warmup 1 2>&1 | tail -1 | cut -c1-120
