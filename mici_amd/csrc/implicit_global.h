@@ -39,8 +39,8 @@ constexpr int kPanelDoubles = 16 * DPMAX;      // = 32 * 512
 constexpr int kOffNat = 0;                     // [DPMAX + 8]
 constexpr int kOffPb = kOffNat + DPMAX + 8;    // [32 * 32] pivot block, inverted in place
 constexpr int kOffFlag = kOffPb + 1024;        // [8] flags / log det of the block
-constexpr int kOffRed = kOffFlag + 8;          // [2][16]
-constexpr int kOffRC = kOffRed + 32;           // [2][2][32] pivot row / column of the pivot-block inversion, double-buffered
+constexpr int kOffRed = kOffFlag + 8;          // [2][2][16]  (two sets, two values a reduction)
+constexpr int kOffRC = kOffRed + 64;           // [2][2][32] pivot row / column of the pivot-block inversion, double-buffered
 constexpr int kOffX = kOffRC + 128;            // [NB][pitch]  X = Q - E
 constexpr int kLdsDoubles = kOffX + kPanelDoubles;
 static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU");
@@ -71,13 +71,19 @@ struct TeamOfGlobal {  // the workgroup as a team (user_metric.h mm_user_prepare
 template <int RMETRIC, int NB>
 struct GlobalBackend {
   static constexpr int PITCH = kPanelDoubles / NB;  // panel row pitch: 1024 (NB = 16), 512 (NB = 32)
-  static constexpr int kOffPart = kOffX + kPanelDoubles / 2;  // [NT] partial sums of the products (the panel is idle then)
+  static constexpr int kOffPart = kOffX + kPanelDoubles / 2;  // [2][NT] partial sums of the products (the panel is idle then)
+  static constexpr int kOffNat2 = kOffPart + 2 * NT;          // [DPMAX] the second operand vector of a lock-step pair
   static constexpr int CB = NB > 16 ? 16 : NB;               // pivots per block of the Cholesky factorisation (sample_momentum)
   static constexpr bool kSolveByInverse = true;   // implicit_core.h: a factorised solve = invert + product
   static constexpr bool kUnifiedConstruct = false;
   static constexpr bool kCountersInLds = false;
   static constexpr bool kRefine = true;           // solve-only constructions refined from the held inverse
   bool refine_on;
+  // implicit_core.h refine_solve2 (round 6): the reversibility-check solve and the C-adjoint solve of a step in lock step - here
+  // a product IS a pass over 1 - 2 MB of HBM (or L2, for the shared base matrix), and two right-hand sides share it.  Built-in
+  // metrics (a user metric's M(x) v evaluates its entries per product and point: nothing to share).
+  static constexpr bool kDual = RMETRIC != MM_RMETRIC_USER;
+  bool dual_off;                                  // MICI_AMD_DUAL=0: one solve after the other
   int dim, dp, tid, target, flip;
   double inv_dim_;
   double* lds;
@@ -91,8 +97,8 @@ struct GlobalBackend {
   const double* base;   // rank-one metric: base matrix [dim][dim]; user metric: its params
   const double* tparams;
   double st_[SL_COUNT_REFINE];  // the step's flat per-thread state: registers (every index is a compile-time constant)
-  double rs_[RS_COUNT];
-  double xpt_;                  // this thread's coordinate of the refinement products' point
+  double rs_[2 * RS_COUNT];     // (the second system of a lock-step pair in [RS_COUNT ..])
+  double xpt_, xpt2_;           // this thread's coordinate of the refinement products' point(s)
   __device__ __forceinline__ double& slot(int i) { return st_[i]; }
   __device__ __forceinline__ double& rslot(int i) { return rs_[i]; }
   __device__ __forceinline__ bool flat_active() const { return tid < dim; }
@@ -100,7 +106,7 @@ struct GlobalBackend {
   // ---- workgroup reductions: one barrier each (two sets of partials used alternately, as softabs.h block_reduce4) ------
   __device__ __forceinline__ double reduce(double v, bool use_max) {
     const int lane = tid & 63, wave = tid >> 6;
-    double* const set = lds + kOffRed + 16 * flip;
+    double* const set = lds + kOffRed + 32 * flip;
     flip ^= 1;
     v = use_max ? wave_max(v) : wave_sum(v);
     if (lane == 0) set[wave] = v;
@@ -110,10 +116,46 @@ struct GlobalBackend {
     for (int w = 1; w < NT / 64; ++w) r = use_max ? nanmax(r, set[w]) : r + set[w];
     return r;
   }
+  // two values through ONE barrier
+  __device__ __forceinline__ void reduce2(double a, double b, bool use_max, double* ra, double* rb) {
+    const int lane = tid & 63, wave = tid >> 6;
+    double* const set = lds + kOffRed + 32 * flip;
+    flip ^= 1;
+    a = use_max ? wave_max(a) : wave_sum(a);
+    b = use_max ? wave_max(b) : wave_sum(b);
+    if (lane == 0) {
+      set[wave] = a;
+      set[16 + wave] = b;
+    }
+    __syncthreads();
+    double x = set[0], y = set[16];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) {
+      x = use_max ? nanmax(x, set[w]) : x + set[w];
+      y = use_max ? nanmax(y, set[16 + w]) : y + set[16 + w];
+    }
+    *ra = x;
+    *rb = y;
+  }
   __device__ __forceinline__ double sum1(double a) { return reduce(tid < dim ? a : 0.0, false); }
   __device__ __forceinline__ void sum2(double a, double b, double* sa, double* sb) {
-    *sa = sum1(a);
-    *sb = sum1(b);
+    reduce2(tid < dim ? a : 0.0, tid < dim ? b : 0.0, false, sa, sb);
+  }
+  __device__ __forceinline__ void sum2x(double a, double b, double* sa, double* sb) { sum2(a, b, sa, sb); }
+  __device__ __forceinline__ void sum4(double a, double b, double c, double d, double* sa, double* sb, double* sc, double* sd) {
+    sum2(a, b, sa, sb);
+    sum2(c, d, sc, sd);
+  }
+  __device__ __forceinline__ void norm2(double a, double b, int kind, double* na, double* nb) {
+    const double xa = tid < dim ? a : 0.0, xb = tid < dim ? b : 0.0;
+    if (kind == MM_NORM_LINF) {
+      reduce2(fabs(xa), fabs(xb), true, na, nb);
+    } else {
+      double sa, sb;
+      reduce2(xa * xa, xb * xb, false, &sa, &sb);
+      *na = sqrt(sa);
+      *nb = sqrt(sb);
+    }
   }
   __device__ __forceinline__ double norm(double x, int kind) {
     const double a = tid < dim ? x : 0.0;
@@ -125,6 +167,66 @@ struct GlobalBackend {
   __device__ __forceinline__ void publish(double v) {
     __syncthreads();  // (readers of the previous contents are done)
     lds[kOffNat + tid] = tid < dim ? v : 0.0;
+    __syncthreads();
+  }
+
+  __device__ __forceinline__ void publish2(double v0, double v1) {
+    __syncthreads();
+    lds[kOffNat + tid] = tid < dim ? v0 : 0.0;
+    lds[kOffNat2 + tid] = tid < dim ? v1 : 0.0;
+    __syncthreads();
+  }
+  // two products in one pass over the matrix: every load feeds both accumulators (implicit_core.h refine_solve2)
+  template <class T>
+  __device__ __forceinline__ void column_walk2(const T* __restrict__ mat, int ld, int n, double* r0, double* r1) {
+    const bool two = 2 * dim <= NT;
+    const int h = (two && tid >= NT / 2) ? 1 : 0;
+    const int c = tid - h * (NT / 2);
+    const int nh = two ? ((n + 1) >> 1) : n;
+    const int j0 = h * nh, j1 = (j0 + nh < n) ? j0 + nh : n;
+    constexpr int W2 = kWalk / 2;
+    double y[W2], z[W2];
+#pragma unroll
+    for (int e = 0; e < W2; ++e) y[e] = z[e] = 0.0;
+    if (c < dim) {
+      const T* col = mat + c;
+      const double* nat = lds + kOffNat;
+      const double* nat2 = lds + kOffNat2;
+      int j = j0;
+      for (; j + kWalk <= j1; j += kWalk) {
+        T a[kWalk];
+#pragma unroll
+        for (int e = 0; e < kWalk; ++e) a[e] = col[(size_t)(j + e) * ld];
+#pragma unroll
+        for (int e = 0; e < kWalk; ++e) {
+          y[e % W2] = __builtin_fma((double)a[e], nat[j + e], y[e % W2]);
+          z[e % W2] = __builtin_fma((double)a[e], nat2[j + e], z[e % W2]);
+        }
+      }
+      for (; j < j1; ++j) {
+        const double a = (double)col[(size_t)j * ld];
+        y[0] = __builtin_fma(a, nat[j], y[0]);
+        z[0] = __builtin_fma(a, nat2[j], z[0]);
+      }
+    }
+#pragma unroll
+    for (int hh = W2 / 2; hh >= 1; hh >>= 1)
+#pragma unroll
+      for (int e = 0; e < hh; ++e) {
+        y[e] += y[e + hh];
+        z[e] += z[e + hh];
+      }
+    if (!two) {
+      *r0 = c < dim ? y[0] : 0.0;
+      *r1 = c < dim ? z[0] : 0.0;
+      return;
+    }
+    double* part = lds + kOffPart;  // [2][NT]
+    part[tid] = y[0];
+    part[NT + tid] = z[0];
+    __syncthreads();
+    *r0 = tid < dim ? part[tid] + part[NT / 2 + tid] : 0.0;
+    *r1 = tid < dim ? part[NT + tid] + part[NT + NT / 2 + tid] : 0.0;
     __syncthreads();
   }
 
@@ -475,6 +577,33 @@ struct GlobalBackend {
     publish(v);
     return pscale_ * column_walk(Af, dp, dim);
   }
+  // the lock-step pair's preconditioner products z = F r (refine_solve2 calls nothing else through matvec2): one pass
+  __device__ __forceinline__ void matvec2(double v0, double v1, double* y0, double* y1) {
+    publish2(v0, v1);
+    double a, b;
+    column_walk2(Af, dp, dim, &a, &b);
+    *y0 = pscale_ * a;
+    *y1 = pscale_ * b;
+  }
+  __device__ __forceinline__ void metric_point2(double x0, double x1) {
+    xpt_ = tid < dim ? x0 : 0.0;
+    xpt2_ = tid < dim ? x1 : 0.0;
+  }
+  __device__ __forceinline__ void metric_apply2(double v0, double v1, double* y0, double* y1) {
+    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
+      *y0 = tid < dim ? __builtin_fma(xpt_ * xpt_, v0, v0) : 0.0;
+      *y1 = tid < dim ? __builtin_fma(xpt2_ * xpt2_, v1, v1) : 0.0;
+    } else if constexpr (RMETRIC == MM_RMETRIC_RANK1) {
+      publish2(v0, v1);
+      double a, b, d0, d1;
+      column_walk2(base, dim, dim, &a, &b);  // B v0, B v1: one pass over the base matrix
+      sum2(xpt_ * v0, xpt2_ * v1, &d0, &d1);
+      *y0 = tid < dim ? __builtin_fma(xpt_, d0 * inv_dim_, a) : 0.0;
+      *y1 = tid < dim ? __builtin_fma(xpt2_, d1 * inv_dim_, b) : 0.0;
+    } else {
+      *y0 = *y1 = 0.0;  // (user metrics: kDual is false)
+    }
+  }
   __device__ __forceinline__ double diag() const { return tid < dim ? A[(size_t)tid * dp + tid] : 0.0; }
   // ---- refinement products: M(x) v matrix-free ---------------------------------------------------------------------------
   __device__ __forceinline__ void metric_point(double x) {
@@ -651,7 +780,9 @@ __device__ __forceinline__ void init_backend(GlobalBackend<RMETRIC, NB>& bk, con
   bk.base = A.rparams;
   bk.tparams = A.tparams;
   bk.refine_on = A.no_refine == 0;
+  bk.dual_off = A.no_dual != 0;
   bk.xpt_ = 0.0;
+  bk.xpt2_ = 0.0;
 }
 
 // MIDPOINT: ImplicitMidpointIntegrator (integrators.py:547-681) on the same backend (a full sweep per function evaluation)
