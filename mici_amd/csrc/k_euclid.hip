@@ -131,6 +131,71 @@ __global__ __launch_bounds__(256) void leapfrog_elem_kernel(
                                                  tparams, minv_diag, mm_comp_coefs{});
 }
 
+// The same leapfrog for SHORT launches (n_steps <= kStreamSteps, even dim): there the kernel is HBM-bound - a launch is one read
+// and one write of the (q, p) state, 32 D bytes a chain-step at n_steps = 1 (the regime BASELINE.json's north_star calls
+// "coalesced HBM loads of the per-chain (q,p) state"; bench.py c2i_stream) - and what limits the loop above is not arithmetic
+// but bytes in flight and index arithmetic: one 16-byte load per array per trip of a grid-stride loop with a 64-bit division
+// in it.  Here a thread owns kStreamItems consecutive 16-byte element pairs of the flat [n_chains x dim] arrays, all its loads are
+// issued before the first use (2 x kStreamItems x 16 B in flight a lane), the chain index comes from a 32-bit division (the
+// launcher falls back to the general kernel beyond 2^31 element pairs), and the stores are non-temporal (they are not read
+// again by this launch).  Arithmetic identical to leapfrog_elem_body's.
+constexpr int kStreamSteps = 8;
+constexpr int kStreamItems = 4;
+template <int TARGET, int METRIC>
+__global__ __launch_bounds__(256) void leapfrog_stream_kernel(
+    double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
+    const double* __restrict__ step_scale, const int32_t* __restrict__ chain_steps, int32_t* __restrict__ status,
+    int32_t* __restrict__ n_done, unsigned total_pairs, unsigned pairs_per_chain, int dim, double step_size, int n_steps,
+    const double* __restrict__ tparams, const double* __restrict__ minv_diag) {
+  // item k of this thread: pair index base + k * 256 (a wave's 64 lanes read 1 KB contiguous per item and array)
+  const unsigned base = (blockIdx.x * kStreamItems) * 256u + threadIdx.x;
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  d2v qv[kStreamItems], pv[kStreamItems];
+  unsigned idx[kStreamItems];
+#pragma unroll
+  for (int k = 0; k < kStreamItems; ++k) {
+    idx[k] = base + k * 256u;
+    if (idx[k] < total_pairs) {
+      qv[k] = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(pos) + idx[k]);
+      pv[k] = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(mom) + idx[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kStreamItems; ++k) {
+    if (idx[k] >= total_pairs) continue;
+    const unsigned chain = idx[k] / pairs_per_chain;
+    const int d0 = (int)(idx[k] - chain * pairs_per_chain) * 2;
+    const double t = mmdev::signed_step(dir, step_scale, chain, step_size);
+    const double ht = 0.5 * t;
+    const int my_steps = mmdev::chain_steps(chain_steps, chain, n_steps);
+    double q[2] = {qv[k].x, qv[k].y}, p[2] = {pv[k].x, pv[k].y}, g[2], tp0[2], tp1[2], mi[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      if constexpr (TARGET == T_DIAG) { tp0[v] = tparams[d0 + v]; tp1[v] = 0.0; }
+      else if constexpr (TARGET == T_POLY) { tp0[v] = tparams[0]; tp1[v] = tparams[1]; }
+      else { tp0[v] = 0.0; tp1[v] = 0.0; }
+      mi[v] = (METRIC == M_DIAG) ? minv_diag[d0 + v] : 1.0;
+      g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
+    }
+    for (int s = 0; s < my_steps; ++s) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        p[v] -= ht * g[v];
+        if constexpr (METRIC == M_DIAG) q[v] += t * (mi[v] * p[v]);
+        else q[v] += t * p[v];
+        g[v] = elem_grad<TARGET>(q[v], tp0[v], tp1[v]);
+        p[v] -= ht * g[v];
+      }
+    }
+    __builtin_nontemporal_store(d2v{q[0], q[1]}, reinterpret_cast<d2v*>(pos) + idx[k]);
+    __builtin_nontemporal_store(d2v{p[0], p[1]}, reinterpret_cast<d2v*>(mom) + idx[k]);
+    if (d0 == 0) {
+      status[chain] = 0;
+      n_done[chain] = my_steps;
+    }
+  }
+}
+
 template <int TARGET, int METRIC, int VEC>
 __global__ __launch_bounds__(256) void composition_elem_kernel(
     double* __restrict__ pos, double* __restrict__ mom, const int8_t* __restrict__ dir,
@@ -400,6 +465,14 @@ int launch_elem(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_ste
   const int64_t cap = (int64_t)ctx->n_cu * 8;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
+  if (!cf && vec2 && n_steps <= kStreamSteps && total < (int64_t)1 << 31) {
+    const unsigned sblocks = (unsigned)((total + 256 * kStreamItems - 1) / (256 * kStreamItems));
+    hipLaunchKernelGGL((leapfrog_stream_kernel<TARGET, METRIC>), dim3(sblocks), dim3(256), 0, ctx->stream, s->d_pos, s->d_mom,
+                       s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done, (unsigned)total,
+                       (unsigned)(dim / 2), dim, h, n_steps, m->d_target_params, m->d_metric_inv);
+    MM_HIP_CHECK(ctx, hipGetLastError());
+    return MM_OK;
+  }
   if (cf && vec2)
     hipLaunchKernelGGL((composition_elem_kernel<TARGET, METRIC, 2>), dim3((unsigned)blocks), dim3(256),
                        0, ctx->stream, s->d_pos, s->d_mom, s->d_dir, s->d_step_scale, s->d_chain_steps, s->d_status, s->d_n_done, s->n, dim, h, n_steps,
