@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - leapfrog-steps/sec (all chains) of the MI355X integrator hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2i_stream|c2iv|c2bcss|c3|c3b|c4|c5|c3_user|c4_general|c3b_dense|c4_d512]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2i_stream|c2iv|c2bcss|c3|c3b|c4|c5|c3_user|c4_general|c3b_dense|c4_d512|c3b_d128|c3b_d256]
                     [--traj-len L] [--chains-per-gpu M] [--no-extra-configs] [--no-cpu-baseline]
 
 Contract (driver): W untimed warm-up passes, then EXACTLY K timed passes bracketed by a barrier +
@@ -198,11 +198,16 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
                          "target) + ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
                     system=system, make_oracle=make_oracle, q0=q0, p0=p0, momenta=mom, bytes_per_chain_step=32.0 * dim,
                     flops_per_chain_step=None, bound="mfma", kind="riemann")
-    if config in ("c3b", "c3b_dense"):
+    if config in ("c3b", "c3b_dense", "c3b_d128", "c3b_d256"):
         # c3b_dense (VERDICT r03 #1c): SoftAbs on the BANANA - its tridiagonal Hessian and matrix-Tressian product reach the
         # library as user source (mici_amd/user_examples.py BANANA_HESS): the dense path - G = A X on the matrix cores,
         # grad_log_abs_det / grad_quadratic_form_inv formed in full - none of the arrowhead structure c3(b) leans on
         dim, h, traj = 64, 0.02, 100
+        wide = config in ("c3b_d128", "c3b_d256")
+        if wide:
+            # round 6: the SoftAbs workspace tiers - 64 < D <= 256, the three matrices of a chain in a global-memory
+            # workspace (csrc/softabs.h NP = 128 / 256) - on the c3(b) funnel at two and four times its dimension
+            dim, traj = (128, 10) if config == "c3b_d128" else (256, 4)
         wts = np.linspace(0.5, 2.0, dim - 1)
         if config == "c3b_dense":
             h = 0.01  # (at 0.02 half of the banana chains meet a ConvergenceError within 100 steps - in the reference too)
@@ -218,13 +223,15 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
             return orc.RiemannianSystem(omdl.Banana(dim) if config == "c3b_dense" else omdl.Funnel(wts), None, 1.0)
 
         integ = integrators.ImplicitLeapfrogIntegrator(system, h)
-        q0 = crng.standard_normal((n_chains, dim))
+        q0 = (0.5 if wide else 1.0) * crng.standard_normal((n_chains, dim))
         z = crng.standard_normal((n_chains, dim))
         p0 = system.sample_momentum_batch(q0, z) if device else _oracle_momenta("softabs", make_oracle(), q0, z)
         mom = None if device else p0
         p0 = p0 if device else mom.p0
         return dict(name=("c3b_dense SoftAbsRiemannianMetricSystem (banana target, Hessian / MTP as USER SOURCE: dense path) + "
-                          if config == "c3b_dense" else "c3(b) SoftAbsRiemannianMetricSystem (scaled funnel) + ")
+                          if config == "c3b_dense" else
+                          f"{config} SoftAbsRiemannianMetricSystem (scaled funnel, workspace tier) + " if wide else
+                          "c3(b) SoftAbsRiemannianMetricSystem (scaled funnel) + ")
                     + "ImplicitLeapfrogIntegrator", dim=dim, h=h, traj=traj, integ=integ,
                     system=system, make_oracle=make_oracle, q0=q0, p0=p0, momenta=mom, bytes_per_chain_step=32.0 * dim,
                     flops_per_chain_step=None, bound="mfma", kind="softabs")
@@ -267,11 +274,12 @@ def _sweep_mfma_counts(dim):
 
 
 DEFAULT_CHAINS = {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048, "c3_user": 1024, "c4_general": 1024, "c3b_dense": 1024,
-                  "c4_d512": 256, "c2i_stream": 1 << 20}  # per GPU; else 4096
+                  "c4_d512": 256, "c2i_stream": 1 << 20, "c3b_d128": 256, "c3b_d256": 256}  # per GPU; else 4096
 CPU_CHAINS = {"c2i_stream": 1 << 16}  # chains of the cpu_baseline sample where the device shard would not fit a host's pool
-EXTRA_CONFIGS = ("c2i", "c2i_stream", "c2iv", "c3", "c3b", "c4", "c5", "c3_user", "c4_general", "c3b_dense", "c4_d512")
+EXTRA_CONFIGS = ("c2i", "c2i_stream", "c2iv", "c3", "c3b", "c4", "c5", "c3_user", "c4_general", "c3b_dense", "c4_d512",
+                 "c3b_d128", "c3b_d256")
 # pass counts of the extra configs are capped (a c3(b) pass is ~1 s, a c4 pass ~0.1-0.3 s)
-EXTRA_STEP_CAP = {"c3b": 5, "c4": 10, "c4_general": 10, "c3b_dense": 5, "c4_d512": 3}
+EXTRA_STEP_CAP = {"c3b": 5, "c4": 10, "c4_general": 10, "c3b_dense": 5, "c4_d512": 3, "c3b_d128": 3, "c3b_d256": 2}
 BASELINE_CONFIG = {"c2": "BASELINE.json configs[1]", "c2i": "BASELINE.json configs[1] (iso-Gaussian variant, SURVEY 8d c2(i))",
                    "c2i_stream": "BASELINE.json configs[1] sizes (iso-Gaussian, D = 128) with n_steps = 1 and 2^20 chains: the "
                                  "HBM-bound regime of the (q, p) state loads north_star names",
@@ -281,7 +289,9 @@ BASELINE_CONFIG = {"c2": "BASELINE.json configs[1]", "c2i": "BASELINE.json confi
                    "c3_user": "BASELINE.json configs[2] sizes, a metric_func that is not built in (user source)",
                    "c4_general": "BASELINE.json configs[3] (per-GPU shard), its metric_func handed over as user source",
                    "c3b_dense": "BASELINE.json configs[2] (SoftAbs path) on the banana target: a dense (user-source) Hessian",
-                   "c4_d512": "BASELINE.json configs[3] at twice the dimension (D = 512: the global-memory tier)"}
+                   "c4_d512": "BASELINE.json configs[3] at twice the dimension (D = 512: the global-memory tier)",
+                   "c3b_d128": "BASELINE.json configs[2] (SoftAbs path) at D = 128, 256 chains: the workspace tier NP = 128",
+                   "c3b_d256": "BASELINE.json configs[2] (SoftAbs path) at D = 256, 256 chains: the workspace tier NP = 256"}
 
 
 # ---- CPU baseline: the oracle on this box's host cores ------------
@@ -371,7 +381,7 @@ def cpu_baseline_measure(config, budget_s):
         sample = f"oracle.leapfrog_steps_batch (NumPy, vectorised over chains): {nw} workers x {shard} chains"
         worker = _cpu_shard_euclid
     else:
-        steps = {"riemann": 2 if w["dim"] > 128 else 5, "softabs": 3, "constrained": 50}[w["kind"]]
+        steps = {"riemann": 2 if w["dim"] > 128 else 5, "softabs": 3 if w["dim"] <= 64 else 1, "constrained": 50}[w["kind"]]
         fn = orc.constrained_leapfrog_steps if w["kind"] == "constrained" else orc.implicit_leapfrog_steps
         n_single = min(n // 2, 64)
         t0, n1, done, spent = time.perf_counter(), 0, 0, 0.0
@@ -640,7 +650,8 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
         # k_softabs.hip refine_eigh): every 64^3 product of the kernel runs on the matrix cores and is counted there.
         n_prod = counters_acc.get("n_mfma_products", 0)
         if n_prod:
-            w["executed"] = dict(mfma_flops_per_chain_step=n_prod * 2.0 * 64.0**3 / max(done_local, 1.0),
+            npd = 64.0 if d <= 64 else (128.0 if d <= 128 else 256.0)  # the products' padded size (softabs.h NP)
+            w["executed"] = dict(mfma_flops_per_chain_step=n_prod * 2.0 * npd**3 / max(done_local, 1.0),
                                  valu_flops_per_chain_step=0.0,
                                  mfma_products_per_chain_step=n_prod / max(done_local, 1.0),
                                  refined_decompositions_per_chain_step=counters_acc.get("n_refine", 0) / max(done_local, 1.0),

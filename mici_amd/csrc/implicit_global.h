@@ -562,23 +562,41 @@ struct GlobalBackend {
     return ok && (ld == ld);
   }
 
+  // diag(1 + q^2): the metric is diagonal - its inverse, log det and square root are elementwise, one register a
+  // thread, no workspace and no sweep; every construction is "factorised" that way (init_backend switches the refinement off)
+  double dinv_;  // MM_RMETRIC_DIAGQUAD: this thread's diagonal entry of the held inverse
+  __device__ __forceinline__ bool build_diag(double x, double* logdet) {
+    const double d = __builtin_fma(x, x, 1.0);
+    dinv_ = tid < dim ? 1.0 / d : 0.0;
+    const double bad = reduce((tid < dim && !(d < 1.7e308)) ? 1.0 : 0.0, false);  // "Array is not finite." (NaN / overflow)
+    if (logdet) *logdet = reduce(tid < dim ? log(d) : 0.0, false);
+    return bad == 0.0;
+  }
   __device__ __forceinline__ bool build_and_invert(double x) {
+    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) return build_diag(x, nullptr);
     const bool fin = build(x);
     return invert(nullptr) && fin;
   }
 
   // ---- y = M(x0)^-1 v -------------------------------------------------------------------------------------------------------
   __device__ __forceinline__ double matvec(double v) {
+    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) return tid < dim ? dinv_ * v : 0.0;
     publish(v);
     return column_walk(A, dp, dim);
   }
   // z = F r of the refinement solves (implicit_core.h precond_trait): the scaled FP32 copy
   __device__ __forceinline__ double precond(double v) {
+    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) return tid < dim ? dinv_ * v : 0.0;
     publish(v);
     return pscale_ * column_walk(Af, dp, dim);
   }
   // the lock-step pair's preconditioner products z = F r (refine_solve2 calls nothing else through matvec2): one pass
   __device__ __forceinline__ void matvec2(double v0, double v1, double* y0, double* y1) {
+    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
+      *y0 = tid < dim ? dinv_ * v0 : 0.0;
+      *y1 = tid < dim ? dinv_ * v1 : 0.0;
+      return;
+    }
     publish2(v0, v1);
     double a, b;
     column_walk2(Af, dp, dim, &a, &b);
@@ -604,7 +622,10 @@ struct GlobalBackend {
       *y0 = *y1 = 0.0;  // (user metrics: kDual is false)
     }
   }
-  __device__ __forceinline__ double diag() const { return tid < dim ? A[(size_t)tid * dp + tid] : 0.0; }
+  __device__ __forceinline__ double diag() const {
+    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) return tid < dim ? dinv_ : 0.0;
+    return tid < dim ? A[(size_t)tid * dp + tid] : 0.0;
+  }
   // ---- refinement products: M(x) v matrix-free ---------------------------------------------------------------------------
   __device__ __forceinline__ void metric_point(double x) {
     xpt_ = tid < dim ? x : 0.0;
@@ -675,7 +696,7 @@ struct GlobalBackend {
   __device__ __forceinline__ double half_vjp_inv(double q) {
     if constexpr (RMETRIC == MM_RMETRIC_USER) return user_half_vjp<false>(0.0);
     else if constexpr (RMETRIC == MM_RMETRIC_RANK1) return matvec(q) * inv_dim_;
-    else return tid < dim ? q * A[(size_t)tid * dp + tid] : 0.0;
+    else return tid < dim ? q * dinv_ : 0.0;
   }
   // dense metric: grad_quadratic_form_inv(p) = -(M^-1 p)(M^-1 p)^T   (matrices.py:1179-1181)
   __device__ __forceinline__ double dh2_dpos(double p, double q) {
@@ -779,7 +800,8 @@ __device__ __forceinline__ void init_backend(GlobalBackend<RMETRIC, NB>& bk, con
   bk.pscale_ = 1.0;
   bk.base = A.rparams;
   bk.tparams = A.tparams;
-  bk.refine_on = A.no_refine == 0;
+  bk.refine_on = A.no_refine == 0 && RMETRIC != MM_RMETRIC_DIAGQUAD;  // (a diagonal metric: every construction elementwise)
+  bk.dinv_ = 0.0;
   bk.dual_off = A.no_dual != 0;
   bk.xpt_ = 0.0;
   bk.xpt2_ = 0.0;
@@ -821,6 +843,21 @@ __device__ __forceinline__ void riemann_aux_global_body(const ImplicitArgs& A, d
   const double q = act ? A.pos[chain * dim + tid] : 0.0;
   const double p = act ? A.mom[chain * dim + tid] : 0.0;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {  // elementwise (see build_diag)
+    double logdet;
+    const bool okd = bk.build_diag(q, &logdet);
+    if constexpr (OP == 0) {
+      const double e = bk.neg_log_dens_elem(q) + (act ? 0.5 * p * bk.matvec(p) : 0.0);
+      const double h = bk.reduce(e, false) + 0.5 * logdet;
+      if (tid == 0) A.out[chain] = okd ? h : nan;
+    } else if constexpr (OP == 1) {
+      const double u = bk.matvec(p);
+      if (act) A.out[chain * dim + tid] = okd ? u : nan;
+    } else {
+      if (act) A.mom[chain * dim + tid] = okd ? sqrt(__builtin_fma(q, q, 1.0)) * A.z[chain * dim + tid] : nan;
+    }
+    return;
+  }
   bool ok = bk.build(q);
   if constexpr (OP == 0) {
     double logdet;

@@ -12,7 +12,7 @@ int fill_args(mm_ctx* ctx, const mm_model* m, mm_state* s, ImplicitArgs& a) {
     return MM_ERR_UNSUPPORTED;
   }
   if (m->rmetric != MM_RMETRIC_RANK1 && m->rmetric != MM_RMETRIC_DIAGQUAD) {
-    mm_set_error(ctx, "dense-Riemannian kernels beyond dim 279: built-in metrics only");
+    mm_set_error(ctx, "internal: this entry point runs the built-in metrics of the global-memory tier (a user metric beyond dim 279 runs its own run-time compiled kernels, mm_rtc.hip MM_RTC_FAM_GLOBAL)");
     return MM_ERR_UNSUPPORTED;
   }
   a = ImplicitArgs{};

@@ -52,6 +52,18 @@ int mm_state_ensure_work(mm_ctx* ctx, mm_state* s, size_t bytes) {
     if (s->d_work) (void)hipFree(s->d_work);
     s->d_work = nullptr;
     s->work_bytes = 0;
+    //  a batch whose per-chain workspaces do not fit the device fails HERE, with the chain count that would fit,
+    // not as a raw allocation error: the global-memory tiers take 12 D^2 bytes (dense Riemannian) / ~5 MB (SoftAbs, D = 256) a chain
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b) {
+      const size_t per_chain = s->n > 0 ? bytes / (size_t)s->n : bytes;
+      mm_set_error(ctx, "per-chain device workspace does not fit: " + std::to_string(bytes >> 20) + " MiB needed for " +
+                            std::to_string((long long)s->n) + " chains (" + std::to_string(per_chain >> 10) +
+                            " KiB a chain), " + std::to_string(free_b >> 20) + " MiB free - at most " +
+                            std::to_string((long long)(per_chain ? free_b / per_chain : 0)) +
+                            " chains of this size fit one batch; split the batch");
+      return MM_ERR_UNSUPPORTED;
+    }
     MM_HIP_CHECK(ctx, hipMalloc(&s->d_work, bytes));
     s->work_bytes = bytes;
   }

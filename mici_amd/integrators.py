@@ -242,7 +242,7 @@ class ImplicitMidpointIntegrator(ImplicitLeapfrogIntegrator):
     """Implicit midpoint integrator for general Hamiltonians (reference integrators.py:547-681): implicit
     Euler half step (fixed point in the concatenated (pos, mom) vector), explicit Euler half step,
     reversibility check.  Device support: Euclidean-metric systems (dim <= 1024), dense-Riemannian systems
-    (dim <= 1024: built-in metrics beyond 279) and SoftAbs systems (dim <= 256, user Hessians included).  Same constructor arguments and solver options as :py:class:`ImplicitLeapfrogIntegrator`."""
+    (dim <= 1024, built-in and user metrics alike: beyond 279 on the global-memory tier) and SoftAbs systems (dim <= 256, user Hessians included).  Same constructor arguments and solver options as :py:class:`ImplicitLeapfrogIntegrator`."""
 
     _needs = None  # euclid or riemann
 

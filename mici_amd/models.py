@@ -129,7 +129,7 @@ class UserMetric(RiemannianMetric):
 
     and is compiled for gfx950 (hipRTC) with the library's dense-Riemannian kernels (the auxiliary kernels when the
     system's device model is created, the matrix-core leapfrog kernels on their first launch); ``params`` are handed to
-    both.  ``dim`` <= 1024 (beyond 279 on the global-memory tier; the aux opt-in is 560 doubles at most).  The text may opt into per-point precomputation (``#define MM_USER_AUX n`` +
+    both.  ``dim`` <= 1024 (beyond 279 on the global-memory tier; the aux opt-in is 560 doubles at most, and ``MM_USER_AUX`` must be a plain decimal literal - the library reads it from the text, expressions are rejected).  The text may opt into per-point precomputation (``#define MM_USER_AUX n`` +
     ``mm_user_prepare``) and the team-form vector-Jacobian product (``#define MM_USER_VJP_FLAT`` +
     ``mm_user_vjp_flat``): csrc/user_metric.h - both decide how fast the system runs, neither changes results."""
 

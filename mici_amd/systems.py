@@ -242,7 +242,7 @@ class SoftAbsRiemannianMetricSystem(System):
     """SoftAbs-regularised Hessian metric (reference systems.py:1737-1920).  The built-in targets with a device Hessian
     (funnel, poly) bring it themselves; for any other target ``hess_neg_log_dens`` takes a ``models.UserHessian`` - the
     Hessian and its matrix-Tressian product as device code (the reference's ``hess_neg_log_dens`` / ``mtp_neg_log_dens``
-    callables), dense, dim <= 64."""
+    callables), dense, dim <= 256 (beyond 64 on the workspace tiers of csrc/softabs.h)."""
 
     _kind = "riemann"
 

@@ -58,9 +58,9 @@ def test_global_tier_matches_oracle(kind, dim, n, h, steps):
         assert_close(p[c], po, 1e-10, f"p chain {c}")
     assert counters["n_fp_solves"] == 4 * n * steps
     if kind == "rank1":  # one sweep per step, the solve-only constructions refined (a rank-two perturbation: two CG steps).
-        # diag(1 + q^2) has D distinct ratios (1 + x_k^2) / (1 + x_0^2): its CG runs out of its twelve iterations and the
-        # factorisation takes over - correct, just a sweep per construction
         assert counters["n_factor_full"] <= n * (steps + 1) + 2, counters
+    else:  # diag(1 + q^2) (round 6): every construction elementwise - no refinement pairs, no workspace
+        assert counters["n_refine"] == 0, counters
     # reversible, and the same bits twice
     qb, pb, sb, nb = integ.step_batch(q, p, -dirs, n_steps=steps)
     assert np.all(sb == 0)
