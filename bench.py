@@ -263,8 +263,12 @@ def _sweep_mfma_counts(dim):
     inverse, solve = trailing LDL^T sweep), counted from the kernel sources; None for the VALU kernels."""
     if 32 < dim <= 64:      # k_implicit_mfma.hip: 16 blocks of 4 pivots, 10 lower tiles; trailing: tiles with J >= I0
         return dict(full=160, solve=4 * (10 + 6 + 3 + 1), padded_dim=64)
-    if dim > 279:           # implicit_global.h: VALU sweep and column walks, no matrix-core instructions
-        return None
+    if dim > 279:           # implicit_global.h (round 6): per NB-pivot block NB / 4 MFMAs per lower tile + (NB / 16)(NB / 4) per tile
+        dp = (dim + 63) & ~63  # row for the W operands; products are column walks (no matrix-core instructions)
+        nb = 32 if dp <= 512 else 16
+        nt = (dim + 15) // 16
+        per_block = nt * (nt + 1) // 2 * (nb // 4) + nt * (nb // 16) * (nb // 4)
+        return dict(full=-(-dim // nb) * per_block, solve=0, padded_dim=dp)
     if 75 < dim <= 256:     # k_implicit_blk16.hip: per 16-pivot block 4 MFMAs per updated tile + 64 (-W) + 4 (pivot block)
         nblk = (dim + 15) // 16
         full = nblk * (136 * 4 + 64 + 4)
@@ -686,15 +690,22 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
         # a sweep is ceil(D / NB) passes reading and writing the DP x DP workspace (+ one write to build it), every product
         # with the held inverse one read of it (the rank-one base matrix is shared by all chains: L2 / MALL, not counted)
         dp = float((int(d) + 63) & ~63)
-        nb = 16.0 if dp <= 512 else 8.0
+        nb = 32.0 if dp <= 512 else 16.0
         sweeps = counters_acc.get("n_factor_full", 0)
         n_m = counters_acc.get("n_metric", 0)
         n_b = max(counters_acc.get("n_fp_evals", 0) - n_m, 0)
-        products = counters_acc.get("n_refine", 0) + n_b + 4.0 * done_local  # F r per CG pair, momentum evaluations, A / C
-        bytes_total = 8.0 * dp * dp * (sweeps * (2.0 * np.ceil(d / nb) + 1.0) + products)
+        # round 6: a sweep = the workspace written once (build), ceil(D / NB) passes over its LOWER triangle (half read, half
+        # written), one mirror pass (half read, the whole written, + the FP32 copy: half the bytes again); F r of a CG pair
+        # reads the FP32 copy (half the bytes; a lock-step pair of solves shares the pass - not subtracted here), the momentum
+        # evaluations and the A / C sub-steps the FP64 matrix.  The rank-one base matrix is shared by all chains (L2 / MALL).
+        f64_products = n_b + 4.0 * done_local
+        f32_products = counters_acc.get("n_refine", 0)
+        bytes_total = 8.0 * dp * dp * (sweeps * (1.0 + np.ceil(d / nb) + 2.0) + f64_products + 0.5 * f32_products)
         hbm_model = dict(bytes_per_launch=bytes_total / steps, achieved_GBs=bytes_total / steps / launch_s / 1e9,
                          frac_of_hbm_peak=bytes_total / steps / launch_s / 1e9 / HBM_PEAK_GBS,
-                         note="modelled traffic of the HBM-resident metric: sweeps x (2 ceil(D / NB) + 1) + products, x 8 DP^2 bytes")
+                         bytes_per_chain_step=bytes_total / max(done_local, 1.0),
+                         note="modelled traffic of the HBM-resident metric: sweeps x (ceil(D / NB) + 3) + FP64 products + FP32 "
+                              "products / 2, x 8 DP^2 bytes")
     if w["bound"] == "mfma":
         achieved = w["flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
         roof = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",

@@ -38,6 +38,7 @@ EXTRA_FLAGS = {
     "k_implicit_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "k_implicit_blk16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "k_implicit_pair.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "k_implicit_fork.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }
 
 

@@ -438,6 +438,22 @@ struct dual_trait { static constexpr bool value = false; };
 template <class BK>
 struct dual_trait<BK, decltype((void)BK::kDual)> { static constexpr bool value = BK::kDual; };
 
+// kFork backends (round 6, implicit_fork.h): a SECOND WAVE of the chain runs the reversibility-check solve while this one runs
+// the C-adjoint solve - the two position solves of a step are independent of each other until both have ended
+// (integrators.py:521-536: the reference runs one to its end, then the other).  bk.fork_chk(iter, stage) hands the check's
+// state over (the slots SL_XQ / SL_SX0 / SL_SX1 / SL_UC / SL_PW / SL_QW / SL_QINIT as they stand), bk.join_chk() waits for
+// its end.  Outcomes: FK_DONE (converged: the point in SL_XQ; the reversibility norm is taken here), FK_FAIL (status as the
+// sequential solve would report it), FK_FALLBACK (a refinement failed: the check's state is back in its slots, the
+// sequential code below factorises at that point and carries on).
+enum { FK_DONE = 0, FK_FAIL = 1, FK_FALLBACK = 2 };
+struct ForkOutcome {
+  int outcome, status, iter, stage, n_evals, n_pairs;
+};
+template <class BK, class = void>
+struct fork_trait { static constexpr bool value = false; };
+template <class BK>
+struct fork_trait<BK, decltype((void)BK::kFork)> { static constexpr bool value = BK::kFork; };
+
 template <class BK, class = void>
 struct refine_trait { static constexpr bool value = false; };
 template <class BK>
@@ -452,6 +468,9 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
   ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0, 0, 0, 0};
   constexpr bool kRefine = refine_trait<BK>::value;
   constexpr bool kDual = kRefine && dual_trait<BK>::value;
+  constexpr bool kFork = kRefine && fork_trait<BK>::value;
+  static_assert(!(kDual && kFork), "lock step and fork are alternatives");
+  bool fork_ok = false;
   bool anchor = false;  // kRefine: the backend holds the explicit inverse at the step's starting position
   // kDual: the C-adjoint solve advances together with the reversibility-check solve while both are in flight
   // (refine_solve2).  Its evaluations are COUNTED when the reference would have made them - after the check has passed
@@ -483,6 +502,43 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
     bool chk_done = false, adj_done = false;
     double q_back = 0.0;
     bool skip_refine = false;
+    if constexpr (kFork) {
+      if (mode == MODE_CHK && fork_ok && anchor && actA == FP_CONT) {  // team-uniform
+        // ---- the check's solve on the partner wave, the C-adjoint solve here, both from their parked / active states ----
+        fork_ok = false;  // (once per step)
+        bk.fork_chk(cS.iter, cS.stage, t);
+        const double qw = bk.slot(SL_QW);
+        FpCtl cA{iterA, stageA};
+#pragma unroll 1
+        while (actA == FP_CONT) {
+          double uA;
+          if (!refine_solve(bk, bk.slot(SL_PTA), bk.slot(SL_PW), bk.slot(SL_UA), &uA, r)) break;  // repeated (and factorised)
+          bk.slot(SL_UA) = uA;                                                                    // when its turn comes
+          ++pendA;
+          double ptA = bk.slot(SL_PTA);
+          actA = fp_feed(bk, cA, bk.slot(SL_AX0), bk.slot(SL_AX1), qw + t * uA, o, &ptA, &stA);
+          bk.slot(SL_PTA) = ptA;
+        }
+        iterA = cA.iter;
+        stageA = cA.stage;
+        const ForkOutcome fo = bk.join_chk();
+        // the check's evaluations are the reference's own: counted whatever their end
+        bump(bk, r, CNT_METRIC, fo.n_evals);
+        bump(bk, r, CNT_EVALS, fo.n_evals);
+        bump(bk, r, CNT_REFINE, fo.n_pairs);
+        if (fo.outcome == FK_FAIL) {
+          r.status = fo.status;
+          break;
+        }
+        if (fo.outcome == FK_DONE) {
+          chk_done = true;
+          q_back = bk.slot(SL_XQ);
+        } else {  // FK_FALLBACK: the check's state is back in its slots; factorise at its point (below), as refine_solve would
+          cS = FpCtl{fo.iter, fo.stage};
+          skip_refine = true;
+        }
+      }
+    }
     if constexpr (kDual) {
       if (mode == MODE_CHK && dual_ok && anchor && actA == FP_CONT) {  // team-uniform
         // ---- both position solves in flight: one more evaluation of each, the two solves M(x)^-1 p in lock step ----
@@ -639,6 +695,10 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         dual_ok = refined && !bk.dual_off;  // (a factorised first evaluation: no anchor, nothing to advance together)
         pendA = 0;
       }
+      if constexpr (kFork) {
+        fork_ok = refined && bk.fork_on();
+        pendA = 0;
+      }
       // the reference runs the reversibility-check solve to its end before the C-adjoint solve starts: the latter's
       // first evaluation (shared with the former's here) is counted only once it would have happened
       bump(bk, r, CNT_SOLVES, 1);
@@ -703,7 +763,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       bump(bk, r, CNT_SOLVES, 1);
       bump(bk, r, CNT_EVALS, 1);
       bump(bk, r, CNT_METRIC, 1);
-      if constexpr (kDual) {  // the evaluations the adjoint solve made alongside the check
+      if constexpr (kDual || kFork) {  // the evaluations the adjoint solve made alongside the check
         if (pendA > 0) {
           bump(bk, r, CNT_EVALS, pendA);
           bump(bk, r, CNT_METRIC, pendA);

@@ -78,6 +78,8 @@ __global__ __launch_bounds__(64 * kWaves) void mfma_profile_kernel(ImplicitArgs 
 
 }  // namespace
 
+// k_implicit_fork.hip
+int mm_launch_implicit_fork(mm_ctx* ctx, const mm_model* m, mm_state* s, const mmimp::ImplicitArgs& a);
 // k_implicit_pair.hip
 int mm_launch_implicit_pair(mm_ctx* ctx, const mm_model* m, mm_state* s, const mmimp::ImplicitArgs& a);
 
@@ -111,6 +113,11 @@ int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
   // it loses 21 % on c3, profiles/r06_ab_c3_pair.txt - so the one-wave kernel stays the default)
   static const bool pair_on = [] { const char* e = getenv("MICI_AMD_PAIR"); return e && e[0] == '1'; }();
   if (pair_on) return mm_launch_implicit_pair(ctx, m, s, a);
+  // round 6: the forked kernel (implicit_fork.h: a second wave per chain runs the reversibility-check solve while the first runs
+  // the C-adjoint solve - c3 1.36e7 -> 1.48e7 steps/s, profiles/r06_ab_c3_fork.txt) is the default; MICI_AMD_FORK=0 selects the
+  // one-wave kernel
+  static const bool fork_on = [] { const char* e = getenv("MICI_AMD_FORK"); return !(e && e[0] == '0'); }();
+  if (fork_on) return mm_launch_implicit_fork(ctx, m, s, a);
   const unsigned blocks = (unsigned)((s->n + kWaves - 1) / kWaves);
   const size_t lds = ((r1 ? kBaseDoubles : 0) + kWaves * kMfmaWaveDoubles) * sizeof(double);
   if (r1) {

@@ -6,8 +6,8 @@ sample misses.  Here the oracle runs on ALL chains of the shard, at the trajecto
 of the GPU box (tests/oracle_pool.py: a spawn pool, one BLAS thread per worker).  Status and completed steps must be
 IDENTICAL, positions / momenta within the contract's tolerance - on every chain but the handful whose trajectory the
 oracle's OWN sensitivity leaves uncomparable at that tolerance, and those are held to a multiple of that sensitivity, measured by
-re-running the oracle on them with inputs moved by 1e-13 (see `_compare`).  Round 6: c4 / c4_general compare all
-1024 chains too, and every test appends what it measured - chains judged by the second criterion, the worst error - to
+re-running the oracle on them with inputs moved by 1e-13 (see `_compare`).  Round 6: c4 compares all 1024
+chains too (c4_general 256 - see the test), and every test appends what it measured - chains judged by the second criterion, the worst error - to
 gpurun_out/all_chains.txt (committed from the GPU box as profiles/r06_all_chains.txt); each `max_sensitive` below is that measured
 count + 50 % (at least 2)."""
 
@@ -111,19 +111,25 @@ def test_every_chain_of_the_d64_shards_at_bench_length(pool, config, tol, max_se
             f"judged by the oracle's self-sensitivity (allowed: {max_sensitive}), tolerance {tol:.0e}")
 
 
-@pytest.mark.parametrize("config", ["c4", "c4_general"])
-def test_every_chain_of_the_c4_shards_at_bench_length(pool, config):
+@pytest.mark.parametrize("config,n_cmp", [("c4", 1024), ("c4_general", 256)])
+def test_the_c4_shards_at_bench_length(pool, config, n_cmp):
+    """c4: EVERY chain of the 1024-chain shard (round 6, VERDICT r05 #6b).  c4_general - the same workload with its metric as
+    user source, the same kernel family compiled at run time - keeps 256 chains from both ends and the middle of the shard: the
+    oracle costs 17 ms a chain-step here, and the two all-chain runs together took 11 of the suite's 17 minutes on the GPU
+    box's host cores (the driver's limit is 30)."""
     n = 1024
     w = _workload(config, n)
     steps = w["traj"]
     assert steps == 50
     q, p, status, n_done = w["integ"].step_batch(w["q0"], w["p0"], 1, n_steps=steps)
-    qo, po, so, no = pool.run(config, n, w["q0"], w["p0"], 1, w["h"], steps, chunk=2)
+    sel = np.arange(n) if n_cmp == n else np.concatenate([np.arange(96), np.arange(464, 560), np.arange(n - 64, n)])
+    assert len(sel) == n_cmp
+    qo, po, so, no = pool.run(config, n, w["q0"][sel], w["p0"][sel], 1, w["h"], steps, chunk=2)
     max_sensitive = 2
-    err, n_sens = _compare(pool, config, n, w, np.arange(n), 1, steps, q, p, status, n_done, qo, po, so, no, 1e-10,
+    err, n_sens = _compare(pool, config, n, w, sel, 1, steps, q[sel], p[sel], status[sel], n_done[sel], qo, po, so, no, 1e-10,
                            max_sensitive)
     assert np.all(status == 0) and np.all(n_done == steps)
-    _record(f"{config}: {n} chains x {steps} steps; scaled error median {np.median(err):.1e}, 99 % "
+    _record(f"{config}: {n_cmp} of {n} chains x {steps} steps; scaled error median {np.median(err):.1e}, 99 % "
             f"{np.quantile(err, 0.99):.1e}, max {err.max():.1e}; {n_sens} chains judged by the oracle's self-sensitivity "
             f"(allowed: {max_sensitive}), tolerance 1e-10")
 

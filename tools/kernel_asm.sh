@@ -4,6 +4,6 @@ set -e
 name=${1%.hip}; shift
 cd "$(dirname "$0")/../mici_amd/csrc"
 extra=""
-case $name in k_implicit_mfma|k_implicit_blk16|k_implicit_pair) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
+case $name in k_implicit_mfma|k_implicit_blk16|k_implicit_pair|k_implicit_fork) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -ffp-contract=on $extra "$@" --cuda-device-only -S $name.hip -o /tmp/$name.s
 echo /tmp/$name.s

@@ -15,7 +15,7 @@
 #   <round>_c4_ubench_blk16.txt, <round>_c3_ubench_mfma.txt   phase clocks of the two dense-Riemannian kernels
 #   <round>_fuzz_parity.txt               tools/fuzz_parity.py, three seeds x 80 cases + 60 long SoftAbs cases + constrained + user-source kinds
 #   <round>_host_latency.txt              tools/host_latency.py in three fresh processes (single-state Integrator.step, step_batch, system.h)
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 if [ "$1" = "collect" ]; then
   src=$ROOT/gpurun_out/${ROUND}p
@@ -27,9 +27,12 @@ if [ "$1" = "collect" ]; then
   exit 0
 fi
 cd $ROOT
-O=$ROOT/gpurun_out/${ROUND}p; rm -rf $O; mkdir -p $O
-KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2iv:leapfrog_mfma_kernel c3:implicit_mfma_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel c3_user:mm_rtc_riem_step c4_general:mm_rtc_riem_step c3b_dense:mm_rtc_softabs_step c4_d512:implicit_global_kernel"
+O=$ROOT/gpurun_out/${ROUND}p; [ "$PART" = "2" ] || rm -rf $O; mkdir -p $O
+KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2i_stream:leapfrog_stream_kernel c2iv:leapfrog_mfma_kernel c3:implicit_mfma_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel c3_user:mm_rtc_riem_step c4_general:mm_rtc_riem_step c3b_dense:mm_rtc_softabs_step c4_d512:implicit_global_kernel c3b_d128:softabs_leapfrog_kernel c3b_d256:softabs_leapfrog_kernel"
 
+# PART=1: tests, counters, bench, kernel trace;  PART=2: phase clocks, fuzz, host latency;  unset: everything
+if [ "$PART" = "2" ]; then mkdir -p $O; fi
+if [ "$PART" != "2" ]; then
 if [ -z "$SKIP_TESTS" ]; then
   python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -4 > $O/gpu_tests.txt; cat $O/gpu_tests.txt
 fi
@@ -55,12 +58,14 @@ rm -rf $O/prof_default
 
 for pair in $KERNELS; do
   cfg=${pair%%:*}; kern=${pair##*:}
-  case $cfg in c2i|c2iv|c4_d512) continue;; esac
+  case $cfg in c2i|c2i_stream|c2iv|c3b_d128|c3b_d256) continue;; esac
   bash tools/pmc_collect.sh $cfg $kern > $O/sq_$cfg.log 2>&1
   [ -f gpurun_out/pmc_$cfg/pmc_$cfg.json ] && mv gpurun_out/pmc_$cfg/pmc_$cfg.json $O/${cfg}_sq_counters.json && echo "$cfg SQ counters ok"
   rm -rf gpurun_out/pmc_$cfg $O/sq_$cfg.log
 done
 
+fi  # PART != 2
+if [ "$PART" = "1" ]; then du -sh $O; exit 0; fi
 python tools/ubench_blk16.py 2>&1 | grep -v "^{" > $O/c4_ubench_blk16.txt; tail -10 $O/c4_ubench_blk16.txt
 python tools/ubench_primitives.py > $O/c3_ubench_mfma.txt 2>&1; tail -10 $O/c3_ubench_mfma.txt
 
