@@ -1,4 +1,5 @@
-// Device code of the FORKED matrix-core wave kernel (round 6; k_implicit_fork.hip instantiates it for the built-in metrics).
+// Device code of the FORKED matrix-core wave kernel (round 6; k_implicit_fork.hip instantiates it for the built-in metrics,
+// mm_rtc.hip compiles it at run time around a USER metric).
 //
 // Implicit leapfrog on dense-metric Riemannian systems, 32 < D <= 64: the one-wave-per-chain kernel of implicit_mfma.h with a
 // SECOND wave per chain that takes the reversibility-check solve of C off the first wave's hands.  gfx950 / CDNA4.
@@ -50,7 +51,9 @@ enum { MB_ITER = 8, MB_STAGE, MB_T, MB_OUTCOME, MB_STATUS, MB_RITER, MB_RSTAGE, 
 
 template <int RMETRIC>
 __host__ __device__ constexpr int fork_lds_doubles() {
-  return (RMETRIC == MM_RMETRIC_RANK1 ? kBaseDoubles : 0) + kChains * (kMfmaWaveDoubles + kHelperDoubles);
+  // (a user metric: both waves carry their own copy of the hooks' LDS blocks, user_metric.h)
+  return (RMETRIC == MM_RMETRIC_RANK1 ? kBaseDoubles : 0) +
+         kChains * (kMfmaWaveDoubles + kHelperDoubles + (RMETRIC == MM_RMETRIC_USER ? 2 * mmuser::lds_doubles(64) : 0));
 }
 
 template <int RMETRIC>
@@ -62,7 +65,6 @@ struct ForkBackend : mmmfma::MfmaBackend<RMETRIC, false> {
   using Base::w;
   using Base::fr_;
   using Base::fd_;
-  static_assert(RMETRIC != MM_RMETRIC_USER, "built-in metrics (a user metric's tiles of M(x) do not fit next to the row)");
   static constexpr bool kDual = false;
   static constexpr bool kFork = true;
   bool fork_off;   // MICI_AMD_FORK=0: wave B idles (A/B runs)
@@ -154,6 +156,10 @@ struct ForkBackend : mmmfma::MfmaBackend<RMETRIC, false> {
 #pragma unroll
     for (int k = 0; k < 64; ++k) fr_[k] = 0.0;
     fd_ = 0.0;
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {  // (a refinement solve's tiles of M(x) are dead between solves)
+#pragma unroll
+      for (int t = 0; t < kTiles; ++t) this->mx_[t] = d4{0.0, 0.0, 0.0, 0.0};
+    }
     bool ok = Base::build(x);
     if (need_inverse) {  // wave-uniform
       ok = this->template sweep<false>() && ok;
@@ -252,8 +258,10 @@ __device__ __forceinline__ void implicit_fork_body(const ImplicitArgs& A, double
     }
   }
   const int cslot = wave & (kChains - 1), role = wave >> 2;
-  double* wa = lds + base_elems + cslot * kMfmaWaveDoubles;
-  double* wb = lds + base_elems + kChains * kMfmaWaveDoubles + cslot * kHelperDoubles;
+  constexpr int kUser = RMETRIC == MM_RMETRIC_USER ? mmuser::lds_doubles(64) : 0;
+  constexpr int kUA = (mmuser::kAux + 1) & ~1;
+  double* wa = lds + base_elems + cslot * (kMfmaWaveDoubles + kUser);
+  double* wb = lds + base_elems + kChains * (kMfmaWaveDoubles + kUser) + cslot * (kHelperDoubles + kUser);
   if (role == 1 && lane < 16) reinterpret_cast<int*>(wb + 192)[lane] = 0;  // the mailbox flags
   __syncthreads();
   const int64_t chain = (int64_t)blockIdx.x * kChains + cslot;
@@ -285,6 +293,13 @@ __device__ __forceinline__ void implicit_fork_body(const ImplicitArgs& A, double
     bk.w.mpart = nullptr;
     bk.w.stash = nullptr;
     bk.w.prof = nullptr;
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {  // the products' point and its aux block (the held inverse's: wave A only)
+      double* up = wb + kHelperDoubles;
+      bk.w.uq = up;
+      bk.w.ux = up + 64;
+      bk.w.uaq = up + 128;
+      bk.w.uax = up + 128 + kUA;
+    }
     if (!bk.fork_off) bk.helper_loop(A.opts);
     return;
   }
@@ -297,6 +312,14 @@ __device__ __forceinline__ void implicit_fork_body(const ImplicitArgs& A, double
   bk.w.mpart = bk.w.part + 64 * kRowPitch;
   bk.w.stash = bk.w.mpart + 192;
   bk.w.prof = bk.w.stash + SL_COUNT_REFINE * 64;
+  if constexpr (RMETRIC == MM_RMETRIC_USER) {
+    double* up = wa + kMfmaWaveDoubles;
+    bk.w.uq = up;
+    bk.w.ux = up + 64;
+    bk.w.uaq = up + 128;
+    bk.w.uax = up + 128 + kUA;
+    bk.work = A.work ? A.work + chain * (int64_t)(64 * 64) : nullptr;
+  }
   const bool act = lane < dim;
   double q = act ? A.pos[chain * dim + lane] : 0.0;
   double p = act ? A.mom[chain * dim + lane] : 0.0;
