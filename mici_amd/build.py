@@ -137,7 +137,7 @@ def _compile_and_link(sources, objdir, lib, extra, headers_time, force, jobs, ve
     return objs
 
 
-RTC_HEADERS = ["constrained_core.h", "constrained_wave.h", "implicit_wave.h", "implicit_mfma.h", "implicit_blk16.h", "implicit_team.h",
+RTC_HEADERS = ["constrained_core.h", "constrained_wave.h", "implicit_wave.h", "implicit_mfma.h", "implicit_fork.h", "implicit_blk16.h", "implicit_team.h",
                "implicit_global.h",
                "softabs.h", "user_metric.h", "user_hessian.h", "implicit_core.h", "mm_device.h",
                os.path.join("..", "..", "include", "mici_amd.h")]

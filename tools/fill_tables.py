@@ -8,7 +8,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r05")
+ROUND = os.environ.get("ROUND", "r06")
 
 
 def sci(x):
@@ -29,7 +29,10 @@ def main():
              "c3b": "c3(b) SoftAbs D=64", "c4": "c4 shard D=256, 1024 chains", "c5": "c5 shard, 2048 chains",
              "c3_user": "c3_user D=64: softplus + rank-one metric as user source", "c4_general": "c4_general D=256: the c4 metric as user source",
              "c3b_dense": "c3b_dense D=64: SoftAbs on the banana, Hessian as user source (h = 0.01)",
-             "c4_d512": "c4_d512 D=512, 256 chains: the c4 workload on the global-memory tier"}
+             "c4_d512": "c4_d512 D=512, 256 chains: the c4 workload on the global-memory tier",
+             "c2i_stream": "c2i_stream: c2(i) with n_steps = 1, 2²⁰ chains (the HBM-bound regime)",
+             "c3b_d128": "c3b_d128: SoftAbs funnel D=128, 256 chains (workspace tier)",
+             "c3b_d256": "c3b_d256: SoftAbs funnel D=256, 256 chains (workspace tier)"}
     for k, v in rec.get("configs", {}).items():
         if "error" not in v:
             rows.append((k, names.get(k, k), v))
@@ -44,13 +47,15 @@ def main():
         if roof.get("hbm_model"):
             hm = roof["hbm_model"]
             ex = f"HBM-bound: modelled {hm['bytes_per_launch'] / 1e9:.0f} GB per launch = {hm['achieved_GBs'] / 1e3:.2f} TB/s ({hm['frac_of_hbm_peak']:.2f} of peak)"
-        if roof.get("executed"):
+            if roof.get("executed"):
+                ex += f"; MFMA busy {roof['mfma_busy']:.3f}"
+        elif roof.get("executed"):
             e = roof["executed"]
             if "refine_pairs_per_chain_step" in e:
                 ex = (f"MFMA busy {roof['mfma_busy']:.3f}; {e['refine_pairs_per_chain_step']:.1f} CG pairs + "
                       f"{e['sweeps_per_chain_step']:.2f} sweeps per step")
             else:  # SoftAbs: eigenvector refinement
-                ex = (f"MFMA busy {roof['mfma_busy']:.3f}; {e['mfma_products_per_chain_step']:.0f} 64³ products, "
+                ex = (f"MFMA busy {roof['mfma_busy']:.3f}; {e['mfma_products_per_chain_step']:.0f} NP³ products, "
                       f"{e['refined_decompositions_per_chain_step']:.1f} refined decompositions + "
                       f"{e['jacobi_sweeps_per_chain_step']:.2f} Jacobi sweeps per step")
         tr = roof.get("traffic")
