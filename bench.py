@@ -207,7 +207,7 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
         if wide:
             # round 6: the SoftAbs workspace tiers - 64 < D <= 256, the three matrices of a chain in a global-memory
             # workspace (csrc/softabs.h NP = 128 / 256) - on the c3(b) funnel at two and four times its dimension
-            dim, traj = (128, 10) if config == "c3b_d128" else (256, 4)
+            dim, traj = (128, 20) if config == "c3b_d128" else (256, 10)  # (a pass restarts from q0: its first decomposition is cold)
         wts = np.linspace(0.5, 2.0, dim - 1)
         if config == "c3b_dense":
             h = 0.01  # (at 0.02 half of the banana chains meet a ConvergenceError within 100 steps - in the reference too)

@@ -63,6 +63,7 @@ struct SaLds {
   double* Vt;     // NP > 64: V^T, kept beside V (row-major, LD): the operand a product walks ALONG the rows of V is read
   double* X2t;    //          down the columns of V^T instead - 16 lanes on one 128-byte run, not on 16 cache lines
   double* snapg;  // NP > 64: [2][NP][NP] the step's two basis snapshots (double precision: the workspace has the room)
+  double* panel;  // NP > 64: [kPanelK][kPanelRows + NP] operand panels of staged_product (LDS, behind the ring)
 };
 constexpr int kRingDoubles = 15 * 8 * 2;  // (c, s) of the 15 local rounds x 8 pair slots of a block round
 
@@ -194,7 +195,12 @@ struct SoftAbsBackendT {
   static constexpr int kSnapDoubles = NP == 64 ? NP * NP : 0;  // 2 x NP x NP floats
   static constexpr int kSnapExtra = NP == 64 ? kSnapDoubles - (2 * GW * kRingDoubles - kRingScratch) : 0;
   static_assert(NP != 64 || (2 * GW * kRingDoubles >= kRingScratch && kSnapExtra > 0), "ring / snapshot layout");
-  static constexpr int kLdsDoubles = kLdsVectors + (kMatricesInLds ? MAT + 2 * MATJ : 0) + kSnapExtra;
+  // NP > 64 (round 6): operand panels of the refinement's products staged in LDS (staged_product): KP rows of the A operand
+  // (the output rows of one pass: 128 columns) and of the B operand (NP columns)
+  static constexpr int kPanelK = NP == 256 ? 16 : 32;
+  static constexpr int kPanelRows = NP == 256 ? 128 : NP;  // output rows a pass of staged_product covers
+  static constexpr int kPanelDoubles = kMatricesInLds ? 0 : kPanelK * (kPanelRows + NP);
+  static constexpr int kLdsDoubles = kLdsVectors + (kMatricesInLds ? MAT + 2 * MATJ : 0) + kSnapExtra + kPanelDoubles;
   static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU");
   static constexpr int kWorkDoubles = kMatricesInLds ? 0 : 6 * MAT + 2 * MATJ + 2 * NP * NP;  // per chain, global memory (H, W, V; S, R, X2, Vt, X2t; snapshots)
   __device__ static __forceinline__ double rp_sum(double v) { return rp_sum_n<RP>(v); }
@@ -855,10 +861,64 @@ struct SoftAbsBackendT {
     }
   }
 
-  __device__ __forceinline__ int refine_eigh_global() {
-    constexpr int T = NP / 16, KQ = NP / 4, QR = T / 4, NQ = T * QR, NW = NT / 64;
+  // C = A^T B over the whole NP x NP output (both operands row-major with leading dimension LD, walked down their columns),
+  // the operands STAGED THROUGH LDS (round 6): quad_tiles' waves each read their own 16-column strip of A and 64-column strip
+  // of B from memory - 160 KB a quad, 10 MB a product at NP = 256 where the operands are 1 MB - and with 256 chains' 1.6 MB
+  // of matrices each beyond the L2 that was HBM traffic: 1.5 GB a chain-step, 3.1 TB/s (profiles/r06_c3b_d256_pmc_hbm.json).
+  // Here the workgroup loads kPanelK rows of both operands once (coalesced), every wave takes its k-steps' operands from
+  // LDS (sixteen consecutive doubles a lane group: conflict-free), and a wave's output tiles - T / 2 of one tile row - stay
+  // in its accumulators across the panels.  NP = 256: two passes of 128 output rows (eight accumulator tiles a wave: the
+  // 128-register budget of a 1024-thread workgroup), the B panels read twice: 1.6 MB a product.
+  // init(i, c) starts entry (i, c), store(i, c, v) takes it.  Ends with the panels free (a barrier) but NOT with the stores
+  // visible: the caller's barrier does that.
+  template <class InitF, class StoreF>
+  __device__ __forceinline__ void staged_product(const double* __restrict__ A, const double* __restrict__ B, InitF init,
+                                                 StoreF store) {
+    constexpr int T = NP / 16, KP = kPanelK, RH = kPanelRows, HALVES = NP / RH, TPW = T / 2;
+    static_assert(RH / 16 * 2 == NT / 64, "two waves a tile row of a pass");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, j = lane & 15;
+    double* const pa = w.panel;            // [KP][RH]
+    double* const pb = w.panel + KP * RH;  // [KP][NP]
+#pragma unroll 1
+    for (int h = 0; h < HALVES; ++h) {
+      const int I = (RH / 16) * h + (wave >> 1), J0 = TPW * (wave & 1);
+      d4 acc[TPW];
+#pragma unroll
+      for (int u = 0; u < TPW; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[u][r] = init(16 * I + 4 * r + g, 16 * (J0 + u) + j);
+#pragma unroll 1
+      for (int p0 = 0; p0 < NP; p0 += KP) {
+        __syncthreads();  // (the previous panel has been consumed)
+        for (int el = tid; el < KP * RH; el += NT) {
+          const int kk = el / RH, ii = el % RH;
+          pa[el] = A[(p0 + kk) * LD + RH * h + ii];
+        }
+        for (int el = tid; el < KP * NP; el += NT) {
+          const int kk = el / NP, c = el % NP;
+          pb[el] = B[(p0 + kk) * LD + c];
+        }
+        __syncthreads();
+        const double* const al = pa + g * RH + 16 * (I - (RH / 16) * h) + j;
+        const double* const bl = pb + g * NP + 16 * J0 + j;
+#pragma unroll
+        for (int sidx = 0; sidx < KP / 4; ++sidx) {
+          const double a = al[4 * sidx * RH];
+#pragma unroll
+          for (int u = 0; u < TPW; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl[4 * sidx * NP + 16 * u], acc[u], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TPW; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) store(16 * I + 4 * r + g, 16 * (J0 + u) + j, acc[u][r]);
+    }
+    __syncthreads();
+  }
+
+  __device__ __forceinline__ int refine_eigh_global() {
     double* const Gm = w.W;  // G = A X, then E (row-major, leading dimension LD)
     double prev = 0.0;
     ++unchecked;
@@ -866,16 +926,7 @@ struct SoftAbsBackendT {
       double* const X = w.V;
       if constexpr (USERH) {
         // a dense Hessian: G = A X as a tiled product, A symmetric and read down its columns
-#pragma unroll 1
-        for (int qd = wave; qd < NQ; qd += NW) {
-          const int I = qd / QR, J0 = 4 * (qd % QR);
-          d4 ax[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-          quad_tiles<false>(w.H + KQ * g * LD + 16 * I + j, X + KQ * g * LD + 16 * J0 + j, nullptr, ax);
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Gm[(16 * I + 4 * r + g) * LD + 16 * (J0 + u) + j] = ax[u][r];
-        }
+        staged_product(w.H, X, [](int, int) { return 0.0; }, [&](int i, int c, double v) { Gm[i * LD + c] = v; });
         ++n_products;
       } else {
       // G = A X from the structure of the built-in Hessians (diagonal; arrowhead), as refine_eigh()
@@ -900,27 +951,15 @@ struct SoftAbsBackendT {
         unchecked = 0;
         ++n_products;
       }
-#pragma unroll 1
-      for (int qd = wave; qd < NQ; qd += NW) {  // tiles of S = X^T G and of X^T X, four in a row at a time
-        const int I = qd / QR, J0 = 4 * (qd % QR);
-        const double* const xi = X + KQ * g * LD + 16 * I + j;
-        {
-          d4 sv[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-          quad_tiles<false>(xi, Gm + KQ * g * LD + 16 * J0 + j, nullptr, sv);
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) w.S[(16 * I + 4 * r + g) * LD + 16 * (J0 + u) + j] = sv[u][r];
+      // S = X^T G, then R = X^T X (or the identity, see above)
+      staged_product(X, Gm, [](int, int) { return 0.0; }, [&](int i, int c, double v) { w.S[i * LD + c] = v; });
+      if (with_xx) {
+        staged_product(X, X, [](int, int) { return 0.0; }, [&](int i, int c, double v) { w.R[i * LD + c] = v; });
+      } else {
+        for (int el = tid; el < NP * NP; el += NT) {
+          const int i = el / NP, c = el % NP;
+          w.R[i * LD + c] = i == c ? 1.0 : 0.0;
         }
-        d4 xx[4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-        if (with_xx) quad_tiles<false>(xi, X + KQ * g * LD + 16 * J0 + j, nullptr, xx);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * I + 4 * r + g, c = 16 * (J0 + u) + j;
-            w.R[i * LD + c] = with_xx ? xx[u][r] : (i == c ? 1.0 : 0.0);
-          }
       }
       __syncthreads();
       if (tid < NP) w.lam[tid] = tid < dim ? fdiv(w.S[tid * LD + tid], w.R[tid * LD + tid]) : 1.0;
@@ -947,23 +986,14 @@ struct SoftAbsBackendT {
       if (!last && pass > 0 && !(max_e < prev)) return -1;
       prev = max_e;
       ++n_products;
-#pragma unroll 1
-      for (int qd = wave; qd < NQ; qd += NW) {  // X' = X + X E into the other basis buffer (and its transpose)
-        const int I = qd / QR, J0 = 4 * (qd % QR);
-        d4 acc[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[u][r] = X[(16 * I + 4 * r + g) * LD + 16 * (J0 + u) + j];
-        // X[16 I + j][k] = X^T[k][16 I + j]: the a operand down a column of the transpose
-        quad_tiles<false>(w.Vt + KQ * g * LD + 16 * I + j, Gm + KQ * g * LD + 16 * J0 + j, nullptr, acc);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            w.X2[(16 * I + 4 * r + g) * LD + 16 * (J0 + u) + j] = acc[u][r];
-            w.X2t[(16 * (J0 + u) + j) * LD + 16 * I + 4 * r + g] = acc[u][r];
-          }
+      // X' = X + X E into the other basis buffer (and its transpose): X[i][k] = X^T[k][i], the A operand is V^T
+      {
+        double* const x2 = w.X2;
+        double* const x2t = w.X2t;
+        staged_product(w.Vt, Gm, [&](int i, int c) { return X[i * LD + c]; }, [&](int i, int c, double v) {
+          x2[i * LD + c] = v;
+          x2t[c * LD + i] = v;
+        });
       }
       __syncthreads();
       {
@@ -1729,8 +1759,9 @@ __device__ __forceinline__ void init_backend(SoftAbsBackendT<NP, USERH>& bk, con
   bk.w.cnt = p; p += 8;
   bk.w.prof = p; p += 24;
   bk.w.stash = p; p += SL_COUNT * (NP + 1);
-  bk.w.ring = p;  // (last: the snapshots start in its tail and run on behind it, see kRingScratch)
+  bk.w.ring = p;  // (last of the vectors: the snapshots start in its tail and run on behind it, see kRingScratch)
   bk.w.snap = reinterpret_cast<float*>(p + B::kRingScratch);
+  bk.w.panel = lds + B::kLdsDoubles - B::kPanelDoubles;  // (NP > 64: the last kPanelDoubles of the allocation)
   if (B::kMatricesInLds && A.dim < NP) {  // w.V is read whole by the matrix-core products: zero beyond dim, once
     for (int el = threadIdx.x; el < NP * NP; el += NT) {
       const int i = el / NP, j = el % NP;
