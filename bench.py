@@ -162,9 +162,10 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
         # source (mici_amd/user_examples.py), compiled around the matrix-core kernels at run time.  c3_user: a metric that
         # is not built in (softplus diagonal + rank one, D = 64); c4_general: the c4 workload itself with its rank-one
         # metric handed over as user source (D = 256) - M(x) v of the refinement solves from the user's entries.
-        # c4_d512 (round 5): the c4 workload at twice the dimension - beyond what a CU's registers hold, on the global-memory
+        # c4_d512 (round 5; round 6: c4's own trajectory length, 50 - it was 5 while a pass took 0.1 s a step): the c4 workload
+        # at twice the dimension - beyond what a CU's registers hold, on the global-memory
         # tier (csrc/implicit_global.h: the chain's metric in HBM, blocked sweep, column-walk products)
-        dim, h, traj = (64, 0.02, 100) if config in ("c3", "c3_user") else ((512, 0.008, 5) if config == "c4_d512"
+        dim, h, traj = (64, 0.02, 100) if config in ("c3", "c3_user") else ((512, 0.008, 50) if config == "c4_d512"
                                                                               else (256, 0.01, 50))
         if config == "c3_user":
             from mici_amd import user_examples
