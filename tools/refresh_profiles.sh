@@ -30,6 +30,7 @@ cd $ROOT
 O=$ROOT/gpurun_out/${ROUND}p; [ "$PART" = "2" ] || [ -n "$ONLY" ] || rm -rf $O; mkdir -p $O
 KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2i_stream:leapfrog_stream_kernel c2iv:leapfrog_mfma_kernel c3:implicit_fork_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel c3_user:mm_rtc_riem_step c4_general:mm_rtc_riem_step c3b_dense:mm_rtc_softabs_step c4_d512:implicit_global_kernel c3b_d128:softabs_leapfrog_kernel c3b_d256:softabs_leapfrog_kernel"
 
+NF=80; [ -n "$SHORT_FUZZ" ] && NF=30
 # PART=1: tests, counters, bench, kernel trace;  PART=2: phase clocks, fuzz, host latency;  unset: everything
 if [ "$PART" = "2" ]; then mkdir -p $O; fi
 if [ "$PART" != "2" ]; then
@@ -38,7 +39,6 @@ if [ -n "$ONLY" ]; then K2=""; for pair in $KERNELS; do for o in $ONLY; do [ "${
 if [ -z "$SKIP_TESTS" ]; then
   python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -4 > $O/gpu_tests.txt; cat $O/gpu_tests.txt
 fi
-NF=80; [ -n "$SHORT_FUZZ" ] && NF=30
 for pair in $KERNELS; do
   cfg=${pair%%:*}; kern=${pair##*:}
   bash tools/pmc_hbm.sh $cfg $kern > $O/pmc_hbm_$cfg.log 2>&1
