@@ -679,10 +679,14 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
             mfma_flops = 2048.0 * (counters_acc.get("n_factor_full", 0) * mf["full"]
                                    + counters_acc.get("n_factor_solve", 0) * mf["solve"])
             dp = float(mf["padded_dim"])
-            valu_flops = (4.0 * counters_acc.get("n_refine", 0) + 2.0 * n_b + 6.0 * done_local) * dp * dp
+            # (round 6: a solve-only construction of the rank-one-update metric by the Woodbury identity, implicit_core.h
+            # lowrank_solve, is ONE product with the held inverse: 2 D^2 flops)
+            n_lr = counters_acc.get("n_lowrank", 0)
+            valu_flops = (4.0 * counters_acc.get("n_refine", 0) + 2.0 * n_lr + 2.0 * n_b + 6.0 * done_local) * dp * dp
             w["executed"] = dict(mfma_flops_per_chain_step=mfma_flops / max(done_local, 1.0),
                                  valu_flops_per_chain_step=valu_flops / max(done_local, 1.0),
                                  refine_pairs_per_chain_step=counters_acc.get("n_refine", 0) / max(done_local, 1.0),
+                                 lowrank_solves_per_chain_step=n_lr / max(done_local, 1.0),
                                  sweeps_per_chain_step=(counters_acc.get("n_factor_full", 0)
                                                         + counters_acc.get("n_factor_solve", 0)) / max(done_local, 1.0))
     hbm_model = None
@@ -699,7 +703,9 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
         # written), one mirror pass (half read, the whole written, + the FP32 copy: half the bytes again); F r of a CG pair
         # reads the FP32 copy (half the bytes; a lock-step pair of solves shares the pass - not subtracted here), the momentum
         # evaluations and the A / C sub-steps the FP64 matrix.  The rank-one base matrix is shared by all chains (L2 / MALL).
-        f64_products = n_b + 4.0 * done_local
+        # (round 6: the Woodbury solves of the rank-one-update metric read the FP64 inverse once each; in lock step two share a pass -
+        # not subtracted here)
+        f64_products = n_b + 4.0 * done_local + counters_acc.get("n_lowrank", 0)
         f32_products = counters_acc.get("n_refine", 0)
         bytes_total = 8.0 * dp * dp * (sweeps * (1.0 + np.ceil(d / nb) + 2.0) + f64_products + 0.5 * f32_products)
         hbm_model = dict(bytes_per_launch=bytes_total / steps, achieved_GBs=bytes_total / steps / launch_s / 1e9,

@@ -33,7 +33,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define MM_ABI_VERSION 3
+#define MM_ABI_VERSION 4
 
 typedef struct mm_ctx mm_ctx;
 typedef struct mm_model mm_model;
@@ -181,6 +181,9 @@ typedef struct mm_counters {
   int64_t n_factor_solve; /* trailing sweeps: LDL^T factorisation + one substitution */
   int64_t n_mfma_products; /* SoftAbs, D <= 64: 64^3 products run on the matrix cores (refinement passes, G = H V,
                             * B = A J of grad_quadratic_form_inv) */
+  int64_t n_lowrank;      /* round 6: solve-only constructions of the built-in rank-one-update metric obtained from the
+                           * explicit inverse at the step's start by the Woodbury identity (one product each; no CG pair,
+                           * no factorisation).  MICI_AMD_LOWRANK=0 routes them through the CG refinement instead. */
 } mm_counters;
 
 /* ---- library / context ------------------------------------------------------------------------- */

@@ -12,7 +12,7 @@ from .errors import DeviceError
 _LIB_PATH = os.environ.get("MICI_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmici_amd.so")
 
 MM_COMM_ID_BYTES = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_double_p = C.POINTER(C.c_double)
 c_int8_p = C.POINTER(C.c_int8)
@@ -71,7 +71,7 @@ class ProjOpts(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_grad", "n_metric", "n_inverse", "n_fp_evals", "n_fp_solves", "n_newton_iters",
-        "n_constr", "n_eigh", "n_refine", "n_factor_full", "n_factor_solve", "n_mfma_products")]
+        "n_constr", "n_eigh", "n_refine", "n_factor_full", "n_factor_solve", "n_mfma_products", "n_lowrank")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

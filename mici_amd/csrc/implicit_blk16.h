@@ -239,8 +239,13 @@ struct Team16 {
   __device__ __forceinline__ double sum(double x) const { return uniform_f64(team_reduce(x, 0, red)); }
 };
 
-template <int RMETRIC, bool PROFILE = false>
+template <int RMETRIC, bool PROFILE = false, bool LOWRANK = false>
 struct TeamBlk16 {
+  // implicit_core.h lowrank_solve (round 6): the rank-one-update metric's solve-only constructions by the Woodbury identity
+  // from the held inverse - one product F d (matvec) each instead of ~2.5 CG pairs of M(x) v + F r
+  static constexpr bool kLowRank = LOWRANK && RMETRIC == MM_RMETRIC_RANK1;
+  __device__ __forceinline__ double lowrank_scale() const { return (double)dim; }
+  __device__ static constexpr bool lowrank_on() { return true; }  // (compile-time: the launcher picks the instantiation)
   static constexpr bool kSolveByInverse = false;
   static constexpr bool kUnifiedConstruct = true;  // implicit_core.h: one construction site, mode at run time
   static constexpr bool kCountersInLds = true;     // implicit_core.h: work counters in LDS, bumped by thread 0
@@ -333,6 +338,7 @@ struct TeamBlk16 {
     r.n_refine = (long long)lds[kOffRed + 16 + CNT_REFINE];
     r.n_full = (long long)lds[kOffRed + 16 + CNT_FULL];
     r.n_trail = (long long)lds[kOffRed + 16 + CNT_TRAIL];
+    r.n_lowrank = (long long)lds[kOffRed + 16 + CNT_LOWRANK];
   }
   static_assert(CNT_COUNT <= 8, "work counters occupy lds[kOffRed + 16 .. 23]");
   // developer builds: the clock since the last call goes to the phase announced then; [kOffProf + PH_COUNT] = that
@@ -372,6 +378,38 @@ struct TeamBlk16 {
     __syncthreads();
     *sa = uniform_f64(ra);
     *sb = uniform_f64(rb);
+  }
+  // four team-uniform sums in one pass (two barriers); partials in the last wave's block of the sweeps' scratch (no sweep runs
+  // while a solve-only construction is in flight)
+  __device__ __forceinline__ void sum4(double a, double b, double c, double d, double* sa, double* sb, double* sc,
+                                       double* sd) {
+    const int lane = fresh_lane(), wv = opaque_wave(wave);
+    const bool act = tid < dim;
+    a = wave_sum(act ? a : 0.0);
+    b = wave_sum(act ? b : 0.0);
+    c = wave_sum(act ? c : 0.0);
+    d = wave_sum(act ? d : 0.0);
+    double* red = lds + kOffScr + 7 * 64;  // [4][8]
+    if (lane == 0) {
+      red[wv] = a;
+      red[8 + wv] = b;
+      red[16 + wv] = c;
+      red[24 + wv] = d;
+    }
+    __syncthreads();
+    double ra = red[0], rb = red[8], rc = red[16], rd = red[24];
+#pragma unroll
+    for (int k = 1; k < NWAVE; ++k) {
+      ra += red[k];
+      rb += red[8 + k];
+      rc += red[16 + k];
+      rd += red[24 + k];
+    }
+    __syncthreads();
+    *sa = uniform_f64(ra);
+    *sb = uniform_f64(rb);
+    *sc = uniform_f64(rc);
+    *sd = uniform_f64(rd);
   }
   __device__ __forceinline__ double& slot(int i) { return lds[kOffStash + i * VLM + (tid < DPM ? tid : DPM)]; }
 
@@ -1130,8 +1168,8 @@ struct TeamBlk16 {
   }
 };
 
-template <int RMETRIC, bool PROFILE>
-__device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC, PROFILE>& bk, const ImplicitArgs& A, double* lds) {
+template <int RMETRIC, bool PROFILE, bool LOWRANK>
+__device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC, PROFILE, LOWRANK>& bk, const ImplicitArgs& A, double* lds) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   __builtin_assume(wv >= 0 && wv < NWAVE);
   bk.wave = wv;
@@ -1154,9 +1192,9 @@ __device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC, PROFILE>& bk, co
   __syncthreads();
 }
 
-template <int RMETRIC, bool PROFILE = false>
+template <int RMETRIC, bool PROFILE = false, bool LOWRANK = false>
 __device__ __forceinline__ void implicit_blk16_body(const ImplicitArgs& A, double* lds) {
-  TeamBlk16<RMETRIC, PROFILE> bk;
+  TeamBlk16<RMETRIC, PROFILE, LOWRANK> bk;
   init_backend(bk, A, lds);
   const int64_t chain = blockIdx.x;
   const int tid = threadIdx.x, dim = A.dim;
@@ -1185,10 +1223,10 @@ __device__ __forceinline__ void implicit_blk16_body(const ImplicitArgs& A, doubl
 }
 
 #ifndef MM_RTC_BUILD  // the in-tree instantiations (a run-time translation unit defines an extern "C" wrapper instead)
-template <int RMETRIC, bool PROFILE = false>
+template <int RMETRIC, bool PROFILE = false, bool LOWRANK = false>
 __global__ __launch_bounds__(NTHR, 2) void implicit_blk16_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  implicit_blk16_body<RMETRIC, PROFILE>(A, lds);
+  implicit_blk16_body<RMETRIC, PROFILE, LOWRANK>(A, lds);
 }
 #endif
 

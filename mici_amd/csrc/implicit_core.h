@@ -55,6 +55,7 @@ struct ImplicitArgs {
                   // memory the held inverse is dumped to (user_metric.h), NP the backend's padded dimension
   int no_dual;    // 1: the two position solves of a step one after the other, as in rounds 1-4 (MICI_AMD_DUAL=0: A/B runs
                   // against the lock-step form)
+  int no_lowrank; // 1: MICI_AMD_LOWRANK=0 (backends that decide it at run time: the global-memory tier)
 };
 
 // MICI_AMD_REFINE=0 in the environment switches the refinement of the solve-only constructions off (read once)
@@ -67,6 +68,15 @@ inline int mm_refine_disabled() {
   return off;
 }
 // MICI_AMD_DUAL=0: the reversibility-check solve and the C-adjoint solve of a step run one after the other (read once)
+// MICI_AMD_LOWRANK=0: the rank-one-update metric's solve-only constructions by the CG refinement, as every other metric's
+// (lowrank_solve below is the default for it; read once)
+inline int mm_lowrank_disabled() {
+  static const int off = [] {
+    const char* e = getenv("MICI_AMD_LOWRANK");
+    return (e && e[0] == '0') ? 1 : 0;
+  }();
+  return off;
+}
 inline int mm_dual_disabled() {
   static const int off = [] {
     const char* e = getenv("MICI_AMD_DUAL");
@@ -145,12 +155,13 @@ struct ChainResult {
   int status, done;
   long long n_evals, n_solves, n_metric, n_grad;
   long long n_refine, n_full, n_trail;  // executed work: PCG product pairs, full sweeps, trailing sweeps
+  long long n_lowrank;                  // solve-only constructions by the low-rank-update identity (lowrank_solve)
 };
 
 // Work counters of a chain.  A backend with kCountersInLds keeps them in LDS (bumped by one thread) instead of in
 // four 64-bit registers of every thread that are live across the whole step: the register-resident-metric team
 // kernel has none to spare.
-enum { CNT_EVALS = 0, CNT_SOLVES, CNT_METRIC, CNT_GRAD, CNT_REFINE, CNT_FULL, CNT_TRAIL, CNT_COUNT };
+enum { CNT_EVALS = 0, CNT_SOLVES, CNT_METRIC, CNT_GRAD, CNT_REFINE, CNT_FULL, CNT_TRAIL, CNT_LOWRANK, CNT_COUNT };
 template <class BK>
 __device__ __forceinline__ void bump(BK& bk, ChainResult& r, const int which, const int n) {
   if constexpr (BK::kCountersInLds) {
@@ -162,7 +173,8 @@ __device__ __forceinline__ void bump(BK& bk, ChainResult& r, const int which, co
     else if (which == CNT_GRAD) r.n_grad += n;
     else if (which == CNT_REFINE) r.n_refine += n;
     else if (which == CNT_FULL) r.n_full += n;
-    else r.n_trail += n;
+    else if (which == CNT_TRAIL) r.n_trail += n;
+    else r.n_lowrank += n;
   }
 }
 
@@ -438,6 +450,78 @@ struct dual_trait { static constexpr bool value = false; };
 template <class BK>
 struct dual_trait<BK, decltype((void)BK::kDual)> { static constexpr bool value = BK::kDual; };
 
+// ---- solve-only constructions of a LOW-RANK-UPDATE metric by the Woodbury identity (round 6) ------------------------------
+// A backend with kLowRank says: metric_func(x) = B + x x^T / D with a constant B (the built-in rank-one-update metric, BASELINE
+// c3 / c4).  The metric at a fixed-point iterate x then differs from the metric at the step's start x0 - whose EXPLICIT inverse
+// F the backend holds - by a rank-TWO term,
+//     M(x) = M(x0) + (d x^T + x0 d^T) / D,    d = x - x0,
+// and M(x)^-1 p follows from F by the Woodbury identity (the reference's own tool for such matrices: matrices.py
+// SymmetricLowRankUpdateMatrix / PositiveDefiniteLowRankUpdateMatrix) with ONE product F d per evaluation:
+//     u = c - (F d) w1 - b w2,   b = F x0,  c = F p  (both fixed while the step's two position solves run),
+//     K w = (x^T c, d^T c),      K = D I + [x^T F d, x^T b; d^T F d, d^T b]   (2 x 2; K -> [D, x0^T b; 0, D] as d -> 0).
+// The d-form keeps K's condition at O(1) and the correction small where the iterates are close to x0; its error is that of
+// applying F - the explicit inverse the momentum updates apply anyway (measured against extended precision: on a par with a
+// LAPACK solve of M(x), tools/lowrank_accuracy.py).  det K = D^2 det M(x) / det M(x0) > 0 for positive-definite metrics:
+// a determinant that is not finite, not positive or tiny hands the construction to the factorisation, which reports the
+// reference's errors.  The CG refinement (refine_solve) stays the path of every other metric; MICI_AMD_LOWRANK=0 selects it
+// for this one too.  F is symmetric (the backends keep its lower triangle), so x0^T F d = d^T b and the five inner
+// products reduce to three per evaluation + two per step (sbb = x0^T b, sbc = x0^T c).
+template <class BK, class = void>
+struct lowrank_trait { static constexpr bool value = false; };
+template <class BK>
+struct lowrank_trait<BK, decltype((void)BK::kLowRank)> { static constexpr bool value = BK::kLowRank; };
+enum { LR_B = 0, LR_C = 1 };  // rslot() indices (the CG state's: no refinement runs on a kLowRank backend)
+
+// the 2 x 2 system and the correction, from the three inner products of an evaluation (team-uniform arithmetic)
+__device__ __forceinline__ bool lowrank_finish(double D, double sbb, double sbc, double e3, double e4, double r2, double ad,
+                                               double b, double c, double* u_out) {
+  const double k11 = D + (e3 + e4), k12 = sbb + e4, k21 = e3, k22 = D + e4, r1 = sbc + r2;
+  const double det = __builtin_fma(k11, k22, -(k12 * k21));
+  const double idet = 1.0 / det;
+  const double w1 = __builtin_fma(r1, k22, -(k12 * r2)) * idet, w2 = __builtin_fma(k11, r2, -(k21 * r1)) * idet;
+  *u_out = c - __builtin_fma(ad, w1, b * w2);
+  // (a NaN or an infinity anywhere in x, F d, b or c reaches one of the sums, hence det or w)
+  return det > 1e-8 * D * D && det < 1e8 * D * D && fabs(w1) < 1e300 && fabs(w2) < 1e300;
+}
+
+template <class BK>
+__device__ __forceinline__ bool lowrank_solve(BK& bk, double x, double sbb, double sbc, double* u_out, ChainResult& r) {
+  const int ph0 = prof(bk, PH_FAPPLY);
+  const double d = x - bk.slot(SL_Q);
+  const double ad = bk.matvec(d);
+  prof(bk, PH_RSUM);
+  const double b = bk.rslot(LR_B), c = bk.rslot(LR_C);
+  double e3, e4, r2, unused;
+  bk.sum4(d * ad, d * b, d * c, 0.0, &e3, &e4, &r2, &unused);
+  const bool ok = lowrank_finish(bk.lowrank_scale(), sbb, sbc, e3, e4, r2, ad, b, c, u_out);
+  bump(bk, r, CNT_LOWRANK, 1);
+  prof(bk, ph0);
+  return ok;
+}
+
+// kDual backends: one evaluation of the reversibility-check solve and one of the C-adjoint solve together (see refine_solve2)
+// - the two products F d share ONE pass over the held inverse (bk.matvec2_exact: the inverse itself, not a preconditioner's
+// copy of it), which on the global-memory tier is the evaluation's whole HBM traffic.
+template <class BK>
+__device__ __forceinline__ void lowrank_solve2(BK& bk, double xC, double xA, double sbb, double sbc, double* uC, double* uA,
+                                               bool* okC, bool* okA, ChainResult& r) {
+  const int ph0 = prof(bk, PH_FAPPLY);
+  const double x0 = bk.slot(SL_Q);
+  const double dC = xC - x0, dA = xA - x0;
+  double adC, adA;
+  bk.matvec2_exact(dC, dA, &adC, &adA);
+  prof(bk, PH_RSUM);
+  const double b = bk.rslot(LR_B), c = bk.rslot(LR_C);
+  double e3C, e4C, r2C, e3A, e4A, r2A;
+  bk.sum4(dC * adC, dC * b, dC * c, dA * adA, &e3C, &e4C, &r2C, &e3A);
+  bk.sum2(dA * b, dA * c, &e4A, &r2A);
+  const double D = bk.lowrank_scale();
+  *okC = lowrank_finish(D, sbb, sbc, e3C, e4C, r2C, adC, b, c, uC);
+  *okA = lowrank_finish(D, sbb, sbc, e3A, e4A, r2A, adA, b, c, uA);
+  bump(bk, r, CNT_LOWRANK, 2);
+  prof(bk, ph0);
+}
+
 // kFork backends (round 6, implicit_fork.h): a SECOND WAVE of the chain runs the reversibility-check solve while this one runs
 // the C-adjoint solve - the two position solves of a step are independent of each other until both have ended
 // (integrators.py:521-536: the reference runs one to its end, then the other).  bk.fork_chk(iter, stage) hands the check's
@@ -465,11 +549,16 @@ struct refine_trait<BK, decltype((void)BK::kRefine)> { static constexpr bool val
 template <class BK>
 __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t, int n_steps,
                                                                const mm_fp_opts& o) {
-  ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0, 0, 0, 0};
+  ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   constexpr bool kRefine = refine_trait<BK>::value;
+  constexpr bool kLowRank = kRefine && lowrank_trait<BK>::value;  // lowrank_solve instead of refine_solve
   constexpr bool kDual = kRefine && dual_trait<BK>::value;
   constexpr bool kFork = kRefine && fork_trait<BK>::value;
   static_assert(!(kDual && kFork), "lock step and fork are alternatives");
+  static_assert(!(kLowRank && kFork), "a forked backend runs the refinement");
+  bool lr_on = false;  // (a compile-time constant where the backend's lowrank_on() is: the refinement's code is then dead)
+  if constexpr (kLowRank) lr_on = bk.lowrank_on();
+  double lr_sbb = 0.0, lr_sbc = 0.0;  // kLowRank: x0^T F x0, x0^T F p of the step in flight (team-uniform)
   bool fork_ok = false;
   bool anchor = false;  // kRefine: the backend holds the explicit inverse at the step's starting position
   // kDual: the C-adjoint solve advances together with the reversibility-check solve while both are in flight
@@ -547,8 +636,12 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         // sequential code below carries on from exactly there.
         double uC, uA;
         bool okC, okA;
-        refine_solve2(bk, bk.slot(SL_XQ), bk.slot(SL_PTA), bk.slot(SL_PW), bk.slot(SL_UC), bk.slot(SL_UA), &uC, &uA,
-                      &okC, &okA, r);
+        if (lr_on) {
+          if constexpr (kLowRank) lowrank_solve2(bk, bk.slot(SL_XQ), bk.slot(SL_PTA), lr_sbb, lr_sbc, &uC, &uA, &okC, &okA, r);
+        } else {
+          refine_solve2(bk, bk.slot(SL_XQ), bk.slot(SL_PTA), bk.slot(SL_PW), bk.slot(SL_UC), bk.slot(SL_UA), &uC, &uA,
+                        &okC, &okA, r);
+        }
         if (!okA) dual_ok = false;  // the adjoint solve's evaluation is repeated (and factorised) when its turn comes
         if (!okC) {
           skip_refine = true;       // the check's refinement failed: factorise at its point (below), as refine_solve would
@@ -603,8 +696,12 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       if (!need_inverse && anchor && bk.refine_on && !skip_refine) {  // team-uniform
         // (both guesses read, one selected - and written back by a uniform branch below: no slot is indexed by a run-time
         // value, so a backend may keep its slots in registers)
-        const double g_chk = bk.slot(SL_UC), g_adj = bk.slot(SL_UA);
-        refined = refine_solve(bk, bk.slot(SL_XQ), bk.slot(SL_PW), mode == MODE_CHK ? g_chk : g_adj, &u_pos, r);
+        if (lr_on) {
+          if constexpr (kLowRank) refined = lowrank_solve(bk, bk.slot(SL_XQ), lr_sbb, lr_sbc, &u_pos, r);
+        } else {
+          const double g_chk = bk.slot(SL_UC), g_adj = bk.slot(SL_UA);
+          refined = refine_solve(bk, bk.slot(SL_XQ), bk.slot(SL_PW), mode == MODE_CHK ? g_chk : g_adj, &u_pos, r);
+        }
         anchor = refined;  // a failed refinement is followed by the factorisation below, which overwrites the inverse
       }
     }
@@ -668,7 +765,12 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       }
       // ---- A: p -= t dh1_dpos(q), dh1 = grad + 0.5 vjp(M^-1)            integrators.py:493-494
       const double q = bk.slot(SL_Q);
-      double pw = bk.slot(SL_P) - t * (bk.slot(SL_G) + bk.half_vjp_inv(q));
+      const double hvq = bk.half_vjp_inv(q);
+      // kLowRank: 0.5 vjp(M^-1) of the rank-one-update metric IS F q / D - the b of lowrank_solve, for this step's solves
+      if constexpr (kLowRank) {
+        if (lr_on) bk.rslot(LR_B) = hvq * bk.lowrank_scale();
+      }
+      double pw = bk.slot(SL_P) - t * (bk.slot(SL_G) + hvq);
       // ---- B fwd: solve p' = p - t dh2_dpos(q, p')                        integrators.py:496-502
       bump(bk, r, CNT_SOLVES, 1);
       r.status = momentum_solve(bk, pw, t, q, o, &pw, r);
@@ -676,9 +778,16 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       // ---- C fwd: q += t M(q)^-1 p                                        integrators.py:517-519
       bk.slot(SL_QINIT) = q;
       const double u0 = bk.matvec(pw);
-      if constexpr (kRefine) {  // M(q)^-1 p: the first guess of both position solves
-        bk.slot(SL_UC) = u0;
-        bk.slot(SL_UA) = u0;
+      if constexpr (kRefine) {
+        if (lr_on) {  // c = F p and the two inner products that stay fixed while the position solves run
+          if constexpr (kLowRank) {
+            bk.rslot(LR_C) = u0;
+            bk.sum2(q * bk.rslot(LR_B), q * u0, &lr_sbb, &lr_sbc);
+          }
+        } else {  // M(q)^-1 p: the first guess of both position solves
+          bk.slot(SL_UC) = u0;
+          bk.slot(SL_UA) = u0;
+        }
       }
       const double qw = q + t * u0;
       bk.slot(SL_PW) = pw;
@@ -869,7 +978,7 @@ enum { MPM_FWD = 0, MPM_ADJ = 1, MPM_BACK = 2 };
 template <class BK>
 __device__ __forceinline__ ChainResult implicit_midpoint_chain(BK& bk, double t, int n_steps,
                                                                const mm_fp_opts& o) {
-  ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0, 0, 0, 0};
+  ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const double half = 0.5 * t;
   int mode = MPM_FWD;
   FpCtl c{0, 0};
@@ -957,6 +1066,7 @@ __device__ __forceinline__ void add_counters(mm_counters* c, const ChainResult& 
   atomicAdd((unsigned long long*)&c->n_refine, (unsigned long long)r.n_refine);
   atomicAdd((unsigned long long*)&c->n_factor_full, (unsigned long long)r.n_full);
   atomicAdd((unsigned long long*)&c->n_factor_solve, (unsigned long long)r.n_trail);
+  if (r.n_lowrank) atomicAdd((unsigned long long*)&c->n_lowrank, (unsigned long long)r.n_lowrank);
   atomicAdd((unsigned long long*)&c->n_fp_evals, (unsigned long long)r.n_evals);
   atomicAdd((unsigned long long*)&c->n_fp_solves, (unsigned long long)r.n_solves);
 }

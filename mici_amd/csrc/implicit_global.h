@@ -84,6 +84,13 @@ struct GlobalBackend {
   // metrics (a user metric's M(x) v evaluates its entries per product and point: nothing to share).
   static constexpr bool kDual = RMETRIC != MM_RMETRIC_USER;
   bool dual_off;                                  // MICI_AMD_DUAL=0: one solve after the other
+  // implicit_core.h lowrank_solve (round 6): the rank-one-update metric's solve-only constructions by the Woodbury identity
+  // from the held inverse - ONE pass over the FP64 inverse (F d) each instead of ~2.5 CG pairs; decided at run time here
+  // (MICI_AMD_LOWRANK=0: the lock-step CG refinement)
+  static constexpr bool kLowRank = RMETRIC == MM_RMETRIC_RANK1;
+  bool lowrank_on_;
+  __device__ __forceinline__ bool lowrank_on() const { return lowrank_on_; }
+  __device__ __forceinline__ double lowrank_scale() const { return (double)dim; }
   int dim, dp, tid, target, flip;
   double inv_dim_;
   double* lds;
@@ -603,6 +610,16 @@ struct GlobalBackend {
     *y0 = pscale_ * a;
     *y1 = pscale_ * b;
   }
+  // two products with the held inverse ITSELF in one pass (implicit_core.h lowrank_solve2)
+  __device__ __forceinline__ void matvec2_exact(double v0, double v1, double* y0, double* y1) {
+    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
+      *y0 = tid < dim ? dinv_ * v0 : 0.0;
+      *y1 = tid < dim ? dinv_ * v1 : 0.0;
+      return;
+    }
+    publish2(v0, v1);
+    column_walk2(A, dp, dim, y0, y1);
+  }
   __device__ __forceinline__ void metric_point2(double x0, double x1) {
     xpt_ = tid < dim ? x0 : 0.0;
     xpt2_ = tid < dim ? x1 : 0.0;
@@ -803,6 +820,7 @@ __device__ __forceinline__ void init_backend(GlobalBackend<RMETRIC, NB>& bk, con
   bk.refine_on = A.no_refine == 0 && RMETRIC != MM_RMETRIC_DIAGQUAD;  // (a diagonal metric: every construction elementwise)
   bk.dinv_ = 0.0;
   bk.dual_off = A.no_dual != 0;
+  bk.lowrank_on_ = A.no_lowrank == 0;
   bk.xpt_ = 0.0;
   bk.xpt2_ = 0.0;
 }

@@ -90,9 +90,14 @@ __host__ __device__ constexpr int mfma_wave_doubles() {
   return kMfmaWaveDoubles + (RMETRIC == MM_RMETRIC_USER ? mmuser::lds_doubles(64) : 0);
 }
 
-template <int RMETRIC, bool PROFILE = false>
+template <int RMETRIC, bool PROFILE = false, bool LOWRANK = false>
 struct MfmaBackend {
   static constexpr bool kProf = PROFILE;  // developer builds: cycles per phase of the step
+  // implicit_core.h lowrank_solve (round 6): the rank-one-update metric's solve-only constructions by the Woodbury identity
+  // from the held inverse - one row product F d each instead of ~3 CG pairs
+  static constexpr bool kLowRank = LOWRANK && RMETRIC == MM_RMETRIC_RANK1;
+  __device__ __forceinline__ double lowrank_scale() const { return (double)dim; }
+  __device__ static constexpr bool lowrank_on() { return true; }  // (compile-time: the launcher picks the instantiation)
   __device__ __forceinline__ int prof_switch(int phase) {
     int old = 0;
     if (lane == 0) {
@@ -326,6 +331,7 @@ struct MfmaBackend {
   }
 
   // the points of a lock-step pair: system 0's where metric_point() puts it, system 1's behind it
+  __device__ __forceinline__ void matvec2_exact(double v0, double v1, double* y0, double* y1) { matvec2(v0, v1, y0, y1); }
   __device__ __forceinline__ void metric_point2(double x0, double x1) {
     w.qt[lane] = (lane < dim) ? x0 : 0.0;
     w.qt[64 + lane] = (lane < dim) ? x1 : 0.0;
@@ -793,7 +799,7 @@ struct MfmaBackend {
   }
 };
 
-template <int RMETRIC, bool PROFILE = false>
+template <int RMETRIC, bool PROFILE = false, bool LOWRANK = false>
 __device__ __forceinline__ void implicit_mfma_body(const ImplicitArgs& A, double* lds) {
   double* base_lds = lds;
   const int base_elems = (RMETRIC == MM_RMETRIC_RANK1) ? kBaseDoubles : 0;
@@ -815,7 +821,7 @@ __device__ __forceinline__ void implicit_mfma_body(const ImplicitArgs& A, double
   double p = act ? A.mom[chain * dim + lane] : 0.0;
   const double t = signed_step(A.dir, A.step_scale, chain, A.step_size);
 
-  MfmaBackend<RMETRIC, PROFILE> bk;
+  MfmaBackend<RMETRIC, PROFILE, LOWRANK> bk;
   bk.dim = dim;
   bk.inv_dim_ = 1.0 / (double)dim;
   bk.lane = lane;
@@ -871,10 +877,10 @@ __device__ __forceinline__ void implicit_mfma_body(const ImplicitArgs& A, double
 
 
 #ifndef MM_RTC_BUILD  // the in-tree instantiations (a run-time translation unit defines an extern "C" wrapper instead)
-template <int RMETRIC, bool PROFILE = false>
+template <int RMETRIC, bool PROFILE = false, bool LOWRANK = false>
 __global__ __launch_bounds__(64 * kWaves) void implicit_mfma_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  implicit_mfma_body<RMETRIC, PROFILE>(A, lds);
+  implicit_mfma_body<RMETRIC, PROFILE, LOWRANK>(A, lds);
 }
 #endif
 

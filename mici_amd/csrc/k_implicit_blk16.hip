@@ -166,8 +166,13 @@ int mm_launch_implicit_blk16(mm_ctx* ctx, const mm_model* m, mm_state* s, double
   a.no_refine = mm_refine_disabled();
   a.no_dual = mm_dual_disabled();
   a.counters = d_counters;
-  if (m->rmetric == MM_RMETRIC_RANK1)
+  if (m->rmetric == MM_RMETRIC_RANK1) {
+    // round 6: solve-only constructions by the Woodbury identity from the held inverse (implicit_core.h lowrank_solve);
+    // MICI_AMD_LOWRANK=0: the CG refinement
+    if (!mm_lowrank_disabled() && a.no_refine == 0)
+      return launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_RANK1, false, true>, a);
     return launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_RANK1>, a);
+  }
   return launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_DIAGQUAD>, a);
 }
 
@@ -250,7 +255,8 @@ extern "C" __attribute__((visibility("default"))) int mm_debug_blk16_step_profil
   double* d_out = nullptr;
   MM_HIP_CHECK(ctx, hipMalloc(&d_out, bytes));
   a.out = d_out;
-  int lrc = launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_RANK1, true>, a);
+  int lrc = mm_lowrank_disabled() ? launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_RANK1, true>, a)
+                                  : launch_blk16(ctx, implicit_blk16_kernel<MM_RMETRIC_RANK1, true, true>, a);
   if (lrc == MM_OK) {
     hipError_t e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -111,6 +111,18 @@ int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
   const bool r1 = m->rmetric == MM_RMETRIC_RANK1;
   // round 6: MICI_AMD_PAIR=1 selects the two-waves-per-chain kernel (implicit_pair.h: built, parity-green, and measured -
   // it loses 21 % on c3, profiles/r06_ab_c3_pair.txt - so the one-wave kernel stays the default)
+  // round 6: the rank-one-update metric's solve-only constructions by the Woodbury identity from the held inverse
+  // (implicit_core.h lowrank_solve; one-wave kernel); MICI_AMD_LOWRANK=0: the CG refinement (forked kernel by default)
+  if (r1 && !mm_lowrank_disabled() && a.no_refine == 0) {
+    const unsigned blocks = (unsigned)((s->n + kWaves - 1) / kWaves);
+    const size_t lds = (kBaseDoubles + kWaves * kMfmaWaveDoubles) * sizeof(double);
+    MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(implicit_mfma_kernel<MM_RMETRIC_RANK1, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((implicit_mfma_kernel<MM_RMETRIC_RANK1, false, true>), dim3(blocks), dim3(64 * kWaves), lds,
+                       ctx->stream, a);
+    MM_HIP_CHECK(ctx, hipGetLastError());
+    return MM_OK;
+  }
   static const bool pair_on = [] { const char* e = getenv("MICI_AMD_PAIR"); return e && e[0] == '1'; }();
   if (pair_on) return mm_launch_implicit_pair(ctx, m, s, a);
   // round 6: the forked kernel (implicit_fork.h: a second wave per chain runs the reversibility-check solve while the first runs
@@ -188,10 +200,17 @@ extern "C" __attribute__((visibility("default"))) int mm_debug_mfma_step_profile
   a.out = d_out;
   const unsigned blocks = (unsigned)((s->n + kWaves - 1) / kWaves);
   const size_t lds = (kBaseDoubles + kWaves * kMfmaWaveDoubles) * sizeof(double);
-  MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(implicit_mfma_kernel<MM_RMETRIC_RANK1, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((implicit_mfma_kernel<MM_RMETRIC_RANK1, true>), dim3(blocks), dim3(64 * kWaves), lds, ctx->stream,
-                     a);
+  if (mm_lowrank_disabled()) {
+    MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(implicit_mfma_kernel<MM_RMETRIC_RANK1, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((implicit_mfma_kernel<MM_RMETRIC_RANK1, true>), dim3(blocks), dim3(64 * kWaves), lds, ctx->stream,
+                       a);
+  } else {
+    MM_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(implicit_mfma_kernel<MM_RMETRIC_RANK1, true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((implicit_mfma_kernel<MM_RMETRIC_RANK1, true, true>), dim3(blocks), dim3(64 * kWaves), lds,
+                       ctx->stream, a);
+  }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

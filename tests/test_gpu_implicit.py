@@ -497,29 +497,40 @@ def test_refined_solves_equal_factorised_solves():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode in ("1", "0"):
+    # "1": the default - round 6: the rank-one-update metric's solve-only constructions by the Woodbury identity from the held
+    # inverse (implicit_core.h lowrank_solve) on the matrix-core kernels; "cg": MICI_AMD_LOWRANK=0, the CG refinement there
+    # too; "0": MICI_AMD_REFINE=0, every construction factorised
+    for mode, env in (("1", {}), ("cg", {"MICI_AMD_LOWRANK": "0"}), ("0", {"MICI_AMD_REFINE": "0"})):
         r = subprocess.run([sys.executable, "-c", _REFINE_SCRIPT.format(root=root)], capture_output=True, text=True,
-                           env=dict(os.environ, MICI_AMD_REFINE=mode), cwd=root)
+                           env=dict(os.environ, **env), cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
     for key in res["1"]:
-        a, b = res["1"][key], res["0"][key]
-        assert a["status"] == b["status"] and a["n_done"] == b["n_done"], key
-        ca, cb = a["counters"], b["counters"]
-        for k in ("n_fp_evals", "n_fp_solves", "n_metric", "n_grad"):
-            assert ca[k] == cb[k], (key, k, ca[k], cb[k])
-        if key.startswith(("70_", "270_")):
-            # the VALU team kernels (round 4: refinement there too) have no factorised solve-only path: switched off, every
-            # construction is a full inversion (11 a step); refined, one a step is
-            assert cb["n_refine"] == 0 and cb["n_factor_solve"] == 0 and ca["n_factor_solve"] == 0
-            assert ca["n_refine"] > 0 and 4 * ca["n_factor_full"] < cb["n_factor_full"], (key, ca, cb)
-        else:
-            assert cb["n_refine"] == 0 and cb["n_factor_solve"] > 0          # switched off: trailing sweeps only
-            assert ca["n_refine"] > 0 and ca["n_factor_solve"] < cb["n_factor_solve"]
-            assert ca["n_factor_full"] == cb["n_factor_full"]
-        ok = np.array(a["status"]) == 0
-        assert_close(np.array(a["q"])[ok], np.array(b["q"])[ok], 1e-11, f"{key} positions")
-        assert_close(np.array(a["p"])[ok], np.array(b["p"])[ok], 1e-11, f"{key} momenta")
+        b = res["0"][key]
+        cb = b["counters"]
+        for mode in ("1", "cg"):
+            a = res[mode][key]
+            assert a["status"] == b["status"] and a["n_done"] == b["n_done"], (key, mode)
+            ca = a["counters"]
+            for k in ("n_fp_evals", "n_fp_solves", "n_metric", "n_grad"):
+                assert ca[k] == cb[k], (key, mode, k, ca[k], cb[k])
+            lowrank = mode == "1" and key.startswith(("64_", "200_"))  # (the kernels with the Woodbury path: c3's and c4's)
+            if key.startswith(("70_", "270_")):
+                # the VALU team kernels (round 4: refinement there too) have no factorised solve-only path: switched off, every
+                # construction is a full inversion (11 a step); refined, one a step is
+                assert cb["n_refine"] == 0 and cb["n_factor_solve"] == 0 and ca["n_factor_solve"] == 0
+                assert ca["n_refine"] > 0 and 4 * ca["n_factor_full"] < cb["n_factor_full"], (key, ca, cb)
+            else:
+                assert cb["n_refine"] == 0 and cb["n_factor_solve"] > 0          # switched off: trailing sweeps only
+                if lowrank:
+                    assert ca["n_lowrank"] > 0 and ca["n_refine"] == 0, (key, ca)
+                else:
+                    assert ca["n_refine"] > 0 and ca["n_lowrank"] == 0, (key, mode, ca)
+                assert ca["n_factor_solve"] < cb["n_factor_solve"]
+                assert ca["n_factor_full"] == cb["n_factor_full"]
+            ok = np.array(a["status"]) == 0
+            assert_close(np.array(a["q"])[ok], np.array(b["q"])[ok], 1e-11, f"{key} {mode} positions")
+            assert_close(np.array(a["p"])[ok], np.array(b["p"])[ok], 1e-11, f"{key} {mode} momenta")
     small = res["1"]["64_0.02"]["counters"]
     assert small["n_factor_solve"] == 0 and np.all(np.array(res["1"]["64_0.02"]["status"]) == 0)
     big = res["1"]["64_0.35"]
