@@ -184,6 +184,9 @@ typedef struct mm_counters {
   int64_t n_lowrank;      /* round 6: solve-only constructions of the built-in rank-one-update metric obtained from the
                            * explicit inverse at the step's start by the Woodbury identity (one product each; no CG pair,
                            * no factorisation).  MICI_AMD_LOWRANK=0 routes them through the CG refinement instead. */
+  int64_t n_inverse_update; /* round 6: explicit inverses of that metric carried to the step's new position by the symmetric
+                             * rank-two update of the held inverse instead of a full sweep (n_factor_full counts the sweeps
+                             * that did run: one per launch + one every MICI_AMD_LOWRANK_REFRESH steps + the fallbacks) */
 } mm_counters;
 
 /* ---- library / context ------------------------------------------------------------------------- */

@@ -71,7 +71,7 @@ class ProjOpts(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_grad", "n_metric", "n_inverse", "n_fp_evals", "n_fp_solves", "n_newton_iters",
-        "n_constr", "n_eigh", "n_refine", "n_factor_full", "n_factor_solve", "n_mfma_products", "n_lowrank")]
+        "n_constr", "n_eigh", "n_refine", "n_factor_full", "n_factor_solve", "n_mfma_products", "n_lowrank", "n_inverse_update")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

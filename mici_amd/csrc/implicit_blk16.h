@@ -76,8 +76,8 @@ constexpr int kOffStash = 0;                               // [SL_COUNT_REFINE][
 constexpr int kOffNat = kOffStash + SL_COUNT_REFINE * VLM; // [VLM] natural-order vector
 constexpr int kOffVperm = kOffNat + VLM;                   // [DPM] the same vector as [I][g][r]: row operands as one 32-byte read
 constexpr int kOffAux = kOffVperm + DPM;                   // [VLM] second natural-order vector (z of the substitution)
-constexpr int kOffRed = kOffAux + VLM;                     // [24]  team reductions / flags / work counters
-constexpr int kOffScr = kOffRed + 24;                      // [NWAVE][64]: [0] scratch of the in-tile sweep, [1..4] T = -P^-1
+constexpr int kOffRed = kOffAux + VLM;                     // [32]  team reductions / flags / work counters ([16 ..])
+constexpr int kOffScr = kOffRed + 32;                      // [NWAVE][64]: [0] scratch of the in-tile sweep, [1..4] T = -P^-1
                                                            // in lane order, [5][0] its positive-definite flag
 constexpr int kOffX = kOffScr + NWAVE * 64;                // [2][DPM][CS]  panel, double-buffered by block parity
 constexpr int kOffPart = kOffX + 2 * DPM * CS;             // [DPM][PSTR]
@@ -246,6 +246,8 @@ struct TeamBlk16 {
   static constexpr bool kLowRank = LOWRANK && RMETRIC == MM_RMETRIC_RANK1;
   __device__ __forceinline__ double lowrank_scale() const { return (double)dim; }
   __device__ static constexpr bool lowrank_on() { return true; }  // (compile-time: the launcher picks the instantiation)
+  int lr_refresh_;
+  __device__ __forceinline__ int lowrank_refresh() const { return lr_refresh_; }
   static constexpr bool kSolveByInverse = false;
   static constexpr bool kUnifiedConstruct = true;  // implicit_core.h: one construction site, mode at run time
   static constexpr bool kCountersInLds = true;     // implicit_core.h: work counters in LDS, bumped by thread 0
@@ -339,8 +341,9 @@ struct TeamBlk16 {
     r.n_full = (long long)lds[kOffRed + 16 + CNT_FULL];
     r.n_trail = (long long)lds[kOffRed + 16 + CNT_TRAIL];
     r.n_lowrank = (long long)lds[kOffRed + 16 + CNT_LOWRANK];
+    r.n_inv_update = (long long)lds[kOffRed + 16 + CNT_INVUPD];
   }
-  static_assert(CNT_COUNT <= 8, "work counters occupy lds[kOffRed + 16 .. 23]");
+  static_assert(CNT_COUNT <= 16, "work counters occupy lds[kOffRed + 16 .. 31]");
   // developer builds: the clock since the last call goes to the phase announced then; [kOffProf + PH_COUNT] = that
   // phase, [+ PH_COUNT + 1] = the time of the call.  Thread 0 only.
   __device__ __forceinline__ int prof_switch(int phase) {
@@ -980,6 +983,33 @@ struct TeamBlk16 {
     return tid < dim ? -y : 0.0;
   }
 
+  // ---- implicit_core.h lowrank_update: F += al a a^T + be (a b^T + b a^T) + ga b b^T on the tiles (they hold -F) ------------
+  // entry (i, j) takes a_i u_j + b_i v_j with u = al a + be b, v = be a + ga b: the row operands a, b in the [I][g][r] order
+  // (one 32-byte read a tile), the column operands u, v in natural order.  Eight multiply-adds a tile and lane.
+  __device__ __forceinline__ void inverse_update(double al, double be, double ga, double a, double b) {
+    if (tid < DPM) {
+      const bool act = tid < dim;
+      const int pi = (((tid >> 4) << 2) + (tid & 3)) << 2 | ((tid >> 2) & 3);
+      lds[kOffVperm + pi] = act ? a : 0.0;
+      lds[kOffB + pi] = act ? b : 0.0;
+      lds[kOffNat + tid] = act ? __builtin_fma(al, a, be * b) : 0.0;
+      lds[kOffAux + tid] = act ? __builtin_fma(be, a, ga * b) : 0.0;
+    }
+    __syncthreads();
+    const int w = opaque_wave(wave);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int I = tile_i(s, w), J = tile_j(s, w);
+      const d4 ar = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
+      const d4 br = *reinterpret_cast<const d4*>(lds + kOffB + ((I * 4 + g) << 2));
+      const double uj = lds[kOffNat + 16 * J + j], vj = lds[kOffAux + 16 * J + j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[s][r] = __builtin_fma(-ar[r], uj, __builtin_fma(-br[r], vj, acc[s][r]));
+    }
+    __syncthreads();
+  }
+
   // ---- u = M^-1 b from the trailing-sweep (LDL^T) factors: the backward substitution over the tile rows, one workgroup
   // barrier per tile row --------------------------------------------------------------------------------------------
   // (the forward and diagonal passes ran inside sweep<true>: aux holds z = D^-1 L^-1 b)
@@ -1183,8 +1213,9 @@ __device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC, PROFILE, LOWRANK
   bk.tparams = A.tparams;
   bk.work = A.work ? A.work + (int64_t)blockIdx.x * (DPM * DPM) : nullptr;
   bk.refine_on = A.no_refine == 0;
+  bk.lr_refresh_ = A.lowrank_refresh;
   for (int i = threadIdx.x; i < DPM * PSTR; i += NTHR) lds[kOffPart + i] = 0.0;  // unused partial-sum slots stay 0
-  if (threadIdx.x < 8) lds[kOffRed + 16 + threadIdx.x] = 0.0;                     // work counters
+  if (threadIdx.x < 16) lds[kOffRed + 16 + threadIdx.x] = 0.0;                    // work counters
   if constexpr (PROFILE) {
     if (threadIdx.x < PH_COUNT + 2)
       lds[kOffProf + threadIdx.x] = threadIdx.x == PH_COUNT + 1 ? (double)__builtin_readcyclecounter() : 0.0;

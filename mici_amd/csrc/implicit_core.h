@@ -56,6 +56,7 @@ struct ImplicitArgs {
   int no_dual;    // 1: the two position solves of a step one after the other, as in rounds 1-4 (MICI_AMD_DUAL=0: A/B runs
                   // against the lock-step form)
   int no_lowrank; // 1: MICI_AMD_LOWRANK=0 (backends that decide it at run time: the global-memory tier)
+  int lowrank_refresh;  // kLowRank backends: explicit-inverse updates in a row before the next factorisation (lowrank_update)
 };
 
 // MICI_AMD_REFINE=0 in the environment switches the refinement of the solve-only constructions off (read once)
@@ -76,6 +77,16 @@ inline int mm_lowrank_disabled() {
     return (e && e[0] == '0') ? 1 : 0;
   }();
   return off;
+}
+// MICI_AMD_LOWRANK_REFRESH=n: the held inverse of the rank-one-update metric is carried from step to step by the rank-two update
+// (lowrank_update) at most n times in a row before it is factorised afresh (default 64; 0: factorised every step)
+inline int mm_lowrank_refresh() {
+  static const int n = [] {
+    const char* e = getenv("MICI_AMD_LOWRANK_REFRESH");
+    const int v = e ? atoi(e) : 64;
+    return v < 0 ? 0 : v;
+  }();
+  return n;
 }
 inline int mm_dual_disabled() {
   static const int off = [] {
@@ -156,12 +167,13 @@ struct ChainResult {
   long long n_evals, n_solves, n_metric, n_grad;
   long long n_refine, n_full, n_trail;  // executed work: PCG product pairs, full sweeps, trailing sweeps
   long long n_lowrank;                  // solve-only constructions by the low-rank-update identity (lowrank_solve)
+  long long n_inv_update;               // explicit inverses carried to the step's new position by the same identity
 };
 
 // Work counters of a chain.  A backend with kCountersInLds keeps them in LDS (bumped by one thread) instead of in
 // four 64-bit registers of every thread that are live across the whole step: the register-resident-metric team
 // kernel has none to spare.
-enum { CNT_EVALS = 0, CNT_SOLVES, CNT_METRIC, CNT_GRAD, CNT_REFINE, CNT_FULL, CNT_TRAIL, CNT_LOWRANK, CNT_COUNT };
+enum { CNT_EVALS = 0, CNT_SOLVES, CNT_METRIC, CNT_GRAD, CNT_REFINE, CNT_FULL, CNT_TRAIL, CNT_LOWRANK, CNT_INVUPD, CNT_COUNT };
 template <class BK>
 __device__ __forceinline__ void bump(BK& bk, ChainResult& r, const int which, const int n) {
   if constexpr (BK::kCountersInLds) {
@@ -174,7 +186,8 @@ __device__ __forceinline__ void bump(BK& bk, ChainResult& r, const int which, co
     else if (which == CNT_REFINE) r.n_refine += n;
     else if (which == CNT_FULL) r.n_full += n;
     else if (which == CNT_TRAIL) r.n_trail += n;
-    else r.n_lowrank += n;
+    else if (which == CNT_LOWRANK) r.n_lowrank += n;
+    else r.n_inv_update += n;
   }
 }
 
@@ -499,6 +512,37 @@ __device__ __forceinline__ bool lowrank_solve(BK& bk, double x, double sbb, doub
   return ok;
 }
 
+// The EXPLICIT inverse itself travels the same way (round 6): the step ends at x = x0 + d, where B-adjoint and the next
+// step's A / B / C need M(x)^-1 as a matrix - and M(x)^-1 = F - [F d, b] K^-1 [(b + F d)^T; (F d)^T] is a symmetric rank-two
+// update of the held inverse,
+//     F += al a a^T + be (a b^T + b a^T) + ga b b^T,   a = F d,  al = -(k22 - k12) / det,  be = -k22 / det,  ga = k21 / det
+// (k11 - k21 = k22 makes it symmetric), O(D^2) instead of the sweep's 2 D^3 flops.  Applied to an inverse that carries a
+// rounding error E - F = (M(x0) + E)^-1 - the identity yields (M(x) + E)^-1 exactly: errors add up, one update's rounding at a
+// time, and are not amplified (200 updates in a row: 2.7e-15 relative, tools/lowrank_accuracy.py).  The backend still
+// factorises afresh at every launch's first step, after bk.lowrank_refresh() updates in a row (MICI_AMD_LOWRANK_REFRESH,
+// default 64; 0: every step, the round-5 behaviour), whenever a solve of the step fell back to the factorisation, and when
+// det K is not finite, not positive or tiny.
+template <class BK>
+__device__ __forceinline__ bool lowrank_update(BK& bk, double x, double sbb, ChainResult& r) {
+  const int ph0 = prof(bk, PH_FULL);
+  const double d = x - bk.slot(SL_Q);
+  const double a = bk.matvec(d);
+  const double b = bk.rslot(LR_B);
+  double e3, e4;
+  bk.sum2(d * a, d * b, &e3, &e4);
+  const double D = bk.lowrank_scale();
+  const double k11 = D + (e3 + e4), k12 = sbb + e4, k21 = e3, k22 = D + e4;
+  const double det = __builtin_fma(k11, k22, -(k12 * k21));
+  const bool ok = det > 1e-8 * D * D && det < 1e8 * D * D;  // (a NaN or an infinity in x reaches e3 / e4, hence det)
+  if (ok) {
+    const double idet = 1.0 / det;
+    bk.inverse_update(-(k22 - k12) * idet, -k22 * idet, k21 * idet, a, b);
+    bump(bk, r, CNT_INVUPD, 1);
+  }
+  prof(bk, ph0);
+  return ok;
+}
+
 // kDual backends: one evaluation of the reversibility-check solve and one of the C-adjoint solve together (see refine_solve2)
 // - the two products F d share ONE pass over the held inverse (bk.matvec2_exact: the inverse itself, not a preconditioner's
 // copy of it), which on the global-memory tier is the evaluation's whole HBM traffic.
@@ -549,7 +593,7 @@ struct refine_trait<BK, decltype((void)BK::kRefine)> { static constexpr bool val
 template <class BK>
 __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t, int n_steps,
                                                                const mm_fp_opts& o) {
-  ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   constexpr bool kRefine = refine_trait<BK>::value;
   constexpr bool kLowRank = kRefine && lowrank_trait<BK>::value;  // lowrank_solve instead of refine_solve
   constexpr bool kDual = kRefine && dual_trait<BK>::value;
@@ -558,6 +602,9 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
   static_assert(!(kLowRank && kFork), "a forked backend runs the refinement");
   bool lr_on = false;  // (a compile-time constant where the backend's lowrank_on() is: the refinement's code is then dead)
   if constexpr (kLowRank) lr_on = bk.lowrank_on();
+  int lr_since = 0;         // kLowRank: steps since the held inverse was last factorised (lowrank_update in between)
+  bool hv_valid = false;    // the A sub-step that ends a step and the one that starts the next share 0.5 vjp(M^-1) at q'
+  double hv_next = 0.0;
   double lr_sbb = 0.0, lr_sbc = 0.0;  // kLowRank: x0^T F x0, x0^T F p of the step in flight (team-uniform)
   bool fork_ok = false;
   bool anchor = false;  // kRefine: the backend holds the explicit inverse at the step's starting position
@@ -705,9 +752,19 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         anchor = refined;  // a failed refinement is followed by the factorisation below, which overwrites the inverse
       }
     }
+    if constexpr (kLowRank) {
+      if (lr_on && mode == MODE_BADJ && anchor && lr_since < bk.lowrank_refresh()) {  // team-uniform
+        refined = lowrank_update(bk, bk.slot(SL_XQ), lr_sbb, r);  // the held inverse, carried from q to q'
+        if (refined) ++lr_since;
+      }
+    }
     if (refined) {
       okm = true;
+      if constexpr (kLowRank) anchor = true;
     } else {
+      if constexpr (kLowRank) {
+        if (need_inverse) lr_since = 0;
+      }
       prof(bk, need_inverse ? PH_FULL : PH_TRAIL);
       if constexpr (BK::kUnifiedConstruct) {
         // one construction site, the mode decided at run time: explicit inverse, or the single solve M(x)^-1 pw
@@ -755,7 +812,9 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         }
         // ---- A: p -= t dh1_dpos(q')                                      integrators.py:544
         const double g = bk.slot(SL_GNEW);
-        pw = pw - t * (g + bk.half_vjp_inv(qw));
+        hv_next = bk.half_vjp_inv(qw);
+        hv_valid = true;
+        pw = pw - t * (g + hv_next);
         bk.slot(SL_G) = g;
         bk.slot(SL_Q) = qw;
         bk.slot(SL_P) = pw;
@@ -765,7 +824,9 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       }
       // ---- A: p -= t dh1_dpos(q), dh1 = grad + 0.5 vjp(M^-1)            integrators.py:493-494
       const double q = bk.slot(SL_Q);
-      const double hvq = bk.half_vjp_inv(q);
+      // (the step that just ended evaluated it at this very point with this very inverse: reused, bit for bit)
+      const double hvq = hv_valid ? hv_next : bk.half_vjp_inv(q);
+      hv_valid = false;
       // kLowRank: 0.5 vjp(M^-1) of the rank-one-update metric IS F q / D - the b of lowrank_solve, for this step's solves
       if constexpr (kLowRank) {
         if (lr_on) bk.rslot(LR_B) = hvq * bk.lowrank_scale();
@@ -978,7 +1039,7 @@ enum { MPM_FWD = 0, MPM_ADJ = 1, MPM_BACK = 2 };
 template <class BK>
 __device__ __forceinline__ ChainResult implicit_midpoint_chain(BK& bk, double t, int n_steps,
                                                                const mm_fp_opts& o) {
-  ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const double half = 0.5 * t;
   int mode = MPM_FWD;
   FpCtl c{0, 0};
@@ -1067,6 +1128,7 @@ __device__ __forceinline__ void add_counters(mm_counters* c, const ChainResult& 
   atomicAdd((unsigned long long*)&c->n_factor_full, (unsigned long long)r.n_full);
   atomicAdd((unsigned long long*)&c->n_factor_solve, (unsigned long long)r.n_trail);
   if (r.n_lowrank) atomicAdd((unsigned long long*)&c->n_lowrank, (unsigned long long)r.n_lowrank);
+  if (r.n_inv_update) atomicAdd((unsigned long long*)&c->n_inverse_update, (unsigned long long)r.n_inv_update);
   atomicAdd((unsigned long long*)&c->n_fp_evals, (unsigned long long)r.n_evals);
   atomicAdd((unsigned long long*)&c->n_fp_solves, (unsigned long long)r.n_solves);
 }

@@ -91,6 +91,8 @@ struct GlobalBackend {
   bool lowrank_on_;
   __device__ __forceinline__ bool lowrank_on() const { return lowrank_on_; }
   __device__ __forceinline__ double lowrank_scale() const { return (double)dim; }
+  int lr_refresh_;
+  __device__ __forceinline__ int lowrank_refresh() const { return lr_refresh_; }
   int dim, dp, tid, target, flip;
   double inv_dim_;
   double* lds;
@@ -610,6 +612,41 @@ struct GlobalBackend {
     *y0 = pscale_ * a;
     *y1 = pscale_ * b;
   }
+  // implicit_core.h lowrank_update: F += al a a^T + be (a b^T + b a^T) + ga b b^T - ONE read-modify-write pass over the FP64
+  // workspace (4 MB at D = 512) where the sweep makes ceil(D / NB) + 3.  Entry (j, c) takes a_j u_c + b_j v_c, u = al a + be b,
+  // v = be a + ga b: a, b broadcast from LDS per row, u_c, v_c in registers per column (coalesced over the threads, rows split
+  // between the two threads of a column as in column_walk).  The FP32 copy is the CG refinement's preconditioner: not read
+  // while the Woodbury path is on, rewritten by the next factorisation.
+  __device__ __forceinline__ void inverse_update(double al, double be, double ga, double a, double b) {
+    if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) return;
+    publish2(a, b);
+    double* part = lds + kOffPart;  // [2][NT]
+    part[tid] = tid < dim ? __builtin_fma(al, a, be * b) : 0.0;
+    part[NT + tid] = tid < dim ? __builtin_fma(be, a, ga * b) : 0.0;
+    __syncthreads();
+    const bool two = 2 * dim <= NT;
+    const int h = (two && tid >= NT / 2) ? 1 : 0;
+    const int c = tid - h * (NT / 2);
+    const int nh = two ? ((dim + 1) >> 1) : dim;
+    const int j0 = h * nh, j1 = (j0 + nh < dim) ? j0 + nh : dim;
+    if (c < dim) {
+      const double uc = part[c], vc = part[NT + c];
+      const double* nat = lds + kOffNat;
+      const double* nat2 = lds + kOffNat2;
+      double* col = A + c;
+      int j = j0;
+      for (; j + kWalk <= j1; j += kWalk) {
+        double x[kWalk];
+#pragma unroll
+        for (int e = 0; e < kWalk; ++e) x[e] = col[(size_t)(j + e) * dp];
+#pragma unroll
+        for (int e = 0; e < kWalk; ++e)
+          col[(size_t)(j + e) * dp] = __builtin_fma(nat[j + e], uc, __builtin_fma(nat2[j + e], vc, x[e]));
+      }
+      for (; j < j1; ++j) col[(size_t)j * dp] = __builtin_fma(nat[j], uc, __builtin_fma(nat2[j], vc, col[(size_t)j * dp]));
+    }
+    __syncthreads();  // (workgroup-scope release / acquire of the global stores: the next product reads them)
+  }
   // two products with the held inverse ITSELF in one pass (implicit_core.h lowrank_solve2)
   __device__ __forceinline__ void matvec2_exact(double v0, double v1, double* y0, double* y1) {
     if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) {
@@ -820,7 +857,8 @@ __device__ __forceinline__ void init_backend(GlobalBackend<RMETRIC, NB>& bk, con
   bk.refine_on = A.no_refine == 0 && RMETRIC != MM_RMETRIC_DIAGQUAD;  // (a diagonal metric: every construction elementwise)
   bk.dinv_ = 0.0;
   bk.dual_off = A.no_dual != 0;
-  bk.lowrank_on_ = A.no_lowrank == 0;
+  bk.lowrank_on_ = A.no_lowrank == 0 && A.no_refine == 0;
+  bk.lr_refresh_ = A.lowrank_refresh;
   bk.xpt_ = 0.0;
   bk.xpt2_ = 0.0;
 }

@@ -98,6 +98,8 @@ struct MfmaBackend {
   static constexpr bool kLowRank = LOWRANK && RMETRIC == MM_RMETRIC_RANK1;
   __device__ __forceinline__ double lowrank_scale() const { return (double)dim; }
   __device__ static constexpr bool lowrank_on() { return true; }  // (compile-time: the launcher picks the instantiation)
+  int lr_refresh_;
+  __device__ __forceinline__ int lowrank_refresh() const { return lr_refresh_; }
   __device__ __forceinline__ int prof_switch(int phase) {
     int old = 0;
     if (lane == 0) {
@@ -730,6 +732,24 @@ struct MfmaBackend {
 
   __device__ __forceinline__ double diag() { return lane < dim ? fd_ : 0.0; }
 
+  // implicit_core.h lowrank_update: F += al a a^T + be (a b^T + b a^T) + ga b b^T on the row form - lane i adds
+  // a_i u_j + b_i v_j to its row, u = al a + be b and v = be a + ga b broadcast from LDS.  (The tiles of the sweep go stale:
+  // the next factorisation rebuilds them; every product of the step reads the rows.)
+  __device__ __forceinline__ void inverse_update(double al, double be, double ga, double a, double b) {
+    const double u = lane < dim ? __builtin_fma(al, a, be * b) : 0.0, v = lane < dim ? __builtin_fma(be, a, ga * b) : 0.0;
+    w.nat[lane] = u;
+    w.aux[lane] = v;
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const d4 uu = *reinterpret_cast<const d4*>(w.nat + 4 * k), vv = *reinterpret_cast<const d4*>(w.aux + 4 * k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fr_[4 * k + e] = __builtin_fma(a, uu[e], __builtin_fma(b, vv[e], fr_[4 * k + e]));
+    }
+    fd_ = __builtin_fma(a, u, __builtin_fma(b, v, fd_));
+    wave_sync();
+  }
+
   // 0.5 * vjp_metric_func(q)(V) of a user metric.  q is the point of the held inverse: build() left it in w.uq (natural
   // order) with its aux block in w.uaq.  OUTER: V = -u u^T, else the explicit inverse in the tiles - handed to the user's
   // team-form hook as it is (user_metric.h MM_USER_VJP_FLAT), or dumped to the chain's dense global array for V(i, j).
@@ -837,6 +857,7 @@ __device__ __forceinline__ void implicit_mfma_body(const ImplicitArgs& A, double
   bk.w.prof = bk.w.stash + SL_COUNT_REFINE * 64;
   bk.refine_on = A.no_refine == 0;
   bk.dual_off = A.no_dual != 0;
+  bk.lr_refresh_ = A.lowrank_refresh;
   bk.base_lds = base_lds;
   bk.tparams = A.tparams;
   bk.uparams = A.rparams;

@@ -165,6 +165,7 @@ int mm_launch_implicit_blk16(mm_ctx* ctx, const mm_model* m, mm_state* s, double
   a.opts = opts;
   a.no_refine = mm_refine_disabled();
   a.no_dual = mm_dual_disabled();
+  a.lowrank_refresh = mm_lowrank_refresh();
   a.counters = d_counters;
   if (m->rmetric == MM_RMETRIC_RANK1) {
     // round 6: solve-only constructions by the Woodbury identity from the held inverse (implicit_core.h lowrank_solve);
@@ -251,6 +252,7 @@ extern "C" __attribute__((visibility("default"))) int mm_debug_blk16_step_profil
   a.step_size = h;
   a.n_steps = n_steps;
   a.opts = *opts;
+  a.lowrank_refresh = mm_lowrank_refresh();
   const size_t bytes = (size_t)s->n * PH_COUNT * sizeof(double);
   double* d_out = nullptr;
   MM_HIP_CHECK(ctx, hipMalloc(&d_out, bytes));

@@ -68,6 +68,7 @@ static int launch_step(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, in
   a.counters = d_counters;
   a.no_refine = mm_refine_disabled();
   a.no_dual = mm_dual_disabled();
+  a.lowrank_refresh = mm_lowrank_refresh();
   a.no_lowrank = mm_lowrank_disabled();
   if (midpoint) return MM_GLOB_DISPATCH(implicit_global_kernel, true);
   return MM_GLOB_DISPATCH(implicit_global_kernel, false);

@@ -107,6 +107,7 @@ int mm_launch_implicit_mfma(mm_ctx* ctx, const mm_model* m, mm_state* s, double 
   a.opts = opts;
   a.no_refine = mm_refine_disabled();
   a.no_dual = mm_dual_disabled();
+  a.lowrank_refresh = mm_lowrank_refresh();
   a.counters = d_counters;
   const bool r1 = m->rmetric == MM_RMETRIC_RANK1;
   // round 6: MICI_AMD_PAIR=1 selects the two-waves-per-chain kernel (implicit_pair.h: built, parity-green, and measured -
@@ -194,6 +195,7 @@ extern "C" __attribute__((visibility("default"))) int mm_debug_mfma_step_profile
   a.step_size = h;
   a.n_steps = n_steps;
   a.opts = *opts;
+  a.lowrank_refresh = mm_lowrank_refresh();
   const size_t bytes = (size_t)s->n * PH_COUNT * sizeof(double);
   double* d_out = nullptr;
   MM_HIP_CHECK(ctx, hipMalloc(&d_out, bytes));

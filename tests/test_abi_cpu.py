@@ -60,7 +60,7 @@ def test_struct_sizes_match_header():
     import ctypes as C
     assert C.sizeof(_ffi.FpOpts) == 40
     assert C.sizeof(_ffi.ProjOpts) == 56
-    assert C.sizeof(_ffi.Counters) == 104
+    assert C.sizeof(_ffi.Counters) == 112
     assert C.sizeof(_ffi.ModelDesc) == 96
 
 

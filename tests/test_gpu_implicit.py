@@ -527,7 +527,13 @@ def test_refined_solves_equal_factorised_solves():
                 else:
                     assert ca["n_refine"] > 0 and ca["n_lowrank"] == 0, (key, mode, ca)
                 assert ca["n_factor_solve"] < cb["n_factor_solve"]
-                assert ca["n_factor_full"] == cb["n_factor_full"]
+                if lowrank:
+                    # the explicit inverse travels from step to step by the rank-two update (lowrank_update): a sweep at the
+                    # launch's first step, after 64 updates in a row and where a chain's solve fell back to the factorisation
+                    assert ca["n_inverse_update"] > 0
+                    assert ca["n_factor_full"] + ca["n_inverse_update"] == cb["n_factor_full"], (key, ca, cb)
+                else:
+                    assert ca["n_factor_full"] == cb["n_factor_full"] and ca["n_inverse_update"] == 0
             ok = np.array(a["status"]) == 0
             assert_close(np.array(a["q"])[ok], np.array(b["q"])[ok], 1e-11, f"{key} {mode} positions")
             assert_close(np.array(a["p"])[ok], np.array(b["p"])[ok], 1e-11, f"{key} {mode} momenta")
