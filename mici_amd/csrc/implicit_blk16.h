@@ -76,8 +76,8 @@ constexpr int kOffStash = 0;                               // [SL_COUNT_REFINE][
 constexpr int kOffNat = kOffStash + SL_COUNT_REFINE * VLM; // [VLM] natural-order vector
 constexpr int kOffVperm = kOffNat + VLM;                   // [DPM] the same vector as [I][g][r]: row operands as one 32-byte read
 constexpr int kOffAux = kOffVperm + DPM;                   // [VLM] second natural-order vector (z of the substitution)
-constexpr int kOffRed = kOffAux + VLM;                     // [32]  team reductions / flags / work counters ([16 ..])
-constexpr int kOffScr = kOffRed + 32;                      // [NWAVE][64]: [0] scratch of the in-tile sweep, [1..4] T = -P^-1
+constexpr int kOffRed = kOffAux + VLM;                     // [24]  team reductions / flags
+constexpr int kOffScr = kOffRed + 24;                      // [NWAVE][64]: [0] scratch of the in-tile sweep, [1..4] T = -P^-1
                                                            // in lane order, [5][0] its positive-definite flag
 constexpr int kOffX = kOffScr + NWAVE * 64;                // [2][DPM][CS]  panel, double-buffered by block parity
 constexpr int kOffPart = kOffX + 2 * DPM * CS;             // [DPM][PSTR]
@@ -93,6 +93,7 @@ constexpr int kUserLdsDoubles = kOffUax + ((mmuser::kAux + 1) & ~1);
 template <int RMETRIC>
 __host__ __device__ constexpr int blk16_lds_doubles() { return RMETRIC == MM_RMETRIC_USER ? kUserLdsDoubles : kLdsDoubles; }
 static_assert(kUserLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU (user metric)");
+constexpr int kOffCnt = kOffScr + 6 * 64 + 24;             // [16] work counters (free part of Scr: a user metric's LDS is full to the last 64 bytes)
 constexpr int kOffProf = kOffScr + 6 * 64 + 8;             // developer builds: [PH_COUNT + 2] phase clocks (free part of Scr)
 static_assert(PH_COUNT + 2 <= 48, "phase clocks must fit the unused part of the Scr block");
 // Scratch of the refinement solves (implicit_core.h refine_solve) lives in the panel buffers: no sweep runs while one
@@ -102,6 +103,7 @@ constexpr int kOffRs = kOffXnat + VLM;                     // [RS_COUNT][VLM]
 static_assert(kOffRs + RS_COUNT * VLM <= kOffPart, "refinement scratch must fit the panel buffers");
 static_assert((kOffVperm % 2) == 0 && (kOffScr % 2) == 0 && (kOffX % 2) == 0, "16-byte alignment of the d4 accesses");
 static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS budget of a CU");
+static_assert((kLdsDoubles + DPM + 2 * 560) * 8 <= 160 * 1024, "LDS budget of a CU with the largest user aux block (MM_USER_AUX = 560)");
 
 __device__ __forceinline__ int fresh_lane() {
   // the lane index straight from the hardware (two VALU instructions): never worth a long-lived register
@@ -330,20 +332,20 @@ struct TeamBlk16 {
   }
 
   __device__ __forceinline__ void count(const int which, const int n) {
-    if (tid == 0) lds[kOffRed + 16 + which] += (double)n;  // exact in a double far beyond any launch's counts
+    if (tid == 0) lds[kOffCnt + which] += (double)n;  // exact in a double far beyond any launch's counts
   }
   __device__ __forceinline__ void read_counts(ChainResult& r) const {  // only thread 0's copy is used
-    r.n_evals = (long long)lds[kOffRed + 16 + CNT_EVALS];
-    r.n_solves = (long long)lds[kOffRed + 16 + CNT_SOLVES];
-    r.n_metric = (long long)lds[kOffRed + 16 + CNT_METRIC];
-    r.n_grad = (long long)lds[kOffRed + 16 + CNT_GRAD];
-    r.n_refine = (long long)lds[kOffRed + 16 + CNT_REFINE];
-    r.n_full = (long long)lds[kOffRed + 16 + CNT_FULL];
-    r.n_trail = (long long)lds[kOffRed + 16 + CNT_TRAIL];
-    r.n_lowrank = (long long)lds[kOffRed + 16 + CNT_LOWRANK];
-    r.n_inv_update = (long long)lds[kOffRed + 16 + CNT_INVUPD];
+    r.n_evals = (long long)lds[kOffCnt + CNT_EVALS];
+    r.n_solves = (long long)lds[kOffCnt + CNT_SOLVES];
+    r.n_metric = (long long)lds[kOffCnt + CNT_METRIC];
+    r.n_grad = (long long)lds[kOffCnt + CNT_GRAD];
+    r.n_refine = (long long)lds[kOffCnt + CNT_REFINE];
+    r.n_full = (long long)lds[kOffCnt + CNT_FULL];
+    r.n_trail = (long long)lds[kOffCnt + CNT_TRAIL];
+    r.n_lowrank = (long long)lds[kOffCnt + CNT_LOWRANK];
+    r.n_inv_update = (long long)lds[kOffCnt + CNT_INVUPD];
   }
-  static_assert(CNT_COUNT <= 16, "work counters occupy lds[kOffRed + 16 .. 31]");
+  static_assert(CNT_COUNT <= 16, "work counters occupy lds[kOffCnt .. + 15]");
   // developer builds: the clock since the last call goes to the phase announced then; [kOffProf + PH_COUNT] = that
   // phase, [+ PH_COUNT + 1] = the time of the call.  Thread 0 only.
   __device__ __forceinline__ int prof_switch(int phase) {
@@ -413,6 +415,55 @@ struct TeamBlk16 {
     *sb = uniform_f64(rb);
     *sc = uniform_f64(rc);
     *sd = uniform_f64(rd);
+  }
+  // a norm (kind as norm()) and a team sum through ONE pair of barriers (implicit_core.h momentum_solve_lowrank)
+  __device__ __forceinline__ void norm_dot(double x, int kind, double y, double* err, double* s) {
+    const int lane = fresh_lane(), wv = opaque_wave(wave);
+    const bool act = tid < dim;
+    const double a = act ? x : 0.0;
+    const bool linf = kind == MM_NORM_LINF;  // team-uniform
+    const double n = linf ? wave_max(fabs(a)) : wave_sum(a * a);
+    const double d = wave_sum(act ? y : 0.0);
+    double* red = lds + kOffRed;
+    if (lane == 0) {
+      red[wv] = n;
+      red[8 + wv] = d;
+    }
+    __syncthreads();
+    double rn = red[0], rd = red[8];
+#pragma unroll
+    for (int k = 1; k < NWAVE; ++k) {
+      rn = linf ? nanmax(rn, red[k]) : rn + red[k];
+      rd += red[8 + k];
+    }
+    __syncthreads();
+    *err = uniform_f64(linf ? rn : sqrt(rn));
+    *s = uniform_f64(rd);
+  }
+  __device__ __forceinline__ void sum3(double a, double b, double c, double* sa, double* sb, double* sc) {
+    const int lane = fresh_lane(), wv = opaque_wave(wave);
+    const bool act = tid < dim;
+    a = wave_sum(act ? a : 0.0);
+    b = wave_sum(act ? b : 0.0);
+    c = wave_sum(act ? c : 0.0);
+    double* red = lds + kOffScr + 7 * 64;  // [3][8]
+    if (lane == 0) {
+      red[wv] = a;
+      red[8 + wv] = b;
+      red[16 + wv] = c;
+    }
+    __syncthreads();
+    double ra = red[0], rb = red[8], rc = red[16];
+#pragma unroll
+    for (int k = 1; k < NWAVE; ++k) {
+      ra += red[k];
+      rb += red[8 + k];
+      rc += red[16 + k];
+    }
+    __syncthreads();
+    *sa = uniform_f64(ra);
+    *sb = uniform_f64(rb);
+    *sc = uniform_f64(rc);
   }
   __device__ __forceinline__ double& slot(int i) { return lds[kOffStash + i * VLM + (tid < DPM ? tid : DPM)]; }
 
@@ -1215,7 +1266,7 @@ __device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC, PROFILE, LOWRANK
   bk.refine_on = A.no_refine == 0;
   bk.lr_refresh_ = A.lowrank_refresh;
   for (int i = threadIdx.x; i < DPM * PSTR; i += NTHR) lds[kOffPart + i] = 0.0;  // unused partial-sum slots stay 0
-  if (threadIdx.x < 16) lds[kOffRed + 16 + threadIdx.x] = 0.0;                    // work counters
+  if (threadIdx.x < 16) lds[kOffCnt + threadIdx.x] = 0.0;                    // work counters
   if constexpr (PROFILE) {
     if (threadIdx.x < PH_COUNT + 2)
       lds[kOffProf + threadIdx.x] = threadIdx.x == PH_COUNT + 1 ? (double)__builtin_readcyclecounter() : 0.0;

@@ -490,7 +490,7 @@ __device__ __forceinline__ bool lowrank_finish(double D, double sbb, double sbc,
                                                double b, double c, double* u_out) {
   const double k11 = D + (e3 + e4), k12 = sbb + e4, k21 = e3, k22 = D + e4, r1 = sbc + r2;
   const double det = __builtin_fma(k11, k22, -(k12 * k21));
-  const double idet = 1.0 / det;
+  const double idet = mmdev::rcp_nr(det);  // (lean reciprocal: the IEEE division is ~30 dependent instructions on a lone wave)
   const double w1 = __builtin_fma(r1, k22, -(k12 * r2)) * idet, w2 = __builtin_fma(k11, r2, -(k21 * r1)) * idet;
   *u_out = c - __builtin_fma(ad, w1, b * w2);
   // (a NaN or an infinity anywhere in x, F d, b or c reaches one of the sums, hence det or w)
@@ -504,8 +504,8 @@ __device__ __forceinline__ bool lowrank_solve(BK& bk, double x, double sbb, doub
   const double ad = bk.matvec(d);
   prof(bk, PH_RSUM);
   const double b = bk.rslot(LR_B), c = bk.rslot(LR_C);
-  double e3, e4, r2, unused;
-  bk.sum4(d * ad, d * b, d * c, 0.0, &e3, &e4, &r2, &unused);
+  double e3, e4, r2;
+  bk.sum3(d * ad, d * b, d * c, &e3, &e4, &r2);
   const bool ok = lowrank_finish(bk.lowrank_scale(), sbb, sbc, e3, e4, r2, ad, b, c, u_out);
   bump(bk, r, CNT_LOWRANK, 1);
   prof(bk, ph0);
@@ -535,12 +535,57 @@ __device__ __forceinline__ bool lowrank_update(BK& bk, double x, double sbb, Cha
   const double det = __builtin_fma(k11, k22, -(k12 * k21));
   const bool ok = det > 1e-8 * D * D && det < 1e8 * D * D;  // (a NaN or an infinity in x reaches e3 / e4, hence det)
   if (ok) {
-    const double idet = 1.0 / det;
+    const double idet = mmdev::rcp_nr(det);
     bk.inverse_update(-(k22 - k12) * idet, -k22 * idet, k21 * idet, a, b);
     bump(bk, r, CNT_INVUPD, 1);
   }
   prof(bk, ph0);
   return ok;
+}
+
+// The momentum fixed points x = base - tt dh2_dpos(q, x) of this metric: dh2_dpos(q, x) = -(F x)(q^T F x) / D, and
+// q^T F x = b^T x with b = F q - known before the product F x is, so the inner product leaves the iteration's dependent chain
+// and shares ONE team reduction with the convergence norm of the iterate it belongs to (bk.norm_dot where a backend has it).
+template <class BK, class = void>
+struct normdot_trait { static constexpr bool value = false; };
+template <class BK>
+struct normdot_trait<BK, decltype((void)&BK::norm_dot)> { static constexpr bool value = true; };
+template <class BK>
+__device__ __forceinline__ int momentum_solve_lowrank(BK& bk, double base, double tt, double b, const mm_fp_opts& o,
+                                                      double* result, ChainResult& r) {
+  FpCtl c{0, 0};
+  double x0 = base, x1 = 0.0, pt = base;
+  int status = MM_ST_OK;
+  const int ph0 = prof(bk, PH_MOMENTUM);
+  const double inv_d = 1.0 / bk.lowrank_scale();
+  double s = bk.sum1(b * pt);
+  for (;;) {
+    const double u = bk.matvec(pt);
+    const double fx = base + tt * ((u * s) * inv_d);
+    bump(bk, r, CNT_EVALS, 1);
+    double x, out;
+    if (!fp_pre(c, x0, x1, fx, o, &x, &out)) {  // (a Steffensen half step: no test follows)
+      pt = out;
+      s = bk.sum1(b * pt);
+      continue;
+    }
+    double err;
+    if constexpr (normdot_trait<BK>::value) {
+      bk.norm_dot(x - x0, o.norm, b * x, &err, &s);
+    } else {
+      err = bk.norm(x - x0, o.norm);
+      s = bk.sum1(b * x);
+    }
+    const int act = fp_post(c, x0, x, err, o, &pt, &status);
+    if (act == FP_DONE) break;
+    if (act == FP_FAIL) {
+      prof(bk, ph0);
+      return status;
+    }
+  }
+  prof(bk, ph0);
+  *result = pt;
+  return MM_ST_OK;
 }
 
 // kDual backends: one evaluation of the reversibility-check solve and one of the C-adjoint solve together (see refine_solve2)
@@ -801,10 +846,25 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         // ---- B adj: p -= t dh2_dpos(q', p) then reversibility check     integrators.py:504-515
         const double qw = bk.slot(SL_QW);
         const double p_init = bk.slot(SL_PW);
+        // kLowRank: 0.5 vjp(M^-1) at q' (the final A below and the next step's first A) is F q' / D - the b of this solve's
+        // inner products: evaluated up front (a function of the inverse and q' alone)
+        if constexpr (kLowRank) {
+          if (lr_on) {
+            hv_next = bk.half_vjp_inv(qw);
+            hv_valid = true;
+          }
+        }
         double pw = p_init - t * bk.dh2_dpos(p_init, qw);
         double p_back;
         bump(bk, r, CNT_SOLVES, 1);
-        r.status = momentum_solve(bk, pw, -t, qw, o, &p_back, r);
+        bool lr_done = false;
+        if constexpr (kLowRank) {
+          if (lr_on) {
+            r.status = momentum_solve_lowrank(bk, pw, -t, hv_next * bk.lowrank_scale(), o, &p_back, r);
+            lr_done = true;
+          }
+        }
+        if (!lr_done) r.status = momentum_solve(bk, pw, -t, qw, o, &p_back, r);
         if (r.status != MM_ST_OK) break;
         if (bk.norm(p_back - bk.slot(SL_PW), o.rev_norm) > o.rev_tol) {
           r.status = MM_ST_NON_REVERSIBLE;
@@ -812,8 +872,10 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         }
         // ---- A: p -= t dh1_dpos(q')                                      integrators.py:544
         const double g = bk.slot(SL_GNEW);
-        hv_next = bk.half_vjp_inv(qw);
-        hv_valid = true;
+        if (!hv_valid) {
+          hv_next = bk.half_vjp_inv(qw);
+          hv_valid = true;
+        }
         pw = pw - t * (g + hv_next);
         bk.slot(SL_G) = g;
         bk.slot(SL_Q) = qw;
@@ -834,7 +896,16 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       double pw = bk.slot(SL_P) - t * (bk.slot(SL_G) + hvq);
       // ---- B fwd: solve p' = p - t dh2_dpos(q, p')                        integrators.py:496-502
       bump(bk, r, CNT_SOLVES, 1);
-      r.status = momentum_solve(bk, pw, t, q, o, &pw, r);
+      {
+        bool lr_done = false;
+        if constexpr (kLowRank) {
+          if (lr_on) {
+            r.status = momentum_solve_lowrank(bk, pw, t, bk.rslot(LR_B), o, &pw, r);
+            lr_done = true;
+          }
+        }
+        if (!lr_done) r.status = momentum_solve(bk, pw, t, q, o, &pw, r);
+      }
       if (r.status != MM_ST_OK) break;
       // ---- C fwd: q += t M(q)^-1 p                                        integrators.py:517-519
       bk.slot(SL_QINIT) = q;

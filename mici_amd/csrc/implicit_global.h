@@ -155,6 +155,10 @@ struct GlobalBackend {
     sum2(a, b, sa, sb);
     sum2(c, d, sc, sd);
   }
+  __device__ __forceinline__ void sum3(double a, double b, double c, double* sa, double* sb, double* sc) {
+    sum2(a, b, sa, sb);
+    *sc = sum1(c);
+  }
   __device__ __forceinline__ void norm2(double a, double b, int kind, double* na, double* nb) {
     const double xa = tid < dim ? a : 0.0, xb = tid < dim ? b : 0.0;
     if (kind == MM_NORM_LINF) {

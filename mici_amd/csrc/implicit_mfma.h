@@ -130,7 +130,16 @@ struct MfmaBackend {
 
   // (the step's slots in registers instead of LDS - there is room since round 4 - were measured and lose: 1.17e7 against
   // 1.24e7 steps/s on c3)
-  __device__ __forceinline__ double& slot(int i) { return w.stash[i * 64 + lane]; }
+#ifndef MM_MFMA_LR_SLOT_REGS
+#define MM_MFMA_LR_SLOT_REGS 0
+#endif
+  // (round 6, the Woodbury kernel: without the CG vectors and the M(x) v operands there is room again - A/B macro)
+  static constexpr bool kSlotRegs = kLowRank && MM_MFMA_LR_SLOT_REGS;
+  double st_[kSlotRegs ? SL_COUNT_REFINE : 1];
+  __device__ __forceinline__ double& slot(int i) {
+    if constexpr (kSlotRegs) return st_[i];
+    else return w.stash[i * 64 + lane];
+  }
   __device__ __forceinline__ bool flat_active() const { return lane < dim; }
 
   // ---- metric_func(x) into the tiles; false if an entry is not finite ----------------------------
@@ -231,6 +240,16 @@ struct MfmaBackend {
                                        double* sd) {
     sum2(a, b, sa, sb);
     sum2(c, d, sc, sd);
+  }
+  // (two independent DPP chains: the scheduler interleaves them)
+  __device__ __forceinline__ void norm_dot(double x, int kind, double y, double* err, double* s) {
+    const double a = wave_norm_accum(0.0, lane < dim ? x : 0.0, kind);
+    *s = wave_sum(lane < dim ? y : 0.0);
+    *err = wave_norm_finish(a, kind);
+  }
+  __device__ __forceinline__ void sum3(double a, double b, double c, double* sa, double* sb, double* sc) {
+    sum2(a, b, sa, sb);
+    *sc = wave_sum(lane < dim ? c : 0.0);
   }
   __device__ __forceinline__ void norm2(double a, double b, int kind, double* na, double* nb) {
     const double xa = wave_norm_accum(0.0, lane < dim ? a : 0.0, kind), xb = wave_norm_accum(0.0, lane < dim ? b : 0.0, kind);

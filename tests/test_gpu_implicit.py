@@ -543,6 +543,62 @@ def test_refined_solves_equal_factorised_solves():
     assert any(s != 0 for s in big["status"])  # the scenario has failing chains ...
 
 
+_LOWRANK_SCRIPT = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from mici_amd import integrators, models, systems
+from oracle import models as omdl
+out = {{}}
+for dim, h, steps, n in ((64, 0.02, 300, 32), (200, 0.01, 150, 8), (320, 0.008, 40, 4)):
+    rng = np.random.default_rng(dim)
+    system = systems.DenseRiemannianMetricSystem(models.Banana(dim), models.Rank1Metric(omdl.make_spd(dim, rng)))
+    integ = integrators.ImplicitLeapfrogIntegrator(system, h)
+    q0 = rng.standard_normal((n, dim))
+    p0 = system.sample_momentum_batch(q0, rng.standard_normal((n, dim)))
+    q, p, st, nd = integ.step_batch(q0, p0, 1, n_steps=steps)
+    out[str(dim)] = dict(q=q.tolist(), p=p.tolist(), status=st.tolist(), n_done=nd.tolist(), steps=steps, n=n,
+                         counters={{k: int(v) for k, v in integ.last_counters.items()}})
+print(json.dumps(out))
+"""
+
+
+def test_inverse_updates_do_not_drift_and_are_refreshed_on_schedule():
+    """the rank-one-update metric's explicit inverse is carried from step to step by a symmetric rank-two
+    update (implicit_core.h lowrank_update) and factorised afresh at a launch's first step and after
+    MICI_AMD_LOWRANK_REFRESH updates in a row.  Long launches on the c3 kernel (D = 64, 300 steps), the c4 kernel (D = 200, 150
+    steps) and the global-memory tier (D = 320, 40 steps) with the default schedule (64), with a sweep every 7th step and with a
+    sweep every step (0: the round-5 behaviour): same statuses, same fixed-point evaluation counts, states equal far inside
+    the parity tolerance, and exactly the scheduled number of sweeps."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for refresh in ("64", "7", "0"):
+        r = subprocess.run([sys.executable, "-c", _LOWRANK_SCRIPT.format(root=root)], capture_output=True, text=True,
+                           env=dict(os.environ, MICI_AMD_LOWRANK_REFRESH=refresh), cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[refresh] = json.loads(r.stdout.strip().splitlines()[-1])
+    for key, b in res["0"].items():
+        cb = b["counters"]
+        assert all(s == 0 for s in b["status"]), (key, b["status"])  # (step sizes at which every chain completes)
+        assert cb["n_inverse_update"] == 0 and cb["n_factor_full"] == b["n"] * (b["steps"] + 1) and cb["n_lowrank"] > 0
+        for refresh in ("64", "7"):
+            a = res[refresh][key]
+            ca = a["counters"]
+            assert a["status"] == b["status"] and a["n_done"] == b["n_done"], (key, refresh)
+            for k in ("n_fp_evals", "n_fp_solves", "n_metric", "n_grad", "n_lowrank"):
+                assert ca[k] == cb[k], (key, refresh, k, ca[k], cb[k])
+            # sweeps: the cold one + one after every `refresh` updates in a row (no fallbacks in these runs)
+            per_chain = 1 + a["steps"] // (int(refresh) + 1)
+            assert ca["n_factor_full"] == a["n"] * per_chain, (key, refresh, ca)
+            assert ca["n_factor_full"] + ca["n_inverse_update"] == cb["n_factor_full"], (key, refresh, ca, cb)
+            assert_close(np.array(a["q"]), np.array(b["q"]), 1e-10, f"D = {key} refresh {refresh} positions")
+            assert_close(np.array(a["p"]), np.array(b["p"]), 1e-10, f"D = {key} refresh {refresh} momenta")
+
+
 _SOFTABS_REFINE_SCRIPT = r"""
 import json, sys
 import numpy as np
