@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - leapfrog-steps/sec (all chains) of the MI355X integrator hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2i_stream|c2iv|c2bcss|c3|c3b|c4|c5|c3_user|c4_general|c3b_dense|c4_d512|c3b_d128|c3b_d256]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2i|c2i_stream|c2iv|c2bcss|c3|c3b|c4|c5|c3_user|c4_general|c4_user_lowrank|c3b_dense|c4_d512|c3b_d128|c3b_d256]
                     [--traj-len L] [--chains-per-gpu M] [--no-extra-configs] [--no-cpu-baseline]
 
 Contract (driver): W untimed warm-up passes, then EXACTLY K timed passes bracketed by a barrier +
@@ -157,7 +157,7 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
                     traj=traj, integ=integ, system=system, make_oracle=make_oracle, q0=q0, p0=p0,
                     bytes_per_chain_step=32.0 * dim, flops_per_chain_step=flops, valu_executed_flops_per_chain_step=exec_flops,
                     bound="hbm" if config in ("c2i", "c2i_stream") else "mfma", kind="euclid")
-    if config in ("c3", "c4", "c3_user", "c4_general", "c4_d512"):
+    if config in ("c3", "c4", "c3_user", "c4_general", "c4_user_lowrank", "c4_d512"):
         # c3_user / c4_general (VERDICT r03 #1c): the GENERAL dense-Riemannian path - the metric reaches the library as user
         # source (mici_amd/user_examples.py), compiled around the matrix-core kernels at run time.  c3_user: a metric that
         # is not built in (softplus diagonal + rank one, D = 64); c4_general: the c4 workload itself with its rank-one
@@ -178,6 +178,12 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
                 from mici_amd import user_examples
                 rmetric = models.UserMetric(dim, user_examples.RANK1_AS_USER_FLAT, base)
                 mname = "rank-one-update dense metric as USER SOURCE (hipRTC, MM_USER_VJP_FLAT)"
+            elif config == "c4_user_lowrank":
+                # round 6: the same user source DECLARING its structure (user_metric.h MM_USER_LOWRANK: M = C + s u(q) u(q)^T) - the
+                # Woodbury path of DESIGN section 4.3f around a user metric; c4_general stays the undeclared, generic path
+                from mici_amd import user_examples
+                rmetric = models.UserMetric(dim, user_examples.RANK1_AS_USER_LOWRANK, base)
+                mname = "rank-one-update dense metric as USER SOURCE that declares its structure (hipRTC, MM_USER_VJP_FLAT + MM_USER_LOWRANK)"
             else:
                 rmetric = models.Rank1Metric(base)
                 mname = "rank-one-update dense metric"
@@ -278,13 +284,13 @@ def _sweep_mfma_counts(dim):
     return None
 
 
-DEFAULT_CHAINS = {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048, "c3_user": 1024, "c4_general": 1024, "c3b_dense": 1024,
+DEFAULT_CHAINS = {"c3": 1024, "c3b": 1024, "c4": 1024, "c5": 2048, "c3_user": 1024, "c4_general": 1024, "c4_user_lowrank": 1024, "c3b_dense": 1024,
                   "c4_d512": 256, "c2i_stream": 1 << 20, "c3b_d128": 256, "c3b_d256": 256}  # per GPU; else 4096
 CPU_CHAINS = {"c2i_stream": 1 << 16}  # chains of the cpu_baseline sample where the device shard would not fit a host's pool
-EXTRA_CONFIGS = ("c2i", "c2i_stream", "c2iv", "c3", "c3b", "c4", "c5", "c3_user", "c4_general", "c3b_dense", "c4_d512",
+EXTRA_CONFIGS = ("c2i", "c2i_stream", "c2iv", "c3", "c3b", "c4", "c5", "c3_user", "c4_general", "c4_user_lowrank", "c3b_dense", "c4_d512",
                  "c3b_d128", "c3b_d256")
 # pass counts of the extra configs are capped (a c3(b) pass is ~1 s, a c4 pass ~0.1-0.3 s)
-EXTRA_STEP_CAP = {"c3b": 5, "c4": 10, "c4_general": 10, "c3b_dense": 5, "c4_d512": 3, "c3b_d128": 3, "c3b_d256": 2}
+EXTRA_STEP_CAP = {"c3b": 5, "c4": 10, "c4_general": 10, "c4_user_lowrank": 10, "c3b_dense": 5, "c4_d512": 3, "c3b_d128": 3, "c3b_d256": 2}
 BASELINE_CONFIG = {"c2": "BASELINE.json configs[1]", "c2i": "BASELINE.json configs[1] (iso-Gaussian variant, SURVEY 8d c2(i))",
                    "c2i_stream": "BASELINE.json configs[1] sizes (iso-Gaussian, D = 128) with n_steps = 1 and 2^20 chains: the "
                                  "HBM-bound regime of the (q, p) state loads north_star names",
@@ -293,6 +299,7 @@ BASELINE_CONFIG = {"c2": "BASELINE.json configs[1]", "c2i": "BASELINE.json confi
                    "c4": "BASELINE.json configs[3] (per-GPU shard)", "c5": "BASELINE.json configs[4] (per-GPU shard)",
                    "c3_user": "BASELINE.json configs[2] sizes, a metric_func that is not built in (user source)",
                    "c4_general": "BASELINE.json configs[3] (per-GPU shard), its metric_func handed over as user source",
+                   "c4_user_lowrank": "BASELINE.json configs[3] (per-GPU shard), its metric_func handed over as user source that declares its constant + rank-one structure",
                    "c3b_dense": "BASELINE.json configs[2] (SoftAbs path) on the banana target: a dense (user-source) Hessian",
                    "c4_d512": "BASELINE.json configs[3] at twice the dimension (D = 512: the global-memory tier)",
                    "c3b_d128": "BASELINE.json configs[2] (SoftAbs path) at D = 128, 256 chains: the workspace tier NP = 128",

@@ -53,6 +53,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // array from registers to scratch memory (code sinking works from the end of the blocks upwards).
 #define MM_CASE_MARK(N) asm volatile("; tile slot case " #N)
 
+#ifndef MM_BLK16_UPD_BARRIER
+#define MM_BLK16_UPD_BARRIER 0  // (inverse_update: a scheduling barrier every two tiles - compile record: 760 B of scratch against 500)
+#endif
 #ifndef MM_BLK16_PERMLANE
 #define MM_BLK16_PERMLANE 1  // semantics verified on the MI355X by tests/test_gpu_blk16.py::test_permlane_swap_semantics
 #endif
@@ -245,8 +248,38 @@ template <int RMETRIC, bool PROFILE = false, bool LOWRANK = false>
 struct TeamBlk16 {
   // implicit_core.h lowrank_solve (round 6): the rank-one-update metric's solve-only constructions by the Woodbury identity
   // from the held inverse - one product F d (matvec) each instead of ~2.5 CG pairs of M(x) v + F r
-  static constexpr bool kLowRank = LOWRANK && RMETRIC == MM_RMETRIC_RANK1;
-  __device__ __forceinline__ double lowrank_scale() const { return (double)dim; }
+  // (the built-in rank-one-update metric, or a user metric that declares the structure: user_metric.h MM_USER_LOWRANK)
+  static constexpr bool kLowRankBuiltin = RMETRIC == MM_RMETRIC_RANK1;
+  static constexpr bool kLowRank = LOWRANK && (kLowRankBuiltin || (RMETRIC == MM_RMETRIC_USER && mmuser::kLowRank));
+  __device__ __forceinline__ double lowrank_scale() const {
+    if constexpr (kLowRankBuiltin) return (double)dim;
+    else return uniform_f64(mmuser::lowrank_inv_s(dim, base));
+  }
+  // u(x), this thread's element (user metric: the point published for the hook, its aux block prepared - a team collective)
+  __device__ __forceinline__ double lowrank_vec(double x) {
+    if constexpr (kLowRankBuiltin) {
+      return x;
+    } else {
+      metric_point(x);
+      const double u = mmuser::lowrank_u(lds + kOffXnat, tid, dim, base, lds + kOffUax);
+      __syncthreads();  // (the next point overwrites kOffXnat / kOffUax)
+      return tid < dim ? u : 0.0;
+    }
+  }
+  __device__ __forceinline__ double& lowrank_u0() {
+    if constexpr (kLowRankBuiltin) return slot(SL_Q);
+    else return rslot(LR_U0);
+  }
+  // a user metric's hooks evaluate its vector-Jacobian products at "the point of the held inverse" (kOffUq, kOffUaq - build()
+  // sets them): an inverse carried to x by lowrank_update takes the point with it
+  __device__ __forceinline__ void held_point(double x) {
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {
+      if (tid < DPM) lds[kOffUq + tid] = tid < dim ? x : 0.0;
+      __syncthreads();
+      mmuser::prepare(Team16{lds + kOffRed, (int)tid}, lds + kOffUq, dim, base, lds + kOffUaq);
+      __syncthreads();
+    }
+  }
   __device__ static constexpr bool lowrank_on() { return true; }  // (compile-time: the launcher picks the instantiation)
   int lr_refresh_;
   __device__ __forceinline__ int lowrank_refresh() const { return lr_refresh_; }
@@ -1057,6 +1090,10 @@ struct TeamBlk16 {
       const double uj = lds[kOffNat + 16 * J + j], vj = lds[kOffAux + 16 * J + j];
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[s][r] = __builtin_fma(-ar[r], uj, __builtin_fma(-br[r], vj, acc[s][r]));
+      // (left alone the scheduler hoists the seventeen tiles' operand loads to the top, and some fifty values are spilled and
+      // reloaded around this loop every step - 12.7 GB of scratch traffic a c4 launch, at L2 speed; a scheduling barrier every
+      // two tiles makes the allocation worse, not better: A/B macro)
+      if (MM_BLK16_UPD_BARRIER && (s & 1)) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }

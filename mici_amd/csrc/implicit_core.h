@@ -483,7 +483,12 @@ template <class BK, class = void>
 struct lowrank_trait { static constexpr bool value = false; };
 template <class BK>
 struct lowrank_trait<BK, decltype((void)BK::kLowRank)> { static constexpr bool value = BK::kLowRank; };
-enum { LR_B = 0, LR_C = 1 };  // rslot() indices (the CG state's: no refinement runs on a kLowRank backend)
+// The same holds for ANY metric C + s u(x) u(x)^T with a constant C (a user metric that declares it: user_metric.h
+// MM_USER_LOWRANK): d = u(x) - u(x0), D -> 1 / s.  A backend says which through kLowRankBuiltin - true: u(x) = x, and b = F x0
+// comes for free from the A sub-step (0.5 vjp(M^-1) = F q / D); false: bk.lowrank_vec(x) evaluates u at a point (a team
+// collective: it publishes the point for the user's hook), u(x0) is kept in bk.lowrank_u0(), b costs one product a step, and
+// after an update of the inverse bk.held_point(x) moves the point the user's vector-Jacobian products are evaluated at.
+enum { LR_B = 0, LR_C = 1, LR_U0 = 2 };  // rslot() indices (the CG state's: no refinement runs while the Woodbury path is on)
 
 // the 2 x 2 system and the correction, from the three inner products of an evaluation (team-uniform arithmetic)
 __device__ __forceinline__ bool lowrank_finish(double D, double sbb, double sbc, double e3, double e4, double r2, double ad,
@@ -497,10 +502,15 @@ __device__ __forceinline__ bool lowrank_finish(double D, double sbb, double sbc,
   return det > 1e-8 * D * D && det < 1e8 * D * D && fabs(w1) < 1e300 && fabs(w2) < 1e300;
 }
 
+template <class BK, bool ON>
+struct lowrank_builtin { static constexpr bool value = false; };
+template <class BK>
+struct lowrank_builtin<BK, true> { static constexpr bool value = BK::kLowRankBuiltin; };
+
 template <class BK>
 __device__ __forceinline__ bool lowrank_solve(BK& bk, double x, double sbb, double sbc, double* u_out, ChainResult& r) {
   const int ph0 = prof(bk, PH_FAPPLY);
-  const double d = x - bk.slot(SL_Q);
+  const double d = bk.lowrank_vec(x) - bk.lowrank_u0();
   const double ad = bk.matvec(d);
   prof(bk, PH_RSUM);
   const double b = bk.rslot(LR_B), c = bk.rslot(LR_C);
@@ -525,7 +535,7 @@ __device__ __forceinline__ bool lowrank_solve(BK& bk, double x, double sbb, doub
 template <class BK>
 __device__ __forceinline__ bool lowrank_update(BK& bk, double x, double sbb, ChainResult& r) {
   const int ph0 = prof(bk, PH_FULL);
-  const double d = x - bk.slot(SL_Q);
+  const double d = bk.lowrank_vec(x) - bk.lowrank_u0();
   const double a = bk.matvec(d);
   const double b = bk.rslot(LR_B);
   double e3, e4;
@@ -537,6 +547,8 @@ __device__ __forceinline__ bool lowrank_update(BK& bk, double x, double sbb, Cha
   if (ok) {
     const double idet = mmdev::rcp_nr(det);
     bk.inverse_update(-(k22 - k12) * idet, -k22 * idet, k21 * idet, a, b);
+    // (a user metric's vector-Jacobian products are evaluated at "the point of the held inverse", which the backend keeps)
+    if constexpr (!BK::kLowRankBuiltin) bk.held_point(x);
     bump(bk, r, CNT_INVUPD, 1);
   }
   prof(bk, ph0);
@@ -595,8 +607,8 @@ template <class BK>
 __device__ __forceinline__ void lowrank_solve2(BK& bk, double xC, double xA, double sbb, double sbc, double* uC, double* uA,
                                                bool* okC, bool* okA, ChainResult& r) {
   const int ph0 = prof(bk, PH_FAPPLY);
-  const double x0 = bk.slot(SL_Q);
-  const double dC = xC - x0, dA = xA - x0;
+  const double u0 = bk.lowrank_u0();
+  const double dC = bk.lowrank_vec(xC) - u0, dA = bk.lowrank_vec(xA) - u0;
   double adC, adA;
   bk.matvec2_exact(dC, dA, &adC, &adA);
   prof(bk, PH_RSUM);
@@ -645,6 +657,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
   constexpr bool kFork = kRefine && fork_trait<BK>::value;
   static_assert(!(kDual && kFork), "lock step and fork are alternatives");
   static_assert(!(kLowRank && kFork), "a forked backend runs the refinement");
+  constexpr bool kLowRankMom = kLowRank && lowrank_builtin<BK, kLowRank>::value;  // momentum_solve_lowrank (built-in metric)
   bool lr_on = false;  // (a compile-time constant where the backend's lowrank_on() is: the refinement's code is then dead)
   if constexpr (kLowRank) lr_on = bk.lowrank_on();
   int lr_since = 0;         // kLowRank: steps since the held inverse was last factorised (lowrank_update in between)
@@ -848,7 +861,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         const double p_init = bk.slot(SL_PW);
         // kLowRank: 0.5 vjp(M^-1) at q' (the final A below and the next step's first A) is F q' / D - the b of this solve's
         // inner products: evaluated up front (a function of the inverse and q' alone)
-        if constexpr (kLowRank) {
+        if constexpr (kLowRankMom) {
           if (lr_on) {
             hv_next = bk.half_vjp_inv(qw);
             hv_valid = true;
@@ -858,7 +871,7 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         double p_back;
         bump(bk, r, CNT_SOLVES, 1);
         bool lr_done = false;
-        if constexpr (kLowRank) {
+        if constexpr (kLowRankMom) {
           if (lr_on) {
             r.status = momentum_solve_lowrank(bk, pw, -t, hv_next * bk.lowrank_scale(), o, &p_back, r);
             lr_done = true;
@@ -891,14 +904,22 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
       hv_valid = false;
       // kLowRank: 0.5 vjp(M^-1) of the rank-one-update metric IS F q / D - the b of lowrank_solve, for this step's solves
       if constexpr (kLowRank) {
-        if (lr_on) bk.rslot(LR_B) = hvq * bk.lowrank_scale();
+        if (lr_on) {
+          if constexpr (BK::kLowRankBuiltin) {
+            bk.rslot(LR_B) = hvq * bk.lowrank_scale();
+          } else {  // a declared user metric: u(q), and b = F u(q) by a product of its own
+            const double u0 = bk.lowrank_vec(q);
+            bk.lowrank_u0() = u0;
+            bk.rslot(LR_B) = bk.matvec(u0);
+          }
+        }
       }
       double pw = bk.slot(SL_P) - t * (bk.slot(SL_G) + hvq);
       // ---- B fwd: solve p' = p - t dh2_dpos(q, p')                        integrators.py:496-502
       bump(bk, r, CNT_SOLVES, 1);
       {
         bool lr_done = false;
-        if constexpr (kLowRank) {
+        if constexpr (kLowRankMom) {
           if (lr_on) {
             r.status = momentum_solve_lowrank(bk, pw, t, bk.rslot(LR_B), o, &pw, r);
             lr_done = true;
@@ -914,7 +935,8 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         if (lr_on) {  // c = F p and the two inner products that stay fixed while the position solves run
           if constexpr (kLowRank) {
             bk.rslot(LR_C) = u0;
-            bk.sum2(q * bk.rslot(LR_B), q * u0, &lr_sbb, &lr_sbc);
+            const double ux0 = bk.lowrank_u0();
+            bk.sum2(ux0 * bk.rslot(LR_B), ux0 * u0, &lr_sbb, &lr_sbc);
           }
         } else {  // M(q)^-1 p: the first guess of both position solves
           bk.slot(SL_UC) = u0;

@@ -87,10 +87,41 @@ struct GlobalBackend {
   // implicit_core.h lowrank_solve (round 6): the rank-one-update metric's solve-only constructions by the Woodbury identity
   // from the held inverse - ONE pass over the FP64 inverse (F d) each instead of ~2.5 CG pairs; decided at run time here
   // (MICI_AMD_LOWRANK=0: the lock-step CG refinement)
-  static constexpr bool kLowRank = RMETRIC == MM_RMETRIC_RANK1;
+  // (the built-in rank-one-update metric, or a user metric that declares the structure: user_metric.h MM_USER_LOWRANK)
+  static constexpr bool kLowRankBuiltin = RMETRIC == MM_RMETRIC_RANK1;
+  static constexpr bool kLowRank = kLowRankBuiltin || (RMETRIC == MM_RMETRIC_USER && mmuser::kLowRank);
   bool lowrank_on_;
   __device__ __forceinline__ bool lowrank_on() const { return lowrank_on_; }
-  __device__ __forceinline__ double lowrank_scale() const { return (double)dim; }
+  __device__ __forceinline__ double lowrank_scale() const {
+    if constexpr (kLowRankBuiltin) return (double)dim;
+    else return mmuser::lowrank_inv_s(dim, base);
+  }
+  // u(x), this thread's element (user metric: the point published for the hook, its aux block prepared - a team collective)
+  __device__ __forceinline__ double lowrank_vec(double x) {
+    if constexpr (kLowRankBuiltin) {
+      return x;
+    } else {
+      metric_point(x);
+      const double u = mmuser::lowrank_u(lds + kOffUx, tid, dim, base, lds + kOffUax);
+      __syncthreads();  // (the next point overwrites kOffUx / kOffUax)
+      return tid < dim ? u : 0.0;
+    }
+  }
+  __device__ __forceinline__ double& lowrank_u0() {
+    if constexpr (kLowRankBuiltin) return st_[SL_Q];
+    else return rs_[LR_U0];
+  }
+  // a user metric's hooks evaluate its vector-Jacobian products at "the point of the held inverse" (kOffUq, kOffUaq - build()
+  // sets them): an inverse carried to x by lowrank_update takes the point with it
+  __device__ __forceinline__ void held_point(double x) {
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {
+      __syncthreads();
+      lds[kOffUq + tid] = tid < dim ? x : 0.0;
+      __syncthreads();
+      mmuser::prepare(TeamOfGlobal<GlobalBackend>{*this}, lds + kOffUq, dim, base, lds + kOffUaq);
+      __syncthreads();
+    }
+  }
   int lr_refresh_;
   __device__ __forceinline__ int lowrank_refresh() const { return lr_refresh_; }
   int dim, dp, tid, target, flip;

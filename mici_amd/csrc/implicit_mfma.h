@@ -95,8 +95,41 @@ struct MfmaBackend {
   static constexpr bool kProf = PROFILE;  // developer builds: cycles per phase of the step
   // implicit_core.h lowrank_solve (round 6): the rank-one-update metric's solve-only constructions by the Woodbury identity
   // from the held inverse - one row product F d each instead of ~3 CG pairs
-  static constexpr bool kLowRank = LOWRANK && RMETRIC == MM_RMETRIC_RANK1;
-  __device__ __forceinline__ double lowrank_scale() const { return (double)dim; }
+  // (the built-in rank-one-update metric, or a user metric that declares the structure: user_metric.h MM_USER_LOWRANK)
+  static constexpr bool kLowRankBuiltin = RMETRIC == MM_RMETRIC_RANK1;
+  static constexpr bool kLowRank = LOWRANK && (kLowRankBuiltin || (RMETRIC == MM_RMETRIC_USER && mmuser::kLowRank));
+  __device__ __forceinline__ double lowrank_scale() const {
+    if constexpr (kLowRankBuiltin) return (double)dim;
+    else return mmuser::lowrank_inv_s(dim, uparams);
+  }
+  // u(x), this lane's element (user metric: the point published for the hook, its aux block prepared - a wave collective)
+  __device__ __forceinline__ double lowrank_vec(double x) {
+    if constexpr (kLowRankBuiltin) {
+      return x;
+    } else {
+      w.ux[lane] = (lane < dim) ? x : 0.0;
+      wave_sync();
+      mmuser::prepare(mmuser::WaveTeam{lane}, w.ux, dim, uparams, w.uax);
+      wave_sync();
+      const double u = mmuser::lowrank_u(w.ux, lane, dim, uparams, w.uax);
+      wave_sync();  // (the next point overwrites w.ux / w.uax)
+      return lane < dim ? u : 0.0;
+    }
+  }
+  __device__ __forceinline__ double& lowrank_u0() {
+    if constexpr (kLowRankBuiltin) return slot(SL_Q);
+    else return rslot(LR_U0);
+  }
+  // a user metric's hooks evaluate its vector-Jacobian products at "the point of the held inverse" (w.uq, w.uaq - build() sets
+  // them): an inverse carried to x by lowrank_update takes the point with it
+  __device__ __forceinline__ void held_point(double x) {
+    if constexpr (RMETRIC == MM_RMETRIC_USER) {
+      w.uq[lane] = (lane < dim) ? x : 0.0;
+      wave_sync();
+      mmuser::prepare(mmuser::WaveTeam{lane}, w.uq, dim, uparams, w.uaq);
+      wave_sync();
+    }
+  }
   __device__ static constexpr bool lowrank_on() { return true; }  // (compile-time: the launcher picks the instantiation)
   int lr_refresh_;
   __device__ __forceinline__ int lowrank_refresh() const { return lr_refresh_; }

@@ -202,6 +202,8 @@ static int launch_user_metric(mm_ctx* ctx, const mm_model* m, mm_state* s, int w
   a.z = d_z;
   a.no_refine = mm_refine_disabled();
   a.no_dual = mm_dual_disabled();
+  a.no_lowrank = mm_lowrank_disabled();  // (a user metric that declares MM_USER_LOWRANK: user_metric.h)
+  a.lowrank_refresh = mm_lowrank_refresh();
   return mm_rtc_launch_riemann(ctx, m, s, which, &a);
 }
 

@@ -75,6 +75,7 @@ struct mm_model {
   std::string user_src;        // the user's text (kept for the families compiled later)
   int user_aux = 0;            // MM_USER_AUX of the user's text (0: none)
   bool user_flat_vjp = false;  // MM_USER_VJP_FLAT
+  bool user_lowrank = false;   // MM_USER_LOWRANK (the metric is C + s u(q) u(q)^T: Woodbury path)
   double h_target_params[4] = {0, 0, 0, 0};  // first few params host-side (scalars)
   double h_rmetric_params[4] = {0, 0, 0, 0};
   double h_constr_params[4] = {0, 0, 0, 0};

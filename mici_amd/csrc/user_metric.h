@@ -35,6 +35,15 @@
 //                                                            products run on the backend's own mat-vec.
 //                                                            Without it the backends dump the inverse to a dense array
 //                                                            (LDS on the wave kernels, global memory beyond) for V(i, j).
+//   #define MM_USER_LOWRANK                                  (round 6) the metric is a CONSTANT matrix plus a rank-one term in a
+//     double mm_user_lowrank_u(q, i, dim, params [, aux])    vector function of the position: M(q) = C + s u(q) u(q)^T with
+//     double mm_user_lowrank_inv_s(dim, params)              s > 0 constant - element i of u(q), and 1 / s.  mm_user_metric and
+//                                                            the vector-Jacobian product stay as they are (they define the
+//                                                            metric; this only DECLARES its structure).  The kernels with a
+//                                                            Woodbury path (32 < D <= 1024: DESIGN section 4.3f) then take the
+//                                                            position solves' M(x)^-1 p from the explicit inverse at the step's
+//                                                            start - one product each instead of a CG refinement - and carry
+//                                                            that inverse from step to step by a rank-two update.
 // Write mm_user_metric WITHOUT control flow - selects on values that are loaded unconditionally (`d = aux[1 + i]; return
 // i == j ? v + d : v;`), not conditional loads (`i == j ? v + aux[1 + i] : v` is a branch): the hook is inlined into loops
 // over the register-resident metric tiles, and a branch per entry there made the register allocator keep tiles in scratch
@@ -74,6 +83,15 @@ __device__ double mm_user_vjp(const double* q, const MmMat& V, int k, int dim, c
 __device__ double mm_user_vjp(const double* q, const MmMat& V, int k, int dim, const double* params);
 #endif
 
+#ifdef MM_USER_LOWRANK
+#ifdef MM_USER_AUX
+__device__ double mm_user_lowrank_u(const double* q, int i, int dim, const double* params, const double* aux);
+#else
+__device__ double mm_user_lowrank_u(const double* q, int i, int dim, const double* params);
+#endif
+__device__ double mm_user_lowrank_inv_s(int dim, const double* params);
+#endif
+
 #endif  // MM_RTC_BUILD && MM_RTC_USER_METRIC
 
 namespace mmuser {
@@ -88,6 +106,22 @@ constexpr int kAux = 0;
 constexpr bool kFlatVjp = true;
 #else
 constexpr bool kFlatVjp = false;
+#endif
+#ifdef MM_USER_LOWRANK
+constexpr bool kLowRank = true;
+__device__ __forceinline__ double lowrank_u(const double* q, int i, int dim, const double* params, const double* aux) {
+  const int ic = i < dim ? i : dim - 1;  // (idle threads evaluate a valid element; callers mask the result)
+#ifdef MM_USER_AUX
+  return ::mm_user_lowrank_u(q, ic, dim, params, aux);
+#else
+  return ::mm_user_lowrank_u(q, ic, dim, params);
+#endif
+}
+__device__ __forceinline__ double lowrank_inv_s(int dim, const double* params) { return ::mm_user_lowrank_inv_s(dim, params); }
+#else
+constexpr bool kLowRank = false;
+__device__ __forceinline__ double lowrank_u(const double*, int, int, const double*, const double*) { return 0.0; }
+__device__ __forceinline__ double lowrank_inv_s(int, const double*) { return 1.0; }
 #endif
 // doubles of LDS a backend sets aside per chain for a user metric: the point q of the held inverse and the point x of the
 // refinement products in natural order (zero padded to `np`), and the two aux blocks that belong to them
@@ -140,6 +174,9 @@ __device__ __forceinline__ double vjp_flat(Ops& V, const double* q, int k, int d
 #else  // the in-tree instantiations never reach a user hook
 constexpr int kAux = 0;
 constexpr bool kFlatVjp = false;
+constexpr bool kLowRank = false;
+__device__ __forceinline__ double lowrank_u(const double*, int, int, const double*, const double*) { return 0.0; }
+__device__ __forceinline__ double lowrank_inv_s(int, const double*) { return 1.0; }
 __host__ __device__ constexpr int lds_doubles(int) { return 0; }
 __device__ __forceinline__ double entry(const double*, int, int, int, const double*, const double*) { return 0.0; }
 __device__ __forceinline__ double entry_padded(const double*, int, int, int, const double*, const double*) { return 0.0; }

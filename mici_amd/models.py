@@ -131,7 +131,12 @@ class UserMetric(RiemannianMetric):
     system's device model is created, the matrix-core leapfrog kernels on their first launch); ``params`` are handed to
     both.  ``dim`` <= 1024 (beyond 279 on the global-memory tier; the aux opt-in is 560 doubles at most, and ``MM_USER_AUX`` must be a plain decimal literal - the library reads it from the text, expressions are rejected).  The text may opt into per-point precomputation (``#define MM_USER_AUX n`` +
     ``mm_user_prepare``) and the team-form vector-Jacobian product (``#define MM_USER_VJP_FLAT`` +
-    ``mm_user_vjp_flat``): csrc/user_metric.h - both decide how fast the system runs, neither changes results."""
+    ``mm_user_vjp_flat``): csrc/user_metric.h - both decide how fast the system runs, neither changes results.  A metric of
+    the form C + s u(q) u(q)^T with a constant matrix C may DECLARE it (``#define MM_USER_LOWRANK`` + ``mm_user_lowrank_u`` /
+    ``mm_user_lowrank_inv_s``, round 6): at 32 < dim <= 1024 the implicit leapfrog then takes the position solves' M(x)^-1 p from
+    the explicit inverse at the step's start by the Woodbury identity and carries that inverse from step to step by a rank-two
+    update - the path of the built-in ``Rank1Metric`` (mici_amd/user_examples.py RANK1_AS_USER_LOWRANK,
+    SIN_RANK1_LOWRANK)."""
 
     def __init__(self, dim, source, params=()):
         super().__init__(RMETRIC_USER, dim, params)

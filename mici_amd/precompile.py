@@ -55,6 +55,13 @@ def default_jobs():
                "SOFTPLUS_RANK1_FAST": (ue.SOFTPLUS_RANK1_FAST, tuple(d for d in TEST_DIMS if d <= 64)),
                # (its aux block is 2 D + 2 doubles of the 560 a source may ask for: D <= 279)
                "SOFTPLUS_RANK1_FAST_WIDE": (ue.SOFTPLUS_RANK1_FAST_WIDE, tuple(d for d in TEST_DIMS if 64 < d <= 279))}
+    # round 6: metrics that declare their constant + rank-one structure (MM_USER_LOWRANK): bench.py c4_user_lowrank and
+    # tests/test_gpu_user_target.py - the families with a Woodbury path, and the auxiliary family of each size
+    lowrank_dims = (64, 130, 256, 320)
+    sources["RANK1_AS_USER_LOWRANK"] = (ue.RANK1_AS_USER_LOWRANK, lowrank_dims)
+    for d in lowrank_dims:
+        if d <= 256:
+            sources[f"SIN_RANK1_LOWRANK_{d}"] = (ue.sin_rank1_lowrank(d), (d,))
     tests = os.path.join(HERE, "..", "tests")
     if os.path.exists(os.path.join(tests, "user_sources.py")):  # the plain-form sources of the GPU tests
         sys.path.insert(0, tests)

@@ -18,6 +18,46 @@ __device__ double mm_user_vjp_flat(Ops& V, const double* q, int k, int dim, cons
 }
 """
 
+# The same metric DECLARING its structure (csrc/user_metric.h MM_USER_LOWRANK, round 6): M(q) = C + s u(q) u(q)^T with C = B,
+# u(q) = q, 1 / s = D.  The kernels with a Woodbury path (32 < D <= 1024) then take the position solves' M(x)^-1 p from the held
+# inverse and carry the inverse from step to step by a rank-two update (DESIGN section 4.3f) - bench.py c4_user_lowrank.
+RANK1_AS_USER_LOWRANK = "#define MM_USER_LOWRANK\n" + RANK1_AS_USER_FLAT + r"""
+__device__ double mm_user_lowrank_u(const double* q, int i, int dim, const double* params) { return q[i]; }
+__device__ double mm_user_lowrank_inv_s(int dim, const double* params) { return (double)dim; }
+"""
+
+# M(q) = B + (2 / D) u(q) u(q)^T with u_i(q) = q_i + sin(q_i) / 2 (oracle/models.py SinRank1Metric): constant + rank one in a
+# NONLINEAR function of the position, declared.  Per point: u_i and 1 + cos(q_i) / 2 (aux[i], aux[dim + i]);
+# vjp(V)_k = (2 / D) 2 (V u)_k (1 + cos(q_k) / 2) on the backend's mat-vec.
+SIN_RANK1_LOWRANK = r"""
+#define MM_USER_AUX 560
+#define MM_USER_VJP_FLAT
+#define MM_USER_LOWRANK
+template <class Team>
+__device__ void mm_user_prepare(Team& tm, const double* q, int dim, const double* params, double* aux) {
+  for (int i = tm.rank(); i < dim; i += tm.size()) {
+    aux[i] = q[i] + 0.5 * sin(q[i]);
+    aux[dim + i] = 1.0 + 0.5 * cos(q[i]);
+  }
+}
+__device__ double mm_user_metric(const double* q, int i, int j, int dim, const double* params, const double* aux) {
+  return __builtin_fma(aux[i], aux[j] * (2.0 / (double)dim), params[i * dim + j]);
+}
+template <class Ops>
+__device__ double mm_user_vjp_flat(Ops& V, const double* q, int k, int dim, const double* params, const double* aux) {
+  const bool on = V.active();
+  const double uk = on ? aux[k] : 0.0, dk = on ? aux[dim + k] : 0.0;
+  return (2.0 / (double)dim) * 2.0 * V.matvec(uk) * dk;
+}
+__device__ double mm_user_lowrank_u(const double* q, int i, int dim, const double* params, const double* aux) { return aux[i]; }
+__device__ double mm_user_lowrank_inv_s(int dim, const double* params) { return 0.5 * (double)dim; }
+"""
+
+def sin_rank1_lowrank(dim):
+    """SIN_RANK1_LOWRANK with the aux block it needs at this size (2 D doubles of at most 560: D <= 280)."""
+    return SIN_RANK1_LOWRANK.replace("#define MM_USER_AUX 560", f"#define MM_USER_AUX {2 * int(dim)}")
+
+
 # M(q) = diag(1 + softplus(q_i)) + c c^T (1 + |q|^2 / D), params = c[dim] (oracle/models.py SoftPlusRank1Metric - not built
 # into the device library).  Per point: |q|^2 by one team reduction (aux[0]), softplus(q_i) (aux[1 + i]) and the parameters
 # themselves (aux[1 + dim + i]: an entry then reads LDS only - at D <= 64 a lone wave cannot hide a global load); the

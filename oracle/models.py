@@ -325,6 +325,32 @@ class SoftPlusRank1Metric:
         return lambda v: np.diagonal(v) / (1.0 + np.exp(-q)) + (self.c @ v @ self.c) * 2.0 * q / self.dim
 
 
+class SinRank1Metric:
+    """A constant matrix plus a rank-one term in a NONLINEAR vector function of the position - the structure a user metric
+    declares with MM_USER_LOWRANK (csrc/user_metric.h): M(q) = B + s u(q) u(q)^T, u_i(q) = q_i + sin(q_i) / 2, s = 2 / D;
+    vjp(V)_k = s ((V + V^T) u)_k (1 + cos(q_k) / 2).  params: B row-major."""
+
+    mid = RMETRIC_USER
+
+    def __init__(self, base):
+        self.base = np.ascontiguousarray(base, dtype=np.float64)
+        self.dim = self.base.shape[0]
+
+    def params(self):
+        return self.base.ravel()
+
+    def u(self, q):
+        return q + 0.5 * np.sin(q)
+
+    def metric_func(self, q):
+        u = self.u(q)
+        return self.base + np.outer(u, u) * (2.0 / self.dim)
+
+    def vjp_metric_func(self, q):
+        u = self.u(q)
+        return lambda v: (2.0 / self.dim) * ((v + v.T) @ u) * (1.0 + 0.5 * np.cos(q))
+
+
 class DiagQuadMetric:
     """M(q) = diag(1 + q^2) held as a dense matrix; vjp(V)_i = 2 q_i V_ii
     (dense twin of the reference's DiagonalRiemannian test system,

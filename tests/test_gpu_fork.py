@@ -39,6 +39,7 @@ def _run(tmp_path, name, **env):
     e = dict(os.environ)
     for k in ("MICI_AMD_FORK", "MICI_AMD_DUAL", "MICI_AMD_REFINE", "MICI_AMD_PAIR"):
         e.pop(k, None)
+    e["MICI_AMD_LOWRANK"] = "0"  # (the forked kernel runs the CG refinement: the rank-one metric's default is the Woodbury path)
     e.update(env)
     r = subprocess.run([sys.executable, "-c", PROG, path], env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]

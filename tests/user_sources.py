@@ -87,8 +87,8 @@ __device__ double mm_user_vjp(const double* q, const MmMat& V, int k, int dim, c
 # ---- round 4: the two opt-ins of csrc/user_metric.h (MM_USER_AUX, MM_USER_VJP_FLAT).  The texts live with the package
 # (mici_amd/user_examples.py: bench.py measures them as c3_user / c4_general): RANK1_AS_USER_FLAT must reproduce the built-in
 # kernels bit for bit; SOFTPLUS_RANK1_FAST is oracle/models.py SoftPlusRank1Metric with both opt-ins.
-from mici_amd.user_examples import (BANANA_HESS, RANK1_AS_USER_FLAT, SOFTPLUS_RANK1_FAST,  # noqa: E402,F401
-                                    SOFTPLUS_RANK1_FAST_WIDE)
+from mici_amd.user_examples import (BANANA_HESS, RANK1_AS_USER_FLAT, RANK1_AS_USER_LOWRANK,  # noqa: E402,F401
+                                    SIN_RANK1_LOWRANK, SOFTPLUS_RANK1_FAST, SOFTPLUS_RANK1_FAST_WIDE)
 
 SOFTPLUS_RANK1_FAST_256 = SOFTPLUS_RANK1_FAST_WIDE
 

@@ -28,6 +28,7 @@ def main():
     names = {"c2i": "c2(i) iso-Gaussian", "c2iv": "c2(iv) + dense metric", "c3": "c3(a) D=64, 1024 chains",
              "c3b": "c3(b) SoftAbs D=64", "c4": "c4 shard D=256, 1024 chains", "c5": "c5 shard, 2048 chains",
              "c3_user": "c3_user D=64: softplus + rank-one metric as user source", "c4_general": "c4_general D=256: the c4 metric as user source",
+             "c4_user_lowrank": "c4_user_lowrank D=256: the c4 metric as user source that declares its structure (MM_USER_LOWRANK)",
              "c3b_dense": "c3b_dense D=64: SoftAbs on the banana, Hessian as user source (h = 0.01)",
              "c4_d512": "c4_d512 D=512, 256 chains: the c4 workload on the global-memory tier",
              "c2i_stream": "c2i_stream: c2(i) with n_steps = 1, 2²⁰ chains (the HBM-bound regime)",
@@ -36,22 +37,33 @@ def main():
     for k, v in rec.get("configs", {}).items():
         if "error" not in v:
             rows.append((k, names.get(k, k), v))
-    out = ["| config | steps/s (1 GPU) | kernel ms per launch | roofline (algorithmic) | executed | HBM traffic per launch (PMC) |",
+    out = ["| config | steps/s (1 GPU) | kernel ms per launch | roofline (algorithmic; executed flops where the Woodbury path runs) | executed | HBM traffic per launch (PMC) |",
            "|---|---|---|---|---|---|"]
     for key, name, r in rows:
         roof = r["roofline"]
         frac = f"{roof['frac']:.3f} of {'FP64 MFMA' if roof['bound'] == 'mfma' else 'HBM'} peak ({roof['achieved']:.1f} {roof['unit']})"
         if "fp64_valu" in roof:
             frac += f"; FP64 VALU {roof['fp64_valu']['frac']:.2f}"
+        if roof.get("reference_algorithm"):  # round 6: the Woodbury path - `frac` prices executed flops
+            ra = roof["reference_algorithm"]
+            frac = (f"executed: {roof['frac']:.3f} of FP64 peak ({roof['achieved']:.1f} TFLOP/s); the reference's algorithm at this "
+                    f"rate would need {ra['ratio_to_fp64_peak']:.2f} × peak")
         ex = "—"
         if roof.get("hbm_model"):
             hm = roof["hbm_model"]
             ex = f"HBM-bound: modelled {hm['bytes_per_launch'] / 1e9:.0f} GB per launch = {hm['achieved_GBs'] / 1e3:.2f} TB/s ({hm['frac_of_hbm_peak']:.2f} of peak)"
             if roof.get("executed"):
                 ex += f"; MFMA busy {roof['mfma_busy']:.3f}"
+                e = roof["executed"]
+                if e.get("lowrank_solves_per_chain_step"):
+                    ex += (f"; {e['lowrank_solves_per_chain_step']:.1f} Woodbury solves + {e['inverse_updates_per_chain_step']:.2f} "
+                           f"inverse updates + {e['sweeps_per_chain_step']:.2f} sweeps per step")
         elif roof.get("executed"):
             e = roof["executed"]
-            if "refine_pairs_per_chain_step" in e:
+            if e.get("lowrank_solves_per_chain_step"):
+                ex = (f"{e['lowrank_solves_per_chain_step']:.1f} Woodbury solves + {e['inverse_updates_per_chain_step']:.2f} inverse "
+                      f"updates + {e['sweeps_per_chain_step']:.2f} sweeps per step; MFMA busy {roof['mfma_busy']:.3f}")
+            elif "refine_pairs_per_chain_step" in e:
                 ex = (f"MFMA busy {roof['mfma_busy']:.3f}; {e['refine_pairs_per_chain_step']:.1f} CG pairs + "
                       f"{e['sweeps_per_chain_step']:.2f} sweeps per step")
             else:  # SoftAbs: eigenvector refinement

@@ -28,7 +28,7 @@ if [ "$1" = "collect" ]; then
 fi
 cd $ROOT
 O=$ROOT/gpurun_out/${ROUND}p; [ "$PART" = "2" ] || [ -n "$ONLY" ] || rm -rf $O; mkdir -p $O
-KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2i_stream:leapfrog_stream_kernel c2iv:leapfrog_mfma_kernel c3:implicit_mfma_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel c3_user:mm_rtc_riem_step c4_general:mm_rtc_riem_step c3b_dense:mm_rtc_softabs_step c4_d512:implicit_global_kernel c3b_d128:softabs_leapfrog_kernel c3b_d256:softabs_leapfrog_kernel"
+KERNELS="c2:leapfrog_mfma_kernel c2i:leapfrog_elem c2i_stream:leapfrog_stream_kernel c2iv:leapfrog_mfma_kernel c3:implicit_mfma_kernel c3b:softabs_leapfrog_kernel c4:implicit_blk16_kernel c5:constrained_leapfrog_kernel c3_user:mm_rtc_riem_step c4_general:mm_rtc_riem_step c4_user_lowrank:mm_rtc_riem_step c3b_dense:mm_rtc_softabs_step c4_d512:implicit_global_kernel c3b_d128:softabs_leapfrog_kernel c3b_d256:softabs_leapfrog_kernel"
 
 NF=80; [ -n "$SHORT_FUZZ" ] && NF=30
 # PART=1: tests, counters, bench, kernel trace;  PART=2: phase clocks, fuzz, host latency;  unset: everything

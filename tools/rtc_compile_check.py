@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("MICI_AMD_RTC_CACHE", "off")
 os.environ.setdefault("MICI_AMD_RTC_SEED", "off")
 
-FAMS = {"wave": 0, "mfma": 1, "team": 2, "blk16": 3, "softabs": 4}
+FAMS = {"wave": 0, "mfma": 1, "team": 2, "blk16": 3, "softabs": 4, "global": 5}
 
 
 def resources(path):
