@@ -57,6 +57,7 @@ struct ImplicitArgs {
                   // against the lock-step form)
   int no_lowrank; // 1: MICI_AMD_LOWRANK=0 (backends that decide it at run time: the global-memory tier)
   int lowrank_refresh;  // kLowRank backends: explicit-inverse updates in a row before the next factorisation (lowrank_update)
+  int no_sym;     // 1: MICI_AMD_GLOBAL_SYM=0 (global-memory tier: products with the held inverse read the whole matrix)
 };
 
 // MICI_AMD_REFINE=0 in the environment switches the refinement of the solve-only constructions off (read once)

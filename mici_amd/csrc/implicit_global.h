@@ -28,6 +28,8 @@ namespace mmglob {
 using namespace mmdev;
 using namespace mmimp;
 
+typedef double d4s __attribute__((ext_vector_type(4)));  // (sym_walk: a lane's four adjacent entries of a tile row)
+
 constexpr int NT = 1024;      // threads per chain = largest D
 constexpr int DPMAX = 1024;
 // Pivots per block of the sweep: the panel X (NB x DP doubles) must fit a CU's LDS - 32 pivots up to DP = 512, 16 beyond
@@ -313,6 +315,84 @@ struct GlobalBackend {
     const double r = tid < dim ? part[tid] + part[NT / 2 + tid] : 0.0;
     __syncthreads();  // (the next product rewrites the partials)
     return r;
+  }
+
+  // ---- y = A v from the LOWER tiles of the symmetric held inverse (round 6) -----------------------------------------------
+  // The Woodbury path (implicit_core.h lowrank_solve / lowrank_update) makes a step ~24 products with the held inverse and
+  // one sweep per launch: the products ARE the tier's HBM traffic, and a column walk reads both triangles of a symmetric
+  // matrix.  Here every 16 x 16 tile on or below the diagonal is read ONCE and used twice - directly (row sums, accumulated
+  // in-lane along a tile row) and mirrored (its columns' sums: a transposing butterfly over the sixteen lanes of a DPP row,
+  // added into the wave's own partial vector) - half the bytes of the pass.  Wave w owns the tile rows w and nt - 1 - w
+  // (nt + 1 tiles for every wave at nt = 32), four adjacent tiles - 512 contiguous bytes of each of the sixteen rows - per
+  // trip; the sixteen waves' partial vectors ([16][dp] doubles in the idle panel) are summed in a fixed order at the end:
+  // the result does not depend on timing.  Padded size <= 512 (the partial vectors must fit the panel's first half).
+  bool sym_on_;
+  __device__ __forceinline__ bool sym_ok() const { return sym_on_ && dp <= 512; }
+  __device__ static __forceinline__ double row_reduce16(const d4s rs, const int j) {
+    const bool h8 = (j & 8) != 0, h4 = (j & 4) != 0;
+    double k0v = h8 ? rs[2] : rs[0], k1v = h8 ? rs[3] : rs[1];
+    const double s0v = h8 ? rs[0] : rs[2], s1v = h8 ? rs[1] : rs[3];
+    k0v += dpp_move<kDppMirror>(s0v);
+    k1v += dpp_move<kDppMirror>(s1v);
+    double kk = h4 ? k1v : k0v;
+    const double ss = h4 ? k0v : k1v;
+    kk += dpp_move<kDppHalfMirror>(ss);
+    kk += dpp_move<kDppXor2>(kk);
+    kk += dpp_move<kDppXor1>(kk);
+    return kk;
+  }
+  __device__ __forceinline__ double sym_walk(const double* __restrict__ mat) {  // the operand is published (kOffNat)
+    double* buf = lds + kOffX;  // [16][dp]
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < 16 * dp; e += NT) buf[e] = 0.0;
+    __syncthreads();
+    const int nt = (dim + 15) >> 4;
+    const int row = lane & 15, cg = lane >> 4;
+    const double* nat = lds + kOffNat;
+    double* mine = buf + wave * dp;
+#pragma unroll 1
+    for (int p = wave; 2 * p < nt; p += 16) {
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        const int I = half == 0 ? p : nt - 1 - p;
+        if (half == 1 && I == p) break;  // (the middle tile row of an odd count)
+        const double vI = nat[16 * I + row];
+        const double* rowp = mat + (size_t)(16 * I + row) * dp + 4 * cg;
+        double accd = 0.0;
+#pragma unroll 1
+        for (int J = 0; J <= I; J += 4) {
+          d4s a[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            a[u] = (J + u <= I) ? *reinterpret_cast<const d4s*>(rowp + 16 * (J + u)) : d4s{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (J + u > I) break;  // (wave-uniform)
+            const d4s vJ = *reinterpret_cast<const d4s*>(nat + 16 * (J + u) + 4 * cg);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) accd = __builtin_fma(a[u][k], vJ[k], accd);
+            if (J + u < I) {  // below the diagonal: the mirrored tile's rows are this tile's columns
+              d4s m;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) m[k] = a[u][k] * vI;
+              const double val = row_reduce16(m, row);  // lane `row`: the sum of column 4 cg + (row >> 2) over the sixteen rows
+              if ((row & 3) == 0) mine[16 * (J + u) + 4 * cg + (row >> 2)] += val;
+            }
+          }
+        }
+        accd += __shfl_xor(accd, 16);
+        accd += __shfl_xor(accd, 32);
+        if (cg == 0) mine[16 * I + row] += accd;
+      }
+    }
+    __syncthreads();
+    double y = 0.0;
+    if (tid < dp) {
+#pragma unroll
+      for (int w = 0; w < 16; ++w) y += buf[w * dp + tid];
+    }
+    __syncthreads();  // (the next product zeroes the partial vectors)
+    return tid < dim ? y : 0.0;
   }
 
   // ---- metric_func(x) into the workspace (identity on the padding); false: an entry is not finite -------------------
@@ -626,6 +706,9 @@ struct GlobalBackend {
   __device__ __forceinline__ double matvec(double v) {
     if constexpr (RMETRIC == MM_RMETRIC_DIAGQUAD) return tid < dim ? dinv_ * v : 0.0;
     publish(v);
+    if constexpr (kLowRankBuiltin) {
+      if (sym_ok()) return sym_walk(A);
+    }
     return column_walk(A, dp, dim);
   }
   // z = F r of the refinement solves (implicit_core.h precond_trait): the scaled FP32 copy
@@ -891,7 +974,10 @@ __device__ __forceinline__ void init_backend(GlobalBackend<RMETRIC, NB>& bk, con
   bk.tparams = A.tparams;
   bk.refine_on = A.no_refine == 0 && RMETRIC != MM_RMETRIC_DIAGQUAD;  // (a diagonal metric: every construction elementwise)
   bk.dinv_ = 0.0;
-  bk.dual_off = A.no_dual != 0;
+  // (sym_walk reads half the matrix per product: the lock step's shared pass - the same saving for two of a step's ~24
+  // products only - is off while it is on)
+  bk.sym_on_ = A.no_sym == 0 && A.no_lowrank == 0 && A.no_refine == 0;
+  bk.dual_off = A.no_dual != 0 || (RMETRIC == MM_RMETRIC_RANK1 && bk.sym_on_ && bk.dp <= 512);
   bk.lowrank_on_ = A.no_lowrank == 0 && A.no_refine == 0;
   bk.lr_refresh_ = A.lowrank_refresh;
   bk.xpt_ = 0.0;

@@ -70,6 +70,10 @@ static int launch_step(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, in
   a.no_dual = mm_dual_disabled();
   a.lowrank_refresh = mm_lowrank_refresh();
   a.no_lowrank = mm_lowrank_disabled();
+  {  // MICI_AMD_GLOBAL_SYM=0: products with the held inverse by the full column walk (A/B runs against sym_walk)
+    static const int off = [] { const char* e = getenv("MICI_AMD_GLOBAL_SYM"); return (e && e[0] == '0') ? 1 : 0; }();
+    a.no_sym = off;
+  }
   if (midpoint) return MM_GLOB_DISPATCH(implicit_global_kernel, true);
   return MM_GLOB_DISPATCH(implicit_global_kernel, false);
 }
