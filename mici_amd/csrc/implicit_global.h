@@ -746,7 +746,13 @@ struct GlobalBackend {
     const int h = (two && tid >= NT / 2) ? 1 : 0;
     const int c = tid - h * (NT / 2);
     const int nh = two ? ((dim + 1) >> 1) : dim;
-    const int j0 = h * nh, j1 = (j0 + nh < dim) ? j0 + nh : dim;
+    int j0 = h * nh;
+    const int j1 = (j0 + nh < dim) ? j0 + nh : dim;
+    // (while the products read the lower tiles only - sym_walk - so does the update: the diagonal tiles whole, nothing above
+    // them; the next factorisation's mirror pass rewrites the upper triangle)
+    if constexpr (kLowRankBuiltin) {
+      if (sym_ok() && j0 < (c & ~15)) j0 = c & ~15;
+    }
     if (c < dim) {
       const double uc = part[c], vc = part[NT + c];
       const double* nat = lds + kOffNat;
