@@ -396,9 +396,50 @@ struct TeamBlk16 {
   __device__ __forceinline__ double& rslot(int i) { return lds[kOffRs + i * VLM + (tid < DPM ? tid : DPM)]; }
 
   // two team-uniform sums over the chain's elements in one pass (two barriers)
-  __device__ __forceinline__ void sum2(double a, double b, double* sa, double* sb) {
+  // Round 6, the Woodbury kernels (kLowRank): a step there is ~21 products and ~45 team reductions, and its ~130 workgroup
+  // barriers are a sixth of its time.  Their reductions alternate between TWO sets of partials (as softabs.h block_reduce4
+  // and implicit_global.h reduce do): the writer of a set is always behind a barrier every reader of its previous contents
+  // has passed, so ONE barrier per reduction is enough.  rflip_ is team-uniform (every wave runs the same reductions).
+  int rflip_;
+  __device__ __forceinline__ double* flip_set() {
+    double* p = lds + kOffScr + 7 * 64 + 32 * rflip_;  // [2][up to 3 values][8 waves]  (the inverting wave's sweep scratch)
+    rflip_ ^= 1;
+    return p;
+  }
+  // up to three values through one barrier: v0 by `max0 ? NaN-propagating max : sum`, v1 / v2 sums
+  template <int NV>
+  __device__ __forceinline__ void flip_reduce(const bool max0, double v0, double v1, double v2, double* r0, double* r1,
+                                              double* r2) {
     const int lane = fresh_lane(), wv = opaque_wave(wave);
+    v0 = max0 ? wave_max(v0) : wave_sum(v0);
+    if constexpr (NV > 1) v1 = wave_sum(v1);
+    if constexpr (NV > 2) v2 = wave_sum(v2);
+    double* red = flip_set();
+    if (lane == 0) {
+      red[wv] = v0;
+      if constexpr (NV > 1) red[8 + wv] = v1;
+      if constexpr (NV > 2) red[16 + wv] = v2;
+    }
+    __syncthreads();
+    double a = red[0], b = NV > 1 ? red[8] : 0.0, c = NV > 2 ? red[16] : 0.0;
+#pragma unroll
+    for (int k = 1; k < NWAVE; ++k) {
+      a = max0 ? nanmax(a, red[k]) : a + red[k];
+      if constexpr (NV > 1) b += red[8 + k];
+      if constexpr (NV > 2) c += red[16 + k];
+    }
+    *r0 = uniform_f64(a);
+    if constexpr (NV > 1) *r1 = uniform_f64(b);
+    if constexpr (NV > 2) *r2 = uniform_f64(c);
+  }
+  __device__ __forceinline__ void sum2(double a, double b, double* sa, double* sb) {
     const bool act = tid < dim;
+    if constexpr (kLowRank) {
+      double unused;
+      flip_reduce<2>(false, act ? a : 0.0, act ? b : 0.0, 0.0, sa, sb, &unused);
+      return;
+    }
+    const int lane = fresh_lane(), wv = opaque_wave(wave);
     a = wave_sum(act ? a : 0.0);
     b = wave_sum(act ? b : 0.0);
     double* red = lds + kOffRed;
@@ -417,91 +458,29 @@ struct TeamBlk16 {
     *sa = uniform_f64(ra);
     *sb = uniform_f64(rb);
   }
-  // four team-uniform sums in one pass (two barriers); partials in the last wave's block of the sweeps' scratch (no sweep runs
-  // while a solve-only construction is in flight)
-  __device__ __forceinline__ void sum4(double a, double b, double c, double d, double* sa, double* sb, double* sc,
-                                       double* sd) {
-    const int lane = fresh_lane(), wv = opaque_wave(wave);
-    const bool act = tid < dim;
-    a = wave_sum(act ? a : 0.0);
-    b = wave_sum(act ? b : 0.0);
-    c = wave_sum(act ? c : 0.0);
-    d = wave_sum(act ? d : 0.0);
-    double* red = lds + kOffScr + 7 * 64;  // [4][8]
-    if (lane == 0) {
-      red[wv] = a;
-      red[8 + wv] = b;
-      red[16 + wv] = c;
-      red[24 + wv] = d;
-    }
-    __syncthreads();
-    double ra = red[0], rb = red[8], rc = red[16], rd = red[24];
-#pragma unroll
-    for (int k = 1; k < NWAVE; ++k) {
-      ra += red[k];
-      rb += red[8 + k];
-      rc += red[16 + k];
-      rd += red[24 + k];
-    }
-    __syncthreads();
-    *sa = uniform_f64(ra);
-    *sb = uniform_f64(rb);
-    *sc = uniform_f64(rc);
-    *sd = uniform_f64(rd);
-  }
-  // a norm (kind as norm()) and a team sum through ONE pair of barriers (implicit_core.h momentum_solve_lowrank)
+  // a norm (kind as norm()) and a team sum through one barrier (implicit_core.h momentum_solve_lowrank)
   __device__ __forceinline__ void norm_dot(double x, int kind, double y, double* err, double* s) {
-    const int lane = fresh_lane(), wv = opaque_wave(wave);
     const bool act = tid < dim;
     const double a = act ? x : 0.0;
     const bool linf = kind == MM_NORM_LINF;  // team-uniform
-    const double n = linf ? wave_max(fabs(a)) : wave_sum(a * a);
-    const double d = wave_sum(act ? y : 0.0);
-    double* red = lds + kOffRed;
-    if (lane == 0) {
-      red[wv] = n;
-      red[8 + wv] = d;
-    }
-    __syncthreads();
-    double rn = red[0], rd = red[8];
-#pragma unroll
-    for (int k = 1; k < NWAVE; ++k) {
-      rn = linf ? nanmax(rn, red[k]) : rn + red[k];
-      rd += red[8 + k];
-    }
-    __syncthreads();
-    *err = uniform_f64(linf ? rn : sqrt(rn));
-    *s = uniform_f64(rd);
+    double r, unused;
+    flip_reduce<2>(linf, linf ? fabs(a) : a * a, act ? y : 0.0, 0.0, &r, s, &unused);
+    *err = linf ? r : sqrt(r);
   }
   __device__ __forceinline__ void sum3(double a, double b, double c, double* sa, double* sb, double* sc) {
-    const int lane = fresh_lane(), wv = opaque_wave(wave);
     const bool act = tid < dim;
-    a = wave_sum(act ? a : 0.0);
-    b = wave_sum(act ? b : 0.0);
-    c = wave_sum(act ? c : 0.0);
-    double* red = lds + kOffScr + 7 * 64;  // [3][8]
-    if (lane == 0) {
-      red[wv] = a;
-      red[8 + wv] = b;
-      red[16 + wv] = c;
-    }
-    __syncthreads();
-    double ra = red[0], rb = red[8], rc = red[16];
-#pragma unroll
-    for (int k = 1; k < NWAVE; ++k) {
-      ra += red[k];
-      rb += red[8 + k];
-      rc += red[16 + k];
-    }
-    __syncthreads();
-    *sa = uniform_f64(ra);
-    *sb = uniform_f64(rb);
-    *sc = uniform_f64(rc);
+    flip_reduce<3>(false, act ? a : 0.0, act ? b : 0.0, act ? c : 0.0, sa, sb, sc);
   }
   __device__ __forceinline__ double& slot(int i) { return lds[kOffStash + i * VLM + (tid < DPM ? tid : DPM)]; }
 
   __device__ __forceinline__ double norm(double x, int kind) {
     const double a = tid < dim ? x : 0.0;
+    if constexpr (kLowRank) {
+      const bool linf = kind == MM_NORM_LINF;  // team-uniform
+      double r, u1, u2;
+      flip_reduce<1>(linf, linf ? fabs(a) : a * a, 0.0, 0.0, &r, &u1, &u2);
+      return linf ? r : sqrt(r);
+    }
     if (kind == MM_NORM_LINF) return uniform_f64(team_reduce(fabs(a), 1, lds + kOffRed));
     return uniform_f64(sqrt(team_reduce(a * a, 0, lds + kOffRed)));
   }
@@ -1063,7 +1042,9 @@ struct TeamBlk16 {
 #pragma unroll
       for (int k = 0; k < PSTR; ++k) y += src[k];
     }
-    __syncthreads();
+    // (the partial sums are next written behind the NEXT product's publish barrier, which every reader here reaches first:
+    // the Woodbury kernels - whose only other users of LDS between two products are the flip reductions - do without this one)
+    if constexpr (!kLowRank) __syncthreads();
     return tid < dim ? -y : 0.0;
   }
 
@@ -1302,6 +1283,7 @@ __device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC, PROFILE, LOWRANK
   bk.work = A.work ? A.work + (int64_t)blockIdx.x * (DPM * DPM) : nullptr;
   bk.refine_on = A.no_refine == 0;
   bk.lr_refresh_ = A.lowrank_refresh;
+  bk.rflip_ = 0;
   for (int i = threadIdx.x; i < DPM * PSTR; i += NTHR) lds[kOffPart + i] = 0.0;  // unused partial-sum slots stay 0
   if (threadIdx.x < 16) lds[kOffCnt + threadIdx.x] = 0.0;                    // work counters
   if constexpr (PROFILE) {
