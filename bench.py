@@ -718,14 +718,21 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
         # (round 6: the Woodbury solves of the rank-one-update metric read the FP64 inverse once each; in lock step two share a pass -
         # not subtracted here)
         # an inverse update (lowrank_update) is one product + one read-modify-write pass of the FP64 workspace: 3 passes' bytes
-        f64_products = n_b + 4.0 * done_local + counters_acc.get("n_lowrank", 0) + 3.0 * counters_acc.get("n_inverse_update", 0)
+        n_lr, n_up = counters_acc.get("n_lowrank", 0), counters_acc.get("n_inverse_update", 0)
+        f64_products = n_b + 4.0 * done_local + n_lr + 3.0 * n_up
+        note_sym = ""
+        if n_lr > 0 and dp <= 512 and os.environ.get("MICI_AMD_GLOBAL_SYM", "1") != "0":
+            # implicit_global.h sym_walk: a product reads the lower tiles of the symmetric inverse (half a pass), the update's
+            # read-modify-write touches the lower tiles too: product 0.5 + 2 x 0.5
+            f64_products = 0.5 * (n_b + 4.0 * done_local + n_lr) + 1.5 * n_up
+            note_sym = "; products and updates on the lower tiles only (sym_walk): half the bytes each"
         f32_products = counters_acc.get("n_refine", 0)
         bytes_total = 8.0 * dp * dp * (sweeps * (1.0 + np.ceil(d / nb) + 2.0) + f64_products + 0.5 * f32_products)
         hbm_model = dict(bytes_per_launch=bytes_total / steps, achieved_GBs=bytes_total / steps / launch_s / 1e9,
                          frac_of_hbm_peak=bytes_total / steps / launch_s / 1e9 / HBM_PEAK_GBS,
                          bytes_per_chain_step=bytes_total / max(done_local, 1.0),
                          note="modelled traffic of the HBM-resident metric: sweeps x (ceil(D / NB) + 3) + FP64 products + FP32 "
-                              "products / 2, x 8 DP^2 bytes")
+                              "products / 2, x 8 DP^2 bytes" + note_sym)
     if w["bound"] == "mfma":
         achieved = w["flops_per_chain_step"] * chain_steps_per_launch / launch_s / 1e12
         roof = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
