@@ -151,7 +151,9 @@ struct MfmaBackend {
   bool refine_on;                        // false: MICI_AMD_REFINE=0, every construction is factorised
   // implicit_core.h refine_solve2: the two position solves of a step in lock step (round 5).  Built-in metrics; a user
   // metric's M(x) is forty registers of entries per point, two points do not fit next to the inverse's row.
-  static constexpr bool kDual = MM_MFMA_DUAL && RMETRIC != MM_RMETRIC_USER;
+  // (round 6: ON in the Woodbury kernel of the built-in metric - lowrank_solve2 advances the reversibility-check solve and the
+  // C-adjoint solve together on interleaved products, matvec2_exact; MICI_AMD_DUAL=0: one after the other)
+  static constexpr bool kDual = MM_MFMA_DUAL ? RMETRIC != MM_RMETRIC_USER : (LOWRANK && RMETRIC == MM_RMETRIC_RANK1);
   bool dual_off;                         // true: MICI_AMD_DUAL=0, one solve after the other
   d4 acc[kTiles];
   int dim, lane, target;
@@ -385,7 +387,37 @@ struct MfmaBackend {
   }
 
   // the points of a lock-step pair: system 0's where metric_point() puts it, system 1's behind it
-  __device__ __forceinline__ void matvec2_exact(double v0, double v1, double* y0, double* y1) { matvec2(v0, v1, y0, y1); }
+  // implicit_core.h lowrank_solve2 (round 6): the two position solves' products F d_C, F d_A INTERLEAVED - every register of the
+  // inverse's row feeds two multiply-adds with independent accumulators, the two broadcast vectors are read side by side: a
+  // lone wave's dependent chains get a second stream to fill their latency with (the Woodbury kernel has no CG vectors and no
+  // M(x) v operands next to the row: the registers the lock step of section 4.3d lacked)
+  __device__ __forceinline__ void matvec2_exact(double v0, double v1, double* y0, double* y1) {
+    w.nat[lane] = (lane < dim) ? v0 : 0.0;
+    w.aux[lane] = (lane < dim) ? v1 : 0.0;
+    wave_sync();
+    double a[kAcc], b[kAcc];
+#pragma unroll
+    for (int e = 0; e < kAcc; ++e) a[e] = b[e] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const d4 va = *reinterpret_cast<const d4*>(w.nat + 4 * k), vb = *reinterpret_cast<const d4*>(w.aux + 4 * k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[(4 * k + e) % kAcc] = __builtin_fma(fr_[4 * k + e], va[e], a[(4 * k + e) % kAcc]);
+        b[(4 * k + e) % kAcc] = __builtin_fma(fr_[4 * k + e], vb[e], b[(4 * k + e) % kAcc]);
+      }
+    }
+    wave_sync();  // (the next product overwrites w.nat / w.aux)
+#pragma unroll
+    for (int h = kAcc / 2; h >= 1; h >>= 1)
+#pragma unroll
+      for (int e = 0; e < h; ++e) {
+        a[e] += a[e + h];
+        b[e] += b[e + h];
+      }
+    *y0 = lane < dim ? a[0] : 0.0;
+    *y1 = lane < dim ? b[0] : 0.0;
+  }
   __device__ __forceinline__ void metric_point2(double x0, double x1) {
     w.qt[lane] = (lane < dim) ? x0 : 0.0;
     w.qt[64 + lane] = (lane < dim) ? x1 : 0.0;

@@ -59,7 +59,7 @@ int launch(mm_ctx* ctx, K kernel, const ImplicitArgs& a) {
 
 static int launch_step(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, int n_steps, const mm_fp_opts& opts,
                        mm_counters* d_counters, bool midpoint) {
-  ImplicitArgs a;
+  ImplicitArgs a{};
   const int rc = fill_args(ctx, m, s, a);
   if (rc != MM_OK) return rc;
   a.step_size = h;
@@ -88,7 +88,7 @@ int mm_launch_implicit_midpoint_global(mm_ctx* ctx, const mm_model* m, mm_state*
 }
 
 int mm_launch_riemann_aux_global(mm_ctx* ctx, const mm_model* m, mm_state* s, int op, double* d_out, const double* d_z) {
-  ImplicitArgs a;
+  ImplicitArgs a{};
   const int rc = fill_args(ctx, m, s, a);
   if (rc != MM_OK) return rc;
   a.out = d_out;
