@@ -283,6 +283,15 @@ struct TeamBlk16 {
   __device__ static constexpr bool lowrank_on() { return true; }  // (compile-time: the launcher picks the instantiation)
   int lr_refresh_;
   __device__ __forceinline__ int lowrank_refresh() const { return lr_refresh_; }
+  // implicit_core.h lowrank_solve2: the reversibility-check solve and the C-adjoint solve of a step in lock step on the
+  // Woodbury path of the built-in metric - one pass over the register tiles serves both products (matvec2_exact), one
+  // barrier both norms / all six inner products (MICI_AMD_DUAL=0: one solve after the other).  A/B macro.
+#ifndef MM_BLK16_LR_DUAL
+#define MM_BLK16_LR_DUAL 1
+#endif
+  static constexpr bool kDual = MM_BLK16_LR_DUAL && LOWRANK && RMETRIC == MM_RMETRIC_RANK1;
+  static constexpr bool kDualLowRankOnly = true;  // (implicit_core.h: no paired CG products on this backend)
+  bool dual_off;
   static constexpr bool kSolveByInverse = false;
   static constexpr bool kUnifiedConstruct = true;  // implicit_core.h: one construction site, mode at run time
   static constexpr bool kCountersInLds = true;     // implicit_core.h: work counters in LDS, bumped by thread 0
@@ -406,31 +415,48 @@ struct TeamBlk16 {
     rflip_ ^= 1;
     return p;
   }
-  // up to three values through one barrier: v0 by `max0 ? NaN-propagating max : sum`, v1 / v2 sums
-  template <int NV>
+  // up to four values through one barrier: v0 (and v1 with MAX01) by `max0 ? NaN-propagating max : sum`, the others sums
+  template <int NV, bool MAX01 = false>
   __device__ __forceinline__ void flip_reduce(const bool max0, double v0, double v1, double v2, double* r0, double* r1,
-                                              double* r2) {
+                                              double* r2, double v3 = 0.0, double* r3 = nullptr) {
     const int lane = fresh_lane(), wv = opaque_wave(wave);
     v0 = max0 ? wave_max(v0) : wave_sum(v0);
-    if constexpr (NV > 1) v1 = wave_sum(v1);
+    if constexpr (NV > 1) v1 = (MAX01 && max0) ? wave_max(v1) : wave_sum(v1);
     if constexpr (NV > 2) v2 = wave_sum(v2);
+    if constexpr (NV > 3) v3 = wave_sum(v3);
     double* red = flip_set();
     if (lane == 0) {
       red[wv] = v0;
       if constexpr (NV > 1) red[8 + wv] = v1;
       if constexpr (NV > 2) red[16 + wv] = v2;
+      if constexpr (NV > 3) red[24 + wv] = v3;
     }
     __syncthreads();
-    double a = red[0], b = NV > 1 ? red[8] : 0.0, c = NV > 2 ? red[16] : 0.0;
+    double a = red[0], b = NV > 1 ? red[8] : 0.0, c = NV > 2 ? red[16] : 0.0, d = NV > 3 ? red[24] : 0.0;
 #pragma unroll
     for (int k = 1; k < NWAVE; ++k) {
       a = max0 ? nanmax(a, red[k]) : a + red[k];
-      if constexpr (NV > 1) b += red[8 + k];
+      if constexpr (NV > 1) b = (MAX01 && max0) ? nanmax(b, red[8 + k]) : b + red[8 + k];
       if constexpr (NV > 2) c += red[16 + k];
+      if constexpr (NV > 3) d += red[24 + k];
     }
     *r0 = uniform_f64(a);
     if constexpr (NV > 1) *r1 = uniform_f64(b);
     if constexpr (NV > 2) *r2 = uniform_f64(c);
+    if constexpr (NV > 3) *r3 = uniform_f64(d);
+  }
+  __device__ __forceinline__ void sum4(double a, double b, double c, double d, double* sa, double* sb, double* sc,
+                                       double* sd) {
+    const bool act = tid < dim;
+    flip_reduce<4>(false, act ? a : 0.0, act ? b : 0.0, act ? c : 0.0, sa, sb, sc, act ? d : 0.0, sd);
+  }
+  __device__ __forceinline__ void norm2(double a, double b, int kind, double* na, double* nb) {
+    const bool act = tid < dim, linf = kind == MM_NORM_LINF;
+    const double xa = act ? a : 0.0, xb = act ? b : 0.0;
+    double ra, rb, unused;
+    flip_reduce<2, true>(linf, linf ? fabs(xa) : xa * xa, linf ? fabs(xb) : xb * xb, 0.0, &ra, &rb, &unused);
+    *na = linf ? ra : sqrt(ra);
+    *nb = linf ? rb : sqrt(rb);
   }
   __device__ __forceinline__ void sum2(double a, double b, double* sa, double* sb) {
     const bool act = tid < dim;
@@ -1048,6 +1074,84 @@ struct TeamBlk16 {
     return tid < dim ? -y : 0.0;
   }
 
+  // ---- two products with the held inverse in ONE pass over the register tiles (implicit_core.h lowrank_solve2) ---------------
+  // matvec() with every tile register feeding both vectors.  The second vector's operand copies and partial sums live in the
+  // idle panel (behind the Woodbury path's three flat vectors); its never-written partial slots are garbage after a sweep,
+  // so both final sums mask them (slot k <= the element's own tile row) instead of relying on zeros.
+  static constexpr int kOffNat2 = kOffRs + RS_COUNT * VLM;  // [VLM]
+  static constexpr int kOffVperm2 = kOffNat2 + VLM;          // [DPM]
+  static constexpr int kOffPart2 = kOffVperm2 + DPM;         // [DPM][PSTR]
+  static_assert(kOffPart2 + DPM * PSTR <= kOffPart, "the lock step's second operand / partial sums must fit the panel buffers");
+  static_assert((kOffVperm2 % 2) == 0, "16-byte alignment of the d4 accesses");
+  __device__ __forceinline__ void matvec2_exact(double v0, double v1, double* y0, double* y1) {
+    if (tid < DPM) {
+      const double a = tid < dim ? v0 : 0.0, b = tid < dim ? v1 : 0.0;
+      const int pi = ((((tid >> 4) << 2) + (tid & 3)) << 2) + ((tid >> 2) & 3);
+      lds[kOffNat + tid] = a;
+      lds[kOffVperm + pi] = a;
+      lds[kOffNat2 + tid] = b;
+      lds[kOffVperm2 + pi] = b;
+    }
+    __syncthreads();
+    const int w = opaque_wave(wave);
+    const int ln = fresh_lane(), g = ln >> 4, j = ln & 15;
+    double* part = lds + kOffPart;
+    double* part2 = lds + kOffPart2;
+    d4 rs0[NCLASS], rs1[NCLASS];
+#pragma unroll
+    for (int c = 0; c < NCLASS; ++c) rs0[c] = rs1[c] = d4{0.0, 0.0, 0.0, 0.0};
+    double mir0[4] = {0.0, 0.0, 0.0, 0.0}, mir1[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      const int I = tile_i(s, w), J = tile_j(s, w);
+      const double vc0 = lds[kOffNat + 16 * J + j], vc1 = lds[kOffNat2 + 16 * J + j];
+      const d4 a = acc[s];
+      add_row(s, w, rs0, a, vc0);
+      add_row(s, w, rs1, a, vc1);
+      if (!is_diag_slot(s)) {
+        const d4 vr0 = *reinterpret_cast<const d4*>(lds + kOffVperm + ((I * 4 + g) << 2));
+        const d4 vr1 = *reinterpret_cast<const d4*>(lds + kOffVperm2 + ((I * 4 + g) << 2));
+        double m0 = a[0] * vr0[0], m1 = a[0] * vr1[0];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+          m0 = __builtin_fma(a[r], vr0[r], m0);
+          m1 = __builtin_fma(a[r], vr1[r], m1);
+        }
+        mir0[(s - 1) & 3] = m0;
+        mir1[(s - 1) & 3] = m1;
+        if (((s - 1) & 3) == 3 || s == NSLOT - 2) {
+          const bool full = ((s - 1) & 3) == 3;
+          store_mirrored4(part, s - ((s - 1) & 3), w, g, j, mir0[0], mir0[1], mir0[2], full ? mir0[3] : 0.0);
+          store_mirrored4(part2, s - ((s - 1) & 3), w, g, j, mir1[0], mir1[1], mir1[2], full ? mir1[3] : 0.0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0x206);  // arithmetic and LDS stores may cross, loads may not
+    }
+#pragma unroll
+    for (int c = 0; c < NCLASS; ++c) {
+      const int e = (16 * row_of_class(c, w) + 4 * (j >> 2) + g) * PSTR + 16;
+      part[e] = row_reduce16(rs0[c], j);
+      part2[e] = row_reduce16(rs1[c], j);
+    }
+    __syncthreads();
+    double a = 0.0, b = 0.0;
+    if (tid < DPM) {
+      const double* s0 = lds + kOffPart + tid * PSTR;
+      const double* s1 = lds + kOffPart2 + tid * PSTR;
+      const int own = tid >> 4;  // column-sum slots k <= the element's own tile row are never written
+#pragma unroll
+      for (int k = 0; k < PSTR - 1; ++k) {
+        const double p0 = s0[k], p1 = s1[k];
+        a += (k > own) ? p0 : 0.0;
+        b += (k > own) ? p1 : 0.0;
+      }
+      a += s0[PSTR - 1];
+      b += s1[PSTR - 1];
+    }
+    *y0 = tid < dim ? -a : 0.0;
+    *y1 = tid < dim ? -b : 0.0;
+  }
+
   // ---- implicit_core.h lowrank_update: F += al a a^T + be (a b^T + b a^T) + ga b b^T on the tiles (they hold -F) ------------
   // entry (i, j) takes a_i u_j + b_i v_j with u = al a + be b, v = be a + ga b: the row operands a, b in the [I][g][r] order
   // (one 32-byte read a tile), the column operands u, v in natural order.  Eight multiply-adds a tile and lane.
@@ -1284,6 +1388,7 @@ __device__ __forceinline__ void init_backend(TeamBlk16<RMETRIC, PROFILE, LOWRANK
   bk.refine_on = A.no_refine == 0;
   bk.lr_refresh_ = A.lowrank_refresh;
   bk.rflip_ = 0;
+  bk.dual_off = A.no_dual != 0;
   for (int i = threadIdx.x; i < DPM * PSTR; i += NTHR) lds[kOffPart + i] = 0.0;  // unused partial-sum slots stay 0
   if (threadIdx.x < 16) lds[kOffCnt + threadIdx.x] = 0.0;                    // work counters
   if constexpr (PROFILE) {

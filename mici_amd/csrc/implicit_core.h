@@ -460,6 +460,10 @@ template <class BK>
 struct basis_trait<BK, decltype((void)BK::kBasisSlots)> { static constexpr bool value = BK::kBasisSlots; };
 
 template <class BK, class = void>
+struct dual_lowrank_only_trait { static constexpr bool value = false; };
+template <class BK>
+struct dual_lowrank_only_trait<BK, decltype((void)BK::kDualLowRankOnly)> { static constexpr bool value = BK::kDualLowRankOnly; };
+template <class BK, class = void>
 struct dual_trait { static constexpr bool value = false; };
 template <class BK>
 struct dual_trait<BK, decltype((void)BK::kDual)> { static constexpr bool value = BK::kDual; };
@@ -745,8 +749,10 @@ __device__ __forceinline__ ChainResult implicit_leapfrog_chain(BK& bk, double t,
         if (lr_on) {
           if constexpr (kLowRank) lowrank_solve2(bk, bk.slot(SL_XQ), bk.slot(SL_PTA), lr_sbb, lr_sbc, &uC, &uA, &okC, &okA, r);
         } else {
-          refine_solve2(bk, bk.slot(SL_XQ), bk.slot(SL_PTA), bk.slot(SL_PW), bk.slot(SL_UC), bk.slot(SL_UA), &uC, &uA,
-                        &okC, &okA, r);
+          // (a backend whose lock step exists on the Woodbury path only - kDualLowRankOnly - has no paired CG products)
+          if constexpr (!dual_lowrank_only_trait<BK>::value)
+            refine_solve2(bk, bk.slot(SL_XQ), bk.slot(SL_PTA), bk.slot(SL_PW), bk.slot(SL_UC), bk.slot(SL_UA), &uC, &uA,
+                          &okC, &okA, r);
         }
         if (!okA) dual_ok = false;  // the adjoint solve's evaluation is repeated (and factorised) when its turn comes
         if (!okC) {
