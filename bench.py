@@ -214,7 +214,10 @@ def make_workload(config, n_chains, rng, device=True, chain_rng=None):
         if wide:
             # round 6: the SoftAbs workspace tiers - 64 < D <= 256, the three matrices of a chain in a global-memory
             # workspace (csrc/softabs.h NP = 128 / 256) - on the c3(b) funnel at two and four times its dimension
-            dim, traj = (128, 20) if config == "c3b_d128" else (256, 10)  # (a pass restarts from q0: its first decomposition is cold)
+            # c3(b)'s own trajectory length (100; until the end of round 6 these entries ran 20 / 10 steps, where the cold first
+            # decomposition of a pass - it restarts from q0 - weighed 5 - 10 times as much: D = 256 3.0e3 steps/s at 10 steps,
+            # 5.1e3 at 40)
+            dim, traj = (128, 100) if config == "c3b_d128" else (256, 100)
         wts = np.linspace(0.5, 2.0, dim - 1)
         if config == "c3b_dense":
             h = 0.01  # (at 0.02 half of the banana chains meet a ConvergenceError within 100 steps - in the reference too)
