@@ -724,7 +724,7 @@ def run_config(ctx, rdzv, config, steps, warmup, rank, world, chains_per_gpu=Non
         n_lr, n_up = counters_acc.get("n_lowrank", 0), counters_acc.get("n_inverse_update", 0)
         f64_products = n_b + 4.0 * done_local + n_lr + 3.0 * n_up
         note_sym = ""
-        if n_lr > 0 and dp <= 512 and os.environ.get("MICI_AMD_GLOBAL_SYM", "1") != "0":
+        if n_lr > 0 and os.environ.get("MICI_AMD_GLOBAL_SYM", "1") != "0":
             # implicit_global.h sym_walk: a product reads the lower tiles of the symmetric inverse (half a pass), the update's
             # read-modify-write touches the lower tiles too: product 0.5 + 2 x 0.5
             f64_products = 0.5 * (n_b + 4.0 * done_local + n_lr) + 1.5 * n_up

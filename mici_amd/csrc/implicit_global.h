@@ -329,9 +329,9 @@ struct GlobalBackend {
   // added into the wave's own partial vector) - half the bytes of the pass.  Wave w owns the tile rows w and nt - 1 - w
   // (nt + 1 tiles for every wave at nt = 32), four adjacent tiles - 512 contiguous bytes of each of the sixteen rows - per
   // trip; the sixteen waves' partial vectors ([16][dp] doubles in the idle panel) are summed in a fixed order at the end:
-  // the result does not depend on timing.  Padded size <= 512 (the partial vectors must fit the panel's first half).
+  // the result does not depend on timing.  The partial vectors fill the panel at the tier's largest padded size (1024).
   bool sym_on_;
-  __device__ __forceinline__ bool sym_ok() const { return sym_on_ && dp <= 512; }
+  __device__ __forceinline__ bool sym_ok() const { return sym_on_; }  // ([16][dp] partial vectors = the panel at dp = 1024)
   __device__ static __forceinline__ double row_reduce16(const d4s rs, const int j) {
     const bool h8 = (j & 8) != 0, h4 = (j & 4) != 0;
     double k0v = h8 ? rs[2] : rs[0], k1v = h8 ? rs[3] : rs[1];
@@ -987,7 +987,7 @@ __device__ __forceinline__ void init_backend(GlobalBackend<RMETRIC, NB>& bk, con
   // (sym_walk reads half the matrix per product: the lock step's shared pass - the same saving for two of a step's ~24
   // products only - is off while it is on)
   bk.sym_on_ = A.no_sym == 0 && A.no_lowrank == 0 && A.no_refine == 0;
-  bk.dual_off = A.no_dual != 0 || (RMETRIC == MM_RMETRIC_RANK1 && bk.sym_on_ && bk.dp <= 512);
+  bk.dual_off = A.no_dual != 0 || (RMETRIC == MM_RMETRIC_RANK1 && bk.sym_on_);
   bk.lowrank_on_ = A.no_lowrank == 0 && A.no_refine == 0;
   bk.lr_refresh_ = A.lowrank_refresh;
   bk.xpt_ = 0.0;
