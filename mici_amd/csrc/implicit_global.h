@@ -93,11 +93,9 @@ struct GlobalBackend {
   static constexpr bool kLowRankBuiltin = RMETRIC == MM_RMETRIC_RANK1;
   static constexpr bool kLowRank = kLowRankBuiltin || (RMETRIC == MM_RMETRIC_USER && mmuser::kLowRank);
   bool lowrank_on_;
-#ifdef MM_GLOBAL_LOWRANK_CT  // (compile experiment: the Woodbury path decided at compile time - the CG refinement's code dead)
-  __device__ static constexpr bool lowrank_on() { return true; }
-#else
+  // (decided at compile time - the CG refinement's code dead - the kernel's allocation hardly changes: 800 B of scratch a lane
+  // against 864)
   __device__ __forceinline__ bool lowrank_on() const { return lowrank_on_; }
-#endif
   __device__ __forceinline__ double lowrank_scale() const {
     if constexpr (kLowRankBuiltin) return (double)dim;
     else return mmuser::lowrank_inv_s(dim, base);
