@@ -381,6 +381,51 @@ struct WaveBackend {
     return ok;
   }
   __device__ __forceinline__ double matvec(double v) { return matvec_flat<TS>(T, v, lane, w); }
+  // ---- implicit_core.h lowrank_solve / lowrank_update (round 6): the built-in rank-one-update metric's
+  // solve-only constructions by the Woodbury identity from the held inverse, the inverse carried from step to step by the
+  // symmetric rank-two update; decided at run time (MICI_AMD_LOWRANK=0: the CG refinement) -------------------------------
+  static constexpr bool kLowRankBuiltin = RMETRIC == MM_RMETRIC_RANK1;
+  static constexpr bool kLowRank = kLowRankBuiltin;
+  bool lowrank_on_;
+  int lr_refresh_;
+  __device__ __forceinline__ bool lowrank_on() const { return lowrank_on_; }
+  __device__ __forceinline__ int lowrank_refresh() const { return lr_refresh_; }
+  __device__ __forceinline__ double lowrank_scale() const { return (double)dim; }
+  __device__ __forceinline__ double lowrank_vec(double x) const { return x; }
+  __device__ __forceinline__ double& lowrank_u0() { return slot(SL_Q); }
+  __device__ __forceinline__ void sum3(double a, double b, double c, double* sa, double* sb, double* sc) {
+    *sa = wave_sum(lane < dim ? a : 0.0);
+    *sb = wave_sum(lane < dim ? b : 0.0);
+    *sc = wave_sum(lane < dim ? c : 0.0);
+  }
+  // T += a u^T + b v^T with u = al a + be b, v = be a + ga b: lane (ti, tj) holds the entries (ti + 8 a', tj + 8 b') - its row
+  // operands are group ti of the permuted vectors a, b, its column operands group tj of u, v
+  __device__ __forceinline__ void inverse_update(double al, double be, double ga, double a, double b) {
+    const int ti = lane >> 3, tj = lane & 7;
+    if (lane < Geo<TS>::DP) {
+      const bool act = lane < dim;
+      const double am = act ? a : 0.0, bm = act ? b : 0.0;
+      const int pp = Geo<TS>::pos(lane);
+      w.col[pp] = am;
+      w.aux[pp] = bm;
+      w.vin[pp] = __builtin_fma(al, am, be * bm);
+      w.vout[pp] = __builtin_fma(be, am, ga * bm);
+    }
+    wave_sync();
+    double ar[TS], br[TS], uc[TS], vc[TS];
+#pragma unroll
+    for (int k = 0; k < TS; ++k) {
+      ar[k] = w.col[ti * TS + k];
+      br[k] = w.aux[ti * TS + k];
+      uc[k] = w.vin[tj * TS + k];
+      vc[k] = w.vout[tj * TS + k];
+    }
+#pragma unroll
+    for (int x = 0; x < TS; ++x)
+#pragma unroll
+      for (int y = 0; y < TS; ++y) T[x][y] = __builtin_fma(ar[x], uc[y], __builtin_fma(br[x], vc[y], T[x][y]));
+    wave_sync();
+  }
   // ---- refinement solves (implicit_core.h refine_solve): M(x) v in the form that suits the metric ----------------------
   double rs_[RS_COUNT], xpt_;
   __device__ __forceinline__ double& rslot(int i) { return rs_[i]; }
@@ -532,6 +577,8 @@ __device__ __forceinline__ void implicit_leapfrog_body(const ImplicitArgs& A, do
   bk.blk = wl + 320 + SL_COUNT_REFINE * 64;
   bk.base_lds = (RMETRIC == MM_RMETRIC_USER) ? A.rparams : base_lds;  // a user metric reads its params directly
   bk.refine_on = A.no_refine == 0;
+  bk.lowrank_on_ = A.no_lowrank == 0 && A.no_refine == 0;
+  bk.lr_refresh_ = A.lowrank_refresh;
   bk.tparams = A.tparams;
   bk.slot(SL_Q) = q;
   bk.slot(SL_P) = p;

@@ -239,6 +239,8 @@ int mm_launch_implicit_leapfrog(mm_ctx* ctx, const mm_model* m, mm_state* s, dou
   a.counters = d_counters;
   a.no_refine = mm_refine_disabled();
   a.no_dual = mm_dual_disabled();
+  a.no_lowrank = mm_lowrank_disabled();  // (round 6: the Woodbury path of the built-in rank-one-update metric)
+  a.lowrank_refresh = mm_lowrank_refresh();
   return dispatch(ctx, m, StepFn{ctx, a, s->n});
 }
 

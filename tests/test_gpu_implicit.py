@@ -514,7 +514,8 @@ def test_refined_solves_equal_factorised_solves():
             ca = a["counters"]
             for k in ("n_fp_evals", "n_fp_solves", "n_metric", "n_grad"):
                 assert ca[k] == cb[k], (key, mode, k, ca[k], cb[k])
-            lowrank = mode == "1" and key.startswith(("64_", "200_"))  # (the kernels with the Woodbury path: c3's and c4's)
+            # (the kernels with the Woodbury path: c3's and c4's, and the wave-per-chain VALU kernel of D <= 32)
+            lowrank = mode == "1" and key.startswith(("64_", "200_", "20_", "7_"))
             if key.startswith(("70_", "270_")):
                 # the VALU team kernels (round 4: refinement there too) have no factorised solve-only path: switched off, every
                 # construction is a full inversion (11 a step); refined, one a step is
