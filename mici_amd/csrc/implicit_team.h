@@ -121,8 +121,24 @@ struct TeamOf {
   __device__ __forceinline__ double sum(double x) const { return block_reduce<C>(x, 0, red); }
 };
 
-template <class C, int RMETRIC>
+template <class C, int RMETRIC, bool LOWRANK = false>
 struct BlockBackend {
+  // implicit_core.h lowrank_solve / lowrank_update (round 6): the built-in rank-one-update metric's
+  // solve-only constructions by the Woodbury identity from the held inverse, the inverse carried from step to step by the
+  // symmetric rank-two update (the launcher picks the instantiation: MICI_AMD_LOWRANK=0 is the CG refinement)
+  static constexpr bool kLowRankBuiltin = RMETRIC == MM_RMETRIC_RANK1;
+  static constexpr bool kLowRank = LOWRANK && kLowRankBuiltin;
+  __device__ static constexpr bool lowrank_on() { return true; }
+  int lr_refresh_;
+  __device__ __forceinline__ int lowrank_refresh() const { return lr_refresh_; }
+  __device__ __forceinline__ double lowrank_scale() const { return (double)dim; }
+  __device__ __forceinline__ double lowrank_vec(double x) const { return x; }
+  __device__ __forceinline__ double& lowrank_u0() { return slot(mmimp::SL_Q); }
+  __device__ __forceinline__ void sum3(double a, double b, double c, double* sa, double* sb, double* sc) {
+    *sa = sum1(a);
+    *sb = sum1(b);
+    *sc = sum1(c);
+  }
   static constexpr bool kSolveByInverse = true;  // implicit_core.h: solve = invert + mat-vec, one construction site
   static constexpr bool kUnifiedConstruct = false;
   static constexpr bool kCountersInLds = false;
@@ -576,6 +592,39 @@ struct BlockBackend {
     return tid < dim ? y : 0.0;
   }
 
+  // implicit_core.h lowrank_update: the tiles += a u^T + b v^T with u = al a + be b, v = be a + ga b.  Thread (ti >= tj) owns
+  // the entries (ti + PG a', tj + PG b'): its row operands are group ti of the permuted vectors a, b, its column operands
+  // group tj of u, v (three of the four vectors in the idle partial-sum buffer)
+  __device__ __forceinline__ void inverse_update(double al, double be, double ga, double a, double b) {
+    const int tid = opaque(this->tid), ti = opaque(this->ti), tj = opaque(this->tj);
+    constexpr int PVL = C::PV;
+    if (tid < DP) {
+      const bool act = tid < dim;
+      const double am = act ? a : 0.0, bm = act ? b : 0.0;
+      const int pp = ppos(tid);
+      w.vin[pp] = am;
+      w.part[pp] = bm;
+      w.part[PVL + pp] = __builtin_fma(al, am, be * bm);
+      w.part[2 * PVL + pp] = __builtin_fma(be, am, ga * bm);
+    }
+    __syncthreads();
+    if (tile) {
+      double ar[TS], br[TS], uc[TS], vc[TS];
+#pragma unroll
+      for (int k = 0; k < TS; ++k) {
+        ar[k] = w.vin[ti * GS + k];
+        br[k] = w.part[ti * GS + k];
+        uc[k] = w.part[PVL + tj * GS + k];
+        vc[k] = w.part[2 * PVL + tj * GS + k];
+      }
+#pragma unroll
+      for (int x = 0; x < TS; ++x)
+#pragma unroll
+        for (int y = 0; y < TS; ++y) at(x, y) = __builtin_fma(ar[x], uc[y], __builtin_fma(br[x], vc[y], at(x, y)));
+    }
+    __syncthreads();
+  }
+
   __device__ __forceinline__ double diag() {
     if (tile && ti == tj) {
 #pragma unroll
@@ -671,8 +720,8 @@ struct BlockBackend {
   }
 };
 
-template <class C, int RMETRIC>
-__device__ __forceinline__ void init_backend(BlockBackend<C, RMETRIC>& bk, const ImplicitArgs& A,
+template <class C, int RMETRIC, bool LOWRANK = false>
+__device__ __forceinline__ void init_backend(BlockBackend<C, RMETRIC, LOWRANK>& bk, const ImplicitArgs& A,
                                              double* lds) {
   constexpr int PG = C::PG, TS = C::TS, PV = C::PV, VL = C::VL, NTILE = C::NTILE;
   const int tid = threadIdx.x;
@@ -693,7 +742,7 @@ __device__ __forceinline__ void init_backend(BlockBackend<C, RMETRIC>& bk, const
   bk.w.nat = bk.w.part + C::PART;
   bk.w.aux = bk.w.nat + VL;
   bk.w.red = bk.w.aux + VL;
-  using BK = BlockBackend<C, RMETRIC>;
+  using BK = BlockBackend<C, RMETRIC, LOWRANK>;
   bk.w.stash = bk.w.red + 16;
   bk.w.trow = bk.w.stash + BK::kSlots * VL;
   double* nxt = bk.w.trow + (C::PARK ? TS * C::NT : 0);
@@ -705,17 +754,18 @@ __device__ __forceinline__ void init_backend(BlockBackend<C, RMETRIC>& bk, const
   bk.w.ux = bk.w.nat;
   bk.w.uax = bk.w.aux;
   bk.refine_on = A.no_refine == 0;
+  bk.lr_refresh_ = A.lowrank_refresh;
   bk.base = A.rparams;
   bk.tparams = A.tparams;
   bk.work = A.work ? A.work + (int64_t)blockIdx.x * (C::DP * C::DP) : nullptr;
 }
 
 // MIDPOINT: ImplicitMidpointIntegrator (integrators.py:547-681) on the same backend and slot storage
-template <class C, int RMETRIC, bool MIDPOINT>
+template <class C, int RMETRIC, bool MIDPOINT, bool LOWRANK = false>
 __device__ __forceinline__ void implicit_team_body(const ImplicitArgs& A, double* lds) {
   const int64_t chain = blockIdx.x;
-  BlockBackend<C, RMETRIC> bk;
-  init_backend<C, RMETRIC>(bk, A, lds);
+  BlockBackend<C, RMETRIC, LOWRANK> bk;
+  init_backend<C, RMETRIC, LOWRANK>(bk, A, lds);
   const int dim = A.dim, tid = threadIdx.x;
   const bool act = tid < dim;
   double q = act ? A.pos[chain * dim + tid] : 0.0;
@@ -771,10 +821,10 @@ __device__ __forceinline__ void riemann_aux_team_body(const ImplicitArgs& A, dou
 }
 
 #ifndef MM_RTC_BUILD  // the in-tree instantiations (a run-time translation unit defines extern "C" wrappers instead)
-template <class C, int RMETRIC, bool MIDPOINT>
+template <class C, int RMETRIC, bool MIDPOINT, bool LOWRANK = false>
 __global__ __launch_bounds__(C::NT, C::MINW) void implicit_team_kernel(ImplicitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  implicit_team_body<C, RMETRIC, MIDPOINT>(A, lds);
+  implicit_team_body<C, RMETRIC, MIDPOINT, LOWRANK>(A, lds);
 }
 template <class C, int RMETRIC, int OP>
 __global__ __launch_bounds__(C::NT, C::MINW) void riemann_aux_team_kernel(ImplicitArgs A) {

@@ -40,6 +40,10 @@ int launch_step(mm_ctx* ctx, const mm_model* m, const ImplicitArgs& a, bool midp
   if (midpoint)
     return r1 ? launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_RANK1, true>, a)
               : launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_DIAGQUAD, true>, a);
+  // round 6: the rank-one-update metric's Woodbury path (implicit_core.h lowrank_solve / lowrank_update); MICI_AMD_LOWRANK=0:
+  // the CG refinement
+  if (r1 && a.no_lowrank == 0 && a.no_refine == 0)
+    return launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_RANK1, false, true>, a);
   return r1 ? launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_RANK1, false>, a)
             : launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_DIAGQUAD, false>, a);
 }
@@ -101,6 +105,8 @@ static int launch_large(mm_ctx* ctx, const mm_model* m, mm_state* s, double h, i
   a.counters = d_counters;
   a.no_refine = mm_refine_disabled();
   a.no_dual = mm_dual_disabled();
+  a.no_lowrank = mm_lowrank_disabled();
+  a.lowrank_refresh = mm_lowrank_refresh();
   const int v = team_variant(m->dim);
   return v == 0   ? launch_step<CfgMid>(ctx, m, a, midpoint)
          : v == 1 ? launch_step<CfgSmall>(ctx, m, a, midpoint)
