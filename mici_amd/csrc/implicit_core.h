@@ -560,6 +560,27 @@ __device__ __forceinline__ bool lowrank_update(BK& bk, double x, double sbb, Cha
   return ok;
 }
 
+// The same update between two ARBITRARY points (the implicit midpoint rule below: every evaluation of its fixed point needs the
+// explicit inverse at a new point): the inverse held at x_prev, b = F x_prev in rslot(LR_B); built-in metric (u(x) = x).
+template <class BK>
+__device__ __forceinline__ bool lowrank_update_at(BK& bk, double x, double x_prev, ChainResult& r) {
+  const double d = x - x_prev;
+  const double a = bk.matvec(d);
+  const double b = bk.rslot(LR_B);
+  double e3, e4, sbb;
+  bk.sum3(d * a, d * b, x_prev * b, &e3, &e4, &sbb);
+  const double D = bk.lowrank_scale();
+  const double k11 = D + (e3 + e4), k12 = sbb + e4, k21 = e3, k22 = D + e4;
+  const double det = __builtin_fma(k11, k22, -(k12 * k21));
+  const bool ok = det > 1e-8 * D * D && det < 1e8 * D * D;
+  if (ok) {
+    const double idet = mmdev::rcp_nr(det);
+    bk.inverse_update(-(k22 - k12) * idet, -k22 * idet, k21 * idet, a, b);
+    bump(bk, r, CNT_INVUPD, 1);
+  }
+  return ok;
+}
+
 // The momentum fixed points x = base - tt dh2_dpos(q, x) of this metric: dh2_dpos(q, x) = -(F x)(q^T F x) / D, and
 // q^T F x = b^T x with b = F q - known before the product F x is, so the inner product leaves the iteration's dependent chain
 // and shares ONE team reduction with the convergence norm of the iterate it belongs to (bk.norm_dot where a backend has it).
@@ -1086,7 +1107,8 @@ enum {
   MP_PRQ, MP_PRP,      // state after the implicit half step (reference point of the reversibility check)
   MP_COUNT
 };
-static_assert(MP_COUNT <= SL_COUNT, "midpoint slots must fit the backends' slot storage");
+enum { MP_HELD = MP_COUNT };  // kLowRank backends: the point of the held inverse (round 6)
+static_assert(MP_COUNT + 1 <= SL_COUNT, "midpoint slots must fit the backends' slot storage");
 
 template <class BK>
 __device__ __forceinline__ int fp_feed2(BK& bk, FpCtl& c, double fq, double fp, const mm_fp_opts& o,
@@ -1140,6 +1162,16 @@ template <class BK>
 __device__ __forceinline__ ChainResult implicit_midpoint_chain(BK& bk, double t, int n_steps,
                                                                const mm_fp_opts& o) {
   ChainResult r{MM_ST_OK, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // Round 6: every evaluation of the midpoint rule's fixed point needs the EXPLICIT inverse at a new
+  // point - a full sweep each in rounds 1-5.  For the built-in rank-one-update metric the held inverse travels from one
+  // evaluation point to the next by the symmetric rank-two update (lowrank_update_at: one product + a pass over the held
+  // entries), with b = F x taken from 0.5 vjp(M^-1) = F x / D, which the evaluation computes anyway; a sweep at a launch's
+  // first evaluation, after lowrank_refresh() updates in a row and when an update's determinant leaves its window.
+  constexpr bool kLowRankAny = refine_trait<BK>::value && lowrank_trait<BK>::value;
+  constexpr bool kLowRank = kLowRankAny && lowrank_builtin<BK, kLowRankAny>::value;
+  bool lr_on = false, have_f = false;
+  int lr_since = 0;
+  if constexpr (kLowRank) lr_on = bk.lowrank_on();
   const double half = 0.5 * t;
   int mode = MPM_FWD;
   FpCtl c{0, 0};
@@ -1155,15 +1187,35 @@ __device__ __forceinline__ ChainResult implicit_midpoint_chain(BK& bk, double t,
     const double xq = bk.slot(MP_PTQ), xp = bk.slot(MP_PTP);
     const double gq = bk.grad(xq);
     ++r.n_grad;
-    const bool okm = bk.build_and_invert(xq);
+    bool okm = false, updated = false;
+    if constexpr (kLowRank) {
+      if (lr_on && have_f && lr_since < bk.lowrank_refresh()) {  // team-uniform
+        updated = lowrank_update_at(bk, xq, bk.slot(MP_HELD), r);
+        if (updated) ++lr_since;
+      }
+    }
+    if (updated) {
+      okm = true;
+    } else {
+      okm = bk.build_and_invert(xq);
+      ++r.n_full;
+      lr_since = 0;
+    }
     ++r.n_metric;
-    ++r.n_full;
     if (!okm) {  // LinAlgError: inside a solver it becomes a ConvergenceError (solvers.py:89-93)
       r.status = (mode == MPM_ADJ) ? MM_ST_LINALG : MM_ST_SOLVER_LINALG;
       break;
     }
     const double dq = bk.matvec(xp);
-    const double dp = (gq + bk.half_vjp_inv(xq)) + bk.dh2_dpos(xp, xq);
+    const double hvq = bk.half_vjp_inv(xq);
+    if constexpr (kLowRank) {
+      if (lr_on) {  // the held inverse's point and b = F x for the next evaluation's update
+        bk.rslot(LR_B) = hvq * bk.lowrank_scale();
+        bk.slot(MP_HELD) = xq;
+        have_f = true;
+      }
+    }
+    const double dp = (gq + hvq) + bk.dh2_dpos(xp, xq);
     if (mode == MPM_ADJ) {
       // explicit Euler half step from the implicit half step's result, then start the reverse solve
       const double q2 = xq + half * dq, p2 = xp - half * dp;

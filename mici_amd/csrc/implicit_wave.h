@@ -619,6 +619,8 @@ __device__ __forceinline__ void implicit_midpoint_body(const ImplicitArgs& A, do
   bk.blk = wl + 320 + SL_COUNT_REFINE * 64;
   bk.base_lds = (RMETRIC == MM_RMETRIC_USER) ? A.rparams : base_lds;  // a user metric reads its params directly
   bk.refine_on = A.no_refine == 0;
+  bk.lowrank_on_ = A.no_lowrank == 0 && A.no_refine == 0;
+  bk.lr_refresh_ = A.lowrank_refresh;
   bk.tparams = A.tparams;
   bk.slot(MP_Q) = act ? A.pos[chain * dim + lane] : 0.0;
   bk.slot(MP_P) = act ? A.mom[chain * dim + lane] : 0.0;

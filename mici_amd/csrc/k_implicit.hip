@@ -257,6 +257,9 @@ int mm_launch_implicit_midpoint_riemann(mm_ctx* ctx, const mm_model* m, mm_state
   a.n_steps = n_steps;
   a.opts = opts;
   a.counters = d_counters;
+  a.no_refine = mm_refine_disabled();
+  a.no_lowrank = mm_lowrank_disabled();  // (round 6: the held inverse carried between the midpoint rule's evaluations)
+  a.lowrank_refresh = mm_lowrank_refresh();
   return dispatch(ctx, m, MidpointFn{ctx, a, s->n});
 }
 

@@ -37,9 +37,13 @@ int launch(mm_ctx* ctx, K kernel, const ImplicitArgs& a) {
 template <class C>
 int launch_step(mm_ctx* ctx, const mm_model* m, const ImplicitArgs& a, bool midpoint) {
   const bool r1 = m->rmetric == MM_RMETRIC_RANK1;
-  if (midpoint)
+  if (midpoint) {
+    // (round 6: the rank-one-update metric's held inverse carried between the midpoint rule's evaluations by rank-two updates)
+    if (r1 && a.no_lowrank == 0 && a.no_refine == 0)
+      return launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_RANK1, true, true>, a);
     return r1 ? launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_RANK1, true>, a)
               : launch<C>(ctx, implicit_team_kernel<C, MM_RMETRIC_DIAGQUAD, true>, a);
+  }
   // round 6: the rank-one-update metric's Woodbury path (implicit_core.h lowrank_solve / lowrank_update); MICI_AMD_LOWRANK=0:
   // the CG refinement
   if (r1 && a.no_lowrank == 0 && a.no_refine == 0)
