@@ -59,7 +59,7 @@ def default_jobs():
     # tests/test_gpu_user_target.py - the families with a Woodbury path, and the auxiliary family of each size
     lowrank_dims = (64, 130, 256, 320)
     sources["RANK1_AS_USER_LOWRANK"] = (ue.RANK1_AS_USER_LOWRANK, lowrank_dims)
-    for d in lowrank_dims:
+    for d in (48,) + lowrank_dims:  # (48: the riemann_sinrank1_* fixtures of tests/golden)
         if d <= 256:
             sources[f"SIN_RANK1_LOWRANK_{d}"] = (ue.sin_rank1_lowrank(d), (d,))
     tests = os.path.join(HERE, "..", "tests")

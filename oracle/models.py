@@ -325,12 +325,15 @@ class SoftPlusRank1Metric:
         return lambda v: np.diagonal(v) / (1.0 + np.exp(-q)) + (self.c @ v @ self.c) * 2.0 * q / self.dim
 
 
+RMETRIC_USER_SIN = 102  # (fixture id of SinRank1Metric below: the device library knows it as user source only)
+
+
 class SinRank1Metric:
     """A constant matrix plus a rank-one term in a NONLINEAR vector function of the position - the structure a user metric
     declares with MM_USER_LOWRANK (csrc/user_metric.h): M(q) = B + s u(q) u(q)^T, u_i(q) = q_i + sin(q_i) / 2, s = 2 / D;
     vjp(V)_k = s ((V + V^T) u)_k (1 + cos(q_k) / 2).  params: B row-major."""
 
-    mid = RMETRIC_USER
+    mid = RMETRIC_USER_SIN
 
     def __init__(self, base):
         self.base = np.ascontiguousarray(base, dtype=np.float64)
@@ -597,8 +600,10 @@ def rmetric_from_id(mid, params, dim):
         return DiagQuadMetric(dim)
     if mid == RMETRIC_SOFTABS:
         return None
-    if mid == RMETRIC_USER:  # the one metric of the fixtures that the device library only knows as user source
+    if mid == RMETRIC_USER:  # a metric of the fixtures that the device library only knows as user source
         return SoftPlusRank1Metric(params)
+    if mid == RMETRIC_USER_SIN:  # ... and one that declares its constant + rank-one structure there (MM_USER_LOWRANK)
+        return SinRank1Metric(np.asarray(params).reshape(dim, dim))
     raise ValueError(f"unknown Riemannian metric id {mid}")
 
 

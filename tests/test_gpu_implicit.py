@@ -43,6 +43,9 @@ def build(g, fast_source=False):
         from user_sources import SOFTPLUS_RANK1, softplus_fast
         system = systems.DenseRiemannianMetricSystem(
             target, models.UserMetric(d, softplus_fast(d) if fast_source else SOFTPLUS_RANK1, g["rmetric_params"]))
+    elif mid == omdl.RMETRIC_USER_SIN:  # round 6: a user source that declares its constant + rank-one structure (MM_USER_LOWRANK)
+        from mici_amd.user_examples import sin_rank1_lowrank
+        system = systems.DenseRiemannianMetricSystem(target, models.UserMetric(d, sin_rank1_lowrank(d), g["rmetric_params"]))
     else:
         system = systems.DenseRiemannianMetricSystem(
             target, models.rmetric_from_id(mid, g["rmetric_params"], d))

@@ -1169,6 +1169,18 @@ def main():
         tgt = mdl.Banana(d) if "banana" in name else mdl.Poly(d, 1.0, 1.0 / 3.0)
         add_riemann(name, tgt, mdl.SoftPlusRank1Metric(0.5 * r.standard_normal(d)), None, n, hh, cps, r=r, **kw)
 
+    # ---- round 6: a user metric that DECLARES its constant + rank-one structure (csrc/user_metric.h MM_USER_LOWRANK; oracle
+    #      SinRank1Metric: u nonlinear in q) - the device takes its Woodbury path, the reference its
+    #      Cholesky factorisations: c3's kernel (D = 64), c4's (130, 256), a Steffensen / L2 case, a failing step size
+    for name, d, n, hh, cps, kw in (("riemann_sinrank1_banana_d64", 64, 4, 0.02, [1, 5, 20], {}),
+                                    ("riemann_sinrank1_poly_d130", 130, 3, 0.02, [1, 4, 10], {}),
+                                    ("riemann_sinrank1_banana_d256", 256, 3, 0.01, [1, 3, 8], {}),
+                                    ("riemann_sinrank1_poly_d48_steffensen_l2", 48, 3, 0.04, [1, 5], dict(fp_solver=1, norm=1)),
+                                    ("riemann_sinrank1_poly_d64_fail_bigstep", 64, 5, 0.9, [1, 3], {})):
+        r = case_rng(name)
+        tgt = mdl.Banana(d) if "banana" in name else mdl.Poly(d, 1.0, 1.0 / 3.0)
+        add_riemann(name, tgt, mdl.SinRank1Metric(mdl.make_spd(d, r)), None, n, hh, cps, r=r, **kw)
+
     # ---- constraints that are not built into the device library: they reach it as USER SOURCE compiled by hipRTC
     #      (tests/test_gpu_user_target.py); here the reference and the oracle run their NumPy twin ---------------------
     def add_user_constrained(name, d, n, mk, h, cps, **kw):
